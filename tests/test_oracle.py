@@ -1,0 +1,201 @@
+"""Pins the CPU oracle against everything available without TF/librosa:
+the Expand docstring example (the only reference-authored KAT on the path), the Slaney
+mel-frequency table, torch.stft / scipy conventions, analytic mel inputs, TF-Adam hand values."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ft_oracle as fo
+from oracle import mel_oracle as mo
+
+
+# ---------------------------------------------------------------- Expand (model/layers.py:527-565)
+def test_expand_docstring_example():
+    # model/layers.py:532-542
+    x = np.array([[[0.54710746, 0.8943467], [0.7140938, 0.97968304], [0.5347662, 0.15213418]]],
+                 dtype=np.float32)
+    dims = np.array([[[1], [3], [2]]], dtype=np.int32)
+    want = np.array([[[0.54710746, 0.8943467], [0.7140938, 0.97968304], [0.7140938, 0.97968304],
+                      [0.7140938, 0.97968304], [0.5347662, 0.15213418], [0.5347662, 0.15213418]]],
+                    dtype=np.float32)
+    got = fo.expand_literal_np(x, dims)
+    assert got.shape == (1, 6, 2)
+    np.testing.assert_array_equal(got, want)
+    got_t = fo.expand_torch(torch.from_numpy(x), torch.from_numpy(dims)).numpy()
+    np.testing.assert_array_equal(got_t, want)
+
+
+@pytest.mark.parametrize('seed', range(5))
+def test_expand_literal_equals_index_form(seed):
+    rng = np.random.default_rng(seed)
+    B, T, C = 3, 7, 4
+    x = rng.standard_normal((B, T, C)).astype(np.float32)
+    dur = rng.choice([0., 0.5, 1., 1.5, 2.5, 3.5, 2.49, 4.0], size=(B, T, 1)).astype(np.float32)
+    if seed == 0:
+        dur[1] = 0           # an all-zero sample
+    lit = fo.expand_literal_np(x, dur)
+    idx, lens, out_len = fo.expand_indices_np(dur)
+    assert lit.shape[1] == out_len
+    ref = np.zeros_like(lit)
+    for b in range(B):
+        for j in range(lens[b]):
+            ref[b, j] = x[b, idx[b, j]]
+    np.testing.assert_array_equal(lit, ref)
+    np.testing.assert_array_equal(fo.expand_torch(torch.from_numpy(x), torch.from_numpy(dur)).numpy(), lit)
+
+
+def test_round_half_even_ties():
+    np.testing.assert_array_equal(fo.round_half_even(np.array([0.5, 1.5, 2.5, 3.5, -0.5, 2.4999])),
+                                  np.array([0., 2., 2., 4., -0., 2.]))
+
+
+# ---------------------------------------------------------------- positional encoding / masks
+def test_positional_encoding_values():
+    pe = fo.positional_encoding(50, 16)
+    assert pe.dtype == np.float32 and pe.shape == (50, 16)
+    np.testing.assert_allclose(pe[0, 0::2], 0.0)
+    np.testing.assert_allclose(pe[0, 1::2], 1.0)
+    # column i uses exponent 2*(i//2)/d  (transformer_utils.py:5-7)
+    for p, i in [(3, 4), (7, 5), (49, 15)]:
+        ang = p / (10000 ** (2 * (i // 2) / 16))
+        want = math.sin(ang) if i % 2 == 0 else math.cos(ang)
+        assert abs(pe[p, i] - want) < 1e-6
+
+
+def test_padding_masks():
+    tok = torch.tensor([[3, 0, 5, 0]])
+    m = fo.create_encoder_padding_mask(tok, torch.float32)
+    assert m.shape == (1, 1, 1, 4)
+    np.testing.assert_array_equal(m[0, 0, 0].numpy(), [0, 1, 0, 1])
+    mel = torch.tensor([[[1., -1.], [0., 0.], [0., 1e-9]]])
+    np.testing.assert_array_equal(fo.create_mel_padding_mask(mel)[0, 0, 0].numpy(), [0, 1, 0])
+
+
+# ---------------------------------------------------------------- building blocks vs torch.nn
+def test_layer_norm_matches_torch():
+    x = torch.randn(5, 7, dtype=torch.float64)
+    g, b = torch.randn(7, dtype=torch.float64), torch.randn(7, dtype=torch.float64)
+    np.testing.assert_allclose(fo.layer_norm(x, g, b).numpy(),
+                               torch.nn.functional.layer_norm(x, (7,), g, b, eps=1e-6).numpy(),
+                               rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('k', [3, 5, 4])
+def test_conv1d_same_matches_torch(k):
+    x = torch.randn(2, 9, 3, dtype=torch.float64)
+    w = torch.randn(k, 3, 5, dtype=torch.float64)
+    b = torch.randn(5, dtype=torch.float64)
+    got = fo.conv1d_same(x, w, b)
+    left, right = (k - 1) // 2, k // 2
+    xp = torch.nn.functional.pad(x.transpose(1, 2), (left, right))
+    want = torch.nn.functional.conv1d(xp, w.permute(2, 1, 0), b).transpose(1, 2)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_unmasked_mae_counts_padding():
+    # utils/losses.py:41-49: mask stays None => plain mean including padded zeros
+    t = torch.tensor([[[1.], [0.]]])
+    p = torch.tensor([[[0.5], [0.25]]])
+    assert float(fo.masked_mean_absolute_error(t, p)) == pytest.approx((0.5 + 0.25) / 2)
+    ti = torch.tensor([[[2], [0]]], dtype=torch.int32)
+    assert float(fo.masked_mean_absolute_error(ti, p)) == pytest.approx((1.5 + 0.25) / 2)
+
+
+def test_tf_adam_hand_values():
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=0)
+    m = fo.ForwardTransformerOracle(cfg, W)
+    g = {k: torch.full_like(v, 0.5) for k, v in m.W.items()}
+    w0 = m.W['out.b'].detach().clone()
+    m.learning_rate = 1e-3
+    m.apply_gradients(g)
+    # step 1: m=0.05, v=0.005, lr_t = lr*sqrt(1-.98)/(1-.9) ; theta -= lr_t*m/(sqrt(v)+eps)
+    lr_t = 1e-3 * math.sqrt(1 - 0.98) / (1 - 0.9)
+    want = w0 - lr_t * 0.05 / (math.sqrt(0.005) + 1e-9)
+    np.testing.assert_allclose(m.W['out.b'].detach().numpy(), want.numpy(), rtol=1e-12)
+    assert m.step == 1
+
+
+# ---------------------------------------------------------------- whole model, tiny config
+def test_tiny_forward_shapes_and_quirks():
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=1, perturb=0.05)
+    m = fo.ForwardTransformerOracle(cfg, W)
+    tok, mel, dur, pitch = fo.synthetic_batch(3, 12, 40, seed=2, ragged=True)
+    out = m.val_step(tok, mel, dur, pitch)
+    assert out['mel'].shape == (3, 40, 80)
+    assert out['duration'].shape == (3, 12, 1) and out['pitch'].shape == (3, 12, 1)
+    assert out['expanded_mask'].shape == (3, 1, 1, 40)
+    assert list(out['encoder_attention']) == ['Encoder_DenseBlock1_SelfAttention',
+                                              'Encoder_DenseBlock2_SelfAttention']
+    assert out['decoder_attention']['Decoder_DenseBlock2_SelfAttention'].shape == (3, 2, 40, 40)
+    # padded decoder rows are exactly the output bias (layers.py:230 zeroes them, models.py:543)
+    lens = dur.sum(1)
+    b = int(np.argmin(lens))
+    assert lens[b] < 40
+    np.testing.assert_allclose(out['mel'][b, lens[b]:].numpy(),
+                               np.broadcast_to(W['out.b'], (40 - lens[b], 80)), atol=1e-12)
+    # predictors are masked at padded phonemes (layers.py:485)
+    pad = tok == 0
+    assert np.all(out['duration'].numpy()[pad] == 0) and np.all(out['pitch'].numpy()[pad] == 0)
+    # loss = 1*mel + 1*dur + 3*pitch  (models.py:485)
+    l = out['losses']
+    assert float(out['loss']) == pytest.approx(float(l['mel'] + l['duration'] + 3 * l['pitch']))
+
+
+def test_tiny_train_step_reduces_loss_fp32_close_to_fp64():
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=3, perturb=0.02)
+    batch = fo.synthetic_batch(2, 10, 30, seed=4)
+    m64 = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    m32 = fo.ForwardTransformerOracle(cfg, W, torch.float32)
+    m64.learning_rate = m32.learning_rate = 1e-3
+    l64 = [float(m64.train_step(*batch)['loss']) for _ in range(5)]
+    l32 = [float(m32.train_step(*batch)['loss']) for _ in range(5)]
+    assert l64[-1] < l64[0]
+    np.testing.assert_allclose(l32, l64, rtol=2e-5)
+
+
+# ---------------------------------------------------------------- mel path (data/audio.py:72-92)
+def test_slaney_mel_frequency_table():
+    # librosa documentation example mel_frequencies(n_mels=40) (fmin 0, fmax 11025), SURVEY 8c.3
+    f = mo.mel_frequencies(40, 0.0, 11025.0)
+    head = [0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855,
+            853.173, 938.49, 1024.856, 1119.114, 1222.042, 1334.436]
+    np.testing.assert_allclose(f[:16], head, atol=5e-4)
+    np.testing.assert_allclose(f[-3:], [9246.028, 10096.408, 11025.], atol=5e-4)
+
+
+def test_lj_filterbank_structure():
+    B = mo.mel_filterbank(22050, 1024, 80, 0, 8000)
+    assert B.shape == (80, 513) and B.dtype == np.float32
+    assert np.count_nonzero(B) == 727
+    assert np.nonzero(B.sum(0))[0].max() == 371
+    assert abs(B.max() - 0.02649) < 1e-4
+    assert (B.sum(1) > 0).all()
+
+
+def test_stft_matches_torch_stft():
+    y = mo.synthetic_clip(5000, seed=0)
+    D = mo.stft(y, 1024, 256, 1024)
+    assert D.shape == (513, 1 + 5000 // 256) and D.dtype == np.complex64
+    T = torch.stft(torch.from_numpy(y).double(), 1024, 256, 1024,
+                   window=torch.hann_window(1024, periodic=True, dtype=torch.float64),
+                   center=True, pad_mode='reflect', return_complex=True).numpy()
+    np.testing.assert_allclose(D, T.astype(np.complex64), rtol=0, atol=2e-5)
+
+
+def test_mel_silence_and_sine():
+    m = mo.mel_spectrogram(np.zeros(4000, np.float32))
+    assert m.shape == (1 + 4000 // 256, 80) and m.dtype == np.float32
+    np.testing.assert_allclose(m, math.log(1e-5), rtol=1e-6)        # -11.512925
+    t = np.arange(22050) / 22050.0
+    y = (0.5 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)
+    m = mo.mel_spectrogram(y)
+    centre = mo.mel_frequencies(82, 0, 8000)[1:-1]
+    assert abs(centre[int(m[40].argmax())] - 1000.0) < 60.0
+    # fp32 pipeline agrees with an all-fp64 evaluation to ~1e-6 relative on linear mel
+    me = mo.mel_spectrogram(y, exact=True)
+    np.testing.assert_allclose(np.exp(m), np.exp(me), rtol=2e-5, atol=1e-7)
