@@ -1,0 +1,242 @@
+/* libttsmi - C ABI of the MI355X-native (gfx950 / CDNA4) ForwardTransformer TTS hot path.
+ *
+ * The reference (as-ideas/TransformerTTS, Python on TensorFlow 2 + librosa) has NO plugin / FFI
+ * interface: its boundary is the Python API
+ * model/models.py:ForwardTransformer.{call,train_step,val_step,predict} and
+ * data/audio.py:Audio.mel_spectrogram.  This header is the C ABI inserted UNDER that Python API:
+ * each entry point replaces the TensorFlow / NumPy op(s) the reference dispatches to at the cited
+ * file:line (paths relative to the reference root).  The host-side mirror of the Python API lives
+ * in transformertts_amd/ and binds these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 (TTSMI_OK) or a negative TTSMI_ERR_* code; the message is
+ *     available from ttsmi_last_error() (thread-local).  No exception crosses the ABI.
+ *   - no allocation, no synchronisation, no mutable global state: every buffer is a caller-owned
+ *     DEVICE pointer, scratch is passed as (ws, ws_bytes) with a *_ws_bytes() query, every launch
+ *     is asynchronous on the explicit stream (a hipStream_t passed as void*).  All entry points
+ *     are therefore hipGraph-capturable.
+ *   - layout: row-major, channels-last [B, T, C]; matrices are [rows, cols] with a leading
+ *     dimension in ELEMENTS.  Keras kernel layouts are kept: Dense [in, out], Conv1D [k, in, out].
+ *   - dtype: TTSMI_F32 = everything fp32 (exact-fp32 MFMA, the 1e-4 parity path);
+ *            TTSMI_BF16 = GEMM/attention operands rounded to bf16, fp32 accumulate, fp32 storage.
+ */
+#ifndef TTSMI_H
+#define TTSMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTSMI_VERSION 100
+
+enum {
+    TTSMI_OK = 0,
+    TTSMI_ERR_INVALID_ARG = -1,
+    TTSMI_ERR_LAUNCH = -2,
+    TTSMI_ERR_UNSUPPORTED = -3,
+    TTSMI_ERR_WORKSPACE = -4
+};
+enum { TTSMI_F32 = 0, TTSMI_BF16 = 1 };
+
+typedef void* ttsmi_stream_t; /* hipStream_t */
+
+int ttsmi_version(void);
+const char* ttsmi_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers.  Replaces tf.keras.layers.Dense at model/layers.py:93-94,116-120,479 and
+ * model/models.py:410,422 (forward) and the tape.gradient of them (model/models.py:480).
+ * y[M,N] = act([x | x2][M,K] . w[K,N] + bias).  x2 != NULL splits the K axis: columns [0,K1) come
+ * from x, [K1,K) from x2 - this is Dense(concat([q_in, ctx])) of model/layers.py:148-149 without
+ * the concat buffer.  bias may be NULL.  relu != 0 applies max(.,0).
+ * ------------------------------------------------------------------------------------------- */
+int ttsmi_linear_fwd(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int K1,
+                     const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
+                     int M, int N, int K, int relu, int dtype, ttsmi_stream_t stream);
+/* dx[M,K] = (dy[M,N] . w[K,N]^T) * (relu_src > 0)      (relu_src NULL = no mask) */
+int ttsmi_linear_dgrad(const void* dy, int64_t lddy, const void* w, int64_t ldw,
+                       const void* relu_src, int64_t ld_relu, void* dx, int64_t lddx,
+                       int M, int N, int K, int dtype, ttsmi_stream_t stream);
+/* dw[K,N] = x[M,K]^T . dy[M,N]  (deterministic split over M through ws),  db[N] = colsum(dy)
+ * (db may be NULL). */
+size_t ttsmi_linear_wgrad_ws_bytes(int M, int N, int K);
+int ttsmi_linear_wgrad(const void* x, int64_t ldx, const void* dy, int64_t lddy, float* dw,
+                       int64_t lddw, float* db, int M, int N, int K, void* ws, size_t ws_bytes,
+                       int dtype, ttsmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conv1D(kernel k, stride 1, padding 'same', channels-last) as an implicit GEMM over the k taps.
+ * Replaces tf.keras.layers.Conv1D at model/layers.py:19-26,56-63,498-505.
+ * x [B,T,Cin], w [k,Cin,Cout], y [B,T,Cout]; zero padding (k-1)/2 left, k/2 right.
+ * ------------------------------------------------------------------------------------------- */
+int ttsmi_conv1d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int T,
+                     int Cin, int Cout, int k, int relu, int dtype, ttsmi_stream_t stream);
+/* dx = conv_transpose(dy, w) * (relu_src > 0) */
+int ttsmi_conv1d_dgrad(const void* dy, const void* w, const void* relu_src, void* dx, int B, int T,
+                       int Cin, int Cout, int k, int dtype, ttsmi_stream_t stream);
+size_t ttsmi_conv1d_wgrad_ws_bytes(int B, int T, int Cin, int Cout, int k);
+int ttsmi_conv1d_wgrad(const void* x, const void* dy, float* dw, float* db, int B, int T, int Cin,
+                       int Cout, int k, void* ws, size_t ws_bytes, int dtype,
+                       ttsmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused scaled-dot-product self-attention (flash style: the [B,H,T,T] logits never reach HBM).
+ * Replaces model/layers.py:123-129 (split heads), :176-195 (ScaledDotProductAttention) and
+ * :144-147 (merge heads).
+ * qkv  [B*T, 3*H*dh]: the fused Wq|Wk|Wv projection output, columns [q | k | v], head h at
+ *      columns h*dh..(h+1)*dh of each third (so no head transpose is ever materialised).
+ * key_pad [B,T] uint8, 1 = padded key: logits += -1e9 there, exactly like the reference's
+ *      additive mask (model/layers.py:186-187), including fp32 absorption of the logit.
+ * klen [B] int32: 1 + index of the last unpadded key (T if every key is padded) - lets the kernel
+ *      skip key tiles that are entirely padded (their softmax weight is exactly 0 in fp32).
+ * ctx  [B*T, H*dh] merged-head context;  lse [B,H,T] log-sum-exp of each row (for backward).
+ * p_drop/seed/site: inverted dropout on the attention weights (model/layers.py:192).
+ * ------------------------------------------------------------------------------------------- */
+int ttsmi_attention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
+                        float* lse, int B, int H, int T, int dh, float p_drop, uint64_t seed,
+                        const int64_t* step_dev, uint32_t site, int dtype, ttsmi_stream_t stream);
+/* dqkv [B*T, 3*H*dh] from dctx; delta_ws: B*H*T floats of scratch. */
+size_t ttsmi_attention_bwd_ws_bytes(int B, int H, int T, int dh);
+int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen,
+                        const void* ctx, const void* dctx, const float* lse, void* dqkv, int B,
+                        int H, int T, int dh, float p_drop, uint64_t seed, const int64_t* step_dev,
+                        uint32_t site, void* ws, size_t ws_bytes, int dtype,
+                        ttsmi_stream_t stream);
+/* Materialise the (post-dropout) attention weights [B,H,T,T] the reference returns from every call
+ * (model/layers.py:195,302-310) - only when the caller asks for them. */
+int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float* lse,
+                            float* weights, int B, int H, int T, int dh, float p_drop,
+                            uint64_t seed, const int64_t* step_dev, uint32_t site, int dtype,
+                            ttsmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused [dropout ->] residual add -> LayerNormalization(eps) [-> + s*PE] [-> dropout] [-> row mask]
+ * Replaces tf.keras.layers.LayerNormalization at model/layers.py:27,96,207,295,508 together with
+ * the element-wise ops around it: residual adds (:40,:102,:211), `x += s*PE` + dropout (:300-301),
+ * `* dense_mask` (:229-230,:262-264), predictor dropout (:515,:523).
+ *   z = keep_in(x) + res;  n = (z - mean)/sqrt(var + eps);  y = n*gamma + beta
+ *   y += pe_scale[0] * pe[(row % T), :]     if pe != NULL
+ *   y  = keep_out(y)                         if p_out > 0
+ *   y  = 0 on rows with row_pad[row] != 0    if row_pad != NULL
+ * mean/rstd [M] are saved for backward.  res, pe, row_pad may be NULL.
+ * Dropout masks are a pure function of (seed + step_dev[0], site, element index): backward
+ * regenerates them, nothing is stored.  step_dev (may be NULL) is a DEVICE int64 step counter so
+ * that a captured hipGraph draws fresh masks on every replay.
+ * ------------------------------------------------------------------------------------------- */
+int ttsmi_add_layernorm_fwd(const float* x, const float* res, const float* gamma,
+                            const float* beta, const float* pe, const float* pe_scale, int T,
+                            const uint8_t* row_pad, float p_in, uint32_t site_in, float p_out,
+                            uint32_t site_out, uint64_t seed, const int64_t* step_dev, float eps,
+                            float* y, float* mean, float* rstd, int M, int C,
+                            ttsmi_stream_t stream);
+/* dx (grad wrt x), dres (grad wrt res; may alias dx when p_in == 0; NULL if no res),
+ * dgamma/dbeta [C], dpe_scale [1] (NULL if no pe).  relu_in != 0 additionally multiplies dx by
+ * (x > 0) - the backward of the ReLU that produced x (predictor conv->relu->LN, layers.py:513).
+ * y is the forward output (needed only when p_out > 0 is NOT needed - masks are regenerated). */
+size_t ttsmi_add_layernorm_bwd_ws_bytes(int M, int C);
+int ttsmi_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
+                            const float* mean, const float* rstd, const float* pe,
+                            const float* pe_scale, int T, const uint8_t* row_pad, float p_in,
+                            uint32_t site_in, float p_out, uint32_t site_out, uint64_t seed,
+                            const int64_t* step_dev, int relu_in, float* dx, float* dres, float* dgamma, float* dbeta,
+                            float* dpe_scale, int M, int C, void* ws, size_t ws_bytes,
+                            ttsmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small element-wise / gather ops of ForwardTransformer.call (model/models.py:518-550)
+ * ------------------------------------------------------------------------------------------- */
+/* models.py:521 + transformer_utils.py:24-26: key_pad[b,t] = (tok == 0); klen as above. */
+int ttsmi_token_pad_mask(const int32_t* tokens, uint8_t* key_pad, int32_t* klen, int B, int T,
+                         ttsmi_stream_t stream);
+/* models.py:541 + transformer_utils.py:29-32 restated on lengths: key_pad[b,t] = (t >= len[b]). */
+int ttsmi_length_pad_mask(const int32_t* len, uint8_t* key_pad, int32_t* klen, int B, int T,
+                          ttsmi_stream_t stream);
+/* models.py:522 Embedding lookup and its scatter-add backward (deterministic). */
+int ttsmi_embedding_fwd(const int32_t* tokens, const float* table, float* y, int M, int V, int C,
+                        ttsmi_stream_t stream);
+int ttsmi_embedding_bwd(const int32_t* tokens, const float* dy, float* dtable, int M, int V, int C,
+                        ttsmi_stream_t stream);
+/* models.py:527-531: y = x + relu(p[m]*w[c] + b[c])  (Dense(d, relu) on a width-1 input). */
+int ttsmi_pitch_embed_fwd(const float* x, const float* p, const float* w, const float* b, float* y,
+                          int M, int C, ttsmi_stream_t stream);
+size_t ttsmi_pitch_embed_bwd_ws_bytes(int M, int C);
+int ttsmi_pitch_embed_bwd(const float* dy, const float* p, const float* w, const float* b,
+                          float* dp, float* dw, float* db, int M, int C, void* ws, size_t ws_bytes,
+                          ttsmi_stream_t stream);
+/* layers.py:479,484-485: y[m] = act(x[m,:] . w + b) * (1 - row_pad[m])  (Dense(1) head). */
+int ttsmi_rowdot_fwd(const float* x, const float* w, const float* b, const uint8_t* row_pad,
+                     float* y, int M, int C, int relu, ttsmi_stream_t stream);
+size_t ttsmi_rowdot_bwd_ws_bytes(int M, int C);
+int ttsmi_rowdot_bwd(const float* dy, const float* y, const float* x, const float* w,
+                     const uint8_t* row_pad, float* dx, float* dw, float* db, int M, int C,
+                     int relu, void* ws, size_t ws_bytes, ttsmi_stream_t stream);
+/* layers.py:482: y = x * (1 - row_pad[m]) (in place allowed). */
+int ttsmi_rowmask_mul(const float* x, const uint8_t* row_pad, float* y, int M, int C,
+                      ttsmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Length regulator.  Replaces Expand.call model/layers.py:549-565 (tile + ragged boolean mask).
+ * ttsmi_lenreg_index: dims = int32(round_half_even(dur)) (negative -> 0), cum[b, 0..Tp] =
+ *   exclusive prefix sum, len[b] = sum, idx[b, j] = phoneme covering output frame j or -1 for
+ *   j >= min(len[b], cap).  BIT-EXACT integer contract.  dur is f32 or i32 (dur_is_int).
+ * ------------------------------------------------------------------------------------------- */
+int ttsmi_lenreg_index(const void* dur, int dur_is_int, int32_t* idx, int32_t* cum, int32_t* len,
+                       int B, int Tp, int cap, ttsmi_stream_t stream);
+/* y[b,j,:] = idx[b,j] >= 0 ? x[b, idx[b,j], :] : 0 */
+int ttsmi_lenreg_fwd(const float* x, const int32_t* idx, float* y, int B, int Tp, int cap, int C,
+                     ttsmi_stream_t stream);
+/* dx[b,i,:] = sum_{j in [cum[b,i], min(cum[b,i+1], cap))} dy[b,j,:]  (contiguous segment sum) */
+int ttsmi_lenreg_bwd(const float* dy, const int32_t* cum, float* dx, int B, int Tp, int cap, int C,
+                     ttsmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss + optimiser.
+ * ttsmi_l1_loss: utils/losses.py:41-49 with mask=None (= plain mean |t - p| over n elements),
+ *   weighted as utils/losses.py:63-70.  loss_out[0] = mean|t-p| (unweighted); if grad != NULL,
+ *   grad[i] = coeff * sign(p - t) / n.  target is f32 or i32 (target_is_int).
+ *   pred is [rows, cols] with row stride ld_pred; target dense [rows, cols].
+ * ttsmi_adam_tf: tf.keras.optimizers.Adam(lr, 0.9, 0.98, 1e-9) of
+ *   utils/training_config_manager.py:102-106, applied at model/models.py:481:
+ *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t * m / (sqrt(v) + eps), with
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed ON DEVICE from lr_dev[0] and t = step_dev[0] (the
+ *   1-based iteration, i.e. optimizer.iterations after the increment) so that a captured hipGraph
+ *   stays valid while lr and t change.  bf16_copy (may be NULL) receives
+ *   the updated parameters rounded to bf16 for the TTSMI_BF16 GEMM path.
+ * ------------------------------------------------------------------------------------------- */
+size_t ttsmi_l1_loss_ws_bytes(int64_t n);
+int ttsmi_l1_loss(const float* pred, int64_t ld_pred, const void* target, int target_is_int,
+                  int64_t rows, int64_t cols, float coeff, float* grad, int64_t ld_grad,
+                  float* loss_out, void* ws, size_t ws_bytes, ttsmi_stream_t stream);
+int ttsmi_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
+                  const int64_t* step_dev, float b1, float b2, float eps, uint16_t* bf16_copy,
+                  ttsmi_stream_t stream);
+/* step_dev[0] += 1 (so that the optimiser step and the dropout stream advance inside a graph). */
+int ttsmi_step_increment(int64_t* step_dev, ttsmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * wav -> STFT -> mel -> log.  Replaces librosa.stft + librosa.feature.melspectrogram(S=|D|) +
+ * MelGAN/WaveRNN normalisation at data/audio.py:72-92,209-242 as ONE batched kernel.
+ * wav: concatenated float32 clips, clip c = wav[clip_off[c] .. clip_off[c+1]);
+ * out: concatenated [frames, n_mels] float32, clip c at rows frame_off[c] .. frame_off[c+1]),
+ *      frames_c = 1 + len_c / hop (center=True, reflect padding n_fft/2).
+ * window [n_fft] float32 (periodic Hann of win_length centred in n_fft - built by the caller);
+ * mel filterbank in CSR-by-row form: for mel m, bins mel_lo[m] .. mel_lo[m]+mel_cnt[m]) with
+ * weights mel_w[mel_ptr[m] ..].  normalizer: 0 = MelGAN log(clip(S, clip_min)),
+ * 1 = WaveRNN dB normalisation (min_level_db = -100, max_norm = 4).
+ * ------------------------------------------------------------------------------------------- */
+int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* frame_off,
+                      int n_clips, int64_t total_frames, int n_fft, int hop, const float* window,
+                      int n_mels, const int32_t* mel_lo, const int32_t* mel_cnt,
+                      const int32_t* mel_ptr, const float* mel_w, int normalizer, float clip_min,
+                      float* out, ttsmi_stream_t stream);
+
+/* Utility: fp32 -> bf16 (round to nearest even) for the TTSMI_BF16 weight copies. */
+int ttsmi_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, ttsmi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTSMI_H */

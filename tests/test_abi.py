@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary: libttsmi.so loads, exports every symbol include/ttsmi.h
+declares, the ctypes table binds each with the declared parameter count, and argument validation
+returns error codes (no compute launches - there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'ttsmi.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b(?:int|size_t|const char\*)\s+(ttsmi_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
+        name, params = m.group(1), m.group(2).strip()
+        n = 0 if params in ('', 'void') else len([p for p in params.split(',') if p.strip()])
+        out[name] = n
+    return out
+
+
+@pytest.fixture(scope='module')
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from transformertts_amd import _lib
+    return _lib
+
+
+def test_header_declares_expected_surface():
+    d = _declared()
+    for name in ('ttsmi_linear_fwd', 'ttsmi_attention_fwd', 'ttsmi_attention_bwd',
+                 'ttsmi_add_layernorm_fwd', 'ttsmi_conv1d_fwd', 'ttsmi_lenreg_index',
+                 'ttsmi_lenreg_fwd', 'ttsmi_l1_loss', 'ttsmi_adam_tf', 'ttsmi_stft_logmel'):
+        assert name in d
+    assert len(d) >= 35
+
+
+def test_library_exports_and_binds_every_declared_symbol(built):
+    d = _declared()
+    l = built.lib()
+    assert set(d) == set(built.SIGNATURES), set(d) ^ set(built.SIGNATURES)
+    for name, nparams in d.items():
+        assert hasattr(l, name), f'{name} not exported'
+        assert len(built.SIGNATURES[name][1]) == nparams, name
+    assert l.ttsmi_version() == 100
+
+
+def test_invalid_arguments_return_error_codes_not_crashes(built):
+    l = built.lib()
+    rc = l.ttsmi_linear_fwd(None, 0, None, 0, 0, None, 0, None, None, 0, 4, 4, 4, 0, 0, None)
+    assert rc == -1
+    assert b'null' in l.ttsmi_last_error()
+    with pytest.raises(built.TtsmiError):
+        built.check(rc, 'linear_fwd')
+    # unsupported dtype / n_fft are reported, not ignored
+    one = ctypes.c_void_p(16)
+    rc = l.ttsmi_linear_fwd(one, 4, None, 0, 0, one, 4, None, one, 4, 4, 4, 4, 0, 7, None)
+    assert rc == -1 and b'dtype' in l.ttsmi_last_error()
+    rc = l.ttsmi_stft_logmel(one, one, one, 1, 1, 2048, 256, one, 80, one, one, one, one, 0, 1e-5, one, None)
+    assert rc == -3 and b'n_fft' in l.ttsmi_last_error()
+    assert l.ttsmi_linear_wgrad_ws_bytes(28800, 1024, 256) > 0
+
+
+def test_missing_library_fails_loudly(built, monkeypatch):
+    monkeypatch.setattr(built, '_lib', None)
+    monkeypatch.setattr(built, 'LIB_PATH', '/nonexistent/libttsmi.so')
+    with pytest.raises(built.TtsmiError):
+        built.lib()

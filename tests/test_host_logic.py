@@ -1,0 +1,98 @@
+"""CPU tests of the host-side logic (no kernels run): constants handed to the kernels equal the
+oracle's, parameter layout, tokenizer, loud failure without a GPU."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ft_oracle as fo
+from oracle import mel_oracle as mo
+
+
+def test_sparse_filterbank_equals_oracle_dense_basis():
+    from transformertts_amd.data.audio import hann_window_padded, mel_filterbank_sparse
+    for (sr, n_fft, n_mels, fmin, fmax) in [(22050, 1024, 80, 0, 8000), (22050, 2048, 80, 40, None),
+                                             (16000, 1024, 40, 0, None)]:
+        lo, cnt, ptr, w = mel_filterbank_sparse(sr, n_fft, n_mels, fmin, fmax)
+        dense = np.zeros((n_mels, 1 + n_fft // 2), np.float32)
+        for m in range(n_mels):
+            dense[m, lo[m]:lo[m] + cnt[m]] = w[ptr[m]:ptr[m] + cnt[m]]
+        np.testing.assert_array_equal(dense, mo.mel_filterbank(sr, n_fft, n_mels, fmin, fmax))
+    assert len(mel_filterbank_sparse(22050, 1024, 80, 0, 8000)[3]) >= 727
+    import scipy.signal
+    np.testing.assert_allclose(hann_window_padded(1024, 1024),
+                               scipy.signal.get_window('hann', 1024, fftbins=True), atol=1e-7)
+    w = hann_window_padded(1100, 2048)
+    assert w[:474].sum() == 0 and w[474 + 1100:].sum() == 0
+    np.testing.assert_allclose(w[474:474 + 1100], scipy.signal.get_window('hann', 1100, fftbins=True), atol=1e-7)
+
+
+def test_flat_params_layout_and_spec_matches_oracle():
+    from transformertts_amd.model.models import FlatParams, _blocks_spec, _predictor_spec
+    spec = OrderedDict()
+    spec['a'] = (3, 5)
+    spec['s'] = ()
+    spec['b'] = (7,)
+    P = FlatParams(spec, 'cpu')
+    assert P.offsets['a'] == (0, 15) and P.offsets['s'] == (16, 1) and P.offsets['b'] == (20, 7)
+    assert P.total == 28 and P.n_params == 23
+    P.g['b'].fill_(2.0)
+    assert P.grad[20:27].eq(2).all() and P.grad[:20].eq(0).all()
+    assert P.w['a'].requires_grad and P.w['a'].data_ptr() == P.data.data_ptr()
+    # parameter count of the benchmark config equals the oracle's spec (SURVEY: 11.06 M)
+    cfg = fo.make_config()
+    n_or = sum(int(np.prod(s)) for s in fo.weight_spec(cfg).values())
+    mine = OrderedDict()
+    mine['embedding'] = (127, 256)
+    mine.update(_blocks_spec('enc', 256, [4] * 6, 6, 1024, None, 3))
+    mine.update(_predictor_spec('dur', 256, [256, 226], 3))
+    mine.update(_predictor_spec('pitch', 256, [256, 226], 3))
+    mine['pitch_embed.w'] = (1, 256)
+    mine['pitch_embed.b'] = (256,)
+    mine.update(_blocks_spec('dec', 256, [4] * 6, 6, 1024, None, 3))
+    mine['out.w'] = (256, 80)
+    mine['out.b'] = (80,)
+    n_mine = sum(int(np.prod(s)) for s in mine.values())
+    assert n_mine == n_or
+    assert 11.0e6 < n_or < 11.1e6
+
+
+def test_tokenizer_matches_reference_semantics():
+    from transformertts_amd.data.text import Tokenizer
+    t = Tokenizer(add_start_end=False, model_breathing=False)
+    assert t.vocab_size == 127 and t.decode([0]) == '/'
+    assert t.decode(t('hɛloʊ')) == 'hɛloʊ'
+    # reference tests/test_char_tokenizer.py alphabet 'ab c' with start/end + breathing defaults
+    t2 = Tokenizer(alphabet=list('ab c'))
+    assert t2.start_token_index == 5 and t2.end_token_index == 6 and t2.vocab_size == 8
+    with pytest.raises(KeyError):
+        t2('a b d')
+    t3 = Tokenizer(alphabet=list('ab c'), model_breathing=False)
+    assert t3.vocab_size == 7 and t3('a b') == [5, 2, 1, 3, 6]
+
+
+def test_no_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from transformertts_amd import _lib
+    from transformertts_amd.data.audio import Audio
+    from transformertts_amd.model.models import ForwardTransformer
+    with pytest.raises(_lib.TtsmiError):
+        ForwardTransformer.from_config(fo.tiny_config())
+    with pytest.raises(_lib.TtsmiError):
+        Audio(22050, 1024, 80, 256, 1024, 0, 8000, 'MelGAN')
+    from transformertts_amd import ops
+    with pytest.raises(_lib.TtsmiError):
+        ops.linear_fwd(torch.zeros(4, 4), torch.zeros(4, 4), None)
+
+
+def test_product_code_never_imports_the_oracle():
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'transformertts_amd')
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), os.path.join(dp, f)

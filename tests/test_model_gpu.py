@@ -1,0 +1,215 @@
+"""-m gpu parity of the whole ForwardTransformer path and of the STFT->mel kernel against the CPU
+oracle on identical weights / inputs.  Contract (BASELINE.json north_star): length-regulator index
+expansion bit-exact; fp32 mel and loss within 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ft_oracle as fo
+from oracle import mel_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _model(cfg, W, **kw):
+    from transformertts_amd.model.models import ForwardTransformer
+    m = ForwardTransformer.from_config(dict(cfg, **kw))
+    m.load_weights_dict(W)
+    return m
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope='module')
+def tiny():
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=7, perturb=0.02)
+    return cfg, W
+
+
+def test_weights_roundtrip(tiny):
+    cfg, W = tiny
+    m = _model(cfg, W)
+    back = m.weights_dict()
+    assert list(back) == list(W)
+    for k in W:
+        np.testing.assert_array_equal(back[k], W[k].astype(np.float32))
+    assert m.params.n_params == sum(int(np.prod(v.shape)) for v in W.values())
+
+
+@pytest.mark.parametrize('ragged', [False, True])
+def test_val_step_matches_oracle(tiny, ragged):
+    cfg, W = tiny
+    batch = fo.synthetic_batch(4, 50, 200, seed=11, ragged=ragged)
+    ref = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    want = ref.val_step(*batch)
+    m = _model(cfg, W)
+    got = m.val_step(*batch)
+    assert got['mel'].shape == want['mel'].shape
+    assert _rel(got['mel'], want['mel']) < TOL
+    assert _rel(got['duration'], want['duration']) < TOL
+    assert _rel(got['pitch'], want['pitch']) < TOL
+    assert abs(float(got['loss']) - float(want['loss'])) / float(want['loss']) < TOL
+    for k in ('mel', 'duration', 'pitch'):
+        assert abs(float(got['losses'][k]) - float(want['losses'][k])) / float(want['losses'][k]) < TOL
+    np.testing.assert_array_equal(got['expanded_mask'].cpu().numpy(), want['expanded_mask'].numpy())
+    assert list(got['encoder_attention']) == list(want['encoder_attention'])
+    assert list(got['decoder_attention']) == list(want['decoder_attention'])
+    for name in want['decoder_attention']:
+        assert _rel(got['decoder_attention'][name], want['decoder_attention'][name]) < TOL
+    for name in want['encoder_attention']:
+        assert _rel(got['encoder_attention'][name], want['encoder_attention'][name]) < TOL
+
+
+@pytest.mark.parametrize('ragged', [False, True])
+def test_train_step_grads_and_adam_match_oracle(tiny, ragged):
+    cfg, W = tiny
+    batch = fo.synthetic_batch(4, 50, 200, seed=12, ragged=ragged)
+    ref = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    ref.learning_rate = 1e-3
+    want = ref.train_step(*batch)
+    m = _model(cfg, W)
+    m._compile(learning_rate=1e-3)
+    got = m.train_step(*batch)
+    assert abs(float(got['loss']) - float(want['loss'])) / float(want['loss']) < TOL
+    assert _rel(got['mel'], want['mel']) < TOL
+    grads = m.grads_dict()
+    worst = ('', 0.0)
+    gnorm = max(float(v.abs().max()) for v in want['grads'].values())
+    for k, gw in want['grads'].items():
+        # per-tensor: relative to the tensor's own scale, floored at 1e-3 of the global grad scale
+        scale = max(float(gw.abs().max()), 1e-3 * gnorm)
+        e = float(np.abs(grads[k].astype(np.float64) - gw.numpy()).max()) / scale
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 2e-4, worst
+    new_w = m.weights_dict()
+    for k, v in ref.weights_numpy().items():
+        assert np.abs(new_w[k] - v).max() < 2e-5, k
+    assert m.step == 1 and ref.step == 1
+    # several more steps stay locked to the oracle
+    for _ in range(3):
+        want = ref.train_step(*batch)
+        got = m.train_step(*batch)
+    assert abs(float(got['loss']) - float(want['loss'])) / float(want['loss']) < TOL
+    assert m.step == 4
+
+
+def test_conv_block_variant_matches_oracle():
+    """SelfAttentionConvBlock path (the reference's shipped default) at a small size."""
+    cfg = fo.make_config(d_model=64, enc_heads=(2, 2), dec_heads=(2, 2), ffn=128, enc_dense_blocks=1,
+                         dec_dense_blocks=0, conv_filters=(128, 64), dur_filters=(64, 30),
+                         pitch_filters=(48, 34))
+    W = fo.init_weights(cfg, seed=3, perturb=0.02)
+    batch = fo.synthetic_batch(3, 33, 140, seed=5, ragged=True)
+    ref = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    ref.learning_rate = 1e-3
+    want = ref.train_step(*batch)
+    m = _model(cfg, W)
+    m._compile(learning_rate=1e-3)
+    got = m.train_step(*batch)
+    assert abs(float(got['loss']) - float(want['loss'])) / float(want['loss']) < TOL
+    assert _rel(got['mel'], want['mel']) < TOL
+    new_w = m.weights_dict()
+    for k, v in ref.weights_numpy().items():
+        assert np.abs(new_w[k] - v).max() < 2e-5, k
+
+
+def test_predict_matches_oracle(tiny):
+    cfg, W = tiny
+    W = dict(W)
+    W['dur.lin.b'] = W['dur.lin.b'] + 2.3          # untrained weights give ~0 durations; shift them
+    tok = np.array([[5, 17, 3, 99, 42, 7, 8, 120, 1, 64]], dtype=np.int32)
+    ref = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    with torch.no_grad():
+        want = ref.call(tok, training=False, durations_scalar=1. / 0.8)
+    m = _model(cfg, W)
+    got = m.predict(tok[0], encode=False, speed_regulator=0.8)
+    assert got['mel'].shape == tuple(want['mel'][0].shape)
+    assert _rel(got['mel'], want['mel'][0]) < TOL
+    assert _rel(got['duration'], want['duration']) < TOL
+    # per-symbol clamps (models.py:579-595) + forced durations / pitch
+    dur = np.full((1, 10), 3.5, dtype=np.float32)
+    pit = np.linspace(-1, 1, 10, dtype=np.float32)[None]
+    with torch.no_grad():
+        want = ref.call(tok, target_durations=torch.from_numpy(dur)[..., None],
+                        target_pitch=torch.from_numpy(pit)[..., None], training=False)
+    got = m.predict(tok, encode=False, phoneme_durations=torch.from_numpy(dur), phoneme_pitch=torch.from_numpy(pit))
+    assert got['mel'].shape[0] == 4 * 10 - 0 or got['mel'].shape[0] == want['mel'].shape[1]
+    assert _rel(got['mel'], want['mel'][0]) < TOL
+
+
+def test_dropout_training_step_is_finite_and_reproducible(tiny):
+    cfg, W = tiny
+    batch = fo.synthetic_batch(4, 50, 200, seed=13)
+    outs = []
+    for _ in range(2):
+        m = _model(cfg, W, dropout_rate=0.1, predictors_dropout=0.1, seed=5)
+        m._compile(learning_rate=1e-3)
+        outs.append([float(m.train_step(*batch)['loss']) for _ in range(3)])
+    assert outs[0] == outs[1]                      # same seed, same device step counter -> same masks
+    assert all(np.isfinite(outs[0]))
+    m0 = _model(cfg, W)
+    l0 = float(m0.val_step(*batch)['loss'])
+    assert abs(outs[0][0] - l0) / l0 < 0.2         # dropout perturbs, does not destroy, the loss
+
+
+def test_save_load_roundtrip(tiny, tmp_path):
+    cfg, W = tiny
+    batch = fo.synthetic_batch(2, 20, 60, seed=14)
+    m = _model(cfg, W)
+    m._compile(learning_rate=1e-3)
+    m.train_step(*batch)
+    m.save_model(str(tmp_path / 'ckpt'))
+    from transformertts_amd.model.models import ForwardTransformer
+    m2 = ForwardTransformer.load_model(str(tmp_path / 'ckpt'))
+    assert m2.step == 1
+    a, b = m.train_step(*batch), m2.train_step(*batch)
+    assert float(a['loss']) == float(b['loss'])
+    assert torch.equal(m.params.data, m2.params.data)
+
+
+# ---------------------------------------------------------------------------------------- mel path
+def _audio(**kw):
+    from transformertts_amd.data.audio import Audio
+    cfg = dict(sampling_rate=22050, n_fft=1024, mel_channels=80, hop_length=256, win_length=1024,
+               f_min=0, f_max=8000, normalizer='MelGAN')
+    cfg.update(kw)
+    return Audio.from_config(cfg)
+
+
+def test_mel_matches_oracle_ragged_batch():
+    audio = _audio()
+    lens = [24000, 51234, 30976, 1025, 22050, 66000]     # incl. len % hop == 0 and a very short clip
+    clips = [mo.synthetic_clip(n, seed=i) for i, n in enumerate(lens)]
+    mel, frame_off = audio.mel_spectrogram_batch(clips)
+    mel = mel.cpu().numpy()
+    assert mel.shape == (sum(1 + n // 256 for n in lens), 80)
+    for i, y in enumerate(clips):
+        got = mel[frame_off[i]:frame_off[i + 1]]
+        want = mo.mel_spectrogram(y)
+        assert got.shape == want.shape
+        # fp32 mel within 1e-4 relative on the linear (pre-log) mel energies; log values to 1e-4 abs
+        assert np.abs(np.exp(got.astype(np.float64)) - np.exp(want.astype(np.float64))).max() \
+            / np.exp(want.astype(np.float64)).max() < TOL
+        assert np.abs(got - want).max() < 2e-4
+        single = audio.mel_spectrogram(y)
+        np.testing.assert_array_equal(single, got)
+
+
+def test_mel_analytic_and_wavernn_normalizer():
+    audio = _audio()
+    sil = audio.mel_spectrogram(np.zeros(5000, np.float32))
+    np.testing.assert_allclose(sil, np.log(1e-5), rtol=1e-6)
+    y = mo.synthetic_clip(40000, seed=3)
+    got = _audio(normalizer='WaveRNN').mel_spectrogram(y)
+    want = mo.mel_spectrogram(y, normalizer='WaveRNN')
+    assert np.abs(got - want).max() < 2e-3             # dB-domain normalisation (range [-4, 4])
+    with pytest.raises(Exception):
+        _audio(n_fft=2048, win_length=1100, hop_length=275).mel_spectrogram(y)

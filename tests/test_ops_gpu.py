@@ -1,0 +1,450 @@
+"""-m gpu parity tests of every libttsmi op, called through the C ABI, against fp64 torch-CPU
+restatements of the same op (oracle/ft_oracle.py building blocks).  Tolerances: integer / index
+work bit-exact; fp32 work 1e-4 relative to the tensor's max magnitude (north_star), usually far
+tighter because the fp32 MFMA path is an exact fp32 FMA chain."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ft_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def _ops():
+    from transformertts_amd import ops
+    return ops
+
+
+def rel_err(got: torch.Tensor, want: torch.Tensor) -> float:
+    want = want.double().cpu()
+    got = got.double().cpu()
+    scale = max(float(want.abs().max()), 1e-30)
+    return float((got - want).abs().max()) / scale
+
+
+def g(*shape, seed=0, scale=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=gen) * scale).float()
+
+
+# ------------------------------------------------------------------------------------ GEMM family
+@pytest.mark.parametrize('M,K,N', [(128, 256, 256), (200, 64, 192), (1, 16, 4), (333, 100, 60),
+                                   (77, 226, 1), (1000, 512, 130), (129, 17, 33)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_linear_fwd(M, K, N, relu):
+    ops = _ops()
+    x, w, b = g(M, K, seed=1), g(K, N, seed=2), g(N, seed=3)
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), relu)
+    want = x.double() @ w.double() + b.double()
+    if relu:
+        want = want.relu()
+    assert rel_err(y, want) < 2e-6
+
+
+def test_linear_fwd_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C write (guide rule 16)."""
+    ops = _ops()
+    n = 160
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97) - 3.0 * torch.arange(n)[None, :]
+    y = ops.linear_fwd(torch.eye(n).to(DEV), w.to(DEV), None, False)
+    assert torch.equal(y.cpu(), w)
+
+
+@pytest.mark.parametrize('M,K1,K2,N', [(300, 64, 64, 64), (129, 256, 256, 256), (50, 16, 48, 20)])
+def test_linear_fwd_dual_a(M, K1, K2, N):
+    ops = _ops()
+    x, x2, w, b = g(M, K1, seed=1), g(M, K2, seed=4), g(K1 + K2, N, seed=2), g(N, seed=3)
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), False, x2.to(DEV))
+    want = torch.cat([x, x2], 1).double() @ w.double() + b.double()
+    assert rel_err(y, want) < 2e-6
+
+
+def test_linear_fwd_strided_input():
+    ops = _ops()
+    big = g(100, 192, seed=5).to(DEV)
+    x = big[:, 64:128]                      # row stride 192, offset keeps 16-byte alignment
+    w = g(64, 32, seed=6)
+    y = ops.linear_fwd(x, w.to(DEV), None, False)
+    assert rel_err(y, big.cpu()[:, 64:128].double() @ w.double()) < 2e-6
+
+
+@pytest.mark.parametrize('M,K,N', [(256, 128, 256), (1000, 64, 192), (333, 100, 60), (77, 226, 1),
+                                   (4000, 256, 1024)])
+def test_linear_backward(M, K, N):
+    ops = _ops()
+    x, w, dy, h = g(M, K, seed=1), g(K, N, seed=2), g(M, N, seed=3), g(M, K, seed=4)
+    dx = ops.linear_dgrad(dy.to(DEV), w.to(DEV))
+    assert rel_err(dx, dy.double() @ w.double().T) < 2e-6
+    dxm = ops.linear_dgrad(dy.to(DEV), w.to(DEV), relu_src=h.to(DEV))
+    assert rel_err(dxm, (dy.double() @ w.double().T) * (h > 0)) < 2e-6
+    dw = torch.full((K, N), 7.0, device=DEV)
+    db = torch.full((N,), 7.0, device=DEV)
+    ops.linear_wgrad(x.to(DEV), dy.to(DEV), dw, db)
+    assert rel_err(dw, x.double().T @ dy.double()) < 3e-6
+    assert rel_err(db, dy.double().sum(0)) < 3e-6
+
+
+@pytest.mark.parametrize('B,T,Cin,Cout,k', [(2, 50, 64, 64, 3), (3, 17, 32, 226, 3), (2, 40, 226, 8, 3),
+                                            (1, 9, 4, 4, 5), (2, 30, 16, 24, 1), (4, 200, 256, 256, 3),
+                                            (2, 13, 12, 20, 4)])
+def test_conv1d_fwd_bwd(B, T, Cin, Cout, k):
+    ops = _ops()
+    x, w, b = g(B, T, Cin, seed=1), g(k, Cin, Cout, seed=2, scale=0.2), g(Cout, seed=3)
+    xd, wd, bd = (t.double().requires_grad_() for t in (x, w, b))
+    want = fo.conv1d_same(xd, wd, bd).relu()
+    y = ops.conv1d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
+    assert rel_err(y, want.detach()) < 2e-6
+    # backward of the pre-activation conv with an upstream gradient dy
+    dy = g(B, T, Cout, seed=4)
+    pre = fo.conv1d_same(xd, wd, bd)
+    pre.backward(dy.double())
+    dx = ops.conv1d_dgrad(dy.to(DEV), w.to(DEV))
+    assert rel_err(dx, xd.grad) < 3e-6
+    dw = torch.empty_like(w, device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    ops.conv1d_wgrad(x.to(DEV), dy.to(DEV), dw, db)
+    assert rel_err(dw, wd.grad) < 3e-6
+    assert rel_err(db, bd.grad) < 3e-6
+    hmask = g(B, T, Cin, seed=5)
+    dxm = ops.conv1d_dgrad(dy.to(DEV), w.to(DEV), relu_src=hmask.to(DEV))
+    assert rel_err(dxm, xd.grad * (hmask > 0)) < 3e-6
+
+
+def test_ffn_and_convstack_autograd():
+    ops = _ops()
+    M, d, F = 300, 64, 256
+    x, w1, b1, w2, b2 = g(M, d, seed=1), g(d, F, seed=2, scale=0.2), g(F, seed=3), g(F, d, seed=4, scale=0.2), g(d, seed=5)
+    ts = [t.to(DEV).requires_grad_() for t in (x, w1, b1, w2, b2)]
+    y = ops.FFNFn.apply(*ts, None, None, None, None)
+    dy = g(M, d, seed=6)
+    y.backward(dy.to(DEV))
+    td = [t.double().requires_grad_() for t in (x, w1, b1, w2, b2)]
+    yd = (td[0] @ td[1] + td[2]).relu() @ td[3] + td[4]
+    yd.backward(dy.double())
+    assert rel_err(y.detach(), yd.detach()) < 2e-6
+    for a, b in zip(ts, td):
+        assert rel_err(a.grad, b.grad) < 5e-6
+    # conv stack (CNNResNorm convs): conv -> relu -> conv
+    B, T, C, Fh = 2, 40, 32, 96
+    x, w0, b0, w1, b1 = g(B, T, C, seed=1), g(3, C, Fh, seed=2, scale=0.2), g(Fh, seed=3), g(3, Fh, C, seed=4, scale=0.2), g(C, seed=5)
+    ts = [t.to(DEV).requires_grad_() for t in (x, w0, b0, w1, b1)]
+    y = ops.ConvStackFn.apply(ts[0], 2, *ts[1:])
+    dy = g(B, T, C, seed=6)
+    y.backward(dy.to(DEV))
+    td = [t.double().requires_grad_() for t in (x, w0, b0, w1, b1)]
+    yd = fo.conv1d_same(fo.conv1d_same(td[0], td[1], td[2]).relu(), td[3], td[4])
+    yd.backward(dy.double())
+    assert rel_err(y.detach(), yd.detach()) < 2e-6
+    for a, b in zip(ts, td):
+        assert rel_err(a.grad, b.grad) < 5e-6
+
+
+# ------------------------------------------------------------------------------------ layernorm
+@pytest.mark.parametrize('M,C', [(37, 64), (100, 256), (9, 226), (50, 384), (20, 1024), (5, 30), (3, 1536)])
+@pytest.mark.parametrize('mode', ['plain', 'res_mask', 'pe', 'relu_in'])
+def test_add_layernorm(M, C, mode):
+    ops = _ops()
+    T = 7
+    x, res, gam, bet = g(M, C, seed=1), g(M, C, seed=2), g(C, seed=3) * 0.3 + 1, g(C, seed=4)
+    pe, ps = g(T, C, seed=5), torch.tensor(0.7)
+    pad = (torch.arange(M) % 5 == 0).to(torch.uint8)
+    if mode == 'relu_in':
+        x = x.relu()
+    kw = {}
+    xd, rd, gd, bd, psd = (t.double().requires_grad_() for t in (x, res, gam, bet, ps))
+    if mode == 'plain':
+        want = fo.layer_norm(xd, gd, bd)
+    elif mode == 'relu_in':
+        pre = g(M, C, seed=1).double().requires_grad_()
+        want = fo.layer_norm(pre.relu(), gd, bd)
+        kw = dict(relu_in=True)
+    elif mode == 'res_mask':
+        want = fo.layer_norm(xd + rd, gd, bd) * (1 - pad.double())[:, None]
+        kw = dict(row_pad=pad.to(DEV))
+    else:
+        want = fo.layer_norm(xd, gd, bd) + psd * pe.double()[torch.arange(M) % T]
+        kw = dict(pe=pe.to(DEV), T=T)
+    xg, rg, gg, bg, psg = (t.to(DEV).requires_grad_() for t in (x, res, gam, bet, ps))
+    y = ops.add_layernorm(xg, rg if mode == 'res_mask' else None, gg, bg,
+                          pe_scale=psg if mode == 'pe' else None, **kw)
+    assert rel_err(y.detach(), want.detach()) < 3e-6
+    dy = g(M, C, seed=9)
+    y.backward(dy.to(DEV))
+    want.backward(dy.double())
+    assert rel_err(gg.grad, gd.grad) < 1e-5 and rel_err(bg.grad, bd.grad) < 1e-5
+    if mode == 'relu_in':
+        assert rel_err(xg.grad, pre.grad) < 1e-5
+    else:
+        assert rel_err(xg.grad, xd.grad) < 1e-5
+    if mode == 'res_mask':
+        assert rel_err(rg.grad, rd.grad) < 1e-5
+    if mode == 'pe':
+        assert rel_err(psg.grad, psd.grad) < 1e-5
+
+
+def test_add_layernorm_dropout_statistics_and_determinism():
+    ops = _ops()
+    M, C, p = 4000, 256, 0.1
+    x, res = g(M, C, seed=1).to(DEV), g(M, C, seed=2).to(DEV)
+    gam, bet = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    drop = ops.DropCtx(seed=123)
+    y0 = ops.add_layernorm(x, None, gam, bet)
+    y1 = ops.add_layernorm(x, None, gam, bet, p_out=p, site_out=3, drop=drop)
+    y2 = ops.add_layernorm(x, None, gam, bet, p_out=p, site_out=3, drop=drop)
+    y3 = ops.add_layernorm(x, None, gam, bet, p_out=p, site_out=4, drop=drop)
+    assert torch.equal(y1, y2)                      # same (seed, site) -> same mask
+    assert not torch.equal(y1, y3)                  # different site -> different mask
+    kept = (y1 != 0)
+    frac = 1.0 - kept.float().mean().item()
+    assert abs(frac - p) < 4 * math.sqrt(p * (1 - p) / (M * C))
+    assert torch.allclose(y1[kept], (y0 / (1 - p))[kept], rtol=1e-6, atol=1e-7)
+    # mask is spatially uncorrelated enough: per-row and per-column drop rates concentrate around p
+    assert abs((~kept).float().mean(0).std().item() - math.sqrt(p * (1 - p) / M)) < 2e-3
+    # backward regenerates the same masks (p_in on the x branch, res untouched)
+    xg, rg = x.clone().requires_grad_(), res.clone().requires_grad_()
+    ya = ops.add_layernorm(xg, rg, gam, bet, p_in=p, site_in=7, drop=drop)
+    ya.sum().backward()
+    zero_in_x = (xg.grad == 0).float().mean().item()
+    assert abs(zero_in_x - p) < 0.01 and (rg.grad == 0).float().mean().item() < 1e-3
+    # a device step counter changes the stream without changing kernel arguments
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    d2 = ops.DropCtx(seed=123, step_dev=step)
+    a = ops.add_layernorm(x, None, gam, bet, p_out=p, site_out=3, drop=d2)
+    ops.step_increment(step)
+    b = ops.add_layernorm(x, None, gam, bet, p_out=p, site_out=3, drop=d2)
+    assert torch.equal(a, y1) and not torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, pad, B, H, T, dh):
+    d = H * dh
+    q, k, v = qkv.double().reshape(B, T, 3, H, dh).permute(2, 0, 3, 1, 4)
+    mask = pad.double()[:, None, None, :]
+    # the reference adds mask*-1e9 in fp32; emulate the fp32 absorption of the logit
+    logits32 = (q @ k.transpose(-1, -2) / math.sqrt(dh)).float() + (mask * -1e9).float()
+    w = torch.softmax(logits32.double(), -1)
+    ctx = (w @ v).permute(0, 2, 1, 3).reshape(B * T, d)
+    return ctx, w
+
+
+@pytest.mark.parametrize('B,H,T,dh', [(2, 2, 50, 32), (3, 4, 200, 64), (1, 1, 1, 32), (2, 4, 333, 64),
+                                      (2, 2, 129, 64), (1, 4, 900, 64)])
+def test_attention_fwd_bwd_weights(B, H, T, dh):
+    ops = _ops()
+    d = H * dh
+    qkv = g(B * T, 3 * d, seed=1)
+    lens = torch.tensor([T] + [max(1, (T * (i + 1)) // (B + 1)) for i in range(B - 1)])
+    pad = (torch.arange(T)[None, :] >= lens[:, None]).to(torch.uint8)
+    if T > 10:
+        pad[0, 3] = 1                              # an interior padded key (token id 0 mid-sequence)
+    padg = pad.to(DEV)
+    klen = torch.zeros(B, dtype=torch.int32)       # klen = 1 + last unpadded index
+    for i, p in enumerate(pad):
+        nz = (p == 0).nonzero()
+        klen[i] = T if len(nz) == 0 else int(nz.max()) + 1
+    qg = qkv.to(DEV).requires_grad_()
+    ctx, lse = ops.AttentionFn.apply(qg, padg, klen.to(DEV), B, H, T, dh, 0.0, None, 0)
+    qd = qkv.double().requires_grad_()
+    want, wts = _attn_ref(qd, pad, B, H, T, dh)
+    assert rel_err(ctx.detach(), want.detach()) < 5e-6
+    w_gpu = ops.attention_weights(qg.detach(), padg, lse, B, H, T, dh)
+    assert rel_err(w_gpu, wts.detach()) < 5e-6
+    dctx = g(B * T, d, seed=2)
+    ctx.backward(dctx.to(DEV))
+    want.backward(dctx.double())
+    assert rel_err(qg.grad, qd.grad) < 2e-5
+
+
+def test_attention_all_keys_padded_is_uniform():
+    ops = _ops()
+    B, H, T, dh = 1, 2, 40, 32
+    qkv = g(B * T, 3 * H * dh, seed=1)
+    pad = torch.ones(B, T, dtype=torch.uint8)
+    padg, klen = ops.length_pad_mask(torch.zeros(B, dtype=torch.int32, device=DEV), T)
+    assert torch.equal(padg.cpu(), pad) and int(klen[0]) == T
+    ctx, lse = ops.AttentionFn.apply(qkv.to(DEV), padg, klen, B, H, T, dh, 0.0, None, 0)
+    want, _ = _attn_ref(qkv, pad, B, H, T, dh)
+    assert rel_err(ctx, want) < 1e-5
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running max to jump at a late key tile (guide rule 26)."""
+    ops = _ops()
+    B, H, T, dh = 1, 1, 300, 64
+    qkv = g(B * T, 3 * dh, seed=3)
+    qkv[:, :dh] *= 0.1
+    qkv[5, :dh] = 3.0
+    qkv[250, dh:2 * dh] = 3.0                      # key 250 spikes against query 5
+    pad = torch.zeros(B, T, dtype=torch.uint8)
+    klen = torch.full((B,), T, dtype=torch.int32)
+    ctx, lse = ops.AttentionFn.apply(qkv.to(DEV), pad.to(DEV), klen.to(DEV), B, H, T, dh, 0.0, None, 0)
+    want, wts = _attn_ref(qkv, pad, B, H, T, dh)
+    assert float(wts[0, 0, 5, 250]) > 0.99
+    assert rel_err(ctx, want) < 5e-6
+
+
+def test_attention_dropout_consistency():
+    """weights kernel, forward and backward all regenerate the same dropout mask."""
+    ops = _ops()
+    B, H, T, dh, p = 2, 2, 150, 32, 0.1
+    d = H * dh
+    qkv = g(B * T, 3 * d, seed=1)
+    pad = torch.zeros(B, T, dtype=torch.uint8)
+    klen = torch.full((B,), T, dtype=torch.int32)
+    drop = ops.DropCtx(seed=99)
+    qg = qkv.to(DEV).requires_grad_()
+    ctx, lse = ops.AttentionFn.apply(qg, pad.to(DEV), klen.to(DEV), B, H, T, dh, p, drop, 5)
+    w = ops.attention_weights(qg.detach(), pad.to(DEV), lse, B, H, T, dh, p, drop, 5).cpu().double()
+    frac = (w == 0).double().mean().item()
+    assert abs(frac - p) < 0.005
+    # rebuild ctx / grads on the CPU from the materialised dropped weights
+    qd = qkv.double().requires_grad_()
+    q, k, v = qd.reshape(B, T, 3, H, dh).permute(2, 0, 3, 1, 4)
+    sm = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), -1)
+    keep = (w != 0).double() / (1 - p)
+    want = ((sm * keep) @ v).permute(0, 2, 1, 3).reshape(B * T, d)
+    assert rel_err(ctx.detach(), want.detach()) < 1e-5
+    dctx = g(B * T, d, seed=2)
+    ctx.backward(dctx.to(DEV))
+    want.backward(dctx.double())
+    assert rel_err(qg.grad, qd.grad) < 3e-5
+
+
+# ------------------------------------------------------------------------------------ small ops
+def test_masks_embedding_pitch_rowdot():
+    ops = _ops()
+    B, T, V, C = 3, 37, 127, 64
+    tok = torch.randint(1, V, (B, T), generator=torch.Generator().manual_seed(0)).int()
+    tok[0, 20:] = 0
+    tok[1, 5] = 0
+    tok[2, :] = 0
+    pad, klen = ops.token_pad_mask(tok.to(DEV))
+    assert torch.equal(pad.cpu(), (tok == 0).to(torch.uint8))
+    assert klen.cpu().tolist() == [20, T, T]
+    pad2, klen2 = ops.length_pad_mask(torch.tensor([5, 0, T + 3], dtype=torch.int32, device=DEV), T)
+    assert klen2.cpu().tolist() == [5, T, T]
+    assert pad2.cpu()[0].tolist() == [0] * 5 + [1] * (T - 5)
+    table = g(V, C, seed=1)
+    tg = table.to(DEV).requires_grad_()
+    e = ops.EmbeddingFn.apply(tok.to(DEV), tg, None)
+    assert torch.equal(e.detach().cpu(), table[tok.long()])
+    dy = g(B, T, C, seed=2)
+    e.backward(dy.to(DEV))
+    td = table.double().requires_grad_()
+    td[tok.long()].backward(dy.double())
+    assert rel_err(tg.grad, td.grad) < 1e-6
+    # pitch embed
+    x, p, w, b = g(B * T, C, seed=3), g(B * T, seed=4), g(C, seed=5), g(C, seed=6)
+    ts = [t.to(DEV).requires_grad_() for t in (x, p, w, b)]
+    y = ops.PitchEmbedFn.apply(*ts, None, None)
+    tdl = [t.double().requires_grad_() for t in (x, p, w, b)]
+    yd = tdl[0] + (tdl[1][:, None] * tdl[2][None, :] + tdl[3]).relu()
+    dy = g(B * T, C, seed=7)
+    y.backward(dy.to(DEV))
+    yd.backward(dy.double())
+    assert rel_err(y.detach(), yd.detach()) < 1e-6
+    for a, bb in zip(ts, tdl):
+        assert rel_err(a.grad, bb.grad) < 1e-5
+    # rowdot head
+    for relu in (False, True):
+        x, w, b = g(B, T, 226, seed=8), g(226, 1, seed=9), g(1, seed=10)
+        ts = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+        y = ops.RowDotFn.apply(*ts, None, None, pad, relu)
+        tdl = [t.double().requires_grad_() for t in (x, w, b)]
+        yd = tdl[0] @ tdl[1] + tdl[2]
+        if relu:
+            yd = yd.relu()
+        yd = yd * (1 - pad.cpu().double())[..., None]
+        dy = g(B, T, 1, seed=11)
+        y.backward(dy.to(DEV))
+        yd.backward(dy.double())
+        assert rel_err(y.detach(), yd.detach()) < 1e-6
+        for a, bb in zip(ts, tdl):
+            assert rel_err(a.grad, bb.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ length regulator
+@pytest.mark.parametrize('seed', range(4))
+def test_lenreg_bit_exact(seed):
+    ops = _ops()
+    rng = np.random.default_rng(seed)
+    B, Tp, C = 4, 300, 64
+    dur = rng.choice([0., 0.5, 1.5, 2.5, 3.5, 1.0, 2.0, 7.49, 7.5, 0.49999997, 12.0], size=(B, Tp)).astype(np.float32)
+    if seed == 0:
+        dur[1] = 0
+    if seed == 1:
+        dur[2, 7] = -3.0                           # negative duration -> clamped to 0 (documented)
+    x = rng.standard_normal((B, Tp, C)).astype(np.float32)
+    d_or = np.maximum(dur, 0)[..., None]
+    idx_w, len_w, out_len = fo.expand_indices_np(d_or)
+    cap = max(out_len, 1)
+    idx, cum, ln = ops.lenreg_index(torch.from_numpy(dur).to(DEV), cap)
+    np.testing.assert_array_equal(ln.cpu().numpy(), len_w)
+    np.testing.assert_array_equal(idx.cpu().numpy()[:, :out_len], idx_w)
+    dims = np.rint(np.maximum(dur, 0)).astype(np.int32)
+    np.testing.assert_array_equal(cum.cpu().numpy()[:, 1:], np.cumsum(dims, 1))
+    xg = torch.from_numpy(x).to(DEV).requires_grad_()
+    y = ops.LenRegFn.apply(xg, idx, cum)
+    want = fo.expand_literal_np(x, d_or)
+    np.testing.assert_array_equal(y.detach().cpu().numpy()[:, :out_len], want)
+    # integer durations give the same table; truncating cap drops frames like the [:, :mel_len] slice
+    idx_i, _, _ = ops.lenreg_index(torch.from_numpy(dims).to(DEV), cap)
+    assert torch.equal(idx_i, idx)
+    cap2 = max(out_len // 2, 1)
+    idx_t, cum_t, _ = ops.lenreg_index(torch.from_numpy(dur).to(DEV), cap2)
+    assert torch.equal(idx_t, idx[:, :cap2])
+    # backward = segment sum
+    dy = torch.from_numpy(rng.standard_normal(y.shape).astype(np.float32)).to(DEV)
+    y.backward(dy)
+    xd = torch.from_numpy(x).double().requires_grad_()
+    fo.expand_torch(xd, torch.from_numpy(d_or)).backward(dy.cpu().double()[:, :out_len])
+    assert rel_err(xg.grad, xd.grad) < 1e-6
+
+
+def test_expand_docstring_example_on_gpu():
+    ops = _ops()
+    x = torch.tensor([[[0.54710746, 0.8943467], [0.7140938, 0.97968304], [0.5347662, 0.15213418]]])
+    idx, cum, ln = ops.lenreg_index(torch.tensor([[1, 3, 2]], dtype=torch.int32, device=DEV), 6)
+    y = ops.LenRegFn.apply(x.to(DEV), idx, cum).cpu()
+    assert idx.cpu().tolist() == [[0, 1, 1, 1, 2, 2]] and int(ln[0]) == 6
+    assert torch.equal(y, x[:, [0, 1, 1, 1, 2, 2]])
+
+
+# ------------------------------------------------------------------------------------ loss + optimiser
+def test_l1_loss_and_adam():
+    ops = _ops()
+    pred, tgt = g(7, 33, 80, seed=1), g(7, 33, 80, seed=2)
+    pred[0, 0, :5] = tgt[0, 0, :5]                 # exact zeros of |t - p|: sign(0) = 0
+    pg = pred.to(DEV).requires_grad_()
+    loss = ops.L1LossFn.apply(pg, tgt.to(DEV))
+    (3.0 * loss).backward()
+    pd = pred.double().requires_grad_()
+    ld = (tgt.double() - pd).abs().mean()
+    (3.0 * ld).backward()
+    assert abs(float(loss) - float(ld)) / float(ld) < 1e-6
+    assert rel_err(pg.grad, pd.grad) < 1e-6
+    ti = torch.randint(0, 9, (4, 50, 1), generator=torch.Generator().manual_seed(3)).int()
+    pr = g(4, 50, 1, seed=4)
+    li = ops.L1LossFn.apply(pr.to(DEV), ti.to(DEV))
+    assert abs(float(li) - float((ti.double() - pr.double()).abs().mean())) < 1e-6
+    # TF-form Adam, three steps, against the oracle's hand restatement
+    n = 1000
+    p0, grads = g(n, seed=5), [g(n, seed=6 + i) for i in range(3)]
+    p, m, v = p0.to(DEV).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    lr = torch.tensor([1e-3], device=DEV)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    pw, mw, vw = p0.double().clone(), torch.zeros(n).double(), torch.zeros(n).double()
+    for t, gr in enumerate(grads, start=1):
+        ops.step_increment(step)
+        ops.adam_tf(p, gr.to(DEV), m, v, lr, step)
+        lr_t = 1e-3 * math.sqrt(1 - 0.98 ** t) / (1 - 0.9 ** t)
+        mw = 0.9 * mw + 0.1 * gr.double()
+        vw = 0.98 * vw + 0.02 * gr.double() ** 2
+        pw = pw - lr_t * mw / (vw.sqrt() + 1e-9)
+    assert int(step.item()) == 3
+    assert rel_err(p, pw) < 1e-6

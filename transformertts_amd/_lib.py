@@ -1,0 +1,97 @@
+"""ctypes binding of libttsmi.so (the C ABI declared in include/ttsmi.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent this raises, so a GPU
+test can never silently pass on some other code path."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libttsmi.so')
+
+P = c_void_p          # every device pointer
+I = c_int
+L = c_int64
+F = c_float
+S = c_void_p          # stream
+
+# name -> (restype, argtypes); order and meaning exactly as in include/ttsmi.h
+SIGNATURES = {
+    'ttsmi_version': (I, []),
+    'ttsmi_last_error': (c_char_p, []),
+    'ttsmi_linear_fwd': (I, [P, L, P, L, I, P, L, P, P, L, I, I, I, I, I, S]),
+    'ttsmi_linear_dgrad': (I, [P, L, P, L, P, L, P, L, I, I, I, I, S]),
+    'ttsmi_linear_wgrad_ws_bytes': (c_size_t, [I, I, I]),
+    'ttsmi_linear_wgrad': (I, [P, L, P, L, P, L, P, I, I, I, P, c_size_t, I, S]),
+    'ttsmi_conv1d_fwd': (I, [P, P, P, P, I, I, I, I, I, I, I, S]),
+    'ttsmi_conv1d_dgrad': (I, [P, P, P, P, I, I, I, I, I, I, S]),
+    'ttsmi_conv1d_wgrad_ws_bytes': (c_size_t, [I, I, I, I, I]),
+    'ttsmi_conv1d_wgrad': (I, [P, P, P, P, I, I, I, I, I, P, c_size_t, I, S]),
+    'ttsmi_attention_fwd': (I, [P, P, P, P, P, I, I, I, I, F, c_uint64, P, c_uint32, I, S]),
+    'ttsmi_attention_bwd_ws_bytes': (c_size_t, [I, I, I, I]),
+    'ttsmi_attention_bwd': (I, [P, P, P, P, P, P, P, I, I, I, I, F, c_uint64, P, c_uint32, P,
+                                c_size_t, I, S]),
+    'ttsmi_attention_weights': (I, [P, P, P, P, I, I, I, I, F, c_uint64, P, c_uint32, I, S]),
+    'ttsmi_add_layernorm_fwd': (I, [P, P, P, P, P, P, I, P, F, c_uint32, F, c_uint32, c_uint64, P,
+                                    F, P, P, P, I, I, S]),
+    'ttsmi_add_layernorm_bwd_ws_bytes': (c_size_t, [I, I]),
+    'ttsmi_add_layernorm_bwd': (I, [P, P, P, P, P, P, P, P, I, P, F, c_uint32, F, c_uint32,
+                                    c_uint64, P, I, P, P, P, P, P, I, I, P, c_size_t, S]),
+    'ttsmi_token_pad_mask': (I, [P, P, P, I, I, S]),
+    'ttsmi_length_pad_mask': (I, [P, P, P, I, I, S]),
+    'ttsmi_embedding_fwd': (I, [P, P, P, I, I, I, S]),
+    'ttsmi_embedding_bwd': (I, [P, P, P, I, I, I, S]),
+    'ttsmi_pitch_embed_fwd': (I, [P, P, P, P, P, I, I, S]),
+    'ttsmi_pitch_embed_bwd_ws_bytes': (c_size_t, [I, I]),
+    'ttsmi_pitch_embed_bwd': (I, [P, P, P, P, P, P, P, I, I, P, c_size_t, S]),
+    'ttsmi_rowdot_fwd': (I, [P, P, P, P, P, I, I, I, S]),
+    'ttsmi_rowdot_bwd_ws_bytes': (c_size_t, [I, I]),
+    'ttsmi_rowdot_bwd': (I, [P, P, P, P, P, P, P, P, I, I, I, P, c_size_t, S]),
+    'ttsmi_rowmask_mul': (I, [P, P, P, I, I, S]),
+    'ttsmi_lenreg_index': (I, [P, I, P, P, P, I, I, I, S]),
+    'ttsmi_lenreg_fwd': (I, [P, P, P, I, I, I, I, S]),
+    'ttsmi_lenreg_bwd': (I, [P, P, P, I, I, I, I, S]),
+    'ttsmi_l1_loss_ws_bytes': (c_size_t, [L]),
+    'ttsmi_l1_loss': (I, [P, L, P, I, L, L, F, P, L, P, P, c_size_t, S]),
+    'ttsmi_adam_tf': (I, [P, P, P, P, L, P, P, F, F, F, P, S]),
+    'ttsmi_step_increment': (I, [P, S]),
+    'ttsmi_stft_logmel': (I, [P, P, P, I, L, I, I, P, I, P, P, P, P, I, F, P, S]),
+    'ttsmi_cast_f32_to_bf16': (I, [P, P, L, S]),
+}
+
+TTSMI_F32, TTSMI_BF16 = 0, 1
+
+_lib = None
+
+
+class TtsmiError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the bound library.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TtsmiError(f'{LIB_PATH} is missing - run `python -c "import __graft_entry__ as g; '
+                         f'g.build()"` (hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+    l = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise TtsmiError(f'libttsmi.so does not export {name}; rebuild it') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str = '') -> None:
+    if rc != 0:
+        msg = lib().ttsmi_last_error()
+        raise TtsmiError(f'{what or "libttsmi"} failed (code {rc}): '
+                         f'{msg.decode() if msg else "unknown error"}')

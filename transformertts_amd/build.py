@@ -1,0 +1,81 @@
+"""Build libttsmi.so (hipcc, gfx950 only) in-tree: transformertts_amd/lib/libttsmi.so.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU build container; the resulting .so is
+git-ignored but travels to the GPU box with the repo snapshot."""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+OBJDIR = os.path.join(HERE, 'build')
+LIB = os.path.join(LIBDIR, 'libttsmi.so')
+SOURCES = ['api.cpp', 'gemm.hip', 'attention.hip', 'layernorm.hip', 'elementwise.hip', 'lenreg.hip',
+           'stft_mel.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'ttsmi.h')]
+    hipcc = _hipcc()
+    jobs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, src + '.o')
+        stamp = obj + '.sha'
+        dig = _digest([sp] + headers)
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+            continue
+        jobs.append((sp, obj, stamp, dig))
+
+    def compile_one(job):
+        sp, obj, stamp, dig = job
+        cmd = [hipcc] + FLAGS + ['-x', 'hip', '-c', sp, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}')
+        with open(stamp, 'w') as f:
+            f.write(dig)
+        return sp
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for done in ex.map(compile_one, jobs):
+                if verbose:
+                    print(f'[ttsmi build] compiled {os.path.basename(done)}', file=sys.stderr)
+    objs = [os.path.join(OBJDIR, s + '.o') for s in SOURCES]
+    if jobs or force or not os.path.exists(LIB):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+        if verbose:
+            print(f'[ttsmi build] linked {LIB}', file=sys.stderr)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,376 @@
+// Fused [dropout ->] residual add -> LayerNorm [-> + s*PE] [-> dropout] [-> row mask], fwd + bwd.
+// HBM-bound: one wave64 owns one row, the row lives in registers between the statistics and the
+// normalisation (each input element is read exactly once, each output written once), row
+// reductions are wave shuffles, loads/stores are 16 B per lane when C % 4 == 0.
+#include "common.h"
+
+#define LN_WAVES 4   // rows per 256-thread block
+
+template <int VW> struct Vec;
+template <> struct Vec<4> { typedef float4 T; };
+template <> struct Vec<1> { typedef float T; };
+
+template <int VW>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[VW]) {
+    if constexpr (VW == 4) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = *p;
+    }
+}
+template <int VW>
+__device__ __forceinline__ void stv(float* p, const float (&v)[VW]) {
+    if constexpr (VW == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        *p = v[0];
+    }
+}
+
+struct LnP {
+    const float* x; const float* res; const float* gamma; const float* beta;
+    const float* pe; const float* pe_scale; int T;
+    const uint8_t* row_pad;
+    uint32_t thr_in, thr_out, site_in, site_out; float inv_in, inv_out; uint64_t seed; const int64_t* step_dev;
+    float eps;
+    float* y; float* mean; float* rstd;
+    int M, C;
+    // backward
+    const float* dy; const float* mean_in; const float* rstd_in;
+    int relu_in;
+    float* dx; float* dres;
+    float* part_g; float* part_b; float* part_s;   // [nwaves][C], [nwaves][C], [nwaves]
+};
+
+// lane owns chunks c = (lane + 64*j) * VW, j < NPL
+template <int VW, int NPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    p.seed = ttsmi_step_seed(p.seed, p.step_dev);
+    const long base = (long)row * p.C;
+    float z[NPL][VW];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        int c = (lane + 64 * j) * VW;
+        if (c < p.C) {
+            ldv<VW>(p.x + base + c, z[j]);
+            if (p.thr_in) {
+#pragma unroll
+                for (int e = 0; e < VW; ++e)
+                    z[j][e] *= ttsmi_keep_scale(p.seed, p.site_in, base + c + e, p.thr_in, p.inv_in);
+            }
+            if (p.res) {
+                float r[VW];
+                ldv<VW>(p.res + base + c, r);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) z[j][e] += r[e];
+            }
+#pragma unroll
+            for (int e = 0; e < VW; ++e) s += z[j][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) z[j][e] = 0.f;
+        }
+    }
+    const float invC = 1.0f / (float)p.C;
+    const float mean = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        int c = (lane + 64 * j) * VW;
+        if (c < p.C) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) { float d = z[j][e] - mean; q += d * d; }
+        }
+    }
+    const float var = wave_sum(q) * invC;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+    const bool padded = p.row_pad && p.row_pad[row];
+    const float ps = p.pe ? p.pe_scale[0] : 0.f;
+    const long pbase = p.pe ? (long)(row % p.T) * p.C : 0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        int c = (lane + 64 * j) * VW;
+        if (c < p.C) {
+            float g[VW], b[VW], o[VW];
+            ldv<VW>(p.gamma + c, g);
+            ldv<VW>(p.beta + c, b);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) o[e] = (z[j][e] - mean) * rstd * g[e] + b[e];
+            if (p.pe) {
+                float pe[VW];
+                ldv<VW>(p.pe + pbase + c, pe);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) o[e] += ps * pe[e];
+            }
+            if (p.thr_out) {
+#pragma unroll
+                for (int e = 0; e < VW; ++e)
+                    o[e] *= ttsmi_keep_scale(p.seed, p.site_out, base + c + e, p.thr_out, p.inv_out);
+            }
+            if (padded) {
+#pragma unroll
+                for (int e = 0; e < VW; ++e) o[e] = 0.f;
+            }
+            stv<VW>(p.y + base + c, o);
+        }
+    }
+}
+
+template <int VW, int NPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
+    const int lane = threadIdx.x & 63;
+    const int wave_g = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * LN_WAVES;
+    p.seed = ttsmi_step_seed(p.seed, p.step_dev);
+    float ag[NPL][VW], ab[NPL][VW];
+    float as = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; }
+    const float invC = 1.0f / (float)p.C;
+
+    for (int row = wave_g; row < p.M; row += nwaves) {
+        const long base = (long)row * p.C;
+        const bool padded = p.row_pad && p.row_pad[row];
+        const float mean = p.mean_in[row], rstd = p.rstd_in[row];
+        const long pbase = p.pe ? (long)(row % p.T) * p.C : 0;
+        float n[NPL][VW], gn[NPL][VW], keep[NPL][VW];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            int c = (lane + 64 * j) * VW;
+            if (c < p.C) {
+                float xv[VW], g[VW], gam[VW];
+                ldv<VW>(p.x + base + c, xv);
+                ldv<VW>(p.dy + base + c, g);
+                ldv<VW>(p.gamma + c, gam);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    float kin = p.thr_in ? ttsmi_keep_scale(p.seed, p.site_in, base + c + e, p.thr_in, p.inv_in) : 1.f;
+                    // relu'(x) of the producer folded into the x branch
+                    keep[j][e] = (p.relu_in && !(xv[e] > 0.f)) ? 0.f : kin;
+                    xv[e] *= kin;
+                }
+                if (p.res) {
+                    float r[VW];
+                    ldv<VW>(p.res + base + c, r);
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) xv[e] += r[e];
+                }
+                if (padded) {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) g[e] = 0.f;
+                }
+                if (p.thr_out) {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e)
+                        g[e] *= ttsmi_keep_scale(p.seed, p.site_out, base + c + e, p.thr_out, p.inv_out);
+                }
+                if (p.pe) {
+                    float pe[VW];
+                    ldv<VW>(p.pe + pbase + c, pe);
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) as += g[e] * pe[e];
+                }
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    float nn = (xv[e] - mean) * rstd;
+                    n[j][e] = nn;
+                    ab[j][e] += g[e];
+                    ag[j][e] += g[e] * nn;
+                    float t = g[e] * gam[e];
+                    gn[j][e] = t;
+                    s1 += t;
+                    s2 += t * nn;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VW; ++e) { n[j][e] = 0.f; gn[j][e] = 0.f; keep[j][e] = 0.f; }
+            }
+        }
+        s1 = wave_sum(s1) * invC;
+        s2 = wave_sum(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            int c = (lane + 64 * j) * VW;
+            if (c < p.C) {
+                float dz[VW], dxv[VW];
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    dz[e] = rstd * (gn[j][e] - s1 - n[j][e] * s2);
+                    dxv[e] = dz[e] * keep[j][e];
+                }
+                if (p.dres && p.dres != p.dx) stv<VW>(p.dres + base + c, dz);
+                stv<VW>(p.dx + base + c, dxv);
+            }
+        }
+    }
+    // per-wave partials of the parameter gradients
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        int c = (lane + 64 * j) * VW;
+        if (c < p.C) {
+            stv<VW>(p.part_g + (long)wave_g * p.C + c, ag[j]);
+            stv<VW>(p.part_b + (long)wave_g * p.C + c, ab[j]);
+        }
+    }
+    as = wave_sum(as);
+    if (lane == 0) p.part_s[wave_g] = as;
+}
+
+// out[c] = sum_w part[w][c]; block handles 64 columns with 4 row-lanes
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part_g,
+                                                              const float* __restrict__ part_b,
+                                                              const float* __restrict__ part_s,
+                                                              float* dgamma, float* dbeta,
+                                                              float* dscale, int nw, int C) {
+    __shared__ float red[2][4][64];
+    int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    int rl = threadIdx.x >> 6;
+    float sg = 0.f, sb = 0.f;
+    if (c < C) {
+        for (int w = rl; w < nw; w += 4) {
+            sg += part_g[(long)w * C + c];
+            sb += part_b[(long)w * C + c];
+        }
+    }
+    red[0][rl][threadIdx.x & 63] = sg;
+    red[1][rl][threadIdx.x & 63] = sb;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        int t = threadIdx.x;
+        dgamma[c] = red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t];
+        dbeta[c] = red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t];
+    }
+    if (blockIdx.x == 0 && dscale) {
+        __syncthreads();
+        float s = 0.f;
+        for (int w = threadIdx.x; w < nw; w += 256) s += part_s[w];
+        s = wave_sum(s);
+        __shared__ float ws4[4];
+        if ((threadIdx.x & 63) == 0) ws4[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) dscale[0] = ws4[0] + ws4[1] + ws4[2] + ws4[3];
+    }
+}
+
+static int ln_bwd_blocks(int M) {
+    int b = ttsmi_cdiv(M, LN_WAVES);
+    return b > 512 ? 512 : (b < 1 ? 1 : b);
+}
+
+template <int VW, int NPL>
+static void launch_fwd(const LnP& p, hipStream_t st) {
+    hipLaunchKernelGGL((ln_fwd_kernel<VW, NPL>), dim3(ttsmi_cdiv(p.M, LN_WAVES)), dim3(256), 0, st, p);
+}
+template <int VW, int NPL>
+static void launch_bwd(const LnP& p, hipStream_t st) {
+    hipLaunchKernelGGL((ln_bwd_kernel<VW, NPL>), dim3(ln_bwd_blocks(p.M)), dim3(256), 0, st, p);
+}
+
+template <bool FWD>
+static int dispatch(const LnP& p, hipStream_t st) {
+    const int C = p.C;
+    bool vec = (C % 4 == 0) && ((((uintptr_t)p.x) & 15) == 0);
+    if (vec) {
+        int chunks = ttsmi_cdiv(C / 4, 64);
+        if (chunks <= 1) { if (FWD) launch_fwd<4, 1>(p, st); else launch_bwd<4, 1>(p, st); }
+        else if (chunks <= 2) { if (FWD) launch_fwd<4, 2>(p, st); else launch_bwd<4, 2>(p, st); }
+        else if (chunks <= 4) { if (FWD) launch_fwd<4, 4>(p, st); else launch_bwd<4, 4>(p, st); }
+        else if (chunks <= 8) { if (FWD) launch_fwd<4, 8>(p, st); else launch_bwd<4, 8>(p, st); }
+        else return TTSMI_ERR_UNSUPPORTED;
+    } else {
+        int chunks = ttsmi_cdiv(C, 64);
+        if (chunks <= 4) { if (FWD) launch_fwd<1, 4>(p, st); else launch_bwd<1, 4>(p, st); }
+        else if (chunks <= 8) { if (FWD) launch_fwd<1, 8>(p, st); else launch_bwd<1, 8>(p, st); }
+        else if (chunks <= 16) { if (FWD) launch_fwd<1, 16>(p, st); else launch_bwd<1, 16>(p, st); }
+        else if (chunks <= 32) { if (FWD) launch_fwd<1, 32>(p, st); else launch_bwd<1, 32>(p, st); }
+        else return TTSMI_ERR_UNSUPPORTED;
+    }
+    return TTSMI_OK;
+}
+
+static void set_drop(LnP& p, float p_in, uint32_t site_in, float p_out, uint32_t site_out,
+                     uint64_t seed, const int64_t* step_dev) {
+    p.step_dev = step_dev;
+    p.thr_in = p_in > 0.f ? ttsmi_drop_threshold(p_in) : 0;
+    p.thr_out = p_out > 0.f ? ttsmi_drop_threshold(p_out) : 0;
+    p.inv_in = p_in > 0.f ? 1.0f / (1.0f - p_in) : 1.f;
+    p.inv_out = p_out > 0.f ? 1.0f / (1.0f - p_out) : 1.f;
+    p.site_in = site_in; p.site_out = site_out; p.seed = seed;
+}
+
+extern "C" {
+
+int ttsmi_add_layernorm_fwd(const float* x, const float* res, const float* gamma,
+                            const float* beta, const float* pe, const float* pe_scale, int T,
+                            const uint8_t* row_pad, float p_in, uint32_t site_in, float p_out,
+                            uint32_t site_out, uint64_t seed, const int64_t* step_dev, float eps,
+                            float* y, float* mean,
+                            float* rstd, int M, int C, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(x && gamma && beta && y && mean && rstd, "add_layernorm_fwd: null pointer");
+    TTSMI_CHECK_ARG(M >= 0 && C > 0, "add_layernorm_fwd: bad shape M=%d C=%d", M, C);
+    TTSMI_CHECK_ARG(!pe || (pe_scale && T > 0), "add_layernorm_fwd: pe needs pe_scale and T");
+    TTSMI_CHECK_ARG(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f,
+                    "add_layernorm_fwd: dropout rate out of [0,1)");
+    if (M == 0) return TTSMI_OK;
+    LnP p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.res = res; p.gamma = gamma; p.beta = beta; p.pe = pe; p.pe_scale = pe_scale; p.T = T;
+    p.row_pad = row_pad; p.eps = eps; p.y = y; p.mean = mean; p.rstd = rstd; p.M = M; p.C = C;
+    set_drop(p, p_in, site_in, p_out, site_out, seed, step_dev);
+    int rc = dispatch<true>(p, (hipStream_t)stream);
+    if (rc) { ttsmi_set_error("add_layernorm_fwd: C=%d too wide", C); return rc; }
+    TTSMI_CHECK_LAUNCH("add_layernorm_fwd");
+    return TTSMI_OK;
+}
+
+size_t ttsmi_add_layernorm_bwd_ws_bytes(int M, int C) {
+    size_t nw = (size_t)ln_bwd_blocks(M) * LN_WAVES;
+    return (2 * nw * (size_t)C + nw) * sizeof(float) + 256;
+}
+
+int ttsmi_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
+                            const float* mean, const float* rstd, const float* pe,
+                            const float* pe_scale, int T, const uint8_t* row_pad, float p_in,
+                            uint32_t site_in, float p_out, uint32_t site_out, uint64_t seed,
+                            const int64_t* step_dev, int relu_in, float* dx, float* dres, float* dgamma, float* dbeta,
+                            float* dpe_scale, int M, int C, void* ws, size_t ws_bytes,
+                            ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta,
+                    "add_layernorm_bwd: null pointer");
+    TTSMI_CHECK_ARG(M > 0 && C > 0, "add_layernorm_bwd: bad shape");
+    TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_add_layernorm_bwd_ws_bytes(M, C),
+                    "add_layernorm_bwd: workspace too small");
+    TTSMI_CHECK_ARG(!(res && !dres), "add_layernorm_bwd: res given but dres is NULL");
+    TTSMI_CHECK_ARG(!(dres == dx && (p_in > 0.f || relu_in)),
+                    "add_layernorm_bwd: dres may alias dx only when p_in == 0 and !relu_in");
+    LnP p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.res = res; p.gamma = gamma; p.pe = pe; p.pe_scale = pe_scale; p.T = T;
+    p.row_pad = row_pad; p.M = M; p.C = C;
+    p.dy = dy; p.mean_in = mean; p.rstd_in = rstd; p.relu_in = relu_in;
+    p.dx = dx; p.dres = res ? dres : nullptr;
+    set_drop(p, p_in, site_in, p_out, site_out, seed, step_dev);
+    size_t nw = (size_t)ln_bwd_blocks(M) * LN_WAVES;
+    p.part_g = (float*)ws;
+    p.part_b = p.part_g + nw * C;
+    p.part_s = p.part_b + nw * C;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = dispatch<false>(p, st);
+    if (rc) { ttsmi_set_error("add_layernorm_bwd: C=%d too wide", C); return rc; }
+    TTSMI_CHECK_LAUNCH("add_layernorm_bwd");
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ttsmi_cdiv(C, 64)), dim3(256), 0, st, p.part_g,
+                       p.part_b, p.part_s, dgamma, dbeta, pe ? dpe_scale : nullptr, (int)nw, C);
+    TTSMI_CHECK_LAUNCH("ln_param_reduce");
+    return TTSMI_OK;
+}
+
+}  // extern "C"

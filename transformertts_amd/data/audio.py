@@ -1,0 +1,167 @@
+"""Audio - mirror of the mel-extraction path of reference data/audio.py (class Audio :13-92,196-198,
+normalisers :201-242) on the batched HIP STFT->mel kernel (ttsmi_stft_logmel).
+
+`Audio.from_config(cfg).mel_spectrogram(wav)` keeps the reference signature (float32 wav [N] ->
+float32 [frames, mel_channels]); `mel_spectrogram_batch` is the MI355X-shaped entry: many clips in
+one launch, concatenated with offset tables, device-resident in and out.
+
+Host-side constants (built once, in float64 numpy like librosa does [3P], then cast): the periodic
+Hann window centred in n_fft, and the Slaney/area-normalised mel filterbank in its sparse
+per-filter (first bin, count, weights) form.  Everything else of the reference class (wav loading,
+VAD trimming, pyworld pitch, Griffin-Lim, plotting: data/audio.py:94-194) is outside the hot path
+ and intentionally not provided."""
+from __future__ import annotations
+
+import sys
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+# ---- Slaney mel scale (librosa.filters.mel(htk=False, norm=1)) [3P] ------------------------------
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+    lin = f / f_sp
+    with np.errstate(divide='ignore', invalid='ignore'):
+        log = min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep
+    return np.where(f >= min_log_hz, log, lin)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank_sparse(sr, n_fft, n_mels, fmin, fmax):
+    """Returns (lo [n_mels] i32, cnt [n_mels] i32, ptr [n_mels] i32, weights f32): filter m covers
+    FFT bins lo[m] .. lo[m]+cnt[m] with weights[ptr[m] ..]."""
+    fmax = float(sr) / 2 if fmax is None else float(fmax)
+    n_bins = 1 + n_fft // 2
+    fftfreqs = np.linspace(0, float(sr) / 2, n_bins)
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(float(fmin)), _hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    lo, cnt, ptr, ws = [], [], [], []
+    for i in range(n_mels):
+        tri = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+        # float32 triangle scaled by the float64 area norm, rounded once - as numpy's in-place
+        # `weights *= enorm[:, None]` on a float32 array does
+        tri = (tri.astype(np.float32).astype(np.float64) * (2.0 / (mel_f[i + 2] - mel_f[i]))).astype(np.float32)
+        nz = np.nonzero(tri)[0]
+        if len(nz) == 0:
+            lo.append(0); cnt.append(0); ptr.append(len(ws)); continue
+        a, b = int(nz[0]), int(nz[-1]) + 1
+        lo.append(a); cnt.append(b - a); ptr.append(len(ws))
+        ws.extend(tri[a:b].tolist())
+    return (np.asarray(lo, np.int32), np.asarray(cnt, np.int32), np.asarray(ptr, np.int32),
+            np.asarray(ws, np.float32))
+
+
+def hann_window_padded(win_length: int, n_fft: int) -> np.ndarray:
+    """scipy.signal.get_window('hann', win_length, fftbins=True) centred in n_fft [3P]."""
+    n = np.arange(win_length, dtype=np.float64)
+    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)
+    lpad = (n_fft - win_length) // 2
+    return np.pad(w, (lpad, n_fft - win_length - lpad)).astype(np.float32)
+
+
+class Normalizer:
+    def normalize(self, S):
+        raise NotImplementedError
+
+    def denormalize(self, S):
+        raise NotImplementedError
+
+
+class MelGAN(Normalizer):                       # reference data/audio.py:209-219
+    kernel_id = 0
+
+    def __init__(self):
+        self.clip_min = 1.0e-5
+
+    def denormalize(self, S):
+        return torch.exp(S) if torch.is_tensor(S) else np.exp(S)
+
+
+class WaveRNN(Normalizer):                      # reference data/audio.py:222-242
+    kernel_id = 1
+
+    def __init__(self):
+        self.min_level_db = -100
+        self.max_norm = 4
+        self.clip_min = 1.0e-5
+
+    def denormalize(self, S):
+        S = (S + self.max_norm) / (2 * self.max_norm)
+        S = (np.clip(S, 0, 1) * -self.min_level_db) + self.min_level_db
+        return np.power(10.0, S * 0.05)
+
+
+class Audio:
+    def __init__(self, sampling_rate: int, n_fft: int, mel_channels: int, hop_length: int,
+                 win_length: int, f_min: int, f_max: int, normalizer: str, norm_wav: bool = None,
+                 target_dBFS: int = None, int16_max: int = None, trim_long_silences: bool = None,
+                 trim_silence: bool = None, trim_silence_top_db: int = None,
+                 vad_window_length: int = None, vad_sample_rate: int = None,
+                 vad_moving_average_width: int = None, vad_max_silence_length: int = None, **kwargs):
+        self.config = {k: v for k, v in locals().items() if k not in ('self', '__class__', 'kwargs')}
+        self.sampling_rate, self.n_fft, self.mel_channels = sampling_rate, n_fft, mel_channels
+        self.hop_length, self.win_length, self.f_min, self.f_max = hop_length, win_length, f_min, f_max
+        self.normalizer = getattr(sys.modules[__name__], normalizer)()
+        self.device = torch.device(kwargs.get('device', 'cuda:0'))
+        if not torch.cuda.is_available():
+            raise ops._lib.TtsmiError('Audio.mel_spectrogram runs on an MI355X through libttsmi.so; no GPU '
+                                      'is visible and there is no CPU fallback')
+        ops._lib.lib()
+        lo, cnt, ptr, w = mel_filterbank_sparse(sampling_rate, n_fft, mel_channels, f_min, f_max)
+        dev = self.device
+        self._mel = tuple(torch.from_numpy(a).to(dev) for a in (lo, cnt, ptr, w))
+        self._window = torch.from_numpy(hann_window_padded(win_length, n_fft)).to(dev)
+
+    @classmethod
+    def from_config(cls, config: dict):
+        return cls(**config)
+
+    def mel_spectrogram_batch(self, wavs: Sequence, lengths: Sequence[int] = None):
+        """wavs: list of 1-D float32 arrays/tensors, OR one already-concatenated device tensor with
+        `lengths`.  Returns (mel [total_frames, mel_channels] on the device, frame_off int64 [n+1])."""
+        if torch.is_tensor(wavs) and lengths is not None:
+            cat = wavs.to(self.device, torch.float32).contiguous()
+            lengths = [int(x) for x in lengths]
+        else:
+            lengths = [int(len(w)) for w in wavs]
+            cat = torch.cat([torch.as_tensor(np.asarray(w.cpu() if torch.is_tensor(w) else w),
+                                             dtype=torch.float32) for w in wavs]).to(self.device)
+        if min(lengths) <= self.n_fft // 2:
+            raise ValueError(f'clips must be longer than n_fft/2 = {self.n_fft // 2} samples (reflect padding)')
+        clip_off = np.zeros(len(lengths) + 1, dtype=np.int64)
+        clip_off[1:] = np.cumsum(lengths)
+        frames = [1 + n // self.hop_length for n in lengths]          # librosa center=True
+        frame_off = np.zeros(len(lengths) + 1, dtype=np.int64)
+        frame_off[1:] = np.cumsum(frames)
+        lo, cnt, ptr, w = self._mel
+        out = ops.stft_logmel(cat, torch.from_numpy(clip_off).to(self.device),
+                              torch.from_numpy(frame_off).to(self.device), int(frame_off[-1]), self.n_fft,
+                              self.hop_length, self._window, self.mel_channels, lo, cnt, ptr, w,
+                              self.normalizer.kernel_id, float(self.normalizer.clip_min))
+        return out, frame_off
+
+    def mel_spectrogram(self, wav):
+        """Reference Audio.mel_spectrogram (data/audio.py:88-92): wav [N] -> [frames, mel_channels].
+        numpy in -> numpy out; CUDA tensor in -> CUDA tensor out."""
+        is_t = torch.is_tensor(wav)
+        mel, _ = self.mel_spectrogram_batch([wav])
+        return mel if is_t else mel.cpu().numpy()
+
+    def _normalize(self, S):
+        raise NotImplementedError('normalisation is fused into the STFT->mel kernel')
+
+    def _denormalize(self, S):
+        return self.normalizer.denormalize(S)

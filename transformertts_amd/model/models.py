@@ -1,0 +1,567 @@
+"""ForwardTransformer - MI355X-native mirror of reference model/models.py:344-642.
+
+Same constructor keywords, same methods (from_config, train_step, val_step, call/__call__, predict,
+set_constants, step, _compile, save_model, load_model) and the same model_out dictionary keys as
+the reference, so train_tts.py / predict_tts.py call sites keep working.  Underneath there is no
+TensorFlow graph: every layer is a fused HIP kernel of libttsmi.so driven through torch autograd
+Functions (transformertts_amd/ops.py); parameters, gradients and Adam state live in three flat fp32
+buffers (one fused TF-form Adam launch, one RCCL all-reduce per step when data-parallel).
+
+Differences a caller can observe (all documented in INTEGRATION.md):
+  * tensors are torch CUDA tensors instead of tf.Tensors;
+  * the 12 attention maps [B,H,T,T] the reference returns from every call are only materialised
+    when ``model.return_attention`` is True (default: True for val_step/predict/call, False for
+    train_step) - writing them is 5 GB of HBM traffic per step at the LJSpeech batch shape;
+  * the decoder padding mask is derived from the summed durations instead of the content test
+    ``sum|x| == 0`` (transformer_utils.py:29-32); identical unless an expanded row is exactly zero.
+"""
+from __future__ import annotations
+
+import math
+import os
+import subprocess
+from collections import OrderedDict
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import yaml
+
+from .. import ops
+from ..data.text import TextToTokens
+from ..utils.losses import masked_mean_absolute_error, weighted_sum_losses
+from .transformer_utils import positional_encoding
+
+
+def _blocks_spec(prefix, d, heads, dense_blocks, ffn, conv_filters, conv_kernel):
+    s = OrderedDict()
+    s[f'{prefix}.ln.gamma'] = (d,)
+    s[f'{prefix}.ln.beta'] = (d,)
+    s[f'{prefix}.pos_scalar'] = ()
+    for i, _ in enumerate(heads):
+        p = f'{prefix}.blk{i}'
+        s[f'{p}.wqkv'] = (d, 3 * d)          # Wq | Wk | Wv fused (layers.py:116-118)
+        s[f'{p}.bqkv'] = (3 * d,)
+        s[f'{p}.wo'] = (2 * d, d)            # Dense(concat([q_in, ctx])) (layers.py:148-149)
+        s[f'{p}.bo'] = (d,)
+        s[f'{p}.ln1.gamma'] = (d,)
+        s[f'{p}.ln1.beta'] = (d,)
+        if i < dense_blocks:
+            s[f'{p}.ffn.w1'] = (d, ffn)
+            s[f'{p}.ffn.b1'] = (ffn,)
+            s[f'{p}.ffn.w2'] = (ffn, d)
+            s[f'{p}.ffn.b2'] = (d,)
+        else:
+            cin = d
+            for j, f in enumerate(conv_filters):
+                s[f'{p}.conv{j}.w'] = (conv_kernel, cin, f)
+                s[f'{p}.conv{j}.b'] = (f,)
+                cin = f
+        s[f'{p}.ln2.gamma'] = (d,)
+        s[f'{p}.ln2.beta'] = (d,)
+    return s
+
+
+def _predictor_spec(prefix, d, filters, k):
+    s = OrderedDict()
+    cin = d
+    for j, f in enumerate(filters):
+        s[f'{prefix}.conv{j}.w'] = (k, cin, f)
+        s[f'{prefix}.conv{j}.b'] = (f,)
+        s[f'{prefix}.ln{j}.gamma'] = (f,)
+        s[f'{prefix}.ln{j}.beta'] = (f,)
+        cin = f
+    s[f'{prefix}.lin.w'] = (cin, 1)
+    s[f'{prefix}.lin.b'] = (1,)
+    return s
+
+
+class FlatParams:
+    """All trainable variables as views of ONE flat fp32 buffer (+ matching gradient / Adam m / v
+    buffers).  Every tensor starts on a 16-byte boundary so the float4 kernel paths apply."""
+
+    ALIGN = 4
+
+    def __init__(self, spec: "OrderedDict[str, tuple]", device):
+        self.spec = spec
+        self.offsets = OrderedDict()
+        off = 0
+        for name, shape in spec.items():
+            n = int(np.prod(shape)) if len(shape) else 1
+            self.offsets[name] = (off, n)
+            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.m = torch.zeros(off, dtype=torch.float32, device=device)
+        self.v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.w: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        for name, shape in spec.items():
+            o, n = self.offsets[name]
+            self.w[name] = self.data[o:o + n].view(shape).requires_grad_()
+            self.g[name] = self.grad[o:o + n].view(shape)
+
+    @property
+    def n_params(self) -> int:
+        return sum(n for _, n in self.offsets.values())
+
+
+class ForwardTransformer:
+    def __init__(self,
+                 encoder_model_dimension: int,
+                 decoder_model_dimension: int,
+                 dropout_rate: float,
+                 decoder_num_heads: list,
+                 encoder_num_heads: list,
+                 encoder_max_position_encoding: int,
+                 decoder_max_position_encoding: int,
+                 encoder_dense_blocks: int,
+                 decoder_dense_blocks: int,
+                 duration_conv_filters: list,
+                 pitch_conv_filters: list,
+                 duration_kernel_size: int,
+                 pitch_kernel_size: int,
+                 predictors_dropout: float,
+                 mel_channels: int,
+                 phoneme_language: str,
+                 with_stress: bool,
+                 model_breathing: bool,
+                 transposed_attn_convs: bool,
+                 encoder_attention_conv_filters: list = None,
+                 decoder_attention_conv_filters: list = None,
+                 encoder_attention_conv_kernel: int = None,
+                 decoder_attention_conv_kernel: int = None,
+                 encoder_feed_forward_dimension: int = None,
+                 decoder_feed_forward_dimension: int = None,
+                 debug=False,
+                 **kwargs):
+        # reference model/models.py:345-440.  Unknown keys are tolerated and echoed in self.config.
+        self.config = self._make_config(locals(), kwargs)
+        self.device = torch.device(kwargs.get('device', 'cuda:0'))
+        if self.device.type != 'cuda' or not torch.cuda.is_available():
+            raise ops._lib.TtsmiError('ForwardTransformer runs on an MI355X through libttsmi.so; no GPU is '
+                                      'visible and there is no CPU fallback')
+        ops._lib.lib()                       # fail loudly now if the HIP library is missing
+        self.text_pipeline = TextToTokens.default(phoneme_language, add_start_end=False,
+                                                  with_stress=with_stress, model_breathing=model_breathing)
+        self.symbols = self.text_pipeline.tokenizer.alphabet
+        self.mel_channels = mel_channels
+        self.vocab_size = self.text_pipeline.tokenizer.vocab_size
+        c = self.config
+        de, dd = encoder_model_dimension, decoder_model_dimension
+        assert de == dd, 'Expand feeds the encoder width straight into the decoder (models.py:402,411)'
+        spec = OrderedDict()
+        spec['embedding'] = (self.vocab_size, de)
+        spec.update(_blocks_spec('enc', de, encoder_num_heads, encoder_dense_blocks,
+                                 encoder_feed_forward_dimension, encoder_attention_conv_filters,
+                                 encoder_attention_conv_kernel))
+        spec.update(_predictor_spec('dur', de, duration_conv_filters, duration_kernel_size))
+        spec.update(_predictor_spec('pitch', de, pitch_conv_filters, pitch_kernel_size))
+        spec['pitch_embed.w'] = (1, de)
+        spec['pitch_embed.b'] = (de,)
+        spec.update(_blocks_spec('dec', dd, decoder_num_heads, decoder_dense_blocks,
+                                 decoder_feed_forward_dimension, decoder_attention_conv_filters,
+                                 decoder_attention_conv_kernel))
+        spec['out.w'] = (dd, mel_channels)
+        spec['out.b'] = (mel_channels,)
+        self.params = FlatParams(spec, self.device)
+        self.pe_enc = torch.from_numpy(positional_encoding(encoder_max_position_encoding, de)).to(self.device)
+        self.pe_dec = torch.from_numpy(positional_encoding(decoder_max_position_encoding, dd)).to(self.device)
+        # optimiser state (reference: tf.keras Adam attached by _compile)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)     # optimizer.iterations
+        self.lr_dev = torch.full((1,), 1e-4, dtype=torch.float32, device=self.device)
+        self._host_step = 0
+        self.beta_1, self.beta_2, self.epsilon = 0.9, 0.98, 1e-9
+        self.loss_weights = [1., 1., 3.]
+        self.loss = [masked_mean_absolute_error] * 3
+        self.drop = ops.DropCtx(seed=int(kwargs.get('seed', 0)), step_dev=self.step_dev)
+        self.return_attention = None         # None = per-method default (see module docstring)
+        self.grad_sync = None                # set by transformertts_amd.dp.DataParallel
+        self.debug = debug
+        self._init_weights(int(kwargs.get('seed', 0)))
+
+    # ------------------------------------------------------------------ construction helpers
+    def _make_config(self, locals_: dict, kwargs: dict) -> dict:
+        config = {}
+        for k, v in locals_.items():
+            if k in kwargs or k in ('self', '__class__', 'kwargs'):
+                continue
+            if isinstance(v, dict):
+                config.update(v)
+            else:
+                config[k] = v
+        config.update(kwargs)
+        return config
+
+    def _init_weights(self, seed: int):
+        """Keras defaults [3P]: glorot_uniform Dense/Conv kernels (per original matrix: wq, wk, wv
+        each [d,d]), zero biases, Embedding U(-0.05, 0.05), LN gamma=1 beta=0, pos scalar 1."""
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        with torch.no_grad():
+            for name, w in self.params.w.items():
+                leaf = name.split('.')[-1]
+                shape = tuple(w.shape)
+                if name == 'embedding':
+                    a = torch.rand(shape, generator=g) * 0.1 - 0.05
+                elif leaf in ('gamma', 'pos_scalar'):
+                    a = torch.ones(shape)
+                elif leaf == 'beta' or (leaf.startswith('b') and len(shape) == 1):
+                    a = torch.zeros(shape)
+                elif leaf == 'wqkv':
+                    d = shape[0]
+                    lim = math.sqrt(6.0 / (2 * d))
+                    a = (torch.rand(shape, generator=g) * 2 - 1) * lim
+                elif len(shape) == 2:
+                    lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+                    a = (torch.rand(shape, generator=g) * 2 - 1) * lim
+                elif len(shape) == 3:
+                    k, cin, cout = shape
+                    lim = math.sqrt(6.0 / (k * cin + k * cout))
+                    a = (torch.rand(shape, generator=g) * 2 - 1) * lim
+                else:
+                    raise ValueError(name)
+                w.copy_(a.to(self.device))
+
+    # ------------------------------------------------------------------ weights interchange
+    def load_weights_dict(self, weights: Dict[str, np.ndarray]):
+        """Load reference-named variables (separate wq/wk/wv, see oracle/ft_oracle.py:weight_spec -
+        the Keras variable layout: Dense [in,out], Conv1D [k,in,out])."""
+        with torch.no_grad():
+            for name, w in self.params.w.items():
+                leaf = name.split('.')[-1]
+                if leaf == 'wqkv':
+                    base = name[:-len('wqkv')]
+                    a = np.concatenate([weights[base + 'wq'], weights[base + 'wk'], weights[base + 'wv']], 1)
+                elif leaf == 'bqkv':
+                    base = name[:-len('bqkv')]
+                    a = np.concatenate([weights[base + 'bq'], weights[base + 'bk'], weights[base + 'bv']], 0)
+                else:
+                    a = weights[name]
+                w.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)).reshape(w.shape).to(self.device))
+
+    def weights_dict(self) -> "OrderedDict[str, np.ndarray]":
+        out = OrderedDict()
+        for name, w in self.params.w.items():
+            a = w.detach().cpu().numpy().copy()
+            leaf = name.split('.')[-1]
+            if leaf == 'wqkv':
+                base, d = name[:-len('wqkv')], a.shape[0]
+                out[base + 'wq'], out[base + 'wk'], out[base + 'wv'] = a[:, :d], a[:, d:2 * d], a[:, 2 * d:]
+            elif leaf == 'bqkv':
+                base, d = name[:-len('bqkv')], a.shape[0] // 3
+                out[base + 'bq'], out[base + 'bk'], out[base + 'bv'] = a[:d], a[d:2 * d], a[2 * d:]
+            else:
+                out[name] = a
+        return out
+
+    def grads_dict(self) -> "OrderedDict[str, np.ndarray]":
+        out = OrderedDict()
+        for name, g in self.params.g.items():
+            a = g.detach().cpu().numpy().copy()
+            leaf = name.split('.')[-1]
+            if leaf == 'wqkv':
+                base, d = name[:-len('wqkv')], a.shape[0]
+                out[base + 'wq'], out[base + 'wk'], out[base + 'wv'] = a[:, :d], a[:, d:2 * d], a[:, 2 * d:]
+            elif leaf == 'bqkv':
+                base, d = name[:-len('bqkv')], a.shape[0] // 3
+                out[base + 'bq'], out[base + 'bk'], out[base + 'bv'] = a[:d], a[d:2 * d], a[2 * d:]
+            else:
+                out[name] = a
+        return out
+
+    # ------------------------------------------------------------------ layers (reference model/layers.py)
+    def _self_attention_blocks(self, prefix, name, x, pad, klen, heads, dense_blocks, pe, rate,
+                               want_attn):
+        """SelfAttentionBlocks.call (layers.py:297-310) on fused kernels.  x [B,T,d]."""
+        W, G, drop = self.params.w, self.params.g, self.drop
+        B, T, d = x.shape
+        M = B * T
+        h = ops.add_layernorm(x.reshape(M, d), None, W[f'{prefix}.ln.gamma'], W[f'{prefix}.ln.beta'],
+                              G[f'{prefix}.ln.gamma'], G[f'{prefix}.ln.beta'], pe=pe,
+                              pe_scale=W[f'{prefix}.pos_scalar'], gpe_scale=G[f'{prefix}.pos_scalar'], T=T,
+                              p_out=rate, site_out=drop.site(), drop=drop)
+        attn = OrderedDict()
+        for i, H in enumerate(heads):
+            p = f'{prefix}.blk{i}'
+            dense = i < dense_blocks
+            qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'])
+            site = drop.site()
+            ctx, lse = ops.AttentionFn.apply(qkv, pad, klen, B, H, T, d // H, rate, drop, site)
+            if want_attn:
+                key = (f'{name}_DenseBlock{i + 1}_SelfAttention' if dense
+                       else f'{name}_ConvBlock{i - dense_blocks + 1}_SelfAttention')
+                attn[key] = ops.attention_weights(qkv.detach(), pad, lse, B, H, T, d // H, rate, drop, site)
+            o = ops.LinearFn.apply(h, ctx, W[f'{p}.wo'], W[f'{p}.bo'], G[f'{p}.wo'], G[f'{p}.bo'])
+            a = ops.add_layernorm(o, h, W[f'{p}.ln1.gamma'], W[f'{p}.ln1.beta'], G[f'{p}.ln1.gamma'],
+                                  G[f'{p}.ln1.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop)
+            if dense:
+                f = ops.FFNFn.apply(a, W[f'{p}.ffn.w1'], W[f'{p}.ffn.b1'], W[f'{p}.ffn.w2'], W[f'{p}.ffn.b2'],
+                                    G[f'{p}.ffn.w1'], G[f'{p}.ffn.b1'], G[f'{p}.ffn.w2'], G[f'{p}.ffn.b2'])
+            else:
+                n = 0
+                while f'{p}.conv{n}.w' in W:
+                    n += 1
+                ps, gs = [], []
+                for j in range(n):
+                    ps += [W[f'{p}.conv{j}.w'], W[f'{p}.conv{j}.b']]
+                    gs += [G[f'{p}.conv{j}.w'], G[f'{p}.conv{j}.b']]
+                f = ops.ConvStackFn.apply(a.reshape(B, T, d), n, *ps, *gs).reshape(M, d)
+            h = ops.add_layernorm(f, a, W[f'{p}.ln2.gamma'], W[f'{p}.ln2.beta'], G[f'{p}.ln2.gamma'],
+                                  G[f'{p}.ln2.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop)
+        return h.reshape(B, T, d), attn
+
+    def _stat_predictor(self, prefix, x, pad, n_layers, relu_head, rate):
+        """StatPredictor.call + CNNDropout.call (layers.py:481-485,510-524).  x [B,T,d]."""
+        W, G, drop = self.params.w, self.params.g, self.drop
+        B, T, _ = x.shape
+        h = ops.RowMaskFn.apply(x, pad)
+        for j in range(n_layers):
+            h = ops.ConvReluPreMaskedFn.apply(h, W[f'{prefix}.conv{j}.w'], W[f'{prefix}.conv{j}.b'],
+                                              G[f'{prefix}.conv{j}.w'], G[f'{prefix}.conv{j}.b'])
+            C = h.shape[-1]
+            h = ops.add_layernorm(h.reshape(B * T, C), None, W[f'{prefix}.ln{j}.gamma'],
+                                  W[f'{prefix}.ln{j}.beta'], G[f'{prefix}.ln{j}.gamma'],
+                                  G[f'{prefix}.ln{j}.beta'], p_out=rate, site_out=drop.site(), drop=drop,
+                                  relu_in=True).reshape(B, T, C)
+        return ops.RowDotFn.apply(h, W[f'{prefix}.lin.w'], W[f'{prefix}.lin.b'], G[f'{prefix}.lin.w'],
+                                  G[f'{prefix}.lin.b'], pad, relu_head)
+
+    # ------------------------------------------------------------------ reference model/models.py:518-550
+    def call(self, x, target_durations=None, target_pitch=None, training=False, durations_scalar=1.,
+             max_durations_mask=None, min_durations_mask=None, mel_len: Optional[int] = None,
+             return_attention: Optional[bool] = None):
+        c, W, G = self.config, self.params.w, self.params.g
+        want_attn = (not training) if return_attention is None else return_attention
+        rate = c['dropout_rate'] if training else 0.0
+        prate = c['predictors_dropout'] if training else 0.0
+        self.drop.reset()
+        x = torch.as_tensor(x, device=self.device).to(torch.int32).contiguous()
+        B, Tp = x.shape
+        pad_e, klen_e = ops.token_pad_mask(x)                                        # :521
+        h = ops.EmbeddingFn.apply(x, W['embedding'], G['embedding'])                 # :522
+        h, enc_attn = self._self_attention_blocks('enc', 'Encoder', h, pad_e, klen_e,
+                                                  c['encoder_num_heads'], c['encoder_dense_blocks'],
+                                                  self.pe_enc, rate, want_attn)      # :523
+        durations = self._stat_predictor('dur', h, pad_e, len(c['duration_conv_filters']), True, prate)
+        pitch = self._stat_predictor('pitch', h, pad_e, len(c['pitch_conv_filters']), False, prate)
+        if target_pitch is not None:                                                 # :527-530
+            p_in = torch.as_tensor(target_pitch, device=self.device).to(torch.float32).reshape(B * Tp)
+        else:
+            p_in = pitch.reshape(B * Tp)
+        h = ops.PitchEmbedFn.apply(h, p_in, W['pitch_embed.w'].reshape(-1), W['pitch_embed.b'],
+                                   G['pitch_embed.w'].reshape(-1), G['pitch_embed.b'])   # :531
+        if target_durations is not None:                                             # :532-535
+            use = torch.as_tensor(target_durations, device=self.device).reshape(B, Tp)
+            if use.dtype not in (torch.int32, torch.float32):
+                use = use.to(torch.int32 if not use.dtype.is_floating_point else torch.float32)
+        else:
+            use = (durations.detach() * float(durations_scalar)).reshape(B, Tp)
+        if max_durations_mask is not None:                                           # :536-537
+            use = torch.minimum(use.to(torch.float32),
+                                torch.as_tensor(max_durations_mask, device=self.device).to(torch.float32))
+        if min_durations_mask is not None:                                           # :538-539
+            use = torch.maximum(use.to(torch.float32),
+                                torch.as_tensor(min_durations_mask, device=self.device).to(torch.float32))
+        if mel_len is None:
+            # inference: the output length max_b sum(round(dur)) is data dependent (one host sync,
+            # like the reference's eager call)
+            _, _, ln = ops.lenreg_index(use, 1)
+            mel_len = max(int(ln.max().item()), 1)
+        idx, cum, lens = ops.lenreg_index(use, mel_len)                              # :540 Expand
+        mels = ops.LenRegFn.apply(h, idx, cum)
+        pad_d, klen_d = ops.length_pad_mask(lens, mel_len)                           # :541
+        expanded_mask = pad_d.to(torch.float32)[:, None, None, :]
+        mels, dec_attn = self._self_attention_blocks('dec', 'Decoder', mels, pad_d, klen_d,
+                                                     c['decoder_num_heads'], c['decoder_dense_blocks'],
+                                                     self.pe_dec, rate, want_attn)   # :542
+        out = ops.LinearFn.apply(mels.reshape(B * mel_len, -1), None, W['out.w'], W['out.b'], G['out.w'],
+                                 G['out.b']).reshape(B, mel_len, self.mel_channels)  # :543
+        return {'mel': out, 'duration': durations, 'pitch': pitch, 'expanded_mask': expanded_mask,
+                'encoder_attention': enc_attn, 'decoder_attention': dec_attn,
+                'expanded_lengths': lens}
+
+    __call__ = call
+
+    # ------------------------------------------------------------------ steps (models.py:464-507)
+    def _losses(self, model_out, target_sequence, target_durations, target_pitch):
+        return weighted_sum_losses((target_sequence, target_durations, target_pitch),
+                                   (model_out['mel'], model_out['duration'], model_out['pitch']),
+                                   self.loss, self.loss_weights)
+
+    def _prep(self, input_sequence, target_sequence, target_durations, target_pitch):
+        dev = self.device
+        x = torch.as_tensor(input_sequence, device=dev).to(torch.int32)
+        ts = torch.as_tensor(target_sequence, device=dev).to(torch.float32).contiguous()
+        td = torch.as_tensor(target_durations, device=dev).to(torch.int32)[..., None].contiguous()   # :465
+        tp = torch.as_tensor(target_pitch, device=dev).to(torch.float32)[..., None].contiguous()     # :466
+        return x, ts, td, tp
+
+    def _train_step(self, input_sequence, target_sequence, target_durations, target_pitch):
+        """reference _train_step models.py:464-482: forward(training=True), weighted L1 losses,
+        backward, one TF-form Adam step.  Requires sum_b(dur) <= mel_len (the reference data has
+        sum(dur_b) == mel_len_b; frames past mel_len would be sliced away at models.py:473)."""
+        x, ts, td, tp = self._prep(input_sequence, target_sequence, target_durations, target_pitch)
+        mel_len = int(ts.shape[1])                                                   # :467
+        ra = False if self.return_attention is None else self.return_attention
+        model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra)
+        loss, loss_vals = self._losses(model_out, ts, td, tp)
+        loss.backward()                                                              # :480
+        if self.grad_sync is not None:
+            self.grad_sync(self.params.grad)          # the single RCCL all-reduce of the step
+        self._apply_gradients()                                                      # :481
+        model_out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in model_out.items()}
+        model_out.update({'loss': loss.detach()})
+        model_out.update({'losses': {'mel': loss_vals[0].detach(), 'duration': loss_vals[1].detach(),
+                                     'pitch': loss_vals[2].detach()}})
+        return model_out
+
+    def _val_step(self, input_sequence, target_sequence, target_durations, target_pitch):
+        x, ts, td, tp = self._prep(input_sequence, target_sequence, target_durations, target_pitch)
+        mel_len = int(ts.shape[1])
+        ra = True if self.return_attention is None else self.return_attention
+        with torch.no_grad():
+            model_out = self.call(x, td, target_pitch=tp, training=False, mel_len=mel_len, return_attention=ra)
+            loss, loss_vals = self._losses(model_out, ts, td, tp)
+        model_out.update({'loss': loss})
+        model_out.update({'losses': {'mel': loss_vals[0], 'duration': loss_vals[1], 'pitch': loss_vals[2]}})
+        return model_out
+
+    train_step = _train_step
+    val_step = _val_step
+
+    def _apply_gradients(self):
+        """tf.keras Adam(lr, 0.9, 0.98, 1e-9) (utils/training_config_manager.py:102-106) as one fused
+        launch over the flat buffers; iteration counter and lr live on the device."""
+        ops.step_increment(self.step_dev)
+        self._host_step += 1
+        P = self.params
+        ops.adam_tf(P.data, P.grad, P.m, P.v, self.lr_dev, self.step_dev, self.beta_1, self.beta_2,
+                    self.epsilon)
+
+    def _compile(self, optimizer=None, learning_rate: Optional[float] = None):
+        """reference _compile models.py:484-490.  `optimizer` may be any object with
+        learning_rate/lr, beta_1, beta_2, epsilon attributes (e.g. the Adam config the reference
+        builds in training_config_manager.py:102-106); only TF-form Adam is implemented."""
+        self.loss_weights = [1., 1., 3.]
+        if optimizer is not None:
+            for src, dst in (('beta_1', 'beta_1'), ('beta_2', 'beta_2'), ('epsilon', 'epsilon')):
+                if hasattr(optimizer, src):
+                    setattr(self, dst, float(getattr(optimizer, src)))
+            lr = getattr(optimizer, 'learning_rate', getattr(optimizer, 'lr', None))
+            if lr is not None:
+                learning_rate = float(lr)
+        if learning_rate is not None:
+            self.set_constants(learning_rate=learning_rate)
+
+    @property
+    def step(self) -> int:                                                           # :514-516
+        return self._host_step
+
+    def set_constants(self, learning_rate: float = None, **kwargs):                  # :552-554
+        if learning_rate is not None:
+            self.lr_dev.fill_(float(learning_rate))
+
+    def _forward(self, input_sequence, durations_scalar):                            # :509-512
+        with torch.no_grad():
+            return self.call(input_sequence, target_durations=None, target_pitch=None, training=False,
+                             durations_scalar=durations_scalar)
+
+    forward = _forward
+
+    # ------------------------------------------------------------------ inference (models.py:556-595)
+    def encode_text(self, text):
+        return self.text_pipeline(text)
+
+    def predict(self, inp, encode=True, speed_regulator=1., phoneme_max_duration=None,
+                phoneme_min_duration=None, max_durations_mask=None, min_durations_mask=None,
+                phoneme_durations=None, phoneme_pitch=None):
+        if encode:
+            inp = self.encode_text(inp)
+        inp = torch.as_tensor(np.asarray(inp.cpu() if torch.is_tensor(inp) else inp), device=self.device)
+        if inp.dim() < 2:
+            inp = inp[None]
+        inp = inp.to(torch.int32)
+        duration_scalar = float(1. / speed_regulator)
+        max_durations_mask = self._make_max_duration_mask(inp, phoneme_max_duration)
+        min_durations_mask = self._make_min_duration_mask(inp, phoneme_min_duration)
+        ra = True if self.return_attention is None else self.return_attention
+        with torch.no_grad():
+            out = self.call(inp, target_durations=phoneme_durations, target_pitch=phoneme_pitch,
+                            training=False, durations_scalar=duration_scalar,
+                            max_durations_mask=max_durations_mask, min_durations_mask=min_durations_mask,
+                            return_attention=ra)
+        out['mel'] = out['mel'].squeeze()                                            # :576
+        return out
+
+    def _make_max_duration_mask(self, encoded_text, phoneme_max_duration):           # :579-586
+        np_text = encoded_text.cpu().numpy()
+        new_mask = np.ones(np_text.shape) * float('inf')
+        if phoneme_max_duration is not None:
+            for sym, val in phoneme_max_duration.items():
+                new_mask[np_text == self.text_pipeline.tokenizer(sym)[0]] = val
+        return torch.from_numpy(new_mask.astype(np.float32)).to(self.device)
+
+    def _make_min_duration_mask(self, encoded_text, phoneme_min_duration):           # :588-595
+        np_text = encoded_text.cpu().numpy()
+        new_mask = np.zeros(np_text.shape)
+        if phoneme_min_duration is not None:
+            for sym, val in phoneme_min_duration.items():
+                new_mask[np_text == self.text_pipeline.tokenizer(sym)[0]] = val
+        return torch.from_numpy(new_mask.astype(np.float32)).to(self.device)
+
+    def build_model_weights(self) -> None:                                           # :597-598
+        pass    # variables exist from construction; kept for call-site compatibility
+
+    # ------------------------------------------------------------------ persistence (models.py:600-642)
+    def save_model(self, path: str):
+        """config.yaml + weights.  The reference writes Keras HDF5 (`model_weights.hdf5`); h5py is
+        not available offline, so the variables are written as `model_weights.npz` under the
+        reference's variable layout (SURVEY.md section 8f.2 - HDF5 interchange is a 'next' row)."""
+        path = Path(path)
+        path.mkdir(parents=True, exist_ok=True)
+        cfg = {k: v for k, v in self.config.items() if k != 'device'}
+        cfg.update({'alphabet': ''.join(self.symbols), 'step': self.step})
+        try:
+            cfg['git_hash'] = subprocess.check_output(['git', 'describe', '--always'],
+                                                      stderr=subprocess.DEVNULL).strip().decode()
+        except Exception:
+            pass
+        with open(path / 'config.yaml', 'w') as f:
+            yaml.safe_dump(cfg, f)
+        np.savez(path / 'model_weights.npz', **self.weights_dict())
+        torch.save({'m': self.params.m.cpu(), 'v': self.params.v.cpu(), 'step': self.step,
+                    'lr': float(self.lr_dev.item())}, path / 'optimizer.pt')
+
+    @classmethod
+    def load_model(cls, path, **kwargs):
+        path = Path(path)
+        with open(path / 'config.yaml', 'r') as f:
+            config = yaml.safe_load(f)
+        for k in ('alphabet', 'step', 'git_hash'):
+            config.pop(k, None)
+        config.update(kwargs)
+        model = cls.from_config(config)
+        model.load_weights(path / 'model_weights.npz')
+        opt = path / 'optimizer.pt'
+        if opt.exists():
+            st = torch.load(opt)
+            model.params.m.copy_(st['m'])
+            model.params.v.copy_(st['v'])
+            model._host_step = int(st['step'])
+            model.step_dev.fill_(int(st['step']))
+            model.lr_dev.fill_(float(st['lr']))
+        return model
+
+    def load_weights(self, path):
+        path = str(path)
+        if path.endswith('.hdf5') or path.endswith('.h5'):
+            raise NotImplementedError('Keras HDF5 import needs h5py (absent offline); convert the checkpoint '
+                                      'to .npz with the reference variable names (SURVEY.md 8f.2)')
+        with np.load(path) as z:
+            self.load_weights_dict({k: z[k] for k in z.files})
+
+    @classmethod
+    def from_config(cls, config: dict, custom_objects=None):                         # :640-642
+        return cls(**config)

@@ -1,0 +1,567 @@
+"""Host-side plumbing over the C ABI: torch tensors in, device pointers + the current HIP stream
+out.  PyTorch is used for device memory, streams and autograd bookkeeping only - every FLOP below
+runs in libttsmi.so (hand-written HIP for gfx950).  Nothing here has a CPU or eager-torch fallback.
+
+Each ``torch.autograd.Function`` is one fused layer of the reference graph (model/layers.py); its
+backward calls the matching dgrad/wgrad/bwd entry points.  Parameter gradients can be written
+STRAIGHT into a caller-provided gradient buffer (``g*`` arguments, views of the flat gradient
+buffer that the single RCCL all-reduce and the fused Adam consume); the Function then returns None
+for that parameter."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import TTSMI_F32, check
+
+LN_EPS = 1e-6
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _need_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise _lib.TtsmiError('libttsmi ops need CUDA(HIP) tensors; there is no CPU fallback')
+
+
+class DropCtx:
+    """Dropout stream of one model: host seed + device step counter (graph-replay safe) and a
+    running site id so every dropout site of the graph draws from its own stream."""
+
+    def __init__(self, seed: int = 0, step_dev: Optional[torch.Tensor] = None):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.step_dev = step_dev
+        self._site = 0
+
+    def reset(self):
+        self._site = 0
+
+    def site(self) -> int:
+        self._site += 1
+        return self._site
+
+
+# =================================================================================================
+# raw calls
+# =================================================================================================
+def linear_fwd(x, w, b, relu=False, x2=None, out=None, dtype=TTSMI_F32):
+    _need_gpu(x)
+    M, K1 = x.shape
+    K, N = w.shape
+    if x2 is not None:
+        assert x2.shape[0] == M and K1 + x2.shape[1] == K
+    else:
+        assert K1 == K, (x.shape, w.shape)
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(_lib.lib().ttsmi_linear_fwd(_p(x), x.stride(0), _p(x2), 0 if x2 is None else x2.stride(0),
+                                      K1 if x2 is not None else 0, _p(w), w.stride(0), _p(b), _p(y),
+                                      y.stride(0), M, N, K, int(relu), dtype, _stream()), 'linear_fwd')
+    return y
+
+
+def linear_dgrad(dy, w, relu_src=None, out=None, dtype=TTSMI_F32):
+    M, N = dy.shape
+    K = w.shape[0]
+    dx = out if out is not None else torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().ttsmi_linear_dgrad(_p(dy), dy.stride(0), _p(w), w.stride(0), _p(relu_src),
+                                        0 if relu_src is None else relu_src.stride(0), _p(dx),
+                                        dx.stride(0), M, N, K, dtype, _stream()), 'linear_dgrad')
+    return dx
+
+
+def linear_wgrad(x, dy, dw, db, dtype=TTSMI_F32):
+    M, K = x.shape
+    N = dy.shape[1]
+    l = _lib.lib()
+    ws = _ws(l.ttsmi_linear_wgrad_ws_bytes(M, N, K), x.device)
+    check(l.ttsmi_linear_wgrad(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(dw), dw.stride(0), _p(db),
+                               M, N, K, _p(ws), ws.numel(), dtype, _stream()), 'linear_wgrad')
+
+
+def conv1d_fwd(x, w, b, relu=False, dtype=TTSMI_F32):
+    B, T, Cin = x.shape
+    k, _, Cout = w.shape
+    y = torch.empty((B, T, Cout), dtype=torch.float32, device=x.device)
+    check(_lib.lib().ttsmi_conv1d_fwd(_p(x), _p(w), _p(b), _p(y), B, T, Cin, Cout, k, int(relu), dtype,
+                                      _stream()), 'conv1d_fwd')
+    return y
+
+
+def conv1d_dgrad(dy, w, relu_src=None, dtype=TTSMI_F32):
+    B, T, Cout = dy.shape
+    k, Cin, _ = w.shape
+    dx = torch.empty((B, T, Cin), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().ttsmi_conv1d_dgrad(_p(dy), _p(w), _p(relu_src), _p(dx), B, T, Cin, Cout, k, dtype,
+                                        _stream()), 'conv1d_dgrad')
+    return dx
+
+
+def conv1d_wgrad(x, dy, dw, db, dtype=TTSMI_F32):
+    B, T, Cin = x.shape
+    Cout = dy.shape[2]
+    k = dw.shape[0]
+    l = _lib.lib()
+    ws = _ws(l.ttsmi_conv1d_wgrad_ws_bytes(B, T, Cin, Cout, k), x.device)
+    check(l.ttsmi_conv1d_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, T, Cin, Cout, k, _p(ws), ws.numel(),
+                               dtype, _stream()), 'conv1d_wgrad')
+
+
+def token_pad_mask(tokens):
+    B, T = tokens.shape
+    pad = torch.empty((B, T), dtype=torch.uint8, device=tokens.device)
+    klen = torch.empty((B,), dtype=torch.int32, device=tokens.device)
+    check(_lib.lib().ttsmi_token_pad_mask(_p(tokens), _p(pad), _p(klen), B, T, _stream()), 'token_pad_mask')
+    return pad, klen
+
+
+def length_pad_mask(lens, T):
+    B = lens.shape[0]
+    pad = torch.empty((B, T), dtype=torch.uint8, device=lens.device)
+    klen = torch.empty((B,), dtype=torch.int32, device=lens.device)
+    check(_lib.lib().ttsmi_length_pad_mask(_p(lens), _p(pad), _p(klen), B, T, _stream()), 'length_pad_mask')
+    return pad, klen
+
+
+def lenreg_index(dur, cap):
+    """dur [B,Tp] int32 or float32 -> (idx [B,cap] i32, cum [B,Tp+1] i32, len [B] i32)."""
+    _need_gpu(dur)
+    dur = _c(dur)
+    B, Tp = dur.shape
+    assert dur.dtype in (torch.int32, torch.float32), dur.dtype
+    idx = torch.empty((B, cap), dtype=torch.int32, device=dur.device)
+    cum = torch.empty((B, Tp + 1), dtype=torch.int32, device=dur.device)
+    ln = torch.empty((B,), dtype=torch.int32, device=dur.device)
+    check(_lib.lib().ttsmi_lenreg_index(_p(dur), int(dur.dtype == torch.int32), _p(idx), _p(cum), _p(ln),
+                                        B, Tp, cap, _stream()), 'lenreg_index')
+    return idx, cum, ln
+
+
+def attention_weights(qkv, key_pad, lse, B, H, T, dh, p_drop=0.0, drop: Optional[DropCtx] = None,
+                      site=0, dtype=TTSMI_F32):
+    w = torch.empty((B, H, T, T), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().ttsmi_attention_weights(_p(qkv), _p(key_pad), _p(lse), _p(w), B, H, T, dh,
+                                             float(p_drop), drop.seed if drop else 0,
+                                             _p(drop.step_dev) if drop else None, site, dtype,
+                                             _stream()), 'attention_weights')
+    return w
+
+
+def adam_tf(p, g, m, v, lr_dev, step_dev, b1=0.9, b2=0.98, eps=1e-9, shadow=None):
+    check(_lib.lib().ttsmi_adam_tf(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), _p(step_dev),
+                                   b1, b2, eps, _p(shadow), _stream()), 'adam_tf')
+
+
+def step_increment(step_dev):
+    check(_lib.lib().ttsmi_step_increment(_p(step_dev), _stream()), 'step_increment')
+
+
+def stft_logmel(wav, clip_off, frame_off, total_frames, n_fft, hop, window, n_mels, mel_lo, mel_cnt,
+                mel_ptr, mel_w, normalizer, clip_min):
+    out = torch.empty((int(total_frames), n_mels), dtype=torch.float32, device=wav.device)
+    check(_lib.lib().ttsmi_stft_logmel(_p(wav), _p(clip_off), _p(frame_off), clip_off.numel() - 1,
+                                       int(total_frames), n_fft, hop, _p(window), n_mels, _p(mel_lo),
+                                       _p(mel_cnt), _p(mel_ptr), _p(mel_w), normalizer, clip_min, _p(out),
+                                       _stream()), 'stft_logmel')
+    return out
+
+
+def _sink(g, like):
+    """Gradient destination: the caller's buffer view, or a fresh tensor."""
+    return g if g is not None else torch.empty_like(like)
+
+
+# =================================================================================================
+# autograd Functions (one per fused layer)
+# =================================================================================================
+class LinearFn(torch.autograd.Function):
+    """y = [x | x2] . w + b.   Dense at model/layers.py:116-120,148-149; model/models.py:422."""
+
+    @staticmethod
+    def forward(ctx, x, x2, w, b, gw, gb):
+        x = _c(x)
+        x2 = None if x2 is None else _c(x2)
+        y = linear_fwd(x, w, b, False, x2)
+        ctx.save_for_backward(x, x2, w)
+        ctx.sinks = (gw, gb)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, w = ctx.saved_tensors
+        gw, gb = ctx.sinks
+        dy = _c(dy)
+        K1 = x.shape[1]
+        dw = _sink(gw, w)
+        db = _sink(gb, dy[0]) if ctx.has_b else None
+        dx = linear_dgrad(dy, w[:K1]) if ctx.needs_input_grad[0] else None
+        linear_wgrad(x, dy, dw[:K1], db)
+        dx2 = None
+        if x2 is not None:
+            dx2 = linear_dgrad(dy, w[K1:]) if ctx.needs_input_grad[1] else None
+            linear_wgrad(x2, dy, dw[K1:], None)
+        return dx, dx2, (None if gw is not None else dw), (None if (gb is not None or db is None) else db), None, None
+
+
+class FFNFn(torch.autograd.Function):
+    """relu(x.w1+b1).w2+b2 - the two Dense layers of FFNResNorm (model/layers.py:99-100)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gw1, gb1, gw2, gb2):
+        x = _c(x)
+        h = linear_fwd(x, w1, b1, True)
+        y = linear_fwd(h, w2, b2, False)
+        ctx.save_for_backward(x, h, w1, w2)
+        ctx.sinks = (gw1, gb1, gw2, gb2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, w1, w2 = ctx.saved_tensors
+        gw1, gb1, gw2, gb2 = ctx.sinks
+        dy = _c(dy)
+        dw2, db2 = _sink(gw2, w2), _sink(gb2, dy[0])
+        linear_wgrad(h, dy, dw2, db2)
+        dh = linear_dgrad(dy, w2, relu_src=h)               # relu' fused in the dgrad epilogue
+        dw1, db1 = _sink(gw1, w1), _sink(gb1, dh[0])
+        linear_wgrad(x, dh, dw1, db1)
+        dx = linear_dgrad(dh, w1)
+        n = lambda g, d: None if g is not None else d
+        return dx, n(gw1, dw1), n(gb1, db1), n(gw2, dw2), n(gb2, db2), None, None, None, None
+
+
+class ConvStackFn(torch.autograd.Function):
+    """conv -> relu -> ... -> conv (no activation after the last): CNNResNorm.call_convs +
+    last_conv, model/layers.py:30-38.  x [B,T,C].  params = (w0,b0,w1,b1,...), sinks likewise."""
+
+    @staticmethod
+    def forward(ctx, x, n_layers, *args):
+        x = _c(x)
+        params, sinks = args[:2 * n_layers], args[2 * n_layers:]
+        acts = [x]
+        h = x
+        for j in range(n_layers):
+            h = conv1d_fwd(h, params[2 * j], params[2 * j + 1], relu=(j < n_layers - 1))
+            acts.append(h)
+        ctx.n = n_layers
+        ctx.save_for_backward(*acts[:-1], *params[0::2])
+        ctx.sinks = sinks
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = ctx.n
+        acts, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        sinks = ctx.sinks
+        g = _c(dy)
+        outs = [None] * (2 * n)
+        for j in reversed(range(n)):
+            gw, gb = (sinks[2 * j], sinks[2 * j + 1]) if sinks else (None, None)
+            dw, db = _sink(gw, ws[j]), _sink(gb, g[0, 0])
+            conv1d_wgrad(acts[j], g, dw, db)
+            outs[2 * j] = None if gw is not None else dw
+            outs[2 * j + 1] = None if gb is not None else db
+            g = conv1d_dgrad(g, ws[j], relu_src=(acts[j] if j > 0 else None))
+        return (g, None, *outs, *([None] * len(sinks)))
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """y = rowmask(keep_out(LN(keep_in(x) + res)*gamma + beta + s*PE)) - see include/ttsmi.h."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, ggamma, gbeta, pe, pe_scale, gpe_scale, T, row_pad,
+                p_in, site_in, p_out, site_out, drop, relu_in):
+        x = _c(x)
+        res = None if res is None else _c(res)
+        shp = x.shape
+        C = shp[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+        seed = drop.seed if drop is not None else 0
+        step_dev = drop.step_dev if drop is not None else None
+        check(_lib.lib().ttsmi_add_layernorm_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(pe), _p(pe_scale),
+                                                 int(T), _p(row_pad), float(p_in), int(site_in), float(p_out),
+                                                 int(site_out), seed, _p(step_dev), LN_EPS, _p(y), _p(mean),
+                                                 _p(rstd), M, C, _stream()), 'add_layernorm_fwd')
+        ctx.save_for_backward(x, res, gamma, mean, rstd, pe, pe_scale, row_pad, step_dev)
+        ctx.cfg = (int(T), float(p_in), int(site_in), float(p_out), int(site_out), seed, bool(relu_in), M, C)
+        ctx.sinks = (ggamma, gbeta, gpe_scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, gamma, mean, rstd, pe, pe_scale, row_pad, step_dev = ctx.saved_tensors
+        T, p_in, site_in, p_out, site_out, seed, relu_in, M, C = ctx.cfg
+        ggamma, gbeta, gpe = ctx.sinks
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        if res is None:
+            dres = None
+        elif p_in > 0 or relu_in:
+            dres = torch.empty_like(x)
+        else:
+            dres = dx
+        dgamma, dbeta = _sink(ggamma, gamma), _sink(gbeta, gamma)
+        dps = None
+        if pe is not None:
+            dps = gpe if gpe is not None else torch.empty((1,), dtype=torch.float32, device=x.device)
+        l = _lib.lib()
+        ws = _ws(l.ttsmi_add_layernorm_bwd_ws_bytes(M, C), x.device)
+        check(l.ttsmi_add_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(pe),
+                                        _p(pe_scale), T, _p(row_pad), p_in, site_in, p_out, site_out, seed,
+                                        _p(step_dev), int(relu_in), _p(dx), _p(dres), _p(dgamma), _p(dbeta),
+                                        _p(dps), M, C, _p(ws), ws.numel(), _stream()), 'add_layernorm_bwd')
+        n = lambda g, d: None if g is not None else d
+        dps_out = None
+        if pe is not None and gpe is None:
+            dps_out = dps.reshape(pe_scale.shape)
+        return (dx, dres, n(ggamma, dgamma), n(gbeta, dbeta), None, None, None, dps_out, None, None, None,
+                None, None, None, None, None, None)
+
+
+def add_layernorm(x, res, gamma, beta, ggamma=None, gbeta=None, pe=None, pe_scale=None, gpe_scale=None,
+                  T=0, row_pad=None, p_in=0.0, site_in=0, p_out=0.0, site_out=0, drop=None, relu_in=False):
+    return AddLayerNormFn.apply(x, res, gamma, beta, ggamma, gbeta, pe, pe_scale, gpe_scale, T, row_pad,
+                                p_in, site_in, p_out, site_out, drop, relu_in)
+
+
+class AttentionFn(torch.autograd.Function):
+    """ctx = softmax(q k^T / sqrt(dh) + pad*-1e9) v per head, on the fused qkv projection output
+    (model/layers.py:123-129,176-195,144-147).  Returns (ctx [M, H*dh], lse [B,H,T])."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_pad, klen, B, H, T, dh, p_drop, drop, site):
+        qkv = _c(qkv)
+        d = H * dh
+        out = torch.empty((B * T, d), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+        seed = drop.seed if drop is not None else 0
+        step_dev = drop.step_dev if drop is not None else None
+        check(_lib.lib().ttsmi_attention_fwd(_p(qkv), _p(key_pad), _p(klen), _p(out), _p(lse), B, H, T, dh,
+                                             float(p_drop), seed, _p(step_dev), int(site), TTSMI_F32,
+                                             _stream()), 'attention_fwd')
+        ctx.save_for_backward(qkv, key_pad, klen, out, lse, step_dev)
+        ctx.cfg = (B, H, T, dh, float(p_drop), seed, int(site))
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, dout, _dlse):
+        qkv, key_pad, klen, out, lse, step_dev = ctx.saved_tensors
+        B, H, T, dh, p_drop, seed, site = ctx.cfg
+        dout = _c(dout)
+        dqkv = torch.empty_like(qkv)
+        l = _lib.lib()
+        ws = _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, dh), qkv.device)
+        check(l.ttsmi_attention_bwd(_p(qkv), _p(key_pad), _p(klen), _p(out), _p(dout), _p(lse), _p(dqkv),
+                                    B, H, T, dh, p_drop, seed, _p(step_dev), site, _p(ws), ws.numel(),
+                                    TTSMI_F32, _stream()), 'attention_bwd')
+        return dqkv, None, None, None, None, None, None, None, None, None
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """models.py:522."""
+
+    @staticmethod
+    def forward(ctx, tokens, table, gtable):
+        tokens = _c(tokens)
+        M = tokens.numel()
+        V, C = table.shape
+        y = torch.empty((*tokens.shape, C), dtype=torch.float32, device=table.device)
+        check(_lib.lib().ttsmi_embedding_fwd(_p(tokens), _p(table), _p(y), M, V, C, _stream()), 'embedding_fwd')
+        ctx.save_for_backward(tokens)
+        ctx.shape = (M, V, C)
+        ctx.sink = gtable
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        tokens, = ctx.saved_tensors
+        M, V, C = ctx.shape
+        dy = _c(dy)
+        dt = ctx.sink if ctx.sink is not None else torch.empty((V, C), dtype=torch.float32, device=dy.device)
+        check(_lib.lib().ttsmi_embedding_bwd(_p(tokens), _p(dy), _p(dt), M, V, C, _stream()), 'embedding_bwd')
+        return None, (None if ctx.sink is not None else dt), None
+
+
+class PitchEmbedFn(torch.autograd.Function):
+    """y = x + relu(p*w + b)   (models.py:527-531).  p [M] (flattened [B,Tp,1])."""
+
+    @staticmethod
+    def forward(ctx, x, p, w, b, gw, gb):
+        x, p = _c(x), _c(p)
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        check(_lib.lib().ttsmi_pitch_embed_fwd(_p(x), _p(p), _p(w), _p(b), _p(y), M, C, _stream()),
+              'pitch_embed_fwd')
+        ctx.save_for_backward(p, w, b)
+        ctx.sinks = (gw, gb)
+        ctx.mc = (M, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, w, b = ctx.saved_tensors
+        gw, gb = ctx.sinks
+        M, C = ctx.mc
+        dy = _c(dy)
+        dw, db = _sink(gw, w), _sink(gb, b)
+        dp = torch.empty_like(p) if ctx.needs_input_grad[1] else None
+        l = _lib.lib()
+        ws = _ws(l.ttsmi_pitch_embed_bwd_ws_bytes(M, C), dy.device)
+        check(l.ttsmi_pitch_embed_bwd(_p(dy), _p(p), _p(w), _p(b), _p(dp), _p(dw), _p(db), M, C, _p(ws),
+                                      ws.numel(), _stream()), 'pitch_embed_bwd')
+        return dy, dp, (None if gw is not None else dw), (None if gb is not None else db), None, None
+
+
+class RowDotFn(torch.autograd.Function):
+    """y[m] = act(x[m,:].w + b) * (1 - row_pad[m])   (layers.py:479,484-485)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gw, gb, row_pad, relu):
+        x = _c(x)
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty((*x.shape[:-1], 1), dtype=torch.float32, device=x.device)
+        check(_lib.lib().ttsmi_rowdot_fwd(_p(x), _p(w), _p(b), _p(row_pad), _p(y), M, C, int(relu),
+                                          _stream()), 'rowdot_fwd')
+        ctx.save_for_backward(x, w, y, row_pad)
+        ctx.cfg = (M, C, bool(relu))
+        ctx.sinks = (gw, gb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, row_pad = ctx.saved_tensors
+        M, C, relu = ctx.cfg
+        gw, gb = ctx.sinks
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dw = _sink(gw, w)
+        db = gb if gb is not None else torch.empty((1,), dtype=torch.float32, device=x.device)
+        l = _lib.lib()
+        ws = _ws(l.ttsmi_rowdot_bwd_ws_bytes(M, C), x.device)
+        check(l.ttsmi_rowdot_bwd(_p(dy), _p(y), _p(x), _p(w), _p(row_pad), _p(dx), _p(dw), _p(db), M, C,
+                                 int(relu), _p(ws), ws.numel(), _stream()), 'rowdot_bwd')
+        return dx, (None if gw is not None else dw), (None if gb is not None else db), None, None, None, None
+
+
+class RowMaskFn(torch.autograd.Function):
+    """y = x * (1 - row_pad)   (layers.py:482)."""
+
+    @staticmethod
+    def forward(ctx, x, row_pad):
+        x = _c(x)
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        check(_lib.lib().ttsmi_rowmask_mul(_p(x), _p(row_pad), _p(y), M, C, _stream()), 'rowmask_mul')
+        ctx.save_for_backward(row_pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        row_pad, = ctx.saved_tensors
+        dy = _c(dy)
+        C = dy.shape[-1]
+        M = dy.numel() // C
+        dx = torch.empty_like(dy)
+        check(_lib.lib().ttsmi_rowmask_mul(_p(dy), _p(row_pad), _p(dx), M, C, _stream()), 'rowmask_mul')
+        return dx, None
+
+
+class LenRegFn(torch.autograd.Function):
+    """Expand (model/layers.py:549-565): y[b,j] = x[b, idx[b,j]] (0 where idx < 0)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, cum):
+        x = _c(x)
+        B, Tp, C = x.shape
+        cap = idx.shape[1]
+        y = torch.empty((B, cap, C), dtype=torch.float32, device=x.device)
+        check(_lib.lib().ttsmi_lenreg_fwd(_p(x), _p(idx), _p(y), B, Tp, cap, C, _stream()), 'lenreg_fwd')
+        ctx.save_for_backward(cum)
+        ctx.shape = (B, Tp, cap, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cum, = ctx.saved_tensors
+        B, Tp, cap, C = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty((B, Tp, C), dtype=torch.float32, device=dy.device)
+        check(_lib.lib().ttsmi_lenreg_bwd(_p(dy), _p(cum), _p(dx), B, Tp, cap, C, _stream()), 'lenreg_bwd')
+        return dx, None, None
+
+
+class L1LossFn(torch.autograd.Function):
+    """mean |target - pred| over every element (utils/losses.py:41-49 with mask=None; integer
+    targets are cast to float).  sign(p-t)/n is produced in the same pass and kept for backward."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        assert pred.dim() >= 2 and pred.stride(-1) == 1
+        cols = pred.shape[-1]
+        rows = pred.numel() // cols
+        p2 = pred.reshape(rows, cols) if pred.is_contiguous() else _c(pred).reshape(rows, cols)
+        target = _c(target)
+        assert target.numel() == rows * cols, (target.shape, pred.shape)
+        assert target.dtype in (torch.float32, torch.int32)
+        grad = torch.empty((rows, cols), dtype=torch.float32, device=pred.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+        l = _lib.lib()
+        ws = _ws(l.ttsmi_l1_loss_ws_bytes(rows * cols), pred.device)
+        check(l.ttsmi_l1_loss(_p(p2), p2.stride(0), _p(target), int(target.dtype == torch.int32), rows, cols,
+                              1.0, _p(grad), cols, _p(loss), _p(ws), ws.numel(), _stream()), 'l1_loss')
+        ctx.save_for_backward(grad)
+        ctx.shape = pred.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        grad, = ctx.saved_tensors
+        return (grad.reshape(ctx.shape) * dl), None
+
+
+class ConvReluPreMaskedFn(torch.autograd.Function):
+    """h = relu(conv1d(x)).  INTERNAL to the predictor layer (layers.py:512-513): its backward
+    expects dy ALREADY multiplied by (h > 0) - the following AddLayerNormFn(relu_in=True) does that
+    inside its own backward kernel, so no separate relu' pass exists."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gw, gb):
+        x = _c(x)
+        h = conv1d_fwd(x, w, b, relu=True)
+        ctx.save_for_backward(x, w)
+        ctx.sinks = (gw, gb)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, w = ctx.saved_tensors
+        gw, gb = ctx.sinks
+        dh = _c(dh)
+        dw, db = _sink(gw, w), _sink(gb, dh[0, 0])
+        conv1d_wgrad(x, dh, dw, db)
+        dx = conv1d_dgrad(dh, w) if ctx.needs_input_grad[0] else None
+        return dx, (None if gw is not None else dw), (None if gb is not None else db), None, None
