@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""bench.py - the headline measurement of BASELINE.json: mel-frames/sec of a full ForwardTransformer
+train step (forward + backward + TF-form Adam [+ gradient all-reduce]) on synthetic
+LJSpeech-shaped batches, 1/2/4/8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload = "configs[1]"): d_model 256, 6+6 dense blocks, 4 heads, FFN 1024, 80-bin
+mel, predictors [256,226] k=3, per-GPU batch 32, every sample 200 phonemes / 900 mel frames
+(SURVEY.md section 8d max-shape set), dropout 0.1 as in the reference's training config.  Weak
+scaling: per-GPU batch fixed, global batch = 32*N, one RCCL all-reduce of the flat fp32 gradient
+buffer per step.  Inputs are resident in HBM before the timed region.
+
+One JSON line is printed by rank 0.  Besides the driver contract it carries
+  roofline     - the dominant kernel family of the step (exact-fp32 MFMA GEMM/attention kernels):
+                 algorithmic FLOPs per launch / average launch duration, measured live with HIP
+                 events on the launch stream in one extra instrumented step after the timed region;
+  cpu_baseline - the reference-restatement oracle (torch-CPU fp32, same graph, attention maps
+                 materialised like the reference) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+
+
+def workload_config(name: str):
+    from transformertts_amd.utils.synthetic import make_config
+    if name == 'configs[1]':
+        return make_config(), dict(B=32, Tp=200, Tm=900)
+    if name == 'configs[0]':
+        return make_config(d_model=64, enc_heads=(2, 2), dec_heads=(2, 2), ffn=256, dur_filters=(64, 64),
+                           pitch_filters=(64, 64)), dict(B=4, Tp=50, Tm=200)
+    raise ValueError(name)
+
+
+# ------------------------------------------------------------------------------------------------
+# per-entry-point algorithmic FLOPs (2 per MAC, no recompute) from the C-ABI arguments
+# ------------------------------------------------------------------------------------------------
+def _flops(name, a):
+    if name == 'ttsmi_linear_fwd':
+        return 2.0 * a[10] * a[11] * a[12]
+    if name == 'ttsmi_linear_dgrad':
+        return 2.0 * a[8] * a[9] * a[10]
+    if name == 'ttsmi_linear_wgrad':
+        return 2.0 * a[7] * a[8] * a[9]
+    if name in ('ttsmi_conv1d_fwd',):
+        return 2.0 * a[4] * a[5] * a[6] * a[7] * a[8]
+    if name == 'ttsmi_conv1d_dgrad':
+        return 2.0 * a[4] * a[5] * a[6] * a[7] * a[8]
+    if name == 'ttsmi_conv1d_wgrad':
+        return 2.0 * a[4] * a[5] * a[6] * a[7] * a[8]
+    if name == 'ttsmi_attention_fwd':
+        B, H, T, dh = a[5], a[6], a[7], a[8]
+        return 4.0 * B * H * T * T * dh                      # QK^T + PV
+    if name == 'ttsmi_attention_bwd':
+        B, H, T, dh = a[7], a[8], a[9], a[10]
+        return 8.0 * B * H * T * T * dh                      # dV, dP, dQ, dK (S recompute not counted)
+    return 0.0
+
+
+KERNEL_OF = {
+    'ttsmi_linear_fwd': 'gemm_f32_kernel<A_KC,B_NC> (Dense/Conv1D forward)',
+    'ttsmi_conv1d_fwd': 'gemm_f32_kernel<A_KC,B_NC> (Dense/Conv1D forward)',
+    'ttsmi_linear_dgrad': 'gemm_f32_kernel<A_KC,B_KC> (dgrad)',
+    'ttsmi_conv1d_dgrad': 'gemm_f32_kernel<A_KC,B_KC> (dgrad)',
+    'ttsmi_linear_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
+    'ttsmi_conv1d_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
+    'ttsmi_attention_fwd': 'attn_fwd_kernel',
+    'ttsmi_attention_bwd': 'attn_bwd_dq_kernel + attn_bwd_dkv_kernel',
+}
+
+
+def instrumented_step(step_fn):
+    """Run one step with every C-ABI call bracketed by HIP events on the launch stream."""
+    from transformertts_amd import _lib
+    recs = []
+
+    def hook(name, args, fn):
+        if name.endswith('_ws_bytes') or name in ('ttsmi_last_error', 'ttsmi_version'):
+            return fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        recs.append((name, _flops(name, args), e0, e1))
+        return rc
+
+    _lib.set_trace(hook)
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_trace(None)
+    groups = {}
+    total_ms = 0.0
+    for name, fl, e0, e1 in recs:
+        ms = e0.elapsed_time(e1)
+        total_ms += ms
+        k = KERNEL_OF.get(name, 'hbm-bound riders (LN, lenreg, loss, Adam, ...)')
+        gsum = groups.setdefault(k, [0, 0.0, 0.0])
+        gsum[0] += 1
+        gsum[1] += fl
+        gsum[2] += ms
+    return groups, total_ms
+
+
+def usable_cpus() -> int:
+    """Cores this process may actually use: min(affinity mask, cgroup v2 cpu.max quota).  The GPU
+    boxes expose 256 logical CPUs but cap the container at a 16-CPU quota; running an OpenMP pool
+    wider than the quota makes the CPU leg orders of magnitude slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(cfg, shape, threads):
+    """Reference-restatement CPU baseline (TF2 is not installable offline): oracle/ft_oracle.py in
+    torch-CPU fp32, same graph incl. materialised attention maps and dropout, on a bounded sample
+    (a slice of the batch axis of the same workload)."""
+    from oracle import ft_oracle as fo
+    torch.set_num_threads(threads)
+    Bs = max(1, min(2, shape['B']))
+    W = fo.init_weights(cfg, seed=0)
+    m = fo.ForwardTransformerOracle(cfg, W, torch.float32)
+    batch = fo.synthetic_batch(Bs, shape['Tp'], shape['Tm'], seed=1234)
+    m.train_step(*batch)                                  # warm-up
+    n = 2
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m.train_step(*batch)
+    dt = (time.perf_counter() - t0) / n
+    return {'value': Bs * shape['Tm'] / dt, 'unit': 'mel-frames/s', 'cores': threads, 'kind': 'port',
+            'sample': f'B={Bs} samples of the same {shape["Tp"]}-phoneme/{shape["Tm"]}-frame workload, '
+                      f'1 warm-up + {n} timed train steps, torch-CPU fp32 restatement of the TF2 graph '
+                      f'(TF2 unavailable offline), {threads} threads, {dt:.2f} s/step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='configs[1]')
+    ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from transformertts_amd import dp
+    rank, local, world = dp.init_process_group()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    from transformertts_amd.model.models import ForwardTransformer
+    cfg, shape = workload_config(args.workload)
+    cfg = dict(cfg, dropout_rate=args.dropout, predictors_dropout=args.dropout, device=str(dev), seed=0)
+    model = ForwardTransformer.from_config(cfg)
+    model._compile(learning_rate=1e-4)
+    wrapped = dp.DataParallel(model)
+
+    from transformertts_amd.utils.synthetic import synthetic_batch
+    tok, mel, dur, pit = synthetic_batch(shape['B'], shape['Tp'], shape['Tm'], seed=1234 + rank)
+    batch = [torch.from_numpy(a).to(dev) for a in (tok, mel, dur, pit)]      # resident in HBM
+
+    def step():
+        return wrapped.train_step(*batch)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(out['loss'])
+    assert np.isfinite(loss), 'non-finite loss'
+    frames = shape['B'] * shape['Tm'] * world
+    ms = 1e3 * elapsed / args.steps
+
+    result = {
+        'metric': 'mel-frames/sec (train step)', 'value': frames / (elapsed / args.steps),
+        'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'BASELINE.json {args.workload}: ForwardTransformer d_model=256 6+6 dense '
+                               f'blocks 4 heads FFN=1024 80-mel, fwd+bwd+TF-Adam, per-GPU batch '
+                               f'{shape["B"]} x {shape["Tp"]} phonemes x {shape["Tm"]} frames '
+                               f'(max-shape set), dropout {args.dropout}'
+                   if args.workload == 'configs[1]' else args.workload,
+                   'global_batch': shape['B'] * world, 'parallelism': f'dp{world}',
+                   'params': model.params.n_params, 'loss_after': loss},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        groups, total_ms = instrumented_step(step)
+        mfma = {k: v for k, v in groups.items() if v[1] > 0}
+        dom = max(mfma.items(), key=lambda kv: kv[1][2])
+        n, fl, gms = dom[1]
+        all_fl = sum(v[1] for v in mfma.values())
+        all_ms = sum(v[2] for v in mfma.values())
+        result['roofline'] = {
+            'bound': 'mfma', 'kernel': dom[0], 'launches_per_step': n,
+            'achieved': fl / gms / 1e9, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': fl / gms / 1e9 / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+            'avg_launch_ms': gms / n, 'algorithmic_gflop_per_launch': fl / n / 1e9,
+            'all_mfma_kernels': {'achieved': all_fl / all_ms / 1e9, 'gflop_per_step': all_fl / 1e9,
+                                 'ms_per_step': all_ms},
+            'per_kernel': {k: {'launches': v[0], 'gflop': v[1] / 1e9, 'ms': v[2],
+                               'tflops': (v[1] / v[2] / 1e9 if v[1] else None)} for k, v in groups.items()},
+            'instrumented_step_ms': total_ms,
+        }
+    elif world > 1 and not args.no_roofline:
+        step()          # keep the collective count equal on every rank
+    if world > 1:
+        sync()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline({k: v for k, v in cfg.items() if k not in ('device', 'seed')},
+                                              shape, usable_cpus())
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -208,7 +208,7 @@ def test_add_layernorm_dropout_statistics_and_determinism():
     # backward regenerates the same masks (p_in on the x branch, res untouched)
     xg, rg = x.clone().requires_grad_(), res.clone().requires_grad_()
     ya = ops.add_layernorm(xg, rg, gam, bet, p_in=p, site_in=7, drop=drop)
-    ya.sum().backward()
+    (ya * g(M, C, seed=8).to(DEV)).sum().backward()
     zero_in_x = (xg.grad == 0).float().mean().item()
     assert abs(zero_in_x - p) < 0.01 and (rg.grad == 0).float().mean().item() < 1e-3
     # a device step counter changes the stream without changing kernel arguments

@@ -8,6 +8,12 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
+# torch MUST be imported before libttsmi.so is dlopen'ed: the PyTorch-ROCm wheel bundles its own
+# libamdhip64.so.7 and libttsmi must bind to THAT runtime instance (same SONAME -> the loader
+# reuses the already-loaded copy), otherwise the process holds two HIP runtimes and the stream
+# handles / device pointers torch hands us belong to the other one ("no ROCm-capable device").
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libttsmi.so')
 
@@ -86,8 +92,33 @@ def lib() -> ctypes.CDLL:
             raise TtsmiError(f'libttsmi.so does not export {name}; rebuild it') from e
         fn.restype = res
         fn.argtypes = args
-    _lib = l
-    return l
+    _lib = _Traced(l)
+    return _lib
+
+
+_trace = None
+
+
+def set_trace(callback) -> None:
+    """Measurement hook (bench.py / profiling only): when set, every C-ABI call is made as
+    callback(name, args, fn) -> rc, so a caller can bracket it with HIP events on the launch stream
+    and attribute algorithmic FLOPs/bytes from the arguments.  None restores direct calls."""
+    global _trace
+    _trace = callback
+
+
+class _Traced:
+    """Attribute proxy over the ctypes library that routes calls through the trace hook if set."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self._fns = {name: getattr(cdll, name) for name in SIGNATURES}
+
+    def __getattr__(self, name):
+        fn = self._fns[name]
+        if _trace is None:
+            return fn
+        return lambda *args: _trace(name, args, fn)
 
 
 def check(rc: int, what: str = '') -> None:

@@ -401,8 +401,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
 #pragma unroll
             for (int qt = 0; qt < KT / 32; ++qt) {
                 if (q0 + qt * 32 >= p.T) break;
-                f32x16 s = dot_rows<DH, SM::KS, false>(Qs, qt * 32 + l31, hh, kreg);    // S[q][key]
-                f32x16 dp = dot_rows<DH, SM::KS, false>(Os, qt * 32 + l31, hh, vreg);   // dP = dO.V^T
+                // A = LDS rows (lane&31 = query row), B = registers (lane&31 = key) -> col = key
+                f32x16 s = dot_rows<DH, SM::KS, true>(Qs, qt * 32 + l31, hh, kreg);     // S[q][key]
+                f32x16 dp = dot_rows<DH, SM::KS, true>(Os, qt * 32 + l31, hh, vreg);    // dP = dO.V^T
                 f32x16 pt;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

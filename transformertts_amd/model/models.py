@@ -241,35 +241,29 @@ class ForwardTransformer:
                     a = weights[name]
                 w.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)).reshape(w.shape).to(self.device))
 
-    def weights_dict(self) -> "OrderedDict[str, np.ndarray]":
+    def _export(self, tensors: Dict[str, torch.Tensor]) -> "OrderedDict[str, np.ndarray]":
+        """Internal (fused wqkv/bqkv) -> reference variable names and order (wq,bq,wk,bk,wv,bv)."""
         out = OrderedDict()
-        for name, w in self.params.w.items():
-            a = w.detach().cpu().numpy().copy()
+        for name, t in tensors.items():
             leaf = name.split('.')[-1]
+            if leaf == 'bqkv':
+                continue
+            a = t.detach().cpu().numpy().copy()
             if leaf == 'wqkv':
                 base, d = name[:-len('wqkv')], a.shape[0]
-                out[base + 'wq'], out[base + 'wk'], out[base + 'wv'] = a[:, :d], a[:, d:2 * d], a[:, 2 * d:]
-            elif leaf == 'bqkv':
-                base, d = name[:-len('bqkv')], a.shape[0] // 3
-                out[base + 'bq'], out[base + 'bk'], out[base + 'bv'] = a[:d], a[d:2 * d], a[2 * d:]
+                bias = tensors[base + 'bqkv'].detach().cpu().numpy().copy()
+                for j, n in enumerate('qkv'):
+                    out[base + 'w' + n] = a[:, j * d:(j + 1) * d]
+                    out[base + 'b' + n] = bias[j * d:(j + 1) * d]
             else:
                 out[name] = a
         return out
 
+    def weights_dict(self) -> "OrderedDict[str, np.ndarray]":
+        return self._export(self.params.w)
+
     def grads_dict(self) -> "OrderedDict[str, np.ndarray]":
-        out = OrderedDict()
-        for name, g in self.params.g.items():
-            a = g.detach().cpu().numpy().copy()
-            leaf = name.split('.')[-1]
-            if leaf == 'wqkv':
-                base, d = name[:-len('wqkv')], a.shape[0]
-                out[base + 'wq'], out[base + 'wk'], out[base + 'wv'] = a[:, :d], a[:, d:2 * d], a[:, 2 * d:]
-            elif leaf == 'bqkv':
-                base, d = name[:-len('bqkv')], a.shape[0] // 3
-                out[base + 'bq'], out[base + 'bk'], out[base + 'bv'] = a[:d], a[d:2 * d], a[2 * d:]
-            else:
-                out[name] = a
-        return out
+        return self._export(self.params.g)
 
     # ------------------------------------------------------------------ layers (reference model/layers.py)
     def _self_attention_blocks(self, prefix, name, x, pad, klen, heads, dense_blocks, pe, rate,
