@@ -43,17 +43,45 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int32_t* __res
         y[i] = (t >= 0 && t < V) ? table[(long)t * C + c] : 0.f;
     }
 }
-// one block per vocabulary row: scans the token list (L2 resident) and sums matching rows in order
+// One block per vocabulary row.  The token list is scanned 256 at a time; matching positions are
+// compacted IN ORDER (wave ballots + prefix) into an LDS list, and only those rows of dy are summed,
+// in ascending position order -> deterministic, and ~M/V row reads per block instead of M tests/thread.
+#define EMB_LIST 1024
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int32_t* __restrict__ tok,
                                                             const float* __restrict__ dy,
                                                             float* __restrict__ dtable, int M,
                                                             int C) {
-    const int v = blockIdx.x;
+    __shared__ int list[EMB_LIST + 256];
+    __shared__ int wcnt[4];
+    __shared__ int count_s;
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) count_s = 0;
+    __syncthreads();
     for (int c0 = 0; c0 < C; c0 += 256) {
-        int c = c0 + threadIdx.x;
+        const int c = c0 + tid;
         float s = 0.f;
-        for (int m = 0; m < M; ++m) {
-            if (tok[m] == v && c < C) s += dy[(long)m * C + c];
+        for (int m0 = 0; m0 < M; m0 += 256) {
+            const int m = m0 + tid;
+            const bool hit = (m < M) && (tok[m] == v);
+            const unsigned long long mask = __ballot(hit);
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[wave] = __popcll(mask);
+            __syncthreads();
+            int base = count_s;
+            for (int w = 0; w < wave; ++w) base += wcnt[w];
+            if (hit) list[base + pos] = m;
+            __syncthreads();
+            if (tid == 0) count_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+            const bool last = (m0 + 256 >= M);
+            if (count_s >= EMB_LIST || last) {          // flush (block-uniform condition)
+                const int n = count_s;
+                if (c < C)
+                    for (int i = 0; i < n; ++i) s += dy[(long)list[i] * C + c];
+                __syncthreads();
+                if (tid == 0) count_s = 0;
+                __syncthreads();
+            }
         }
         if (c < C) dtable[(long)v * C + c] = s;
     }

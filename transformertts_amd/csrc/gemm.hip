@@ -45,6 +45,8 @@ struct GemmP {
     int b_taps, b_kt; long b_tap_stride; int b_flip;   // B_KC tap addressing
     int k_per_split;                   // reduction range per blockIdx.z
     float* ws;                         // split slabs [gridDim.z][M][N] when gridDim.z > 1
+    float* colsum;                     // optional: column sums of the B operand (bias gradient)
+    float* colsum_ws;                  //           their split slabs [gridDim.z][N]
     int tiles_m, tiles_n;
 };
 
@@ -208,11 +210,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     __syncthreads();
 
     const int l31 = lane & 31, kh = lane >> 5;
+    // bias gradient fused into wgrad: the B tile IS dy[rows, n-tile]; the m-tile-0 workgroups add
+    // up its columns while it sits in LDS (one conflict-free ds_read per k per thread)
+    const bool do_colsum = (p.colsum != nullptr) && (tm == 0) && (tid < GBN);
+    float csum = 0.f;
     for (int k0 = kbeg; k0 < kend; k0 += GBK) {
         const bool more = (k0 + GBK) < kend;
         if (more) {
             fetch_a<AM, VEC>(p, m0, k0 + GBK, kend, tid, ra);
             fetch_b<BMODE, VEC>(p, n0, k0 + GBK, kend, tid, rb);
+        }
+        if (do_colsum) {
+#pragma unroll
+            for (int kk = 0; kk < GBK; ++kk) csum += Bs[kk][tid];
         }
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 2) {
@@ -235,6 +245,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool split = gridDim.z > 1;
+    if (do_colsum && n0 + tid < p.N) {
+        if (split) p.colsum_ws[(long)blockIdx.z * p.N + n0 + tid] = csum;
+        else p.colsum[n0 + tid] = csum;
+    }
     float* Cb = split ? p.ws + (long)blockIdx.z * p.M * p.N : p.C;
     const long ldc = split ? (long)p.N : p.ldc;
 #pragma unroll
@@ -261,14 +275,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 
 // dw[i] = sum_s ws[s][i]
 __global__ void split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                    long ldo, int M, int N, int splits) {
+                                    long ldo, int M, int N, int splits,
+                                    const float* __restrict__ cs_ws, float* __restrict__ cs_out) {
     long n = (long)M * N;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+    long total = n + (cs_out ? N : 0);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += ws[(long)z * n + i];
-        int r = (int)(i / N), c = (int)(i - (long)r * N);
-        out[(long)r * ldo + c] = s;
+        if (i < n) {
+            for (int z = 0; z < splits; ++z) s += ws[(long)z * n + i];
+            int r = (int)(i / N), c = (int)(i - (long)r * N);
+            out[(long)r * ldo + c] = s;
+        } else {
+            long c = i - n;
+            for (int z = 0; z < splits; ++z) s += cs_ws[(long)z * N + c];
+            cs_out[c] = s;
+        }
     }
 }
 
@@ -334,9 +356,7 @@ static int pick_splits(int rows, int tiles) {
 static size_t wgrad_ws_bytes(long rows, long kin, long n) {
     int tiles = ttsmi_cdiv(kin, GBM) * ttsmi_cdiv(n, GBN);
     int splits = pick_splits((int)rows, tiles);
-    size_t a = (size_t)splits * kin * n * sizeof(float);
-    size_t b = (size_t)ttsmi_cdiv(rows, 256) * n * sizeof(float);
-    return (a > b ? a : b) + 256;
+    return (size_t)splits * (kin * n + n) * sizeof(float) + 256;
 }
 
 static int colsum(const float* dy, long lddy, float* db, int M, int N, float* ws, hipStream_t st) {
@@ -350,13 +370,25 @@ static int colsum(const float* dy, long lddy, float* db, int M, int N, float* ws
     return TTSMI_OK;
 }
 
+static void setup_wgrad_split(GemmP& p, int rows, float* ws, float* db, int& splits) {
+    int tiles = ttsmi_cdiv(p.M, GBM) * ttsmi_cdiv(p.N, GBN);
+    splits = pick_splits(rows, tiles);
+    int kps = ttsmi_cdiv(rows, splits);
+    kps = ((kps + GBK - 1) / GBK) * GBK;
+    splits = ttsmi_cdiv(rows, kps);
+    p.k_per_split = kps;
+    p.ws = ws;
+    p.colsum = db;
+    p.colsum_ws = ws + (size_t)splits * p.M * p.N;
+}
+
 static int finish_wgrad(GemmP& p, int splits, float* dw, long lddw, hipStream_t st) {
     if (splits > 1) {
         long n = (long)p.M * p.N;
         int blocks = (int)((n + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, dw, lddw,
-                           p.M, p.N, splits);
+                           p.M, p.N, splits, p.colsum_ws, p.colsum);
         TTSMI_CHECK_LAUNCH("split_reduce");
     }
     return TTSMI_OK;
@@ -422,21 +454,13 @@ int ttsmi_linear_wgrad(const void* x, int64_t ldx, const void* dy, int64_t lddy,
     p.B = (const float*)dy; p.ldb = lddy;
     p.C = dw; p.ldc = lddw;
     p.M = K; p.N = N; p.K = M;
-    int tiles = ttsmi_cdiv(K, GBM) * ttsmi_cdiv(N, GBN);
-    int splits = pick_splits(M, tiles);
-    int kps = ttsmi_cdiv(M, splits);
-    kps = ((kps + GBK - 1) / GBK) * GBK;
-    splits = ttsmi_cdiv(M, kps);
-    p.k_per_split = kps;
-    p.ws = (float*)ws;
+    int splits;
+    setup_wgrad_split(p, M, (float*)ws, db, splits);
     bool vec = al16(x) && (ldx % 4 == 0) && (K % 4 == 0) && al16(dy) && (lddy % 4 == 0) &&
                (N % 4 == 0);
     int rc = launch_gemm<A_MC, B_NC>(p, vec, splits, st, "linear_wgrad");
     if (rc) return rc;
-    rc = finish_wgrad(p, splits, dw, lddw, st);
-    if (rc) return rc;
-    if (db) return colsum((const float*)dy, lddy, db, M, N, (float*)ws, st);
-    return TTSMI_OK;
+    return finish_wgrad(p, splits, dw, lddw, st);
 }
 
 int ttsmi_conv1d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int T,
@@ -502,20 +526,12 @@ int ttsmi_conv1d_wgrad(const void* x, const void* dy, float* dw, float* db, int 
     p.B = (const float*)dy; p.ldb = Cout;
     p.C = dw; p.ldc = Cout;
     p.M = kin; p.N = Cout; p.K = rows;
-    int tiles = ttsmi_cdiv(kin, GBM) * ttsmi_cdiv(Cout, GBN);
-    int splits = pick_splits(rows, tiles);
-    int kps = ttsmi_cdiv(rows, splits);
-    kps = ((kps + GBK - 1) / GBK) * GBK;
-    splits = ttsmi_cdiv(rows, kps);
-    p.k_per_split = kps;
-    p.ws = (float*)ws;
+    int splits;
+    setup_wgrad_split(p, rows, (float*)ws, db, splits);
     bool vec = al16(x) && (Cin % 4 == 0) && al16(dy) && (Cout % 4 == 0);
     int rc = launch_gemm<A_MC, B_NC>(p, vec, splits, st, "conv1d_wgrad");
     if (rc) return rc;
-    rc = finish_wgrad(p, splits, dw, Cout, st);
-    if (rc) return rc;
-    if (db) return colsum((const float*)dy, Cout, db, rows, Cout, (float*)ws, st);
-    return TTSMI_OK;
+    return finish_wgrad(p, splits, dw, Cout, st);
 }
 
 }  // extern "C"

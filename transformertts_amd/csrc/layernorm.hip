@@ -225,36 +225,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
     if (lane == 0) p.part_s[wave_g] = as;
 }
 
-// out[c] = sum_w part[w][c]; block handles 64 columns with 4 row-lanes
+// out[c] = sum_w part[w][c]: block = 16 columns x 16 row-lanes (64 B segments per row-lane), so a
+// C=256 reduction runs on 16 workgroups with 16x more loads in flight than a column-per-thread sweep
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part_g,
                                                               const float* __restrict__ part_b,
                                                               const float* __restrict__ part_s,
                                                               float* dgamma, float* dbeta,
                                                               float* dscale, int nw, int C) {
-    __shared__ float red[2][4][64];
-    int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    int rl = threadIdx.x >> 6;
+    __shared__ float red[2][16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float sg = 0.f, sb = 0.f;
     if (c < C) {
-        for (int w = rl; w < nw; w += 4) {
+#pragma unroll 4
+        for (int w = rl; w < nw; w += 16) {
             sg += part_g[(long)w * C + c];
             sb += part_b[(long)w * C + c];
         }
     }
-    red[0][rl][threadIdx.x & 63] = sg;
-    red[1][rl][threadIdx.x & 63] = sb;
+    red[0][rl][cl] = sg;
+    red[1][rl][cl] = sb;
     __syncthreads();
     if (rl == 0 && c < C) {
-        int t = threadIdx.x;
-        dgamma[c] = red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t];
-        dbeta[c] = red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t];
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a += red[0][r][cl]; b += red[1][r][cl]; }
+        dgamma[c] = a;
+        dbeta[c] = b;
     }
     if (blockIdx.x == 0 && dscale) {
+        __shared__ float ws4[4];
         __syncthreads();
         float s = 0.f;
         for (int w = threadIdx.x; w < nw; w += 256) s += part_s[w];
         s = wave_sum(s);
-        __shared__ float ws4[4];
         if ((threadIdx.x & 63) == 0) ws4[threadIdx.x >> 6] = s;
         __syncthreads();
         if (threadIdx.x == 0) dscale[0] = ws4[0] + ws4[1] + ws4[2] + ws4[3];
@@ -367,7 +371,7 @@ int ttsmi_add_layernorm_bwd(const float* dy, const float* x, const float* res, c
     int rc = dispatch<false>(p, st);
     if (rc) { ttsmi_set_error("add_layernorm_bwd: C=%d too wide", C); return rc; }
     TTSMI_CHECK_LAUNCH("add_layernorm_bwd");
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ttsmi_cdiv(C, 64)), dim3(256), 0, st, p.part_g,
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ttsmi_cdiv(C, 16)), dim3(256), 0, st, p.part_g,
                        p.part_b, p.part_s, dgamma, dbeta, pe ? dpe_scale : nullptr, (int)nw, C);
     TTSMI_CHECK_LAUNCH("ln_param_reduce");
     return TTSMI_OK;
