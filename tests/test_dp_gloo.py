@@ -1,0 +1,82 @@
+"""world_size-2 `gloo` test of the data-parallel path on CPU (the model itself needs a GPU, so the
+per-rank gradients come from the CPU oracle here; what is under test is transformertts_amd/dp.py:
+sharding, the single flat-buffer all-reduce, parameter broadcast, and the claim that averaging the
+per-rank gradients of equal-shape shards equals the gradient of the global-batch loss)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat(grads):
+    return torch.cat([g.reshape(-1) for g in grads.values()])
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from oracle import ft_oracle as fo
+    from transformertts_amd import dp
+    r, local, w = dp.init_process_group(backend='gloo')
+    assert (r, w) == (rank, world)
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=1, perturb=0.02)
+    batch = fo.synthetic_batch(4, 16, 48, seed=3)                 # global batch 4, equal shapes
+    shard = dp.shard_batch(batch, rank, world)
+    assert shard[0].shape[0] == 2
+    model = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    g = _flat(model.train_step(*shard, apply=False)['grads']).clone()
+    sync = dp.GradAllReduce()
+    assert sync.world == 2 and not sync.use_avg                   # gloo: SUM then 1/world
+    sync(g)
+    # broadcast: rank 1 starts from garbage and must end with rank 0's parameters
+    params = torch.arange(10, dtype=torch.float32) if rank == 0 else torch.full((10,), -1.0)
+    dp.broadcast_parameters(params, 0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, 'avg.npy'), g.numpy())
+    np.save(os.path.join(out_dir, f'params{rank}.npy'), params.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_equals_global_batch_gradient(tmp_path):
+    from oracle import ft_oracle as fo
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    avg = np.load(tmp_path / 'avg.npy')
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=1, perturb=0.02)
+    batch = fo.synthetic_batch(4, 16, 48, seed=3)
+    model = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    want = _flat(model.train_step(*batch, apply=False)['grads']).numpy()
+    np.testing.assert_allclose(avg, want, rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(np.load(tmp_path / 'params1.npy'), np.arange(10, dtype=np.float32))
+
+
+def test_shard_batch_rejects_uneven_split():
+    from transformertts_amd import dp
+    with pytest.raises(AssertionError):
+        dp.shard_batch([np.zeros((5, 3))], 0, 2)
+    a, = dp.shard_batch([np.arange(8).reshape(4, 2)], 1, 2)
+    np.testing.assert_array_equal(a, [[4, 5], [6, 7]])
+
+
+def test_world_size_one_is_degenerate():
+    from transformertts_amd import dp
+    sync = dp.GradAllReduce()
+    g = torch.ones(4)
+    sync(g)
+    assert torch.equal(g, torch.ones(4))
