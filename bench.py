@@ -66,6 +66,10 @@ def _flops(name, a):
         return 2.0 * a[4] * a[5] * a[6] * a[7] * a[8]
     if name == 'ttsmi_conv1d_wgrad':
         return 2.0 * a[4] * a[5] * a[6] * a[7] * a[8]
+    if name == 'ttsmi_hgemm_tn':
+        return 2.0 * a[13] * a[14] * a[15]
+    if name == 'ttsmi_hgemm_wgrad':
+        return 2.0 * a[6] * a[7] * a[8]
     if name == 'ttsmi_attention_fwd':
         B, H, T, dh = a[5], a[6], a[7], a[8]
         return 4.0 * B * H * T * T * dh                      # QK^T + PV
@@ -82,9 +86,15 @@ KERNEL_OF = {
     'ttsmi_conv1d_dgrad': 'gemm_f32_kernel<A_KC,B_KC> (dgrad)',
     'ttsmi_linear_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
     'ttsmi_conv1d_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
+    'ttsmi_hgemm_tn': 'gemm_bf16_kernel<A=f32> (Dense/Conv1D forward + dgrad, bf16 MFMA)',
+    'ttsmi_hgemm_wgrad': 'gemm_bf16_kernel<A=bf16> (wgrad, bf16 MFMA, + split reduce)',
     'ttsmi_attention_fwd': 'attn_fwd_kernel',
     'ttsmi_attention_bwd': 'attn_bwd_dq_kernel + attn_bwd_dkv_kernel',
 }
+
+
+def peak_of(kernel_name: str) -> float:
+    return PEAK_BF16_MFMA_TFLOPS if 'bf16' in kernel_name else PEAK_F32_MFMA_TFLOPS
 
 
 def instrumented_step(step_fn):
@@ -164,6 +174,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='configs[1]')
     ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -176,7 +187,8 @@ def main():
 
     from transformertts_amd.model.models import ForwardTransformer
     cfg, shape = workload_config(args.workload)
-    cfg = dict(cfg, dropout_rate=args.dropout, predictors_dropout=args.dropout, device=str(dev), seed=0)
+    cfg = dict(cfg, dropout_rate=args.dropout, predictors_dropout=args.dropout, device=str(dev), seed=0,
+               precision=args.precision)
     model = ForwardTransformer.from_config(cfg)
     model._compile(learning_rate=1e-4)
     wrapped = dp.DataParallel(model)
@@ -214,7 +226,7 @@ def main():
         'metric': 'mel-frames/sec (train step)', 'value': frames / (elapsed / args.steps),
         'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': f'BASELINE.json {args.workload}: ForwardTransformer d_model=256 6+6 dense '
                                f'blocks 4 heads FFN=1024 80-mel, fwd+bwd+TF-Adam, per-GPU batch '
                                f'{shape["B"]} x {shape["Tp"]} phonemes x {shape["Tm"]} frames '
@@ -233,8 +245,8 @@ def main():
         all_ms = sum(v[2] for v in mfma.values())
         result['roofline'] = {
             'bound': 'mfma', 'kernel': dom[0], 'launches_per_step': n,
-            'achieved': fl / gms / 1e9, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': fl / gms / 1e9 / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+            'achieved': fl / gms / 1e9, 'peak': peak_of(dom[0]), 'unit': 'TFLOP/s',
+            'frac': fl / gms / 1e9 / peak_of(dom[0]), 'traffic': None,
             'avg_launch_ms': gms / n, 'algorithmic_gflop_per_launch': fl / n / 1e9,
             'all_mfma_kernels': {'achieved': all_fl / all_ms / 1e9, 'gflop_per_step': all_fl / 1e9,
                                  'ms_per_step': all_ms},
@@ -247,7 +259,7 @@ def main():
     if world > 1:
         sync()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline({k: v for k, v in cfg.items() if k not in ('device', 'seed')},
+        result['cpu_baseline'] = cpu_baseline({k: v for k, v in cfg.items() if k not in ('device', 'seed', 'precision')},
                                               shape, usable_cpus())
     if rank == 0:
         print(json.dumps(result))

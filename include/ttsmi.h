@@ -233,6 +233,35 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
                       const int32_t* mel_ptr, const float* mel_w, int normalizer, float clip_min,
                       float* out, ttsmi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * TTSMI_BF16 GEMM path: bf16 operands (round to nearest even), fp32 accumulate on
+ * v_mfma_f32_32x32x16_bf16, fp32 results.  Same reference ops as the fp32 family above
+ * (Dense / Conv1D forward, dgrad, wgrad); the callers provide K-contiguous operands:
+ *
+ * ttsmi_hgemm_tn:  c[M,N] = act( sum_k a[m,k] * b[n,k] + bias ) * (relu_src > 0)
+ *   a: fp32 [M,K] (a_is_f32, converted while staging; optional second K segment a2 from column K1;
+ *      optional Conv1D window: conv_taps > 1 reads the contiguous window of conv_taps*conv_C values
+ *      starting conv_pad frames before row m of a [B*conv_T, conv_C] activation, zero outside the
+ *      sequence) or bf16 [M,K].   b: bf16 [N,K] - W^T for forward, W as stored for dgrad
+ *      (rows = k_in), conv weights pre-laid-out by ttsmi_cast_transpose_bf16 / ttsmi_conv_wdgrad_layout_bf16.
+ * ttsmi_hgemm_wgrad: dw[kin,n] = xT[kin,rows] . dyT[n,rows]^T (+ db[n] = row sums of dyT), operands
+ *   produced by ttsmi_cast_transpose_bf16 with leading dimension ldt (multiple of 8, zero tail).
+ * ttsmi_cast_transpose_bf16: dst[j*C + c][r] = bf16(src[r + j - pad][c]) (0 outside the sequence
+ *   of length T when taps > 1); taps == 1 is a plain cast-transpose.  dst rows have ld_dst >= R.
+ * ------------------------------------------------------------------------------------------- */
+int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int64_t lda2, int K1,
+                   const uint16_t* b, int64_t ldb, const float* bias, const float* relu_src,
+                   int64_t ld_relu, float* c, int64_t ldc, int M, int N, int K, int relu, int conv_taps,
+                   int conv_T, int conv_C, int conv_pad, ttsmi_stream_t stream);
+size_t ttsmi_hgemm_wgrad_ws_bytes(int rows, int kin, int n);
+int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, float* dw, int64_t lddw,
+                      float* db, int rows, int kin, int n, void* ws, size_t ws_bytes,
+                      ttsmi_stream_t stream);
+int ttsmi_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int R,
+                              int C, int taps, int T, int pad, ttsmi_stream_t stream);
+int ttsmi_conv_wdgrad_layout_bf16(const float* w, uint16_t* dst, int k, int Cin, int Cout,
+                                  ttsmi_stream_t stream);
+
 /* Utility: fp32 -> bf16 (round to nearest even) for the TTSMI_BF16 weight copies. */
 int ttsmi_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, ttsmi_stream_t stream);
 

@@ -225,3 +225,31 @@ def test_mel_analytic_and_wavernn_normalizer():
     assert np.abs(got - want).max() < 2e-3             # dB-domain normalisation (range [-4, 4])
     with pytest.raises(Exception):
         _audio(n_fft=2048, win_length=1100, hop_length=275).mel_spectrogram(y)
+
+
+# ---------------------------------------------------------------------------------------- bf16 path
+def test_bf16_precision_tracks_oracle_within_bf16_tolerance(tiny):
+    """TTSMI_BF16 (bf16 operands, fp32 accumulate): not part of the 1e-4 contract; bound stated here:
+    loss within 5e-3 relative, mel within 3e-2 of its max, 20 Adam steps end within 5 % of
+    the fp64 oracle does."""
+    cfg, W = tiny
+    batch = fo.synthetic_batch(4, 50, 200, seed=12, ragged=True)
+    ref = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    ref.learning_rate = 1e-3
+    m = _model(cfg, W, precision='bf16')
+    assert m.precision == 'bf16' and len(m.shadow) > 0
+    m._compile(learning_rate=1e-3)
+    want = ref.val_step(*batch)
+    got = m.val_step(*batch)
+    assert abs(float(got['loss']) - float(want['loss'])) / float(want['loss']) < 5e-3
+    assert _rel(got['mel'], want['mel']) < 3e-2
+    lg, lw = [], []
+    for _ in range(20):
+        lg.append(float(m.train_step(*batch)['loss']))
+        lw.append(float(ref.train_step(*batch)['loss']))
+    assert lg[-1] < 0.9 * lg[0]
+    assert abs(lg[-1] - lw[-1]) / lw[-1] < 5e-2
+    # shadows follow the master weights after every optimiser step
+    sh = m.shadow['out.w']
+    assert torch.equal(sh.wb, m.params.w['out.w'].detach().to(torch.bfloat16))
+    assert torch.equal(sh.wt, m.params.w['out.w'].detach().t().contiguous().to(torch.bfloat16))

@@ -448,3 +448,116 @@ def test_l1_loss_and_adam():
         pw = pw - lr_t * mw / (vw.sqrt() + 1e-9)
     assert int(step.item()) == 3
     assert rel_err(p, pw) < 1e-6
+
+
+# ------------------------------------------------------------------------------------ bf16 GEMM path
+def _bf(x):
+    return x.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize('M,K,N', [(128, 256, 256), (333, 64, 200), (1000, 512, 80), (77, 1024, 130), (5, 8, 3)])
+def test_hgemm_tn_matches_bf16_rounded_reference(M, K, N):
+    ops = _ops()
+    x, w, b = g(M, K, seed=1), g(K, N, seed=2), g(N, seed=3)
+    sh = ops.make_shadow(w.to(DEV))
+    assert torch.equal(sh.wb.cpu(), w.to(torch.bfloat16)) and torch.equal(sh.wt.cpu(), w.t().to(torch.bfloat16))
+    y = ops.hgemm_tn(x.to(DEV), sh.wt, b.to(DEV), relu=True)
+    want = (_bf(x) @ _bf(w) + b.double()).relu()
+    assert rel_err(y, want) < 3e-6                       # only fp32 accumulation error remains
+    dy, h = g(M, N, seed=4), g(M, K, seed=5)
+    if N % 8 == 0:
+        dx = ops.hgemm_tn(dy.to(DEV), sh.wb, relu_src=h.to(DEV))
+        assert rel_err(dx, (_bf(dy) @ _bf(w).T) * (h > 0)) < 3e-6
+    dw = torch.empty(K, N, device=DEV)
+    db = torch.empty(N, device=DEV)
+    ops.hgemm_wgrad(ops.cast_transpose_bf16(x.to(DEV)), ops.cast_transpose_bf16(dy.to(DEV)), dw, db, M)
+    assert rel_err(dw, _bf(x).T @ _bf(dy)) < 3e-6
+    assert rel_err(db, _bf(dy).sum(0)) < 3e-6
+    # and the whole thing is a faithful bf16 approximation of the fp32 op
+    assert rel_err(y, (x.double() @ w.double() + b.double()).relu()) < 2e-2
+
+
+def test_hgemm_dual_a_and_cast_transpose_conv():
+    ops = _ops()
+    M, K1, K2, N = 300, 64, 192, 72
+    x, x2, w = g(M, K1, seed=1), g(M, K2, seed=2), g(K1 + K2, N, seed=3)
+    sh = ops.make_shadow(w.to(DEV))
+    y = ops.hgemm_tn(x.to(DEV), sh.wt, None, False, x2.to(DEV))
+    assert rel_err(y, torch.cat([_bf(x), _bf(x2)], 1) @ _bf(w)) < 3e-6
+    # transposed im2col written by the cast kernel == unfold of the zero-padded sequence
+    B, T, C, k = 3, 11, 8, 3
+    xs = g(B, T, C, seed=4)
+    xt = ops.cast_transpose_bf16(xs.reshape(B * T, C).to(DEV), taps=k, T=T, pad=1).cpu().float()
+    assert xt.shape == (k * C, (B * T + 7) // 8 * 8)
+    xp = torch.nn.functional.pad(xs.to(torch.bfloat16).float(), (0, 0, 1, 1))
+    for j in range(k):
+        want = xp[:, j:j + T, :].reshape(B * T, C).t()
+        assert torch.equal(xt[j * C:(j + 1) * C, :B * T], want)
+    assert float(xt[:, B * T:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('Cout', [64, 226])
+def test_bf16_conv_predictor_layer_autograd(Cout):
+    ops = _ops()
+    B, T, Cin, k = 2, 37, 64, 3
+    x, w, b = g(B, T, Cin, seed=1), g(k, Cin, Cout, seed=2, scale=0.2), g(Cout, seed=3)
+    ts = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+    sh = ops.make_shadow(ts[1])
+    h = ops.ConvReluPreMaskedFn.apply(ts[0], ts[1], ts[2], None, None, sh)
+    td = [_bf(x).requires_grad_(), _bf(w).requires_grad_(), b.double().requires_grad_()]
+    hd = fo.conv1d_same(td[0], td[1], td[2]).relu()
+    assert rel_err(h.detach(), hd.detach()) < 3e-6
+    dh = g(B, T, Cout, seed=4) * (hd.detach() > 0).float()          # pre-masked upstream gradient
+    h.backward(dh.to(DEV))
+    # reference backward with bf16-rounded dh on the GEMM operands
+    pre = fo.conv1d_same(td[0], td[1], td[2])
+    pre.backward(_bf(dh))
+    assert rel_err(ts[1].grad, td[1].grad) < 1e-5
+    assert rel_err(ts[0].grad, td[0].grad) < (1e-5 if Cout % 8 == 0 else 2e-2)   # 226: fp32 dgrad of unrounded dh
+    assert rel_err(ts[2].grad, _bf(dh).sum((0, 1))) < 1e-5
+
+
+@pytest.mark.parametrize('B,H,T,dh', [(2, 2, 50, 32), (3, 4, 200, 64), (2, 4, 333, 64), (1, 4, 900, 64)])
+def test_bf16_attention_fwd_bwd(B, H, T, dh):
+    """TTSMI_BF16 attention vs the fp64 reference evaluated on bf16-rounded q/k/v: what remains is
+    the bf16 rounding of P (and dS / dO), i.e. ~2^-9 relative per element, averaged by the sums."""
+    ops = _ops()
+    from transformertts_amd._lib import TTSMI_BF16
+    d = H * dh
+    qkv = g(B * T, 3 * d, seed=1).to(torch.bfloat16).float()           # exactly representable inputs
+    lens = torch.tensor([T] + [max(1, (T * (i + 1)) // (B + 1)) for i in range(B - 1)])
+    pad = (torch.arange(T)[None, :] >= lens[:, None]).to(torch.uint8)
+    if T > 10:
+        pad[0, 3] = 1
+    klen = torch.zeros(B, dtype=torch.int32)
+    for i, p in enumerate(pad):
+        nz = (p == 0).nonzero()
+        klen[i] = T if len(nz) == 0 else int(nz.max()) + 1
+    qg = qkv.to(DEV).requires_grad_()
+    ctx, lse = ops.AttentionFn.apply(qg, pad.to(DEV), klen.to(DEV), B, H, T, dh, 0.0, None, 0, TTSMI_BF16)
+    qd = qkv.double().requires_grad_()
+    want, _ = _attn_ref(qd, pad, B, H, T, dh)
+    assert rel_err(ctx.detach(), want.detach()) < 6e-3
+    dctx = g(B * T, d, seed=2).to(torch.bfloat16).float()
+    ctx.backward(dctx.to(DEV))
+    want.backward(dctx.double())
+    assert rel_err(qg.grad, qd.grad) < 2e-2
+    # fp32 kernels on the same inputs agree with the bf16 kernels to bf16 accuracy
+    q2 = qkv.to(DEV).requires_grad_()
+    c2, _ = ops.AttentionFn.apply(q2, pad.to(DEV), klen.to(DEV), B, H, T, dh, 0.0, None, 0)
+    assert rel_err(ctx.detach(), c2.detach()) < 6e-3
+
+
+def test_bf16_attention_dropout_matches_fp32_mask():
+    """Both precisions draw the SAME dropout mask (same hash, same element index)."""
+    ops = _ops()
+    from transformertts_amd._lib import TTSMI_BF16
+    B, H, T, dh, p = 2, 2, 150, 32, 0.25
+    qkv = g(B * T, 3 * H * dh, seed=1).to(torch.bfloat16).float().to(DEV)
+    pad = torch.zeros(B, T, dtype=torch.uint8, device=DEV)
+    klen = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    drop = ops.DropCtx(seed=7)
+    a, _ = ops.AttentionFn.apply(qkv, pad, klen, B, H, T, dh, p, drop, 9, TTSMI_BF16)
+    b, _ = ops.AttentionFn.apply(qkv, pad, klen, B, H, T, dh, p, drop, 9)
+    c, _ = ops.AttentionFn.apply(qkv, pad, klen, B, H, T, dh, p, drop, 10)
+    assert rel_err(a, b) < 1e-2 and rel_err(c, b) > 5e-2

@@ -15,8 +15,8 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(LIBDIR, 'libttsmi.so')
-SOURCES = ['api.cpp', 'gemm.hip', 'attention.hip', 'layernorm.hip', 'elementwise.hip', 'lenreg.hip',
-           'stft_mel.hip']
+SOURCES = ['api.cpp', 'gemm.hip', 'gemm_bf16.hip', 'attention.hip', 'attention_bf16.hip', 'layernorm.hip',
+           'elementwise.hip', 'lenreg.hip', 'stft_mel.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 
 

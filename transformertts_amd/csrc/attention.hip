@@ -500,6 +500,9 @@ extern "C" {
 int ttsmi_attention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
                         float* lse, int B, int H, int T, int dh, float p_drop, uint64_t seed,
                         const int64_t* step_dev, uint32_t site, int dtype, ttsmi_stream_t stream) {
+    if (dtype == TTSMI_BF16)
+        return ttsmi_hattention_fwd(qkv, key_pad, klen, ctx, lse, B, H, T, dh, p_drop, seed, step_dev, site,
+                                    (hipStream_t)stream);
     AttnP p;
     int rc = fill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, dtype, "attention_fwd");
     if (rc) return rc;
@@ -522,6 +525,12 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
                         int H, int T, int dh, float p_drop, uint64_t seed, const int64_t* step_dev,
                         uint32_t site, void* ws, size_t ws_bytes, int dtype,
                         ttsmi_stream_t stream) {
+    if (dtype == TTSMI_BF16) {
+        TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_attention_bwd_ws_bytes(B, H, T, dh),
+                        "attention_bwd: workspace too small");
+        return ttsmi_hattention_bwd(qkv, key_pad, klen, ctx, dctx, lse, dqkv, B, H, T, dh, p_drop, seed,
+                                    step_dev, site, ws, (hipStream_t)stream);
+    }
     AttnP p;
     int rc = fill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, dtype, "attention_bwd");
     if (rc) return rc;
@@ -544,7 +553,10 @@ int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float
                             uint64_t seed, const int64_t* step_dev, uint32_t site, int dtype,
                             ttsmi_stream_t stream) {
     AttnP p;
-    int rc = fill(p, qkv, key_pad, nullptr, B, H, T, dh, p_drop, seed, step_dev, site, dtype, "attention_weights");
+    // TTSMI_BF16 callers get the maps recomputed from the fp32 q/k with the exact-fp32 MFMA (they are
+    // a logging output; rows sum to 1 up to the bf16 rounding of the forward's log-sum-exp)
+    (void)dtype;
+    int rc = fill(p, qkv, key_pad, nullptr, B, H, T, dh, p_drop, seed, step_dev, site, TTSMI_F32, "attention_weights");
     if (rc) return rc;
     TTSMI_CHECK_ARG(lse && weights, "attention_weights: null pointer");
     p.lse = (float*)lse; p.weights = weights;

@@ -1,0 +1,551 @@
+// TTSMI_BF16 fused self-attention: bf16 operands (Q, K, V, P, dO, dS rounded to nearest even),
+// fp32 accumulate on v_mfma_f32_32x32x16_bf16, fp32 softmax statistics, fp32 I/O in HBM.
+// Same structure, masking rule, dropout stream and two-pass deterministic backward as the exact-fp32
+// kernels in attention.hip (see the header comment there); what changes is the operand plumbing:
+//
+//  * an MFMA 32x32x16 operand is 8 consecutive-k bf16 per lane.  The "register feedback" trick
+//    survives: accumulator registers 8t..8t+7 of a score tile, converted to bf16, ARE the B operand
+//    of k-step t of the following MFMA chain; the reduction index they represent is
+//    rowmap(8t+e, hh) = 16t + 8*(e>>2) + 4*hh + (e&3), so the matching A operand (V^T, K^T, dO^T or
+//    Q^T) is two 8-byte LDS reads from a TRANSPOSED tile image [c][key] at key offsets
+//    16t + 4hh and 16t + 8 + 4hh.
+//  * tiles that feed a "row" operand (K for QK^T, V for dP, Q / dO in the dK/dV pass) are staged
+//    row-major [row][DH+8] (144-byte rows: conflict-free ds_read_b128); tiles that feed a
+//    "transposed" operand are staged as [c][64+4] (136-byte rows: conflict-free ds_read_b64), the
+//    transposition being done by the staging threads (two rows packed per 32-bit LDS write).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+struct HAttnP {
+    const float* qkv; long ld;
+    const uint8_t* key_pad; const int32_t* klen;
+    float* ctx; float* lse;
+    const float* dctx; const float* octx; float* dqkv; float* delta;
+    int B, H, T;
+    float sqrt_dk;
+    uint32_t thr; float inv_keep; uint64_t seed; const int64_t* step_dev; uint32_t site;
+};
+
+__device__ __forceinline__ int rowmap16(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+#define HKT 64                 // rows (keys or queries) per staged tile
+#define TLD (HKT + 4)          // transposed image row stride (bf16 elements)
+
+// ---- row-major staging: [HKT][DH] fp32 rows -> bf16 [HKT][DH+8] ----------------------------------
+template <int DH>
+__device__ __forceinline__ void rows_fetch(const float* base, long ld, int row0, int nvalid, int tid,
+                                           float4 (&r)[DH / 16]) {
+    constexpr int V4 = DH / 4;
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i) {
+        int id = tid + 256 * i;
+        int row = id / V4, c4 = id - row * V4;
+        r[i] = (row < nvalid) ? *reinterpret_cast<const float4*>(base + (long)(row0 + row) * ld + c4 * 4)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int DH>
+__device__ __forceinline__ void rows_stash(uint16_t* S, int tid, const float4 (&r)[DH / 16]) {
+    constexpr int V4 = DH / 4, LD = DH + 8;
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i) {
+        int id = tid + 256 * i;
+        int row = id / V4, c4 = id - row * V4;
+        bf16x4 h;
+        h[0] = (__bf16)r[i].x; h[1] = (__bf16)r[i].y; h[2] = (__bf16)r[i].z; h[3] = (__bf16)r[i].w;
+        *reinterpret_cast<uint2*>(S + row * LD + c4 * 4) = *reinterpret_cast<uint2*>(&h);
+    }
+}
+// ---- transposed staging: rows (2p, 2p+1) x 4 columns per work item -> [c][TLD] -------------------
+template <int DH>
+__device__ __forceinline__ void trans_fetch(const float* base, long ld, int row0, int nvalid, int tid,
+                                            float4 (&r)[DH / 16]) {
+#pragma unroll
+    for (int i = 0; i < DH / 32; ++i) {
+        int id = tid + 256 * i;
+        int p = id & 31, c4 = id >> 5;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int row = 2 * p + e;
+            r[2 * i + e] = (row < nvalid)
+                               ? *reinterpret_cast<const float4*>(base + (long)(row0 + row) * ld + c4 * 4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+template <int DH>
+__device__ __forceinline__ void trans_stash(uint16_t* St, int tid, const float4 (&r)[DH / 16]) {
+#pragma unroll
+    for (int i = 0; i < DH / 32; ++i) {
+        int id = tid + 256 * i;
+        int p = id & 31, c4 = id >> 5;
+        const float4 a = r[2 * i], b = r[2 * i + 1];
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16x2 h;
+            h[0] = (__bf16)av[e]; h[1] = (__bf16)bv[e];
+            *reinterpret_cast<uint32_t*>(St + (c4 * 4 + e) * TLD + 2 * p) = *reinterpret_cast<uint32_t*>(&h);
+        }
+    }
+}
+
+// one wave's 32 rows as MFMA "row" operand fragments: frag[s] = row[16s + 8g .. +7]
+template <int DH>
+__device__ __forceinline__ void row_frags(const float* base, long ld, int row, bool valid, int g,
+                                          bf16x8 (&f)[DH / 16]) {
+    const float* src = base + (long)row * ld + 8 * g;
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (valid) {
+            a = *reinterpret_cast<const float4*>(src + 16 * s);
+            b = *reinterpret_cast<const float4*>(src + 16 * s + 4);
+        }
+        f[s][0] = (__bf16)a.x; f[s][1] = (__bf16)a.y; f[s][2] = (__bf16)a.z; f[s][3] = (__bf16)a.w;
+        f[s][4] = (__bf16)b.x; f[s][5] = (__bf16)b.y; f[s][6] = (__bf16)b.z; f[s][7] = (__bf16)b.w;
+    }
+}
+
+// acc[i][j] = sum_c S[row i][c] * f_j[c]   (A from the row-major LDS image, B from registers)
+template <int DH>
+__device__ __forceinline__ f32x16 dot16(const uint16_t* S, int row, int g, const bf16x8 (&f)[DH / 16]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const uint16_t* src = S + row * (DH + 8) + 8 * g;
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+        acc = MFMA16(a, f[s], acc);
+    }
+    return acc;
+}
+
+// score tile registers -> two bf16 B-operand fragments (k-steps t = 0, 1)
+__device__ __forceinline__ void to_frags(const f32x16& p, bf16x8 (&pb)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pb[t][e] = (__bf16)p[8 * t + e];
+}
+
+// out[cb][c][lane col] += sum_key St[c][k0 + key] * P[key][col]
+template <int DH>
+__device__ __forceinline__ void accumT16(const uint16_t* St, int k0, int l31, int g, const bf16x8 (&pb)[2],
+                                         f32x16 (&out)[DH / 32]) {
+#pragma unroll
+    for (int cb = 0; cb < DH / 32; ++cb) {
+        const uint16_t* row = St + (cb * 32 + l31) * TLD + k0 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            uint2 lo = *reinterpret_cast<const uint2*>(row + 16 * t);
+            uint2 hi = *reinterpret_cast<const uint2*>(row + 16 * t + 8);
+            uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            out[cb] = MFMA16(*reinterpret_cast<bf16x8*>(&v), pb[t], out[cb]);
+        }
+    }
+}
+
+template <int DH>
+__device__ __forceinline__ void storeT16(float* patch, const f32x16 (&o)[DH / 32], float scale_lane,
+                                         float* dst, long ld, int row0, int nvalid, int lane) {
+    const int l31 = lane & 31, hh = lane >> 5;
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < DH / 32; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[l31 * (DH + 1) + cb * 32 + rowmap16(r, hh)] = o[cb][r] * scale_lane;
+    __syncthreads();
+    for (int j = 0; j < 32; ++j) {
+        if (j >= nvalid) break;
+        for (int c = lane; c < DH; c += 64) dst[(long)(row0 + j) * ld + c] = patch[j * (DH + 1) + c];
+    }
+}
+
+template <int DH>
+struct HSm {
+    static constexpr int ROWS = HKT * (DH + 8);      // uint16 elements of a row-major image
+    static constexpr int TRN = DH * TLD;             // uint16 elements of a transposed image
+    static constexpr int PATCH_BYTES = 4 * 32 * (DH + 1) * 4;
+};
+
+// =================================================================================================
+// forward
+// =================================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
+    using SM = HSm<DH>;
+    constexpr int TILE_BYTES = (SM::ROWS + SM::TRN) * 2;
+    constexpr int MAIN = TILE_BYTES > SM::PATCH_BYTES ? TILE_BYTES : SM::PATCH_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + HKT * 4];
+    uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* Vt = Ks + SM::ROWS;
+    float* padS = reinterpret_cast<float*>(smem + MAIN);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int d = p.H * DH;
+    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const bool qok = q < p.T;
+    const uint64_t seed = ttsmi_step_seed(p.seed, p.step_dev);
+    const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
+    const float* Kb = Qb + d;
+    const float* Vb = Qb + 2 * d;
+
+    bf16x8 qf[DH / 16];
+    row_frags<DH>(Qb, p.ld, q, qok, hh, qf);
+    f32x16 o[DH / 32];
+#pragma unroll
+    for (int cb = 0; cb < DH / 32; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int klen = p.klen[b];
+    const long drop_row = (((long)b * p.H + h) * p.T + q) * (long)p.T;
+    const float inv_sqrt = 1.0f / p.sqrt_dk;
+
+    float4 rk[DH / 16], rv[DH / 16];
+    float rpad = 0.f;
+    {
+        int nv = min(HKT, klen);
+        rows_fetch<DH>(Kb, p.ld, 0, nv, tid, rk);
+        trans_fetch<DH>(Vb, p.ld, 0, nv, tid, rv);
+        if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + tid]) ? 1.f : 0.f;
+    }
+    for (int k0 = 0; k0 < klen; k0 += HKT) {
+        __syncthreads();
+        rows_stash<DH>(Ks, tid, rk);
+        trans_stash<DH>(Vt, tid, rv);
+        if (tid < HKT) padS[tid] = rpad;
+        __syncthreads();
+        if (k0 + HKT < klen) {
+            int nv = min(HKT, klen - (k0 + HKT));
+            rows_fetch<DH>(Kb, p.ld, k0 + HKT, nv, tid, rk);
+            trans_fetch<DH>(Vb, p.ld, k0 + HKT, nv, tid, rv);
+            if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + k0 + HKT + tid]) ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int kt = 0; kt < HKT / 32; ++kt) {
+            if (k0 + kt * 32 >= klen) break;
+            f32x16 s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                 // S^T[key][q]
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int kl = kt * 32 + rowmap16(r, hh);
+                float v = s[r] * inv_sqrt;
+                v += padS[kl] * -1e9f;
+                if (k0 + kl >= klen) v = -INFINITY;
+                s[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float mn = fmaxf(m, mx);
+            float alpha = __expf(m - mn);
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float e = __expf(s[r] - mn);
+                rs += e;
+                if (p.thr) {
+                    int key = k0 + kt * 32 + rowmap16(r, hh);
+                    e *= ttsmi_keep_scale(seed, p.site, (uint64_t)(drop_row + key), p.thr, p.inv_keep);
+                }
+                s[r] = e;
+            }
+            rs += __shfl_xor(rs, 32, 64);
+            l = l * alpha + rs;
+            m = mn;
+#pragma unroll
+            for (int cb = 0; cb < DH / 32; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+            bf16x8 pb[2];
+            to_frags(s, pb);
+            accumT16<DH>(Vt, kt * 32, l31, hh, pb, o);                        // O^T += V^T.P^T
+        }
+    }
+    __syncthreads();
+    if (qok && hh == 0) p.lse[((long)b * p.H + h) * p.T + q] = m + logf(l);
+    float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
+    int row0 = blockIdx.x * 128 + wave * 32;
+    int nvalid = min(32, p.T - row0);
+    storeT16<DH>(patch, o, 1.0f / l, p.ctx + (long)b * p.T * d + h * DH, d, row0, nvalid, lane);
+}
+
+// =================================================================================================
+// backward A: dQ (+ delta)
+// =================================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
+    using SM = HSm<DH>;
+    constexpr int TILE_BYTES = (2 * SM::ROWS + SM::TRN) * 2;
+    constexpr int MAIN = TILE_BYTES > SM::PATCH_BYTES ? TILE_BYTES : SM::PATCH_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + HKT * 4];
+    uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* Vs = Ks + SM::ROWS;
+    uint16_t* Kt = Vs + SM::ROWS;
+    float* padS = reinterpret_cast<float*>(smem + MAIN);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int d = p.H * DH;
+    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const bool qok = q < p.T;
+    const uint64_t seed = ttsmi_step_seed(p.seed, p.step_dev);
+    const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
+    const float* Kb = Qb + d;
+    const float* Vb = Qb + 2 * d;
+    const float* dOb = p.dctx + (long)b * p.T * d + h * DH;
+    const float* Ob = p.octx + (long)b * p.T * d + h * DH;
+
+    bf16x8 qf[DH / 16], dof[DH / 16];
+    row_frags<DH>(Qb, p.ld, q, qok, hh, qf);
+    row_frags<DH>(dOb, d, q, qok, hh, dof);
+    float delta = 0.f;                         // rowsum(dO * O) in fp32 from the fp32 tensors
+    if (qok) {
+        const float* a = dOb + (long)q * d + hh * (DH / 2);
+        const float* c = Ob + (long)q * d + hh * (DH / 2);
+#pragma unroll
+        for (int i = 0; i < DH / 8; ++i) {
+            float4 x = *reinterpret_cast<const float4*>(a + 4 * i), y = *reinterpret_cast<const float4*>(c + 4 * i);
+            delta += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const long sidx = ((long)b * p.H + h) * p.T + q;
+    if (qok && hh == 0) p.delta[sidx] = delta;
+    const float lse = qok ? p.lse[sidx] : INFINITY;
+
+    f32x16 dq[DH / 32];
+#pragma unroll
+    for (int cb = 0; cb < DH / 32; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[cb][r] = 0.f;
+    const int klen = p.klen[b];
+    const long drop_row = sidx * (long)p.T;
+    const float inv_sqrt = 1.0f / p.sqrt_dk;
+
+    float4 rk[DH / 16], rv[DH / 16], rkt[DH / 16];
+    float rpad = 0.f;
+    {
+        int nv = min(HKT, klen);
+        rows_fetch<DH>(Kb, p.ld, 0, nv, tid, rk);
+        rows_fetch<DH>(Vb, p.ld, 0, nv, tid, rv);
+        trans_fetch<DH>(Kb, p.ld, 0, nv, tid, rkt);
+        if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + tid]) ? 1.f : 0.f;
+    }
+    for (int k0 = 0; k0 < klen; k0 += HKT) {
+        __syncthreads();
+        rows_stash<DH>(Ks, tid, rk);
+        rows_stash<DH>(Vs, tid, rv);
+        trans_stash<DH>(Kt, tid, rkt);
+        if (tid < HKT) padS[tid] = rpad;
+        __syncthreads();
+        if (k0 + HKT < klen) {
+            int nv = min(HKT, klen - (k0 + HKT));
+            rows_fetch<DH>(Kb, p.ld, k0 + HKT, nv, tid, rk);
+            rows_fetch<DH>(Vb, p.ld, k0 + HKT, nv, tid, rv);
+            trans_fetch<DH>(Kb, p.ld, k0 + HKT, nv, tid, rkt);
+            if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + k0 + HKT + tid]) ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int kt = 0; kt < HKT / 32; ++kt) {
+            if (k0 + kt * 32 >= klen) break;
+            f32x16 s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                 // S^T
+            f32x16 dp = dot16<DH>(Vs, kt * 32 + l31, hh, dof);               // dP^T = V.dO^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int kl = kt * 32 + rowmap16(r, hh);
+                float v = s[r] * inv_sqrt + padS[kl] * -1e9f;
+                float pr = (k0 + kl >= klen) ? 0.f : __expf(v - lse);
+                float keep = 1.f;
+                if (p.thr) keep = ttsmi_keep_scale(seed, p.site, (uint64_t)(drop_row + k0 + kl), p.thr, p.inv_keep);
+                s[r] = pr * (keep * dp[r] - delta) * inv_sqrt;               // dS^T
+            }
+            bf16x8 pb[2];
+            to_frags(s, pb);
+            accumT16<DH>(Kt, kt * 32, l31, hh, pb, dq);                       // dQ^T += K^T.dS^T
+        }
+    }
+    __syncthreads();
+    float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
+    int row0 = blockIdx.x * 128 + wave * 32;
+    int nvalid = min(32, p.T - row0);
+    storeT16<DH>(patch, dq, 1.0f, p.dqkv + (long)b * p.T * p.ld + h * DH, p.ld, row0, nvalid, lane);
+}
+
+// =================================================================================================
+// backward B: dK, dV (workgroup owns 128 keys, loops over queries)
+// =================================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
+    using SM = HSm<DH>;
+    constexpr int TILE_BYTES = (2 * SM::ROWS + 2 * SM::TRN) * 2;
+    constexpr int MAIN = TILE_BYTES > SM::PATCH_BYTES ? TILE_BYTES : SM::PATCH_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + 2 * HKT * 4];
+    uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* Os = Qs + SM::ROWS;
+    uint16_t* Qt = Os + SM::ROWS;
+    uint16_t* Ot = Qt + SM::TRN;
+    float* lseS = reinterpret_cast<float*>(smem + MAIN);
+    float* delS = lseS + HKT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int d = p.H * DH;
+    const int key = blockIdx.x * 128 + wave * 32 + l31;
+    const int klen = p.klen[b];
+    const bool kok = key < p.T;
+    const bool kact = key < klen;
+    const uint64_t seed = ttsmi_step_seed(p.seed, p.step_dev);
+    const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
+    const float* Kb = Qb + d;
+    const float* Vb = Qb + 2 * d;
+    const float* dOb = p.dctx + (long)b * p.T * d + h * DH;
+
+    bf16x8 kf[DH / 16], vf[DH / 16];
+    row_frags<DH>(Kb, p.ld, key, kok, hh, kf);
+    row_frags<DH>(Vb, p.ld, key, kok, hh, vf);
+    const float padterm = (kok && p.key_pad[(long)b * p.T + key]) ? -1e9f : 0.f;
+
+    f32x16 dk[DH / 32], dv[DH / 32];
+#pragma unroll
+    for (int cb = 0; cb < DH / 32; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[cb][r] = 0.f; dv[cb][r] = 0.f; }
+    const float inv_sqrt = 1.0f / p.sqrt_dk;
+    const long stat0 = ((long)b * p.H + h) * p.T;
+
+    const bool wg_active = blockIdx.x * 128 < klen;
+    if (wg_active) {
+        float4 rq[DH / 16], ro[DH / 16], rqt[DH / 16], rot[DH / 16];
+        float rl = 0.f, rd = 0.f;
+        {
+            int nv = min(HKT, p.T);
+            rows_fetch<DH>(Qb, p.ld, 0, nv, tid, rq);
+            rows_fetch<DH>(dOb, d, 0, nv, tid, ro);
+            trans_fetch<DH>(Qb, p.ld, 0, nv, tid, rqt);
+            trans_fetch<DH>(dOb, d, 0, nv, tid, rot);
+            if (tid < HKT) {
+                rl = tid < nv ? p.lse[stat0 + tid] : INFINITY;
+                rd = tid < nv ? p.delta[stat0 + tid] : 0.f;
+            }
+        }
+        for (int q0 = 0; q0 < p.T; q0 += HKT) {
+            __syncthreads();
+            rows_stash<DH>(Qs, tid, rq);
+            rows_stash<DH>(Os, tid, ro);
+            trans_stash<DH>(Qt, tid, rqt);
+            trans_stash<DH>(Ot, tid, rot);
+            if (tid < HKT) { lseS[tid] = rl; delS[tid] = rd; }
+            __syncthreads();
+            if (q0 + HKT < p.T) {
+                int nv = min(HKT, p.T - (q0 + HKT));
+                rows_fetch<DH>(Qb, p.ld, q0 + HKT, nv, tid, rq);
+                rows_fetch<DH>(dOb, d, q0 + HKT, nv, tid, ro);
+                trans_fetch<DH>(Qb, p.ld, q0 + HKT, nv, tid, rqt);
+                trans_fetch<DH>(dOb, d, q0 + HKT, nv, tid, rot);
+                if (tid < HKT) {
+                    rl = tid < nv ? p.lse[stat0 + q0 + HKT + tid] : INFINITY;
+                    rd = tid < nv ? p.delta[stat0 + q0 + HKT + tid] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int qt = 0; qt < HKT / 32; ++qt) {
+                if (q0 + qt * 32 >= p.T) break;
+                f32x16 s = dot16<DH>(Qs, qt * 32 + l31, hh, kf);             // S[q][key]
+                f32x16 dp = dot16<DH>(Os, qt * 32 + l31, hh, vf);            // dP = dO.V^T
+                f32x16 pt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int ql = qt * 32 + rowmap16(r, hh);
+                    float v = s[r] * inv_sqrt + padterm;
+                    float pr = kact ? __expf(v - lseS[ql]) : 0.f;
+                    float keep = 1.f;
+                    if (p.thr)
+                        keep = ttsmi_keep_scale(seed, p.site, (uint64_t)((stat0 + q0 + ql) * (long)p.T + key),
+                                                p.thr, p.inv_keep);
+                    pt[r] = pr * keep;
+                    s[r] = pr * (keep * dp[r] - delS[ql]) * inv_sqrt;
+                }
+                bf16x8 pb[2], sb[2];
+                to_frags(pt, pb);
+                to_frags(s, sb);
+                accumT16<DH>(Ot, qt * 32, l31, hh, pb, dv);                   // dV^T += dO^T.P
+                accumT16<DH>(Qt, qt * 32, l31, hh, sb, dk);                   // dK^T += Q^T.dS
+            }
+        }
+    }
+    __syncthreads();
+    float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
+    int row0 = blockIdx.x * 128 + wave * 32;
+    int nvalid = min(32, p.T - row0);
+    float* dst = p.dqkv + (long)b * p.T * p.ld + h * DH;
+    storeT16<DH>(patch, dk, 1.0f, dst + d, p.ld, row0, nvalid, lane);
+    storeT16<DH>(patch, dv, 1.0f, dst + 2 * d, p.ld, row0, nvalid, lane);
+}
+
+// ---- host ---------------------------------------------------------------------------------------
+static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32_t* klen, int B, int H,
+                 int T, int dh, float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site,
+                 const char* who) {
+    TTSMI_CHECK_ARG(qkv && key_pad && klen, "%s: null pointer", who);
+    TTSMI_CHECK_ARG(B > 0 && H > 0 && T > 0, "%s: bad shape", who);
+    TTSMI_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: dropout rate out of [0,1)", who);
+    TTSMI_CHECK_ARG((((uintptr_t)qkv) & 15) == 0, "%s: qkv must be 16-byte aligned", who);
+    memset(&p, 0, sizeof(p));
+    p.qkv = (const float*)qkv; p.ld = 3L * H * dh; p.key_pad = key_pad; p.klen = klen;
+    p.B = B; p.H = H; p.T = T; p.sqrt_dk = sqrtf((float)dh);
+    p.thr = p_drop > 0.f ? ttsmi_drop_threshold(p_drop) : 0;
+    p.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.f;
+    p.seed = seed; p.step_dev = step_dev; p.site = site;
+    return TTSMI_OK;
+}
+
+#define HDISPATCH(dh, KERNEL, grid, st, p)                                                     \
+    switch (dh) {                                                                              \
+        case 32: hipLaunchKernelGGL((KERNEL<32>), grid, dim3(256), 0, st, p); break;           \
+        case 64: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, st, p); break;           \
+        default:                                                                               \
+            ttsmi_set_error("bf16 attention: head dim %d not built (32/64)", dh);              \
+            return TTSMI_ERR_UNSUPPORTED;                                                      \
+    }
+
+// called from attention.hip's entry points when dtype == TTSMI_BF16
+int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
+                         float* lse, int B, int H, int T, int dh, float p_drop, uint64_t seed,
+                         const int64_t* step_dev, uint32_t site, hipStream_t st) {
+    HAttnP p;
+    int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_fwd(bf16)");
+    if (rc) return rc;
+    TTSMI_CHECK_ARG(ctx && lse, "attention_fwd(bf16): null pointer");
+    p.ctx = (float*)ctx; p.lse = lse;
+    dim3 grid(ttsmi_cdiv(T, 128), H, B);
+    HDISPATCH(dh, hattn_fwd_kernel, grid, st, p);
+    TTSMI_CHECK_LAUNCH("attention_fwd(bf16)");
+    return TTSMI_OK;
+}
+
+int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
+                         const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
+                         float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, void* ws,
+                         hipStream_t st) {
+    HAttnP p;
+    int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_bwd(bf16)");
+    if (rc) return rc;
+    TTSMI_CHECK_ARG(ctx && dctx && lse && dqkv && ws, "attention_bwd(bf16): null pointer");
+    p.octx = (const float*)ctx; p.dctx = (const float*)dctx; p.lse = (float*)lse;
+    p.dqkv = (float*)dqkv; p.delta = (float*)ws;
+    dim3 grid(ttsmi_cdiv(T, 128), H, B);
+    HDISPATCH(dh, hattn_bwd_dq_kernel, grid, st, p);
+    TTSMI_CHECK_LAUNCH("attention_bwd_dq(bf16)");
+    HDISPATCH(dh, hattn_bwd_dkv_kernel, grid, st, p);
+    TTSMI_CHECK_LAUNCH("attention_bwd_dkv(bf16)");
+    return TTSMI_OK;
+}

@@ -31,6 +31,16 @@ void ttsmi_set_error(const char* fmt, ...);
 
 static inline int ttsmi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// bf16-operand attention kernels (attention_bf16.hip), reached through ttsmi_attention_fwd/bwd with
+// dtype == TTSMI_BF16
+int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
+                         float* lse, int B, int H, int T, int dh, float p_drop, uint64_t seed,
+                         const int64_t* step_dev, uint32_t site, hipStream_t st);
+int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
+                         const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
+                         float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, void* ws,
+                         hipStream_t st);
+
 // ---- wave64 reductions ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -44,9 +54,11 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- counter-based dropout RNG ----------------------------------------------------------------
-// Stateless: keep(seed, stream, idx) so that forward and backward regenerate the same mask without
-// storing it.  A 2-round 64-bit mix (splitmix64 finaliser) per 64-bit counter gives two 32-bit
-// uniform words; one call decides 2 elements.  Statistical quality is checked in tests.
+// Stateless: keep(seed, site, idx) so that forward and backward regenerate the same mask without
+// storing it.  The (seed, site) pair is mixed once per launch with a 64-bit splitmix finaliser
+// (loop invariant - the compiler hoists it); the per-element work is one 32-bit avalanche hash
+// (two multiply-xorshift rounds, ~8 VALU ops), cheap enough to sit inside the attention inner
+// loop next to the MFMAs.  Statistical quality is checked in tests.
 __device__ __forceinline__ uint64_t ttsmi_mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -54,8 +66,13 @@ __device__ __forceinline__ uint64_t ttsmi_mix64(uint64_t z) {
 }
 // returns a uniform 32-bit word for element `idx` of dropout site `site` under `seed`
 __device__ __forceinline__ uint32_t ttsmi_rand32(uint64_t seed, uint32_t site, uint64_t idx) {
-    uint64_t h = ttsmi_mix64(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1));
-    return (uint32_t)(ttsmi_mix64(h ^ (idx * 0xD6E8FEB86659FD93ull)) >> 32);
+    const uint64_t s = ttsmi_mix64(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1));
+    uint32_t h = (uint32_t)idx ^ (uint32_t)s;
+    h += (uint32_t)(idx >> 32) * 0x9E3779B1u + (uint32_t)(s >> 32);
+    h ^= h >> 16; h *= 0x7feb352du;
+    h ^= h >> 15; h *= 0x846ca68bu;
+    h ^= h >> 16;
+    return h;
 }
 // keep-scale: 1/(1-p) if kept else 0.  thr = p * 2^32 (precomputed on the host)
 __device__ __forceinline__ float ttsmi_keep_scale(uint64_t seed, uint32_t site, uint64_t idx,

@@ -1,0 +1,387 @@
+// TTSMI_BF16 GEMM family: bf16 operands (rounded to nearest even), fp32 accumulate on
+// v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense chip peak), fp32 storage everywhere in HBM.
+//
+// One "TN" kernel:  C[M,N] = epilogue( sum_k A[m,k] * B[n,k] )  with BOTH operands K-contiguous,
+// which is the only shape an MFMA bf16 fragment (8 consecutive k per lane) can be fetched in with
+// 16-byte LDS reads.  The callers arrange that:
+//   forward  : A = activations fp32 [M,K] (converted to bf16 while staging), B = W^T bf16 [N,K]
+//   dgrad    : A = dy fp32 [M,N_out],  B = W bf16 [K_in, N_out] as stored (rows = k_in)
+//   wgrad    : A = x^T bf16 [K_in, M], B = dy^T bf16 [N, M] (ttsmi_cast_transpose_bf16), split over M
+//   Conv1D   : forward/dgrad read the contiguous k*C window of frame (b,t) (zero outside the sequence),
+//              weights come pre-laid-out ([Cout][k*Cin] / [Cin][k'*Cout] with flipped taps); wgrad
+//              uses the transposed im2col the cast kernel writes.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), 64x64 per wave = 2x2 MFMA 32x32 tiles (64 fp32
+// accumulators), LDS images [128][64+8] bf16 (144-byte rows: the 16 lanes of a ds_read_b128 group
+// hit 16 different 16-byte slots -> conflict free), register prefetch of the next k-tile.
+// With fp32 activations in HBM these GEMMs are L2/HBM-bound (44 FLOP/B at this tile), not MFMA-bound.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define HBM_ 128
+#define HBN_ 128
+#define HBK_ 64
+#define HLD_ (HBK_ + 8)
+
+struct HGemmP {
+    const void* A; long lda;            // fp32 or bf16 rows
+    const void* A2; long lda2; int K1;  // second K segment (fp32 A only)
+    const uint16_t* B; long ldb;        // bf16 [N][K]
+    float* C; long ldc;
+    const float* bias;
+    const float* relu_src; long ld_relu;
+    int M, N, K;
+    int relu;
+    int a_taps, T, Cw, pad;             // conv windowing on a fp32 A (a_taps == 1: none)
+    int k_per_split;
+    float* ws; float* colsum; float* colsum_ws;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ uint2 pack4(float4 v) {
+    bf16x4 h;
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    return *reinterpret_cast<uint2*>(&h);
+}
+
+// ---- A tile fetch: fp32 source (8 float4 per thread) -------------------------------------------
+__device__ __forceinline__ void fetch_a_f32(const HGemmP& p, int m0, int k0, int kend, int tid,
+                                            float4 (&r)[8]) {
+    const float* A = (const float*)p.A;
+    const float* A2 = (const float*)p.A2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int id = tid + 256 * i;
+        int row = id >> 4, c4 = id & 15;
+        int m = m0 + row, kk = k0 + c4 * 4;
+        bool ok = (m < p.M) && (kk < kend);
+        const float* ptr;
+        if (p.a_taps > 1) {
+            int t = m % p.T, tap = kk / p.Cw, tt = t + tap - p.pad;
+            ok = ok && (tt >= 0) && (tt < p.T);
+            ptr = A + ((long)m - p.pad) * p.Cw + kk;
+        } else if (A2 != nullptr && kk >= p.K1) {
+            ptr = A2 + (long)m * p.lda2 + (kk - p.K1);
+        } else {
+            ptr = A + (long)m * p.lda + kk;
+        }
+        r[i] = ok ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void stash_a_f32(uint16_t (*S)[HLD_], int tid, const float4 (&r)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int id = tid + 256 * i;
+        int row = id >> 4, c4 = id & 15;
+        *reinterpret_cast<uint2*>(&S[row][c4 * 4]) = pack4(r[i]);
+    }
+}
+// ---- bf16 source tile (4 uint4 per thread) -----------------------------------------------------
+__device__ __forceinline__ void fetch_h(const uint16_t* base, long ld, int rows, int r0, int k0,
+                                        int kend, int tid, uint4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int id = tid + 256 * i;
+        int row = id >> 3, c8 = id & 7;
+        int m = r0 + row, kk = k0 + c8 * 8;
+        bool ok = (m < rows) && (kk < kend);
+        r[i] = ok ? *reinterpret_cast<const uint4*>(base + (long)m * ld + kk) : make_uint4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void stash_h(uint16_t (*S)[HLD_], int tid, const uint4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int id = tid + 256 * i;
+        int row = id >> 3, c8 = id & 7;
+        *reinterpret_cast<uint4*>(&S[row][c8 * 8]) = r[i];
+    }
+}
+
+template <bool A_F32>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2][HBM_][HLD_];
+    uint16_t(*As)[HLD_] = smem[0];
+    uint16_t(*Bs)[HLD_] = smem[1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int m0 = tm * HBM_, n0 = tn * HBN_;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int l31 = lane & 31, kg = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[8];      // fp32-A prefetch registers (dead in the bf16-A instantiation)
+    uint4 rah[4];      // bf16-A prefetch registers (dead in the fp32-A instantiation)
+    uint4 rb[4];
+    if (kbeg < kend) {
+        if constexpr (A_F32) fetch_a_f32(p, m0, kbeg, kend, tid, ra);
+        else fetch_h((const uint16_t*)p.A, p.lda, p.M, m0, kbeg, kend, tid, rah);
+        fetch_h(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
+        if constexpr (A_F32) stash_a_f32(As, tid, ra); else stash_h(As, tid, rah);
+        stash_h(Bs, tid, rb);
+    }
+    __syncthreads();
+
+    const bool do_colsum = (p.colsum != nullptr) && (tm == 0) && (tid < HBN_);
+    float csum = 0.f;
+    for (int k0 = kbeg; k0 < kend; k0 += HBK_) {
+        const bool more = (k0 + HBK_) < kend;
+        if (more) {
+            if constexpr (A_F32) fetch_a_f32(p, m0, k0 + HBK_, kend, tid, ra);
+            else fetch_h((const uint16_t*)p.A, p.lda, p.M, m0, k0 + HBK_, kend, tid, rah);
+            fetch_h(p.B, p.ldb, p.N, n0, k0 + HBK_, kend, tid, rb);
+        }
+        if (do_colsum) {                       // bias gradient from the dy^T tile (wgrad)
+#pragma unroll
+            for (int c8 = 0; c8 < HBK_ / 8; ++c8) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(&Bs[tid][c8 * 8]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum += (float)v[e];
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < HBK_ / 16; ++ks) {
+            const int ko = ks * 16 + kg * 8;
+            bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[wr * 64 + l31][ko]);
+            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[wr * 64 + 32 + l31][ko]);
+            bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[wc * 64 + l31][ko]);
+            bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[wc * 64 + 32 + l31][ko]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            if constexpr (A_F32) stash_a_f32(As, tid, ra); else stash_h(As, tid, rah);
+            stash_h(Bs, tid, rb);
+        }
+        __syncthreads();
+    }
+
+    const bool split = gridDim.z > 1;
+    if (do_colsum && n0 + tid < p.N) {
+        if (split) p.colsum_ws[(long)blockIdx.z * p.N + n0 + tid] = csum;
+        else p.colsum[n0 + tid] = csum;
+    }
+    float* Cb = split ? p.ws + (long)blockIdx.z * p.M * p.N : p.C;
+    const long ldc = split ? (long)p.N : p.ldc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int col = n0 + wc * 64 + j * 32 + l31;
+        if (col >= p.N) continue;
+        float bv = (!split && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (!split) {
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu_src) v = p.relu_src[(long)row * p.ld_relu + col] > 0.f ? v : 0.f;
+                }
+                Cb[(long)row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+__global__ void hsplit_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long ldo,
+                                     int M, int N, int splits, const float* __restrict__ cs_ws,
+                                     float* __restrict__ cs_out) {
+    long n = (long)M * N;
+    long total = n + (cs_out ? N : 0);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        if (i < n) {
+            for (int z = 0; z < splits; ++z) s += ws[(long)z * n + i];
+            int r = (int)(i / N), c = (int)(i - (long)r * N);
+            out[(long)r * ldo + c] = s;
+        } else {
+            long c = i - n;
+            for (int z = 0; z < splits; ++z) s += cs_ws[(long)z * N + c];
+            cs_out[c] = s;
+        }
+    }
+}
+
+// ---- fp32 [R, C] -> bf16 transposed [taps*C, Rp] (Rp = ldd >= R, tail zero-filled) -------------
+// dst[j*C + c][r] = src[r + j - pad][c] when frame (r % T) + j - pad stays inside its sequence,
+// else 0.  taps == 1: plain cast-transpose (weights W -> W^T, activations x -> x^T).
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, long lds_,
+                                                             uint16_t* __restrict__ dst, long ldd,
+                                                             int R, int C, int taps, int T, int pad) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, j = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        int r = r0 + rr, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < C) {
+            bool ok = true;
+            long sr = r;
+            if (taps > 1) {
+                int tt = (r % T) + j - pad;
+                ok = (tt >= 0) && (tt < T);
+                sr = (long)r + j - pad;
+            }
+            if (ok) v = src[sr * lds_ + c];
+        }
+        tile[rr][tx] = v;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        int c = c0 + cc, r = r0 + tx;
+        if (c < C && r < ldd) {
+            __bf16 h = (__bf16)tile[tx][cc];
+            dst[((long)j * C + c) * ldd + r] = *reinterpret_cast<uint16_t*>(&h);
+        }
+    }
+}
+
+// conv weight [k, Cin, Cout] fp32 -> dgrad operand bf16 [Cin][k*Cout] with flipped taps:
+// dst[ci][j'*Cout + co] = w[k-1-j'][ci][co]
+__global__ __launch_bounds__(256) void conv_wdgrad_layout_kernel(const float* __restrict__ w,
+                                                                 uint16_t* __restrict__ dst, int k,
+                                                                 int Cin, int Cout) {
+    long n = (long)k * Cin * Cout;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        int co = (int)(i % Cout);
+        long t = i / Cout;
+        int jp = (int)(t % k), ci = (int)(t / k);
+        __bf16 h = (__bf16)w[((long)(k - 1 - jp) * Cin + ci) * Cout + co];
+        dst[i] = *reinterpret_cast<uint16_t*>(&h);
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static void hinit(HGemmP& p) {
+    memset(&p, 0, sizeof(p));
+    p.a_taps = 1;
+}
+
+static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char* name) {
+    p.tiles_m = ttsmi_cdiv(p.M, HBM_);
+    p.tiles_n = ttsmi_cdiv(p.N, HBN_);
+    dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+    if (a_f32) hipLaunchKernelGGL((gemm_bf16_kernel<true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false>), grid, dim3(256), 0, st, p);
+    TTSMI_CHECK_LAUNCH(name);
+    return TTSMI_OK;
+}
+
+static int hpick_splits(long rows, int tiles) {
+    int want = (512 + tiles - 1) / tiles;
+    int maxs = (int)((rows + 511) / 512);
+    int s = want < maxs ? want : maxs;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return s;
+}
+
+extern "C" {
+
+int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int64_t lda2, int K1,
+                   const uint16_t* b, int64_t ldb, const float* bias, const float* relu_src,
+                   int64_t ld_relu, float* c, int64_t ldc, int M, int N, int K, int relu, int conv_taps,
+                   int conv_T, int conv_C, int conv_pad, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(a && b && c, "hgemm_tn: null pointer");
+    TTSMI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "hgemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
+    if (M == 0) return TTSMI_OK;
+    TTSMI_CHECK_ARG(al16(a) && al16(b) && (K % 8 == 0) && (ldb % 8 == 0),
+                    "hgemm_tn: operands must be 16-byte aligned with K %% 8 == 0 (K=%d ldb=%ld)", K, (long)ldb);
+    if (a_is_f32) TTSMI_CHECK_ARG(lda % 4 == 0, "hgemm_tn: lda %% 4 != 0");
+    else TTSMI_CHECK_ARG(lda % 8 == 0 && !a2 && conv_taps <= 1, "hgemm_tn: bf16 A needs lda %% 8 == 0, no A2/conv");
+    if (a2) TTSMI_CHECK_ARG(K1 > 0 && K1 < K && K1 % 8 == 0 && al16(a2) && lda2 % 4 == 0, "hgemm_tn: bad A2 segment");
+    if (conv_taps > 1) TTSMI_CHECK_ARG(conv_C % 4 == 0 && conv_T > 0 && K == conv_taps * conv_C, "hgemm_tn: bad conv window");
+    HGemmP p;
+    hinit(p);
+    p.A = a; p.lda = lda; p.A2 = a2; p.lda2 = lda2; p.K1 = K1;
+    p.B = b; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.relu_src = relu_src; p.ld_relu = ld_relu;
+    p.M = M; p.N = N; p.K = K; p.relu = relu; p.k_per_split = K;
+    if (conv_taps > 1) { p.a_taps = conv_taps; p.T = conv_T; p.Cw = conv_C; p.pad = conv_pad; }
+    return hlaunch(p, a_is_f32 != 0, 1, (hipStream_t)stream, "hgemm_tn");
+}
+
+size_t ttsmi_hgemm_wgrad_ws_bytes(int rows, int kin, int n) {
+    int tiles = ttsmi_cdiv(kin, HBM_) * ttsmi_cdiv(n, HBN_);
+    int splits = hpick_splits(rows, tiles);
+    return (size_t)splits * ((size_t)kin * n + n) * sizeof(float) + 256;
+}
+
+/* dw[kin, n] = xT[kin, rows] . dyT[n, rows]^T, both bf16 with leading dimension ldt >= rows
+ * (multiple of 8, tail zero-filled); db[n] = row sums of dyT (may be NULL). */
+int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, float* dw, int64_t lddw,
+                      float* db, int rows, int kin, int n, void* ws, size_t ws_bytes,
+                      ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(xT && dyT && dw, "hgemm_wgrad: null pointer");
+    TTSMI_CHECK_ARG(rows > 0 && kin > 0 && n > 0 && ldt % 8 == 0 && ldt >= rows, "hgemm_wgrad: bad shape");
+    TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_hgemm_wgrad_ws_bytes(rows, kin, n), "hgemm_wgrad: workspace too small");
+    TTSMI_CHECK_ARG(al16(xT) && al16(dyT), "hgemm_wgrad: operands must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    HGemmP p;
+    hinit(p);
+    p.A = xT; p.lda = ldt; p.B = dyT; p.ldb = ldt; p.C = dw; p.ldc = lddw;
+    p.M = kin; p.N = n; p.K = (int)ldt;            // zero tail contributes nothing
+    int tiles = ttsmi_cdiv(kin, HBM_) * ttsmi_cdiv(n, HBN_);
+    int splits = hpick_splits(rows, tiles);
+    int kps = ttsmi_cdiv(p.K, splits);
+    kps = ((kps + HBK_ - 1) / HBK_) * HBK_;
+    splits = ttsmi_cdiv(p.K, kps);
+    p.k_per_split = kps;
+    p.ws = (float*)ws; p.colsum = db; p.colsum_ws = p.ws + (size_t)splits * kin * n;
+    int rc = hlaunch(p, false, splits, st, "hgemm_wgrad");
+    if (rc) return rc;
+    if (splits > 1) {
+        long tot = (long)kin * n;
+        int blocks = (int)((tot + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(hsplit_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, dw, (long)lddw, kin, n,
+                           splits, p.colsum_ws, db);
+        TTSMI_CHECK_LAUNCH("hgemm_wgrad_reduce");
+    }
+    return TTSMI_OK;
+}
+
+int ttsmi_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int R,
+                              int C, int taps, int T, int pad, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(src && dst && R > 0 && C > 0 && taps >= 1 && ld_dst >= R, "cast_transpose_bf16: bad argument");
+    if (taps > 1) TTSMI_CHECK_ARG(T > 0, "cast_transpose_bf16: conv needs T");
+    dim3 grid(ttsmi_cdiv(ld_dst, 64), ttsmi_cdiv(C, 64), taps);
+    hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, dst,
+                       (long)ld_dst, R, C, taps, T, pad);
+    TTSMI_CHECK_LAUNCH("cast_transpose_bf16");
+    return TTSMI_OK;
+}
+
+int ttsmi_conv_wdgrad_layout_bf16(const float* w, uint16_t* dst, int k, int Cin, int Cout,
+                                  ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(w && dst && k > 0 && Cin > 0 && Cout > 0, "conv_wdgrad_layout_bf16: bad argument");
+    long n = (long)k * Cin * Cout;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_wdgrad_layout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, dst, k,
+                       Cin, Cout);
+    TTSMI_CHECK_LAUNCH("conv_wdgrad_layout_bf16");
+    return TTSMI_OK;
+}
+
+}  // extern "C"

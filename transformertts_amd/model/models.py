@@ -177,10 +177,35 @@ class ForwardTransformer:
         self.loss_weights = [1., 1., 3.]
         self.loss = [masked_mean_absolute_error] * 3
         self.drop = ops.DropCtx(seed=int(kwargs.get('seed', 0)), step_dev=self.step_dev)
+        # 'f32': exact-fp32 MFMA everywhere (the 1e-4 parity path).  'bf16': GEMM / attention operands
+        # rounded to bf16, fp32 accumulate, fp32 master weights + activations (throughput path).
+        self.precision = str(kwargs.get('precision', 'f32'))
+        assert self.precision in ('f32', 'bf16'), self.precision
+        self.shadow: Dict[str, ops.Shadow] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
         self.grad_sync = None                # set by transformertts_amd.dp.DataParallel
         self.debug = debug
         self._init_weights(int(kwargs.get('seed', 0)))
+        self._build_shadows()
+
+    def _shadow_names(self):
+        for name, w in self.params.w.items():
+            leaf = name.split('.')[-1]
+            if leaf in ('wqkv', 'wo', 'w1', 'w2') or name == 'out.w':
+                yield name
+            elif leaf == 'w' and w.dim() == 3 and name.split('.')[0] in ('dur', 'pitch'):
+                yield name
+
+    def _build_shadows(self):
+        """bf16 operand copies of the GEMM weights (precision == 'bf16' only)."""
+        self.shadow = {}
+        if self.precision == 'bf16':
+            for name in self._shadow_names():
+                self.shadow[name] = ops.make_shadow(self.params.w[name])
+
+    def _refresh_shadows(self):
+        for name, sh in self.shadow.items():
+            ops.refresh_shadow(sh, self.params.w[name])
 
     # ------------------------------------------------------------------ construction helpers
     def _make_config(self, locals_: dict, kwargs: dict) -> dict:
@@ -240,6 +265,7 @@ class ForwardTransformer:
                 else:
                     a = weights[name]
                 w.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)).reshape(w.shape).to(self.device))
+        self._refresh_shadows()
 
     def _export(self, tensors: Dict[str, torch.Tensor]) -> "OrderedDict[str, np.ndarray]":
         """Internal (fused wqkv/bqkv) -> reference variable names and order (wq,bq,wk,bk,wv,bv)."""
@@ -269,7 +295,7 @@ class ForwardTransformer:
     def _self_attention_blocks(self, prefix, name, x, pad, klen, heads, dense_blocks, pe, rate,
                                want_attn):
         """SelfAttentionBlocks.call (layers.py:297-310) on fused kernels.  x [B,T,d]."""
-        W, G, drop = self.params.w, self.params.g, self.drop
+        W, G, drop, S = self.params.w, self.params.g, self.drop, self.shadow.get
         B, T, d = x.shape
         M = B * T
         h = ops.add_layernorm(x.reshape(M, d), None, W[f'{prefix}.ln.gamma'], W[f'{prefix}.ln.beta'],
@@ -280,19 +306,22 @@ class ForwardTransformer:
         for i, H in enumerate(heads):
             p = f'{prefix}.blk{i}'
             dense = i < dense_blocks
-            qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'])
+            qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'],
+                                     S(f'{p}.wqkv'))
             site = drop.site()
-            ctx, lse = ops.AttentionFn.apply(qkv, pad, klen, B, H, T, d // H, rate, drop, site)
+            ctx, lse = ops.AttentionFn.apply(qkv, pad, klen, B, H, T, d // H, rate, drop, site,
+                                             ops._lib.TTSMI_BF16 if self.precision == 'bf16' else ops.TTSMI_F32)
             if want_attn:
                 key = (f'{name}_DenseBlock{i + 1}_SelfAttention' if dense
                        else f'{name}_ConvBlock{i - dense_blocks + 1}_SelfAttention')
                 attn[key] = ops.attention_weights(qkv.detach(), pad, lse, B, H, T, d // H, rate, drop, site)
-            o = ops.LinearFn.apply(h, ctx, W[f'{p}.wo'], W[f'{p}.bo'], G[f'{p}.wo'], G[f'{p}.bo'])
+            o = ops.LinearFn.apply(h, ctx, W[f'{p}.wo'], W[f'{p}.bo'], G[f'{p}.wo'], G[f'{p}.bo'], S(f'{p}.wo'))
             a = ops.add_layernorm(o, h, W[f'{p}.ln1.gamma'], W[f'{p}.ln1.beta'], G[f'{p}.ln1.gamma'],
                                   G[f'{p}.ln1.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop)
             if dense:
                 f = ops.FFNFn.apply(a, W[f'{p}.ffn.w1'], W[f'{p}.ffn.b1'], W[f'{p}.ffn.w2'], W[f'{p}.ffn.b2'],
-                                    G[f'{p}.ffn.w1'], G[f'{p}.ffn.b1'], G[f'{p}.ffn.w2'], G[f'{p}.ffn.b2'])
+                                    G[f'{p}.ffn.w1'], G[f'{p}.ffn.b1'], G[f'{p}.ffn.w2'], G[f'{p}.ffn.b2'],
+                                    S(f'{p}.ffn.w1'), S(f'{p}.ffn.w2'))
             else:
                 n = 0
                 while f'{p}.conv{n}.w' in W:
@@ -313,7 +342,8 @@ class ForwardTransformer:
         h = ops.RowMaskFn.apply(x, pad)
         for j in range(n_layers):
             h = ops.ConvReluPreMaskedFn.apply(h, W[f'{prefix}.conv{j}.w'], W[f'{prefix}.conv{j}.b'],
-                                              G[f'{prefix}.conv{j}.w'], G[f'{prefix}.conv{j}.b'])
+                                              G[f'{prefix}.conv{j}.w'], G[f'{prefix}.conv{j}.b'],
+                                              self.shadow.get(f'{prefix}.conv{j}.w'))
             C = h.shape[-1]
             h = ops.add_layernorm(h.reshape(B * T, C), None, W[f'{prefix}.ln{j}.gamma'],
                                   W[f'{prefix}.ln{j}.beta'], G[f'{prefix}.ln{j}.gamma'],
@@ -371,7 +401,7 @@ class ForwardTransformer:
                                                      c['decoder_num_heads'], c['decoder_dense_blocks'],
                                                      self.pe_dec, rate, want_attn)   # :542
         out = ops.LinearFn.apply(mels.reshape(B * mel_len, -1), None, W['out.w'], W['out.b'], G['out.w'],
-                                 G['out.b']).reshape(B, mel_len, self.mel_channels)  # :543
+                                 G['out.b'], self.shadow.get('out.w')).reshape(B, mel_len, self.mel_channels)  # :543
         return {'mel': out, 'duration': durations, 'pitch': pitch, 'expanded_mask': expanded_mask,
                 'encoder_attention': enc_attn, 'decoder_attention': dec_attn,
                 'expanded_lengths': lens}
@@ -433,6 +463,7 @@ class ForwardTransformer:
         P = self.params
         ops.adam_tf(P.data, P.grad, P.m, P.v, self.lr_dev, self.step_dev, self.beta_1, self.beta_2,
                     self.epsilon)
+        self._refresh_shadows()
 
     def _compile(self, optimizer=None, learning_rate: Optional[float] = None):
         """reference _compile models.py:484-490.  `optimizer` may be any object with

@@ -182,6 +182,118 @@ def stft_logmel(wav, clip_off, frame_off, total_frames, n_fft, hop, window, n_me
     return out
 
 
+class Shadow:
+    """bf16 copies of one GEMM weight for the TTSMI_BF16 path, refreshed after every optimiser step:
+      wb  - the weight as stored, bf16 ([K,N] Dense; dgrad reads its rows as K-contiguous operands)
+      wt  - its transpose, bf16 ([N,K] Dense / [Cout, k*Cin] Conv1D; the forward B operand)
+      wd  - Conv1D only: dgrad operand [Cin, k*Cout] with flipped taps."""
+    __slots__ = ('wb', 'wt', 'wd')
+
+    def __init__(self, wb=None, wt=None, wd=None):
+        self.wb, self.wt, self.wd = wb, wt, wd
+
+
+def _al(t, n):
+    return t is not None and t.data_ptr() % 16 == 0 and t.stride(0) % n == 0
+
+
+def hgemm_tn(a, b_h, bias=None, relu=False, a2=None, relu_src=None, conv=None, rows=None):
+    """c[M,N] = act(sum_k a[m,k]*b_h[n,k] + bias) * (relu_src > 0) on bf16 MFMA (include/ttsmi.h)."""
+    a_f32 = a.dtype == torch.float32
+    N, K = b_h.shape
+    M = a.shape[0] if rows is None else rows
+    K1 = a.shape[1] if a2 is not None else 0
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    taps, T, C, pad = conv if conv is not None else (1, 0, 0, 0)
+    check(_lib.lib().ttsmi_hgemm_tn(_p(a), int(a_f32), a.stride(0), _p(a2), 0 if a2 is None else a2.stride(0),
+                                    K1, _p(b_h), b_h.stride(0), _p(bias), _p(relu_src),
+                                    0 if relu_src is None else relu_src.stride(0), _p(c), c.stride(0), M, N, K,
+                                    int(relu), taps, T, C, pad, _stream()), 'hgemm_tn')
+    return c
+
+
+def cast_transpose_bf16(src2d, taps=1, T=0, pad=0):
+    """fp32 [R,C] -> bf16 [taps*C, ldt] (ldt = R rounded up to 8, zero tail)."""
+    R, C = src2d.shape
+    ldt = (R + 7) // 8 * 8
+    dst = torch.empty((taps * C, ldt), dtype=torch.bfloat16, device=src2d.device)
+    check(_lib.lib().ttsmi_cast_transpose_bf16(_p(src2d), src2d.stride(0), _p(dst), ldt, R, C, taps, T, pad,
+                                               _stream()), 'cast_transpose_bf16')
+    return dst
+
+
+def hgemm_wgrad(xT, dyT, dw, db, rows):
+    kin, ldt = xT.shape
+    n = dyT.shape[0]
+    l = _lib.lib()
+    ws = _ws(l.ttsmi_hgemm_wgrad_ws_bytes(rows, kin, n), xT.device)
+    check(l.ttsmi_hgemm_wgrad(_p(xT), _p(dyT), ldt, _p(dw), dw.stride(0), _p(db), rows, kin, n, _p(ws),
+                              ws.numel(), _stream()), 'hgemm_wgrad')
+
+
+def conv_wdgrad_layout_bf16(w):
+    k, cin, cout = w.shape
+    dst = torch.empty((cin, k * cout), dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().ttsmi_conv_wdgrad_layout_bf16(_p(w), _p(dst), k, cin, cout, _stream()), 'conv_wdgrad_layout')
+    return dst
+
+
+def make_shadow(w):
+    """Build the bf16 shadow of a Dense [K,N] or Conv1D [k,Cin,Cout] weight (fp32 tensor)."""
+    with torch.no_grad():
+        wf = w.detach()
+        if wf.dim() == 2:
+            wb = torch.empty(wf.shape, dtype=torch.bfloat16, device=wf.device)
+            check(_lib.lib().ttsmi_cast_f32_to_bf16(_p(wf), _p(wb), wf.numel(), _stream()), 'cast_f32_to_bf16')
+            return Shadow(wb=wb, wt=cast_transpose_bf16(wf))
+        k, cin, cout = wf.shape
+        return Shadow(wt=cast_transpose_bf16(wf.reshape(k * cin, cout)), wd=conv_wdgrad_layout_bf16(wf))
+
+
+def refresh_shadow(sh, w):
+    """Re-cast in place (same buffers: safe under hipGraph replay)."""
+    wf = w.detach()
+    l = _lib.lib()
+    if wf.dim() == 2:
+        check(l.ttsmi_cast_f32_to_bf16(_p(wf), _p(sh.wb), wf.numel(), _stream()), 'cast_f32_to_bf16')
+        K, N = wf.shape
+        check(l.ttsmi_cast_transpose_bf16(_p(wf), wf.stride(0), _p(sh.wt), sh.wt.stride(0), K, N, 1, 0, 0,
+                                          _stream()), 'cast_transpose_bf16')
+    else:
+        k, cin, cout = wf.shape
+        check(l.ttsmi_cast_transpose_bf16(_p(wf), cout, _p(sh.wt), sh.wt.stride(0), k * cin, cout, 1, 0, 0,
+                                          _stream()), 'cast_transpose_bf16')
+        check(l.ttsmi_conv_wdgrad_layout_bf16(_p(wf), _p(sh.wd), k, cin, cout, _stream()), 'conv_wdgrad_layout')
+
+
+# ---- precision-dispatching wrappers: sh is None -> exact-fp32 MFMA kernels ------------------------
+def dense_fwd(x, w, b, relu, x2, sh):
+    K = w.shape[0]
+    if sh is not None and K % 8 == 0 and _al(x, 4) and (x2 is None or (_al(x2, 4) and x.shape[1] % 8 == 0)):
+        return hgemm_tn(x, sh.wt, b, relu, x2)
+    return linear_fwd(x, w, b, relu, x2)
+
+
+def dense_dgrad(dy, w, sh, k0, k1, relu_src=None):
+    """dx = dy . w[k0:k1]^T (* relu mask)."""
+    N = w.shape[1]
+    if sh is not None and N % 8 == 0 and _al(dy, 4) and k0 % 8 == 0:
+        return hgemm_tn(dy, sh.wb[k0:k1], None, False, None, relu_src)
+    return linear_dgrad(dy, w[k0:k1], relu_src)
+
+
+def dense_wgrad(x, dy, dw, db, sh, dyT=None):
+    """dw = x^T . dy, db = colsum(dy).  Returns dyT (bf16 path) so a dual-A caller can reuse it."""
+    if sh is not None:
+        M = x.shape[0]
+        if dyT is None:
+            dyT = cast_transpose_bf16(dy)
+        hgemm_wgrad(cast_transpose_bf16(x), dyT, dw, db, M)
+        return dyT
+    linear_wgrad(x, dy, dw, db)
+    return None
+
+
 def _sink(g, like):
     """Gradient destination: the caller's buffer view, or a fresh tensor."""
     return g if g is not None else torch.empty_like(like)
@@ -194,13 +306,14 @@ class LinearFn(torch.autograd.Function):
     """y = [x | x2] . w + b.   Dense at model/layers.py:116-120,148-149; model/models.py:422."""
 
     @staticmethod
-    def forward(ctx, x, x2, w, b, gw, gb):
+    def forward(ctx, x, x2, w, b, gw, gb, sh=None):
         x = _c(x)
         x2 = None if x2 is None else _c(x2)
-        y = linear_fwd(x, w, b, False, x2)
+        y = dense_fwd(x, w, b, False, x2, sh)
         ctx.save_for_backward(x, x2, w)
         ctx.sinks = (gw, gb)
         ctx.has_b = b is not None
+        ctx.sh = sh
         return y
 
     @staticmethod
@@ -211,25 +324,28 @@ class LinearFn(torch.autograd.Function):
         K1 = x.shape[1]
         dw = _sink(gw, w)
         db = _sink(gb, dy[0]) if ctx.has_b else None
-        dx = linear_dgrad(dy, w[:K1]) if ctx.needs_input_grad[0] else None
-        linear_wgrad(x, dy, dw[:K1], db)
+        sh, K = ctx.sh, w.shape[0]
+        dx = dense_dgrad(dy, w, sh, 0, K1) if ctx.needs_input_grad[0] else None
+        dyT = dense_wgrad(x, dy, dw[:K1], db, sh)
         dx2 = None
         if x2 is not None:
-            dx2 = linear_dgrad(dy, w[K1:]) if ctx.needs_input_grad[1] else None
-            linear_wgrad(x2, dy, dw[K1:], None)
-        return dx, dx2, (None if gw is not None else dw), (None if (gb is not None or db is None) else db), None, None
+            dx2 = dense_dgrad(dy, w, sh, K1, K) if ctx.needs_input_grad[1] else None
+            dense_wgrad(x2, dy, dw[K1:], None, sh, dyT)
+        return (dx, dx2, (None if gw is not None else dw), (None if (gb is not None or db is None) else db),
+                None, None, None)
 
 
 class FFNFn(torch.autograd.Function):
     """relu(x.w1+b1).w2+b2 - the two Dense layers of FFNResNorm (model/layers.py:99-100)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gw1, gb1, gw2, gb2):
+    def forward(ctx, x, w1, b1, w2, b2, gw1, gb1, gw2, gb2, sh1=None, sh2=None):
         x = _c(x)
-        h = linear_fwd(x, w1, b1, True)
-        y = linear_fwd(h, w2, b2, False)
+        h = dense_fwd(x, w1, b1, True, None, sh1)
+        y = dense_fwd(h, w2, b2, False, None, sh2)
         ctx.save_for_backward(x, h, w1, w2)
         ctx.sinks = (gw1, gb1, gw2, gb2)
+        ctx.sh = (sh1, sh2)
         return y
 
     @staticmethod
@@ -237,14 +353,15 @@ class FFNFn(torch.autograd.Function):
         x, h, w1, w2 = ctx.saved_tensors
         gw1, gb1, gw2, gb2 = ctx.sinks
         dy = _c(dy)
+        sh1, sh2 = ctx.sh
         dw2, db2 = _sink(gw2, w2), _sink(gb2, dy[0])
-        linear_wgrad(h, dy, dw2, db2)
-        dh = linear_dgrad(dy, w2, relu_src=h)               # relu' fused in the dgrad epilogue
+        dense_wgrad(h, dy, dw2, db2, sh2)
+        dh = dense_dgrad(dy, w2, sh2, 0, w2.shape[0], relu_src=h)     # relu' fused in the dgrad epilogue
         dw1, db1 = _sink(gw1, w1), _sink(gb1, dh[0])
-        linear_wgrad(x, dh, dw1, db1)
-        dx = linear_dgrad(dh, w1)
+        dense_wgrad(x, dh, dw1, db1, sh1)
+        dx = dense_dgrad(dh, w1, sh1, 0, w1.shape[0])
         n = lambda g, d: None if g is not None else d
-        return dx, n(gw1, dw1), n(gb1, db1), n(gw2, dw2), n(gb2, db2), None, None, None, None
+        return dx, n(gw1, dw1), n(gb1, db1), n(gw2, dw2), n(gb2, db2), None, None, None, None, None, None
 
 
 class ConvStackFn(torch.autograd.Function):
@@ -349,33 +466,35 @@ class AttentionFn(torch.autograd.Function):
     (model/layers.py:123-129,176-195,144-147).  Returns (ctx [M, H*dh], lse [B,H,T])."""
 
     @staticmethod
-    def forward(ctx, qkv, key_pad, klen, B, H, T, dh, p_drop, drop, site):
+    def forward(ctx, qkv, key_pad, klen, B, H, T, dh, p_drop, drop, site, dtype=TTSMI_F32):
         qkv = _c(qkv)
         d = H * dh
+        if dtype != TTSMI_F32 and dh not in (32, 64):
+            dtype = TTSMI_F32                  # bf16 kernels are built for head dims 32 / 64
         out = torch.empty((B * T, d), dtype=torch.float32, device=qkv.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
         seed = drop.seed if drop is not None else 0
         step_dev = drop.step_dev if drop is not None else None
         check(_lib.lib().ttsmi_attention_fwd(_p(qkv), _p(key_pad), _p(klen), _p(out), _p(lse), B, H, T, dh,
-                                             float(p_drop), seed, _p(step_dev), int(site), TTSMI_F32,
+                                             float(p_drop), seed, _p(step_dev), int(site), int(dtype),
                                              _stream()), 'attention_fwd')
         ctx.save_for_backward(qkv, key_pad, klen, out, lse, step_dev)
-        ctx.cfg = (B, H, T, dh, float(p_drop), seed, int(site))
+        ctx.cfg = (B, H, T, dh, float(p_drop), seed, int(site), int(dtype))
         ctx.mark_non_differentiable(lse)
         return out, lse
 
     @staticmethod
     def backward(ctx, dout, _dlse):
         qkv, key_pad, klen, out, lse, step_dev = ctx.saved_tensors
-        B, H, T, dh, p_drop, seed, site = ctx.cfg
+        B, H, T, dh, p_drop, seed, site, dtype = ctx.cfg
         dout = _c(dout)
         dqkv = torch.empty_like(qkv)
         l = _lib.lib()
         ws = _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, dh), qkv.device)
         check(l.ttsmi_attention_bwd(_p(qkv), _p(key_pad), _p(klen), _p(out), _p(dout), _p(lse), _p(dqkv),
                                     B, H, T, dh, p_drop, seed, _p(step_dev), site, _p(ws), ws.numel(),
-                                    TTSMI_F32, _stream()), 'attention_bwd')
-        return dqkv, None, None, None, None, None, None, None, None, None
+                                    dtype, _stream()), 'attention_bwd')
+        return dqkv, None, None, None, None, None, None, None, None, None, None
 
 
 class EmbeddingFn(torch.autograd.Function):
@@ -549,11 +668,18 @@ class ConvReluPreMaskedFn(torch.autograd.Function):
     inside its own backward kernel, so no separate relu' pass exists."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gw, gb):
+    def forward(ctx, x, w, b, gw, gb, sh=None):
         x = _c(x)
-        h = conv1d_fwd(x, w, b, relu=True)
+        B, T, Cin = x.shape
+        k, _, Cout = w.shape
+        if sh is not None and Cin % 8 == 0:
+            h = hgemm_tn(x.reshape(B * T, Cin), sh.wt, b, True, conv=(k, T, Cin, (k - 1) // 2)).reshape(B, T, Cout)
+        else:
+            sh = None
+            h = conv1d_fwd(x, w, b, relu=True)
         ctx.save_for_backward(x, w)
         ctx.sinks = (gw, gb)
+        ctx.sh = sh
         return h
 
     @staticmethod
@@ -562,6 +688,18 @@ class ConvReluPreMaskedFn(torch.autograd.Function):
         gw, gb = ctx.sinks
         dh = _c(dh)
         dw, db = _sink(gw, w), _sink(gb, dh[0, 0])
-        conv1d_wgrad(x, dh, dw, db)
-        dx = conv1d_dgrad(dh, w) if ctx.needs_input_grad[0] else None
-        return dx, (None if gw is not None else dw), (None if gb is not None else db), None, None
+        sh = ctx.sh
+        B, T, Cin = x.shape
+        k, _, Cout = w.shape
+        if sh is not None:
+            xT = cast_transpose_bf16(x.reshape(B * T, Cin), taps=k, T=T, pad=(k - 1) // 2)
+            hgemm_wgrad(xT, cast_transpose_bf16(dh.reshape(B * T, Cout)), dw.reshape(k * Cin, Cout), db, B * T)
+        else:
+            conv1d_wgrad(x, dh, dw, db)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if sh is not None and Cout % 8 == 0:
+                dx = hgemm_tn(dh.reshape(B * T, Cout), sh.wd, conv=(k, T, Cout, k - 1 - (k - 1) // 2)).reshape(B, T, Cin)
+            else:
+                dx = conv1d_dgrad(dh, w)
+        return dx, (None if gw is not None else dw), (None if gb is not None else db), None, None, None
