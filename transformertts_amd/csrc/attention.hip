@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     const int d = p.H * DH;
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
-    const uint64_t seed = ttsmi_step_seed(p.seed, p.step_dev);
+    const uint64_t dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
     const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
     const float* Kb = Qb + d;
     const float* Vb = Qb + 2 * d;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     float m = -INFINITY, l = 0.f;
 
     const int klen = p.klen[b];
-    const long drop_row = (((long)b * p.H + h) * p.T + q) * (long)p.T;
+    const uint32_t drop_rb = ttsmi_row_base(dkey, (uint32_t)(((long)b * p.H + h) * p.T + q));
 
     float4 rk[KT * DH / 1024], rv[KT * DH / 1024];
     float rpad = 0.f;
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
                 float e = expf(s[r] - mn);
                 rs += e;
                 if (p.thr) {
-                    int key = k0 + kt * 32 + rowmap(r, hh);
-                    e *= ttsmi_keep_scale(seed, p.site, (uint64_t)(drop_row + key), p.thr, p.inv_keep);
+                    uint32_t key = k0 + kt * 32 + rowmap(r, hh);
+                    e *= ttsmi_keep_of(ttsmi_pair_hash(drop_rb, key), key, p.thr, p.inv_keep);
                 }
                 s[r] = e;
             }
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     const int d = p.H * DH;
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
-    const uint64_t seed = ttsmi_step_seed(p.seed, p.step_dev);
+    const uint64_t dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
     const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
     const float* Kb = Qb + d;
     const float* Vb = Qb + 2 * d;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
         for (int r = 0; r < 16; ++r) dq[cb][r] = 0.f;
 
     const int klen = p.klen[b];
-    const long drop_row = sidx * (long)p.T;
+    const uint32_t drop_rb = ttsmi_row_base(dkey, (uint32_t)sidx);
     const float inv_sqrt = 1.0f / p.sqrt_dk;
 
     float4 rk[KT * DH / 1024], rv[KT * DH / 1024];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
                 v += padS[kl] * -1e9f;
                 float pr = (k0 + kl >= klen) ? 0.f : expf(v - lse);
                 float keep = 1.f;
-                if (p.thr) keep = ttsmi_keep_scale(seed, p.site, (uint64_t)(drop_row + k0 + kl), p.thr, p.inv_keep);
+                if (p.thr) keep = ttsmi_keep_of(ttsmi_pair_hash(drop_rb, (uint32_t)(k0 + kl)), (uint32_t)(k0 + kl), p.thr, p.inv_keep);
                 s[r] = pr * (keep * dp[r] - delta) * inv_sqrt;                      // dS^T
             }
             accum_T<DH, SM::KS>(Ks, kt * 32, l31, hh, s, dq);                       // dQ^T += K^T.dS^T
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
     const int klen = p.klen[b];
     const bool kok = key < p.T;
     const bool kact = key < klen;             // keys >= klen took no part in the forward
-    const uint64_t seed = ttsmi_step_seed(p.seed, p.step_dev);
+    const uint64_t dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
     const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
     const float* Kb = Qb + d;
     const float* Vb = Qb + 2 * d;
@@ -412,8 +412,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
                     float pr = kact ? expf(v - lseS[ql]) : 0.f;      // lse = +inf for q >= T
                     float keep = 1.f;
                     if (p.thr)
-                        keep = ttsmi_keep_scale(seed, p.site,
-                                                (uint64_t)((stat0 + q0 + ql) * (long)p.T + key), p.thr, p.inv_keep);
+                        keep = ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q0 + ql), (uint32_t)key, p.thr, p.inv_keep);
                     pt[r] = pr * keep;                                               // dropped P
                     s[r] = pr * (keep * dp[r] - delS[ql]) * inv_sqrt;                // dS
                 }
@@ -442,7 +441,7 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(AttnP p) {
     const int key = (blockIdx.x * 4 + wave) * 32 + l31;
     const int q0 = blockIdx.y * 32;
     if ((blockIdx.x * 4 + wave) * 32 >= p.T) return;
-    const uint64_t seed = ttsmi_step_seed(p.seed, p.step_dev);
+    const uint64_t dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
     const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
     float qreg[DH / 2], kreg[DH / 2];
     rows_to_regs<DH>(Qb, p.ld, q0 + l31, q0 + l31 < p.T, hh, qreg);
@@ -460,8 +459,7 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(AttnP p) {
         if (q >= p.T || key >= p.T) continue;
         float v = s[r] / p.sqrt_dk + padterm;
         float pr = expf(v - p.lse[stat0 + q]);
-        if (p.thr)
-            pr *= ttsmi_keep_scale(seed, p.site, (uint64_t)((stat0 + q) * (long)p.T + key), p.thr, p.inv_keep);
+        if (p.thr) pr *= ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q), (uint32_t)key, p.thr, p.inv_keep);
         p.weights[(stat0 + q) * (long)p.T + key] = pr;
     }
 }

@@ -1,7 +1,9 @@
 // TTSMI_BF16 fused self-attention: bf16 operands (Q, K, V, P, dO, dS rounded to nearest even),
 // fp32 accumulate on v_mfma_f32_32x32x16_bf16, fp32 softmax statistics, fp32 I/O in HBM.
 // Same structure, masking rule, dropout stream and two-pass deterministic backward as the exact-fp32
-// kernels in attention.hip (see the header comment there); what changes is the operand plumbing:
+// kernels in attention.hip (see the header comment there); what changes is the operand plumbing and
+// the inner-loop diet (with bf16 MFMA a 32x32 score tile costs only 8 MFMAs = 256 cycles, so the
+// softmax / dropout VALU work per score element is what bounds the kernel):
 //
 //  * an MFMA 32x32x16 operand is 8 consecutive-k bf16 per lane.  The "register feedback" trick
 //    survives: accumulator registers 8t..8t+7 of a score tile, converted to bf16, ARE the B operand
@@ -9,10 +11,12 @@
 //    rowmap(8t+e, hh) = 16t + 8*(e>>2) + 4*hh + (e&3), so the matching A operand (V^T, K^T, dO^T or
 //    Q^T) is two 8-byte LDS reads from a TRANSPOSED tile image [c][key] at key offsets
 //    16t + 4hh and 16t + 8 + 4hh.
-//  * tiles that feed a "row" operand (K for QK^T, V for dP, Q / dO in the dK/dV pass) are staged
-//    row-major [row][DH+8] (144-byte rows: conflict-free ds_read_b128); tiles that feed a
-//    "transposed" operand are staged as [c][64+4] (136-byte rows: conflict-free ds_read_b64), the
-//    transposition being done by the staging threads (two rows packed per 32-bit LDS write).
+//  * every tile is fetched from HBM/L2 once, coalesced, staged row-major [row][DH+8] (144-byte
+//    rows: conflict-free ds_read_b128); tiles that also feed a "transposed" operand are re-laid-out
+//    LDS->LDS into [c][64+4] (136-byte rows: conflict-free ds_read_b64).
+//  * softmax runs in the log2 domain (one fma + v_exp_f32 per element), the additive -1e9 mask,
+//    the tail-of-sequence test and the O rescale are wave-/block-uniform branches that are skipped
+//    on the common path, dropout is a template parameter and costs one 32-bit hash per PAIR of keys.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -20,6 +24,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
 
 struct HAttnP {
     const float* qkv; long ld;
@@ -61,37 +69,24 @@ __device__ __forceinline__ void rows_stash(uint16_t* S, int tid, const float4 (&
         *reinterpret_cast<uint2*>(S + row * LD + c4 * 4) = *reinterpret_cast<uint2*>(&h);
     }
 }
-// ---- transposed staging: rows (2p, 2p+1) x 4 columns per work item -> [c][TLD] -------------------
+// ---- LDS -> LDS re-layout: row image [HKT][DH+8] -> transposed image [DH][TLD] --------------------
+// work item = (row pair p, 4 columns c4): two 8-byte reads, four packed 32-bit writes (conflict free)
 template <int DH>
-__device__ __forceinline__ void trans_fetch(const float* base, long ld, int row0, int nvalid, int tid,
-                                            float4 (&r)[DH / 16]) {
+__device__ __forceinline__ void lds_transpose(const uint16_t* S, uint16_t* St, int tid) {
+    constexpr int LD = DH + 8;
 #pragma unroll
     for (int i = 0; i < DH / 32; ++i) {
         int id = tid + 256 * i;
         int p = id & 31, c4 = id >> 5;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            int row = 2 * p + e;
-            r[2 * i + e] = (row < nvalid)
-                               ? *reinterpret_cast<const float4*>(base + (long)(row0 + row) * ld + c4 * 4)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-}
-template <int DH>
-__device__ __forceinline__ void trans_stash(uint16_t* St, int tid, const float4 (&r)[DH / 16]) {
-#pragma unroll
-    for (int i = 0; i < DH / 32; ++i) {
-        int id = tid + 256 * i;
-        int p = id & 31, c4 = id >> 5;
-        const float4 a = r[2 * i], b = r[2 * i + 1];
-        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bf16x2 h;
-            h[0] = (__bf16)av[e]; h[1] = (__bf16)bv[e];
-            *reinterpret_cast<uint32_t*>(St + (c4 * 4 + e) * TLD + 2 * p) = *reinterpret_cast<uint32_t*>(&h);
-        }
+        uint2 a = *reinterpret_cast<const uint2*>(S + (2 * p) * LD + c4 * 4);
+        uint2 b = *reinterpret_cast<const uint2*>(S + (2 * p + 1) * LD + c4 * 4);
+        uint32_t w0 = (a.x & 0xFFFFu) | (b.x << 16), w1 = (a.x >> 16) | (b.x & 0xFFFF0000u);
+        uint32_t w2 = (a.y & 0xFFFFu) | (b.y << 16), w3 = (a.y >> 16) | (b.y & 0xFFFF0000u);
+        uint16_t* d = St + (c4 * 4) * TLD + 2 * p;
+        *reinterpret_cast<uint32_t*>(d) = w0;
+        *reinterpret_cast<uint32_t*>(d + TLD) = w1;
+        *reinterpret_cast<uint32_t*>(d + 2 * TLD) = w2;
+        *reinterpret_cast<uint32_t*>(d + 3 * TLD) = w3;
     }
 }
 
@@ -178,14 +173,15 @@ struct HSm {
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     using SM = HSm<DH>;
-    constexpr int TILE_BYTES = (SM::ROWS + SM::TRN) * 2;
+    constexpr int TILE_BYTES = (2 * SM::ROWS + SM::TRN) * 2;
     constexpr int MAIN = TILE_BYTES > SM::PATCH_BYTES ? TILE_BYTES : SM::PATCH_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + HKT * 4];
     uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* Vt = Ks + SM::ROWS;
+    uint16_t* Vs = Ks + SM::ROWS;
+    uint16_t* Vt = Vs + SM::ROWS;
     float* padS = reinterpret_cast<float*>(smem + MAIN);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
@@ -193,7 +189,6 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     const int d = p.H * DH;
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
-    const uint64_t seed = ttsmi_step_seed(p.seed, p.step_dev);
     const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
     const float* Kb = Qb + d;
     const float* Vb = Qb + 2 * d;
@@ -205,73 +200,87 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     for (int cb = 0; cb < DH / 32; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY, l = 0.f;                 // running max (log2 units) and sum
     const int klen = p.klen[b];
-    const long drop_row = (((long)b * p.H + h) * p.T + q) * (long)p.T;
-    const float inv_sqrt = 1.0f / p.sqrt_dk;
+    const float c1 = LOG2E / p.sqrt_dk;
+    uint32_t drop_rb = 0;
+    if (DROP) drop_rb = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site),
+                                       (uint32_t)(((long)b * p.H + h) * p.T + q));
 
     float4 rk[DH / 16], rv[DH / 16];
     float rpad = 0.f;
     {
         int nv = min(HKT, klen);
         rows_fetch<DH>(Kb, p.ld, 0, nv, tid, rk);
-        trans_fetch<DH>(Vb, p.ld, 0, nv, tid, rv);
+        rows_fetch<DH>(Vb, p.ld, 0, nv, tid, rv);
         if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + tid]) ? 1.f : 0.f;
     }
     for (int k0 = 0; k0 < klen; k0 += HKT) {
         __syncthreads();
         rows_stash<DH>(Ks, tid, rk);
-        trans_stash<DH>(Vt, tid, rv);
+        rows_stash<DH>(Vs, tid, rv);
         if (tid < HKT) padS[tid] = rpad;
-        __syncthreads();
+        const int anypad = __syncthreads_or(tid < HKT && rpad != 0.f);
+        lds_transpose<DH>(Vs, Vt, tid);
         if (k0 + HKT < klen) {
             int nv = min(HKT, klen - (k0 + HKT));
             rows_fetch<DH>(Kb, p.ld, k0 + HKT, nv, tid, rk);
-            trans_fetch<DH>(Vb, p.ld, k0 + HKT, nv, tid, rv);
+            rows_fetch<DH>(Vb, p.ld, k0 + HKT, nv, tid, rv);
             if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + k0 + HKT + tid]) ? 1.f : 0.f;
         }
+        __syncthreads();
 #pragma unroll
         for (int kt = 0; kt < HKT / 32; ++kt) {
-            if (k0 + kt * 32 >= klen) break;
+            const int kbase = k0 + kt * 32;
+            if (kbase >= klen) break;
             f32x16 s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                 // S^T[key][q]
-            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int kl = kt * 32 + rowmap16(r, hh);
-                float v = s[r] * inv_sqrt;
-                v += padS[kl] * -1e9f;
-                if (k0 + kl >= klen) v = -INFINITY;
-                s[r] = v;
-                mx = fmaxf(mx, v);
+            for (int r = 0; r < 16; ++r) s[r] *= c1;
+            if (anypad) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] += padS[kt * 32 + rowmap16(r, hh)] * (-1e9f * LOG2E);
             }
+            if (kbase + 32 > klen) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + rowmap16(r, hh) >= klen) s[r] = -INFINITY;
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float mn = fmaxf(m, mx);
-            float alpha = __expf(m - mn);
+            const float mn = fmaxf(m, mx);
+            const float alpha = EXP2(m - mn);
             float rs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float e = __expf(s[r] - mn);
-                rs += e;
-                if (p.thr) {
-                    int key = k0 + kt * 32 + rowmap16(r, hh);
-                    e *= ttsmi_keep_scale(seed, p.site, (uint64_t)(drop_row + key), p.thr, p.inv_keep);
+                s[r] = EXP2(s[r] - mn);
+                rs += s[r];
+            }
+            if (DROP) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {                // keys of (r, r+1) are (even, odd) neighbours
+                    const uint32_t hsh = ttsmi_pair_hash(drop_rb, (uint32_t)(kbase + rowmap16(r, hh)));
+                    s[r] *= ((hsh & 0xFFFFu) >= p.thr) ? p.inv_keep : 0.f;
+                    s[r + 1] *= ((hsh >> 16) >= p.thr) ? p.inv_keep : 0.f;
                 }
-                s[r] = e;
             }
             rs += __shfl_xor(rs, 32, 64);
             l = l * alpha + rs;
             m = mn;
+            if (!__all(alpha == 1.0f)) {
 #pragma unroll
-            for (int cb = 0; cb < DH / 32; ++cb)
+                for (int cb = 0; cb < DH / 32; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+            }
             bf16x8 pb[2];
             to_frags(s, pb);
             accumT16<DH>(Vt, kt * 32, l31, hh, pb, o);                        // O^T += V^T.P^T
         }
     }
     __syncthreads();
-    if (qok && hh == 0) p.lse[((long)b * p.H + h) * p.T + q] = m + logf(l);
+    if (qok && hh == 0) p.lse[((long)b * p.H + h) * p.T + q] = (m + log2f(l)) * LN2;
     float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
     int row0 = blockIdx.x * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
 // =================================================================================================
 // backward A: dQ (+ delta)
 // =================================================================================================
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = (2 * SM::ROWS + SM::TRN) * 2;
@@ -297,7 +306,6 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     const int d = p.H * DH;
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
-    const uint64_t seed = ttsmi_step_seed(p.seed, p.step_dev);
     const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
     const float* Kb = Qb + d;
     const float* Vb = Qb + 2 * d;
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     delta += __shfl_xor(delta, 32, 64);
     const long sidx = ((long)b * p.H + h) * p.T + q;
     if (qok && hh == 0) p.delta[sidx] = delta;
-    const float lse = qok ? p.lse[sidx] : INFINITY;
+    const float lse2 = qok ? p.lse[sidx] * LOG2E : INFINITY;
 
     f32x16 dq[DH / 32];
 #pragma unroll
@@ -328,46 +336,60 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[cb][r] = 0.f;
     const int klen = p.klen[b];
-    const long drop_row = sidx * (long)p.T;
     const float inv_sqrt = 1.0f / p.sqrt_dk;
+    const float c1 = LOG2E * inv_sqrt;
+    uint32_t drop_rb = 0;
+    if (DROP) drop_rb = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site), (uint32_t)sidx);
 
-    float4 rk[DH / 16], rv[DH / 16], rkt[DH / 16];
+    float4 rk[DH / 16], rv[DH / 16];
     float rpad = 0.f;
     {
         int nv = min(HKT, klen);
         rows_fetch<DH>(Kb, p.ld, 0, nv, tid, rk);
         rows_fetch<DH>(Vb, p.ld, 0, nv, tid, rv);
-        trans_fetch<DH>(Kb, p.ld, 0, nv, tid, rkt);
         if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + tid]) ? 1.f : 0.f;
     }
     for (int k0 = 0; k0 < klen; k0 += HKT) {
         __syncthreads();
         rows_stash<DH>(Ks, tid, rk);
         rows_stash<DH>(Vs, tid, rv);
-        trans_stash<DH>(Kt, tid, rkt);
         if (tid < HKT) padS[tid] = rpad;
-        __syncthreads();
+        const int anypad = __syncthreads_or(tid < HKT && rpad != 0.f);
+        lds_transpose<DH>(Ks, Kt, tid);
         if (k0 + HKT < klen) {
             int nv = min(HKT, klen - (k0 + HKT));
             rows_fetch<DH>(Kb, p.ld, k0 + HKT, nv, tid, rk);
             rows_fetch<DH>(Vb, p.ld, k0 + HKT, nv, tid, rv);
-            trans_fetch<DH>(Kb, p.ld, k0 + HKT, nv, tid, rkt);
             if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + k0 + HKT + tid]) ? 1.f : 0.f;
         }
+        __syncthreads();
 #pragma unroll
         for (int kt = 0; kt < HKT / 32; ++kt) {
-            if (k0 + kt * 32 >= klen) break;
+            const int kbase = k0 + kt * 32;
+            if (kbase >= klen) break;
             f32x16 s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                 // S^T
             f32x16 dp = dot16<DH>(Vs, kt * 32 + l31, hh, dof);               // dP^T = V.dO^T
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int kl = kt * 32 + rowmap16(r, hh);
-                float v = s[r] * inv_sqrt + padS[kl] * -1e9f;
-                float pr = (k0 + kl >= klen) ? 0.f : __expf(v - lse);
-                float keep = 1.f;
-                if (p.thr) keep = ttsmi_keep_scale(seed, p.site, (uint64_t)(drop_row + k0 + kl), p.thr, p.inv_keep);
-                s[r] = pr * (keep * dp[r] - delta) * inv_sqrt;               // dS^T
+            for (int r = 0; r < 16; ++r) s[r] = s[r] * c1 - lse2;
+            if (anypad) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] += padS[kt * 32 + rowmap16(r, hh)] * (-1e9f * LOG2E);
             }
+            if (kbase + 32 > klen) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + rowmap16(r, hh) >= klen) s[r] = -INFINITY;
+            }
+            if (DROP) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const uint32_t hsh = ttsmi_pair_hash(drop_rb, (uint32_t)(kbase + rowmap16(r, hh)));
+                    dp[r] *= ((hsh & 0xFFFFu) >= p.thr) ? p.inv_keep : 0.f;
+                    dp[r + 1] *= ((hsh >> 16) >= p.thr) ? p.inv_keep : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = EXP2(s[r]) * (dp[r] - delta) * inv_sqrt;   // dS^T
             bf16x8 pb[2];
             to_frags(s, pb);
             accumT16<DH>(Kt, kt * 32, l31, hh, pb, dq);                       // dQ^T += K^T.dS^T
@@ -383,18 +405,19 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
 // =================================================================================================
 // backward B: dK, dV (workgroup owns 128 keys, loops over queries)
 // =================================================================================================
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = (2 * SM::ROWS + 2 * SM::TRN) * 2;
     constexpr int MAIN = TILE_BYTES > SM::PATCH_BYTES ? TILE_BYTES : SM::PATCH_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + 2 * HKT * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + 3 * HKT * 4];
     uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Os = Qs + SM::ROWS;
     uint16_t* Qt = Os + SM::ROWS;
     uint16_t* Ot = Qt + SM::TRN;
     float* lseS = reinterpret_cast<float*>(smem + MAIN);
     float* delS = lseS + HKT;
+    uint32_t* rbS = reinterpret_cast<uint32_t*>(delS + HKT);     // dropout row bases of the q tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -403,7 +426,6 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     const int klen = p.klen[b];
     const bool kok = key < p.T;
     const bool kact = key < klen;
-    const uint64_t seed = ttsmi_step_seed(p.seed, p.step_dev);
     const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
     const float* Kb = Qb + d;
     const float* Vb = Qb + 2 * d;
@@ -412,7 +434,8 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     bf16x8 kf[DH / 16], vf[DH / 16];
     row_frags<DH>(Kb, p.ld, key, kok, hh, kf);
     row_frags<DH>(Vb, p.ld, key, kok, hh, vf);
-    const float padterm = (kok && p.key_pad[(long)b * p.T + key]) ? -1e9f : 0.f;
+    // keys that took no part in the forward (>= klen) get probability 0 through a -inf logit
+    const float padterm = !kact ? -INFINITY : ((p.key_pad[(long)b * p.T + key]) ? -1e9f * LOG2E : 0.f);
 
     f32x16 dk[DH / 32], dv[DH / 32];
 #pragma unroll
@@ -420,20 +443,21 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[cb][r] = 0.f; dv[cb][r] = 0.f; }
     const float inv_sqrt = 1.0f / p.sqrt_dk;
+    const float c1 = LOG2E * inv_sqrt;
     const long stat0 = ((long)b * p.H + h) * p.T;
+    uint64_t dkey = 0;
+    if (DROP) dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
 
     const bool wg_active = blockIdx.x * 128 < klen;
     if (wg_active) {
-        float4 rq[DH / 16], ro[DH / 16], rqt[DH / 16], rot[DH / 16];
+        float4 rq[DH / 16], ro[DH / 16];
         float rl = 0.f, rd = 0.f;
         {
             int nv = min(HKT, p.T);
             rows_fetch<DH>(Qb, p.ld, 0, nv, tid, rq);
             rows_fetch<DH>(dOb, d, 0, nv, tid, ro);
-            trans_fetch<DH>(Qb, p.ld, 0, nv, tid, rqt);
-            trans_fetch<DH>(dOb, d, 0, nv, tid, rot);
             if (tid < HKT) {
-                rl = tid < nv ? p.lse[stat0 + tid] : INFINITY;
+                rl = tid < nv ? p.lse[stat0 + tid] * LOG2E : INFINITY;
                 rd = tid < nv ? p.delta[stat0 + tid] : 0.f;
             }
         }
@@ -441,21 +465,24 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
             __syncthreads();
             rows_stash<DH>(Qs, tid, rq);
             rows_stash<DH>(Os, tid, ro);
-            trans_stash<DH>(Qt, tid, rqt);
-            trans_stash<DH>(Ot, tid, rot);
-            if (tid < HKT) { lseS[tid] = rl; delS[tid] = rd; }
+            if (tid < HKT) {
+                lseS[tid] = rl;
+                delS[tid] = rd;
+                if (DROP) rbS[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0 + tid));
+            }
             __syncthreads();
+            lds_transpose<DH>(Qs, Qt, tid);
+            lds_transpose<DH>(Os, Ot, tid);
             if (q0 + HKT < p.T) {
                 int nv = min(HKT, p.T - (q0 + HKT));
                 rows_fetch<DH>(Qb, p.ld, q0 + HKT, nv, tid, rq);
                 rows_fetch<DH>(dOb, d, q0 + HKT, nv, tid, ro);
-                trans_fetch<DH>(Qb, p.ld, q0 + HKT, nv, tid, rqt);
-                trans_fetch<DH>(dOb, d, q0 + HKT, nv, tid, rot);
                 if (tid < HKT) {
-                    rl = tid < nv ? p.lse[stat0 + q0 + HKT + tid] : INFINITY;
+                    rl = tid < nv ? p.lse[stat0 + q0 + HKT + tid] * LOG2E : INFINITY;
                     rd = tid < nv ? p.delta[stat0 + q0 + HKT + tid] : 0.f;
                 }
             }
+            __syncthreads();
 #pragma unroll
             for (int qt = 0; qt < HKT / 32; ++qt) {
                 if (q0 + qt * 32 >= p.T) break;
@@ -464,15 +491,18 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
                 f32x16 pt;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int ql = qt * 32 + rowmap16(r, hh);
-                    float v = s[r] * inv_sqrt + padterm;
-                    float pr = kact ? __expf(v - lseS[ql]) : 0.f;
-                    float keep = 1.f;
-                    if (p.thr)
-                        keep = ttsmi_keep_scale(seed, p.site, (uint64_t)((stat0 + q0 + ql) * (long)p.T + key),
-                                                p.thr, p.inv_keep);
-                    pt[r] = pr * keep;
-                    s[r] = pr * (keep * dp[r] - delS[ql]) * inv_sqrt;
+                    const int ql = qt * 32 + rowmap16(r, hh);
+                    float pr = EXP2(s[r] * c1 + padterm - lseS[ql]);        // lse = +inf for q >= T
+                    float dpr = dp[r];
+                    if (DROP) {
+                        const uint32_t hsh = ttsmi_pair_hash(rbS[ql], (uint32_t)key);
+                        const float keep = ttsmi_keep_of(hsh, (uint32_t)key, p.thr, p.inv_keep);
+                        dpr *= keep;
+                        pt[r] = pr * keep;
+                    } else {
+                        pt[r] = pr;
+                    }
+                    s[r] = pr * (dpr - delS[ql]) * inv_sqrt;                 // dS
                 }
                 bf16x8 pb[2], sb[2];
                 to_frags(pt, pb);
@@ -508,10 +538,16 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
     return TTSMI_OK;
 }
 
+#define HLAUNCH(KERNEL, DHV, grid, st, p)                                                      \
+    do {                                                                                       \
+        if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, true>), grid, dim3(256), 0, st, p);       \
+        else hipLaunchKernelGGL((KERNEL<DHV, false>), grid, dim3(256), 0, st, p);              \
+    } while (0)
+
 #define HDISPATCH(dh, KERNEL, grid, st, p)                                                     \
     switch (dh) {                                                                              \
-        case 32: hipLaunchKernelGGL((KERNEL<32>), grid, dim3(256), 0, st, p); break;           \
-        case 64: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, st, p); break;           \
+        case 32: HLAUNCH(KERNEL, 32, grid, st, p); break;                                      \
+        case 64: HLAUNCH(KERNEL, 64, grid, st, p); break;                                      \
         default:                                                                               \
             ttsmi_set_error("bf16 attention: head dim %d not built (32/64)", dh);              \
             return TTSMI_ERR_UNSUPPORTED;                                                      \

@@ -54,40 +54,50 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- counter-based dropout RNG ----------------------------------------------------------------
-// Stateless: keep(seed, site, idx) so that forward and backward regenerate the same mask without
-// storing it.  The (seed, site) pair is mixed once per launch with a 64-bit splitmix finaliser
-// (loop invariant - the compiler hoists it); the per-element work is one 32-bit avalanche hash
-// (two multiply-xorshift rounds, ~8 VALU ops), cheap enough to sit inside the attention inner
-// loop next to the MFMAs.  Statistical quality is checked in tests.
+// Stateless: keep(seed, step, site, row, col) so that forward and backward regenerate the same mask
+// without storing it, in every kernel and in both precisions.  Cost model (it sits inside the
+// attention inner loop next to the MFMAs):
+//   per launch : one 64-bit splitmix of (seed + step counter, site)          -> ttsmi_drop_key
+//   per row    : one 32-bit avalanche of the row index                        -> ttsmi_row_base
+//   per PAIR of adjacent columns (2j, 2j+1): one 32-bit avalanche (~8 VALU)   -> ttsmi_pair_hash
+//   per element: a 16-bit half of that hash against thr16 = round(p * 65536)  -> ttsmi_keep_of
+// Statistical quality (rate, row/column independence, site independence) is checked in tests.
 __device__ __forceinline__ uint64_t ttsmi_mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-// returns a uniform 32-bit word for element `idx` of dropout site `site` under `seed`
-__device__ __forceinline__ uint32_t ttsmi_rand32(uint64_t seed, uint32_t site, uint64_t idx) {
-    const uint64_t s = ttsmi_mix64(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1));
-    uint32_t h = (uint32_t)idx ^ (uint32_t)s;
-    h += (uint32_t)(idx >> 32) * 0x9E3779B1u + (uint32_t)(s >> 32);
+__device__ __forceinline__ uint32_t ttsmi_mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x7feb352du;
     h ^= h >> 15; h *= 0x846ca68bu;
     h ^= h >> 16;
     return h;
 }
-// keep-scale: 1/(1-p) if kept else 0.  thr = p * 2^32 (precomputed on the host)
-__device__ __forceinline__ float ttsmi_keep_scale(uint64_t seed, uint32_t site, uint64_t idx,
-                                                  uint32_t thr, float inv_keep) {
-    return ttsmi_rand32(seed, site, idx) >= thr ? inv_keep : 0.0f;
+// The host seed is advanced by a DEVICE step counter so that a captured hipGraph draws fresh masks
+// on every replay (kernel arguments are frozen at capture).
+__device__ __forceinline__ uint64_t ttsmi_drop_key(uint64_t seed, const int64_t* step_dev, uint32_t site) {
+    uint64_t s = step_dev ? seed + 0xA0761D6478BD642Full * (uint64_t)(*step_dev) : seed;
+    return ttsmi_mix64(s + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1));
 }
-// Effective seed of a launch: the host seed advanced by a DEVICE step counter, so that a captured
-// hipGraph draws fresh masks on every replay (kernel arguments are frozen at capture).
-__device__ __forceinline__ uint64_t ttsmi_step_seed(uint64_t seed, const int64_t* step_dev) {
-    return step_dev ? seed + 0xA0761D6478BD642Full * (uint64_t)(*step_dev) : seed;
+__device__ __forceinline__ uint32_t ttsmi_row_base(uint64_t key, uint32_t row) {
+    return ttsmi_mix32(row ^ (uint32_t)key) + (uint32_t)(key >> 32);
 }
-static inline uint32_t ttsmi_drop_threshold(float p) {
-    double t = (double)p * 4294967296.0;
+__device__ __forceinline__ uint32_t ttsmi_pair_hash(uint32_t row_base, uint32_t col) {
+    return ttsmi_mix32(row_base + (col >> 1) * 0x85EBCA6Bu);
+}
+__device__ __forceinline__ float ttsmi_keep_of(uint32_t h, uint32_t col, uint32_t thr16, float inv_keep) {
+    uint32_t u = (col & 1u) ? (h >> 16) : (h & 0xFFFFu);
+    return u >= thr16 ? inv_keep : 0.0f;
+}
+// convenience: one element
+__device__ __forceinline__ float ttsmi_keep_scale(uint64_t key, uint32_t row, uint32_t col, uint32_t thr16,
+                                                  float inv_keep) {
+    return ttsmi_keep_of(ttsmi_pair_hash(ttsmi_row_base(key, row), col), col, thr16, inv_keep);
+}
+static inline uint32_t ttsmi_drop_threshold(float p) {      // thr16
+    double t = (double)p * 65536.0 + 0.5;
     if (t < 0) t = 0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    if (t > 65535.0) t = 65535.0;
     return (uint32_t)t;
 }
 

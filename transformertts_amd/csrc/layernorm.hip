@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= p.M) return;
-    p.seed = ttsmi_step_seed(p.seed, p.step_dev);
+    const uint64_t key_in = ttsmi_drop_key(p.seed, p.step_dev, p.site_in);
+    const uint64_t key_out = ttsmi_drop_key(p.seed, p.step_dev, p.site_out);
     const long base = (long)row * p.C;
     float z[NPL][VW];
     float s = 0.f;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
             if (p.thr_in) {
 #pragma unroll
                 for (int e = 0; e < VW; ++e)
-                    z[j][e] *= ttsmi_keep_scale(p.seed, p.site_in, base + c + e, p.thr_in, p.inv_in);
+                    z[j][e] *= ttsmi_keep_scale(key_in, (uint32_t)row, (uint32_t)(c + e), p.thr_in, p.inv_in);
             }
             if (p.res) {
                 float r[VW];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
             if (p.thr_out) {
 #pragma unroll
                 for (int e = 0; e < VW; ++e)
-                    o[e] *= ttsmi_keep_scale(p.seed, p.site_out, base + c + e, p.thr_out, p.inv_out);
+                    o[e] *= ttsmi_keep_scale(key_out, (uint32_t)row, (uint32_t)(c + e), p.thr_out, p.inv_out);
             }
             if (padded) {
 #pragma unroll
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
     const int lane = threadIdx.x & 63;
     const int wave_g = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * LN_WAVES;
-    p.seed = ttsmi_step_seed(p.seed, p.step_dev);
+    const uint64_t key_in = ttsmi_drop_key(p.seed, p.step_dev, p.site_in);
+    const uint64_t key_out = ttsmi_drop_key(p.seed, p.step_dev, p.site_out);
     float ag[NPL][VW], ab[NPL][VW];
     float as = 0.f;
 #pragma unroll
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
                 ldv<VW>(p.gamma + c, gam);
 #pragma unroll
                 for (int e = 0; e < VW; ++e) {
-                    float kin = p.thr_in ? ttsmi_keep_scale(p.seed, p.site_in, base + c + e, p.thr_in, p.inv_in) : 1.f;
+                    float kin = p.thr_in ? ttsmi_keep_scale(key_in, (uint32_t)row, (uint32_t)(c + e), p.thr_in, p.inv_in) : 1.f;
                     // relu'(x) of the producer folded into the x branch
                     keep[j][e] = (p.relu_in && !(xv[e] > 0.f)) ? 0.f : kin;
                     xv[e] *= kin;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
                 if (p.thr_out) {
 #pragma unroll
                     for (int e = 0; e < VW; ++e)
-                        g[e] *= ttsmi_keep_scale(p.seed, p.site_out, base + c + e, p.thr_out, p.inv_out);
+                        g[e] *= ttsmi_keep_scale(key_out, (uint32_t)row, (uint32_t)(c + e), p.thr_out, p.inv_out);
                 }
                 if (p.pe) {
                     float pe[VW];
