@@ -70,6 +70,8 @@ def _flops(name, a):
         return 2.0 * a[13] * a[14] * a[15]
     if name == 'ttsmi_hgemm_wgrad':
         return 2.0 * a[6] * a[7] * a[8]
+    if name == 'ttsmi_hgemm_wgrad_rows':
+        return 2.0 * a[7] * a[8] * a[9]
     if name == 'ttsmi_attention_fwd':
         B, H, T, dh = a[5], a[6], a[7], a[8]
         return 4.0 * B * H * T * T * dh                      # QK^T + PV
@@ -88,6 +90,7 @@ KERNEL_OF = {
     'ttsmi_conv1d_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
     'ttsmi_hgemm_tn': 'gemm_bf16_kernel<A=f32> (Dense/Conv1D forward + dgrad, bf16 MFMA)',
     'ttsmi_hgemm_wgrad': 'gemm_bf16_kernel<A=bf16> (wgrad, bf16 MFMA, + split reduce)',
+    'ttsmi_hgemm_wgrad_rows': 'wgrad_rows_kernel (wgrad from fp32 rows, bf16 MFMA, + split reduce)',
     'ttsmi_attention_fwd': 'attn_fwd_kernel',
     'ttsmi_attention_bwd': 'attn_bwd_dq_kernel + attn_bwd_dkv_kernel',
 }
@@ -174,7 +177,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='configs[1]')
     ap.add_argument('--dropout', type=float, default=0.1)
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'])
+    # BASELINE.json configs[1] is quoted in bf16: bf16 GEMM/attention operands, fp32 accumulate, fp32
+    # master weights / activations / optimiser.  --precision f32 runs the exact-fp32 parity path.
+    ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()

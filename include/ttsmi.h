@@ -257,6 +257,13 @@ size_t ttsmi_hgemm_wgrad_ws_bytes(int rows, int kin, int n);
 int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, float* dw, int64_t lddw,
                       float* db, int rows, int kin, int n, void* ws, size_t ws_bytes,
                       ttsmi_stream_t stream);
+/* dw[kin,n] = x[rows,kin]^T . dy[rows,n] (+ db) straight from the row-major fp32 tensors (operands are
+ * rounded to bf16 and transposed inside the kernel).  Conv1D wgrad: conv_taps > 1, x is [B*conv_T,
+ * conv_C] with conv_C %% 128 == 0 and kin = conv_taps*conv_C. */
+size_t ttsmi_hgemm_wgrad_rows_ws_bytes(int rows, int kin, int n);
+int ttsmi_hgemm_wgrad_rows(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, int64_t lddw,
+                           float* db, int rows, int kin, int n, int conv_taps, int conv_T, int conv_C,
+                           int conv_pad, void* ws, size_t ws_bytes, ttsmi_stream_t stream);
 int ttsmi_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int R,
                               int C, int taps, int T, int pad, ttsmi_stream_t stream);
 int ttsmi_conv_wdgrad_layout_bf16(const float* w, uint16_t* dst, int k, int Cin, int Cout,

@@ -561,3 +561,24 @@ def test_bf16_attention_dropout_matches_fp32_mask():
     b, _ = ops.AttentionFn.apply(qkv, pad, klen, B, H, T, dh, p, drop, 9)
     c, _ = ops.AttentionFn.apply(qkv, pad, klen, B, H, T, dh, p, drop, 10)
     assert rel_err(a, b) < 1e-2 and rel_err(c, b) > 5e-2
+
+
+@pytest.mark.parametrize('M,K,N', [(1000, 256, 128), (333, 64, 200), (28800 // 8, 1024, 256), (77, 100, 60)])
+def test_hgemm_wgrad_rows(M, K, N):
+    ops = _ops()
+    x, dy = g(M, K, seed=1), g(M, N, seed=2)
+    dw, db = torch.empty(K, N, device=DEV), torch.empty(N, device=DEV)
+    ops.hgemm_wgrad_rows(x.to(DEV), dy.to(DEV), dw, db)
+    assert rel_err(dw, _bf(x).T @ _bf(dy)) < 3e-6
+    assert rel_err(db, _bf(dy).sum(0)) < 3e-6
+
+
+def test_hgemm_wgrad_rows_conv():
+    ops = _ops()
+    B, T, Cin, Cout, k = 3, 41, 128, 72, 3
+    x, dy = g(B, T, Cin, seed=1), g(B, T, Cout, seed=2)
+    dw, db = torch.empty(k * Cin, Cout, device=DEV), torch.empty(Cout, device=DEV)
+    ops.hgemm_wgrad_rows(x.reshape(B * T, Cin).to(DEV), dy.reshape(B * T, Cout).to(DEV), dw, db, conv=(k, T, Cin, 1))
+    xd, wd = _bf(x), torch.zeros(k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    fo.conv1d_same(xd, wd, torch.zeros(Cout, dtype=torch.float64)).backward(_bf(dy))
+    assert rel_err(dw.reshape(k, Cin, Cout), wd.grad) < 3e-6

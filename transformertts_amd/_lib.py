@@ -69,6 +69,8 @@ SIGNATURES = {
     'ttsmi_hgemm_wgrad_ws_bytes': (c_size_t, [I, I, I]),
     'ttsmi_hgemm_wgrad': (I, [P, P, L, P, L, P, I, I, I, P, c_size_t, S]),
     'ttsmi_cast_transpose_bf16': (I, [P, L, P, L, I, I, I, I, I, S]),
+    'ttsmi_hgemm_wgrad_rows_ws_bytes': (c_size_t, [I, I, I]),
+    'ttsmi_hgemm_wgrad_rows': (I, [P, L, P, L, P, L, P, I, I, I, I, I, I, I, P, c_size_t, S]),
     'ttsmi_conv_wdgrad_layout_bf16': (I, [P, P, I, I, I, S]),
 }
 

@@ -15,6 +15,8 @@
 // accumulators), LDS images [128][64+8] bf16 (144-byte rows: the 16 lanes of a ds_read_b128 group
 // hit 16 different 16-byte slots -> conflict free), register prefetch of the next k-tile.
 // With fp32 activations in HBM these GEMMs are L2/HBM-bound (44 FLOP/B at this tile), not MFMA-bound.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -47,13 +49,14 @@ __device__ __forceinline__ uint2 pack4(float4 v) {
     return *reinterpret_cast<uint2*>(&h);
 }
 
-// ---- A tile fetch: fp32 source (8 float4 per thread) -------------------------------------------
+// ---- A tile fetch: fp32 source (BM/16 float4 per thread) -----------------------------------------
+template <int BM>
 __device__ __forceinline__ void fetch_a_f32(const HGemmP& p, int m0, int k0, int kend, int tid,
-                                            float4 (&r)[8]) {
+                                            float4 (&r)[BM / 16]) {
     const float* A = (const float*)p.A;
     const float* A2 = (const float*)p.A2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < BM / 16; ++i) {
         int id = tid + 256 * i;
         int row = id >> 4, c4 = id & 15;
         int m = m0 + row, kk = k0 + c4 * 4;
@@ -71,19 +74,21 @@ __device__ __forceinline__ void fetch_a_f32(const HGemmP& p, int m0, int k0, int
         r[i] = ok ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
-__device__ __forceinline__ void stash_a_f32(uint16_t (*S)[HLD_], int tid, const float4 (&r)[8]) {
+template <int BM>
+__device__ __forceinline__ void stash_a_f32(uint16_t (*S)[HLD_], int tid, const float4 (&r)[BM / 16]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < BM / 16; ++i) {
         int id = tid + 256 * i;
         int row = id >> 4, c4 = id & 15;
         *reinterpret_cast<uint2*>(&S[row][c4 * 4]) = pack4(r[i]);
     }
 }
-// ---- bf16 source tile (4 uint4 per thread) -----------------------------------------------------
+// ---- bf16 source tile of ROWS rows (ROWS/32 uint4 per thread) -----------------------------------
+template <int ROWS>
 __device__ __forceinline__ void fetch_h(const uint16_t* base, long ld, int rows, int r0, int k0,
-                                        int kend, int tid, uint4 (&r)[4]) {
+                                        int kend, int tid, uint4 (&r)[ROWS / 32]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i) {
         int id = tid + 256 * i;
         int row = id >> 3, c8 = id & 7;
         int m = r0 + row, kk = k0 + c8 * 8;
@@ -91,47 +96,56 @@ __device__ __forceinline__ void fetch_h(const uint16_t* base, long ld, int rows,
         r[i] = ok ? *reinterpret_cast<const uint4*>(base + (long)m * ld + kk) : make_uint4(0, 0, 0, 0);
     }
 }
-__device__ __forceinline__ void stash_h(uint16_t (*S)[HLD_], int tid, const uint4 (&r)[4]) {
+template <int ROWS>
+__device__ __forceinline__ void stash_h(uint16_t (*S)[HLD_], int tid, const uint4 (&r)[ROWS / 32]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i) {
         int id = tid + 256 * i;
         int row = id >> 3, c8 = id & 7;
         *reinterpret_cast<uint4*>(&S[row][c8 * 8]) = r[i];
     }
 }
 
-template <bool A_F32>
+#define EPLD 68     // fp32 row stride of the per-wave epilogue patch [32][64+4]
+
+// BM = 128: wave tile 64x64 (2x2 MFMA tiles); BM = 64: wave tile 32x64 (1x2) - half the registers,
+// twice the resident workgroups: these GEMMs are HBM/L2-latency bound, not MFMA bound.
+template <bool A_F32, int BM>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2][HBM_][HLD_];
-    uint16_t(*As)[HLD_] = smem[0];
-    uint16_t(*Bs)[HLD_] = smem[1];
+    constexpr int MI = BM / 64;
+    constexpr int TILE_BYTES = (BM + HBN_) * HLD_ * 2;
+    constexpr int PATCH_BYTES = 4 * 32 * EPLD * 4;
+    constexpr int SMEM_BYTES = TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+    uint16_t(*As)[HLD_] = reinterpret_cast<uint16_t(*)[HLD_]>(smem);
+    uint16_t(*Bs)[HLD_] = As + BM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
-    const int m0 = tm * HBM_, n0 = tn * HBN_;
+    const int m0 = tm * BM, n0 = tn * HBN_;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int l31 = lane & 31, kg = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[8];      // fp32-A prefetch registers (dead in the bf16-A instantiation)
-    uint4 rah[4];      // bf16-A prefetch registers (dead in the fp32-A instantiation)
-    uint4 rb[4];
+    float4 ra[BM / 16];   // fp32-A prefetch registers (dead in the bf16-A instantiation)
+    uint4 rah[BM / 32];   // bf16-A prefetch registers (dead in the fp32-A instantiation)
+    uint4 rb[HBN_ / 32];
     if (kbeg < kend) {
-        if constexpr (A_F32) fetch_a_f32(p, m0, kbeg, kend, tid, ra);
-        else fetch_h((const uint16_t*)p.A, p.lda, p.M, m0, kbeg, kend, tid, rah);
-        fetch_h(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
-        if constexpr (A_F32) stash_a_f32(As, tid, ra); else stash_h(As, tid, rah);
-        stash_h(Bs, tid, rb);
+        if constexpr (A_F32) fetch_a_f32<BM>(p, m0, kbeg, kend, tid, ra);
+        else fetch_h<BM>((const uint16_t*)p.A, p.lda, p.M, m0, kbeg, kend, tid, rah);
+        fetch_h<HBN_>(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
+        if constexpr (A_F32) stash_a_f32<BM>(As, tid, ra); else stash_h<BM>(As, tid, rah);
+        stash_h<HBN_>(Bs, tid, rb);
     }
     __syncthreads();
 
@@ -140,9 +154,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
     for (int k0 = kbeg; k0 < kend; k0 += HBK_) {
         const bool more = (k0 + HBK_) < kend;
         if (more) {
-            if constexpr (A_F32) fetch_a_f32(p, m0, k0 + HBK_, kend, tid, ra);
-            else fetch_h((const uint16_t*)p.A, p.lda, p.M, m0, k0 + HBK_, kend, tid, rah);
-            fetch_h(p.B, p.ldb, p.N, n0, k0 + HBK_, kend, tid, rb);
+            if constexpr (A_F32) fetch_a_f32<BM>(p, m0, k0 + HBK_, kend, tid, ra);
+            else fetch_h<BM>((const uint16_t*)p.A, p.lda, p.M, m0, k0 + HBK_, kend, tid, rah);
+            fetch_h<HBN_>(p.B, p.ldb, p.N, n0, k0 + HBK_, kend, tid, rb);
         }
         if (do_colsum) {                       // bias gradient from the dy^T tile (wgrad)
 #pragma unroll
@@ -155,19 +169,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
 #pragma unroll
         for (int ks = 0; ks < HBK_ / 16; ++ks) {
             const int ko = ks * 16 + kg * 8;
-            bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[wr * 64 + l31][ko]);
-            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[wr * 64 + 32 + l31][ko]);
-            bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[wc * 64 + l31][ko]);
-            bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[wc * 64 + 32 + l31][ko]);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            bf16x8 a[MI], b[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(&As[wr * (BM / 2) + i * 32 + l31][ko]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[wc * 64 + j * 32 + l31][ko]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
         if (more) {
-            if constexpr (A_F32) stash_a_f32(As, tid, ra); else stash_h(As, tid, rah);
-            stash_h(Bs, tid, rb);
+            if constexpr (A_F32) stash_a_f32<BM>(As, tid, ra); else stash_h<BM>(As, tid, rah);
+            stash_h<HBN_>(Bs, tid, rb);
         }
         __syncthreads();
     }
@@ -177,25 +194,214 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
         if (split) p.colsum_ws[(long)blockIdx.z * p.N + n0 + tid] = csum;
         else p.colsum[n0 + tid] = csum;
     }
+    // ---- epilogue: accumulators -> per-wave LDS patch -> full-row 16-byte stores -----------------
     float* Cb = split ? p.ws + (long)blockIdx.z * p.M * p.N : p.C;
     const long ldc = split ? (long)p.N : p.ldc;
+    const bool vec = ((ldc & 3) == 0) && ((p.N & 3) == 0) && ((((uintptr_t)Cb) & 15) == 0);
+    const bool fuse = !split;
+    float* patch = reinterpret_cast<float*>(smem) + wave * 32 * EPLD;
+    const int rl = lane >> 4, c4 = lane & 15;
+    const int col = n0 + wc * 64 + c4 * 4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fuse && p.bias) {
+        if (col + 0 < p.N) bias4.x = p.bias[col + 0];
+        if (col + 1 < p.N) bias4.y = p.bias[col + 1];
+        if (col + 2 < p.N) bias4.z = p.bias[col + 2];
+        if (col + 3 < p.N) bias4.w = p.bias[col + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * kg) * EPLD + j * 32 + l31] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int prow = it * 4 + rl;
+            const int row = m0 + wr * (BM / 2) + i * 32 + prow;
+            if (row >= p.M || col >= p.N) continue;
+            float4 v = *reinterpret_cast<const float4*>(patch + prow * EPLD + c4 * 4);
+            if (fuse) {
+                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            float* dst = Cb + (long)row * ldc + col;
+            if (vec) {
+                if (fuse && p.relu_src) {
+                    float4 m = *reinterpret_cast<const float4*>(p.relu_src + (long)row * p.ld_relu + col);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                    v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(dst) = v;
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e >= p.N) break;
+                    float x = vv[e];
+                    if (fuse && p.relu_src) x = p.relu_src[(long)row * p.ld_relu + col + e] > 0.f ? x : 0.f;
+                    dst[e] = x;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+// =================================================================================================
+// wgrad straight from the row-major fp32 activations: dW[K_in, N] = X[M, K_in]^T . dY[M, N].
+// Both operands are fetched as [64 rows][128 cols] fp32 tiles (coalesced 512-byte rows), rounded to
+// bf16 into LDS row images, re-laid-out LDS->LDS into k-contiguous images [128][64+8] (the MFMA
+// fragments need 8 consecutive reduction indices = 8 consecutive ROWS of the source), then consumed
+// like any TN tile.  Versus cast_transpose + TN-GEMM this reads each fp32 activation once and
+// writes nothing but dW: half the HBM traffic and two launches fewer per weight gradient.
+// Conv1D: the K_in tile [j*Cin + c0, +128) lies inside one tap j (Cin % 128 == 0), so its source is
+// the same X tile shifted by (j - pad) frames, rows outside their sequence zeroed.
+// =================================================================================================
+#define WR_ROWS 64
+#define WR_RLD (128 + 8)       // bf16 row image stride
+struct WRowsP {
+    const float* X; long ldx; const float* DY; long lddy;
+    float* dW; long lddw;
+    int M, K, N;                       // rows, K_in (= taps*Cin), N
+    int taps, T, Cin, pad;
+    int k_per_split;
+    float* ws; float* colsum; float* colsum_ws;
+    int tiles_k, tiles_n;
+};
+
+__device__ __forceinline__ void wr_fetch(const float* base, long ld, int ncols, int row0, int rend, int col0,
+                                         int shift, int T, int tid, float4 (&r)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int id = tid + 256 * i;
+        int row = id >> 5, c4 = id & 31;
+        int m = row0 + row, col = col0 + c4 * 4;
+        bool ok = (m < rend) && (col < ncols);
+        long src = m;
+        if (shift != 0 || T > 0) {
+            if (T > 0) {
+                int tt = (m % T) + shift;
+                ok = ok && (tt >= 0) && (tt < T);
+            }
+            src = (long)m + shift;
+        }
+        r[i] = ok ? *reinterpret_cast<const float4*>(base + src * ld + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void wr_stash(uint16_t* S, int tid, const float4 (&r)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int id = tid + 256 * i;
+        int row = id >> 5, c4 = id & 31;
+        *reinterpret_cast<uint2*>(S + row * WR_RLD + c4 * 4) = pack4(r[i]);
+    }
+}
+// row image [64][WR_RLD] -> k-contiguous image [128][HLD_]: item = (row pair p, 4 columns)
+__device__ __forceinline__ void wr_transpose(const uint16_t* S, uint16_t (*St)[HLD_], int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int id = tid + 256 * i;
+        int p = id & 31, c4 = id >> 5;
+        uint2 a = *reinterpret_cast<const uint2*>(S + (2 * p) * WR_RLD + c4 * 4);
+        uint2 b = *reinterpret_cast<const uint2*>(S + (2 * p + 1) * WR_RLD + c4 * 4);
+        *reinterpret_cast<uint32_t*>(&St[c4 * 4 + 0][2 * p]) = (a.x & 0xFFFFu) | (b.x << 16);
+        *reinterpret_cast<uint32_t*>(&St[c4 * 4 + 1][2 * p]) = (a.x >> 16) | (b.x & 0xFFFF0000u);
+        *reinterpret_cast<uint32_t*>(&St[c4 * 4 + 2][2 * p]) = (a.y & 0xFFFFu) | (b.y << 16);
+        *reinterpret_cast<uint32_t*>(&St[c4 * 4 + 3][2 * p]) = (a.y >> 16) | (b.y & 0xFFFF0000u);
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_rows_kernel(WRowsP p) {
+    constexpr int ROWIMG = WR_ROWS * WR_RLD;             // uint16 elements
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * ROWIMG + 2 * 128 * HLD_) * 2];
+    uint16_t* Xr = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* Yr = Xr + ROWIMG;
+    uint16_t(*Xt)[HLD_] = reinterpret_cast<uint16_t(*)[HLD_]>(Yr + ROWIMG);
+    uint16_t(*Yt)[HLD_] = Xt + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, kg = lane >> 5;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p.tiles_n, tk = bid / p.tiles_n;
+    const int k0 = tk * 128, n0 = tn * 128;
+    const int mbeg = blockIdx.z * p.k_per_split;
+    const int mend = min(p.M, mbeg + p.k_per_split);
+    // conv: this K_in tile belongs to tap j; read X columns [k0 - j*Cin, +128) shifted by j - pad frames
+    int tap = 0, xcol0 = k0, shift = 0, Tw = 0, xcols = p.K;
+    if (p.taps > 1) {
+        tap = k0 / p.Cin; xcol0 = k0 - tap * p.Cin; shift = tap - p.pad; Tw = p.T; xcols = p.Cin;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 rx[8], ry[8];
+    if (mbeg < mend) {
+        wr_fetch(p.X, p.ldx, xcols, mbeg, mend, xcol0, shift, Tw, tid, rx);
+        wr_fetch(p.DY, p.lddy, p.N, mbeg, mend, n0, 0, 0, tid, ry);
+    }
+    const bool do_colsum = (p.colsum != nullptr) && (tk == 0) && (tid < 128);
+    float csum = 0.f;
+    for (int m0 = mbeg; m0 < mend; m0 += WR_ROWS) {
+        wr_stash(Xr, tid, rx);
+        wr_stash(Yr, tid, ry);
+        __syncthreads();
+        if (m0 + WR_ROWS < mend) {
+            wr_fetch(p.X, p.ldx, xcols, m0 + WR_ROWS, mend, xcol0, shift, Tw, tid, rx);
+            wr_fetch(p.DY, p.lddy, p.N, m0 + WR_ROWS, mend, n0, 0, 0, tid, ry);
+        }
+        wr_transpose(Xr, Xt, tid);
+        wr_transpose(Yr, Yt, tid);
+        __syncthreads();
+        if (do_colsum) {
+#pragma unroll
+            for (int c8 = 0; c8 < WR_ROWS / 8; ++c8) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(&Yt[tid][c8 * 8]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum += (float)v[e];
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < WR_ROWS / 16; ++ks) {
+            const int ko = ks * 16 + kg * 8;
+            bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&Xt[wr * 64 + l31][ko]);
+            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Xt[wr * 64 + 32 + l31][ko]);
+            bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Yt[wc * 64 + l31][ko]);
+            bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Yt[wc * 64 + 32 + l31][ko]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        // the next iteration's stash overwrites Xr/Yr (free since the transposes) and its transposes
+        // overwrite Xt/Yt only after the barrier that follows the stash
+    }
+    const bool split = gridDim.z > 1;
+    if (do_colsum && n0 + tid < p.N) {
+        if (split) p.colsum_ws[(long)blockIdx.z * p.N + n0 + tid] = csum;
+        else p.colsum[n0 + tid] = csum;
+    }
+    float* Cb = split ? p.ws + (long)blockIdx.z * p.K * p.N : p.dW;
+    const long ldc = split ? (long)p.N : p.lddw;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         int col = n0 + wc * 64 + j * 32 + l31;
         if (col >= p.N) continue;
-        float bv = (!split && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (!split) {
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.relu_src) v = p.relu_src[(long)row * p.ld_relu + col] > 0.f ? v : 0.f;
-                }
-                Cb[(long)row * ldc + col] = v;
+                int row = k0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (row < p.K) Cb[(long)row * ldc + col] = acc[i][j][r];
             }
         }
     }
@@ -278,12 +484,29 @@ static void hinit(HGemmP& p) {
     p.a_taps = 1;
 }
 
+static int hgemm_bm(bool a_f32) {
+    // tuning knob (measurement only): TTSMI_HGEMM_BM=64|128 overrides the default tile height
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("TTSMI_HGEMM_BM");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 64 || forced == 128) return forced;
+    return a_f32 ? 64 : 128;
+}
+
 static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char* name) {
-    p.tiles_m = ttsmi_cdiv(p.M, HBM_);
+    const int bm = hgemm_bm(a_f32);
+    p.tiles_m = ttsmi_cdiv(p.M, bm);
     p.tiles_n = ttsmi_cdiv(p.N, HBN_);
     dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-    if (a_f32) hipLaunchKernelGGL((gemm_bf16_kernel<true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<false>), grid, dim3(256), 0, st, p);
+    if (a_f32) {
+        if (bm == 64) hipLaunchKernelGGL((gemm_bf16_kernel<true, 64>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, 128>), grid, dim3(256), 0, st, p);
+    } else {
+        if (bm == 64) hipLaunchKernelGGL((gemm_bf16_kernel<false, 64>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<false, 128>), grid, dim3(256), 0, st, p);
+    }
     TTSMI_CHECK_LAUNCH(name);
     return TTSMI_OK;
 }
@@ -357,6 +580,48 @@ int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, floa
         hipLaunchKernelGGL(hsplit_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, dw, (long)lddw, kin, n,
                            splits, p.colsum_ws, db);
         TTSMI_CHECK_LAUNCH("hgemm_wgrad_reduce");
+    }
+    return TTSMI_OK;
+}
+
+size_t ttsmi_hgemm_wgrad_rows_ws_bytes(int rows, int kin, int n) { return ttsmi_hgemm_wgrad_ws_bytes(rows, kin, n); }
+
+int ttsmi_hgemm_wgrad_rows(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, int64_t lddw,
+                           float* db, int rows, int kin, int n, int conv_taps, int conv_T, int conv_C,
+                           int conv_pad, void* ws, size_t ws_bytes, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(x && dy && dw, "hgemm_wgrad_rows: null pointer");
+    TTSMI_CHECK_ARG(rows > 0 && kin > 0 && n > 0, "hgemm_wgrad_rows: bad shape");
+    TTSMI_CHECK_ARG(al16(x) && al16(dy) && ldx % 4 == 0 && lddy % 4 == 0 && n % 4 == 0,
+                    "hgemm_wgrad_rows: operands must be 16-byte aligned with ld %% 4 == 0");
+    if (conv_taps > 1)
+        TTSMI_CHECK_ARG(conv_C % 128 == 0 && kin == conv_taps * conv_C && conv_T > 0 && ldx == conv_C,
+                        "hgemm_wgrad_rows: conv needs Cin %% 128 == 0");
+    else
+        TTSMI_CHECK_ARG(kin % 4 == 0, "hgemm_wgrad_rows: K %% 4 != 0");
+    TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_hgemm_wgrad_ws_bytes(rows, kin, n), "hgemm_wgrad_rows: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    WRowsP p;
+    memset(&p, 0, sizeof(p));
+    p.X = x; p.ldx = ldx; p.DY = dy; p.lddy = lddy; p.dW = dw; p.lddw = lddw;
+    p.M = rows; p.K = kin; p.N = n;
+    p.taps = conv_taps > 1 ? conv_taps : 1; p.T = conv_T; p.Cin = conv_C; p.pad = conv_pad;
+    p.tiles_k = ttsmi_cdiv(kin, 128); p.tiles_n = ttsmi_cdiv(n, 128);
+    int tiles = p.tiles_k * p.tiles_n;
+    int splits = hpick_splits(rows, tiles);
+    int kps = ttsmi_cdiv(rows, splits);
+    kps = ((kps + WR_ROWS - 1) / WR_ROWS) * WR_ROWS;
+    splits = ttsmi_cdiv(rows, kps);
+    p.k_per_split = kps;
+    p.ws = (float*)ws; p.colsum = db; p.colsum_ws = p.ws + (size_t)splits * kin * n;
+    hipLaunchKernelGGL(wgrad_rows_kernel, dim3(tiles, 1, splits), dim3(256), 0, st, p);
+    TTSMI_CHECK_LAUNCH("hgemm_wgrad_rows");
+    if (splits > 1) {
+        long tot = (long)kin * n;
+        int blocks = (int)((tot + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(hsplit_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, dw, (long)lddw, kin, n,
+                           splits, p.colsum_ws, db);
+        TTSMI_CHECK_LAUNCH("hgemm_wgrad_rows_reduce");
     }
     return TTSMI_OK;
 }

@@ -285,13 +285,30 @@ def dense_dgrad(dy, w, sh, k0, k1, relu_src=None):
 def dense_wgrad(x, dy, dw, db, sh, dyT=None):
     """dw = x^T . dy, db = colsum(dy).  Returns dyT (bf16 path) so a dual-A caller can reuse it."""
     if sh is not None:
-        M = x.shape[0]
+        M, K = x.shape
+        N = dy.shape[1]
+        if K % 4 == 0 and N % 4 == 0 and _al(x, 4) and _al(dy, 4):
+            hgemm_wgrad_rows(x, dy, dw, db)             # reads the fp32 rows once, transposes in LDS
+            return None
         if dyT is None:
             dyT = cast_transpose_bf16(dy)
         hgemm_wgrad(cast_transpose_bf16(x), dyT, dw, db, M)
         return dyT
     linear_wgrad(x, dy, dw, db)
     return None
+
+
+def hgemm_wgrad_rows(x, dy, dw, db, conv=None):
+    """dw[K,N] = x[M,K]^T . dy[M,N] (+db) on bf16 MFMA straight from row-major fp32 operands.
+    conv = (taps, T, Cin, pad): x is [B*T, Cin], dw is [taps*Cin, N]."""
+    M = x.shape[0]
+    N = dy.shape[1]
+    taps, T, C, pad = conv if conv is not None else (1, 0, 0, 0)
+    kin = dw.shape[0]
+    l = _lib.lib()
+    ws = _ws(l.ttsmi_hgemm_wgrad_rows_ws_bytes(M, kin, N), x.device)
+    check(l.ttsmi_hgemm_wgrad_rows(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(dw), dw.stride(0), _p(db), M, kin,
+                                   N, taps, T, C, pad, _p(ws), ws.numel(), _stream()), 'hgemm_wgrad_rows')
 
 
 def _sink(g, like):
@@ -691,7 +708,10 @@ class ConvReluPreMaskedFn(torch.autograd.Function):
         sh = ctx.sh
         B, T, Cin = x.shape
         k, _, Cout = w.shape
-        if sh is not None:
+        if sh is not None and Cin % 128 == 0 and Cout % 4 == 0:
+            hgemm_wgrad_rows(x.reshape(B * T, Cin), dh.reshape(B * T, Cout), dw.reshape(k * Cin, Cout), db,
+                             conv=(k, T, Cin, (k - 1) // 2))
+        elif sh is not None:
             xT = cast_transpose_bf16(x.reshape(B * T, Cin), taps=k, T=T, pad=(k - 1) // 2)
             hgemm_wgrad(xT, cast_transpose_bf16(dh.reshape(B * T, Cout)), dw.reshape(k * Cin, Cout), db, B * T)
         else:
