@@ -10,11 +10,26 @@
 // output row is written with one coalesced store.  HBM traffic: every sample is fetched ~once
 // (the 4x frame overlap is served by L2 because consecutive frames run in the same workgroup),
 // 4*n_mels bytes written per frame.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define NFFT 1024
 #define NC 512          // complex points
 #define FR_PER_WG 4     // waves per workgroup = frames in flight
+// The FFT exchange buffers are PRIVATE to a wave: what the passes need between a wave's LDS writes and
+// its own later reads is ordering, not a workgroup barrier (LDS executes one wave's accesses in
+// order).  A wavefront-scope fence pins the compiler's ordering and costs no instruction, so the
+// four waves of a workgroup drift freely and hide each other's memory latency.
+#define WAVE_SYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
+#define MELW_MAX 1536
+#define MELS_MAX 128
+#define ZP(i) ((i) + ((i) >> 3))   // one pad slot per 8 complex points: the radix-8 scatter of pass 1
+                                  // (lane stride 8 points) then lands on 16 distinct banks
 
 struct MelP {
     const float* wav; const int64_t* clip_off; const int64_t* frame_off;
@@ -25,6 +40,7 @@ struct MelP {
     int normalizer; float clip_min;
     float* out;
     int groups_per_wg;
+    int ablate;      // measurement only (TTSMI_MEL_ABLATE): 1 = no sample loads, 2 = no mel stage, 4 = no passes 2/3, 8 = no post-processing
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -74,7 +90,7 @@ __device__ __forceinline__ int clip_of_frame(const int64_t* frame_off, int n_cli
 
 __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     __shared__ float2 tw[NFFT];                       // exp(-2 pi i k / 1024)
-    __shared__ float2 buf[FR_PER_WG][NC + 8];
+    __shared__ float2 buf[FR_PER_WG][NC + NC / 8 + 8];   // padded: physical index = i + (i >> 3)
     __shared__ float mag[FR_PER_WG][NC + 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rev[8] = {0, 4, 2, 6, 1, 5, 3, 7};
@@ -84,23 +100,51 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         sincospif(-2.0f * (float)k / (float)NFFT, &s, &c);
         tw[k] = make_float2(c, s);
     }
+    // sparse filterbank -> LDS once per workgroup (727 weights + 3 x 80 ints for the LJSpeech setting);
+    // larger banks than the LDS copy holds are read from global memory instead
+    __shared__ float melwS[MELW_MAX];
+    __shared__ int melloS[MELS_MAX], melcntS[MELS_MAX], melptrS[MELS_MAX];
+    const int nnz = p.mel_ptr[p.n_mels - 1] + p.mel_cnt[p.n_mels - 1];
+    const bool mel_in_lds = (nnz <= MELW_MAX) && (p.n_mels <= MELS_MAX);
+    if (mel_in_lds) {
+        for (int i = tid; i < nnz; i += 256) melwS[i] = p.mel_w[i];
+        for (int i = tid; i < p.n_mels; i += 256) {
+            melloS[i] = p.mel_lo[i]; melcntS[i] = p.mel_cnt[i]; melptrS[i] = p.mel_ptr[i];
+        }
+    }
     __syncthreads();
 
     float2* zb = buf[wave];
     float* mg = mag[wave];
-    for (int g = 0; g < p.groups_per_wg; ++g) {
-        const long f = ((long)blockIdx.x * p.groups_per_wg + g) * FR_PER_WG + wave;
-        const bool active = f < p.total_frames;
-        float2 u[8];
+    // the lane's 16 window taps never change: keep them in registers
+    float2 win[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int n = 2 * (lane + 64 * r);
+        win[r] = make_float2(p.window[n], p.window[n + 1]);
+    }
+    // clip of the previous frame: a wave's consecutive frames rarely change clip
+    int cur = -1;
+    long cur_f0 = 0, cur_f1 = 0, cur_base = 0;
+    int cur_L = 1;
+    // raw samples of frame f -> x[8] (pairs z[i + 64 r]); issued one iteration ahead of their use so
+    // the HBM/L2 latency of frame g+1 hides under the FFT of frame g
+    auto load_frame = [&](long f, float2 (&x)[8]) {
+        const bool act = (f < p.total_frames) && !(p.ablate & 1);
         long base = 0;
         int L = 1, t = 0;
-        if (active) {
-            int c = clip_of_frame(p.frame_off, p.n_clips, f);
-            base = p.clip_off[c];
-            L = (int)(p.clip_off[c + 1] - base);
-            t = (int)(f - p.frame_off[c]);
+        if (act) {
+            if (cur < 0 || f < cur_f0 || f >= cur_f1) {   // wave-uniform: one dependent search per clip change
+                cur = clip_of_frame(p.frame_off, p.n_clips, f);
+                cur_f0 = p.frame_off[cur];
+                cur_f1 = p.frame_off[cur + 1];
+                cur_base = p.clip_off[cur];
+                cur_L = (int)(p.clip_off[cur + 1] - cur_base);
+            }
+            base = cur_base;
+            L = cur_L;
+            t = (int)(f - cur_f0);
         }
-        // ---- pass 1 (p = 1): lane i loads z[i + 64 r], r = 0..7, straight from global ----------
         const int start = t * p.hop - NFFT / 2;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -112,49 +156,61 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
                 if (gi < 0) gi = -gi;                     // np.pad(mode='reflect')
                 if (gi >= L) gi = 2 * (L - 1) - gi;
                 gi = gi < 0 ? 0 : gi;
-                v[e] = active ? p.wav[base + gi] * p.window[n + e] : 0.f;
+                v[e] = act ? p.wav[base + gi] : 0.f;
             }
-            u[r] = make_float2(v[0], v[1]);
+            x[r] = make_float2(v[0], v[1]);
         }
+    };
+    const long f_first = (long)blockIdx.x * p.groups_per_wg * FR_PER_WG + wave;
+    float2 xs[8];
+    load_frame(f_first, xs);
+    for (int g = 0; g < p.groups_per_wg; ++g) {
+        const long f = f_first + (long)g * FR_PER_WG;
+        const bool active = f < p.total_frames;
+        float2 u[8];
+        // ---- pass 1 (p = 1): lane i holds z[i + 64 r], r = 0..7 ---------------------------------
+#pragma unroll
+        for (int r = 0; r < 8; ++r) u[r] = make_float2(xs[r].x * win[r].x, xs[r].y * win[r].y);
+        if (g + 1 < p.groups_per_wg) load_frame(f + FR_PER_WG, xs);
         fft8(u);
         {
             int j = lane << 3;                            // k = 0
 #pragma unroll
-            for (int r = 0; r < 8; ++r) zb[j + r] = u[rev[r]];
+            for (int r = 0; r < 8; ++r) zb[ZP(j + r)] = u[rev[r]];
         }
-        __syncthreads();
+        WAVE_SYNC();
         // ---- pass 2 (p = 8) --------------------------------------------------------------------
-        {
+        if (!(p.ablate & 4)) {
             int k = lane & 7, j = ((lane - k) << 3) + k;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                float2 x = zb[lane + 64 * r];
+                float2 x = zb[ZP(lane + 64 * r)];
                 u[r] = r ? cmul(x, tw[(16 * k * r) & (NFFT - 1)]) : x;
             }
-            __syncthreads();
+            WAVE_SYNC();
             fft8(u);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) zb[j + r * 8] = u[rev[r]];
+            for (int r = 0; r < 8; ++r) zb[ZP(j + r * 8)] = u[rev[r]];
         }
-        __syncthreads();
+        WAVE_SYNC();
         // ---- pass 3 (p = 64) -------------------------------------------------------------------
-        {
+        if (!(p.ablate & 4)) {
             int k = lane;                                  // j = k
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                float2 x = zb[lane + 64 * r];
+                float2 x = zb[ZP(lane + 64 * r)];
                 u[r] = r ? cmul(x, tw[(2 * k * r) & (NFFT - 1)]) : x;
             }
-            __syncthreads();
+            WAVE_SYNC();
             fft8(u);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) zb[k + r * 64] = u[rev[r]];
+            for (int r = 0; r < 8; ++r) zb[ZP(k + r * 64)] = u[rev[r]];
         }
-        __syncthreads();
+        WAVE_SYNC();
         // ---- real-FFT post-processing: |X[k]|, k = 0..512 -------------------------------------
-        for (int k = lane; k <= NC; k += 64) {
-            float2 zk = zb[k & (NC - 1)];
-            float2 zc = zb[(NC - k) & (NC - 1)];
+        for (int k = lane; k <= NC && !(p.ablate & 8); k += 64) {
+            float2 zk = zb[ZP(k & (NC - 1))];
+            float2 zc = zb[ZP((NC - k) & (NC - 1))];
             zc.y = -zc.y;
             float2 e = cadd(zk, zc), o = csub(zk, zc);
             float2 w = (k < NC) ? tw[k] : make_float2(-1.f, 0.f);
@@ -163,13 +219,19 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
             float xr = 0.5f * (e.x + wo.y), xi = 0.5f * (e.y - wo.x);
             mg[k] = sqrtf(xr * xr + xi * xi);
         }
-        __syncthreads();
+        WAVE_SYNC();
         // ---- sparse mel + normalisation ---------------------------------------------------------
-        for (int m = lane; m < p.n_mels; m += 64) {
-            int lo = p.mel_lo[m], cnt = p.mel_cnt[m];
-            const float* w = p.mel_w + p.mel_ptr[m];
+        for (int m = lane; m < p.n_mels && !(p.ablate & 2); m += 64) {
             float s = 0.f;
-            for (int i = 0; i < cnt; ++i) s += w[i] * mg[lo + i];
+            if (mel_in_lds) {
+                const int lo = melloS[m], cnt = melcntS[m];
+                const float* w = melwS + melptrS[m];
+                for (int i = 0; i < cnt; ++i) s += w[i] * mg[lo + i];
+            } else {
+                const int lo = p.mel_lo[m], cnt = p.mel_cnt[m];
+                const float* w = p.mel_w + p.mel_ptr[m];
+                for (int i = 0; i < cnt; ++i) s += w[i] * mg[lo + i];
+            }
             float o;
             if (p.normalizer == 0) {
                 o = logf(fmaxf(s, p.clip_min));
@@ -180,7 +242,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
             }
             if (active) p.out[f * p.n_mels + m] = o;
         }
-        __syncthreads();
+        WAVE_SYNC();
     }
 }
 
@@ -205,6 +267,7 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
     p.total_frames = total_frames; p.hop = hop; p.window = window; p.n_mels = n_mels;
     p.mel_lo = mel_lo; p.mel_cnt = mel_cnt; p.mel_ptr = mel_ptr; p.mel_w = mel_w;
     p.normalizer = normalizer; p.clip_min = clip_min; p.out = out;
+    { const char* e = getenv("TTSMI_MEL_ABLATE"); p.ablate = e ? atoi(e) : 0; }
     long groups = (total_frames + FR_PER_WG - 1) / FR_PER_WG;
     int gpw = 1;
     while (gpw < 16 && groups / (gpw * 2) >= 2048) gpw *= 2;   // amortise the twiddle build
