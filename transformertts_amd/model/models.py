@@ -182,6 +182,7 @@ class ForwardTransformer:
         self.precision = str(kwargs.get('precision', 'f32'))
         assert self.precision in ('f32', 'bf16'), self.precision
         self.shadow: Dict[str, ops.Shadow] = {}
+        self.overlap_wgrad = bool(kwargs.get('overlap_wgrad', True))   # wgrad on a second HIP stream
         self.return_attention = None         # None = per-method default (see module docstring)
         self.grad_sync = None                # set by transformertts_amd.dp.DataParallel
         self.debug = debug
@@ -431,7 +432,10 @@ class ForwardTransformer:
         ra = False if self.return_attention is None else self.return_attention
         model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra)
         loss, loss_vals = self._losses(model_out, ts, td, tp)
+        ops.enable_wgrad_stream(self.overlap_wgrad)
         loss.backward()                                                              # :480
+        ops.wgrad_join()
+        ops.enable_wgrad_stream(False)
         if self.grad_sync is not None:
             self.grad_sync(self.params.grad)          # the single RCCL all-reduce of the step
         self._apply_gradients()                                                      # :481

@@ -282,19 +282,62 @@ def dense_dgrad(dy, w, sh, k0, k1, relu_src=None):
     return linear_dgrad(dy, w[k0:k1], relu_src)
 
 
+class _WgradStream:
+    """Weight gradients are off the critical path of backward (nothing downstream reads them until
+    the optimiser step), so they are launched on a second HIP stream and overlap the dgrad / attention
+    / LayerNorm chain of the main stream: both are HBM-latency bound and fill each other's bubbles.
+    Joined (wgrad_join) before the gradient all-reduce / Adam."""
+    stream = None
+    enabled = False
+    pending = False
+    keep = []
+
+
+def enable_wgrad_stream(flag: bool = True):
+    _WgradStream.enabled = bool(flag)
+
+
+def _on_wgrad_stream(fn, *inputs):
+    if not _WgradStream.enabled:
+        return fn()
+    main = torch.cuda.current_stream()
+    if _WgradStream.stream is None:
+        _WgradStream.stream = torch.cuda.Stream()
+    side = _WgradStream.stream
+    side.wait_stream(main)                    # the operands were produced on the main stream
+    with torch.cuda.stream(side):
+        fn()                                  # workspace allocated in here belongs to the side stream
+    for t in inputs:
+        t.record_stream(side)                 # keep the caching allocator from recycling them early
+    # Hold a reference until the join: autograd sums the gradients of a multiply-used tensor IN PLACE
+    # into a buffer it owns exclusively (use_count == 1) - e.g. the LayerNorm backward output that is
+    # both this layer's dy and the residual branch's gradient.  A second owner makes it allocate the
+    # sum instead of mutating a tensor the side stream is still reading.
+    _WgradStream.keep.extend(inputs)
+    _WgradStream.pending = True
+
+
+def wgrad_join():
+    if _WgradStream.pending:
+        torch.cuda.current_stream().wait_stream(_WgradStream.stream)
+        _WgradStream.pending = False
+    _WgradStream.keep.clear()
+
+
 def dense_wgrad(x, dy, dw, db, sh, dyT=None):
     """dw = x^T . dy, db = colsum(dy).  Returns dyT (bf16 path) so a dual-A caller can reuse it."""
     if sh is not None:
         M, K = x.shape
         N = dy.shape[1]
         if K % 4 == 0 and N % 4 == 0 and _al(x, 4) and _al(dy, 4):
-            hgemm_wgrad_rows(x, dy, dw, db)             # reads the fp32 rows once, transposes in LDS
+            # reads the fp32 rows once, transposes in LDS
+            _on_wgrad_stream(lambda: hgemm_wgrad_rows(x, dy, dw, db), x, dy)
             return None
         if dyT is None:
             dyT = cast_transpose_bf16(dy)
         hgemm_wgrad(cast_transpose_bf16(x), dyT, dw, db, M)
         return dyT
-    linear_wgrad(x, dy, dw, db)
+    _on_wgrad_stream(lambda: linear_wgrad(x, dy, dw, db), x, dy)
     return None
 
 
