@@ -180,6 +180,10 @@ def main():
     # BASELINE.json configs[1] is quoted in bf16: bf16 GEMM/attention operands, fp32 accumulate, fp32
     # master weights / activations / optimiser.  --precision f32 runs the exact-fp32 parity path.
     ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16'])
+    # hipGraph replay of the step is implemented and bit-identical to eager (tests/test_model_gpu.py),
+    # but at this workload the eager host loop (~12.3 ms of Python per step) still hides behind the GPU
+    # (~13 ms) while ROCm graph replay adds per-node overhead: eager 12.5 ms vs graph 13.4 ms measured.
+    ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -193,7 +197,7 @@ def main():
     from transformertts_amd.model.models import ForwardTransformer
     cfg, shape = workload_config(args.workload)
     cfg = dict(cfg, dropout_rate=args.dropout, predictors_dropout=args.dropout, device=str(dev), seed=0,
-               precision=args.precision)
+               precision=args.precision, use_graph=args.graph)
     model = ForwardTransformer.from_config(cfg)
     model._compile(learning_rate=1e-4)
     wrapped = dp.DataParallel(model)
@@ -242,6 +246,7 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
+        model.use_graph = False             # the instrumented step brackets every launch: run it eagerly
         groups, total_ms = instrumented_step(step)
         mfma = {k: v for k, v in groups.items() if v[1] > 0}
         dom = max(mfma.items(), key=lambda kv: kv[1][2])
@@ -260,11 +265,12 @@ def main():
             'instrumented_step_ms': total_ms,
         }
     elif world > 1 and not args.no_roofline:
+        model.use_graph = False
         step()          # keep the collective count equal on every rank
     if world > 1:
         sync()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline({k: v for k, v in cfg.items() if k not in ('device', 'seed', 'precision')},
+        result['cpu_baseline'] = cpu_baseline({k: v for k, v in cfg.items() if k not in ('device', 'seed', 'precision', 'use_graph')},
                                               shape, usable_cpus())
     if rank == 0:
         print(json.dumps(result))

@@ -253,3 +253,31 @@ def test_bf16_precision_tracks_oracle_within_bf16_tolerance(tiny):
     sh = m.shadow['out.w']
     assert torch.equal(sh.wb, m.params.w['out.w'].detach().to(torch.bfloat16))
     assert torch.equal(sh.wt, m.params.w['out.w'].detach().t().contiguous().to(torch.bfloat16))
+
+
+def test_graph_replay_equals_eager_training(tiny):
+    """train_step replayed from captured hipGraphs (use_graph=True) is the same computation as the
+    eager step: identical losses and bit-identical weights after several steps, with dropout on (the
+    dropout stream and the Adam bias correction follow the DEVICE step counter inside the graph) and
+    with a fresh batch copied into the static buffers every step."""
+    cfg, W = tiny
+    batches = [fo.synthetic_batch(4, 50, 200, seed=20 + i) for i in range(3)]
+    runs = []
+    for use_graph in (False, True):
+        for prec in ('f32', 'bf16'):
+            m = _model(cfg, W, dropout_rate=0.1, predictors_dropout=0.1, seed=3, use_graph=use_graph,
+                       precision=prec)
+            m._compile(learning_rate=1e-3)
+            losses = []
+            for i in range(7):
+                if i == 4:
+                    m.set_constants(learning_rate=5e-4)          # lr lives on the device: no re-capture
+                out = m.train_step(*batches[i % 3])
+                losses.append(float(out['loss']))
+            assert m.step == 7
+            runs.append((use_graph, prec, losses, m.params.data.clone()))
+    for prec in ('f32', 'bf16'):
+        eager = [r for r in runs if not r[0] and r[1] == prec][0]
+        graph = [r for r in runs if r[0] and r[1] == prec][0]
+        assert eager[2] == graph[2], (prec, eager[2], graph[2])
+        assert torch.equal(eager[3], graph[3]), prec

@@ -183,6 +183,8 @@ class ForwardTransformer:
         assert self.precision in ('f32', 'bf16'), self.precision
         self.shadow: Dict[str, ops.Shadow] = {}
         self.overlap_wgrad = bool(kwargs.get('overlap_wgrad', True))   # wgrad on a second HIP stream
+        self.use_graph = bool(kwargs.get('use_graph', False))          # replay train_step from hipGraphs
+        self._graphs: Dict[tuple, dict] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
         self.grad_sync = None                # set by transformertts_amd.dp.DataParallel
         self.debug = debug
@@ -428,6 +430,18 @@ class ForwardTransformer:
         backward, one TF-form Adam step.  Requires sum_b(dur) <= mel_len (the reference data has
         sum(dur_b) == mel_len_b; frames past mel_len would be sliced away at models.py:473)."""
         x, ts, td, tp = self._prep(input_sequence, target_sequence, target_durations, target_pitch)
+        if self.use_graph:
+            return self._train_step_graphed(x, ts, td, tp)
+        model_out = self._forward_backward(x, ts, td, tp)
+        if self.grad_sync is not None:
+            self.grad_sync(self.params.grad)          # the single RCCL all-reduce of the step
+        self._apply_gradients()                                                      # :481
+        self._host_step += 1
+        return model_out
+
+    def _forward_backward(self, x, ts, td, tp):
+        """forward(training=True) + losses + backward into the flat gradient buffer.  No host sync,
+        no allocation outside torch's allocator: hipGraph-capturable as one unit."""
         mel_len = int(ts.shape[1])                                                   # :467
         ra = False if self.return_attention is None else self.return_attention
         model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra)
@@ -436,14 +450,49 @@ class ForwardTransformer:
         loss.backward()                                                              # :480
         ops.wgrad_join()
         ops.enable_wgrad_stream(False)
-        if self.grad_sync is not None:
-            self.grad_sync(self.params.grad)          # the single RCCL all-reduce of the step
-        self._apply_gradients()                                                      # :481
         model_out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in model_out.items()}
         model_out.update({'loss': loss.detach()})
         model_out.update({'losses': {'mel': loss_vals[0].detach(), 'duration': loss_vals[1].detach(),
                                      'pitch': loss_vals[2].detach()}})
         return model_out
+
+    def _train_step_graphed(self, x, ts, td, tp):
+        """The same step replayed from two captured hipGraphs per batch shape (forward+backward, and
+        Adam + bf16 shadow refresh; the gradient all-reduce runs between them).  A step is ~700 kernel
+        launches driven from Python - ~12 ms of host time at the 6+6-block configuration, more than
+        the GPU needs - so replaying them removes the host from the critical path.  Everything a replay
+        must vary lives on the device: the batch (copied into static buffers), the learning rate, the
+        optimiser step counter and, derived from it, the dropout stream.
+        First call of a shape runs eagerly (warm-up), the second captures, later ones replay.  The
+        returned tensors are the graph's static outputs: consume them before the next step."""
+        key = (tuple(x.shape), tuple(ts.shape))
+        st = self._graphs.get(key)
+        if st is None:
+            self._graphs[key] = {'calls': 1}
+            model_out = self._forward_backward(x, ts, td, tp)
+            if self.grad_sync is not None:
+                self.grad_sync(self.params.grad)
+            self._apply_gradients()
+            self._host_step += 1
+            return model_out
+        if 'fb' not in st:
+            st['in'] = [t.clone() for t in (x, ts, td, tp)]
+            torch.cuda.synchronize()
+            st['fb'] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st['fb']):
+                st['out'] = self._forward_backward(*st['in'])
+            st['opt'] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st['opt'], pool=st['fb'].pool()):
+                self._apply_gradients()
+        for dst, src in zip(st['in'], (x, ts, td, tp)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        st['fb'].replay()
+        if self.grad_sync is not None:
+            self.grad_sync(self.params.grad)
+        st['opt'].replay()
+        self._host_step += 1
+        return st['out']
 
     def _val_step(self, input_sequence, target_sequence, target_durations, target_pitch):
         x, ts, td, tp = self._prep(input_sequence, target_sequence, target_durations, target_pitch)
@@ -463,7 +512,6 @@ class ForwardTransformer:
         """tf.keras Adam(lr, 0.9, 0.98, 1e-9) (utils/training_config_manager.py:102-106) as one fused
         launch over the flat buffers; iteration counter and lr live on the device."""
         ops.step_increment(self.step_dev)
-        self._host_step += 1
         P = self.params
         ops.adam_tf(P.data, P.grad, P.m, P.v, self.lr_dev, self.step_dev, self.beta_1, self.beta_2,
                     self.epsilon)

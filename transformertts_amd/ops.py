@@ -307,12 +307,13 @@ def _on_wgrad_stream(fn, *inputs):
     side.wait_stream(main)                    # the operands were produced on the main stream
     with torch.cuda.stream(side):
         fn()                                  # workspace allocated in here belongs to the side stream
-    for t in inputs:
-        t.record_stream(side)                 # keep the caching allocator from recycling them early
-    # Hold a reference until the join: autograd sums the gradients of a multiply-used tensor IN PLACE
-    # into a buffer it owns exclusively (use_count == 1) - e.g. the LayerNorm backward output that is
-    # both this layer's dy and the residual branch's gradient.  A second owner makes it allocate the
-    # sum instead of mutating a tensor the side stream is still reading.
+    # Hold a reference until the join (which makes the main stream wait for the side stream):
+    #  * the caching allocator cannot recycle the operands while the side stream may still read them
+    #    (no record_stream needed, which also keeps this legal under hipGraph capture);
+    #  * autograd sums the gradients of a multiply-used tensor IN PLACE into a buffer it owns
+    #    exclusively (use_count == 1) - e.g. the LayerNorm backward output that is both this layer's dy
+    #    and the residual branch's gradient.  A second owner makes it allocate the sum instead of
+    #    mutating a tensor the side stream is still reading.
     _WgradStream.keep.extend(inputs)
     _WgradStream.pending = True
 
