@@ -56,10 +56,11 @@ const char* ttsmi_last_error(void);
 int ttsmi_linear_fwd(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int K1,
                      const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
                      int M, int N, int K, int relu, int dtype, ttsmi_stream_t stream);
-/* dx[M,K] = (dy[M,N] . w[K,N]^T) * (relu_src > 0)      (relu_src NULL = no mask) */
+/* dx[M,K] (+)= (dy[M,N] . w[K,N]^T) * (relu_src > 0)   (relu_src NULL = no mask; accumulate != 0 adds
+ * into dx - the sum of a multiply-used activation's gradients without a separate add pass) */
 int ttsmi_linear_dgrad(const void* dy, int64_t lddy, const void* w, int64_t ldw,
                        const void* relu_src, int64_t ld_relu, void* dx, int64_t lddx,
-                       int M, int N, int K, int dtype, ttsmi_stream_t stream);
+                       int M, int N, int K, int accumulate, int dtype, ttsmi_stream_t stream);
 /* dw[K,N] = x[M,K]^T . dy[M,N]  (deterministic split over M through ws),  db[N] = colsum(dy)
  * (db may be NULL). */
 size_t ttsmi_linear_wgrad_ws_bytes(int M, int N, int K);
@@ -238,7 +239,7 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
  * v_mfma_f32_32x32x16_bf16, fp32 results.  Same reference ops as the fp32 family above
  * (Dense / Conv1D forward, dgrad, wgrad); the callers provide K-contiguous operands:
  *
- * ttsmi_hgemm_tn:  c[M,N] = act( sum_k a[m,k] * b[n,k] + bias ) * (relu_src > 0)
+ * ttsmi_hgemm_tn:  c[M,N] (+)= act( sum_k a[m,k] * b[n,k] + bias ) * (relu_src > 0)   (accumulate adds into c)
  *   a: fp32 [M,K] (a_is_f32, converted while staging; optional second K segment a2 from column K1;
  *      optional Conv1D window: conv_taps > 1 reads the contiguous window of conv_taps*conv_C values
  *      starting conv_pad frames before row m of a [B*conv_T, conv_C] activation, zero outside the
@@ -251,8 +252,8 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
  * ------------------------------------------------------------------------------------------- */
 int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int64_t lda2, int K1,
                    const uint16_t* b, int64_t ldb, const float* bias, const float* relu_src,
-                   int64_t ld_relu, float* c, int64_t ldc, int M, int N, int K, int relu, int conv_taps,
-                   int conv_T, int conv_C, int conv_pad, ttsmi_stream_t stream);
+                   int64_t ld_relu, float* c, int64_t ldc, int M, int N, int K, int relu, int accumulate,
+                   int conv_taps, int conv_T, int conv_C, int conv_pad, ttsmi_stream_t stream);
 size_t ttsmi_hgemm_wgrad_ws_bytes(int rows, int kin, int n);
 int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, float* dw, int64_t lddw,
                       float* db, int rows, int kin, int n, void* ws, size_t ws_bytes,

@@ -40,7 +40,7 @@ struct GemmP {
     const float* bias;
     const float* relu_src; long ld_relu;
     int M, N, K;
-    int relu;
+    int relu, accumulate;              // accumulate: C += result
     int a_taps, T, Cw, pad;            // conv windowing on A (a_taps == 1: none)
     int b_taps, b_kt; long b_tap_stride; int b_flip;   // B_KC tap addressing
     int k_per_split;                   // reduction range per blockIdx.z
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
                 if (!split) {
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.relu_src) v = p.relu_src[(long)row * p.ld_relu + col] > 0.f ? v : 0.f;
+                    if (p.accumulate) v += Cb[(long)row * ldc + col];
                 }
                 Cb[(long)row * ldc + col] = v;
             }
@@ -419,7 +420,7 @@ int ttsmi_linear_fwd(const void* x, int64_t ldx, const void* x2, int64_t ldx2, i
 
 int ttsmi_linear_dgrad(const void* dy, int64_t lddy, const void* w, int64_t ldw,
                        const void* relu_src, int64_t ld_relu, void* dx, int64_t lddx, int M, int N,
-                       int K, int dtype, ttsmi_stream_t stream) {
+                       int K, int accumulate, int dtype, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(dy && w && dx, "linear_dgrad: null pointer");
     TTSMI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_dgrad: bad shape");
     TTSMI_CHECK_ARG(dtype == TTSMI_F32, "linear_dgrad: dtype %d not built", dtype);
@@ -431,7 +432,7 @@ int ttsmi_linear_dgrad(const void* dy, int64_t lddy, const void* w, int64_t ldw,
     p.B = (const float*)w; p.ldb = ldw;
     p.C = (float*)dx; p.ldc = lddx;
     p.relu_src = (const float*)relu_src; p.ld_relu = ld_relu;
-    p.M = M; p.N = K; p.K = N; p.k_per_split = N;
+    p.M = M; p.N = K; p.K = N; p.k_per_split = N; p.accumulate = accumulate;
     p.b_kt = N;
     bool vec = al16(dy) && (lddy % 4 == 0) && (N % 4 == 0) && al16(w) && (ldw % 4 == 0);
     return launch_gemm<A_KC, B_KC>(p, vec, 1, (hipStream_t)stream, "linear_dgrad");

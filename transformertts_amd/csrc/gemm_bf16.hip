@@ -36,7 +36,7 @@ struct HGemmP {
     const float* bias;
     const float* relu_src; long ld_relu;
     int M, N, K;
-    int relu;
+    int relu, accumulate;               // accumulate: C += result (fused gradient accumulation)
     int a_taps, T, Cw, pad;             // conv windowing on a fp32 A (a_taps == 1: none)
     int k_per_split;
     float* ws; float* colsum; float* colsum_ws;
@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
                     v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
                     v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
                 }
+                if (fuse && p.accumulate) {
+                    float4 o = *reinterpret_cast<const float4*>(dst);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
                 *reinterpret_cast<float4*>(dst) = v;
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -242,6 +246,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
                     if (col + e >= p.N) break;
                     float x = vv[e];
                     if (fuse && p.relu_src) x = p.relu_src[(long)row * p.ld_relu + col + e] > 0.f ? x : 0.f;
+                    if (fuse && p.accumulate) x += dst[e];
                     dst[e] = x;
                 }
             }
@@ -524,8 +529,8 @@ extern "C" {
 
 int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int64_t lda2, int K1,
                    const uint16_t* b, int64_t ldb, const float* bias, const float* relu_src,
-                   int64_t ld_relu, float* c, int64_t ldc, int M, int N, int K, int relu, int conv_taps,
-                   int conv_T, int conv_C, int conv_pad, ttsmi_stream_t stream) {
+                   int64_t ld_relu, float* c, int64_t ldc, int M, int N, int K, int relu, int accumulate,
+                   int conv_taps, int conv_T, int conv_C, int conv_pad, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(a && b && c, "hgemm_tn: null pointer");
     TTSMI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "hgemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
     if (M == 0) return TTSMI_OK;
@@ -539,7 +544,7 @@ int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int
     hinit(p);
     p.A = a; p.lda = lda; p.A2 = a2; p.lda2 = lda2; p.K1 = K1;
     p.B = b; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.relu_src = relu_src; p.ld_relu = ld_relu;
-    p.M = M; p.N = N; p.K = K; p.relu = relu; p.k_per_split = K;
+    p.M = M; p.N = N; p.K = K; p.relu = relu; p.accumulate = accumulate; p.k_per_split = K;
     if (conv_taps > 1) { p.a_taps = conv_taps; p.T = conv_T; p.Cw = conv_C; p.pad = conv_pad; }
     return hlaunch(p, a_is_f32 != 0, 1, (hipStream_t)stream, "hgemm_tn");
 }

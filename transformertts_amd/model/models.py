@@ -184,6 +184,8 @@ class ForwardTransformer:
         self.shadow: Dict[str, ops.Shadow] = {}
         self.overlap_wgrad = bool(kwargs.get('overlap_wgrad', True))   # wgrad on a second HIP stream
         self.use_graph = bool(kwargs.get('use_graph', False))          # replay train_step from hipGraphs
+        self.fused_blocks = bool(kwargs.get('fused_blocks', True))     # one autograd node per dense block
+        self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
         self.grad_sync = None                # set by transformertts_amd.dp.DataParallel
@@ -306,9 +308,20 @@ class ForwardTransformer:
                               pe_scale=W[f'{prefix}.pos_scalar'], gpe_scale=G[f'{prefix}.pos_scalar'], T=T,
                               p_out=rate, site_out=drop.site(), drop=drop)
         attn = OrderedDict()
+        dtype = ops._lib.TTSMI_BF16 if self.precision == 'bf16' else ops.TTSMI_F32
         for i, H in enumerate(heads):
             p = f'{prefix}.blk{i}'
             dense = i < dense_blocks
+            if dense and self.fused_blocks:
+                # one autograd node per block (ops.DenseBlockFn); sites in the per-layer order
+                Pb, Gb, Sb = self._block_views(p)
+                sites = (drop.site(), drop.site(), drop.site())
+                h, qkv, lse = ops.DenseBlockFn.apply(h, Pb, Gb, Sb, pad, klen, B, H, T, rate, drop, sites, dtype,
+                                                     want_attn)
+                if want_attn:
+                    attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
+                        qkv, pad, lse, B, H, T, d // H, rate, drop, sites[0])
+                continue
             qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'],
                                      S(f'{p}.wqkv'))
             site = drop.site()
@@ -337,6 +350,19 @@ class ForwardTransformer:
             h = ops.add_layernorm(f, a, W[f'{p}.ln2.gamma'], W[f'{p}.ln2.beta'], G[f'{p}.ln2.gamma'],
                                   G[f'{p}.ln2.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop)
         return h.reshape(B, T, d), attn
+
+    _BLOCK_KEYS = ('wqkv', 'bqkv', 'wo', 'bo', 'ln1.gamma', 'ln1.beta', 'ffn.w1', 'ffn.b1', 'ffn.w2', 'ffn.b2',
+                   'ln2.gamma', 'ln2.beta')
+
+    def _block_views(self, p):
+        """(parameters, gradient sinks, bf16 shadows) of one dense block, keyed by their local names."""
+        v = self._block_cache.get(p)
+        if v is None:
+            W, G = self.params.w, self.params.g
+            v = ({k: W[f'{p}.{k}'] for k in self._BLOCK_KEYS}, {k: G[f'{p}.{k}'] for k in self._BLOCK_KEYS},
+                 {k: self.shadow[f'{p}.{k}'] for k in self._BLOCK_KEYS if f'{p}.{k}' in self.shadow})
+            self._block_cache[p] = v
+        return v
 
     def _stat_predictor(self, prefix, x, pad, n_layers, relu_head, rate):
         """StatPredictor.call + CNNDropout.call (layers.py:481-485,510-524).  x [B,T,d]."""

@@ -76,13 +76,15 @@ def linear_fwd(x, w, b, relu=False, x2=None, out=None, dtype=TTSMI_F32):
     return y
 
 
-def linear_dgrad(dy, w, relu_src=None, out=None, dtype=TTSMI_F32):
+def linear_dgrad(dy, w, relu_src=None, out=None, dtype=TTSMI_F32, accumulate=False):
+    """dx = dy . w^T (* relu mask); accumulate=True adds into `out` instead of overwriting it."""
     M, N = dy.shape
     K = w.shape[0]
+    assert not accumulate or out is not None
     dx = out if out is not None else torch.empty((M, K), dtype=torch.float32, device=dy.device)
     check(_lib.lib().ttsmi_linear_dgrad(_p(dy), dy.stride(0), _p(w), w.stride(0), _p(relu_src),
                                         0 if relu_src is None else relu_src.stride(0), _p(dx),
-                                        dx.stride(0), M, N, K, dtype, _stream()), 'linear_dgrad')
+                                        dx.stride(0), M, N, K, int(accumulate), dtype, _stream()), 'linear_dgrad')
     return dx
 
 
@@ -197,18 +199,20 @@ def _al(t, n):
     return t is not None and t.data_ptr() % 16 == 0 and t.stride(0) % n == 0
 
 
-def hgemm_tn(a, b_h, bias=None, relu=False, a2=None, relu_src=None, conv=None, rows=None):
-    """c[M,N] = act(sum_k a[m,k]*b_h[n,k] + bias) * (relu_src > 0) on bf16 MFMA (include/ttsmi.h)."""
+def hgemm_tn(a, b_h, bias=None, relu=False, a2=None, relu_src=None, conv=None, rows=None, out=None,
+             accumulate=False):
+    """c[M,N] (+)= act(sum_k a[m,k]*b_h[n,k] + bias) * (relu_src > 0) on bf16 MFMA (include/ttsmi.h)."""
     a_f32 = a.dtype == torch.float32
     N, K = b_h.shape
     M = a.shape[0] if rows is None else rows
     K1 = a.shape[1] if a2 is not None else 0
-    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert not accumulate or out is not None
+    c = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
     taps, T, C, pad = conv if conv is not None else (1, 0, 0, 0)
     check(_lib.lib().ttsmi_hgemm_tn(_p(a), int(a_f32), a.stride(0), _p(a2), 0 if a2 is None else a2.stride(0),
                                     K1, _p(b_h), b_h.stride(0), _p(bias), _p(relu_src),
                                     0 if relu_src is None else relu_src.stride(0), _p(c), c.stride(0), M, N, K,
-                                    int(relu), taps, T, C, pad, _stream()), 'hgemm_tn')
+                                    int(relu), int(accumulate), taps, T, C, pad, _stream()), 'hgemm_tn')
     return c
 
 
@@ -274,12 +278,12 @@ def dense_fwd(x, w, b, relu, x2, sh):
     return linear_fwd(x, w, b, relu, x2)
 
 
-def dense_dgrad(dy, w, sh, k0, k1, relu_src=None):
-    """dx = dy . w[k0:k1]^T (* relu mask)."""
+def dense_dgrad(dy, w, sh, k0, k1, relu_src=None, out=None, accumulate=False):
+    """dx (+)= dy . w[k0:k1]^T (* relu mask)."""
     N = w.shape[1]
     if sh is not None and N % 8 == 0 and _al(dy, 4) and k0 % 8 == 0:
-        return hgemm_tn(dy, sh.wb[k0:k1], None, False, None, relu_src)
-    return linear_dgrad(dy, w[k0:k1], relu_src)
+        return hgemm_tn(dy, sh.wb[k0:k1], None, False, None, relu_src, out=out, accumulate=accumulate)
+    return linear_dgrad(dy, w[k0:k1], relu_src, out=out, accumulate=accumulate)
 
 
 class _WgradStream:
@@ -767,3 +771,107 @@ class ConvReluPreMaskedFn(torch.autograd.Function):
             else:
                 dx = conv1d_dgrad(dh, w)
         return dx, (None if gw is not None else dw), (None if gb is not None else db), None, None, None
+
+
+# =================================================================================================
+# One autograd node per SelfAttentionDenseBlock (model/layers.py:214-230)
+# =================================================================================================
+def _ln_fwd(x, res, gamma, beta, row_pad, p_in, site_in, drop):
+    M, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    check(_lib.lib().ttsmi_add_layernorm_fwd(_p(x), _p(res), _p(gamma), _p(beta), None, None, 0, _p(row_pad),
+                                             float(p_in), int(site_in), 0.0, 0, drop.seed, _p(drop.step_dev),
+                                             LN_EPS, _p(y), _p(mean), _p(rstd), M, C, _stream()), 'add_layernorm_fwd')
+    return y, mean, rstd
+
+
+def _ln_bwd(dy, x, res, gamma, mean, rstd, row_pad, p_in, site_in, drop, dgamma, dbeta):
+    """Returns (dx, dres); dres aliases dx when the x branch has no dropout."""
+    M, C = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if p_in > 0 else dx
+    l = _lib.lib()
+    ws = _ws(l.ttsmi_add_layernorm_bwd_ws_bytes(M, C), x.device)
+    check(l.ttsmi_add_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), None, None, 0,
+                                    _p(row_pad), float(p_in), int(site_in), 0.0, 0, drop.seed, _p(drop.step_dev),
+                                    0, _p(dx), _p(dres), _p(dgamma), _p(dbeta), None, M, C, _p(ws), ws.numel(),
+                                    _stream()), 'add_layernorm_bwd')
+    return dx, dres
+
+
+class DenseBlockFn(torch.autograd.Function):
+    """SelfAttentionDenseBlock.call (model/layers.py:226-230) as ONE autograd node:
+        qkv = h.Wqkv+b -> attention -> [h | ctx].Wo+b -> a = LN(drop(.) + h)*mask
+        -> relu(a.W1+b1).W2+b2 -> out = LN(drop(.) + a)*mask
+    with a hand-ordered backward.  Compared with chaining the per-layer Functions this (i) costs one
+    Python autograd node instead of seven per block (the eager host loop was as long as the GPU
+    step), (ii) lets the three gradient contributions of `h` and the two of `a` be summed inside the
+    dgrad GEMM epilogues (accumulate) instead of by separate full-tensor add kernels, and (iii) frees
+    each intermediate gradient as soon as its consumers are launched.
+    P = dict of the block's parameter tensors, G = dict of their gradient sinks (views of the flat
+    gradient buffer), S = dict of bf16 shadows (empty for the fp32 path)."""
+
+    @staticmethod
+    def forward(ctx, h, P, G, S, pad, klen, B, H, T, rate, drop, sites, dtype, want_lse):
+        h = _c(h)
+        M, d = h.shape
+        dh_ = d // H
+        if dtype != TTSMI_F32 and dh_ not in (32, 64):
+            dtype = TTSMI_F32
+        qkv = dense_fwd(h, P['wqkv'], P['bqkv'], False, None, S.get('wqkv'))
+        cx = torch.empty((M, d), dtype=torch.float32, device=h.device)
+        lse = torch.empty((B, H, T), dtype=torch.float32, device=h.device)
+        check(_lib.lib().ttsmi_attention_fwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(lse), B, H, T, dh_, float(rate),
+                                             drop.seed, _p(drop.step_dev), sites[0], int(dtype), _stream()),
+              'attention_fwd')
+        o = dense_fwd(h, P['wo'], P['bo'], False, cx, S.get('wo'))
+        a, mean1, rstd1 = _ln_fwd(o, h, P['ln1.gamma'], P['ln1.beta'], pad, rate, sites[1], drop)
+        h1 = dense_fwd(a, P['ffn.w1'], P['ffn.b1'], True, None, S.get('ffn.w1'))
+        f = dense_fwd(h1, P['ffn.w2'], P['ffn.b2'], False, None, S.get('ffn.w2'))
+        out, mean2, rstd2 = _ln_fwd(f, a, P['ln2.gamma'], P['ln2.beta'], pad, rate, sites[2], drop)
+        ctx.save_for_backward(h, qkv, cx, lse, o, a, h1, f, mean1, rstd1, mean2, rstd2, pad, klen)
+        ctx.cfg = (P, G, S, B, H, T, dh_, float(rate), drop, sites, int(dtype))
+        ctx.mark_non_differentiable(qkv, lse)
+        return out, qkv, lse
+
+    @staticmethod
+    def backward(ctx, dout, _dqkv, _dlse):
+        h, qkv, cx, lse, o, a, h1, f, mean1, rstd1, mean2, rstd2, pad, klen = ctx.saved_tensors
+        P, G, S, B, H, T, dh_, rate, drop, sites, dtype = ctx.cfg
+        d = h.shape[1]
+        dout = _c(dout)
+        # ---- LN2 + FFN -----------------------------------------------------------------------
+        df, da = _ln_bwd(dout, f, a, P['ln2.gamma'], mean2, rstd2, pad, rate, sites[2], drop,
+                         G['ln2.gamma'], G['ln2.beta'])
+        if da is df:                       # the GEMM below accumulates into da: it must own its buffer
+            da = df.clone() if rate <= 0 else da
+        dense_wgrad(h1, df, G['ffn.w2'], G['ffn.b2'], S.get('ffn.w2'))
+        dh1 = dense_dgrad(df, P['ffn.w2'], S.get('ffn.w2'), 0, P['ffn.w2'].shape[0], relu_src=h1)
+        dense_wgrad(a, dh1, G['ffn.w1'], G['ffn.b1'], S.get('ffn.w1'))
+        dense_dgrad(dh1, P['ffn.w1'], S.get('ffn.w1'), 0, d, out=da, accumulate=True)      # da += dh1.W1^T
+        del dh1
+        # ---- LN1 + output projection -----------------------------------------------------------
+        do, dh = _ln_bwd(da, o, h, P['ln1.gamma'], mean1, rstd1, pad, rate, sites[1], drop,
+                         G['ln1.gamma'], G['ln1.beta'])
+        if dh is do:
+            dh = do.clone()
+        del da
+        sho = S.get('wo')
+        dyT = dense_wgrad(h, do, G['wo'][:d], G['bo'], sho)
+        dense_wgrad(cx, do, G['wo'][d:], None, sho, dyT)
+        dense_dgrad(do, P['wo'], sho, 0, d, out=dh, accumulate=True)                        # dh += do.Wo_top^T
+        dctx = dense_dgrad(do, P['wo'], sho, d, 2 * d)
+        del do
+        # ---- attention + qkv projection --------------------------------------------------------
+        dqkv = torch.empty_like(qkv)
+        l = _lib.lib()
+        ws = _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, dh_), h.device)
+        check(l.ttsmi_attention_bwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(dctx), _p(lse), _p(dqkv), B, H, T, dh_,
+                                    rate, drop.seed, _p(drop.step_dev), sites[0], _p(ws), ws.numel(), dtype,
+                                    _stream()), 'attention_bwd')
+        shq = S.get('wqkv')
+        dense_wgrad(h, dqkv, G['wqkv'], G['bqkv'], shq)
+        dense_dgrad(dqkv, P['wqkv'], shq, 0, d, out=dh, accumulate=True)                    # dh += dqkv.Wqkv^T
+        return (dh,) + (None,) * 13
