@@ -71,7 +71,7 @@ def _flops(name, a):
     if name == 'ttsmi_hgemm_wgrad':
         return 2.0 * a[6] * a[7] * a[8]
     if name == 'ttsmi_hgemm_wgrad_rows':
-        return 2.0 * a[7] * a[8] * a[9]
+        return 2.0 * a[9] * a[10] * a[11]
     if name == 'ttsmi_attention_fwd':
         B, H, T, dh = a[5], a[6], a[7], a[8]
         return 4.0 * B * H * T * T * dh                      # QK^T + PV

@@ -250,9 +250,11 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
  * ttsmi_cast_transpose_bf16: dst[j*C + c][r] = bf16(src[r + j - pad][c]) (0 outside the sequence
  *   of length T when taps > 1); taps == 1 is a plain cast-transpose.  dst rows have ld_dst >= R.
  * ------------------------------------------------------------------------------------------- */
+/* flags of ttsmi_hgemm_tn */
+enum { TTSMI_GEMM_RELU = 1, TTSMI_GEMM_ACCUMULATE = 2, TTSMI_GEMM_OUT_BF16 = 4, TTSMI_GEMM_MASK_BF16 = 8 };
 int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int64_t lda2, int K1,
                    const uint16_t* b, int64_t ldb, const float* bias, const float* relu_src,
-                   int64_t ld_relu, float* c, int64_t ldc, int M, int N, int K, int relu, int accumulate,
+                   int64_t ld_relu, void* c, int64_t ldc, int M, int N, int K, int flags,
                    int conv_taps, int conv_T, int conv_C, int conv_pad, ttsmi_stream_t stream);
 size_t ttsmi_hgemm_wgrad_ws_bytes(int rows, int kin, int n);
 int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, float* dw, int64_t lddw,
@@ -262,9 +264,10 @@ int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, floa
  * rounded to bf16 and transposed inside the kernel).  Conv1D wgrad: conv_taps > 1, x is [B*conv_T,
  * conv_C] with conv_C %% 128 == 0 and kin = conv_taps*conv_C. */
 size_t ttsmi_hgemm_wgrad_rows_ws_bytes(int rows, int kin, int n);
-int ttsmi_hgemm_wgrad_rows(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, int64_t lddw,
-                           float* db, int rows, int kin, int n, int conv_taps, int conv_T, int conv_C,
-                           int conv_pad, void* ws, size_t ws_bytes, ttsmi_stream_t stream);
+int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
+                           float* dw, int64_t lddw, float* db, int rows, int kin, int n, int conv_taps,
+                           int conv_T, int conv_C, int conv_pad, void* ws, size_t ws_bytes,
+                           ttsmi_stream_t stream);
 int ttsmi_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int R,
                               int C, int taps, int T, int pad, ttsmi_stream_t stream);
 int ttsmi_conv_wdgrad_layout_bf16(const float* w, uint16_t* dst, int k, int Cin, int Cout,

@@ -582,3 +582,34 @@ def test_hgemm_wgrad_rows_conv():
     xd, wd = _bf(x), torch.zeros(k, Cin, Cout, dtype=torch.float64, requires_grad=True)
     fo.conv1d_same(xd, wd, torch.zeros(Cout, dtype=torch.float64)).backward(_bf(dy))
     assert rel_err(dw.reshape(k, Cin, Cout), wd.grad) < 3e-6
+
+
+def test_hgemm_bf16_outputs_masks_and_sources():
+    """FFN-internal tensors of the TTSMI_BF16 path live in bf16: GEMM output, ReLU mask, A operand and
+    both wgrad sources."""
+    ops = _ops()
+    M, d, F = 500, 64, 256
+    a, w1, b1, w2 = g(M, d, seed=1), g(d, F, seed=2, scale=0.2), g(F, seed=3), g(F, d, seed=4, scale=0.2)
+    s1, s2 = ops.make_shadow(w1.to(DEV)), ops.make_shadow(w2.to(DEV))
+    h1 = ops.hgemm_tn(a.to(DEV), s1.wt, b1.to(DEV), relu=True, out_bf16=True)
+    assert h1.dtype == torch.bfloat16
+    want_h1 = (_bf(a) @ _bf(w1) + b1.double()).relu()
+    assert rel_err(h1.float(), want_h1) < 5e-3                      # one bf16 rounding of the output
+    assert torch.equal(h1.cpu() > 0, want_h1.to(torch.bfloat16) > 0) or rel_err(h1.float(), want_h1) < 5e-3
+    f = ops.hgemm_tn(h1, s2.wt)                                       # bf16 A operand
+    assert rel_err(f, h1.double().cpu() @ _bf(w2)) < 3e-6
+    df = g(M, d, seed=5)
+    dh1 = ops.hgemm_tn(df.to(DEV), s2.wb, relu_src=h1, out_bf16=True)  # bf16 mask + bf16 out
+    want_dh1 = (_bf(df) @ _bf(w2).T) * (h1.cpu() > 0)
+    assert rel_err(dh1.float(), want_dh1) < 5e-3
+    dw2, db2 = torch.empty(F, d, device=DEV), torch.empty(d, device=DEV)
+    ops.hgemm_wgrad_rows(h1, df.to(DEV), dw2, db2)                    # bf16 x, fp32 dy
+    assert rel_err(dw2, h1.double().cpu().T @ _bf(df)) < 3e-6
+    dw1, db1 = torch.empty(d, F, device=DEV), torch.empty(F, device=DEV)
+    ops.hgemm_wgrad_rows(a.to(DEV), dh1, dw1, db1)                    # fp32 x, bf16 dy
+    assert rel_err(dw1, _bf(a).T @ dh1.double().cpu()) < 3e-6
+    assert rel_err(db1, dh1.double().cpu().sum(0)) < 3e-6
+    da = g(M, d, seed=6).to(DEV)
+    da0 = da.clone()
+    ops.hgemm_tn(dh1, s1.wb, out=da, accumulate=True)                 # bf16 A + accumulate
+    assert rel_err(da, da0.double().cpu() + dh1.double().cpu() @ _bf(w1).T) < 3e-6

@@ -65,12 +65,12 @@ SIGNATURES = {
     'ttsmi_step_increment': (I, [P, S]),
     'ttsmi_stft_logmel': (I, [P, P, P, I, L, I, I, P, I, P, P, P, P, I, F, P, S]),
     'ttsmi_cast_f32_to_bf16': (I, [P, P, L, S]),
-    'ttsmi_hgemm_tn': (I, [P, I, L, P, L, I, P, L, P, P, L, P, L, I, I, I, I, I, I, I, I, I, S]),
+    'ttsmi_hgemm_tn': (I, [P, I, L, P, L, I, P, L, P, P, L, P, L, I, I, I, I, I, I, I, I, S]),
     'ttsmi_hgemm_wgrad_ws_bytes': (c_size_t, [I, I, I]),
     'ttsmi_hgemm_wgrad': (I, [P, P, L, P, L, P, I, I, I, P, c_size_t, S]),
     'ttsmi_cast_transpose_bf16': (I, [P, L, P, L, I, I, I, I, I, S]),
     'ttsmi_hgemm_wgrad_rows_ws_bytes': (c_size_t, [I, I, I]),
-    'ttsmi_hgemm_wgrad_rows': (I, [P, L, P, L, P, L, P, I, I, I, I, I, I, I, P, c_size_t, S]),
+    'ttsmi_hgemm_wgrad_rows': (I, [P, I, L, P, I, L, P, L, P, I, I, I, I, I, I, I, P, c_size_t, S]),
     'ttsmi_conv_wdgrad_layout_bf16': (I, [P, P, I, I, I, S]),
 }
 

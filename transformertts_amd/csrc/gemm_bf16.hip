@@ -37,6 +37,7 @@ struct HGemmP {
     const float* relu_src; long ld_relu;
     int M, N, K;
     int relu, accumulate;               // accumulate: C += result (fused gradient accumulation)
+    int c_bf16, mask_bf16;              // C stored as bf16 / relu_src is bf16
     int a_taps, T, Cw, pad;             // conv windowing on a fp32 A (a_taps == 1: none)
     int k_per_split;
     float* ws; float* colsum; float* colsum_ws;
@@ -230,9 +231,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
             float* dst = Cb + (long)row * ldc + col;
             if (vec) {
                 if (fuse && p.relu_src) {
-                    float4 m = *reinterpret_cast<const float4*>(p.relu_src + (long)row * p.ld_relu + col);
-                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-                    v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    if (p.mask_bf16) {      // bf16 activation: > 0  <=>  sign clear and magnitude non-zero
+                        uint2 mb = *reinterpret_cast<const uint2*>((const uint16_t*)p.relu_src + (long)row * p.ld_relu + col);
+                        auto pos = [](uint32_t h) { return ((h & 0x8000u) == 0u) && ((h & 0x7FFFu) != 0u); };
+                        v.x = pos(mb.x & 0xFFFFu) ? v.x : 0.f; v.y = pos(mb.x >> 16) ? v.y : 0.f;
+                        v.z = pos(mb.y & 0xFFFFu) ? v.z : 0.f; v.w = pos(mb.y >> 16) ? v.w : 0.f;
+                    } else {
+                        float4 m = *reinterpret_cast<const float4*>(p.relu_src + (long)row * p.ld_relu + col);
+                        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    }
+                }
+                if (fuse && p.c_bf16) {
+                    *reinterpret_cast<uint2*>((uint16_t*)p.C + (long)row * p.ldc + col) = pack4(v);
+                    continue;
                 }
                 if (fuse && p.accumulate) {
                     float4 o = *reinterpret_cast<const float4*>(dst);
@@ -278,6 +290,26 @@ struct WRowsP {
     int tiles_k, tiles_n;
 };
 
+// bf16-source variant: 4 bf16 (8 bytes) per item, no conversion
+__device__ __forceinline__ void wr_fetch_h(const uint16_t* base, long ld, int ncols, int row0, int rend, int col0,
+                                           int tid, uint2 (&r)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int id = tid + 256 * i;
+        int row = id >> 5, c4 = id & 31;
+        int m = row0 + row, col = col0 + c4 * 4;
+        bool ok = (m < rend) && (col < ncols);
+        r[i] = ok ? *reinterpret_cast<const uint2*>(base + (long)m * ld + col) : make_uint2(0u, 0u);
+    }
+}
+__device__ __forceinline__ void wr_stash_h(uint16_t* S, int tid, const uint2 (&r)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int id = tid + 256 * i;
+        int row = id >> 5, c4 = id & 31;
+        *reinterpret_cast<uint2*>(S + row * WR_RLD + c4 * 4) = r[i];
+    }
+}
 __device__ __forceinline__ void wr_fetch(const float* base, long ld, int ncols, int row0, int rend, int col0,
                                          int shift, int T, int tid, float4 (&r)[8]) {
 #pragma unroll
@@ -320,6 +352,7 @@ __device__ __forceinline__ void wr_transpose(const uint16_t* S, uint16_t (*St)[H
     }
 }
 
+template <bool XH, bool YH>
 __global__ __launch_bounds__(256) void wgrad_rows_kernel(WRowsP p) {
     constexpr int ROWIMG = WR_ROWS * WR_RLD;             // uint16 elements
     __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * ROWIMG + 2 * 128 * HLD_) * 2];
@@ -349,21 +382,22 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(WRowsP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 rx[8], ry[8];
-    if (mbeg < mend) {
-        wr_fetch(p.X, p.ldx, xcols, mbeg, mend, xcol0, shift, Tw, tid, rx);
-        wr_fetch(p.DY, p.lddy, p.N, mbeg, mend, n0, 0, 0, tid, ry);
-    }
+    float4 rx[8], ry[8];       // fp32-source prefetch registers
+    uint2 rxh[8], ryh[8];      // bf16-source prefetch registers (the unused set is dead code)
+    auto fetch_tiles = [&](int mrow) {
+        if constexpr (XH) wr_fetch_h((const uint16_t*)p.X, p.ldx, xcols, mrow, mend, xcol0, tid, rxh);
+        else wr_fetch(p.X, p.ldx, xcols, mrow, mend, xcol0, shift, Tw, tid, rx);
+        if constexpr (YH) wr_fetch_h((const uint16_t*)p.DY, p.lddy, p.N, mrow, mend, n0, tid, ryh);
+        else wr_fetch(p.DY, p.lddy, p.N, mrow, mend, n0, 0, 0, tid, ry);
+    };
+    if (mbeg < mend) fetch_tiles(mbeg);
     const bool do_colsum = (p.colsum != nullptr) && (tk == 0) && (tid < 128);
     float csum = 0.f;
     for (int m0 = mbeg; m0 < mend; m0 += WR_ROWS) {
-        wr_stash(Xr, tid, rx);
-        wr_stash(Yr, tid, ry);
+        if constexpr (XH) wr_stash_h(Xr, tid, rxh); else wr_stash(Xr, tid, rx);
+        if constexpr (YH) wr_stash_h(Yr, tid, ryh); else wr_stash(Yr, tid, ry);
         __syncthreads();
-        if (m0 + WR_ROWS < mend) {
-            wr_fetch(p.X, p.ldx, xcols, m0 + WR_ROWS, mend, xcol0, shift, Tw, tid, rx);
-            wr_fetch(p.DY, p.lddy, p.N, m0 + WR_ROWS, mend, n0, 0, 0, tid, ry);
-        }
+        if (m0 + WR_ROWS < mend) fetch_tiles(m0 + WR_ROWS);
         wr_transpose(Xr, Xt, tid);
         wr_transpose(Yr, Yt, tid);
         __syncthreads();
@@ -517,7 +551,8 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
 }
 
 static int hpick_splits(long rows, int tiles) {
-    int want = (512 + tiles - 1) / tiles;
+    // ~1 workgroup per CU: wgrad overlaps the main stream, and fewer splits = less slab traffic
+    int want = (256 + tiles - 1) / tiles;
     int maxs = (int)((rows + 511) / 512);
     int s = want < maxs ? want : maxs;
     if (s > 64) s = 64;
@@ -529,8 +564,10 @@ extern "C" {
 
 int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int64_t lda2, int K1,
                    const uint16_t* b, int64_t ldb, const float* bias, const float* relu_src,
-                   int64_t ld_relu, float* c, int64_t ldc, int M, int N, int K, int relu, int accumulate,
+                   int64_t ld_relu, void* c, int64_t ldc, int M, int N, int K, int flags,
                    int conv_taps, int conv_T, int conv_C, int conv_pad, ttsmi_stream_t stream) {
+    const int relu = flags & TTSMI_GEMM_RELU, accumulate = flags & TTSMI_GEMM_ACCUMULATE;
+    const int c_bf16 = flags & TTSMI_GEMM_OUT_BF16, mask_bf16 = flags & TTSMI_GEMM_MASK_BF16;
     TTSMI_CHECK_ARG(a && b && c, "hgemm_tn: null pointer");
     TTSMI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "hgemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
     if (M == 0) return TTSMI_OK;
@@ -543,8 +580,13 @@ int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int
     HGemmP p;
     hinit(p);
     p.A = a; p.lda = lda; p.A2 = a2; p.lda2 = lda2; p.K1 = K1;
-    p.B = b; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.relu_src = relu_src; p.ld_relu = ld_relu;
-    p.M = M; p.N = N; p.K = K; p.relu = relu; p.accumulate = accumulate; p.k_per_split = K;
+    p.B = b; p.ldb = ldb; p.C = (float*)c; p.ldc = ldc; p.bias = bias; p.relu_src = relu_src; p.ld_relu = ld_relu;
+    p.c_bf16 = c_bf16 ? 1 : 0; p.mask_bf16 = mask_bf16 ? 1 : 0;
+    if (c_bf16)
+        TTSMI_CHECK_ARG(!accumulate && N % 4 == 0 && ldc % 4 == 0 && ((((uintptr_t)c) & 7) == 0),
+                        "hgemm_tn: bf16 output needs N %% 4 == 0, ldc %% 4 == 0, no accumulate");
+    if (mask_bf16) TTSMI_CHECK_ARG(N % 4 == 0 && ld_relu % 4 == 0, "hgemm_tn: bf16 mask needs N %% 4 == 0");
+    p.M = M; p.N = N; p.K = K; p.relu = relu ? 1 : 0; p.accumulate = accumulate ? 1 : 0; p.k_per_split = K;
     if (conv_taps > 1) { p.a_taps = conv_taps; p.T = conv_T; p.Cw = conv_C; p.pad = conv_pad; }
     return hlaunch(p, a_is_f32 != 0, 1, (hipStream_t)stream, "hgemm_tn");
 }
@@ -591,9 +633,11 @@ int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, floa
 
 size_t ttsmi_hgemm_wgrad_rows_ws_bytes(int rows, int kin, int n) { return ttsmi_hgemm_wgrad_ws_bytes(rows, kin, n); }
 
-int ttsmi_hgemm_wgrad_rows(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, int64_t lddw,
-                           float* db, int rows, int kin, int n, int conv_taps, int conv_T, int conv_C,
-                           int conv_pad, void* ws, size_t ws_bytes, ttsmi_stream_t stream) {
+int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
+                           float* dw, int64_t lddw, float* db, int rows, int kin, int n, int conv_taps,
+                           int conv_T, int conv_C, int conv_pad, void* ws, size_t ws_bytes,
+                           ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(!(x_is_bf16 && conv_taps > 1), "hgemm_wgrad_rows: conv needs an fp32 x");
     TTSMI_CHECK_ARG(x && dy && dw, "hgemm_wgrad_rows: null pointer");
     TTSMI_CHECK_ARG(rows > 0 && kin > 0 && n > 0, "hgemm_wgrad_rows: bad shape");
     TTSMI_CHECK_ARG(al16(x) && al16(dy) && ldx % 4 == 0 && lddy % 4 == 0 && n % 4 == 0,
@@ -607,7 +651,7 @@ int ttsmi_hgemm_wgrad_rows(const float* x, int64_t ldx, const float* dy, int64_t
     hipStream_t st = (hipStream_t)stream;
     WRowsP p;
     memset(&p, 0, sizeof(p));
-    p.X = x; p.ldx = ldx; p.DY = dy; p.lddy = lddy; p.dW = dw; p.lddw = lddw;
+    p.X = (const float*)x; p.ldx = ldx; p.DY = (const float*)dy; p.lddy = lddy; p.dW = dw; p.lddw = lddw;
     p.M = rows; p.K = kin; p.N = n;
     p.taps = conv_taps > 1 ? conv_taps : 1; p.T = conv_T; p.Cin = conv_C; p.pad = conv_pad;
     p.tiles_k = ttsmi_cdiv(kin, 128); p.tiles_n = ttsmi_cdiv(n, 128);
@@ -618,7 +662,11 @@ int ttsmi_hgemm_wgrad_rows(const float* x, int64_t ldx, const float* dy, int64_t
     splits = ttsmi_cdiv(rows, kps);
     p.k_per_split = kps;
     p.ws = (float*)ws; p.colsum = db; p.colsum_ws = p.ws + (size_t)splits * kin * n;
-    hipLaunchKernelGGL(wgrad_rows_kernel, dim3(tiles, 1, splits), dim3(256), 0, st, p);
+    dim3 wgrid(tiles, 1, splits);
+    if (x_is_bf16 && dy_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<true, true>), wgrid, dim3(256), 0, st, p);
+    else if (x_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<true, false>), wgrid, dim3(256), 0, st, p);
+    else if (dy_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<false, true>), wgrid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_rows_kernel<false, false>), wgrid, dim3(256), 0, st, p);
     TTSMI_CHECK_LAUNCH("hgemm_wgrad_rows");
     if (splits > 1) {
         long tot = (long)kin * n;

@@ -200,19 +200,23 @@ def _al(t, n):
 
 
 def hgemm_tn(a, b_h, bias=None, relu=False, a2=None, relu_src=None, conv=None, rows=None, out=None,
-             accumulate=False):
-    """c[M,N] (+)= act(sum_k a[m,k]*b_h[n,k] + bias) * (relu_src > 0) on bf16 MFMA (include/ttsmi.h)."""
+             accumulate=False, out_bf16=False):
+    """c[M,N] (+)= act(sum_k a[m,k]*b_h[n,k] + bias) * (relu_src > 0) on bf16 MFMA (include/ttsmi.h).
+    a may be fp32 or bf16; relu_src may be fp32 or bf16; out_bf16 stores c as bf16."""
     a_f32 = a.dtype == torch.float32
     N, K = b_h.shape
     M = a.shape[0] if rows is None else rows
     K1 = a.shape[1] if a2 is not None else 0
     assert not accumulate or out is not None
-    c = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
+    c = out if out is not None else torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32,
+                                                device=a.device)
     taps, T, C, pad = conv if conv is not None else (1, 0, 0, 0)
+    flags = (1 if relu else 0) | (2 if accumulate else 0) | (4 if c.dtype == torch.bfloat16 else 0) | \
+            (8 if (relu_src is not None and relu_src.dtype == torch.bfloat16) else 0)
     check(_lib.lib().ttsmi_hgemm_tn(_p(a), int(a_f32), a.stride(0), _p(a2), 0 if a2 is None else a2.stride(0),
                                     K1, _p(b_h), b_h.stride(0), _p(bias), _p(relu_src),
                                     0 if relu_src is None else relu_src.stride(0), _p(c), c.stride(0), M, N, K,
-                                    int(relu), int(accumulate), taps, T, C, pad, _stream()), 'hgemm_tn')
+                                    flags, taps, T, C, pad, _stream()), 'hgemm_tn')
     return c
 
 
@@ -355,8 +359,9 @@ def hgemm_wgrad_rows(x, dy, dw, db, conv=None):
     kin = dw.shape[0]
     l = _lib.lib()
     ws = _ws(l.ttsmi_hgemm_wgrad_rows_ws_bytes(M, kin, N), x.device)
-    check(l.ttsmi_hgemm_wgrad_rows(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(dw), dw.stride(0), _p(db), M, kin,
-                                   N, taps, T, C, pad, _p(ws), ws.numel(), _stream()), 'hgemm_wgrad_rows')
+    check(l.ttsmi_hgemm_wgrad_rows(_p(x), int(x.dtype == torch.bfloat16), x.stride(0), _p(dy),
+                                   int(dy.dtype == torch.bfloat16), dy.stride(0), _p(dw), dw.stride(0), _p(db), M,
+                                   kin, N, taps, T, C, pad, _p(ws), ws.numel(), _stream()), 'hgemm_wgrad_rows')
 
 
 def _sink(g, like):
@@ -828,8 +833,16 @@ class DenseBlockFn(torch.autograd.Function):
               'attention_fwd')
         o = dense_fwd(h, P['wo'], P['bo'], False, cx, S.get('wo'))
         a, mean1, rstd1 = _ln_fwd(o, h, P['ln1.gamma'], P['ln1.beta'], pad, rate, sites[1], drop)
-        h1 = dense_fwd(a, P['ffn.w1'], P['ffn.b1'], True, None, S.get('ffn.w1'))
-        f = dense_fwd(h1, P['ffn.w2'], P['ffn.b2'], False, None, S.get('ffn.w2'))
+        s1, s2 = S.get('ffn.w1'), S.get('ffn.w2')
+        F = P['ffn.w1'].shape[1]
+        if s1 is not None and s2 is not None and d % 8 == 0 and F % 8 == 0:
+            # TTSMI_BF16: the FFN hidden activation (the largest tensor of the block, M x F) and its
+            # gradient exist only as bf16 - they are GEMM operands and nothing else
+            h1 = hgemm_tn(a, s1.wt, P['ffn.b1'], relu=True, out_bf16=True)
+            f = hgemm_tn(h1, s2.wt, P['ffn.b2'])
+        else:
+            h1 = dense_fwd(a, P['ffn.w1'], P['ffn.b1'], True, None, s1)
+            f = dense_fwd(h1, P['ffn.w2'], P['ffn.b2'], False, None, s2)
         out, mean2, rstd2 = _ln_fwd(f, a, P['ln2.gamma'], P['ln2.beta'], pad, rate, sites[2], drop)
         ctx.save_for_backward(h, qkv, cx, lse, o, a, h1, f, mean1, rstd1, mean2, rstd2, pad, klen)
         ctx.cfg = (P, G, S, B, H, T, dh_, float(rate), drop, sites, int(dtype))
@@ -847,10 +860,17 @@ class DenseBlockFn(torch.autograd.Function):
                          G['ln2.gamma'], G['ln2.beta'])
         if da is df:                       # the GEMM below accumulates into da: it must own its buffer
             da = df.clone() if rate <= 0 else da
-        dense_wgrad(h1, df, G['ffn.w2'], G['ffn.b2'], S.get('ffn.w2'))
-        dh1 = dense_dgrad(df, P['ffn.w2'], S.get('ffn.w2'), 0, P['ffn.w2'].shape[0], relu_src=h1)
-        dense_wgrad(a, dh1, G['ffn.w1'], G['ffn.b1'], S.get('ffn.w1'))
-        dense_dgrad(dh1, P['ffn.w1'], S.get('ffn.w1'), 0, d, out=da, accumulate=True)      # da += dh1.W1^T
+        if h1.dtype == torch.bfloat16:
+            s1, s2 = S['ffn.w1'], S['ffn.w2']
+            _on_wgrad_stream(lambda: hgemm_wgrad_rows(h1, df, G['ffn.w2'], G['ffn.b2']), h1, df)
+            dh1 = hgemm_tn(df, s2.wb, relu_src=h1, out_bf16=True)                            # relu' fused, bf16 out
+            _on_wgrad_stream(lambda: hgemm_wgrad_rows(a, dh1, G['ffn.w1'], G['ffn.b1']), a, dh1)
+            hgemm_tn(dh1, s1.wb, out=da, accumulate=True)                                    # da += dh1.W1^T
+        else:
+            dense_wgrad(h1, df, G['ffn.w2'], G['ffn.b2'], S.get('ffn.w2'))
+            dh1 = dense_dgrad(df, P['ffn.w2'], S.get('ffn.w2'), 0, P['ffn.w2'].shape[0], relu_src=h1)
+            dense_wgrad(a, dh1, G['ffn.w1'], G['ffn.b1'], S.get('ffn.w1'))
+            dense_dgrad(dh1, P['ffn.w1'], S.get('ffn.w1'), 0, d, out=da, accumulate=True)  # da += dh1.W1^T
         del dh1
         # ---- LN1 + output projection -----------------------------------------------------------
         do, dh = _ln_bwd(da, o, h, P['ln1.gamma'], mean1, rstd1, pad, rate, sites[1], drop,
