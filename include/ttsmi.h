@@ -39,7 +39,9 @@ enum {
     TTSMI_ERR_UNSUPPORTED = -3,
     TTSMI_ERR_WORKSPACE = -4
 };
-enum { TTSMI_F32 = 0, TTSMI_BF16 = 1 };
+/* TTSMI_BF16_QKV (attention entry points only): as TTSMI_BF16, and the qkv / dqkv tensors themselves
+ * are bf16 in HBM (written by ttsmi_hgemm_tn with OUT_BF16, consumed by the bf16 GEMM kernels). */
+enum { TTSMI_F32 = 0, TTSMI_BF16 = 1, TTSMI_BF16_QKV = 2 };
 
 typedef void* ttsmi_stream_t; /* hipStream_t */
 

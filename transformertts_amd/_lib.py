@@ -74,7 +74,7 @@ SIGNATURES = {
     'ttsmi_conv_wdgrad_layout_bf16': (I, [P, P, I, I, I, S]),
 }
 
-TTSMI_F32, TTSMI_BF16 = 0, 1
+TTSMI_F32, TTSMI_BF16, TTSMI_BF16_QKV = 0, 1, 2
 
 _lib = None
 

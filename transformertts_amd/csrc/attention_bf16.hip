@@ -69,6 +69,69 @@ __device__ __forceinline__ void rows_stash(uint16_t* S, int tid, const float4 (&
         *reinterpret_cast<uint2*>(S + row * LD + c4 * 4) = *reinterpret_cast<uint2*>(&h);
     }
 }
+// bf16-source rows (qkv kept in bf16 by the producer GEMM): 4 bf16 per item, no conversion
+template <int DH>
+__device__ __forceinline__ void rows_fetch_h(const uint16_t* base, long ld, int row0, int nvalid, int tid,
+                                             uint2 (&r)[DH / 16]) {
+    constexpr int V4 = DH / 4;
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i) {
+        int id = tid + 256 * i;
+        int row = id / V4, c4 = id - row * V4;
+        r[i] = (row < nvalid) ? *reinterpret_cast<const uint2*>(base + (long)(row0 + row) * ld + c4 * 4)
+                              : make_uint2(0u, 0u);
+    }
+}
+template <int DH>
+__device__ __forceinline__ void rows_stash_h(uint16_t* S, int tid, const uint2 (&r)[DH / 16]) {
+    constexpr int V4 = DH / 4, LD = DH + 8;
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i) {
+        int id = tid + 256 * i;
+        int row = id / V4, c4 = id - row * V4;
+        *reinterpret_cast<uint2*>(S + row * LD + c4 * 4) = r[i];
+    }
+}
+template <int DH>
+__device__ __forceinline__ void row_frags_h(const uint16_t* base, long ld, int row, bool valid, int g,
+                                            bf16x8 (&f)[DH / 16]) {
+    const uint16_t* src = base + (long)row * ld + 8 * g;
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        uint4 v = valid ? *reinterpret_cast<const uint4*>(src + 16 * s) : make_uint4(0u, 0u, 0u, 0u);
+        f[s] = *reinterpret_cast<bf16x8*>(&v);
+    }
+}
+// generic tile pipeline pieces: QH selects the bf16-source versions
+template <int DH, bool QH>
+struct Tile {
+    float4 f[DH / 16];
+    uint2 h[DH / 16];
+    __device__ __forceinline__ void fetch(const float* base, long ld, int row0, int nvalid, int tid) {
+        if constexpr (QH) rows_fetch_h<DH>((const uint16_t*)base, ld, row0, nvalid, tid, h);
+        else rows_fetch<DH>(base, ld, row0, nvalid, tid, f);
+    }
+    __device__ __forceinline__ void stash(uint16_t* S, int tid) {
+        if constexpr (QH) rows_stash_h<DH>(S, tid, h);
+        else rows_stash<DH>(S, tid, f);
+    }
+};
+// element pointer into a [.., ld] tensor whose element type is fp32 (QH = false) or bf16 (QH = true),
+// carried as const float* (only ever dereferenced through the helpers above)
+template <bool QH>
+__device__ __forceinline__ const float* eptr(const float* base, long elems) {
+    return QH ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(base) + elems) : base + elems;
+}
+template <int DH>
+__device__ __forceinline__ void row_frags(const float* base, long ld, int row, bool valid, int g,
+                                          bf16x8 (&f)[DH / 16]);
+template <int DH, bool QH>
+__device__ __forceinline__ void frags_of(const float* base, long ld, int row, bool valid, int g,
+                                         bf16x8 (&f)[DH / 16]) {
+    if constexpr (QH) row_frags_h<DH>((const uint16_t*)base, ld, row, valid, g, f);
+    else row_frags<DH>(base, ld, row, valid, g, f);
+}
+
 // ---- LDS -> LDS re-layout: row image [HKT][DH+8] -> transposed image [DH][TLD] --------------------
 // work item = (row pair p, 4 columns c4): two 8-byte reads, four packed 32-bit writes (conflict free)
 template <int DH>
@@ -147,7 +210,7 @@ __device__ __forceinline__ void accumT16(const uint16_t* St, int k0, int l31, in
     }
 }
 
-template <int DH>
+template <int DH, bool OUT_H = false>
 __device__ __forceinline__ void storeT16(float* patch, const f32x16 (&o)[DH / 32], float scale_lane,
                                          float* dst, long ld, int row0, int nvalid, int lane) {
     const int l31 = lane & 31, hh = lane >> 5;
@@ -159,7 +222,14 @@ __device__ __forceinline__ void storeT16(float* patch, const f32x16 (&o)[DH / 32
     __syncthreads();
     for (int j = 0; j < 32; ++j) {
         if (j >= nvalid) break;
-        for (int c = lane; c < DH; c += 64) dst[(long)(row0 + j) * ld + c] = patch[j * (DH + 1) + c];
+        for (int c = lane; c < DH; c += 64) {
+            if constexpr (OUT_H) {
+                __bf16 hv = (__bf16)patch[j * (DH + 1) + c];
+                reinterpret_cast<uint16_t*>(dst)[(long)(row0 + j) * ld + c] = *reinterpret_cast<uint16_t*>(&hv);
+            } else {
+                dst[(long)(row0 + j) * ld + c] = patch[j * (DH + 1) + c];
+            }
+        }
     }
 }
 
@@ -173,7 +243,7 @@ struct HSm {
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool QH>
 __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = (2 * SM::ROWS + SM::TRN) * 2;
@@ -189,12 +259,12 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     const int d = p.H * DH;
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
-    const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
-    const float* Kb = Qb + d;
-    const float* Vb = Qb + 2 * d;
+    const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
+    const float* Kb = eptr<QH>(Qb, d);
+    const float* Vb = eptr<QH>(Qb, 2 * d);
 
     bf16x8 qf[DH / 16];
-    row_frags<DH>(Qb, p.ld, q, qok, hh, qf);
+    frags_of<DH, QH>(Qb, p.ld, q, qok, hh, qf);
     f32x16 o[DH / 32];
 #pragma unroll
     for (int cb = 0; cb < DH / 32; ++cb)
@@ -207,25 +277,25 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     if (DROP) drop_rb = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site),
                                        (uint32_t)(((long)b * p.H + h) * p.T + q));
 
-    float4 rk[DH / 16], rv[DH / 16];
+    Tile<DH, QH> rk, rv;
     float rpad = 0.f;
     {
         int nv = min(HKT, klen);
-        rows_fetch<DH>(Kb, p.ld, 0, nv, tid, rk);
-        rows_fetch<DH>(Vb, p.ld, 0, nv, tid, rv);
+        rk.fetch(Kb, p.ld, 0, nv, tid);
+        rv.fetch(Vb, p.ld, 0, nv, tid);
         if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + tid]) ? 1.f : 0.f;
     }
     for (int k0 = 0; k0 < klen; k0 += HKT) {
         __syncthreads();
-        rows_stash<DH>(Ks, tid, rk);
-        rows_stash<DH>(Vs, tid, rv);
+        rk.stash(Ks, tid);
+        rv.stash(Vs, tid);
         if (tid < HKT) padS[tid] = rpad;
         const int anypad = __syncthreads_or(tid < HKT && rpad != 0.f);
         lds_transpose<DH>(Vs, Vt, tid);
         if (k0 + HKT < klen) {
             int nv = min(HKT, klen - (k0 + HKT));
-            rows_fetch<DH>(Kb, p.ld, k0 + HKT, nv, tid, rk);
-            rows_fetch<DH>(Vb, p.ld, k0 + HKT, nv, tid, rv);
+            rk.fetch(Kb, p.ld, k0 + HKT, nv, tid);
+            rv.fetch(Vb, p.ld, k0 + HKT, nv, tid);
             if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + k0 + HKT + tid]) ? 1.f : 0.f;
         }
         __syncthreads();
@@ -290,7 +360,7 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
 // =================================================================================================
 // backward A: dQ (+ delta)
 // =================================================================================================
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool QH>
 __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = (2 * SM::ROWS + SM::TRN) * 2;
@@ -306,14 +376,14 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     const int d = p.H * DH;
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
-    const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
-    const float* Kb = Qb + d;
-    const float* Vb = Qb + 2 * d;
+    const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
+    const float* Kb = eptr<QH>(Qb, d);
+    const float* Vb = eptr<QH>(Qb, 2 * d);
     const float* dOb = p.dctx + (long)b * p.T * d + h * DH;
     const float* Ob = p.octx + (long)b * p.T * d + h * DH;
 
     bf16x8 qf[DH / 16], dof[DH / 16];
-    row_frags<DH>(Qb, p.ld, q, qok, hh, qf);
+    frags_of<DH, QH>(Qb, p.ld, q, qok, hh, qf);
     row_frags<DH>(dOb, d, q, qok, hh, dof);
     float delta = 0.f;                         // rowsum(dO * O) in fp32 from the fp32 tensors
     if (qok) {
@@ -341,25 +411,25 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     uint32_t drop_rb = 0;
     if (DROP) drop_rb = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site), (uint32_t)sidx);
 
-    float4 rk[DH / 16], rv[DH / 16];
+    Tile<DH, QH> rk, rv;
     float rpad = 0.f;
     {
         int nv = min(HKT, klen);
-        rows_fetch<DH>(Kb, p.ld, 0, nv, tid, rk);
-        rows_fetch<DH>(Vb, p.ld, 0, nv, tid, rv);
+        rk.fetch(Kb, p.ld, 0, nv, tid);
+        rv.fetch(Vb, p.ld, 0, nv, tid);
         if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + tid]) ? 1.f : 0.f;
     }
     for (int k0 = 0; k0 < klen; k0 += HKT) {
         __syncthreads();
-        rows_stash<DH>(Ks, tid, rk);
-        rows_stash<DH>(Vs, tid, rv);
+        rk.stash(Ks, tid);
+        rv.stash(Vs, tid);
         if (tid < HKT) padS[tid] = rpad;
         const int anypad = __syncthreads_or(tid < HKT && rpad != 0.f);
         lds_transpose<DH>(Ks, Kt, tid);
         if (k0 + HKT < klen) {
             int nv = min(HKT, klen - (k0 + HKT));
-            rows_fetch<DH>(Kb, p.ld, k0 + HKT, nv, tid, rk);
-            rows_fetch<DH>(Vb, p.ld, k0 + HKT, nv, tid, rv);
+            rk.fetch(Kb, p.ld, k0 + HKT, nv, tid);
+            rv.fetch(Vb, p.ld, k0 + HKT, nv, tid);
             if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + k0 + HKT + tid]) ? 1.f : 0.f;
         }
         __syncthreads();
@@ -399,13 +469,14 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
     int row0 = blockIdx.x * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
-    storeT16<DH>(patch, dq, 1.0f, p.dqkv + (long)b * p.T * p.ld + h * DH, p.ld, row0, nvalid, lane);
+    storeT16<DH, QH>(patch, dq, 1.0f, const_cast<float*>(eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH)), p.ld, row0,
+                     nvalid, lane);
 }
 
 // =================================================================================================
 // backward B: dK, dV (workgroup owns 128 keys, loops over queries)
 // =================================================================================================
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool QH>
 __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = (2 * SM::ROWS + 2 * SM::TRN) * 2;
@@ -426,14 +497,14 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     const int klen = p.klen[b];
     const bool kok = key < p.T;
     const bool kact = key < klen;
-    const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
-    const float* Kb = Qb + d;
-    const float* Vb = Qb + 2 * d;
+    const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
+    const float* Kb = eptr<QH>(Qb, d);
+    const float* Vb = eptr<QH>(Qb, 2 * d);
     const float* dOb = p.dctx + (long)b * p.T * d + h * DH;
 
     bf16x8 kf[DH / 16], vf[DH / 16];
-    row_frags<DH>(Kb, p.ld, key, kok, hh, kf);
-    row_frags<DH>(Vb, p.ld, key, kok, hh, vf);
+    frags_of<DH, QH>(Kb, p.ld, key, kok, hh, kf);
+    frags_of<DH, QH>(Vb, p.ld, key, kok, hh, vf);
     // keys that took no part in the forward (>= klen) get probability 0 through a -inf logit
     const float padterm = !kact ? -INFINITY : ((p.key_pad[(long)b * p.T + key]) ? -1e9f * LOG2E : 0.f);
 
@@ -450,11 +521,12 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
 
     const bool wg_active = blockIdx.x * 128 < klen;
     if (wg_active) {
-        float4 rq[DH / 16], ro[DH / 16];
+        Tile<DH, QH> rq;
+        float4 ro[DH / 16];
         float rl = 0.f, rd = 0.f;
         {
             int nv = min(HKT, p.T);
-            rows_fetch<DH>(Qb, p.ld, 0, nv, tid, rq);
+            rq.fetch(Qb, p.ld, 0, nv, tid);
             rows_fetch<DH>(dOb, d, 0, nv, tid, ro);
             if (tid < HKT) {
                 rl = tid < nv ? p.lse[stat0 + tid] * LOG2E : INFINITY;
@@ -463,7 +535,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
         }
         for (int q0 = 0; q0 < p.T; q0 += HKT) {
             __syncthreads();
-            rows_stash<DH>(Qs, tid, rq);
+            rq.stash(Qs, tid);
             rows_stash<DH>(Os, tid, ro);
             if (tid < HKT) {
                 lseS[tid] = rl;
@@ -475,7 +547,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
             lds_transpose<DH>(Os, Ot, tid);
             if (q0 + HKT < p.T) {
                 int nv = min(HKT, p.T - (q0 + HKT));
-                rows_fetch<DH>(Qb, p.ld, q0 + HKT, nv, tid, rq);
+                rq.fetch(Qb, p.ld, q0 + HKT, nv, tid);
                 rows_fetch<DH>(dOb, d, q0 + HKT, nv, tid, ro);
                 if (tid < HKT) {
                     rl = tid < nv ? p.lse[stat0 + q0 + HKT + tid] * LOG2E : INFINITY;
@@ -516,9 +588,9 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
     int row0 = blockIdx.x * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
-    float* dst = p.dqkv + (long)b * p.T * p.ld + h * DH;
-    storeT16<DH>(patch, dk, 1.0f, dst + d, p.ld, row0, nvalid, lane);
-    storeT16<DH>(patch, dv, 1.0f, dst + 2 * d, p.ld, row0, nvalid, lane);
+    const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH);
+    storeT16<DH, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
+    storeT16<DH, QH>(patch, dv, 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -540,8 +612,13 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
 
 #define HLAUNCH(KERNEL, DHV, grid, st, p)                                                      \
     do {                                                                                       \
-        if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, true>), grid, dim3(256), 0, st, p);       \
-        else hipLaunchKernelGGL((KERNEL<DHV, false>), grid, dim3(256), 0, st, p);              \
+        if (qh) {                                                                              \
+            if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, true, true>), grid, dim3(256), 0, st, p);   \
+            else hipLaunchKernelGGL((KERNEL<DHV, false, true>), grid, dim3(256), 0, st, p);          \
+        } else {                                                                               \
+            if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, true, false>), grid, dim3(256), 0, st, p);  \
+            else hipLaunchKernelGGL((KERNEL<DHV, false, false>), grid, dim3(256), 0, st, p);         \
+        }                                                                                      \
     } while (0)
 
 #define HDISPATCH(dh, KERNEL, grid, st, p)                                                     \
@@ -556,7 +633,7 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
 // called from attention.hip's entry points when dtype == TTSMI_BF16
 int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
                          float* lse, int B, int H, int T, int dh, float p_drop, uint64_t seed,
-                         const int64_t* step_dev, uint32_t site, hipStream_t st) {
+                         const int64_t* step_dev, uint32_t site, int qh, hipStream_t st) {
     HAttnP p;
     int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_fwd(bf16)");
     if (rc) return rc;
@@ -571,7 +648,7 @@ int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t*
 int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
                          const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
                          float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, void* ws,
-                         hipStream_t st) {
+                         int qh, hipStream_t st) {
     HAttnP p;
     int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_bwd(bf16)");
     if (rc) return rc;

@@ -320,7 +320,7 @@ class ForwardTransformer:
                                                      want_attn)
                 if want_attn:
                     attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
-                        qkv, pad, lse, B, H, T, d // H, rate, drop, sites[0])
+                        qkv.float() if qkv.dtype != torch.float32 else qkv, pad, lse, B, H, T, d // H, rate, drop, sites[0])
                 continue
             qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'],
                                      S(f'{p}.wqkv'))

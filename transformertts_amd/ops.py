@@ -825,7 +825,13 @@ class DenseBlockFn(torch.autograd.Function):
         dh_ = d // H
         if dtype != TTSMI_F32 and dh_ not in (32, 64):
             dtype = TTSMI_F32
-        qkv = dense_fwd(h, P['wqkv'], P['bqkv'], False, None, S.get('wqkv'))
+        shq = S.get('wqkv')
+        if shq is not None and dtype != TTSMI_F32 and d % 8 == 0:
+            # TTSMI_BF16: qkv (and dqkv in backward) are pure GEMM / attention operands: keep them in bf16
+            qkv = hgemm_tn(h, shq.wt, P['bqkv'], out_bf16=True)
+            dtype = _lib.TTSMI_BF16_QKV
+        else:
+            qkv = dense_fwd(h, P['wqkv'], P['bqkv'], False, None, shq)
         cx = torch.empty((M, d), dtype=torch.float32, device=h.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=h.device)
         check(_lib.lib().ttsmi_attention_fwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(lse), B, H, T, dh_, float(rate),
@@ -892,6 +898,10 @@ class DenseBlockFn(torch.autograd.Function):
                                     rate, drop.seed, _p(drop.step_dev), sites[0], _p(ws), ws.numel(), dtype,
                                     _stream()), 'attention_bwd')
         shq = S.get('wqkv')
-        dense_wgrad(h, dqkv, G['wqkv'], G['bqkv'], shq)
-        dense_dgrad(dqkv, P['wqkv'], shq, 0, d, out=dh, accumulate=True)                    # dh += dqkv.Wqkv^T
+        if dqkv.dtype == torch.bfloat16:
+            _on_wgrad_stream(lambda: hgemm_wgrad_rows(h, dqkv, G['wqkv'], G['bqkv']), h, dqkv)
+            hgemm_tn(dqkv, shq.wb, out=dh, accumulate=True)                                  # dh += dqkv.Wqkv^T
+        else:
+            dense_wgrad(h, dqkv, G['wqkv'], G['bqkv'], shq)
+            dense_dgrad(dqkv, P['wqkv'], shq, 0, d, out=dh, accumulate=True)                # dh += dqkv.Wqkv^T
         return (dh,) + (None,) * 13
