@@ -272,6 +272,18 @@ int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void
                            ttsmi_stream_t stream);
 int ttsmi_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int R,
                               int C, int taps, int T, int pad, ttsmi_stream_t stream);
+/* Batched cast-transpose (the per-step refresh of every GEMM weight's bf16 W^T in one launch).
+ * desc_dev: DEVICE array of n_desc descriptors; descriptor i owns the 64x64 tiles
+ * [tile_start, tile_start + tiles_r * ceil(C/64)), tiles_r = ceil(ld_dst/64), ordered by tile_start;
+ * dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) for r < R (0 for R <= r < ld_dst), c < C. */
+typedef struct {
+    const float* src;
+    uint16_t* dst;
+    int64_t ld_src, ld_dst;
+    int32_t R, C, tile_start, tiles_r;
+} ttsmi_transpose_desc;
+int ttsmi_cast_transpose_bf16_batched(const ttsmi_transpose_desc* desc_dev, int n_desc, int total_tiles,
+                                      ttsmi_stream_t stream);
 int ttsmi_conv_wdgrad_layout_bf16(const float* w, uint16_t* dst, int k, int Cin, int Cout,
                                   ttsmi_stream_t stream);
 

@@ -35,10 +35,10 @@ def test_flat_params_layout_and_spec_matches_oracle():
     spec['s'] = ()
     spec['b'] = (7,)
     P = FlatParams(spec, 'cpu')
-    assert P.offsets['a'] == (0, 15) and P.offsets['s'] == (16, 1) and P.offsets['b'] == (20, 7)
-    assert P.total == 28 and P.n_params == 23
+    assert P.offsets['a'] == (0, 15) and P.offsets['s'] == (16, 1) and P.offsets['b'] == (24, 7)
+    assert P.total == 32 and P.n_params == 23          # every tensor starts on a 32-byte boundary
     P.g['b'].fill_(2.0)
-    assert P.grad[20:27].eq(2).all() and P.grad[:20].eq(0).all()
+    assert P.grad[24:31].eq(2).all() and P.grad[:24].eq(0).all()
     assert P.w['a'].requires_grad and P.w['a'].data_ptr() == P.data.data_ptr()
     # parameter count of the benchmark config equals the oracle's spec (SURVEY: 11.06 M)
     cfg = fo.make_config()

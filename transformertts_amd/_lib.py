@@ -72,6 +72,7 @@ SIGNATURES = {
     'ttsmi_hgemm_wgrad_rows_ws_bytes': (c_size_t, [I, I, I]),
     'ttsmi_hgemm_wgrad_rows': (I, [P, I, L, P, I, L, P, L, P, I, I, I, I, I, I, I, P, c_size_t, S]),
     'ttsmi_conv_wdgrad_layout_bf16': (I, [P, P, I, I, I, S]),
+    'ttsmi_cast_transpose_bf16_batched': (I, [P, I, I, S]),
 }
 
 TTSMI_F32, TTSMI_BF16, TTSMI_BF16_QKV = 0, 1, 2

@@ -500,6 +500,36 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// Batched form for the per-step weight-shadow refresh: ONE launch transposes every GEMM weight
+// (descriptor table resident on the device; block -> descriptor by tile prefix).
+__global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const ttsmi_transpose_desc* __restrict__ desc,
+                                                                     int n_desc) {
+    __shared__ float tile[64][65];
+    __shared__ int which;
+    if (threadIdx.x == 0) {
+        int i = 0;
+        while (i + 1 < n_desc && desc[i + 1].tile_start <= (int)blockIdx.x) ++i;
+        which = i;
+    }
+    __syncthreads();
+    const ttsmi_transpose_desc d = desc[which];
+    const int t = blockIdx.x - d.tile_start;
+    const int r0 = (t % d.tiles_r) * 64, c0 = (t / d.tiles_r) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        int r = r0 + rr, c = c0 + tx;
+        tile[rr][tx] = (r < d.R && c < d.C) ? d.src[(long)r * d.ld_src + c] : 0.f;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        int c = c0 + cc, r = r0 + tx;
+        if (c < d.C && r < d.ld_dst) {
+            __bf16 h = (__bf16)tile[tx][cc];
+            d.dst[(long)c * d.ld_dst + r] = *reinterpret_cast<uint16_t*>(&h);
+        }
+    }
+}
+
 // conv weight [k, Cin, Cout] fp32 -> dgrad operand bf16 [Cin][k*Cout] with flipped taps:
 // dst[ci][j'*Cout + co] = w[k-1-j'][ci][co]
 __global__ __launch_bounds__(256) void conv_wdgrad_layout_kernel(const float* __restrict__ w,
@@ -687,6 +717,15 @@ int ttsmi_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, i
     hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, dst,
                        (long)ld_dst, R, C, taps, T, pad);
     TTSMI_CHECK_LAUNCH("cast_transpose_bf16");
+    return TTSMI_OK;
+}
+
+int ttsmi_cast_transpose_bf16_batched(const ttsmi_transpose_desc* desc_dev, int n_desc, int total_tiles,
+                                      ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(desc_dev && n_desc > 0 && total_tiles > 0, "cast_transpose_bf16_batched: bad argument");
+    hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       desc_dev, n_desc);
+    TTSMI_CHECK_LAUNCH("cast_transpose_bf16_batched");
     return TTSMI_OK;
 }
 

@@ -81,7 +81,7 @@ class FlatParams:
     """All trainable variables as views of ONE flat fp32 buffer (+ matching gradient / Adam m / v
     buffers).  Every tensor starts on a 16-byte boundary so the float4 kernel paths apply."""
 
-    ALIGN = 4
+    ALIGN = 8     # 32 B in fp32, 16 B in the flat bf16 shadow copy (views of it are GEMM operands)
 
     def __init__(self, spec: "OrderedDict[str, tuple]", device):
         self.spec = spec
@@ -204,13 +204,16 @@ class ForwardTransformer:
     def _build_shadows(self):
         """bf16 operand copies of the GEMM weights (precision == 'bf16' only)."""
         self.shadow = {}
+        self.shadow_set = None
         if self.precision == 'bf16':
-            for name in self._shadow_names():
-                self.shadow[name] = ops.make_shadow(self.params.w[name])
+            P = self.params
+            self.shadow_set = ops.ShadowSet(P.data, P.offsets, P.w, list(self._shadow_names()))
+            self.shadow = self.shadow_set.sh
+            self.shadow_set.refresh(False)
 
-    def _refresh_shadows(self):
-        for name, sh in self.shadow.items():
-            ops.refresh_shadow(sh, self.params.w[name])
+    def _refresh_shadows(self, wb_is_current: bool = False):
+        if self.shadow_set is not None:
+            self.shadow_set.refresh(wb_is_current)
 
     # ------------------------------------------------------------------ construction helpers
     def _make_config(self, locals_: dict, kwargs: dict) -> dict:
@@ -539,9 +542,10 @@ class ForwardTransformer:
         launch over the flat buffers; iteration counter and lr live on the device."""
         ops.step_increment(self.step_dev)
         P = self.params
+        ss = self.shadow_set
         ops.adam_tf(P.data, P.grad, P.m, P.v, self.lr_dev, self.step_dev, self.beta_1, self.beta_2,
-                    self.epsilon)
-        self._refresh_shadows()
+                    self.epsilon, shadow=None if ss is None else ss.flat_bf16)
+        self._refresh_shadows(wb_is_current=True)
 
     def _compile(self, optimizer=None, learning_rate: Optional[float] = None):
         """reference _compile models.py:484-490.  `optimizer` may be any object with

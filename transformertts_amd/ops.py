@@ -274,6 +274,64 @@ def refresh_shadow(sh, w):
         check(l.ttsmi_conv_wdgrad_layout_bf16(_p(wf), _p(sh.wd), k, cin, cout, _stream()), 'conv_wdgrad_layout')
 
 
+class ShadowSet:
+    """All bf16 weight shadows of a model, refreshed with O(1) launches per optimiser step:
+      * `wb` (weights as stored) are views of ONE flat bf16 buffer that the fused Adam kernel writes
+        while it updates the fp32 master weights (no extra launch, no extra read of the weights);
+      * every `wt` (W^T / conv forward layout) comes from ONE batched cast-transpose launch driven by
+        a descriptor table that lives on the device;
+      * the few Conv1D dgrad layouts (`wd`) keep one small launch each.
+    flat: the fp32 flat parameter buffer; offsets: name -> (offset, numel); views: name -> fp32 view."""
+
+    def __init__(self, flat, offsets, views, names):
+        import numpy as np
+        dev = flat.device
+        self.flat = flat
+        self.flat_bf16 = torch.empty(flat.numel(), dtype=torch.bfloat16, device=dev)
+        self.sh = {}
+        self._conv = []
+        recs = []
+        tile = 0
+        for name in names:
+            w = views[name].detach()
+            o, n = offsets[name]
+            assert (o * 2) % 16 == 0, 'parameter offsets must keep bf16 views 16-byte aligned'
+            if w.dim() == 2:
+                K, N = w.shape
+                wt = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
+                self.sh[name] = Shadow(wb=self.flat_bf16[o:o + n].view(K, N), wt=wt)
+                R, C = K, N
+            else:
+                k, cin, cout = w.shape
+                wt = torch.empty((cout, k * cin), dtype=torch.bfloat16, device=dev)
+                wd = torch.empty((cin, k * cout), dtype=torch.bfloat16, device=dev)
+                self.sh[name] = Shadow(wt=wt, wd=wd)
+                self._conv.append((w, wd))
+                R, C = k * cin, cout
+            tiles_r = (R + 63) // 64
+            recs.append((w.data_ptr(), wt.data_ptr(), C, R, R, C, tile, tiles_r))
+            tile += tiles_r * ((C + 63) // 64)
+        self.n_desc, self.total_tiles = len(recs), tile
+        dt = np.dtype([('src', '<u8'), ('dst', '<u8'), ('ld_src', '<i8'), ('ld_dst', '<i8'), ('R', '<i4'),
+                       ('C', '<i4'), ('tile_start', '<i4'), ('tiles_r', '<i4')])
+        arr = np.array(recs, dtype=dt)
+        assert arr.itemsize == 48
+        self.desc = torch.from_numpy(arr.view(np.uint8).copy()).to(dev) if recs else None
+
+    def refresh(self, wb_is_current: bool):
+        """wb_is_current: the Adam kernel of this step already wrote the flat bf16 copy."""
+        l = _lib.lib()
+        if not wb_is_current:
+            check(l.ttsmi_cast_f32_to_bf16(_p(self.flat), _p(self.flat_bf16), self.flat.numel(), _stream()),
+                  'cast_f32_to_bf16')
+        if self.desc is not None:
+            check(l.ttsmi_cast_transpose_bf16_batched(_p(self.desc), self.n_desc, self.total_tiles, _stream()),
+                  'cast_transpose_bf16_batched')
+        for w, wd in self._conv:
+            k, cin, cout = w.shape
+            check(l.ttsmi_conv_wdgrad_layout_bf16(_p(w), _p(wd), k, cin, cout, _stream()), 'conv_wdgrad_layout')
+
+
 # ---- precision-dispatching wrappers: sh is None -> exact-fp32 MFMA kernels ------------------------
 def dense_fwd(x, w, b, relu, x2, sh):
     K = w.shape[0]
