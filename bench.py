@@ -14,9 +14,13 @@ scaling: per-GPU batch fixed, global batch = 32*N, one RCCL all-reduce of the fl
 buffer per step.  Inputs are resident in HBM before the timed region.
 
 One JSON line is printed by rank 0.  Besides the driver contract it carries
-  roofline     - the dominant kernel family of the step (exact-fp32 MFMA GEMM/attention kernels):
-                 algorithmic FLOPs per launch / average launch duration, measured live with HIP
-                 events on the launch stream in one extra instrumented step after the timed region;
+  roofline     - the dominant kernel family of the step (the one with the most launch time): its
+                 algorithmic bytes and FLOPs per launch / its average launch
+                 duration, measured live with HIP events on the stream each launch goes to, in one
+                 extra instrumented step after the timed region.  `bound` is chosen by the family's
+                 arithmetic intensity against the ridge (peak FLOP/s / peak HBM B/s): the bf16 path's
+                 K=256..1024 GEMMs sit below it (HBM-bound), the exact-fp32 path's above (MFMA-bound).
+                 `traffic` = measured HBM bytes per launch from the committed PMC passes;
   cpu_baseline - the reference-restatement oracle (torch-CPU fp32, same graph, attention maps
                  materialised like the reference) timed on this host on a bounded sample.
 """
@@ -81,6 +85,57 @@ def _flops(name, a):
     return 0.0
 
 
+def _bytes(name, a):
+    """Algorithmic HBM bytes of one launch: every operand read once, every result written once (an
+    accumulate epilogue also reads its output), weights included; no re-reads, no workspace."""
+    if name == 'ttsmi_hgemm_tn':
+        a_f32, K1, relu_src, M, N, K, flags, taps = a[1], a[5], a[9], a[13], a[14], a[15], a[16], a[17]
+        k_cols = K // taps if taps > 1 else K                 # implicit-GEMM conv reads x once, not k times
+        out_b = 2 if flags & 4 else 4
+        byt = M * k_cols * (4 if a_f32 else 2) + 2.0 * K * N + M * N * out_b * (2 if flags & 2 else 1)
+        if relu_src:
+            byt += M * N * (2 if flags & 8 else 4)
+        return byt
+    if name == 'ttsmi_hgemm_wgrad_rows':
+        xh, yh, rows, kin, n, taps = a[1], a[4], a[9], a[10], a[11], a[12]
+        k_cols = kin // taps if taps > 1 else kin
+        return rows * k_cols * (2 if xh else 4) + rows * n * (2 if yh else 4) + 4.0 * kin * n
+    if name == 'ttsmi_hgemm_wgrad':
+        rows, kin, n = a[6], a[7], a[8]
+        return 2.0 * rows * (kin + n) + 4.0 * kin * n
+    if name == 'ttsmi_attention_fwd':
+        B, H, T, dh, dtype = a[5], a[6], a[7], a[8], a[13]
+        rows, d = B * T, H * dh
+        return rows * 3 * d * (2 if dtype == 2 else 4) + rows * d * 4 + B * H * T * 4
+    if name == 'ttsmi_attention_bwd':
+        B, H, T, dh, dtype = a[7], a[8], a[9], a[10], a[17]
+        rows, d = B * T, H * dh
+        qb = 2 if dtype == 2 else 4
+        # dq pass: q,k,v + ctx + dctx + lse -> dq, delta;  dkv pass: q,k,v + dctx + lse + delta -> dk,dv
+        return (2 * rows * 3 * d * qb + rows * d * 4 * 3 + rows * 3 * d * qb + 4.0 * B * H * T * 4)
+    if name == 'ttsmi_linear_fwd':
+        M, N, K = a[10], a[11], a[12]
+        return 4.0 * (M * K + K * N + M * N)
+    if name == 'ttsmi_linear_dgrad':
+        M, N, K, acc = a[8], a[9], a[10], a[11]
+        return 4.0 * (M * N + K * N + M * K * (2 if acc else 1)) + (4.0 * M * K if a[4] else 0)
+    if name == 'ttsmi_linear_wgrad':
+        M, N, K = a[7], a[8], a[9]
+        return 4.0 * (M * K + M * N + K * N)
+    if name in ('ttsmi_conv1d_fwd', 'ttsmi_conv1d_dgrad', 'ttsmi_conv1d_wgrad'):
+        B, T, Cin, Cout, k = a[4], a[5], a[6], a[7], a[8]
+        return 4.0 * (B * T * (Cin + Cout) + k * Cin * Cout)
+    if name == 'ttsmi_add_layernorm_fwd':
+        M, C = a[18], a[19]
+        return 4.0 * M * C * (2 + (1 if a[1] else 0))
+    if name == 'ttsmi_add_layernorm_bwd':
+        M, C = a[22], a[23]
+        return 4.0 * M * C * (3 + (1 if a[2] else 0) + (1 if a[18] and a[18] != a[17] else 0))
+    if name == 'ttsmi_adam_tf':
+        return a[4] * (7 * 4.0 + (2 if a[10] else 0))
+    return 0.0
+
+
 KERNEL_OF = {
     'ttsmi_linear_fwd': 'gemm_f32_kernel<A_KC,B_NC> (Dense/Conv1D forward)',
     'ttsmi_conv1d_fwd': 'gemm_f32_kernel<A_KC,B_NC> (Dense/Conv1D forward)',
@@ -91,8 +146,28 @@ KERNEL_OF = {
     'ttsmi_hgemm_tn': 'gemm_bf16_kernel<A=f32> (Dense/Conv1D forward + dgrad, bf16 MFMA)',
     'ttsmi_hgemm_wgrad': 'gemm_bf16_kernel<A=bf16> (wgrad, bf16 MFMA, + split reduce)',
     'ttsmi_hgemm_wgrad_rows': 'wgrad_rows_kernel (wgrad from fp32 rows, bf16 MFMA, + split reduce)',
-    'ttsmi_attention_fwd': 'attn_fwd_kernel',
-    'ttsmi_attention_bwd': 'attn_bwd_dq_kernel + attn_bwd_dkv_kernel',
+    'ttsmi_attention_fwd': 'attn_fwd_kernel (exact fp32 MFMA)',
+    'ttsmi_attention_bwd': 'attn_bwd_dq_kernel + attn_bwd_dkv_kernel (exact fp32 MFMA)',
+}
+RIDERS = 'hbm-bound riders (LN, lenreg, loss, Adam, ...)'
+HATTN_FWD = 'hattn_fwd_kernel (bf16 MFMA flash attention forward)'
+HATTN_BWD = 'hattn_bwd_dq_kernel + hattn_bwd_dkv_kernel (bf16 MFMA flash attention backward)'
+
+
+def kernel_family(name, args):
+    if name == 'ttsmi_attention_fwd' and args[13] != 0:
+        return HATTN_FWD
+    if name == 'ttsmi_attention_bwd' and args[17] != 0:
+        return HATTN_BWD
+    return KERNEL_OF.get(name, RIDERS)
+
+
+PMC_FILE = 'r01_pmc_hbm_traffic_bf16.json'
+PMC_KERNELS = {       # kernel family -> rocprof kernel-name prefixes (bf16 path; the PMC passes ran that path)
+    KERNEL_OF['ttsmi_hgemm_tn']: ['gemm_bf16_kernel'],
+    KERNEL_OF['ttsmi_hgemm_wgrad_rows']: ['wgrad_rows_kernel', 'hsplit_reduce_kernel'],
+    HATTN_FWD: ['hattn_fwd_kernel'],
+    HATTN_BWD: ['hattn_bwd_'],
 }
 
 
@@ -101,7 +176,8 @@ def peak_of(kernel_name: str) -> float:
 
 
 def instrumented_step(step_fn):
-    """Run one step with every C-ABI call bracketed by HIP events on the launch stream."""
+    """Run one step with every C-ABI call bracketed by HIP events on the stream it launches on.
+    Returns per-call records (entry point, algorithmic flops, algorithmic bytes, shape key, ms)."""
     from transformertts_amd import _lib
     recs = []
 
@@ -112,7 +188,9 @@ def instrumented_step(step_fn):
         e0.record()
         rc = fn(*args)
         e1.record()
-        recs.append((name, _flops(name, args), e0, e1))
+        fam = kernel_family(name, args)
+        key = tuple(x for x in args if isinstance(x, int) and not isinstance(x, bool) and 0 <= x < (1 << 26))
+        recs.append((fam, name, _flops(name, args), _bytes(name, args), key, e0, e1))
         return rc
 
     _lib.set_trace(hook)
@@ -121,17 +199,36 @@ def instrumented_step(step_fn):
         torch.cuda.synchronize()
     finally:
         _lib.set_trace(None)
+    return [(fam, n, fl, by, key, e0.elapsed_time(e1)) for fam, n, fl, by, key, e0, e1 in recs]
+
+
+def group_records(recs):
+    """kernel family -> [launches, flops, bytes, ms]"""
     groups = {}
-    total_ms = 0.0
-    for name, fl, e0, e1 in recs:
-        ms = e0.elapsed_time(e1)
-        total_ms += ms
-        k = KERNEL_OF.get(name, 'hbm-bound riders (LN, lenreg, loss, Adam, ...)')
-        gsum = groups.setdefault(k, [0, 0.0, 0.0])
-        gsum[0] += 1
-        gsum[1] += fl
-        gsum[2] += ms
-    return groups, total_ms
+    for k, _name, fl, by, _key, ms in recs:
+        g = groups.setdefault(k, [0, 0.0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += fl
+        g[2] += by
+        g[3] += ms
+    return groups
+
+
+def pmc_traffic(kernel_family: str):
+    """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/, collected by
+    tools/gpu_profile.sh with separate FETCH_SIZE / WRITE_SIZE runs and the guide's gfx950 correction)."""
+    path = os.path.join(ROOT, 'profiles', PMC_FILE)
+    prefixes = PMC_KERNELS.get(kernel_family)
+    if not prefixes or not os.path.exists(path):
+        return None
+    ks = json.load(open(path))['kernels']
+    n = b = 0.0
+    for k, v in ks.items():
+        if any(k.startswith(p) for p in prefixes):
+            if k.startswith(prefixes[0]):      # helper kernels of the same entry point add bytes, not launches
+                n += v['launches']
+            b += v['launches'] * v['hbm_bytes_per_launch']
+    return b / n if n else None
 
 
 def usable_cpus() -> int:
@@ -247,22 +344,31 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         model.use_graph = False             # the instrumented step brackets every launch: run it eagerly
-        groups, total_ms = instrumented_step(step)
-        mfma = {k: v for k, v in groups.items() if v[1] > 0}
-        dom = max(mfma.items(), key=lambda kv: kv[1][2])
-        n, fl, gms = dom[1]
-        all_fl = sum(v[1] for v in mfma.values())
-        all_ms = sum(v[2] for v in mfma.values())
+        groups = group_records(instrumented_step(step))
+        # the dominant kernel family = the one the step spends most launch time in (side-stream wgrad
+        # launches overlap the main stream, so the sum of launch times exceeds the step time)
+        dom, (n, fl, by, gms) = max(((k, v) for k, v in groups.items() if k != RIDERS), key=lambda kv: kv[1][3])
+        peak_fl = peak_of(dom)
+        ridge = peak_fl * 1e12 / (PEAK_HBM_GBS * 1e9)            # FLOP/byte where the two roofs meet
+        hbm_bound = fl / by < ridge
+        gbs, tfs = by / gms / 1e6, fl / gms / 1e9
+        traffic = pmc_traffic(dom) if args.precision == 'bf16' and args.workload == 'configs[1]' else None
         result['roofline'] = {
-            'bound': 'mfma', 'kernel': dom[0], 'launches_per_step': n,
-            'achieved': fl / gms / 1e9, 'peak': peak_of(dom[0]), 'unit': 'TFLOP/s',
-            'frac': fl / gms / 1e9 / peak_of(dom[0]), 'traffic': None,
-            'avg_launch_ms': gms / n, 'algorithmic_gflop_per_launch': fl / n / 1e9,
-            'all_mfma_kernels': {'achieved': all_fl / all_ms / 1e9, 'gflop_per_step': all_fl / 1e9,
-                                 'ms_per_step': all_ms},
-            'per_kernel': {k: {'launches': v[0], 'gflop': v[1] / 1e9, 'ms': v[2],
-                               'tflops': (v[1] / v[2] / 1e9 if v[1] else None)} for k, v in groups.items()},
-            'instrumented_step_ms': total_ms,
+            'bound': 'hbm' if hbm_bound else 'mfma', 'kernel': dom, 'launches_per_step': n,
+            'achieved': gbs if hbm_bound else tfs, 'peak': PEAK_HBM_GBS if hbm_bound else peak_fl,
+            'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
+            'frac': gbs / PEAK_HBM_GBS if hbm_bound else tfs / peak_fl,
+            'traffic': traffic,
+            'traffic_note': ('HBM bytes per launch from the committed PMC passes (profiles/' + PMC_FILE +
+                             ', FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 correction applied)')
+                            if traffic else None,
+            'avg_launch_ms': gms / n, 'algorithmic_mb_per_launch': by / n / 1e6,
+            'algorithmic_gflop_per_launch': fl / n / 1e9, 'flop_per_byte': fl / by, 'ridge_flop_per_byte': ridge,
+            'other_roof_frac': tfs / peak_fl if hbm_bound else gbs / PEAK_HBM_GBS,
+            'per_kernel': {k: {'launches': v[0], 'gflop': v[1] / 1e9, 'algorithmic_mb': v[2] / 1e6, 'ms': v[3],
+                               'tflops': (v[1] / v[3] / 1e9 if v[1] else None),
+                               'gbs': (v[2] / v[3] / 1e6 if v[2] else None)} for k, v in groups.items()},
+            'sum_of_launch_ms': sum(v[3] for v in groups.values()),
         }
     elif world > 1 and not args.no_roofline:
         model.use_graph = False

@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Summarise two rocprofv3 PMC passes (one `--pmc FETCH_SIZE`, one `--pmc WRITE_SIZE`, each with
+`--kernel-trace` only - TCC has 4 counter slots, FETCH_SIZE costs 3 and WRITE_SIZE 2) into HBM bytes
+per launch per kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes:
+
+  * both counters are reported in KiB;
+  * on gfx950 FETCH_SIZE reports exactly half the bytes of a wide (16 B/lane) coalesced streaming
+    read, so it is doubled.  Calibrated in this very trace on two kernels whose byte counts are
+    known exactly: adam_tf_kernel reads 4 fp32 arrays of n_params and writes 3 + one bf16 copy,
+    cast_bf16_kernel reads n_params fp32 and writes n_params bf16 - both match 2*FETCH + WRITE to
+    < 0.2 % (WRITE_SIZE needs no correction).  Every hot kernel here loads 16 B/lane.
+
+Usage: python tools/rocpd_pmc_traffic.py <fetch.db> <write.db> <out.json>"""
+import json
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r'\(.*$', '', name)
+    return re.sub(r'^void ', '', name).strip()
+
+
+def load(path):
+    db = sqlite3.connect(path)
+    agg = {}
+    for k, v in db.execute('select kernel_name, value from counters_collection'):
+        a = agg.setdefault(short(k), [0, 0.0])
+        a[0] += 1
+        a[1] += v
+    return agg
+
+
+def main():
+    f, w = load(sys.argv[1]), load(sys.argv[2])
+    out = {}
+    for k, (n, fv) in f.items():
+        wn, wv = w.get(k, (n, 0.0))
+        out[k] = {'launches': n,
+                  'fetch_size_kib_raw_per_launch': fv / n,
+                  'write_size_kib_per_launch': wv / max(wn, 1),
+                  'hbm_bytes_per_launch': (2.0 * fv / n + wv / max(wn, 1)) * 1024.0}
+    out = dict(sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches']))
+    json.dump({'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950, 16 B/lane loads; '
+                             'calibrated on adam_tf_kernel and cast_bf16_kernel in this trace)',
+               'kernels': out}, open(sys.argv[3], 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()

@@ -155,9 +155,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     float* padS = smem + SM::MAIN;            // KT pad flags as floats (0 / 1)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int ntile = (p.T + 127) >> 7;                 // 1-D grid: all q/key tiles of one (b, h) on one XCD
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = lid % ntile, h = (lid / ntile) % p.H, b = lid / (ntile * p.H);
     const int d = p.H * DH;
-    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const int q = bx * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
     const uint64_t dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
     const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     __syncthreads();
     if (qok && hh == 0) p.lse[((long)b * p.H + h) * p.T + q] = m + logf(l);
     float* patch = smem + wave * 32 * (DH + 1);
-    int row0 = blockIdx.x * 128 + wave * 32;
+    int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
     store_T<DH>(patch, o, 1.0f / l, p.ctx + (long)b * p.T * d + h * DH, d, row0, nvalid, lane);
 }
@@ -255,9 +257,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     float* padS = smem + SM::MAIN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int ntile = (p.T + 127) >> 7;                 // 1-D grid: all q/key tiles of one (b, h) on one XCD
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = lid % ntile, h = (lid / ntile) % p.H, b = lid / (ntile * p.H);
     const int d = p.H * DH;
-    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const int q = bx * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
     const uint64_t dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
     const float* Qb = p.qkv + (long)b * p.T * p.ld + h * DH;
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     }
     __syncthreads();
     float* patch = smem + wave * 32 * (DH + 1);
-    int row0 = blockIdx.x * 128 + wave * 32;
+    int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
     store_T<DH>(patch, dq, 1.0f, p.dqkv + (long)b * p.T * p.ld + h * DH, p.ld, row0, nvalid, lane);
 }
@@ -347,9 +351,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
     float* delS = lseS + KT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int ntile = (p.T + 127) >> 7;                 // 1-D grid: all q/key tiles of one (b, h) on one XCD
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = lid % ntile, h = (lid / ntile) % p.H, b = lid / (ntile * p.H);
     const int d = p.H * DH;
-    const int key = blockIdx.x * 128 + wave * 32 + l31;
+    const int key = bx * 128 + wave * 32 + l31;
     const int klen = p.klen[b];
     const bool kok = key < p.T;
     const bool kact = key < klen;             // keys >= klen took no part in the forward
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
 
     float4 rq[KT * DH / 1024], ro[KT * DH / 1024];
     float rl = 0.f, rd = 0.f;
-    const bool wg_active = blockIdx.x * 128 < klen;   // block-uniform
+    const bool wg_active = bx * 128 < klen;   // block-uniform
     if (wg_active) {
         int nv = min(KT, p.T);
         slab_fetch<DH>(Qb, p.ld, 0, nv, tid, rq);
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
     }
     __syncthreads();
     float* patch = smem + wave * 32 * (DH + 1);
-    int row0 = blockIdx.x * 128 + wave * 32;
+    int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
     float* dst = p.dqkv + (long)b * p.T * p.ld + h * DH;
     store_T<DH>(patch, dk, 1.0f, dst + d, p.ld, row0, nvalid, lane);
@@ -506,7 +512,7 @@ int ttsmi_attention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
     if (rc) return rc;
     TTSMI_CHECK_ARG(klen && ctx && lse, "attention_fwd: null pointer");
     p.ctx = (float*)ctx; p.lse = lse;
-    dim3 grid(ttsmi_cdiv(T, 128), H, B);
+    dim3 grid(ttsmi_cdiv(T, 128) * H * B);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DH(dh, attn_fwd_kernel, grid, st, p);
     TTSMI_CHECK_LAUNCH("attention_fwd");
@@ -537,7 +543,7 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
                     "attention_bwd: workspace too small");
     p.octx = (const float*)ctx; p.dctx = (const float*)dctx; p.lse = (float*)lse;
     p.dqkv = (float*)dqkv; p.delta = (float*)ws;
-    dim3 grid(ttsmi_cdiv(T, 128), H, B);
+    dim3 grid(ttsmi_cdiv(T, 128) * H * B);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DH(dh, attn_bwd_dq_kernel, grid, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dq");

@@ -255,9 +255,11 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     float* padS = reinterpret_cast<float*>(smem + MAIN);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int ntile = (p.T + 127) >> 7;                 // 1-D grid: all q/key tiles of one (b, h) on one XCD
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = lid % ntile, h = (lid / ntile) % p.H, b = lid / (ntile * p.H);
     const int d = p.H * DH;
-    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const int q = bx * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     __syncthreads();
     if (qok && hh == 0) p.lse[((long)b * p.H + h) * p.T + q] = (m + log2f(l)) * LN2;
     float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
-    int row0 = blockIdx.x * 128 + wave * 32;
+    int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
     storeT16<DH>(patch, o, 1.0f / l, p.ctx + (long)b * p.T * d + h * DH, d, row0, nvalid, lane);
 }
@@ -372,9 +374,11 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     float* padS = reinterpret_cast<float*>(smem + MAIN);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int ntile = (p.T + 127) >> 7;                 // 1-D grid: all q/key tiles of one (b, h) on one XCD
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = lid % ntile, h = (lid / ntile) % p.H, b = lid / (ntile * p.H);
     const int d = p.H * DH;
-    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const int q = bx * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     }
     __syncthreads();
     float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
-    int row0 = blockIdx.x * 128 + wave * 32;
+    int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
     storeT16<DH, QH>(patch, dq, 1.0f, const_cast<float*>(eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH)), p.ld, row0,
                      nvalid, lane);
@@ -491,9 +495,11 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     uint32_t* rbS = reinterpret_cast<uint32_t*>(delS + HKT);     // dropout row bases of the q tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int ntile = (p.T + 127) >> 7;                 // 1-D grid: all q/key tiles of one (b, h) on one XCD
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = lid % ntile, h = (lid / ntile) % p.H, b = lid / (ntile * p.H);
     const int d = p.H * DH;
-    const int key = blockIdx.x * 128 + wave * 32 + l31;
+    const int key = bx * 128 + wave * 32 + l31;
     const int klen = p.klen[b];
     const bool kok = key < p.T;
     const bool kact = key < klen;
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     uint64_t dkey = 0;
     if (DROP) dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
 
-    const bool wg_active = blockIdx.x * 128 < klen;
+    const bool wg_active = bx * 128 < klen;
     if (wg_active) {
         Tile<DH, QH> rq;
         float4 ro[DH / 16];
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     }
     __syncthreads();
     float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
-    int row0 = blockIdx.x * 128 + wave * 32;
+    int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
     const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH);
     storeT16<DH, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
@@ -639,7 +645,7 @@ int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     if (rc) return rc;
     TTSMI_CHECK_ARG(ctx && lse, "attention_fwd(bf16): null pointer");
     p.ctx = (float*)ctx; p.lse = lse;
-    dim3 grid(ttsmi_cdiv(T, 128), H, B);
+    dim3 grid(ttsmi_cdiv(T, 128) * H * B);
     HDISPATCH(dh, hattn_fwd_kernel, grid, st, p);
     TTSMI_CHECK_LAUNCH("attention_fwd(bf16)");
     return TTSMI_OK;
@@ -655,7 +661,7 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     TTSMI_CHECK_ARG(ctx && dctx && lse && dqkv && ws, "attention_bwd(bf16): null pointer");
     p.octx = (const float*)ctx; p.dctx = (const float*)dctx; p.lse = (float*)lse;
     p.dqkv = (float*)dqkv; p.delta = (float*)ws;
-    dim3 grid(ttsmi_cdiv(T, 128), H, B);
+    dim3 grid(ttsmi_cdiv(T, 128) * H * B);
     HDISPATCH(dh, hattn_bwd_dq_kernel, grid, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dq(bf16)");
     HDISPATCH(dh, hattn_bwd_dkv_kernel, grid, st, p);

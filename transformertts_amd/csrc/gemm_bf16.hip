@@ -17,6 +17,7 @@
 // With fp32 activations in HBM these GEMMs are L2/HBM-bound (44 FLOP/B at this tile), not MFMA-bound.
 #include <stdlib.h>
 
+#include <type_traits>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -270,16 +271,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
 
 // =================================================================================================
 // wgrad straight from the row-major fp32 activations: dW[K_in, N] = X[M, K_in]^T . dY[M, N].
-// Both operands are fetched as [64 rows][128 cols] fp32 tiles (coalesced 512-byte rows), rounded to
-// bf16 into LDS row images, re-laid-out LDS->LDS into k-contiguous images [128][64+8] (the MFMA
-// fragments need 8 consecutive reduction indices = 8 consecutive ROWS of the source), then consumed
-// like any TN tile.  Versus cast_transpose + TN-GEMM this reads each fp32 activation once and
-// writes nothing but dW: half the HBM traffic and two launches fewer per weight gradient.
+// Both operands are fetched as [32 rows][128 cols] tiles (coalesced 512-byte fp32 / 256-byte bf16 rows)
+// and rounded to bf16 into row-major LDS images.  The MFMA fragments need 8 consecutive REDUCTION
+// indices per lane = 8 consecutive rows of one column of the image: gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: per 16-lane group a [4 rows][16 cols] block, lane c gets column c's 4 values)
+// delivers exactly that from the row-major image, so no re-layout pass and a single barrier per
+// step (images are double buffered).  Row stride 160 bf16 = 80 dwords = 16 (mod 64): the 4 rows a
+// half-wave reads fall on disjoint bank groups.
+// Versus cast_transpose + TN-GEMM this reads each activation once and writes nothing but dW.
+// db (the bias gradient) rides along as one more MFMA with an all-ones A fragment.
 // Conv1D: the K_in tile [j*Cin + c0, +128) lies inside one tap j (Cin % 128 == 0), so its source is
 // the same X tile shifted by (j - pad) frames, rows outside their sequence zeroed.
 // =================================================================================================
-#define WR_ROWS 64
-#define WR_RLD (128 + 8)       // bf16 row image stride
+#define WR_ROWS 32
+#define WR_RLD 160             // bf16 row image stride
+#define WR_NI (WR_ROWS / 8)    // fetch items per thread per operand
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// 8 consecutive rows (r0..r0+7) of one column per lane, through two transposing reads
+__device__ __forceinline__ bf16x8 wr_tr8(const uint16_t* p) {
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * WR_RLD));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
 struct WRowsP {
     const float* X; long ldx; const float* DY; long lddy;
     float* dW; long lddw;
@@ -290,83 +306,88 @@ struct WRowsP {
     int tiles_k, tiles_n;
 };
 
-// bf16-source variant: 4 bf16 (8 bytes) per item, no conversion
-__device__ __forceinline__ void wr_fetch_h(const uint16_t* base, long ld, int ncols, int row0, int rend, int col0,
-                                           int tid, uint2 (&r)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int id = tid + 256 * i;
-        int row = id >> 5, c4 = id & 31;
-        int m = row0 + row, col = col0 + c4 * 4;
-        bool ok = (m < rend) && (col < ncols);
-        r[i] = ok ? *reinterpret_cast<const uint2*>(base + (long)m * ld + col) : make_uint2(0u, 0u);
+// Per-thread fetch cursor over a row-major operand tile: item i = row (tid >> 5) + 8 i of the step, 4
+// columns at (tid & 31) * 4.  All address arithmetic is done once; a step costs one pointer add (the
+// first version recomputed 64-bit row products and a software `m % T` per item per step - with one
+// wave per SIMD that instruction stream, not HBM, set the step time).
+typedef __attribute__((address_space(1))) const char* wr_gptr;     // forces global_load (not flat_load)
+struct WrCursor {
+    wr_gptr ptr;          // item 0 of the current step
+    long step8, stepS;    // bytes between items (8 rows) / between steps (WR_ROWS rows)
+    int m;                // source row of item 0
+    int tq;               // m % T (conv windows only)
+    bool colok;
+};
+__device__ __forceinline__ WrCursor wr_cursor(const void* base, int ebytes, long ld, int ncols, int row0, int col0,
+                                              int shift, int T, int tid) {
+    WrCursor c;
+    const int row = tid >> 5, col = col0 + (tid & 31) * 4;
+    c.m = row0 + row;
+    c.colok = col < ncols;
+    c.ptr = (wr_gptr)base + (((long)c.m + shift) * ld + col) * ebytes;
+    c.step8 = 8 * ld * ebytes;
+    c.stepS = (long)WR_ROWS * ld * ebytes;
+    c.tq = T > 0 ? c.m % T : 0;
+    return c;
+}
+__device__ __forceinline__ void wr_advance(WrCursor& c, int T) {
+    c.ptr += c.stepS;
+    c.m += WR_ROWS;
+    if (T > 0) {
+        c.tq += WR_ROWS;
+        while (c.tq >= T) c.tq -= T;
     }
 }
-__device__ __forceinline__ void wr_stash_h(uint16_t* S, int tid, const uint2 (&r)[8]) {
+template <typename V> struct wr_raw;
+template <> struct wr_raw<float4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct wr_raw<uint2> { typedef unsigned type __attribute__((ext_vector_type(2))); };
+template <typename V>
+__device__ __forceinline__ void wr_fetch(const WrCursor& c, int rend, int shift, int T, V (&r)[WR_NI]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < WR_NI; ++i) {
+        bool ok = c.colok && (c.m + 8 * i < rend);
+        if (T > 0) {                      // conv tap: the shifted frame must stay inside its sequence
+            int t = c.tq + 8 * i;
+            while (t >= T) t -= T;
+            ok = ok && ((unsigned)(t + shift) < (unsigned)T);
+        }
+        typedef typename wr_raw<V>::type R;
+        R raw = {};
+        if (ok) raw = *(__attribute__((address_space(1))) const R*)(c.ptr + i * c.step8);
+        r[i] = __builtin_bit_cast(V, raw);
+    }
+}
+__device__ __forceinline__ void wr_stash_h(uint16_t* S, int tid, const uint2 (&r)[WR_NI]) {
+#pragma unroll
+    for (int i = 0; i < WR_NI; ++i) {
         int id = tid + 256 * i;
         int row = id >> 5, c4 = id & 31;
         *reinterpret_cast<uint2*>(S + row * WR_RLD + c4 * 4) = r[i];
     }
 }
-__device__ __forceinline__ void wr_fetch(const float* base, long ld, int ncols, int row0, int rend, int col0,
-                                         int shift, int T, int tid, float4 (&r)[8]) {
+__device__ __forceinline__ void wr_stash(uint16_t* S, int tid, const float4 (&r)[WR_NI]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int id = tid + 256 * i;
-        int row = id >> 5, c4 = id & 31;
-        int m = row0 + row, col = col0 + c4 * 4;
-        bool ok = (m < rend) && (col < ncols);
-        long src = m;
-        if (shift != 0 || T > 0) {
-            if (T > 0) {
-                int tt = (m % T) + shift;
-                ok = ok && (tt >= 0) && (tt < T);
-            }
-            src = (long)m + shift;
-        }
-        r[i] = ok ? *reinterpret_cast<const float4*>(base + src * ld + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-__device__ __forceinline__ void wr_stash(uint16_t* S, int tid, const float4 (&r)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < WR_NI; ++i) {
         int id = tid + 256 * i;
         int row = id >> 5, c4 = id & 31;
         *reinterpret_cast<uint2*>(S + row * WR_RLD + c4 * 4) = pack4(r[i]);
     }
 }
-// row image [64][WR_RLD] -> k-contiguous image [128][HLD_]: item = (row pair p, 4 columns)
-__device__ __forceinline__ void wr_transpose(const uint16_t* S, uint16_t (*St)[HLD_], int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int id = tid + 256 * i;
-        int p = id & 31, c4 = id >> 5;
-        uint2 a = *reinterpret_cast<const uint2*>(S + (2 * p) * WR_RLD + c4 * 4);
-        uint2 b = *reinterpret_cast<const uint2*>(S + (2 * p + 1) * WR_RLD + c4 * 4);
-        *reinterpret_cast<uint32_t*>(&St[c4 * 4 + 0][2 * p]) = (a.x & 0xFFFFu) | (b.x << 16);
-        *reinterpret_cast<uint32_t*>(&St[c4 * 4 + 1][2 * p]) = (a.x >> 16) | (b.x & 0xFFFF0000u);
-        *reinterpret_cast<uint32_t*>(&St[c4 * 4 + 2][2 * p]) = (a.y & 0xFFFFu) | (b.y << 16);
-        *reinterpret_cast<uint32_t*>(&St[c4 * 4 + 3][2 * p]) = (a.y >> 16) | (b.y & 0xFFFF0000u);
-    }
-}
-
 template <bool XH, bool YH>
 __global__ __launch_bounds__(256) void wgrad_rows_kernel(WRowsP p) {
     constexpr int ROWIMG = WR_ROWS * WR_RLD;             // uint16 elements
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * ROWIMG + 2 * 128 * HLD_) * 2];
-    uint16_t* Xr = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* Yr = Xr + ROWIMG;
-    uint16_t(*Xt)[HLD_] = reinterpret_cast<uint16_t(*)[HLD_]>(Yr + ROWIMG);
-    uint16_t(*Yt)[HLD_] = Xt + 128;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2][2][ROWIMG];      // [buffer][X | dY]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, kg = lane >> 5;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // 1-D grid, XCD-aware: every tile of one row split lands on one XCD, so the split's rows of X and dY
+    // are fetched from HBM once and shared through that XCD's L2.
+    const int ntiles = p.tiles_k * p.tiles_n, nsplit = gridDim.x / ntiles;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = lid % ntiles, zsplit = lid / ntiles;
     const int tn = bid % p.tiles_n, tk = bid / p.tiles_n;
     const int k0 = tk * 128, n0 = tn * 128;
-    const int mbeg = blockIdx.z * p.k_per_split;
+    const int mbeg = zsplit * p.k_per_split;
     const int mend = min(p.M, mbeg + p.k_per_split);
     // conv: this K_in tile belongs to tap j; read X columns [k0 - j*Cin, +128) shifted by j - pad frames
     int tap = 0, xcol0 = k0, shift = 0, Tw = 0, xcols = p.K;
@@ -382,54 +403,77 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(WRowsP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 rx[8], ry[8];       // fp32-source prefetch registers
-    uint2 rxh[8], ryh[8];      // bf16-source prefetch registers (the unused set is dead code)
-    auto fetch_tiles = [&](int mrow) {
-        if constexpr (XH) wr_fetch_h((const uint16_t*)p.X, p.ldx, xcols, mrow, mend, xcol0, tid, rxh);
-        else wr_fetch(p.X, p.ldx, xcols, mrow, mend, xcol0, shift, Tw, tid, rx);
-        if constexpr (YH) wr_fetch_h((const uint16_t*)p.DY, p.lddy, p.N, mrow, mend, n0, tid, ryh);
-        else wr_fetch(p.DY, p.lddy, p.N, mrow, mend, n0, 0, 0, tid, ry);
+    float4 rx[WR_NI], ry[WR_NI];       // fp32-source prefetch registers
+    uint2 rxh[WR_NI], ryh[WR_NI];      // bf16-source prefetch registers (the unused set is dead code)
+    WrCursor cx = wr_cursor(p.X, XH ? 2 : 4, p.ldx, xcols, mbeg, xcol0, shift, Tw, tid);
+    WrCursor cy = wr_cursor(p.DY, YH ? 2 : 4, p.lddy, p.N, mbeg, n0, 0, 0, tid);
+    auto fetch_tiles = [&]() {
+        if constexpr (XH) wr_fetch(cx, mend, shift, Tw, rxh); else wr_fetch(cx, mend, shift, Tw, rx);
+        if constexpr (YH) wr_fetch(cy, mend, 0, 0, ryh); else wr_fetch(cy, mend, 0, 0, ry);
+        wr_advance(cx, Tw);
+        wr_advance(cy, 0);
     };
-    if (mbeg < mend) fetch_tiles(mbeg);
-    const bool do_colsum = (p.colsum != nullptr) && (tk == 0) && (tid < 128);
-    float csum = 0.f;
-    for (int m0 = mbeg; m0 < mend; m0 += WR_ROWS) {
-        if constexpr (XH) wr_stash_h(Xr, tid, rxh); else wr_stash(Xr, tid, rx);
-        if constexpr (YH) wr_stash_h(Yr, tid, ryh); else wr_stash(Yr, tid, ry);
-        __syncthreads();
-        if (m0 + WR_ROWS < mend) fetch_tiles(m0 + WR_ROWS);
-        wr_transpose(Xr, Xt, tid);
-        wr_transpose(Yr, Yt, tid);
-        __syncthreads();
-        if (do_colsum) {
+    if (mbeg < mend) fetch_tiles();
+    // bias gradient: wave row 0 of the tk == 0 tiles multiplies an all-ones A fragment with its dY fragments
+    const bool do_colsum = (p.colsum != nullptr) && (tk == 0) && (wr == 0);
+    f32x16 cs[2];
 #pragma unroll
-            for (int c8 = 0; c8 < WR_ROWS / 8; ++c8) {
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(&Yt[tid][c8 * 8]);
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) csum += (float)v[e];
+        for (int r = 0; r < 16; ++r) cs[j][r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    // transposing-read lane address: 16-lane group g = lane >> 4 covers rows (g >> 1) * 8 + [0, 4) (second read
+    // +4), columns (g & 1) * 16 + [0, 16); lane t of the group supplies row t >> 2, columns 4 * (t & 3)..+3
+    const int lane_off = ((lane >> 5) * 8 + ((lane & 15) >> 2)) * WR_RLD + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+    // two instantiations of the loop: a data-dependent `if (do_colsum)` around MFMAs inside it makes the
+    // compiler shuttle every accumulator between AGPRs and VGPRs each step
+    auto run = [&](auto colsum_tag) {
+        constexpr bool kColsum = decltype(colsum_tag)::value;
+        int buf = 0;
+        for (int m0 = mbeg; m0 < mend; m0 += WR_ROWS) {
+            uint16_t* Xi = smem[buf][0];
+            uint16_t* Yi = smem[buf][1];
+            if constexpr (XH) wr_stash_h(Xi, tid, rxh); else wr_stash(Xi, tid, rx);
+            if constexpr (YH) wr_stash_h(Yi, tid, ryh); else wr_stash(Yi, tid, ry);
+            __syncthreads();
+            if (m0 + WR_ROWS < mend) fetch_tiles();
+            const uint16_t* xa = Xi + lane_off + wr * 64;
+            const uint16_t* yb = Yi + lane_off + wc * 64;
+    #pragma unroll
+            for (int ks = 0; ks < WR_ROWS / 16; ++ks) {
+                bf16x8 a0 = wr_tr8(xa + ks * 16 * WR_RLD);
+                bf16x8 a1 = wr_tr8(xa + ks * 16 * WR_RLD + 32);
+                bf16x8 b0 = wr_tr8(yb + ks * 16 * WR_RLD);
+                bf16x8 b1 = wr_tr8(yb + ks * 16 * WR_RLD + 32);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+                if constexpr (kColsum) {
+                    cs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b0, cs[0], 0, 0, 0);
+                    cs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b1, cs[1], 0, 0, 0);
+                }
+            }
+            // double-buffered images: the next stash writes the other buffer, whose last readers finished
+            // before they arrived at this iteration's barrier
+            buf ^= 1;
+        }
+    };
+    if (do_colsum) run(std::true_type{}); else run(std::false_type{});
+    const bool split = nsplit > 1;
+    if (do_colsum && kg == 0) {            // every row of cs[j] holds the column sums: take row 0
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int col = n0 + wc * 64 + j * 32 + l31;
+            if (col < p.N) {
+                if (split) p.colsum_ws[(long)zsplit * p.N + col] = cs[j][0];
+                else p.colsum[col] = cs[j][0];
             }
         }
-#pragma unroll
-        for (int ks = 0; ks < WR_ROWS / 16; ++ks) {
-            const int ko = ks * 16 + kg * 8;
-            bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&Xt[wr * 64 + l31][ko]);
-            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Xt[wr * 64 + 32 + l31][ko]);
-            bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Yt[wc * 64 + l31][ko]);
-            bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Yt[wc * 64 + 32 + l31][ko]);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        // the next iteration's stash overwrites Xr/Yr (free since the transposes) and its transposes
-        // overwrite Xt/Yt only after the barrier that follows the stash
     }
-    const bool split = gridDim.z > 1;
-    if (do_colsum && n0 + tid < p.N) {
-        if (split) p.colsum_ws[(long)blockIdx.z * p.N + n0 + tid] = csum;
-        else p.colsum[n0 + tid] = csum;
-    }
-    float* Cb = split ? p.ws + (long)blockIdx.z * p.K * p.N : p.dW;
+    float* Cb = split ? p.ws + (long)zsplit * p.K * p.N : p.dW;
     const long ldc = split ? (long)p.N : p.lddw;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -463,6 +507,74 @@ __global__ void hsplit_reduce_kernel(const float* __restrict__ ws, float* __rest
             for (int z = 0; z < splits; ++z) s += cs_ws[(long)z * N + c];
             cs_out[c] = s;
         }
+    }
+}
+
+// Same reduction, 4 elements per lane and the splits spread over the block's 4 waves: wave w sums the
+// contiguous split range [S*w/4, S*(w+1)/4) in order with 8 loads in flight, wave 0 then adds the four
+// partial sums in wave order - a fixed association, so the result is run-to-run deterministic.  The
+// one-element-per-thread loop above is a serial chain of S dependent-latency loads on a handful of
+// waves (15-25 us per weight); this one keeps ~S/4 x 16 B per lane in flight on 4x the waves.
+__global__ __launch_bounds__(256) void hsplit_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                             long ldo, int M, int N, int splits,
+                                                             const float* __restrict__ cs_ws,
+                                                             float* __restrict__ cs_out) {
+    __shared__ float4 part[3][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const long n = (long)M * N, nq = n >> 2, ncs = cs_out ? (N >> 2) : 0;
+    const long q = blockIdx.x * 64L + l;
+    const bool ok = q < nq + ncs;
+    const bool main_part = q < nq;
+    const float* base = main_part ? ws + q * 4 : cs_ws + (q - nq) * 4;
+    const long stride = main_part ? n : (long)N;
+    const int z0 = splits * w / 4, z1 = splits * (w + 1) / 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (long)(z + u) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; z < z1; ++z) {
+            float4 v = *reinterpret_cast<const float4*>(base + (long)z * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    if (w > 0) part[w - 1][l] = s;
+    __syncthreads();
+    if (w == 0 && ok) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            float4 v = part[u][l];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (main_part) {
+            long i = q * 4;
+            int r = (int)(i / N), c = (int)(i - (long)r * N);
+            *reinterpret_cast<float4*>(out + (long)r * ldo + c) = s;
+        } else {
+            *reinterpret_cast<float4*>(cs_out + (q - nq) * 4) = s;
+        }
+    }
+}
+
+static void hsplit_reduce_launch(hipStream_t st, const float* ws, float* dw, long lddw, int kin, int n, int splits,
+                                 const float* cs_ws, float* db) {
+    const bool vec = (n % 4 == 0) && (lddw % 4 == 0) && (((uintptr_t)dw & 15) == 0) &&
+                     (((uintptr_t)ws & 15) == 0) && (!db || ((uintptr_t)db & 15) == 0);
+    long tot = (long)kin * n;
+    if (vec) {
+        long quads = tot / 4 + (db ? n / 4 : 0);
+        hipLaunchKernelGGL(hsplit_reduce4_kernel, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, ws, dw, lddw,
+                           kin, n, splits, cs_ws, db);
+    } else {
+        int blocks = (int)((tot + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(hsplit_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, lddw, kin, n, splits, cs_ws,
+                           db);
     }
 }
 
@@ -581,11 +693,19 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
 }
 
 static int hpick_splits(long rows, int tiles) {
-    // ~1 workgroup per CU: wgrad overlaps the main stream, and fewer splits = less slab traffic
-    int want = (256 + tiles - 1) / tiles;
+    // ~1 workgroup per CU: wgrad overlaps the main stream, and fewer splits = less slab traffic.
+    // Splits come in multiples of 8 so that the XCD-aware 1-D grid gives every XCD whole splits.
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("TTSMI_WGRAD_WGS");
+        target = e ? atoi(e) : 256;
+        if (target < 8) target = 256;
+    }
+    int want = (target + tiles - 1) / tiles;
+    if (want > 8) want = (want + 7) / 8 * 8;
     int maxs = (int)((rows + 511) / 512);
     int s = want < maxs ? want : maxs;
-    if (s > 64) s = 64;
+    if (s > 128) s = 128;
     if (s < 1) s = 1;
     return s;
 }
@@ -651,11 +771,7 @@ int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, floa
     int rc = hlaunch(p, false, splits, st, "hgemm_wgrad");
     if (rc) return rc;
     if (splits > 1) {
-        long tot = (long)kin * n;
-        int blocks = (int)((tot + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(hsplit_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, dw, (long)lddw, kin, n,
-                           splits, p.colsum_ws, db);
+        hsplit_reduce_launch(st, p.ws, dw, (long)lddw, kin, n, splits, p.colsum_ws, db);
         TTSMI_CHECK_LAUNCH("hgemm_wgrad_reduce");
     }
     return TTSMI_OK;
@@ -692,18 +808,14 @@ int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void
     splits = ttsmi_cdiv(rows, kps);
     p.k_per_split = kps;
     p.ws = (float*)ws; p.colsum = db; p.colsum_ws = p.ws + (size_t)splits * kin * n;
-    dim3 wgrid(tiles, 1, splits);
+    dim3 wgrid(tiles * splits);
     if (x_is_bf16 && dy_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<true, true>), wgrid, dim3(256), 0, st, p);
     else if (x_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<true, false>), wgrid, dim3(256), 0, st, p);
     else if (dy_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<false, true>), wgrid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_rows_kernel<false, false>), wgrid, dim3(256), 0, st, p);
     TTSMI_CHECK_LAUNCH("hgemm_wgrad_rows");
     if (splits > 1) {
-        long tot = (long)kin * n;
-        int blocks = (int)((tot + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(hsplit_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, dw, (long)lddw, kin, n,
-                           splits, p.colsum_ws, db);
+        hsplit_reduce_launch(st, p.ws, dw, (long)lddw, kin, n, splits, p.colsum_ws, db);
         TTSMI_CHECK_LAUNCH("hgemm_wgrad_rows_reduce");
     }
     return TTSMI_OK;
