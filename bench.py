@@ -150,6 +150,7 @@ KERNEL_OF = {
     'ttsmi_attention_bwd': 'attn_bwd_dq_kernel + attn_bwd_dkv_kernel (exact fp32 MFMA)',
 }
 RIDERS = 'hbm-bound riders (LN, lenreg, loss, Adam, ...)'
+SIDE = ' [side stream]'
 HATTN_FWD = 'hattn_fwd_kernel (bf16 MFMA flash attention forward)'
 HATTN_BWD = 'hattn_bwd_dq_kernel + hattn_bwd_dkv_kernel (bf16 MFMA flash attention backward)'
 
@@ -180,6 +181,7 @@ def instrumented_step(step_fn):
     Returns per-call records (entry point, algorithmic flops, algorithmic bytes, shape key, ms)."""
     from transformertts_amd import _lib
     recs = []
+    main_stream = torch.cuda.current_stream().cuda_stream
 
     def hook(name, args, fn):
         if name.endswith('_ws_bytes') or name in ('ttsmi_last_error', 'ttsmi_version'):
@@ -189,6 +191,8 @@ def instrumented_step(step_fn):
         rc = fn(*args)
         e1.record()
         fam = kernel_family(name, args)
+        if torch.cuda.current_stream().cuda_stream != main_stream:
+            fam += SIDE           # weight-gradient launches on the second HIP stream overlap the main stream
         key = tuple(x for x in args if isinstance(x, int) and not isinstance(x, bool) and 0 <= x < (1 << 26))
         recs.append((fam, name, _flops(name, args), _bytes(name, args), key, e0, e1))
         return rc
@@ -218,7 +222,7 @@ def pmc_traffic(kernel_family: str):
     """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/, collected by
     tools/gpu_profile.sh with separate FETCH_SIZE / WRITE_SIZE runs and the guide's gfx950 correction)."""
     path = os.path.join(ROOT, 'profiles', PMC_FILE)
-    prefixes = PMC_KERNELS.get(kernel_family)
+    prefixes = PMC_KERNELS.get(kernel_family.replace(SIDE, ''))
     if not prefixes or not os.path.exists(path):
         return None
     ks = json.load(open(path))['kernels']
@@ -347,7 +351,9 @@ def main():
         groups = group_records(instrumented_step(step))
         # the dominant kernel family = the one the step spends most launch time in (side-stream wgrad
         # launches overlap the main stream, so the sum of launch times exceeds the step time)
-        dom, (n, fl, by, gms) = max(((k, v) for k, v in groups.items() if k != RIDERS), key=lambda kv: kv[1][3])
+        # (the critical path is the main stream: side-stream launches are listed but not eligible)
+        dom, (n, fl, by, gms) = max(((k, v) for k, v in groups.items() if k != RIDERS and not k.endswith(SIDE)),
+                                    key=lambda kv: kv[1][3])
         peak_fl = peak_of(dom)
         ridge = peak_fl * 1e12 / (PEAK_HBM_GBS * 1e9)            # FLOP/byte where the two roofs meet
         hbm_bound = fl / by < ridge
@@ -368,7 +374,8 @@ def main():
             'per_kernel': {k: {'launches': v[0], 'gflop': v[1] / 1e9, 'algorithmic_mb': v[2] / 1e6, 'ms': v[3],
                                'tflops': (v[1] / v[3] / 1e9 if v[1] else None),
                                'gbs': (v[2] / v[3] / 1e6 if v[2] else None)} for k, v in groups.items()},
-            'sum_of_launch_ms': sum(v[3] for v in groups.values()),
+            'main_stream_launch_ms': sum(v[3] for k, v in groups.items() if not k.endswith(SIDE)),
+            'side_stream_launch_ms': sum(v[3] for k, v in groups.items() if k.endswith(SIDE)),
         }
     elif world > 1 and not args.no_roofline:
         model.use_graph = False

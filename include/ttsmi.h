@@ -39,9 +39,10 @@ enum {
     TTSMI_ERR_UNSUPPORTED = -3,
     TTSMI_ERR_WORKSPACE = -4
 };
-/* TTSMI_BF16_QKV (attention entry points only): as TTSMI_BF16, and the qkv / dqkv tensors themselves
- * are bf16 in HBM (written by ttsmi_hgemm_tn with OUT_BF16, consumed by the bf16 GEMM kernels). */
-enum { TTSMI_F32 = 0, TTSMI_BF16 = 1, TTSMI_BF16_QKV = 2 };
+/* TTSMI_BF16_IO (attention entry points only): as TTSMI_BF16, and every activation the entry point
+ * touches - qkv, ctx, dctx, dqkv - is bf16 in HBM (written by / feeding ttsmi_hgemm_tn and
+ * ttsmi_hgemm_wgrad_rows, which take bf16 operands); lse and the delta scratch stay fp32. */
+enum { TTSMI_F32 = 0, TTSMI_BF16 = 1, TTSMI_BF16_IO = 2 };
 
 typedef void* ttsmi_stream_t; /* hipStream_t */
 
@@ -125,6 +126,8 @@ int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float
  *   y  = keep_out(y)                         if p_out > 0
  *   y  = 0 on rows with row_pad[row] != 0    if row_pad != NULL
  * mean/rstd [M] are saved for backward.  res, pe, row_pad may be NULL.
+ * y_bf16 (may be NULL): a bf16 copy of y written by the same pass - the operand the consumer GEMMs
+ * read (TTSMI_BF16 path: halves their A-side traffic; the fp32 y stays the residual stream).
  * Dropout masks are a pure function of (seed + step_dev[0], site, element index): backward
  * regenerates them, nothing is stored.  step_dev (may be NULL) is a DEVICE int64 step counter so
  * that a captured hipGraph draws fresh masks on every replay.
@@ -133,12 +136,14 @@ int ttsmi_add_layernorm_fwd(const float* x, const float* res, const float* gamma
                             const float* beta, const float* pe, const float* pe_scale, int T,
                             const uint8_t* row_pad, float p_in, uint32_t site_in, float p_out,
                             uint32_t site_out, uint64_t seed, const int64_t* step_dev, float eps,
-                            float* y, float* mean, float* rstd, int M, int C,
+                            float* y, float* mean, float* rstd, int M, int C, uint16_t* y_bf16,
                             ttsmi_stream_t stream);
 /* dx (grad wrt x), dres (grad wrt res; may alias dx when p_in == 0; NULL if no res),
  * dgamma/dbeta [C], dpe_scale [1] (NULL if no pe).  relu_in != 0 additionally multiplies dx by
  * (x > 0) - the backward of the ReLU that produced x (predictor conv->relu->LN, layers.py:513).
- * y is the forward output (needed only when p_out > 0 is NOT needed - masks are regenerated). */
+ * Masks are regenerated, the forward output is not needed.
+ * dx_bf16 (may be NULL): dx stored as bf16; when given, dx itself may be NULL (in the dense blocks
+ * dx only feeds dgrad/wgrad GEMMs, the fp32 gradient stream continues through dres). */
 size_t ttsmi_add_layernorm_bwd_ws_bytes(int M, int C);
 int ttsmi_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
                             const float* mean, const float* rstd, const float* pe,
@@ -146,7 +151,7 @@ int ttsmi_add_layernorm_bwd(const float* dy, const float* x, const float* res, c
                             uint32_t site_in, float p_out, uint32_t site_out, uint64_t seed,
                             const int64_t* step_dev, int relu_in, float* dx, float* dres, float* dgamma, float* dbeta,
                             float* dpe_scale, int M, int C, void* ws, size_t ws_bytes,
-                            ttsmi_stream_t stream);
+                            uint16_t* dx_bf16, ttsmi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small element-wise / gather ops of ForwardTransformer.call (model/models.py:518-550)
@@ -242,7 +247,8 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
  * (Dense / Conv1D forward, dgrad, wgrad); the callers provide K-contiguous operands:
  *
  * ttsmi_hgemm_tn:  c[M,N] (+)= act( sum_k a[m,k] * b[n,k] + bias ) * (relu_src > 0)   (accumulate adds into c)
- *   a: fp32 [M,K] (a_is_f32, converted while staging; optional second K segment a2 from column K1;
+ *   a: fp32 [M,K] (a_is_f32, converted while staging; optional second K segment a2 (same element type
+ *      as a; bf16 needs K1 %% 64 == 0) from column K1;
  *      optional Conv1D window: conv_taps > 1 reads the contiguous window of conv_taps*conv_C values
  *      starting conv_pad frames before row m of a [B*conv_T, conv_C] activation, zero outside the
  *      sequence) or bf16 [M,K].   b: bf16 [N,K] - W^T for forward, W as stored for dgrad
@@ -284,7 +290,10 @@ typedef struct {
 } ttsmi_transpose_desc;
 int ttsmi_cast_transpose_bf16_batched(const ttsmi_transpose_desc* desc_dev, int n_desc, int total_tiles,
                                       ttsmi_stream_t stream);
-int ttsmi_conv_wdgrad_layout_bf16(const float* w, uint16_t* dst, int k, int Cin, int Cout,
+/* Conv1D dgrad operand: dst[ci][jp*cout_ld + co] = bf16(w[k-1-jp][ci][co]) (0 for Cout <= co < cout_ld);
+ * cout_ld > Cout pads an output-channel count that is not a multiple of 8 (predictor filters 226)
+ * so that the dgrad runs as a bf16 implicit GEMM over a zero-padded dy. */
+int ttsmi_conv_wdgrad_layout_bf16(const float* w, uint16_t* dst, int k, int Cin, int Cout, int cout_ld,
                                   ttsmi_stream_t stream);
 
 /* Utility: fp32 -> bf16 (round to nearest even) for the TTSMI_BF16 weight copies. */

@@ -41,10 +41,10 @@ SIGNATURES = {
                                 c_size_t, I, S]),
     'ttsmi_attention_weights': (I, [P, P, P, P, I, I, I, I, F, c_uint64, P, c_uint32, I, S]),
     'ttsmi_add_layernorm_fwd': (I, [P, P, P, P, P, P, I, P, F, c_uint32, F, c_uint32, c_uint64, P,
-                                    F, P, P, P, I, I, S]),
+                                    F, P, P, P, I, I, P, S]),
     'ttsmi_add_layernorm_bwd_ws_bytes': (c_size_t, [I, I]),
     'ttsmi_add_layernorm_bwd': (I, [P, P, P, P, P, P, P, P, I, P, F, c_uint32, F, c_uint32,
-                                    c_uint64, P, I, P, P, P, P, P, I, I, P, c_size_t, S]),
+                                    c_uint64, P, I, P, P, P, P, P, I, I, P, c_size_t, P, S]),
     'ttsmi_token_pad_mask': (I, [P, P, P, I, I, S]),
     'ttsmi_length_pad_mask': (I, [P, P, P, I, I, S]),
     'ttsmi_embedding_fwd': (I, [P, P, P, I, I, I, S]),
@@ -71,11 +71,11 @@ SIGNATURES = {
     'ttsmi_cast_transpose_bf16': (I, [P, L, P, L, I, I, I, I, I, S]),
     'ttsmi_hgemm_wgrad_rows_ws_bytes': (c_size_t, [I, I, I]),
     'ttsmi_hgemm_wgrad_rows': (I, [P, I, L, P, I, L, P, L, P, I, I, I, I, I, I, I, P, c_size_t, S]),
-    'ttsmi_conv_wdgrad_layout_bf16': (I, [P, P, I, I, I, S]),
+    'ttsmi_conv_wdgrad_layout_bf16': (I, [P, P, I, I, I, I, S]),
     'ttsmi_cast_transpose_bf16_batched': (I, [P, I, I, S]),
 }
 
-TTSMI_F32, TTSMI_BF16, TTSMI_BF16_QKV = 0, 1, 2
+TTSMI_F32, TTSMI_BF16, TTSMI_BF16_IO = 0, 1, 2
 
 _lib = None
 

@@ -504,9 +504,9 @@ extern "C" {
 int ttsmi_attention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
                         float* lse, int B, int H, int T, int dh, float p_drop, uint64_t seed,
                         const int64_t* step_dev, uint32_t site, int dtype, ttsmi_stream_t stream) {
-    if (dtype == TTSMI_BF16 || dtype == TTSMI_BF16_QKV)
+    if (dtype == TTSMI_BF16 || dtype == TTSMI_BF16_IO)
         return ttsmi_hattention_fwd(qkv, key_pad, klen, ctx, lse, B, H, T, dh, p_drop, seed, step_dev, site,
-                                    dtype == TTSMI_BF16_QKV, (hipStream_t)stream);
+                                    dtype == TTSMI_BF16_IO, (hipStream_t)stream);
     AttnP p;
     int rc = fill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, dtype, "attention_fwd");
     if (rc) return rc;
@@ -529,11 +529,11 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
                         int H, int T, int dh, float p_drop, uint64_t seed, const int64_t* step_dev,
                         uint32_t site, void* ws, size_t ws_bytes, int dtype,
                         ttsmi_stream_t stream) {
-    if (dtype == TTSMI_BF16 || dtype == TTSMI_BF16_QKV) {
+    if (dtype == TTSMI_BF16 || dtype == TTSMI_BF16_IO) {
         TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_attention_bwd_ws_bytes(B, H, T, dh),
                         "attention_bwd: workspace too small");
         return ttsmi_hattention_bwd(qkv, key_pad, klen, ctx, dctx, lse, dqkv, B, H, T, dh, p_drop, seed,
-                                    step_dev, site, ws, dtype == TTSMI_BF16_QKV, (hipStream_t)stream);
+                                    step_dev, site, ws, dtype == TTSMI_BF16_IO, (hipStream_t)stream);
     }
     AttnP p;
     int rc = fill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, dtype, "attention_bwd");

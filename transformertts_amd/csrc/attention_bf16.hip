@@ -1,5 +1,6 @@
 // TTSMI_BF16 fused self-attention: bf16 operands (Q, K, V, P, dO, dS rounded to nearest even),
-// fp32 accumulate on v_mfma_f32_32x32x16_bf16, fp32 softmax statistics, fp32 I/O in HBM.
+// fp32 accumulate on v_mfma_f32_32x32x16_bf16, fp32 softmax statistics; HBM I/O is fp32 (TTSMI_BF16) or
+// bf16 for every activation - qkv, ctx, dctx, dqkv - (TTSMI_BF16_IO; lse / delta stay fp32).
 // Same structure, masking rule, dropout stream and two-pass deterministic backward as the exact-fp32
 // kernels in attention.hip (see the header comment there); what changes is the operand plumbing and
 // the inner-loop diet (with bf16 MFMA a 32x32 score tile costs only 8 MFMAs = 256 cycles, so the
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
     int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
-    storeT16<DH>(patch, o, 1.0f / l, p.ctx + (long)b * p.T * d + h * DH, d, row0, nvalid, lane);
+    storeT16<DH, QH>(patch, o, 1.0f / l, const_cast<float*>(eptr<QH>(p.ctx, (long)b * p.T * d + h * DH)), d, row0,
+                     nvalid, lane);
 }
 
 // =================================================================================================
@@ -383,20 +385,32 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
     const float* Vb = eptr<QH>(Qb, 2 * d);
-    const float* dOb = p.dctx + (long)b * p.T * d + h * DH;
-    const float* Ob = p.octx + (long)b * p.T * d + h * DH;
+    const float* dOb = eptr<QH>(p.dctx, (long)b * p.T * d + h * DH);      // ctx / dctx share qkv's element type
+    const float* Ob = eptr<QH>(p.octx, (long)b * p.T * d + h * DH);
 
     bf16x8 qf[DH / 16], dof[DH / 16];
     frags_of<DH, QH>(Qb, p.ld, q, qok, hh, qf);
-    row_frags<DH>(dOb, d, q, qok, hh, dof);
-    float delta = 0.f;                         // rowsum(dO * O) in fp32 from the fp32 tensors
+    frags_of<DH, QH>(dOb, d, q, qok, hh, dof);
+    float delta = 0.f;                         // rowsum(dO * O), fp32 accumulate
     if (qok) {
-        const float* a = dOb + (long)q * d + hh * (DH / 2);
-        const float* c = Ob + (long)q * d + hh * (DH / 2);
+        if constexpr (QH) {
+            const uint16_t* a = reinterpret_cast<const uint16_t*>(dOb) + (long)q * d + hh * (DH / 2);
+            const uint16_t* c = reinterpret_cast<const uint16_t*>(Ob) + (long)q * d + hh * (DH / 2);
 #pragma unroll
-        for (int i = 0; i < DH / 8; ++i) {
-            float4 x = *reinterpret_cast<const float4*>(a + 4 * i), y = *reinterpret_cast<const float4*>(c + 4 * i);
-            delta += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+            for (int i = 0; i < DH / 16; ++i) {
+                uint4 xa = *reinterpret_cast<const uint4*>(a + 8 * i), ya = *reinterpret_cast<const uint4*>(c + 8 * i);
+                bf16x8 x = *reinterpret_cast<bf16x8*>(&xa), y = *reinterpret_cast<bf16x8*>(&ya);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) delta += (float)x[e] * (float)y[e];
+            }
+        } else {
+            const float* a = dOb + (long)q * d + hh * (DH / 2);
+            const float* c = Ob + (long)q * d + hh * (DH / 2);
+#pragma unroll
+            for (int i = 0; i < DH / 8; ++i) {
+                float4 x = *reinterpret_cast<const float4*>(a + 4 * i), y = *reinterpret_cast<const float4*>(c + 4 * i);
+                delta += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+            }
         }
     }
     delta += __shfl_xor(delta, 32, 64);
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
     const float* Vb = eptr<QH>(Qb, 2 * d);
-    const float* dOb = p.dctx + (long)b * p.T * d + h * DH;
+    const float* dOb = eptr<QH>(p.dctx, (long)b * p.T * d + h * DH);
 
     bf16x8 kf[DH / 16], vf[DH / 16];
     frags_of<DH, QH>(Kb, p.ld, key, kok, hh, kf);
@@ -527,13 +541,12 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
 
     const bool wg_active = bx * 128 < klen;
     if (wg_active) {
-        Tile<DH, QH> rq;
-        float4 ro[DH / 16];
+        Tile<DH, QH> rq, ro;
         float rl = 0.f, rd = 0.f;
         {
             int nv = min(HKT, p.T);
             rq.fetch(Qb, p.ld, 0, nv, tid);
-            rows_fetch<DH>(dOb, d, 0, nv, tid, ro);
+            ro.fetch(dOb, d, 0, nv, tid);
             if (tid < HKT) {
                 rl = tid < nv ? p.lse[stat0 + tid] * LOG2E : INFINITY;
                 rd = tid < nv ? p.delta[stat0 + tid] : 0.f;
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
         for (int q0 = 0; q0 < p.T; q0 += HKT) {
             __syncthreads();
             rq.stash(Qs, tid);
-            rows_stash<DH>(Os, tid, ro);
+            ro.stash(Os, tid);
             if (tid < HKT) {
                 lseS[tid] = rl;
                 delS[tid] = rd;
@@ -554,7 +567,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
             if (q0 + HKT < p.T) {
                 int nv = min(HKT, p.T - (q0 + HKT));
                 rq.fetch(Qb, p.ld, q0 + HKT, nv, tid);
-                rows_fetch<DH>(dOb, d, q0 + HKT, nv, tid, ro);
+                ro.fetch(dOb, d, q0 + HKT, nv, tid);
                 if (tid < HKT) {
                     rl = tid < nv ? p.lse[stat0 + q0 + HKT + tid] * LOG2E : INFINITY;
                     rd = tid < nv ? p.delta[stat0 + q0 + HKT + tid] : 0.f;

@@ -142,9 +142,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
     float4 ra[BM / 16];   // fp32-A prefetch registers (dead in the bf16-A instantiation)
     uint4 rah[BM / 32];   // bf16-A prefetch registers (dead in the fp32-A instantiation)
     uint4 rb[HBN_ / 32];
+    // bf16 A with a second K segment (concat([q_in, ctx]) . W): K1 is a multiple of the k-step, so a
+    // step lies wholly inside one segment
+    auto fetch_a_h = [&](int k0) {
+        if (p.A2 != nullptr && k0 >= p.K1)
+            fetch_h<BM>((const uint16_t*)p.A2, p.lda2, p.M, m0, k0 - p.K1, kend - p.K1, tid, rah);
+        else
+            fetch_h<BM>((const uint16_t*)p.A, p.lda, p.M, m0, k0, p.A2 != nullptr ? min(kend, p.K1) : kend, tid, rah);
+    };
     if (kbeg < kend) {
         if constexpr (A_F32) fetch_a_f32<BM>(p, m0, kbeg, kend, tid, ra);
-        else fetch_h<BM>((const uint16_t*)p.A, p.lda, p.M, m0, kbeg, kend, tid, rah);
+        else fetch_a_h(kbeg);
         fetch_h<HBN_>(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
         if constexpr (A_F32) stash_a_f32<BM>(As, tid, ra); else stash_h<BM>(As, tid, rah);
         stash_h<HBN_>(Bs, tid, rb);
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
         const bool more = (k0 + HBK_) < kend;
         if (more) {
             if constexpr (A_F32) fetch_a_f32<BM>(p, m0, k0 + HBK_, kend, tid, ra);
-            else fetch_h<BM>((const uint16_t*)p.A, p.lda, p.M, m0, k0 + HBK_, kend, tid, rah);
+            else fetch_a_h(k0 + HBK_);
             fetch_h<HBN_>(p.B, p.ldb, p.N, n0, k0 + HBK_, kend, tid, rb);
         }
         if (do_colsum) {                       // bias gradient from the dy^T tile (wgrad)
@@ -646,13 +654,13 @@ __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const ttsmi
 // dst[ci][j'*Cout + co] = w[k-1-j'][ci][co]
 __global__ __launch_bounds__(256) void conv_wdgrad_layout_kernel(const float* __restrict__ w,
                                                                  uint16_t* __restrict__ dst, int k,
-                                                                 int Cin, int Cout) {
-    long n = (long)k * Cin * Cout;
+                                                                 int Cin, int Cout, int CoutP) {
+    long n = (long)k * Cin * CoutP;           // CoutP >= Cout: per-tap column count of dst, zero filled
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        int co = (int)(i % Cout);
-        long t = i / Cout;
+        int co = (int)(i % CoutP);
+        long t = i / CoutP;
         int jp = (int)(t % k), ci = (int)(t / k);
-        __bf16 h = (__bf16)w[((long)(k - 1 - jp) * Cin + ci) * Cout + co];
+        __bf16 h = (__bf16)(co < Cout ? w[((long)(k - 1 - jp) * Cin + ci) * Cout + co] : 0.f);
         dst[i] = *reinterpret_cast<uint16_t*>(&h);
     }
 }
@@ -665,7 +673,7 @@ static void hinit(HGemmP& p) {
     p.a_taps = 1;
 }
 
-static int hgemm_bm(bool a_f32) {
+static int hgemm_bm(bool a_f32, int M, int N, int splits) {
     // tuning knob (measurement only): TTSMI_HGEMM_BM=64|128 overrides the default tile height
     static int forced = -1;
     if (forced < 0) {
@@ -673,11 +681,15 @@ static int hgemm_bm(bool a_f32) {
         forced = e ? atoi(e) : 0;
     }
     if (forced == 64 || forced == 128) return forced;
-    return a_f32 ? 64 : 128;
+    if (a_f32) return 64;
+    // bf16 A: 128-row tiles halve the B re-reads, but a launch that cannot give every CU a workgroup
+    // (encoder-side M = 6400) is latency bound per workgroup: take the 64-row tile, twice the workgroups
+    const long wgs128 = (long)ttsmi_cdiv(M, 128) * ttsmi_cdiv(N, HBN_) * splits;
+    return wgs128 < 256 ? 64 : 128;
 }
 
 static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char* name) {
-    const int bm = hgemm_bm(a_f32);
+    const int bm = hgemm_bm(a_f32, p.M, p.N, splits);
     p.tiles_m = ttsmi_cdiv(p.M, bm);
     p.tiles_n = ttsmi_cdiv(p.N, HBN_);
     dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
@@ -724,7 +736,8 @@ int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int
     TTSMI_CHECK_ARG(al16(a) && al16(b) && (K % 8 == 0) && (ldb % 8 == 0),
                     "hgemm_tn: operands must be 16-byte aligned with K %% 8 == 0 (K=%d ldb=%ld)", K, (long)ldb);
     if (a_is_f32) TTSMI_CHECK_ARG(lda % 4 == 0, "hgemm_tn: lda %% 4 != 0");
-    else TTSMI_CHECK_ARG(lda % 8 == 0 && !a2 && conv_taps <= 1, "hgemm_tn: bf16 A needs lda %% 8 == 0, no A2/conv");
+    else TTSMI_CHECK_ARG(lda % 8 == 0 && conv_taps <= 1 && (!a2 || (K1 % HBK_ == 0 && lda2 % 8 == 0)),
+                         "hgemm_tn: bf16 A needs lda %% 8 == 0, no conv window, A2 (bf16 too) with K1 %% 64 == 0");
     if (a2) TTSMI_CHECK_ARG(K1 > 0 && K1 < K && K1 % 8 == 0 && al16(a2) && lda2 % 4 == 0, "hgemm_tn: bad A2 segment");
     if (conv_taps > 1) TTSMI_CHECK_ARG(conv_C % 4 == 0 && conv_T > 0 && K == conv_taps * conv_C, "hgemm_tn: bad conv window");
     HGemmP p;
@@ -841,14 +854,15 @@ int ttsmi_cast_transpose_bf16_batched(const ttsmi_transpose_desc* desc_dev, int 
     return TTSMI_OK;
 }
 
-int ttsmi_conv_wdgrad_layout_bf16(const float* w, uint16_t* dst, int k, int Cin, int Cout,
+int ttsmi_conv_wdgrad_layout_bf16(const float* w, uint16_t* dst, int k, int Cin, int Cout, int cout_ld,
                                   ttsmi_stream_t stream) {
-    TTSMI_CHECK_ARG(w && dst && k > 0 && Cin > 0 && Cout > 0, "conv_wdgrad_layout_bf16: bad argument");
-    long n = (long)k * Cin * Cout;
+    TTSMI_CHECK_ARG(w && dst && k > 0 && Cin > 0 && Cout > 0 && cout_ld >= Cout,
+                    "conv_wdgrad_layout_bf16: bad argument");
+    long n = (long)k * Cin * cout_ld;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(conv_wdgrad_layout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, dst, k,
-                       Cin, Cout);
+                       Cin, Cout, cout_ld);
     TTSMI_CHECK_LAUNCH("conv_wdgrad_layout_bf16");
     return TTSMI_OK;
 }

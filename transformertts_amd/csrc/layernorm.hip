@@ -28,6 +28,19 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[VW]) {
     }
 }
 
+typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
+template <int VW>
+__device__ __forceinline__ void sth(uint16_t* p, const float (&v)[VW]) {
+    if constexpr (VW == 4) {
+        ln_bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        *reinterpret_cast<uint2*>(p) = *reinterpret_cast<uint2*>(&h);
+    } else {
+        __bf16 h = (__bf16)v[0];
+        *p = *reinterpret_cast<uint16_t*>(&h);
+    }
+}
+
 struct LnP {
     const float* x; const float* res; const float* gamma; const float* beta;
     const float* pe; const float* pe_scale; int T;
@@ -35,11 +48,13 @@ struct LnP {
     uint32_t thr_in, thr_out, site_in, site_out; float inv_in, inv_out; uint64_t seed; const int64_t* step_dev;
     float eps;
     float* y; float* mean; float* rstd;
+    uint16_t* y_h;          // optional bf16 copy of y (the GEMM operand of the consumers)
     int M, C;
     // backward
     const float* dy; const float* mean_in; const float* rstd_in;
     int relu_in;
     float* dx; float* dres;
+    uint16_t* dx_h;         // optional bf16 dx (dx itself may then be NULL: its consumers are GEMMs)
     float* part_g; float* part_b; float* part_s;   // [nwaves][C], [nwaves][C], [nwaves]
 };
 
@@ -119,6 +134,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
                 for (int e = 0; e < VW; ++e) o[e] = 0.f;
             }
             stv<VW>(p.y + base + c, o);
+            if (p.y_h) sth<VW>(p.y_h + base + c, o);
         }
     }
 }
@@ -210,21 +226,51 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
                     dxv[e] = dz[e] * keep[j][e];
                 }
                 if (p.dres && p.dres != p.dx) stv<VW>(p.dres + base + c, dz);
-                stv<VW>(p.dx + base + c, dxv);
+                if (p.dx) stv<VW>(p.dx + base + c, dxv);
+                if (p.dx_h) sth<VW>(p.dx_h + base + c, dxv);
             }
         }
     }
-    // per-wave partials of the parameter gradients
+    // parameter-gradient partials: the block's 4 waves are summed through LDS in wave order, so the
+    // reduce kernel reads one partial row per block instead of one per wave
+    __shared__ float red[LN_WAVES - 1][2][NPL * 64 * VW];
+    const int w = threadIdx.x >> 6;
+    if (w > 0) {
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        int c = (lane + 64 * j) * VW;
-        if (c < p.C) {
-            stv<VW>(p.part_g + (long)wave_g * p.C + c, ag[j]);
-            stv<VW>(p.part_b + (long)wave_g * p.C + c, ab[j]);
-        }
+        for (int j = 0; j < NPL; ++j)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                red[w - 1][0][(lane + 64 * j) * VW + e] = ag[j][e];
+                red[w - 1][1][(lane + 64 * j) * VW + e] = ab[j][e];
+            }
     }
     as = wave_sum(as);
-    if (lane == 0) p.part_s[wave_g] = as;
+    __shared__ float red_s[LN_WAVES];
+    if (lane == 0) red_s[w] = as;
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            int c = (lane + 64 * j) * VW;
+#pragma unroll
+            for (int u = 0; u < LN_WAVES - 1; ++u)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    ag[j][e] += red[u][0][c + e];
+                    ab[j][e] += red[u][1][c + e];
+                }
+            if (c < p.C) {
+                stv<VW>(p.part_g + (long)blockIdx.x * p.C + c, ag[j]);
+                stv<VW>(p.part_b + (long)blockIdx.x * p.C + c, ab[j]);
+            }
+        }
+        if (lane == 0) {
+            float t = red_s[0];
+#pragma unroll
+            for (int u = 1; u < LN_WAVES; ++u) t += red_s[u];
+            p.part_s[blockIdx.x] = t;
+        }
+    }
 }
 
 // out[c] = sum_w part[w][c]: block = 16 columns x 16 row-lanes (64 B segments per row-lane), so a
@@ -239,7 +285,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
     const int c = blockIdx.x * 16 + cl;
     float sg = 0.f, sb = 0.f;
     if (c < C) {
-#pragma unroll 4
+#pragma unroll 8
         for (int w = rl; w < nw; w += 16) {
             sg += part_g[(long)w * C + c];
             sb += part_b[(long)w * C + c];
@@ -320,7 +366,7 @@ int ttsmi_add_layernorm_fwd(const float* x, const float* res, const float* gamma
                             const uint8_t* row_pad, float p_in, uint32_t site_in, float p_out,
                             uint32_t site_out, uint64_t seed, const int64_t* step_dev, float eps,
                             float* y, float* mean,
-                            float* rstd, int M, int C, ttsmi_stream_t stream) {
+                            float* rstd, int M, int C, uint16_t* y_bf16, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(x && gamma && beta && y && mean && rstd, "add_layernorm_fwd: null pointer");
     TTSMI_CHECK_ARG(M >= 0 && C > 0, "add_layernorm_fwd: bad shape M=%d C=%d", M, C);
     TTSMI_CHECK_ARG(!pe || (pe_scale && T > 0), "add_layernorm_fwd: pe needs pe_scale and T");
@@ -331,6 +377,7 @@ int ttsmi_add_layernorm_fwd(const float* x, const float* res, const float* gamma
     memset(&p, 0, sizeof(p));
     p.x = x; p.res = res; p.gamma = gamma; p.beta = beta; p.pe = pe; p.pe_scale = pe_scale; p.T = T;
     p.row_pad = row_pad; p.eps = eps; p.y = y; p.mean = mean; p.rstd = rstd; p.M = M; p.C = C;
+    p.y_h = y_bf16;
     set_drop(p, p_in, site_in, p_out, site_out, seed, step_dev);
     int rc = dispatch<true>(p, (hipStream_t)stream);
     if (rc) { ttsmi_set_error("add_layernorm_fwd: C=%d too wide", C); return rc; }
@@ -339,7 +386,7 @@ int ttsmi_add_layernorm_fwd(const float* x, const float* res, const float* gamma
 }
 
 size_t ttsmi_add_layernorm_bwd_ws_bytes(int M, int C) {
-    size_t nw = (size_t)ln_bwd_blocks(M) * LN_WAVES;
+    size_t nw = (size_t)ln_bwd_blocks(M);
     return (2 * nw * (size_t)C + nw) * sizeof(float) + 256;
 }
 
@@ -349,23 +396,23 @@ int ttsmi_add_layernorm_bwd(const float* dy, const float* x, const float* res, c
                             uint32_t site_in, float p_out, uint32_t site_out, uint64_t seed,
                             const int64_t* step_dev, int relu_in, float* dx, float* dres, float* dgamma, float* dbeta,
                             float* dpe_scale, int M, int C, void* ws, size_t ws_bytes,
-                            ttsmi_stream_t stream) {
-    TTSMI_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta,
+                            uint16_t* dx_bf16, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(dy && x && gamma && mean && rstd && (dx || dx_bf16) && dgamma && dbeta,
                     "add_layernorm_bwd: null pointer");
     TTSMI_CHECK_ARG(M > 0 && C > 0, "add_layernorm_bwd: bad shape");
     TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_add_layernorm_bwd_ws_bytes(M, C),
                     "add_layernorm_bwd: workspace too small");
     TTSMI_CHECK_ARG(!(res && !dres), "add_layernorm_bwd: res given but dres is NULL");
-    TTSMI_CHECK_ARG(!(dres == dx && (p_in > 0.f || relu_in)),
+    TTSMI_CHECK_ARG(!(res && dres == dx && (p_in > 0.f || relu_in)),
                     "add_layernorm_bwd: dres may alias dx only when p_in == 0 and !relu_in");
     LnP p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.res = res; p.gamma = gamma; p.pe = pe; p.pe_scale = pe_scale; p.T = T;
     p.row_pad = row_pad; p.M = M; p.C = C;
     p.dy = dy; p.mean_in = mean; p.rstd_in = rstd; p.relu_in = relu_in;
-    p.dx = dx; p.dres = res ? dres : nullptr;
+    p.dx = dx; p.dres = res ? dres : nullptr; p.dx_h = dx_bf16;
     set_drop(p, p_in, site_in, p_out, site_out, seed, step_dev);
-    size_t nw = (size_t)ln_bwd_blocks(M) * LN_WAVES;
+    size_t nw = (size_t)ln_bwd_blocks(M);
     p.part_g = (float*)ws;
     p.part_b = p.part_g + nw * C;
     p.part_s = p.part_b + nw * C;

@@ -312,6 +312,7 @@ class ForwardTransformer:
                               p_out=rate, site_out=drop.site(), drop=drop)
         attn = OrderedDict()
         dtype = ops._lib.TTSMI_BF16 if self.precision == 'bf16' else ops.TTSMI_F32
+        h_bf = None                      # bf16 copy of h written by the previous block's LayerNorm (TTSMI_BF16)
         for i, H in enumerate(heads):
             p = f'{prefix}.blk{i}'
             dense = i < dense_blocks
@@ -319,12 +320,15 @@ class ForwardTransformer:
                 # one autograd node per block (ops.DenseBlockFn); sites in the per-layer order
                 Pb, Gb, Sb = self._block_views(p)
                 sites = (drop.site(), drop.site(), drop.site())
-                h, qkv, lse = ops.DenseBlockFn.apply(h, Pb, Gb, Sb, pad, klen, B, H, T, rate, drop, sites, dtype,
-                                                     want_attn)
+                h, h_bf, qkv, lse = ops.DenseBlockFn.apply(h, h_bf, Pb, Gb, Sb, pad, klen, B, H, T, rate, drop, sites,
+                                                           dtype, want_attn)
+                if h_bf.numel() == 0:
+                    h_bf = None
                 if want_attn:
                     attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
                         qkv.float() if qkv.dtype != torch.float32 else qkv, pad, lse, B, H, T, d // H, rate, drop, sites[0])
                 continue
+            h_bf = None
             qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'],
                                      S(f'{p}.wqkv'))
             site = drop.site()

@@ -188,7 +188,7 @@ class Shadow:
     """bf16 copies of one GEMM weight for the TTSMI_BF16 path, refreshed after every optimiser step:
       wb  - the weight as stored, bf16 ([K,N] Dense; dgrad reads its rows as K-contiguous operands)
       wt  - its transpose, bf16 ([N,K] Dense / [Cout, k*Cin] Conv1D; the forward B operand)
-      wd  - Conv1D only: dgrad operand [Cin, k*Cout] with flipped taps."""
+      wd  - Conv1D only: dgrad operand [Cin, k*pad8(Cout)] with flipped taps (zero pad columns)."""
     __slots__ = ('wb', 'wt', 'wd')
 
     def __init__(self, wb=None, wt=None, wd=None):
@@ -239,10 +239,16 @@ def hgemm_wgrad(xT, dyT, dw, db, rows):
                               ws.numel(), _stream()), 'hgemm_wgrad')
 
 
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
 def conv_wdgrad_layout_bf16(w):
+    """[Cin, k*pad8(Cout)] bf16 dgrad operand of a Conv1D weight [k, Cin, Cout] (zero pad columns)."""
     k, cin, cout = w.shape
-    dst = torch.empty((cin, k * cout), dtype=torch.bfloat16, device=w.device)
-    check(_lib.lib().ttsmi_conv_wdgrad_layout_bf16(_p(w), _p(dst), k, cin, cout, _stream()), 'conv_wdgrad_layout')
+    dst = torch.empty((cin, k * _pad8(cout)), dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().ttsmi_conv_wdgrad_layout_bf16(_p(w), _p(dst), k, cin, cout, _pad8(cout), _stream()),
+          'conv_wdgrad_layout')
     return dst
 
 
@@ -271,7 +277,8 @@ def refresh_shadow(sh, w):
         k, cin, cout = wf.shape
         check(l.ttsmi_cast_transpose_bf16(_p(wf), cout, _p(sh.wt), sh.wt.stride(0), k * cin, cout, 1, 0, 0,
                                           _stream()), 'cast_transpose_bf16')
-        check(l.ttsmi_conv_wdgrad_layout_bf16(_p(wf), _p(sh.wd), k, cin, cout, _stream()), 'conv_wdgrad_layout')
+        check(l.ttsmi_conv_wdgrad_layout_bf16(_p(wf), _p(sh.wd), k, cin, cout, _pad8(cout), _stream()),
+              'conv_wdgrad_layout')
 
 
 class ShadowSet:
@@ -304,7 +311,7 @@ class ShadowSet:
             else:
                 k, cin, cout = w.shape
                 wt = torch.empty((cout, k * cin), dtype=torch.bfloat16, device=dev)
-                wd = torch.empty((cin, k * cout), dtype=torch.bfloat16, device=dev)
+                wd = torch.empty((cin, k * _pad8(cout)), dtype=torch.bfloat16, device=dev)
                 self.sh[name] = Shadow(wt=wt, wd=wd)
                 self._conv.append((w, wd))
                 R, C = k * cin, cout
@@ -329,7 +336,8 @@ class ShadowSet:
                   'cast_transpose_bf16_batched')
         for w, wd in self._conv:
             k, cin, cout = w.shape
-            check(l.ttsmi_conv_wdgrad_layout_bf16(_p(w), _p(wd), k, cin, cout, _stream()), 'conv_wdgrad_layout')
+            check(l.ttsmi_conv_wdgrad_layout_bf16(_p(w), _p(wd), k, cin, cout, _pad8(cout), _stream()),
+                  'conv_wdgrad_layout')
 
 
 # ---- precision-dispatching wrappers: sh is None -> exact-fp32 MFMA kernels ------------------------
@@ -546,7 +554,7 @@ class AddLayerNormFn(torch.autograd.Function):
         check(_lib.lib().ttsmi_add_layernorm_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(pe), _p(pe_scale),
                                                  int(T), _p(row_pad), float(p_in), int(site_in), float(p_out),
                                                  int(site_out), seed, _p(step_dev), LN_EPS, _p(y), _p(mean),
-                                                 _p(rstd), M, C, _stream()), 'add_layernorm_fwd')
+                                                 _p(rstd), M, C, None, _stream()), 'add_layernorm_fwd')
         ctx.save_for_backward(x, res, gamma, mean, rstd, pe, pe_scale, row_pad, step_dev)
         ctx.cfg = (int(T), float(p_in), int(site_in), float(p_out), int(site_out), seed, bool(relu_in), M, C)
         ctx.sinks = (ggamma, gbeta, gpe_scale)
@@ -574,7 +582,7 @@ class AddLayerNormFn(torch.autograd.Function):
         check(l.ttsmi_add_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(pe),
                                         _p(pe_scale), T, _p(row_pad), p_in, site_in, p_out, site_out, seed,
                                         _p(step_dev), int(relu_in), _p(dx), _p(dres), _p(dgamma), _p(dbeta),
-                                        _p(dps), M, C, _p(ws), ws.numel(), _stream()), 'add_layernorm_bwd')
+                                        _p(dps), M, C, _p(ws), ws.numel(), None, _stream()), 'add_layernorm_bwd')
         n = lambda g, d: None if g is not None else d
         dps_out = None
         if pe is not None and gpe is None:
@@ -829,8 +837,11 @@ class ConvReluPreMaskedFn(torch.autograd.Function):
             conv1d_wgrad(x, dh, dw, db)
         dx = None
         if ctx.needs_input_grad[0]:
-            if sh is not None and Cout % 8 == 0:
-                dx = hgemm_tn(dh.reshape(B * T, Cout), sh.wd, conv=(k, T, Cout, k - 1 - (k - 1) // 2)).reshape(B, T, Cin)
+            if sh is not None:
+                dh2, Cp = dh.reshape(B * T, Cout), _pad8(Cout)
+                if Cp != Cout:             # filters 226: zero-pad dy to 232 columns, wd is laid out to match
+                    dh2 = torch.nn.functional.pad(dh2, (0, Cp - Cout))
+                dx = hgemm_tn(dh2, sh.wd, conv=(k, T, Cp, k - 1 - (k - 1) // 2)).reshape(B, T, Cin)
             else:
                 dx = conv1d_dgrad(dh, w)
         return dx, (None if gw is not None else dw), (None if gb is not None else db), None, None, None
@@ -839,29 +850,47 @@ class ConvReluPreMaskedFn(torch.autograd.Function):
 # =================================================================================================
 # One autograd node per SelfAttentionDenseBlock (model/layers.py:214-230)
 # =================================================================================================
-def _ln_fwd(x, res, gamma, beta, row_pad, p_in, site_in, drop):
+def to_bf16(t):
+    """bf16 copy of an fp32 tensor (one streaming kernel)."""
+    t = _c(t)
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    check(_lib.lib().ttsmi_cast_f32_to_bf16(_p(t), _p(out), t.numel(), _stream()), 'cast_f32_to_bf16')
+    return out
+
+
+def _ln_fwd(x, res, gamma, beta, row_pad, p_in, site_in, drop, want_h=False):
+    """Returns (y, y_bf16 or None, mean, rstd)."""
     M, C = x.shape
     y = torch.empty_like(x)
+    y_h = torch.empty((M, C), dtype=torch.bfloat16, device=x.device) if want_h else None
     mean = torch.empty((M,), dtype=torch.float32, device=x.device)
     rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
     check(_lib.lib().ttsmi_add_layernorm_fwd(_p(x), _p(res), _p(gamma), _p(beta), None, None, 0, _p(row_pad),
                                              float(p_in), int(site_in), 0.0, 0, drop.seed, _p(drop.step_dev),
-                                             LN_EPS, _p(y), _p(mean), _p(rstd), M, C, _stream()), 'add_layernorm_fwd')
-    return y, mean, rstd
+                                             LN_EPS, _p(y), _p(mean), _p(rstd), M, C, _p(y_h), _stream()),
+          'add_layernorm_fwd')
+    return y, y_h, mean, rstd
 
 
-def _ln_bwd(dy, x, res, gamma, mean, rstd, row_pad, p_in, site_in, drop, dgamma, dbeta):
-    """Returns (dx, dres); dres aliases dx when the x branch has no dropout."""
+def _ln_bwd(dy, x, res, gamma, mean, rstd, row_pad, p_in, site_in, drop, dgamma, dbeta, dx_bf16=False):
+    """Returns (dx, dres); dres aliases dx when the x branch has no dropout.  dx_bf16: dx comes back
+    as bf16 (it only feeds GEMMs); the fp32 dx is then written only where dres has to alias it."""
     M, C = x.shape
-    dx = torch.empty_like(x)
-    dres = torch.empty_like(x) if p_in > 0 else dx
+    if dx_bf16:
+        dx_h = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
+        dres = torch.empty_like(x)
+        dx = None if p_in > 0 else dres
+    else:
+        dx_h = None
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if p_in > 0 else dx
     l = _lib.lib()
     ws = _ws(l.ttsmi_add_layernorm_bwd_ws_bytes(M, C), x.device)
     check(l.ttsmi_add_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), None, None, 0,
                                     _p(row_pad), float(p_in), int(site_in), 0.0, 0, drop.seed, _p(drop.step_dev),
                                     0, _p(dx), _p(dres), _p(dgamma), _p(dbeta), None, M, C, _p(ws), ws.numel(),
-                                    _stream()), 'add_layernorm_bwd')
-    return dx, dres
+                                    _p(dx_h), _stream()), 'add_layernorm_bwd')
+    return (dx_h if dx_bf16 else dx), dres
 
 
 class DenseBlockFn(torch.autograd.Function):
@@ -877,64 +906,95 @@ class DenseBlockFn(torch.autograd.Function):
     gradient buffer), S = dict of bf16 shadows (empty for the fp32 path)."""
 
     @staticmethod
-    def forward(ctx, h, P, G, S, pad, klen, B, H, T, rate, drop, sites, dtype, want_lse):
+    def forward(ctx, h, h_bf, P, G, S, pad, klen, B, H, T, rate, drop, sites, dtype, want_lse):
         h = _c(h)
         M, d = h.shape
         dh_ = d // H
+        F = P['ffn.w1'].shape[1]
         if dtype != TTSMI_F32 and dh_ not in (32, 64):
             dtype = TTSMI_F32
-        shq = S.get('wqkv')
-        if shq is not None and dtype != TTSMI_F32 and d % 8 == 0:
-            # TTSMI_BF16: qkv (and dqkv in backward) are pure GEMM / attention operands: keep them in bf16
-            qkv = hgemm_tn(h, shq.wt, P['bqkv'], out_bf16=True)
-            dtype = _lib.TTSMI_BF16_QKV
+        all_h = (dtype != TTSMI_F32 and all(S.get(k) is not None for k in ('wqkv', 'wo', 'ffn.w1', 'ffn.w2'))
+                 and d % 64 == 0 and F % 8 == 0)
+        if all_h:
+            # TTSMI_BF16: every tensor that is only a GEMM / attention operand lives in HBM as bf16 (qkv, ctx,
+            # the FFN hidden h1, and in backward df, do, dctx, dqkv, dh1); the residual stream (h, o, a, f, and
+            # the gradients da, dh) stays fp32, and LayerNorm emits a bf16 copy of its output for the GEMMs.
+            if h_bf is None:
+                h_bf = to_bf16(h)
+            qkv = hgemm_tn(h_bf, S['wqkv'].wt, P['bqkv'], out_bf16=True)
+            dtype = _lib.TTSMI_BF16_IO
+            cx = torch.empty((M, d), dtype=torch.bfloat16, device=h.device)
         else:
-            qkv = dense_fwd(h, P['wqkv'], P['bqkv'], False, None, shq)
-        cx = torch.empty((M, d), dtype=torch.float32, device=h.device)
+            h_bf = None
+            qkv = dense_fwd(h, P['wqkv'], P['bqkv'], False, None, S.get('wqkv'))
+            cx = torch.empty((M, d), dtype=torch.float32, device=h.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=h.device)
         check(_lib.lib().ttsmi_attention_fwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(lse), B, H, T, dh_, float(rate),
                                              drop.seed, _p(drop.step_dev), sites[0], int(dtype), _stream()),
               'attention_fwd')
-        o = dense_fwd(h, P['wo'], P['bo'], False, cx, S.get('wo'))
-        a, mean1, rstd1 = _ln_fwd(o, h, P['ln1.gamma'], P['ln1.beta'], pad, rate, sites[1], drop)
-        s1, s2 = S.get('ffn.w1'), S.get('ffn.w2')
-        F = P['ffn.w1'].shape[1]
-        if s1 is not None and s2 is not None and d % 8 == 0 and F % 8 == 0:
-            # TTSMI_BF16: the FFN hidden activation (the largest tensor of the block, M x F) and its
-            # gradient exist only as bf16 - they are GEMM operands and nothing else
-            h1 = hgemm_tn(a, s1.wt, P['ffn.b1'], relu=True, out_bf16=True)
-            f = hgemm_tn(h1, s2.wt, P['ffn.b2'])
+        if all_h:
+            o = hgemm_tn(h_bf, S['wo'].wt, P['bo'], a2=cx)
+            a, a_bf, mean1, rstd1 = _ln_fwd(o, h, P['ln1.gamma'], P['ln1.beta'], pad, rate, sites[1], drop, True)
+            h1 = hgemm_tn(a_bf, S['ffn.w1'].wt, P['ffn.b1'], relu=True, out_bf16=True)
+            f = hgemm_tn(h1, S['ffn.w2'].wt, P['ffn.b2'])
+            out, out_bf, mean2, rstd2 = _ln_fwd(f, a, P['ln2.gamma'], P['ln2.beta'], pad, rate, sites[2], drop, True)
         else:
-            h1 = dense_fwd(a, P['ffn.w1'], P['ffn.b1'], True, None, s1)
-            f = dense_fwd(h1, P['ffn.w2'], P['ffn.b2'], False, None, s2)
-        out, mean2, rstd2 = _ln_fwd(f, a, P['ln2.gamma'], P['ln2.beta'], pad, rate, sites[2], drop)
-        ctx.save_for_backward(h, qkv, cx, lse, o, a, h1, f, mean1, rstd1, mean2, rstd2, pad, klen)
-        ctx.cfg = (P, G, S, B, H, T, dh_, float(rate), drop, sites, int(dtype))
-        ctx.mark_non_differentiable(qkv, lse)
-        return out, qkv, lse
+            o = dense_fwd(h, P['wo'], P['bo'], False, cx, S.get('wo'))
+            a, a_bf, mean1, rstd1 = _ln_fwd(o, h, P['ln1.gamma'], P['ln1.beta'], pad, rate, sites[1], drop)
+            h1 = dense_fwd(a, P['ffn.w1'], P['ffn.b1'], True, None, S.get('ffn.w1'))
+            f = dense_fwd(h1, P['ffn.w2'], P['ffn.b2'], False, None, S.get('ffn.w2'))
+            out, out_bf, mean2, rstd2 = _ln_fwd(f, a, P['ln2.gamma'], P['ln2.beta'], pad, rate, sites[2], drop)
+        ctx.save_for_backward(h, h_bf, qkv, cx, lse, o, a, a_bf, h1, f, mean1, rstd1, mean2, rstd2, pad, klen)
+        ctx.cfg = (P, G, S, B, H, T, dh_, float(rate), drop, sites, int(dtype), all_h)
+        if out_bf is None:
+            out_bf = out.new_empty(0)
+        ctx.mark_non_differentiable(out_bf, qkv, lse)
+        return out, out_bf, qkv, lse
 
     @staticmethod
-    def backward(ctx, dout, _dqkv, _dlse):
-        h, qkv, cx, lse, o, a, h1, f, mean1, rstd1, mean2, rstd2, pad, klen = ctx.saved_tensors
-        P, G, S, B, H, T, dh_, rate, drop, sites, dtype = ctx.cfg
+    def backward(ctx, dout, _dout_bf, _dqkv, _dlse):
+        h, h_bf, qkv, cx, lse, o, a, a_bf, h1, f, mean1, rstd1, mean2, rstd2, pad, klen = ctx.saved_tensors
+        P, G, S, B, H, T, dh_, rate, drop, sites, dtype, all_h = ctx.cfg
         d = h.shape[1]
         dout = _c(dout)
+        l = _lib.lib()
+        if all_h:
+            s1, s2, sho, shq = S['ffn.w1'], S['ffn.w2'], S['wo'], S['wqkv']
+            # ---- LN2 + FFN ---------------------------------------------------------------------
+            df, da = _ln_bwd(dout, f, a, P['ln2.gamma'], mean2, rstd2, pad, rate, sites[2], drop,
+                             G['ln2.gamma'], G['ln2.beta'], dx_bf16=True)
+            _on_wgrad_stream(lambda: hgemm_wgrad_rows(h1, df, G['ffn.w2'], G['ffn.b2']), h1, df)
+            dh1 = hgemm_tn(df, s2.wb, relu_src=h1, out_bf16=True)                            # relu' fused, bf16 out
+            _on_wgrad_stream(lambda: hgemm_wgrad_rows(a_bf, dh1, G['ffn.w1'], G['ffn.b1']), a_bf, dh1)
+            hgemm_tn(dh1, s1.wb, out=da, accumulate=True)                                    # da += dh1.W1^T
+            del dh1, df
+            # ---- LN1 + output projection ---------------------------------------------------------
+            do, dh = _ln_bwd(da, o, h, P['ln1.gamma'], mean1, rstd1, pad, rate, sites[1], drop,
+                             G['ln1.gamma'], G['ln1.beta'], dx_bf16=True)
+            del da
+            _on_wgrad_stream(lambda: hgemm_wgrad_rows(h_bf, do, G['wo'][:d], G['bo']), h_bf, do)
+            _on_wgrad_stream(lambda: hgemm_wgrad_rows(cx, do, G['wo'][d:], None), cx, do)
+            hgemm_tn(do, sho.wb[:d], out=dh, accumulate=True)                                # dh += do.Wo_top^T
+            dctx = hgemm_tn(do, sho.wb[d:2 * d], out_bf16=True)
+            del do
+            # ---- attention + qkv projection ------------------------------------------------------
+            dqkv = torch.empty_like(qkv)
+            ws = _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, dh_), h.device)
+            check(l.ttsmi_attention_bwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(dctx), _p(lse), _p(dqkv), B, H, T, dh_,
+                                        rate, drop.seed, _p(drop.step_dev), sites[0], _p(ws), ws.numel(), dtype,
+                                        _stream()), 'attention_bwd')
+            _on_wgrad_stream(lambda: hgemm_wgrad_rows(h_bf, dqkv, G['wqkv'], G['bqkv']), h_bf, dqkv)
+            hgemm_tn(dqkv, shq.wb, out=dh, accumulate=True)                                  # dh += dqkv.Wqkv^T
+            return (dh,) + (None,) * 14
         # ---- LN2 + FFN -----------------------------------------------------------------------
         df, da = _ln_bwd(dout, f, a, P['ln2.gamma'], mean2, rstd2, pad, rate, sites[2], drop,
                          G['ln2.gamma'], G['ln2.beta'])
         if da is df:                       # the GEMM below accumulates into da: it must own its buffer
-            da = df.clone() if rate <= 0 else da
-        if h1.dtype == torch.bfloat16:
-            s1, s2 = S['ffn.w1'], S['ffn.w2']
-            _on_wgrad_stream(lambda: hgemm_wgrad_rows(h1, df, G['ffn.w2'], G['ffn.b2']), h1, df)
-            dh1 = hgemm_tn(df, s2.wb, relu_src=h1, out_bf16=True)                            # relu' fused, bf16 out
-            _on_wgrad_stream(lambda: hgemm_wgrad_rows(a, dh1, G['ffn.w1'], G['ffn.b1']), a, dh1)
-            hgemm_tn(dh1, s1.wb, out=da, accumulate=True)                                    # da += dh1.W1^T
-        else:
-            dense_wgrad(h1, df, G['ffn.w2'], G['ffn.b2'], S.get('ffn.w2'))
-            dh1 = dense_dgrad(df, P['ffn.w2'], S.get('ffn.w2'), 0, P['ffn.w2'].shape[0], relu_src=h1)
-            dense_wgrad(a, dh1, G['ffn.w1'], G['ffn.b1'], S.get('ffn.w1'))
-            dense_dgrad(dh1, P['ffn.w1'], S.get('ffn.w1'), 0, d, out=da, accumulate=True)  # da += dh1.W1^T
+            da = df.clone()
+        dense_wgrad(h1, df, G['ffn.w2'], G['ffn.b2'], S.get('ffn.w2'))
+        dh1 = dense_dgrad(df, P['ffn.w2'], S.get('ffn.w2'), 0, P['ffn.w2'].shape[0], relu_src=h1)
+        dense_wgrad(a, dh1, G['ffn.w1'], G['ffn.b1'], S.get('ffn.w1'))
+        dense_dgrad(dh1, P['ffn.w1'], S.get('ffn.w1'), 0, d, out=da, accumulate=True)      # da += dh1.W1^T
         del dh1
         # ---- LN1 + output projection -----------------------------------------------------------
         do, dh = _ln_bwd(da, o, h, P['ln1.gamma'], mean1, rstd1, pad, rate, sites[1], drop,
@@ -950,16 +1010,11 @@ class DenseBlockFn(torch.autograd.Function):
         del do
         # ---- attention + qkv projection --------------------------------------------------------
         dqkv = torch.empty_like(qkv)
-        l = _lib.lib()
         ws = _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, dh_), h.device)
         check(l.ttsmi_attention_bwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(dctx), _p(lse), _p(dqkv), B, H, T, dh_,
                                     rate, drop.seed, _p(drop.step_dev), sites[0], _p(ws), ws.numel(), dtype,
                                     _stream()), 'attention_bwd')
         shq = S.get('wqkv')
-        if dqkv.dtype == torch.bfloat16:
-            _on_wgrad_stream(lambda: hgemm_wgrad_rows(h, dqkv, G['wqkv'], G['bqkv']), h, dqkv)
-            hgemm_tn(dqkv, shq.wb, out=dh, accumulate=True)                                  # dh += dqkv.Wqkv^T
-        else:
-            dense_wgrad(h, dqkv, G['wqkv'], G['bqkv'], shq)
-            dense_dgrad(dqkv, P['wqkv'], shq, 0, d, out=dh, accumulate=True)                # dh += dqkv.Wqkv^T
-        return (dh,) + (None,) * 13
+        dense_wgrad(h, dqkv, G['wqkv'], G['bqkv'], shq)
+        dense_dgrad(dqkv, P['wqkv'], shq, 0, d, out=dh, accumulate=True)                    # dh += dqkv.Wqkv^T
+        return (dh,) + (None,) * 14
