@@ -143,9 +143,9 @@ KERNEL_OF = {
     'ttsmi_conv1d_dgrad': 'gemm_f32_kernel<A_KC,B_KC> (dgrad)',
     'ttsmi_linear_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
     'ttsmi_conv1d_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
-    'ttsmi_hgemm_tn': 'gemm_bf16_kernel<A=f32> (Dense/Conv1D forward + dgrad, bf16 MFMA)',
+    'ttsmi_hgemm_tn': 'gemm_bf16_kernel (Dense/Conv1D forward + dgrad, bf16 MFMA)',
     'ttsmi_hgemm_wgrad': 'gemm_bf16_kernel<A=bf16> (wgrad, bf16 MFMA, + split reduce)',
-    'ttsmi_hgemm_wgrad_rows': 'wgrad_rows_kernel (wgrad from fp32 rows, bf16 MFMA, + split reduce)',
+    'ttsmi_hgemm_wgrad_rows': 'wgrad_rows_kernel (wgrad from row-major activations, bf16 MFMA, + split reduce)',
     'ttsmi_attention_fwd': 'attn_fwd_kernel (exact fp32 MFMA)',
     'ttsmi_attention_bwd': 'attn_bwd_dq_kernel + attn_bwd_dkv_kernel (exact fp32 MFMA)',
 }
@@ -166,7 +166,7 @@ def kernel_family(name, args):
 PMC_FILE = 'r01_pmc_hbm_traffic_bf16.json'
 PMC_KERNELS = {       # kernel family -> rocprof kernel-name prefixes (bf16 path; the PMC passes ran that path)
     KERNEL_OF['ttsmi_hgemm_tn']: ['gemm_bf16_kernel'],
-    KERNEL_OF['ttsmi_hgemm_wgrad_rows']: ['wgrad_rows_kernel', 'hsplit_reduce_kernel'],
+    KERNEL_OF['ttsmi_hgemm_wgrad_rows']: ['wgrad_rows_kernel', 'hsplit_reduce'],
     HATTN_FWD: ['hattn_fwd_kernel'],
     HATTN_BWD: ['hattn_bwd_'],
 }

@@ -262,6 +262,9 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     const int d = p.H * DH;
     const int q = bx * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
+    // T = 900 leaves the last 128-row tile with 4 live rows: waves without any live row only help
+    // staging the K/V tiles, they skip the score arithmetic (the kernel is VALU bound)
+    const bool wave_live = (bx * 128 + wave * 32) < p.T;
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
     const float* Vb = eptr<QH>(Qb, 2 * d);
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
 #pragma unroll
         for (int kt = 0; kt < HKT / 32; ++kt) {
             const int kbase = k0 + kt * 32;
-            if (kbase >= klen) break;
+            if (kbase >= klen || !wave_live) break;
             f32x16 s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                 // S^T[key][q]
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] *= c1;
@@ -382,6 +385,9 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     const int d = p.H * DH;
     const int q = bx * 128 + wave * 32 + l31;
     const bool qok = q < p.T;
+    // T = 900 leaves the last 128-row tile with 4 live rows: waves without any live row only help
+    // staging the K/V tiles, they skip the score arithmetic (the kernel is VALU bound)
+    const bool wave_live = (bx * 128 + wave * 32) < p.T;
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
     const float* Vb = eptr<QH>(Qb, 2 * d);
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
 #pragma unroll
         for (int kt = 0; kt < HKT / 32; ++kt) {
             const int kbase = k0 + kt * 32;
-            if (kbase >= klen) break;
+            if (kbase >= klen || !wave_live) break;
             f32x16 s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                 // S^T
             f32x16 dp = dot16<DH>(Vs, kt * 32 + l31, hh, dof);               // dP^T = V.dO^T
 #pragma unroll
@@ -517,6 +523,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     const int klen = p.klen[b];
     const bool kok = key < p.T;
     const bool kact = key < klen;
+    const bool wave_live = (bx * 128 + wave * 32) < klen;     // a wave whose 32 keys are all dead skips the arithmetic
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
     const float* Vb = eptr<QH>(Qb, 2 * d);
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
             __syncthreads();
 #pragma unroll
             for (int qt = 0; qt < HKT / 32; ++qt) {
-                if (q0 + qt * 32 >= p.T) break;
+                if (q0 + qt * 32 >= p.T || !wave_live) break;
                 f32x16 s = dot16<DH>(Qs, qt * 32 + l31, hh, kf);             // S[q][key]
                 f32x16 dp = dot16<DH>(Os, qt * 32 + l31, hh, vf);            // dP = dO.V^T
                 f32x16 pt;
