@@ -211,25 +211,74 @@ __device__ __forceinline__ void accumT16(const uint16_t* St, int k0, int l31, in
     }
 }
 
+// Same product with the A operand taken straight from the ROW-MAJOR image S[key][DH+8] through gfx950's
+// transposing LDS read: per 16-lane group ds_read_b64_tr_b16 fetches a [4 rows][16 cols] block and hands
+// lane c the 4 values of column c - exactly the "4 consecutive reduction indices of one output row" an
+// MFMA A fragment needs (two reads per fragment: rows +0..3 and +8..11 of rowmap16).  No LDS->LDS
+// re-layout pass, no transposed image, one barrier less per tile.
+typedef short as16x4 __attribute__((ext_vector_type(4)));
+typedef short as16x8 __attribute__((ext_vector_type(8)));
+template <int DH>
+__device__ __forceinline__ void accumTR(const uint16_t* S, int k0, int lane, const bf16x8 (&pb)[2],
+                                        f32x16 (&out)[DH / 32]) {
+    typedef __attribute__((address_space(3))) as16x4* lds_ptr;
+    constexpr int LD = DH + 8;
+    // this lane's share of its group's block: row (lane&15)>>2, columns 4*(lane&3).. ; group = lane>>4:
+    // (group&1) selects the 16-column half, lane>>5 (= hh) the +4 row offset of rowmap16
+    const uint16_t* base = S + (k0 + 4 * (lane >> 5) + ((lane & 15) >> 2)) * LD + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+#pragma unroll
+    for (int cb = 0; cb < DH / 32; ++cb) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint16_t* a = base + (16 * t) * LD + cb * 32;
+            as16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
+            as16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 8 * LD));
+            as16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            out[cb] = MFMA16(__builtin_bit_cast(bf16x8, v), pb[t], out[cb]);
+        }
+    }
+}
+
+// Epilogue: accumulators hold O^T (lane = row, registers = columns).  fp32 output: per-wave fp32 patch
+// [32][DH+1], row-contiguous stores.  bf16 output (OUT_H): the patch is bf16 [32][DH+8] - registers
+// 4g..4g+3 are 4 consecutive columns, packed into one 8-byte LDS write - and leaves as 16-byte stores
+// (8 lanes per row); it is half the size of the K/V tile images, so it no longer sets the LDS footprint.
 template <int DH, bool OUT_H = false>
-__device__ __forceinline__ void storeT16(float* patch, const f32x16 (&o)[DH / 32], float scale_lane,
+__device__ __forceinline__ void storeT16(float* patch_f, const f32x16 (&o)[DH / 32], float scale_lane,
                                          float* dst, long ld, int row0, int nvalid, int lane) {
     const int l31 = lane & 31, hh = lane >> 5;
     __syncthreads();
+    if constexpr (OUT_H) {
+        constexpr int PLD = DH + 8;
+        uint16_t* patch = reinterpret_cast<uint16_t*>(patch_f);
 #pragma unroll
-    for (int cb = 0; cb < DH / 32; ++cb)
+        for (int cb = 0; cb < DH / 32; ++cb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) patch[l31 * (DH + 1) + cb * 32 + rowmap16(r, hh)] = o[cb][r] * scale_lane;
-    __syncthreads();
-    for (int j = 0; j < 32; ++j) {
-        if (j >= nvalid) break;
-        for (int c = lane; c < DH; c += 64) {
-            if constexpr (OUT_H) {
-                __bf16 hv = (__bf16)patch[j * (DH + 1) + c];
-                reinterpret_cast<uint16_t*>(dst)[(long)(row0 + j) * ld + c] = *reinterpret_cast<uint16_t*>(&hv);
-            } else {
-                dst[(long)(row0 + j) * ld + c] = patch[j * (DH + 1) + c];
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (__bf16)(o[cb][4 * g + e] * scale_lane);
+                *reinterpret_cast<uint2*>(patch + l31 * PLD + cb * 32 + 8 * g + 4 * hh) = *reinterpret_cast<uint2*>(&h);
             }
+        __syncthreads();
+        constexpr int CH = DH / 8, RPI = 64 / CH;              // 16-byte chunks per row, rows per iteration
+        uint16_t* out = reinterpret_cast<uint16_t*>(dst);
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int j = it * RPI + lane / CH, c8 = (lane % CH) * 8;
+            if (j < nvalid)
+                *reinterpret_cast<uint4*>(out + (long)(row0 + j) * ld + c8) =
+                    *reinterpret_cast<const uint4*>(patch + j * PLD + c8);
+        }
+    } else {
+#pragma unroll
+        for (int cb = 0; cb < DH / 32; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch_f[l31 * (DH + 1) + cb * 32 + rowmap16(r, hh)] = o[cb][r] * scale_lane;
+        __syncthreads();
+        for (int j = 0; j < 32; ++j) {
+            if (j >= nvalid) break;
+            for (int c = lane; c < DH; c += 64) dst[(long)(row0 + j) * ld + c] = patch_f[j * (DH + 1) + c];
         }
     }
 }
@@ -238,7 +287,8 @@ template <int DH>
 struct HSm {
     static constexpr int ROWS = HKT * (DH + 8);      // uint16 elements of a row-major image
     static constexpr int TRN = DH * TLD;             // uint16 elements of a transposed image
-    static constexpr int PATCH_BYTES = 4 * 32 * (DH + 1) * 4;
+    static constexpr int PATCH_F32 = 4 * 32 * (DH + 1) * 4;       // fp32-output epilogue patches (4 waves)
+    static constexpr int PATCH_H = 4 * 32 * (DH + 8) * 2;         // bf16-output ones
 };
 
 // =================================================================================================
@@ -247,12 +297,12 @@ struct HSm {
 template <int DH, bool DROP, bool QH>
 __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
     using SM = HSm<DH>;
-    constexpr int TILE_BYTES = (2 * SM::ROWS + SM::TRN) * 2;
-    constexpr int MAIN = TILE_BYTES > SM::PATCH_BYTES ? TILE_BYTES : SM::PATCH_BYTES;
+    constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
+    constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
+    constexpr int MAIN = TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + HKT * 4];
     uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vs = Ks + SM::ROWS;
-    uint16_t* Vt = Vs + SM::ROWS;
     float* padS = reinterpret_cast<float*>(smem + MAIN);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
@@ -297,14 +347,12 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
         rv.stash(Vs, tid);
         if (tid < HKT) padS[tid] = rpad;
         const int anypad = __syncthreads_or(tid < HKT && rpad != 0.f);
-        lds_transpose<DH>(Vs, Vt, tid);
         if (k0 + HKT < klen) {
             int nv = min(HKT, klen - (k0 + HKT));
             rk.fetch(Kb, p.ld, k0 + HKT, nv, tid);
             rv.fetch(Vb, p.ld, k0 + HKT, nv, tid);
             if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + k0 + HKT + tid]) ? 1.f : 0.f;
         }
-        __syncthreads();
 #pragma unroll
         for (int kt = 0; kt < HKT / 32; ++kt) {
             const int kbase = k0 + kt * 32;
@@ -352,12 +400,12 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
             }
             bf16x8 pb[2];
             to_frags(s, pb);
-            accumT16<DH>(Vt, kt * 32, l31, hh, pb, o);                        // O^T += V^T.P^T
+            accumTR<DH>(Vs, kt * 32, lane, pb, o);                            // O^T += V^T.P^T
         }
     }
     __syncthreads();
     if (qok && hh == 0) p.lse[((long)b * p.H + h) * p.T + q] = (m + log2f(l)) * LN2;
-    float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
+    float* patch = reinterpret_cast<float*>(smem + wave * (QH ? 32 * (DH + 8) * 2 : 32 * (DH + 1) * 4));
     int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
     storeT16<DH, QH>(patch, o, 1.0f / l, const_cast<float*>(eptr<QH>(p.ctx, (long)b * p.T * d + h * DH)), d, row0,
@@ -370,12 +418,12 @@ __global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
 template <int DH, bool DROP, bool QH>
 __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
     using SM = HSm<DH>;
-    constexpr int TILE_BYTES = (2 * SM::ROWS + SM::TRN) * 2;
-    constexpr int MAIN = TILE_BYTES > SM::PATCH_BYTES ? TILE_BYTES : SM::PATCH_BYTES;
+    constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
+    constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
+    constexpr int MAIN = TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + HKT * 4];
     uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vs = Ks + SM::ROWS;
-    uint16_t* Kt = Vs + SM::ROWS;
     float* padS = reinterpret_cast<float*>(smem + MAIN);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
@@ -449,14 +497,12 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
         rv.stash(Vs, tid);
         if (tid < HKT) padS[tid] = rpad;
         const int anypad = __syncthreads_or(tid < HKT && rpad != 0.f);
-        lds_transpose<DH>(Ks, Kt, tid);
         if (k0 + HKT < klen) {
             int nv = min(HKT, klen - (k0 + HKT));
             rk.fetch(Kb, p.ld, k0 + HKT, nv, tid);
             rv.fetch(Vb, p.ld, k0 + HKT, nv, tid);
             if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + k0 + HKT + tid]) ? 1.f : 0.f;
         }
-        __syncthreads();
 #pragma unroll
         for (int kt = 0; kt < HKT / 32; ++kt) {
             const int kbase = k0 + kt * 32;
@@ -486,11 +532,11 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
             for (int r = 0; r < 16; ++r) s[r] = EXP2(s[r]) * (dp[r] - delta) * inv_sqrt;   // dS^T
             bf16x8 pb[2];
             to_frags(s, pb);
-            accumT16<DH>(Kt, kt * 32, l31, hh, pb, dq);                       // dQ^T += K^T.dS^T
+            accumTR<DH>(Ks, kt * 32, lane, pb, dq);                           // dQ^T += K^T.dS^T
         }
     }
     __syncthreads();
-    float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
+    float* patch = reinterpret_cast<float*>(smem + wave * (QH ? 32 * (DH + 8) * 2 : 32 * (DH + 1) * 4));
     int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
     storeT16<DH, QH>(patch, dq, 1.0f, const_cast<float*>(eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH)), p.ld, row0,
@@ -503,13 +549,12 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
 template <int DH, bool DROP, bool QH>
 __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     using SM = HSm<DH>;
-    constexpr int TILE_BYTES = (2 * SM::ROWS + 2 * SM::TRN) * 2;
-    constexpr int MAIN = TILE_BYTES > SM::PATCH_BYTES ? TILE_BYTES : SM::PATCH_BYTES;
+    constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
+    constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
+    constexpr int MAIN = TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + 3 * HKT * 4];
     uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Os = Qs + SM::ROWS;
-    uint16_t* Qt = Os + SM::ROWS;
-    uint16_t* Ot = Qt + SM::TRN;
     float* lseS = reinterpret_cast<float*>(smem + MAIN);
     float* delS = lseS + HKT;
     uint32_t* rbS = reinterpret_cast<uint32_t*>(delS + HKT);     // dropout row bases of the q tile
@@ -569,8 +614,6 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
                 if (DROP) rbS[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0 + tid));
             }
             __syncthreads();
-            lds_transpose<DH>(Qs, Qt, tid);
-            lds_transpose<DH>(Os, Ot, tid);
             if (q0 + HKT < p.T) {
                 int nv = min(HKT, p.T - (q0 + HKT));
                 rq.fetch(Qb, p.ld, q0 + HKT, nv, tid);
@@ -580,7 +623,6 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
                     rd = tid < nv ? p.delta[stat0 + q0 + HKT + tid] : 0.f;
                 }
             }
-            __syncthreads();
 #pragma unroll
             for (int qt = 0; qt < HKT / 32; ++qt) {
                 if (q0 + qt * 32 >= p.T || !wave_live) break;
@@ -605,13 +647,13 @@ __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
                 bf16x8 pb[2], sb[2];
                 to_frags(pt, pb);
                 to_frags(s, sb);
-                accumT16<DH>(Ot, qt * 32, l31, hh, pb, dv);                   // dV^T += dO^T.P
-                accumT16<DH>(Qt, qt * 32, l31, hh, sb, dk);                   // dK^T += Q^T.dS
+                accumTR<DH>(Os, qt * 32, lane, pb, dv);                       // dV^T += dO^T.P
+                accumTR<DH>(Qs, qt * 32, lane, sb, dk);                       // dK^T += Q^T.dS
             }
         }
     }
     __syncthreads();
-    float* patch = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
+    float* patch = reinterpret_cast<float*>(smem + wave * (QH ? 32 * (DH + 8) * 2 : 32 * (DH + 1) * 4));
     int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
     const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH);
