@@ -133,6 +133,25 @@ def test_conv_block_variant_matches_oracle():
     _adam_weights_close(m, ref, want['grads'])
 
 
+def test_reference_default_head_dim_192_conv_blocks():
+    """The reference's shipped default (config/training_config.yaml:104-118): d_model 384, 2 heads
+    (dh = 192), conv blocks with filters [1536, 384] k=3 - here with 1+1 blocks and a short batch."""
+    cfg = fo.make_config(d_model=384, enc_heads=(2,), dec_heads=(2,), ffn=1536, enc_dense_blocks=0,
+                         dec_dense_blocks=0, conv_filters=(1536, 384), dur_filters=(256, 226),
+                         pitch_filters=(256, 226))
+    W = fo.init_weights(cfg, seed=4, perturb=0.02)
+    batch = fo.synthetic_batch(2, 21, 90, seed=6, ragged=True)
+    ref = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    ref.learning_rate = 1e-3
+    want = ref.train_step(*batch)
+    m = _model(cfg, W)
+    m._compile(learning_rate=1e-3)
+    got = m.train_step(*batch)
+    assert abs(float(got['loss']) - float(want['loss'])) / float(want['loss']) < TOL
+    assert _rel(got['mel'], want['mel']) < TOL
+    _adam_weights_close(m, ref, want['grads'])
+
+
 def test_predict_matches_oracle(tiny):
     cfg, W = tiny
     W = dict(W)

@@ -233,7 +233,7 @@ def _attn_ref(qkv, pad, B, H, T, dh):
 
 
 @pytest.mark.parametrize('B,H,T,dh', [(2, 2, 50, 32), (3, 4, 200, 64), (1, 1, 1, 32), (2, 4, 333, 64),
-                                      (2, 2, 129, 64), (1, 4, 900, 64)])
+                                      (2, 2, 129, 64), (1, 4, 900, 64), (2, 2, 150, 192), (1, 2, 70, 96)])
 def test_attention_fwd_bwd_weights(B, H, T, dh):
     ops = _ops()
     d = H * dh

@@ -494,8 +494,9 @@ static int fill(AttnP& p, const void* qkv, const uint8_t* key_pad, const int32_t
         case 64: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, st, p); break;           \
         case 96: hipLaunchKernelGGL((KERNEL<96>), grid, dim3(256), 0, st, p); break;           \
         case 128: hipLaunchKernelGGL((KERNEL<128>), grid, dim3(256), 0, st, p); break;         \
+        case 192: hipLaunchKernelGGL((KERNEL<192>), grid, dim3(256), 0, st, p); break;         \
         default:                                                                               \
-            ttsmi_set_error("attention: head dim %d not built (32/64/96/128)", dh);            \
+            ttsmi_set_error("attention: head dim %d not built (32/64/96/128/192)", dh);        \
             return TTSMI_ERR_UNSUPPORTED;                                                      \
     }
 
