@@ -28,6 +28,8 @@
     } while (0)
 #define MELW_MAX 1536
 #define MELS_MAX 128
+#define MEL_IT 12         // weights per mel work item
+#define MEL_ITEMS 128     // LDS item-table capacity (LJSpeech bank: 105 items)
 #define ZP(i) ((i) + ((i) >> 3))   // one pad slot per 8 complex points: the radix-8 scatter of pass 1
                                   // (lane stride 8 points) then lands on 16 distinct banks
 
@@ -91,7 +93,7 @@ __device__ __forceinline__ int clip_of_frame(const int64_t* frame_off, int n_cli
 __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     __shared__ float2 tw[NFFT];                       // exp(-2 pi i k / 1024)
     __shared__ float2 buf[FR_PER_WG][NC + NC / 8 + 8];   // padded: physical index = i + (i >> 3)
-    __shared__ float mag[FR_PER_WG][NC + 8];
+    __shared__ float mag[FR_PER_WG][NC + 8 + MEL_IT];      // bins 513.. stay 0 (mel items may read past 512)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rev[8] = {0, 4, 2, 6, 1, 5, 3, 7};
 
@@ -113,9 +115,42 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         }
     }
     __syncthreads();
+    // Lane balance of the sparse mel product: the Slaney filters are 3 bins wide at the bottom and ~37 at
+    // the top, so "one lane per filter" leaves most of the wave idle behind the widest filter.  Filters
+    // are cut into work items of at most MEL_IT weights (about 105 items for the LJSpeech bank); a lane
+    // sums one item per round, a second short pass adds the (<= 4) partial sums of each filter.
+    __shared__ int itLo[MEL_ITEMS], itFirst[MELS_MAX + 1];
+    __shared__ __attribute__((aligned(16))) float itWt[MEL_ITEMS][MEL_IT];   // zero-padded: fixed trip count
+    __shared__ float partS[FR_PER_WG][MEL_ITEMS];
+    if (mel_in_lds) {
+        if (tid == 0) {
+            int acc = 0;
+            for (int m = 0; m < p.n_mels; ++m) {
+                itFirst[m] = acc;
+                acc += (melcntS[m] + MEL_IT - 1) / MEL_IT;
+            }
+            itFirst[p.n_mels] = acc;
+        }
+        __syncthreads();
+        if (itFirst[p.n_mels] <= MEL_ITEMS) {
+            for (int m = tid; m < p.n_mels; m += 256) {
+                const int first = itFirst[m], n = itFirst[m + 1] - first;
+                for (int j = 0; j < n; ++j) {
+                    itLo[first + j] = melloS[m] + j * MEL_IT;
+                    const int cnt = min(MEL_IT, melcntS[m] - j * MEL_IT);
+                    for (int i = 0; i < MEL_IT; ++i)
+                        itWt[first + j][i] = i < cnt ? melwS[melptrS[m] + j * MEL_IT + i] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int n_items = mel_in_lds ? itFirst[p.n_mels] : 0;
+    const bool mel_items = mel_in_lds && n_items <= MEL_ITEMS;
 
     float2* zb = buf[wave];
     float* mg = mag[wave];
+    for (int i = NC + 1 + lane; i < NC + 8 + MEL_IT; i += 64) mg[i] = 0.f;
     // the lane's 16 window taps never change: keep them in registers
     float2 win[8];
 #pragma unroll
@@ -146,6 +181,12 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
             t = (int)(f - cur_f0);
         }
         const int start = t * p.hop - NFFT / 2;
+        if (act && start >= 0 && start + NFFT <= L) {     // wave-uniform: an interior frame needs no reflection
+            const float* src = p.wav + base + start + 2 * lane;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = make_float2(src[128 * r], src[128 * r + 1]);
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             int n = 2 * (lane + 64 * r);
@@ -208,22 +249,46 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         }
         WAVE_SYNC();
         // ---- real-FFT post-processing: |X[k]|, k = 0..512 -------------------------------------
-        for (int k = lane; k <= NC && !(p.ablate & 8); k += 64) {
-            float2 zk = zb[ZP(k & (NC - 1))];
+        // X[k] = (e - i w o)/2 with e = Z[k] + conj(Z[512-k]), o = Z[k] - conj(Z[512-k]), w = exp(-2 pi i k/1024);
+        // the mirror bin shares everything: X[512-k] = (conj(e) - i conj(w o))/2.  One pass over k = 0..256
+        // yields both magnitudes (half the LDS reads and complex multiplies of a pass over all 513 bins).
+        for (int k = lane; k <= NC / 2 && !(p.ablate & 8); k += 64) {
+            float2 zk = zb[ZP(k)];
             float2 zc = zb[ZP((NC - k) & (NC - 1))];
             zc.y = -zc.y;
             float2 e = cadd(zk, zc), o = csub(zk, zc);
-            float2 w = (k < NC) ? tw[k] : make_float2(-1.f, 0.f);
-            // X = 0.5*e - 0.5i * w * o
-            float2 wo = cmul(w, o);
-            float xr = 0.5f * (e.x + wo.y), xi = 0.5f * (e.y - wo.x);
-            mg[k] = sqrtf(xr * xr + xi * xi);
+            float2 wo = cmul(tw[k], o);
+            float xr = e.x + wo.y, xi = e.y - wo.x;            // 2 X[k]
+            float yr = e.x - wo.y, yi = e.y + wo.x;            // 2 conj-mirrored X[512-k]
+            mg[k] = 0.5f * sqrtf(xr * xr + xi * xi);
+            mg[NC - k] = 0.5f * sqrtf(yr * yr + yi * yi);
         }
         WAVE_SYNC();
         // ---- sparse mel + normalisation ---------------------------------------------------------
+        if (mel_items && !(p.ablate & 2)) {
+            float* part = partS[wave];
+            for (int it = lane; it < n_items; it += 64) {
+                const float4* w4 = reinterpret_cast<const float4*>(itWt[it]);
+                const float* x = mg + itLo[it];         // may run up to MEL_IT - 1 bins past the filter: zero weights
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < MEL_IT / 4; ++i) {
+                    const float4 w = w4[i];
+                    s0 += w.x * x[4 * i];
+                    s1 += w.y * x[4 * i + 1];
+                    s2 += w.z * x[4 * i + 2];
+                    s0 += w.w * x[4 * i + 3];
+                }
+                part[it] = (s0 + s1) + s2;
+            }
+            WAVE_SYNC();
+        }
         for (int m = lane; m < p.n_mels && !(p.ablate & 2); m += 64) {
             float s = 0.f;
-            if (mel_in_lds) {
+            if (mel_items) {
+                const float* part = partS[wave];
+                for (int j = itFirst[m]; j < itFirst[m + 1]; ++j) s += part[j];
+            } else if (mel_in_lds) {
                 const int lo = melloS[m], cnt = melcntS[m];
                 const float* w = melwS + melptrS[m];
                 for (int i = 0; i < cnt; ++i) s += w[i] * mg[lo + i];
