@@ -110,12 +110,14 @@ __device__ __forceinline__ void stash_h(uint16_t (*S)[HLD_], int tid, const uint
 
 #define EPLD 68     // fp32 row stride of the per-wave epilogue patch [32][64+4]
 
-// BM = 128: wave tile 64x64 (2x2 MFMA tiles); BM = 64: wave tile 32x64 (1x2) - half the registers,
-// twice the resident workgroups: these GEMMs are HBM/L2-latency bound, not MFMA bound.
-template <bool A_F32, int BM>
+// BM = 128: wave tile 64 rows (2 MFMA tiles); BM = 64: 32 rows - half the registers, twice the resident
+// workgroups.  BN = 128: wave tile 64 columns (2 MFMA tiles); BN = 256: 128 columns (4 tiles).
+// (BN = 256 is a measurement knob, see hlaunch.)
+template <bool A_F32, int BM, int BN = HBN_>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
     constexpr int MI = BM / 64;
-    constexpr int TILE_BYTES = (BM + HBN_) * HLD_ * 2;
+    constexpr int NJ = BN / 64;
+    constexpr int TILE_BYTES = (BM + BN) * HLD_ * 2;
     constexpr int PATCH_BYTES = 4 * 32 * EPLD * 4;
     constexpr int SMEM_BYTES = TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
@@ -126,22 +128,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
     const int wr = wave >> 1, wc = wave & 1;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * HBN_;
+    const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int l31 = lane & 31, kg = lane >> 5;
 
-    f32x16 acc[MI][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[BM / 16];   // fp32-A prefetch registers (dead in the bf16-A instantiation)
     uint4 rah[BM / 32];   // bf16-A prefetch registers (dead in the fp32-A instantiation)
-    uint4 rb[HBN_ / 32];
+    uint4 rb[BN / 32];
     // bf16 A with a second K segment (concat([q_in, ctx]) . W): K1 is a multiple of the k-step, so a
     // step lies wholly inside one segment
     auto fetch_a_h = [&](int k0) {
@@ -153,20 +155,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
     if (kbeg < kend) {
         if constexpr (A_F32) fetch_a_f32<BM>(p, m0, kbeg, kend, tid, ra);
         else fetch_a_h(kbeg);
-        fetch_h<HBN_>(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
+        fetch_h<BN>(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
         if constexpr (A_F32) stash_a_f32<BM>(As, tid, ra); else stash_h<BM>(As, tid, rah);
-        stash_h<HBN_>(Bs, tid, rb);
+        stash_h<BN>(Bs, tid, rb);
     }
     __syncthreads();
 
-    const bool do_colsum = (p.colsum != nullptr) && (tm == 0) && (tid < HBN_);
+    const bool do_colsum = (p.colsum != nullptr) && (tm == 0) && (tid < BN);
     float csum = 0.f;
     for (int k0 = kbeg; k0 < kend; k0 += HBK_) {
         const bool more = (k0 + HBK_) < kend;
         if (more) {
             if constexpr (A_F32) fetch_a_f32<BM>(p, m0, k0 + HBK_, kend, tid, ra);
             else fetch_a_h(k0 + HBK_);
-            fetch_h<HBN_>(p.B, p.ldb, p.N, n0, k0 + HBK_, kend, tid, rb);
+            fetch_h<BN>(p.B, p.ldb, p.N, n0, k0 + HBK_, kend, tid, rb);
         }
         if (do_colsum) {                       // bias gradient from the dy^T tile (wgrad)
 #pragma unroll
@@ -179,22 +181,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
 #pragma unroll
         for (int ks = 0; ks < HBK_ / 16; ++ks) {
             const int ko = ks * 16 + kg * 8;
-            bf16x8 a[MI], b[2];
+            bf16x8 a[MI], b[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
                 a[i] = *reinterpret_cast<const bf16x8*>(&As[wr * (BM / 2) + i * 32 + l31][ko]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[wc * 64 + j * 32 + l31][ko]);
+            for (int j = 0; j < NJ; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(&Bs[wc * (BN / 2) + j * 32 + l31][ko]);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
         if (more) {
             if constexpr (A_F32) stash_a_f32<BM>(As, tid, ra); else stash_h<BM>(As, tid, rah);
-            stash_h<HBN_>(Bs, tid, rb);
+            stash_h<BN>(Bs, tid, rb);
         }
         __syncthreads();
     }
@@ -211,7 +214,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
     const bool fuse = !split;
     float* patch = reinterpret_cast<float*>(smem) + wave * 32 * EPLD;
     const int rl = lane >> 4, c4 = lane & 15;
-    const int col = n0 + wc * 64 + c4 * 4;
+#pragma unroll
+    for (int jh = 0; jh < NJ / 2; ++jh) {              // 64-column halves of the wave tile
+    const int col = n0 + wc * (BN / 2) + jh * 64 + c4 * 4;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (fuse && p.bias) {
         if (col + 0 < p.N) bias4.x = p.bias[col + 0];
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                patch[((r & 3) + 8 * (r >> 2) + 4 * kg) * EPLD + j * 32 + l31] = acc[i][j][r];
+                patch[((r & 3) + 8 * (r >> 2) + 4 * kg) * EPLD + j * 32 + l31] = acc[i][jh * 2 + j][r];
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
             }
         }
         __syncthreads();
+    }
     }
 }
 
@@ -689,6 +695,24 @@ static int hgemm_bm(bool a_f32, int M, int N, int splits) {
 }
 
 static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char* name) {
+    // 128x256 tiles (A re-read N/256 instead of N/128 times) exist as a measurement knob only
+    // (TTSMI_HGEMM_BN=256): on the decoder shapes they are 0-35 % SLOWER than 128x128 / 64x128
+    // (tools/probe_gemm_variants.py) - 252 VGPRs halve the resident workgroups, and these short-K GEMMs
+    // live on latency hiding across workgroups, not on L2 re-read volume.
+    static int forced_bn = -1;
+    if (forced_bn < 0) {
+        const char* e = getenv("TTSMI_HGEMM_BN");
+        forced_bn = e ? atoi(e) : 0;
+    }
+    const bool wide = forced_bn == 256 && !a_f32 && splits == 1 && p.N % 256 == 0;
+    if (wide) {
+        p.tiles_m = ttsmi_cdiv(p.M, 128);
+        p.tiles_n = ttsmi_cdiv(p.N, 256);
+        dim3 grid(p.tiles_m * p.tiles_n, 1, 1);
+        hipLaunchKernelGGL((gemm_bf16_kernel<false, 128, 256>), grid, dim3(256), 0, st, p);
+        TTSMI_CHECK_LAUNCH(name);
+        return TTSMI_OK;
+    }
     const int bm = hgemm_bm(a_f32, p.M, p.N, splits);
     p.tiles_m = ttsmi_cdiv(p.M, bm);
     p.tiles_n = ttsmi_cdiv(p.N, HBN_);
