@@ -52,15 +52,19 @@ __device__ __forceinline__ uint2 pack4(float4 v) {
 }
 
 // ---- A tile fetch: fp32 source (BM/16 float4 per thread) -----------------------------------------
+#define HC4_ (HBK_ / 4)      // float4 chunks per tile row
+#define HC8_ (HBK_ / 8)      // 8 x bf16 chunks per tile row
+#define HNA_(BM) ((BM) * HBK_ / 1024)   // float4 per thread of a BM-row fp32 tile
+#define HNH_(R) ((R) * HBK_ / 2048)     // uint4 per thread of an R-row bf16 tile
 template <int BM>
 __device__ __forceinline__ void fetch_a_f32(const HGemmP& p, int m0, int k0, int kend, int tid,
-                                            float4 (&r)[BM / 16]) {
+                                            float4 (&r)[HNA_(BM)]) {
     const float* A = (const float*)p.A;
     const float* A2 = (const float*)p.A2;
 #pragma unroll
-    for (int i = 0; i < BM / 16; ++i) {
+    for (int i = 0; i < HNA_(BM); ++i) {
         int id = tid + 256 * i;
-        int row = id >> 4, c4 = id & 15;
+        int row = id / HC4_, c4 = id % HC4_;
         int m = m0 + row, kk = k0 + c4 * 4;
         bool ok = (m < p.M) && (kk < kend);
         const float* ptr;
@@ -77,33 +81,33 @@ __device__ __forceinline__ void fetch_a_f32(const HGemmP& p, int m0, int k0, int
     }
 }
 template <int BM>
-__device__ __forceinline__ void stash_a_f32(uint16_t (*S)[HLD_], int tid, const float4 (&r)[BM / 16]) {
+__device__ __forceinline__ void stash_a_f32(uint16_t (*S)[HLD_], int tid, const float4 (&r)[HNA_(BM)]) {
 #pragma unroll
-    for (int i = 0; i < BM / 16; ++i) {
+    for (int i = 0; i < HNA_(BM); ++i) {
         int id = tid + 256 * i;
-        int row = id >> 4, c4 = id & 15;
+        int row = id / HC4_, c4 = id % HC4_;
         *reinterpret_cast<uint2*>(&S[row][c4 * 4]) = pack4(r[i]);
     }
 }
 // ---- bf16 source tile of ROWS rows (ROWS/32 uint4 per thread) -----------------------------------
 template <int ROWS>
 __device__ __forceinline__ void fetch_h(const uint16_t* base, long ld, int rows, int r0, int k0,
-                                        int kend, int tid, uint4 (&r)[ROWS / 32]) {
+                                        int kend, int tid, uint4 (&r)[HNH_(ROWS)]) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
+    for (int i = 0; i < HNH_(ROWS); ++i) {
         int id = tid + 256 * i;
-        int row = id >> 3, c8 = id & 7;
+        int row = id / HC8_, c8 = id % HC8_;
         int m = r0 + row, kk = k0 + c8 * 8;
         bool ok = (m < rows) && (kk < kend);
         r[i] = ok ? *reinterpret_cast<const uint4*>(base + (long)m * ld + kk) : make_uint4(0, 0, 0, 0);
     }
 }
 template <int ROWS>
-__device__ __forceinline__ void stash_h(uint16_t (*S)[HLD_], int tid, const uint4 (&r)[ROWS / 32]) {
+__device__ __forceinline__ void stash_h(uint16_t (*S)[HLD_], int tid, const uint4 (&r)[HNH_(ROWS)]) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
+    for (int i = 0; i < HNH_(ROWS); ++i) {
         int id = tid + 256 * i;
-        int row = id >> 3, c8 = id & 7;
+        int row = id / HC8_, c8 = id % HC8_;
         *reinterpret_cast<uint4*>(&S[row][c8 * 8]) = r[i];
     }
 }
@@ -141,9 +145,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[BM / 16];   // fp32-A prefetch registers (dead in the bf16-A instantiation)
-    uint4 rah[BM / 32];   // bf16-A prefetch registers (dead in the fp32-A instantiation)
-    uint4 rb[BN / 32];
+    float4 ra[HNA_(BM)];   // fp32-A prefetch registers (dead in the bf16-A instantiation)
+    uint4 rah[HNH_(BM)];   // bf16-A prefetch registers (dead in the fp32-A instantiation)
+    uint4 rb[HNH_(BN)];
     // bf16 A with a second K segment (concat([q_in, ctx]) . W): K1 is a multiple of the k-step, so a
     // step lies wholly inside one segment
     auto fetch_a_h = [&](int k0) {
