@@ -295,7 +295,7 @@ struct HSm {
 // forward
 // =================================================================================================
 template <int DH, bool DROP, bool QH>
-__global__ __launch_bounds__(256) void hattn_fwd_kernel(HAttnP p) {
+__global__ __launch_bounds__(256, 3) void hattn_fwd_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
@@ -546,6 +546,7 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
 // =================================================================================================
 // backward B: dK, dV (workgroup owns 128 keys, loops over queries)
 // =================================================================================================
+// 3 workgroups per CU: caps the allocation at 168 VGPRs (the unconstrained build used 172 = 2 waves/SIMD)
 template <int DH, bool DROP, bool QH>
 __global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
     using SM = HSm<DH>;
