@@ -41,7 +41,18 @@ def _worker(rank, world, port, out_dir):
     g = _flat(model.train_step(*shard, apply=False)['grads']).clone()
     sync = dp.GradAllReduce()
     assert sync.world == 2 and not sync.use_avg                   # gloo: SUM then 1/world
+    g2 = g.clone()
     sync(g)
+    # two-bucket path: the decoder half is launched early (as the backward hook does), the head and the
+    # join follow - same result as the single all-reduce
+    assert sync.overlap
+    split = g2.numel() // 3
+    sync.start_tail(g2, split)
+    assert sync._tail is not None
+    g2[:split] += 0.0                                             # "encoder backward" still writing the head
+    sync(g2)
+    assert sync._tail is None
+    torch.testing.assert_close(g2, g, rtol=0, atol=0)
     # broadcast: rank 1 starts from garbage and must end with rank 0's parameters
     params = torch.arange(10, dtype=torch.float32) if rank == 0 else torch.full((10,), -1.0)
     dp.broadcast_parameters(params, 0)

@@ -40,20 +40,58 @@ def init_process_group(backend: Optional[str] = None) -> tuple:
 
 
 class GradAllReduce:
-    """Callable handed to ForwardTransformer.grad_sync: averages the flat gradient buffer in place."""
+    """Callable handed to ForwardTransformer.grad_sync: averages the flat gradient buffer in place.
+
+    Two buckets on RCCL: the flat buffer is laid out [embedding | encoder | predictors | pitch_embed |
+    decoder | mel-out], and backward produces the decoder half first.  `start_tail(flat_grad, split)` is
+    called when backward crosses from the decoder into the encoder (ops.set_lenreg_backward_hook): it
+    launches the all-reduce of `flat_grad[split:]` asynchronously, ordered after everything the main and
+    the weight-gradient streams have queued so far, so that it runs over xGMI underneath the encoder's
+    backward.  `__call__` then reduces the head `[:split]` and joins the tail.  Every rank issues the two
+    collectives in the same order.  TTSMI_DP_OVERLAP=0 falls back to the single all-reduce."""
 
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.use_avg = dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        self.overlap = dist.is_initialized() and os.environ.get('TTSMI_DP_OVERLAP', '1') != '0'
+        self._tail = None                   # (work handle, split) of the in-flight decoder bucket
+        self._launch_stream = None
+
+    def _reduce(self, t: torch.Tensor, async_op: bool = False):
+        """Average over ranks (gloo has no AVG: SUM now, the caller scales once the sum has landed)."""
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
+
+    def start_tail(self, flat_grad: torch.Tensor, split: int, side_stream=None) -> None:
+        if not self.overlap or self.world == 1 or self._tail is not None or split <= 0 or split >= flat_grad.numel():
+            return
+        tail = flat_grad[split:]
+        if flat_grad.is_cuda:
+            main = torch.cuda.current_stream()
+            if self._launch_stream is None:
+                self._launch_stream = torch.cuda.Stream()
+            ls = self._launch_stream
+            ls.wait_stream(main)                      # LayerNorm / bias gradients written on the main stream
+            if side_stream is not None:
+                ls.wait_stream(side_stream)           # weight gradients written on the wgrad stream
+            with torch.cuda.stream(ls):               # the collective is ordered after `ls` as of now
+                work = self._reduce(tail, async_op=True)
+        else:
+            work = self._reduce(tail, async_op=True)
+        self._tail = (work, split)
 
     def __call__(self, flat_grad: torch.Tensor) -> None:
         if self.world == 1:
             return
-        if self.use_avg:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=self.group)
+        if self._tail is not None:
+            work, split = self._tail
+            self._tail = None
+            self._reduce(flat_grad[:split])
+            work.wait()                               # (CUDA: the current stream waits for the decoder bucket)
         else:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self._reduce(flat_grad)
+        if not self.use_avg:
             flat_grad.mul_(1.0 / self.world)
 
 
@@ -83,6 +121,22 @@ class DataParallel:
         model.grad_sync = self.sync if self.sync.world > 1 else None
         if broadcast:
             broadcast_parameters(model.params.data, 0, group)
+            if getattr(model, 'shadow', None) and hasattr(model, '_refresh_shadows'):
+                model._refresh_shadows(False)             # bf16 weight copies follow the broadcast weights
+        if self.sync.world > 1 and self.sync.overlap:
+            self.install_overlap_hook()
+
+    def install_overlap_hook(self):
+        """Start the decoder-half all-reduce when backward crosses into the encoder (see GradAllReduce)."""
+        from . import ops
+        model = self.model
+        dec = [o for n, (o, _) in model.params.offsets.items() if n.startswith('dec.')]
+        self.split = min(dec) if dec else 0       # flat layout: [... encoder side ... | dec.* | out.*]
+
+        def _hook():
+            if model.grad_sync is not None and not getattr(model, 'use_graph', False):
+                self.sync.start_tail(model.params.grad, self.split, ops.wgrad_stream())
+        ops.set_lenreg_backward_hook(_hook)
 
     def __getattr__(self, name):
         return getattr(self.model, name)

@@ -745,6 +745,22 @@ class RowMaskFn(torch.autograd.Function):
         return dx, None
 
 
+# Called at the start of LenRegFn.backward, i.e. when backward crosses from the decoder into the encoder:
+# every decoder-side gradient has been launched by then (data parallel uses it to start the all-reduce
+# of the decoder half of the flat gradient buffer underneath the encoder's backward).
+_lenreg_backward_hook = None
+
+
+def set_lenreg_backward_hook(fn):
+    global _lenreg_backward_hook
+    _lenreg_backward_hook = fn
+
+
+def wgrad_stream():
+    """The side stream the weight gradients run on (None until the first overlapped launch)."""
+    return _WgradStream.stream if _WgradStream.pending else None
+
+
 class LenRegFn(torch.autograd.Function):
     """Expand (model/layers.py:549-565): y[b,j] = x[b, idx[b,j]] (0 where idx < 0)."""
 
@@ -763,6 +779,8 @@ class LenRegFn(torch.autograd.Function):
     def backward(ctx, dy):
         cum, = ctx.saved_tensors
         B, Tp, cap, C = ctx.shape
+        if _lenreg_backward_hook is not None:
+            _lenreg_backward_hook()
         dy = _c(dy)
         dx = torch.empty((B, Tp, C), dtype=torch.float32, device=dy.device)
         check(_lib.lib().ttsmi_lenreg_bwd(_p(dy), _p(cum), _p(dx), B, Tp, cap, C, _stream()), 'lenreg_bwd')
