@@ -10,8 +10,8 @@ LJSpeech-shaped batches, 1/2/4/8 MI355X.
 Workload (config.workload = "configs[1]"): d_model 256, 6+6 dense blocks, 4 heads, FFN 1024, 80-bin
 mel, predictors [256,226] k=3, per-GPU batch 32, every sample 200 phonemes / 900 mel frames
 (SURVEY.md section 8d max-shape set), dropout 0.1 as in the reference's training config.  Weak
-scaling: per-GPU batch fixed, global batch = 32*N, one RCCL all-reduce of the flat fp32 gradient
-buffer per step.  Inputs are resident in HBM before the timed region.
+scaling: per-GPU batch fixed, global batch = 32*N, the flat fp32 gradient buffer is averaged with two
+RCCL all-reduces per step (decoder half overlapped with the encoder's backward).  Inputs are resident in HBM before the timed region.
 
 One JSON line is printed by rank 0.  Besides the driver contract it carries
   roofline     - the dominant kernel family of the step (the one with the most launch time): its
