@@ -147,7 +147,7 @@ struct Smem {
 // forward
 // =================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnP p) {
     using SM = Smem<DH>;
     __shared__ __attribute__((aligned(16))) float smem[SM::MAIN + KT];
     float* Ks = smem;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 // backward, kernel A: dQ (+ delta = rowsum(dO * O)), same orientation as the forward
 // =================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(AttnP p) {
     using SM = Smem<DH>;
     __shared__ __attribute__((aligned(16))) float smem[SM::MAIN + KT];
     float* Ks = smem;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 // backward, kernel B: dK, dV.  Workgroup owns 128 keys (32 per wave, lane&31 = key), loops queries.
 // =================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnP p) {
     using SM = Smem<DH>;
     __shared__ __attribute__((aligned(16))) float smem[SM::MAIN + 2 * KT];
     float* Qs = smem;

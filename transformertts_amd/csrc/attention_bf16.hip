@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void hattn_fwd_kernel(HAttnP p) {
 // backward A: dQ (+ delta)
 // =================================================================================================
 template <int DH, bool DROP, bool QH>
-__global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
+__global__ __launch_bounds__(256, 2) void hattn_bwd_dq_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
@@ -547,8 +547,10 @@ __global__ __launch_bounds__(256) void hattn_bwd_dq_kernel(HAttnP p) {
 // backward B: dK, dV (workgroup owns 128 keys, loops over queries)
 // =================================================================================================
 // 3 workgroups per CU: caps the allocation at 168 VGPRs (the unconstrained build used 172 = 2 waves/SIMD)
+// min 2 workgroups per CU: without the bound the register allocator takes 332 registers (236 VGPR +
+// 96 AGPR) = ONE wave per SIMD; bounded it needs 236 and no spills
 template <int DH, bool DROP, bool QH>
-__global__ __launch_bounds__(256) void hattn_bwd_dkv_kernel(HAttnP p) {
+__global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
