@@ -477,12 +477,15 @@ class ForwardTransformer:
         no allocation outside torch's allocator: hipGraph-capturable as one unit."""
         mel_len = int(ts.shape[1])                                                   # :467
         ra = False if self.return_attention is None else self.return_attention
-        model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra)
-        loss, loss_vals = self._losses(model_out, ts, td, tp)
-        ops.enable_wgrad_stream(self.overlap_wgrad)
-        loss.backward()                                                              # :480
-        ops.wgrad_join()
-        ops.enable_wgrad_stream(False)
+        with ops.pinned_stream():
+            model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra)
+            loss, loss_vals = self._losses(model_out, ts, td, tp)
+            ops.enable_wgrad_stream(self.overlap_wgrad)
+            try:
+                loss.backward()                                                      # :480
+                ops.wgrad_join()
+            finally:
+                ops.enable_wgrad_stream(False)
         model_out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in model_out.items()}
         model_out.update({'loss': loss.detach()})
         model_out.update({'losses': {'mel': loss_vals[0].detach(), 'duration': loss_vals[1].detach(),

@@ -21,11 +21,34 @@ LN_EPS = 1e-6
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
+
+
+# The stream every launch goes to.  Looking it up (torch.cuda.current_stream()) costs ~1 us and a step makes
+# ~600 launches from a host loop that is as long as the GPU step itself, so the model pins the handle for the
+# duration of a step (pinned_stream); the weight-gradient side stream swaps it while it is current.  Unpinned
+# (direct use of the ops), every launch asks torch.
+_PINNED_STREAM = None
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    h = _PINNED_STREAM
+    return h if h is not None else torch.cuda.current_stream().cuda_stream
+
+
+class pinned_stream:
+    """`with ops.pinned_stream():` - launches inside go to the stream that is current on entry."""
+
+    def __enter__(self):
+        global _PINNED_STREAM
+        self.prev = _PINNED_STREAM
+        _PINNED_STREAM = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        global _PINNED_STREAM
+        _PINNED_STREAM = self.prev
+        return False
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
@@ -379,8 +402,15 @@ def _on_wgrad_stream(fn, *inputs):
         _WgradStream.stream = torch.cuda.Stream()
     side = _WgradStream.stream
     side.wait_stream(main)                    # the operands were produced on the main stream
+    global _PINNED_STREAM
+    prev = _PINNED_STREAM
     with torch.cuda.stream(side):
-        fn()                                  # workspace allocated in here belongs to the side stream
+        if prev is not None:
+            _PINNED_STREAM = side.cuda_stream
+        try:
+            fn()                              # workspace allocated in here belongs to the side stream
+        finally:
+            _PINNED_STREAM = prev
     # Hold a reference until the join (which makes the main stream wait for the side stream):
     #  * the caching allocator cannot recycle the operands while the side stream may still read them
     #    (no record_stream needed, which also keeps this legal under hipGraph capture);
