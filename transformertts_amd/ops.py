@@ -10,6 +10,7 @@ for that parameter."""
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -385,6 +386,8 @@ class _WgradStream:
     / LayerNorm chain of the main stream: both are HBM-latency bound and fill each other's bubbles.
     Joined (wgrad_join) before the gradient all-reduce / Adam."""
     stream = None
+    handle = None           # raw hipStream_t of `stream`
+    ws = None               # persistent split-K workspace of the side stream (its kernels run in order)
     enabled = False
     pending = False
     keep = []
@@ -422,6 +425,42 @@ def _on_wgrad_stream(fn, *inputs):
     _WgradStream.pending = True
 
 
+_WGRAD_GENERIC = os.environ.get('TTSMI_WGRAD_GENERIC', '0') == '1'      # measurement knob: old submission path
+
+
+def wgrad_rows_async(x, dy, dw, db, conv=None):
+    """hgemm_wgrad_rows on the weight-gradient stream without entering a torch stream context: the
+    launch takes the stream handle explicitly and the split-K workspace is one persistent buffer owned by
+    that stream (its kernels execute in order, so reuse is safe) - a third of the host cost of the generic
+    _on_wgrad_stream path, which matters with ~60 weight gradients per step."""
+    W = _WgradStream
+    if not W.enabled:
+        return hgemm_wgrad_rows(x, dy, dw, db, conv)
+    if _WGRAD_GENERIC:
+        return _on_wgrad_stream(lambda: hgemm_wgrad_rows(x, dy, dw, db, conv), x, dy)
+    if W.stream is None:
+        W.stream = torch.cuda.Stream()
+    if W.handle is None:
+        W.handle = W.stream.cuda_stream
+    ev = torch.cuda.Event()
+    ev.record()                               # on the current (main) stream: the operands are complete here
+    W.stream.wait_event(ev)
+    M, N = x.shape[0], dy.shape[1]
+    taps, T, C, pad = conv if conv is not None else (1, 0, 0, 0)
+    kin = dw.shape[0]
+    l = _lib.lib()
+    need = l.ttsmi_hgemm_wgrad_rows_ws_bytes(M, kin, N)
+    if W.ws is None or W.ws.numel() < need:
+        with torch.cuda.stream(W.stream):
+            W.ws = torch.empty(int(max(need, 1 << 26)), dtype=torch.uint8, device=x.device)
+    check(l.ttsmi_hgemm_wgrad_rows(_p(x), int(x.dtype == torch.bfloat16), x.stride(0), _p(dy),
+                                   int(dy.dtype == torch.bfloat16), dy.stride(0), _p(dw), dw.stride(0), _p(db), M,
+                                   kin, N, taps, T, C, pad, _p(W.ws), W.ws.numel(), W.handle), 'hgemm_wgrad_rows')
+    W.keep.append(x)
+    W.keep.append(dy)
+    W.pending = True
+
+
 def wgrad_join():
     if _WgradStream.pending:
         torch.cuda.current_stream().wait_stream(_WgradStream.stream)
@@ -436,7 +475,7 @@ def dense_wgrad(x, dy, dw, db, sh, dyT=None):
         N = dy.shape[1]
         if K % 4 == 0 and N % 4 == 0 and _al(x, 4) and _al(dy, 4):
             # reads the fp32 rows once, transposes in LDS
-            _on_wgrad_stream(lambda: hgemm_wgrad_rows(x, dy, dw, db), x, dy)
+            wgrad_rows_async(x, dy, dw, db)
             return None
         if dyT is None:
             dyT = cast_transpose_bf16(dy)
@@ -1011,17 +1050,17 @@ class DenseBlockFn(torch.autograd.Function):
             # ---- LN2 + FFN ---------------------------------------------------------------------
             df, da = _ln_bwd(dout, f, a, P['ln2.gamma'], mean2, rstd2, pad, rate, sites[2], drop,
                              G['ln2.gamma'], G['ln2.beta'], dx_bf16=True)
-            _on_wgrad_stream(lambda: hgemm_wgrad_rows(h1, df, G['ffn.w2'], G['ffn.b2']), h1, df)
+            wgrad_rows_async(h1, df, G['ffn.w2'], G['ffn.b2'])
             dh1 = hgemm_tn(df, s2.wb, relu_src=h1, out_bf16=True)                            # relu' fused, bf16 out
-            _on_wgrad_stream(lambda: hgemm_wgrad_rows(a_bf, dh1, G['ffn.w1'], G['ffn.b1']), a_bf, dh1)
+            wgrad_rows_async(a_bf, dh1, G['ffn.w1'], G['ffn.b1'])
             hgemm_tn(dh1, s1.wb, out=da, accumulate=True)                                    # da += dh1.W1^T
             del dh1, df
             # ---- LN1 + output projection ---------------------------------------------------------
             do, dh = _ln_bwd(da, o, h, P['ln1.gamma'], mean1, rstd1, pad, rate, sites[1], drop,
                              G['ln1.gamma'], G['ln1.beta'], dx_bf16=True)
             del da
-            _on_wgrad_stream(lambda: hgemm_wgrad_rows(h_bf, do, G['wo'][:d], G['bo']), h_bf, do)
-            _on_wgrad_stream(lambda: hgemm_wgrad_rows(cx, do, G['wo'][d:], None), cx, do)
+            wgrad_rows_async(h_bf, do, G['wo'][:d], G['bo'])
+            wgrad_rows_async(cx, do, G['wo'][d:], None)
             hgemm_tn(do, sho.wb[:d], out=dh, accumulate=True)                                # dh += do.Wo_top^T
             dctx = hgemm_tn(do, sho.wb[d:2 * d], out_bf16=True)
             del do
@@ -1031,7 +1070,7 @@ class DenseBlockFn(torch.autograd.Function):
             check(l.ttsmi_attention_bwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(dctx), _p(lse), _p(dqkv), B, H, T, dh_,
                                         rate, drop.seed, _p(drop.step_dev), sites[0], _p(ws), ws.numel(), dtype,
                                         _stream()), 'attention_bwd')
-            _on_wgrad_stream(lambda: hgemm_wgrad_rows(h_bf, dqkv, G['wqkv'], G['bqkv']), h_bf, dqkv)
+            wgrad_rows_async(h_bf, dqkv, G['wqkv'], G['bqkv'])
             hgemm_tn(dqkv, shq.wb, out=dh, accumulate=True)                                  # dh += dqkv.Wqkv^T
             return (dh,) + (None,) * 14
         # ---- LN2 + FFN -----------------------------------------------------------------------
