@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--precision', default='bf16')
     ap.add_argument('--phonemes', type=int, default=400)
     ap.add_argument('--reps', type=int, default=40)
+    ap.add_argument('--cpu', action='store_true', help='also time the torch-CPU restatement (oracle) at batch 1')
     args = ap.parse_args()
     from transformertts_amd.model.models import ForwardTransformer
     cfg, _ = bench.workload_config('configs[1]')
@@ -54,6 +55,26 @@ def main():
         out['cases'].append({'batch': B, 'frames': frames, 'audio_seconds': audio_s, 'p50_ms': p50 * 1e3,
                              'p90_ms': p90 * 1e3, 'rtf_p50': p50 / audio_s,
                              'mel_frames_per_s': frames / p50})
+    if args.cpu:
+        # reference-restatement CPU baseline (TF2 unavailable offline): oracle.call(training=False), fp32,
+        # attention maps materialised like the reference, batch 1, same sentence shape
+        from oracle import ft_oracle as fo
+        torch.set_num_threads(bench.usable_cpus())
+        ocfg = {k: v for k, v in cfg.items() if k not in ('device', 'seed', 'precision')}
+        om = fo.ForwardTransformerOracle(ocfg, fo.init_weights(ocfg, seed=0), torch.float32)
+        tok1 = rng.integers(1, 127, size=(1, args.phonemes)).astype(np.int32)
+        dur1 = rng.multinomial(int(4.5 * args.phonemes), np.ones(args.phonemes) / args.phonemes, size=1).astype(np.int32)
+        with torch.no_grad():
+            om.call(tok1, target_durations=dur1[..., None])
+            t0 = time.perf_counter()
+            n = 3
+            for _ in range(n):
+                o = om.call(tok1, target_durations=dur1[..., None])
+            dt = (time.perf_counter() - t0) / n
+        frames = int(4.5 * args.phonemes)
+        out['cpu_baseline'] = {'batch': 1, 'latency_ms': dt * 1e3, 'rtf': dt / (frames * 256 / 22050.0),
+                               'cores': bench.usable_cpus(), 'kind': 'port',
+                               'sample': f'{n} calls of the torch-CPU fp32 restatement of predict (models.py:559-577)'}
     print(json.dumps(out))
 
 
