@@ -183,15 +183,26 @@ def instrumented_step(step_fn):
     recs = []
     main_stream = torch.cuda.current_stream().cuda_stream
 
+    ext = {}
+
     def hook(name, args, fn):
         if name.endswith('_ws_bytes') or name in ('ttsmi_last_error', 'ttsmi_version'):
             return fn(*args)
+        # the launch stream is the entry point's last argument (the weight gradients pass the side
+        # stream's handle explicitly while torch's current stream stays the main one)
+        h = args[-1] if isinstance(args[-1], int) else None
+        side = h is not None and h != main_stream
+        st = None
+        if side:
+            st = ext.get(h)
+            if st is None:
+                st = ext[h] = torch.cuda.ExternalStream(h)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(st) if st is not None else e0.record()
         rc = fn(*args)
-        e1.record()
+        e1.record(st) if st is not None else e1.record()
         fam = kernel_family(name, args)
-        if torch.cuda.current_stream().cuda_stream != main_stream:
+        if side or torch.cuda.current_stream().cuda_stream != main_stream:
             fam += SIDE           # weight-gradient launches on the second HIP stream overlap the main stream
         key = tuple(x for x in args if isinstance(x, int) and not isinstance(x, bool) and 0 <= x < (1 << 26))
         recs.append((fam, name, _flops(name, args), _bytes(name, args), key, e0, e1))
