@@ -230,6 +230,7 @@ int ttsmi_step_increment(int64_t* step_dev, ttsmi_stream_t stream);
  * wav: concatenated float32 clips, clip c = wav[clip_off[c] .. clip_off[c+1]);
  * out: concatenated [frames, n_mels] float32, clip c at rows frame_off[c] .. frame_off[c+1]),
  *      frames_c = 1 + len_c / hop (center=True, reflect padding n_fft/2).
+ * n_fft: 1024 (MelGAN / LJSpeech config) or 2048 (WaveRNN config, config/data_config_wavernn.yaml:16-23).
  * window [n_fft] float32 (periodic Hann of win_length centred in n_fft - built by the caller);
  * mel filterbank in CSR-by-row form: for mel m, bins mel_lo[m] .. mel_lo[m]+mel_cnt[m]) with
  * weights mel_w[mel_ptr[m] ..].  normalizer: 0 = MelGAN log(clip(S, clip_min)),

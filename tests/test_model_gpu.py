@@ -243,7 +243,29 @@ def test_mel_analytic_and_wavernn_normalizer():
     want = mo.mel_spectrogram(y, normalizer='WaveRNN')
     assert np.abs(got - want).max() < 2e-3             # dB-domain normalisation (range [-4, 4])
     with pytest.raises(Exception):
-        _audio(n_fft=2048, win_length=1100, hop_length=275).mel_spectrogram(y)
+        _audio(n_fft=512, win_length=512, hop_length=128).mel_spectrogram(y)     # only 1024 / 2048 are built
+
+
+def test_mel_wavernn_audio_config_n_fft_2048():
+    """config/data_config_wavernn.yaml:16-23: n_fft 2048, hop 275, win 1100 (zero-padded, centred), fmin 40,
+    fmax sr/2, dB normaliser - the 1024-point complex FFT runs as a radix-2 stage + two 512-point transforms."""
+    kw = dict(n_fft=2048, win_length=1100, hop_length=275, f_min=40, f_max=None)
+    lens = [30000, 51234, 2750, 1100 * 3 + 7]                # incl. len % hop == 0
+    clips = [mo.synthetic_clip(n, seed=10 + i) for i, n in enumerate(lens)]
+    for norm, tol_log in (('MelGAN', 2e-4), ('WaveRNN', 2e-3)):
+        audio = _audio(normalizer=norm, **kw)
+        mel, frame_off = audio.mel_spectrogram_batch(clips)
+        mel = mel.cpu().numpy()
+        assert mel.shape == (sum(1 + n // 275 for n in lens), 80)
+        for i, y in enumerate(clips):
+            got = mel[frame_off[i]:frame_off[i + 1]]
+            want = mo.mel_spectrogram(y, sampling_rate=22050, n_fft=2048, mel_channels=80, hop_length=275,
+                                      win_length=1100, f_min=40, f_max=None, normalizer=norm)
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() < tol_log
+            if norm == 'MelGAN':
+                assert np.abs(np.exp(got.astype(np.float64)) - np.exp(want.astype(np.float64))).max() \
+                    / np.exp(want.astype(np.float64)).max() < TOL
 
 
 # ---------------------------------------------------------------------------------------- bf16 path

@@ -1,8 +1,11 @@
 // wav -> reflect-padded frames -> periodic-Hann window -> 1024-pt real FFT -> |.| -> sparse Slaney
 // mel filterbank -> clip + log, as ONE batched kernel (data/audio.py:72-92,209-242).
 //
-// One wave64 owns one frame.  The 1024-pt real FFT is a 512-pt complex FFT of z[n] = x[2n] + i x[2n+1]
-// done as three radix-8 Stockham passes (512 = 8^3): each lane keeps 8 complex points in registers
+// One wave64 owns one frame.  The n_fft-point real FFT is an (n_fft/2)-point complex FFT of
+// z[n] = x[2n] + i x[2n+1].  n_fft = 1024 (MelGAN / LJSpeech config): one 512-point transform done as
+// three radix-8 Stockham passes (512 = 8^3).  n_fft = 2048 (WaveRNN config, data_config_wavernn.yaml): a
+// radix-2 decimation-in-frequency stage in registers splits the 1024 points into two 512-point
+// transforms (even / odd output bins) that run through the same three passes.  In each 512-point transform each lane keeps 8 complex points in registers
 // per pass, the two inter-pass exchanges go through a per-wave 4 KB LDS buffer, twiddles come from
 // an LDS table of exp(-2 pi i k / 1024) built once per workgroup with sincospi.  The magnitude
 // spectrum (513 bins) stays in LDS; the mel filterbank is applied in its sparse form (each filter
@@ -14,8 +17,7 @@
 
 #include "common.h"
 
-#define NFFT 1024
-#define NC 512          // complex points
+#define SUBN 512        // complex points of one radix-8^3 sub-transform
 #define FR_PER_WG 4     // waves per workgroup = frames in flight
 // The FFT exchange buffers are PRIVATE to a wave: what the passes need between a wave's LDS writes and
 // its own later reads is ordering, not a workgroup barrier (LDS executes one wave's accesses in
@@ -26,12 +28,12 @@
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
         __builtin_amdgcn_wave_barrier();                         \
     } while (0)
-#define MELW_MAX 1536
+#define MELW_MAX 2304
 #define MELS_MAX 128
 #define MEL_IT 12         // weights per mel work item
-#define MEL_ITEMS 128     // LDS item-table capacity (LJSpeech bank: 105 items)
 #define ZP(i) ((i) + ((i) >> 3))   // one pad slot per 8 complex points: the radix-8 scatter of pass 1
                                   // (lane stride 8 points) then lands on 16 distinct banks
+#define ZBUF (SUBN + SUBN / 8 + 8) // padded float2 slots of one sub-transform buffer
 
 struct MelP {
     const float* wav; const int64_t* clip_off; const int64_t* frame_off;
@@ -90,12 +92,61 @@ __device__ __forceinline__ int clip_of_frame(const int64_t* frame_off, int n_cli
     return lo;
 }
 
-__global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
-    __shared__ float2 tw[NFFT];                       // exp(-2 pi i k / 1024)
-    __shared__ float2 buf[FR_PER_WG][NC + NC / 8 + 8];   // padded: physical index = i + (i >> 3)
-    __shared__ float mag[FR_PER_WG][NC + 8 + MEL_IT];      // bins 513.. stay 0 (mel items may read past 512)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One 512-point complex FFT of the values u[r] = z[lane + 64 r] (three radix-8 Stockham passes, two
+// exchanges through the wave-private buffer zb); the result is left in natural order in zb[ZP(k)].
+// tw is the table exp(-2 pi i k / N); TS = N / 512 scales a 512-point twiddle index into it.
+template <int N>
+__device__ __forceinline__ void fft512(float2 (&u)[8], float2* zb, const float2* tw, int lane, bool full) {
+    constexpr int TS = N / SUBN;
     const int rev[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    // ---- pass 1 (p = 1): lane i holds z[i + 64 r], r = 0..7 ---------------------------------
+    fft8(u);
+    {
+        int j = lane << 3;                            // k = 0
+#pragma unroll
+        for (int r = 0; r < 8; ++r) zb[ZP(j + r)] = u[rev[r]];
+    }
+    WAVE_SYNC();
+    // ---- pass 2 (p = 8) --------------------------------------------------------------------
+    if (full) {
+        int k = lane & 7, j = ((lane - k) << 3) + k;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float2 x = zb[ZP(lane + 64 * r)];
+            u[r] = r ? cmul(x, tw[(TS * 8 * k * r) & (N - 1)]) : x;
+        }
+        WAVE_SYNC();
+        fft8(u);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) zb[ZP(j + r * 8)] = u[rev[r]];
+    }
+    WAVE_SYNC();
+    // ---- pass 3 (p = 64) -------------------------------------------------------------------
+    if (full) {
+        int k = lane;                                  // j = k
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float2 x = zb[ZP(lane + 64 * r)];
+            u[r] = r ? cmul(x, tw[(TS * k * r) & (N - 1)]) : x;
+        }
+        WAVE_SYNC();
+        fft8(u);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) zb[ZP(k + r * 64)] = u[rev[r]];
+    }
+    WAVE_SYNC();
+}
+
+template <int NFFT>
+__global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
+    constexpr int NC = NFFT / 2;                // complex points
+    constexpr int NSUB = NC / SUBN;             // 512-point sub-transforms per frame (1 or 2)
+    constexpr int PPL = NC / 64;                // complex points per lane
+    constexpr int MEL_ITEMS = NFFT == 1024 ? 128 : 256;   // LDS item-table capacity (LJSpeech bank: 105 items)
+    __shared__ float2 tw[NFFT];                       // exp(-2 pi i k / NFFT)
+    __shared__ float2 buf[FR_PER_WG][NSUB][ZBUF];     // padded: physical index = i + (i >> 3)
+    __shared__ float mag[FR_PER_WG][NC + 8 + MEL_IT];      // bins NC+1.. stay 0 (mel items may read past NC)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int k = tid; k < NFFT; k += 256) {
         float s, c;
@@ -148,13 +199,13 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     const int n_items = mel_in_lds ? itFirst[p.n_mels] : 0;
     const bool mel_items = mel_in_lds && n_items <= MEL_ITEMS;
 
-    float2* zb = buf[wave];
+    float2* zb = buf[wave][0];
     float* mg = mag[wave];
     for (int i = NC + 1 + lane; i < NC + 8 + MEL_IT; i += 64) mg[i] = 0.f;
-    // the lane's 16 window taps never change: keep them in registers
-    float2 win[8];
+    // the lane's 2 * PPL window taps never change: keep them in registers
+    float2 win[PPL];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < PPL; ++r) {
         int n = 2 * (lane + 64 * r);
         win[r] = make_float2(p.window[n], p.window[n + 1]);
     }
@@ -162,9 +213,9 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     int cur = -1;
     long cur_f0 = 0, cur_f1 = 0, cur_base = 0;
     int cur_L = 1;
-    // raw samples of frame f -> x[8] (pairs z[i + 64 r]); issued one iteration ahead of their use so
+    // raw samples of frame f -> x[PPL] (pairs z[i + 64 r]); issued one iteration ahead of their use so
     // the HBM/L2 latency of frame g+1 hides under the FFT of frame g
-    auto load_frame = [&](long f, float2 (&x)[8]) {
+    auto load_frame = [&](long f, float2 (&x)[PPL]) {
         const bool act = (f < p.total_frames) && !(p.ablate & 1);
         long base = 0;
         int L = 1, t = 0;
@@ -184,11 +235,11 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         if (act && start >= 0 && start + NFFT <= L) {     // wave-uniform: an interior frame needs no reflection
             const float* src = p.wav + base + start + 2 * lane;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) x[r] = make_float2(src[128 * r], src[128 * r + 1]);
+            for (int r = 0; r < PPL; ++r) x[r] = make_float2(src[128 * r], src[128 * r + 1]);
             return;
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < PPL; ++r) {
             int n = 2 * (lane + 64 * r);
             float v[2];
 #pragma unroll
@@ -203,63 +254,47 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         }
     };
     const long f_first = (long)blockIdx.x * p.groups_per_wg * FR_PER_WG + wave;
-    float2 xs[8];
+    float2 xs[PPL];
     load_frame(f_first, xs);
     for (int g = 0; g < p.groups_per_wg; ++g) {
         const long f = f_first + (long)g * FR_PER_WG;
         const bool active = f < p.total_frames;
-        float2 u[8];
-        // ---- pass 1 (p = 1): lane i holds z[i + 64 r], r = 0..7 ---------------------------------
+        float2 w[PPL];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) u[r] = make_float2(xs[r].x * win[r].x, xs[r].y * win[r].y);
+        for (int r = 0; r < PPL; ++r) w[r] = make_float2(xs[r].x * win[r].x, xs[r].y * win[r].y);
         if (g + 1 < p.groups_per_wg) load_frame(f + FR_PER_WG, xs);
-        fft8(u);
-        {
-            int j = lane << 3;                            // k = 0
-#pragma unroll
-            for (int r = 0; r < 8; ++r) zb[ZP(j + r)] = u[rev[r]];
-        }
-        WAVE_SYNC();
-        // ---- pass 2 (p = 8) --------------------------------------------------------------------
-        if (!(p.ablate & 4)) {
-            int k = lane & 7, j = ((lane - k) << 3) + k;
+        const bool full = !(p.ablate & 4);
+        if constexpr (NSUB == 1) {
+            fft512<NFFT>(w, zb, tw, lane, full);           // Z[k] in zb[ZP(k)]
+        } else {
+            // radix-2 DIF stage in registers: z[n] and z[n + 512] sit in the same lane (r and r + 8);
+            //   even bins Z[2k]   = FFT512(z[n] + z[n+512])
+            //   odd  bins Z[2k+1] = FFT512((z[n] - z[n+512]) * exp(-2 pi i n / 1024))
+            float2 ua[8], ub[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                float2 x = zb[ZP(lane + 64 * r)];
-                u[r] = r ? cmul(x, tw[(16 * k * r) & (NFFT - 1)]) : x;
+                ua[r] = cadd(w[r], w[r + 8]);
+                ub[r] = cmul(csub(w[r], w[r + 8]), tw[2 * (lane + 64 * r)]);   // exp(-2 pi i n/1024) = tw2048[2n]
             }
-            WAVE_SYNC();
-            fft8(u);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) zb[ZP(j + r * 8)] = u[rev[r]];
+            fft512<NFFT>(ua, buf[wave][0], tw, lane, full);
+            fft512<NFFT>(ub, buf[wave][NSUB - 1], tw, lane, full);
         }
-        WAVE_SYNC();
-        // ---- pass 3 (p = 64) -------------------------------------------------------------------
-        if (!(p.ablate & 4)) {
-            int k = lane;                                  // j = k
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float2 x = zb[ZP(lane + 64 * r)];
-                u[r] = r ? cmul(x, tw[(2 * k * r) & (NFFT - 1)]) : x;
-            }
-            WAVE_SYNC();
-            fft8(u);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) zb[ZP(k + r * 64)] = u[rev[r]];
-        }
-        WAVE_SYNC();
-        // ---- real-FFT post-processing: |X[k]|, k = 0..512 -------------------------------------
-        // X[k] = (e - i w o)/2 with e = Z[k] + conj(Z[512-k]), o = Z[k] - conj(Z[512-k]), w = exp(-2 pi i k/1024);
-        // the mirror bin shares everything: X[512-k] = (conj(e) - i conj(w o))/2.  One pass over k = 0..256
-        // yields both magnitudes (half the LDS reads and complex multiplies of a pass over all 513 bins).
+        auto Z = [&](int k) -> float2 {                    // k in [0, NC)
+            if constexpr (NSUB == 1) return zb[ZP(k)];
+            else return buf[wave][k & 1][ZP(k >> 1)];
+        };
+        // ---- real-FFT post-processing: |X[k]|, k = 0..NC ---------------------------------------
+        // X[k] = (e - i w o)/2 with e = Z[k] + conj(Z[NC-k]), o = Z[k] - conj(Z[NC-k]), w = exp(-2 pi i k/NFFT);
+        // the mirror bin shares everything: X[NC-k] = (conj(e) - i conj(w o))/2.  One pass over k = 0..NC/2
+        // yields both magnitudes (half the LDS reads and complex multiplies of a pass over all bins).
         for (int k = lane; k <= NC / 2 && !(p.ablate & 8); k += 64) {
-            float2 zk = zb[ZP(k)];
-            float2 zc = zb[ZP((NC - k) & (NC - 1))];
+            float2 zk = Z(k);
+            float2 zc = Z((NC - k) & (NC - 1));
             zc.y = -zc.y;
             float2 e = cadd(zk, zc), o = csub(zk, zc);
             float2 wo = cmul(tw[k], o);
             float xr = e.x + wo.y, xi = e.y - wo.x;            // 2 X[k]
-            float yr = e.x - wo.y, yi = e.y + wo.x;            // 2 conj-mirrored X[512-k]
+            float yr = e.x - wo.y, yi = e.y + wo.x;            // 2 conj-mirrored X[NC-k]
             mg[k] = 0.5f * sqrtf(xr * xr + xi * xi);
             mg[NC - k] = 0.5f * sqrtf(yr * yr + yi * yi);
         }
@@ -322,8 +357,8 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
                         mel_w && out, "stft_logmel: null pointer");
     TTSMI_CHECK_ARG(n_clips > 0 && total_frames > 0 && hop > 0 && n_mels > 0,
                     "stft_logmel: bad shape");
-    if (n_fft != NFFT) {
-        ttsmi_set_error("stft_logmel: n_fft=%d not built (only %d)", n_fft, NFFT);
+    if (n_fft != 1024 && n_fft != 2048) {
+        ttsmi_set_error("stft_logmel: n_fft=%d not built (1024 and 2048 are)", n_fft);
         return TTSMI_ERR_UNSUPPORTED;
     }
     TTSMI_CHECK_ARG(normalizer == 0 || normalizer == 1, "stft_logmel: unknown normalizer %d", normalizer);
@@ -338,8 +373,10 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
     while (gpw < 16 && groups / (gpw * 2) >= 2048) gpw *= 2;   // amortise the twiddle build
     p.groups_per_wg = gpw;
     long blocks = (groups + gpw - 1) / gpw;
-    hipLaunchKernelGGL(stft_logmel_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    if (n_fft == 1024)
+        hipLaunchKernelGGL(stft_logmel_kernel<1024>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(stft_logmel_kernel<2048>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("stft_logmel");
     return TTSMI_OK;
 }
