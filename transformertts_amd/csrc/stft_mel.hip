@@ -28,7 +28,6 @@
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
         __builtin_amdgcn_wave_barrier();                         \
     } while (0)
-#define MELW_MAX 2304
 #define MELS_MAX 128
 #define MEL_IT 12         // weights per mel work item
 #define ZP(i) ((i) + ((i) >> 3))   // one pad slot per 8 complex points: the radix-8 scatter of pass 1
@@ -143,6 +142,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     constexpr int NSUB = NC / SUBN;             // 512-point sub-transforms per frame (1 or 2)
     constexpr int PPL = NC / 64;                // complex points per lane
     constexpr int MEL_ITEMS = NFFT == 1024 ? 128 : 256;   // LDS item-table capacity (LJSpeech bank: 105 items)
+    constexpr int MELW_MAX = NFFT == 1024 ? 1536 : 2304;  // LDS copy of the sparse weights (<= 2 per bin)
     __shared__ float2 tw[NFFT];                       // exp(-2 pi i k / NFFT)
     __shared__ float2 buf[FR_PER_WG][NSUB][ZBUF];     // padded: physical index = i + (i >> 3)
     __shared__ float mag[FR_PER_WG][NC + 8 + MEL_IT];      // bins NC+1.. stay 0 (mel items may read past NC)
