@@ -152,6 +152,32 @@ def test_reference_default_head_dim_192_conv_blocks():
     _adam_weights_close(m, ref, want['grads'])
 
 
+def test_conv_blocks_bf16_path_tracks_oracle():
+    """Conv blocks on the bf16 implicit-GEMM path (forward, dgrad with fused ReLU', wgrad_rows with the conv
+    window) at the reference-default channel counts; dh = 192 keeps the exact-fp32 attention kernels."""
+    cfg = fo.make_config(d_model=384, enc_heads=(2,), dec_heads=(2,), ffn=1536, enc_dense_blocks=0,
+                         dec_dense_blocks=0, conv_filters=(1536, 384), dur_filters=(256, 226),
+                         pitch_filters=(256, 226))
+    W = fo.init_weights(cfg, seed=4, perturb=0.02)
+    batch = fo.synthetic_batch(2, 21, 90, seed=6, ragged=True)
+    ref = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    ref.learning_rate = 1e-3
+    want = ref.train_step(*batch)
+    m = _model(cfg, W, precision='bf16')
+    assert any('conv' in k for k in m.shadow)
+    m._compile(learning_rate=1e-3)
+    got = m.train_step(*batch)
+    assert abs(float(got['loss']) - float(want['loss'])) / float(want['loss']) < 5e-3
+    assert _rel(got['mel'], want['mel']) < 3e-2
+    g = m.grads_dict()
+    # decoder-side conv gradients to bf16 accuracy; the encoder side of this 2 x 21-token batch carries 4-7 %
+    # bf16 noise on EVERY parameter (dense projections included), so it only gets a sanity bound
+    for name, tol in (('dec.blk0.conv0.w', 3e-2), ('dec.blk0.conv1.w', 3e-2), ('dec.blk0.conv1.b', 3e-2),
+                      ('enc.blk0.conv0.w', 0.15), ('enc.blk0.conv1.w', 0.15)):
+        a, b = torch.as_tensor(g[name]).double(), torch.as_tensor(np.asarray(want['grads'][name])).double()
+        assert (a - b).norm() / b.norm() < tol, name
+
+
 def test_predict_matches_oracle(tiny):
     cfg, W = tiny
     W = dict(W)

@@ -133,7 +133,7 @@ def test_ffn_and_convstack_autograd():
     B, T, C, Fh = 2, 40, 32, 96
     x, w0, b0, w1, b1 = g(B, T, C, seed=1), g(3, C, Fh, seed=2, scale=0.2), g(Fh, seed=3), g(3, Fh, C, seed=4, scale=0.2), g(C, seed=5)
     ts = [t.to(DEV).requires_grad_() for t in (x, w0, b0, w1, b1)]
-    y = ops.ConvStackFn.apply(ts[0], 2, *ts[1:])
+    y = ops.ConvStackFn.apply(ts[0], 2, None, *ts[1:])
     dy = g(B, T, C, seed=6)
     y.backward(dy.to(DEV))
     td = [t.double().requires_grad_() for t in (x, w0, b0, w1, b1)]

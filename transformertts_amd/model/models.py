@@ -198,7 +198,7 @@ class ForwardTransformer:
             leaf = name.split('.')[-1]
             if leaf in ('wqkv', 'wo', 'w1', 'w2') or name == 'out.w':
                 yield name
-            elif leaf == 'w' and w.dim() == 3 and name.split('.')[0] in ('dur', 'pitch'):
+            elif leaf == 'w' and w.dim() == 3:          # Conv1D weights: predictors and conv blocks
                 yield name
 
     def _build_shadows(self):
@@ -353,7 +353,8 @@ class ForwardTransformer:
                 for j in range(n):
                     ps += [W[f'{p}.conv{j}.w'], W[f'{p}.conv{j}.b']]
                     gs += [G[f'{p}.conv{j}.w'], G[f'{p}.conv{j}.b']]
-                f = ops.ConvStackFn.apply(a.reshape(B, T, d), n, *ps, *gs).reshape(M, d)
+                shs = tuple(S(f'{p}.conv{j}.w') for j in range(n))
+                f = ops.ConvStackFn.apply(a.reshape(B, T, d), n, shs, *ps, *gs).reshape(M, d)
             h = ops.add_layernorm(f, a, W[f'{p}.ln2.gamma'], W[f'{p}.ln2.beta'], G[f'{p}.ln2.gamma'],
                                   G[f'{p}.ln2.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop)
         return h.reshape(B, T, d), attn

@@ -571,20 +571,36 @@ class FFNFn(torch.autograd.Function):
 
 class ConvStackFn(torch.autograd.Function):
     """conv -> relu -> ... -> conv (no activation after the last): CNNResNorm.call_convs +
-    last_conv, model/layers.py:30-38.  x [B,T,C].  params = (w0,b0,w1,b1,...), sinks likewise."""
+    last_conv, model/layers.py:30-38.  x [B,T,C].  params = (w0,b0,w1,b1,...), sinks likewise.
+    shadows (tuple of ops.Shadow or None per layer, TTSMI_BF16): the convs run as bf16 implicit GEMMs
+    (forward: window over x with W^T; dgrad: window over dy with the flipped-tap layout `wd`, ReLU' of
+    the producing layer fused; wgrad: wgrad_rows with the conv window) - fp32 activations throughout."""
 
     @staticmethod
-    def forward(ctx, x, n_layers, *args):
+    def forward(ctx, x, n_layers, shadows, *args):
         x = _c(x)
         params, sinks = args[:2 * n_layers], args[2 * n_layers:]
+        B, T, _ = x.shape
         acts = [x]
         h = x
+        use_h = []
         for j in range(n_layers):
-            h = conv1d_fwd(h, params[2 * j], params[2 * j + 1], relu=(j < n_layers - 1))
+            w, b = params[2 * j], params[2 * j + 1]
+            k, cin, cout = w.shape
+            sh = shadows[j] if shadows else None
+            ok = sh is not None and cin % 8 == 0
+            use_h.append(ok)
+            if ok:
+                h = hgemm_tn(h.reshape(B * T, cin), sh.wt, b, relu=(j < n_layers - 1),
+                             conv=(k, T, cin, (k - 1) // 2)).reshape(B, T, cout)
+            else:
+                h = conv1d_fwd(h, w, b, relu=(j < n_layers - 1))
             acts.append(h)
         ctx.n = n_layers
         ctx.save_for_backward(*acts[:-1], *params[0::2])
         ctx.sinks = sinks
+        ctx.shadows = shadows
+        ctx.use_h = use_h
         return h
 
     @staticmethod
@@ -596,12 +612,30 @@ class ConvStackFn(torch.autograd.Function):
         outs = [None] * (2 * n)
         for j in reversed(range(n)):
             gw, gb = (sinks[2 * j], sinks[2 * j + 1]) if sinks else (None, None)
-            dw, db = _sink(gw, ws[j]), _sink(gb, g[0, 0])
-            conv1d_wgrad(acts[j], g, dw, db)
+            w = ws[j]
+            k, cin, cout = w.shape
+            B, T, _ = acts[j].shape
+            dw, db = _sink(gw, w), _sink(gb, g[0, 0])
+            relu_src = acts[j] if j > 0 else None
+            if ctx.use_h[j]:
+                sh = ctx.shadows[j]
+                x2, g2 = acts[j].reshape(B * T, cin), g.reshape(B * T, cout)
+                if cin % 128 == 0 and cout % 4 == 0:
+                    wgrad_rows_async(x2, g2, dw.reshape(k * cin, cout), db, conv=(k, T, cin, (k - 1) // 2))
+                else:
+                    xT = cast_transpose_bf16(x2, taps=k, T=T, pad=(k - 1) // 2)
+                    hgemm_wgrad(xT, cast_transpose_bf16(g2), dw.reshape(k * cin, cout), db, B * T)
+                cp = _pad8(cout)
+                if cp != cout:
+                    g2 = torch.nn.functional.pad(g2, (0, cp - cout))
+                g = hgemm_tn(g2, sh.wd, relu_src=None if relu_src is None else relu_src.reshape(B * T, cin),
+                             conv=(k, T, cp, k - 1 - (k - 1) // 2)).reshape(B, T, cin)
+            else:
+                conv1d_wgrad(acts[j], g, dw, db)
+                g = conv1d_dgrad(g, w, relu_src=relu_src)
             outs[2 * j] = None if gw is not None else dw
             outs[2 * j + 1] = None if gb is not None else db
-            g = conv1d_dgrad(g, ws[j], relu_src=(acts[j] if j > 0 else None))
-        return (g, None, *outs, *([None] * len(sinks)))
+        return (g, None, None, *outs, *([None] * len(sinks)))
 
 
 class AddLayerNormFn(torch.autograd.Function):
