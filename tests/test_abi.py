@@ -59,7 +59,7 @@ def test_invalid_arguments_return_error_codes_not_crashes(built):
     one = ctypes.c_void_p(16)
     rc = l.ttsmi_linear_fwd(one, 4, None, 0, 0, one, 4, None, one, 4, 4, 4, 4, 0, 7, None)
     assert rc == -1 and b'dtype' in l.ttsmi_last_error()
-    rc = l.ttsmi_stft_logmel(one, one, one, 1, 1, 2048, 256, one, 80, one, one, one, one, 0, 1e-5, one, None)
+    rc = l.ttsmi_stft_logmel(one, one, one, 1, 1, 512, 256, one, 80, one, one, one, one, 0, 1e-5, one, None)
     assert rc == -3 and b'n_fft' in l.ttsmi_last_error()
     assert l.ttsmi_linear_wgrad_ws_bytes(28800, 1024, 256) > 0
 
