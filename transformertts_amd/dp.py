@@ -6,8 +6,8 @@ and Adam state are replicated, every rank applies the identical fused Adam step.
 
 Loss normalisation: each rank's L1 losses are means over ITS [B_local, T_max, C] block.  With equal
 per-rank shapes (how the trainer forms a global batch: one bucket, split evenly) the average of the
-per-rank gradients equals the gradient of the global-batch mean, so the all-reduce uses AVG (SUM
-followed by 1/world on backends without AVG, e.g. gloo in the CPU tests).
+per-rank gradients equals the gradient of the global-batch mean, so the all-reduce is a SUM followed by
+one 1/world scaling pass.
 
 The gradient buffer is a single contiguous tensor, so the collective is one large message: on the
 xGMI full mesh RCCL can spread it over all 7 links per GPU (direct reduce-scatter + all-gather)
@@ -53,7 +53,9 @@ class GradAllReduce:
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.use_avg = dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        # SUM + one 1/world scaling pass on every backend: ReduceOp.AVG is NCCL-only and not worth a
+        # backend-dependent code path (the scaling pass is one 44 MB stream, ~15 us)
+        self.use_avg = False
         self.overlap = dist.is_initialized() and os.environ.get('TTSMI_DP_OVERLAP', '1') != '0'
         self._tail = None                   # (work handle, split) of the in-flight decoder bucket
         self._launch_stream = None
