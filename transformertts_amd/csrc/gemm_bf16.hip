@@ -288,6 +288,209 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
 
 
 // =================================================================================================
+// LDS-DMA persistent variant of the TN GEMM (bf16 A, K % 64 == 0): c[M,N] (+)= act(a.b^T + bias).mask
+//
+//  * tiles arrive by `global_load_lds_dwordx4` (gfx950 LDS-DMA): a wave instruction moves 64 x 16 B straight
+//    from global memory into 1 KB of LDS - no staging registers, so a whole k-tile (32 KB) is in flight per
+//    workgroup while the previous one is multiplied, and the NEXT TILE's first k-tile is in flight under
+//    the epilogue (persistent tile loop) without costing a single live register.  That is what the
+//    register-staged kernel above cannot do: its stage ablation shows ~1/3 of a short-K launch is the
+//    cold-start fetch every workgroup exposes, and prefetching the next tile through registers spilled.
+//  * the DMA image is lane-linear (lane i -> base + 16 i; placement pinned by tools/probes/lds_dma_probe.hip),
+//    i.e. dense 128-byte rows [row][8 chunks of 8 bf16].  Dense rows would make the ds_read_b128 fragment
+//    reads 8-way bank conflicted, so chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7): the
+//    swizzle costs nothing on the load side (each lane just fetches a different global chunk) and makes
+//    every b128 lane group hit 16 distinct 16-byte slots.
+//  * two 32 KB stages (64 KB LDS, 2 workgroups per CU), ONE barrier per k-step (vmcnt(0) + barrier publishes
+//    the stage that was in flight and retires the one just read); rows past M / N are clamped to the last
+//    valid row on the load side and dropped at the store.
+// =================================================================================================
+#define DBM 128
+#define DBN 128
+#define DSTAGE ((DBM + DBN) * HBK_ * 2)           // bytes per stage: A image then B image
+#define DPLD 68                                    // fp32 row stride of the per-wave epilogue patch [16][64+4]
+// a patch is private to its wave: wave-scope ordering is all its write -> read hand-off needs
+#define HWAVE_SYNC()                                             \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
+    static_assert(HBK_ == 64, "the swizzled image assumes 8 chunks of 8 bf16 per row");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
+    typedef __attribute__((address_space(1))) const void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int kend = p.K;
+    const int nk = p.K / HBK_;
+    // persistent tile walk (see gemm_bf16_kernel's XCD note): XCD x owns tiles [base, base + len)
+    const int T = p.tiles_m * p.tiles_n;
+    const int nx = 8, xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+    const int per = (gridDim.x + nx - 1 - xcd) / nx;
+    const int tq = T / nx, tr = T % nx;
+    const int len = tq + (xcd < tr ? 1 : 0);
+    const int base = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+
+    const uint16_t* A = (const uint16_t*)p.A;
+    const uint16_t* A2 = (const uint16_t*)p.A2;
+    // this lane's place in a DMA wave instruction: 8 rows x 8 chunk positions
+    const int drow = lane >> 3, dpos = lane & 7;
+    auto issue = [&](int m0, int n0, int k0, int st) {
+        unsigned char* As = smem + st * DSTAGE;
+        unsigned char* Bs = As + DBM * HBK_ * 2;
+        const uint16_t* Ab = A;
+        long lda = p.lda;
+        int ka = k0;
+        if (A2 != nullptr && k0 >= p.K1) { Ab = A2; lda = p.lda2; ka = k0 - p.K1; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + drow;
+            const int c = dpos ^ ((row >> 1) & 7);
+            const int gm = min(m0 + row, p.M - 1);
+            __builtin_amdgcn_global_load_lds((gptr)(Ab + (long)gm * lda + ka + c * 8),
+                                             (lptr)(As + (wave * 32 + i * 8) * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + drow;
+            const int c = dpos ^ ((row >> 1) & 7);
+            const int gn = min(n0 + row, p.N - 1);
+            __builtin_amdgcn_global_load_lds((gptr)(p.B + (long)gn * p.ldb + k0 + c * 8),
+                                             (lptr)(Bs + (wave * 32 + i * 8) * 128), 16, 0, 0);
+        }
+    };
+    int st = 0;
+    if (slot < len) {
+        const int t0 = base + slot;
+        issue((t0 / p.tiles_n) * DBM, (t0 % p.tiles_n) * DBN, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    for (int ti = slot; ti < len; ti += per) {
+        const int tile = base + ti;
+        const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+        const int m0 = tm * DBM, n0 = tn * DBN;
+        const bool has_next = (ti + per) < len;
+        const int tnext = tile + per;
+        const int m0n = (tnext / p.tiles_n) * DBM, n0n = (tnext % p.tiles_n) * DBN;
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int ks = 0; ks < nk; ++ks) {
+            const bool more = ks + 1 < nk;
+            if (more) issue(m0, n0, (ks + 1) * HBK_, st ^ 1);
+            else if (has_next) issue(m0n, n0n, 0, st ^ 1);          // next tile's first k-tile, under the epilogue
+            const unsigned char* As = smem + st * DSTAGE;
+            const unsigned char* Bs = As + DBM * HBK_ * 2;
+#pragma unroll
+            for (int kk = 0; kk < HBK_ / 16; ++kk) {
+                const int c = kk * 2 + kg;
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = wr * 64 + i * 32 + l31;
+                    a[i] = *reinterpret_cast<const bf16x8*>(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wc * 64 + j * 32 + l31;
+                    b[j] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0);        // this wave's DMA pieces of the next stage have landed
+            __syncthreads();                      // ... everybody's have, and nobody still reads stage `st`
+            st ^= 1;
+        }
+        // ---- epilogue: the stage just consumed (st ^ 1) is free - its first 17 KB hold the four per-wave patches
+        float* patch = reinterpret_cast<float*>(smem + (st ^ 1) * DSTAGE) + wave * 16 * DPLD;
+        const long ldc = p.ldc;
+        const bool vec = ((ldc & 3) == 0) && ((p.N & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0);
+        const int rl = lane >> 4, c4 = lane & 15;
+        const int col = n0 + wc * 64 + c4 * 4;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            if (col + 0 < p.N) bias4.x = p.bias[col + 0];
+            if (col + 1 < p.N) bias4.y = p.bias[col + 1];
+            if (col + 2 < p.N) bias4.z = p.bias[col + 2];
+            if (col + 3 < p.N) bias4.w = p.bias[col + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                 // registers 8h..8h+7 = rows 16h..16h+15 of the 32-row tile
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        patch[((r & 3) + 8 * (r >> 2) + 4 * kg) * DPLD + j * 32 + l31] = acc[i][j][8 * h + r];
+                HWAVE_SYNC();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int prow = it * 4 + rl;
+                    const int row = m0 + wr * 64 + i * 32 + h * 16 + prow;
+                    if (row >= p.M || col >= p.N) continue;
+                    float4 v = *reinterpret_cast<const float4*>(patch + prow * DPLD + c4 * 4);
+                    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    float* dst = p.C + (long)row * ldc + col;
+                    if (vec) {
+                        if (p.relu_src) {
+                            if (p.mask_bf16) {
+                                uint2 mb = *reinterpret_cast<const uint2*>((const uint16_t*)p.relu_src + (long)row * p.ld_relu + col);
+                                auto pos = [](uint32_t hh) { return ((hh & 0x8000u) == 0u) && ((hh & 0x7FFFu) != 0u); };
+                                v.x = pos(mb.x & 0xFFFFu) ? v.x : 0.f; v.y = pos(mb.x >> 16) ? v.y : 0.f;
+                                v.z = pos(mb.y & 0xFFFFu) ? v.z : 0.f; v.w = pos(mb.y >> 16) ? v.w : 0.f;
+                            } else {
+                                float4 m = *reinterpret_cast<const float4*>(p.relu_src + (long)row * p.ld_relu + col);
+                                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                                v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                            }
+                        }
+                        if (p.c_bf16) {
+                            *reinterpret_cast<uint2*>((uint16_t*)p.C + (long)row * p.ldc + col) = pack4(v);
+                            continue;
+                        }
+                        if (p.accumulate) {
+                            float4 o = *reinterpret_cast<const float4*>(dst);
+                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                        }
+                        *reinterpret_cast<float4*>(dst) = v;
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (col + e >= p.N) break;
+                            float x = vv[e];
+                            if (p.relu_src) x = p.relu_src[(long)row * p.ld_relu + col + e] > 0.f ? x : 0.f;
+                            if (p.accumulate) x += dst[e];
+                            dst[e] = x;
+                        }
+                    }
+                }
+                HWAVE_SYNC();
+            }
+        }
+        __syncthreads();          // the next step's DMA overwrites the stage the patches live in
+    }
+}
+
+// =================================================================================================
 // wgrad straight from the row-major fp32 activations: dW[K_in, N] = X[M, K_in]^T . dY[M, N].
 // Both operands are fetched as [32 rows][128 cols] tiles (coalesced 512-byte fp32 / 256-byte bf16 rows)
 // and rounded to bf16 into row-major LDS images.  The MFMA fragments need 8 consecutive REDUCTION
@@ -716,6 +919,21 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
         hipLaunchKernelGGL((gemm_bf16_kernel<false, 128, 256>), grid, dim3(256), 0, st, p);
         TTSMI_CHECK_LAUNCH(name);
         return TTSMI_OK;
+    }
+    // LDS-DMA persistent kernel (TTSMI_HGEMM_DMA=0 disables it, measurement only)
+    static int use_dma = -1;
+    if (use_dma < 0) { const char* e = getenv("TTSMI_HGEMM_DMA"); use_dma = e ? atoi(e) : 1; }
+    if (use_dma && !a_f32 && splits == 1 && p.colsum == nullptr && p.a_taps == 1 && p.K % HBK_ == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 &&
+        (p.A2 == nullptr || (p.K1 % HBK_ == 0 && p.lda2 % 8 == 0 && al16(p.A2)))) {
+        p.tiles_m = ttsmi_cdiv(p.M, DBM);
+        p.tiles_n = ttsmi_cdiv(p.N, DBN);
+        int nw = p.tiles_m * p.tiles_n;
+        if (nw >= (use_dma > 1 ? 1 : 192)) {          // under-filled launches keep the 64-row register-staged tiles
+            if (nw > 512) nw = 512;
+            hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3(nw), dim3(256), 0, st, p);
+            TTSMI_CHECK_LAUNCH(name);
+            return TTSMI_OK;
+        }
     }
     const int bm = hgemm_bm(a_f32, p.M, p.N, splits);
     p.tiles_m = ttsmi_cdiv(p.M, bm);
