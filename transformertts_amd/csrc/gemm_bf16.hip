@@ -287,6 +287,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
 }
 
 
+// One LDS-DMA instruction, emitted as inline asm ON PURPOSE: for the builtin form the compiler's waitcnt pass
+// treats every later LDS read as a possible consumer of the DMA and inserts s_waitcnt vmcnt(0) in front of
+// it - i.e. the multiply of stage s would wait for the stage that was just put in flight.  The kernels below
+// do their own vmcnt accounting (a fixed number of DMA instructions per step and nothing else on that counter
+// inside the loops).  lds_off = wave-uniform byte offset of the 1 KB destination (lane i lands at +16 i).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // =================================================================================================
 // LDS-DMA persistent variant of the TN GEMM (bf16 A, K % 64 == 0): c[M,N] (+)= act(a.b^T + bias).mask
 //
@@ -351,16 +363,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
             const int row = wave * 32 + i * 8 + drow;
             const int c = dpos ^ ((row >> 1) & 7);
             const int gm = min(m0 + row, p.M - 1);
-            __builtin_amdgcn_global_load_lds((gptr)(Ab + (long)gm * lda + ka + c * 8),
-                                             (lptr)(As + (wave * 32 + i * 8) * 128), 16, 0, 0);
+            lds_dma16(Ab + (long)gm * lda + ka + c * 8, lds_offset(As + (wave * 32 + i * 8) * 128));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave * 32 + i * 8 + drow;
             const int c = dpos ^ ((row >> 1) & 7);
             const int gn = min(n0 + row, p.N - 1);
-            __builtin_amdgcn_global_load_lds((gptr)(p.B + (long)gn * p.ldb + k0 + c * 8),
-                                             (lptr)(Bs + (wave * 32 + i * 8) * 128), 16, 0, 0);
+            lds_dma16(p.B + (long)gn * p.ldb + k0 + c * 8, lds_offset(Bs + (wave * 32 + i * 8) * 128));
         }
     };
     int st = 0;
@@ -368,8 +378,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
         const int t0 = base + slot;
         issue((t0 / p.tiles_n) * DBM, (t0 % p.tiles_n) * DBN, 0, 0);
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xF70);
+    asm volatile("s_barrier" ::: "memory");
 
     for (int ti = slot; ti < len; ti += per) {
         const int tile = base + ti;
@@ -413,8 +423,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
-            __builtin_amdgcn_s_waitcnt(0);        // this wave's DMA pieces of the next stage have landed
-            __syncthreads();                      // ... everybody's have, and nobody still reads stage `st`
+            __builtin_amdgcn_s_waitcnt(0xF70);    // vmcnt(0): this wave's DMA pieces of the next stage have landed
+            asm volatile("s_barrier" ::: "memory");   // ... everybody's have, and nobody still reads stage `st`
             st ^= 1;
         }
         // ---- epilogue: the stage just consumed (st ^ 1) is free - its first 17 KB hold the four per-wave patches
@@ -706,6 +716,148 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(WRowsP p) {
             for (int r = 0; r < 16; ++r) {
                 int row = k0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 if (row < p.K) Cb[(long)row * ldc + col] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// LDS-DMA variant of the row-major wgrad (both operands bf16, no conv window, rows % 32 == 0,
+// K_in % 128 == 0, N % 128 == 0): the 32-row tiles of X and dY arrive by global_load_lds_dwordx4 into a
+// THREE-stage ring (48 KB), two steps in flight while one is multiplied.  The register-staged kernel
+// above completes one step per memory round trip (its 24 KB of loads are issued after the barrier and
+// needed at the next one: ~1.3 us per step measured, 57 steps for the FFN weights); here a step costs its
+// MFMAs and transposing reads.  The DMA image is dense (256-byte rows), which would put the 4 rows a
+// ds_read_b64_tr_b16 group touches on the same banks; the 16-byte chunk c of row r is therefore stored at
+// chunk position c ^ ((r & 3) << 2) (load side, free), and the reads XOR their 8-byte unit index with
+// (r & 3) << 3: the 32 lanes of a read phase then cover 32 distinct units = all 64 banks.
+// vmcnt bookkeeping: a wave issues exactly 4 DMA instructions per step and nothing else on the vector
+// memory counter inside the loop, so "vmcnt(4)" = the previous step has landed, the newest may be in flight.
+// =================================================================================================
+#define WD_STAGES 3
+#define WD_STAGE_BYTES (2 * WR_ROWS * 256)        // X image then dY image, [32 rows][128 bf16]
+
+__device__ __forceinline__ bf16x8 wd_tr8(const unsigned char* img, int row, int unit) {
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    // rows row..row+3 / row+4..row+7 share (row & 3) with `row` only if row % 4 == 0 for the +4 read: they do
+    // not - the swizzle term is per supplied row, and this lane always supplies rows = row (mod 4)
+    const int swz = (row & 3) << 3;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + row * 256 + ((unit ^ swz) << 3)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + (row + 4) * 256 + ((unit ^ swz) << 3)));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WRowsP p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WD_STAGES * WD_STAGE_BYTES];
+    typedef __attribute__((address_space(1))) const void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, kg = lane >> 5;
+    const int ntiles = p.tiles_k * p.tiles_n, nsplit = gridDim.x / ntiles;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = lid % ntiles, zsplit = lid / ntiles;
+    const int tn = bid % p.tiles_n, tk = bid / p.tiles_n;
+    const int k0 = tk * 128, n0 = tn * 128;
+    const int mbeg = zsplit * p.k_per_split;
+    const int mend = min(p.M, mbeg + p.k_per_split);
+    const int nsteps = (mend - mbeg) / WR_ROWS;          // rows % 32 == 0 is a launch precondition
+
+    f32x16 acc[2][2], cs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[j][r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    const bool do_colsum = (p.colsum != nullptr) && (tk == 0) && (wr == 0);
+
+    const uint16_t* X = (const uint16_t*)p.X;
+    const uint16_t* DY = (const uint16_t*)p.DY;
+    // DMA: a wave instruction = 4 rows x 16 chunks of 16 bytes; wave w owns rows [8w, 8w + 8) of a step
+    const int drow = lane >> 4, dpos = lane & 15;
+    auto issue = [&](int step, int stage) {
+        unsigned char* Xi = smem + stage * WD_STAGE_BYTES;
+        unsigned char* Yi = Xi + WR_ROWS * 256;
+        const long m0 = mbeg + (long)step * WR_ROWS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 8 + i * 4 + drow;
+            const int c = dpos ^ ((row & 3) << 2);
+            lds_dma16(X + (m0 + row) * p.ldx + k0 + c * 8, lds_offset(Xi + (wave * 8 + i * 4) * 256));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 8 + i * 4 + drow;
+            const int c = dpos ^ ((row & 3) << 2);
+            lds_dma16(DY + (m0 + row) * p.lddy + n0 + c * 8, lds_offset(Yi + (wave * 8 + i * 4) * 256));
+        }
+    };
+    // transposing-read lane geometry (see wgrad_rows_kernel): rows (lane>>5)*8 + ((lane&15)>>2) (+4),
+    // 8-byte unit = column / 4
+    const int trow = (lane >> 5) * 8 + ((lane & 15) >> 2);
+    const int tunit = ((lane >> 4) & 1) * 4 + (lane & 3);
+    if (nsteps > 0) issue(0, 0);
+    if (nsteps > 1) issue(1, 1);
+    auto run = [&](auto colsum_tag) {
+        constexpr bool kColsum = decltype(colsum_tag)::value;
+        for (int s_ = 0; s_ < nsteps; ++s_) {
+            // step s_ has landed once at most the newest step's 4 DMA instructions are still outstanding
+            if (s_ + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0xF74);      // vmcnt(4), expcnt/lgkmcnt untouched
+            else __builtin_amdgcn_s_waitcnt(0xF70);                      // vmcnt(0)
+            // a bare s_barrier: __syncthreads() carries a full fence = vmcnt(0), which would also wait for the
+            // step that was just put in flight.  Everybody's pieces of this step have landed; stage (s_-1)%3 is retired
+            asm volatile("s_barrier" ::: "memory");
+            if (s_ + 2 < nsteps) issue(s_ + 2, (s_ + 2) % WD_STAGES);
+            const unsigned char* Xi = smem + (s_ % WD_STAGES) * WD_STAGE_BYTES;
+            const unsigned char* Yi = Xi + WR_ROWS * 256;
+#pragma unroll
+            for (int ks = 0; ks < WR_ROWS / 16; ++ks) {
+                const int row = ks * 16 + trow;
+                bf16x8 a0 = wd_tr8(Xi, row, wr * 16 + tunit);
+                bf16x8 a1 = wd_tr8(Xi, row, wr * 16 + 8 + tunit);
+                bf16x8 b0 = wd_tr8(Yi, row, wc * 16 + tunit);
+                bf16x8 b1 = wd_tr8(Yi, row, wc * 16 + 8 + tunit);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+                if constexpr (kColsum) {
+                    cs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b0, cs[0], 0, 0, 0);
+                    cs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b1, cs[1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    if (do_colsum) run(std::true_type{}); else run(std::false_type{});
+    const bool split = nsplit > 1;
+    if (do_colsum && kg == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int col = n0 + wc * 64 + j * 32 + l31;
+            if (split) p.colsum_ws[(long)zsplit * p.N + col] = cs[j][0];
+            else p.colsum[col] = cs[j][0];
+        }
+    }
+    float* Cb = split ? p.ws + (long)zsplit * p.K * p.N : p.dW;
+    const long ldc = split ? (long)p.N : p.lddw;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int col = n0 + wc * 64 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = k0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                Cb[(long)row * ldc + col] = acc[i][j][r];
             }
         }
     }
@@ -1068,7 +1220,12 @@ int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void
     p.k_per_split = kps;
     p.ws = (float*)ws; p.colsum = db; p.colsum_ws = p.ws + (size_t)splits * kin * n;
     dim3 wgrid(tiles * splits);
-    if (x_is_bf16 && dy_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<true, true>), wgrid, dim3(256), 0, st, p);
+    static int wdma = -1;
+    if (wdma < 0) { const char* e = getenv("TTSMI_WGRAD_DMA"); wdma = e ? atoi(e) : 1; }
+    const bool dma_ok = wdma && x_is_bf16 && dy_is_bf16 && conv_taps <= 1 && rows % WR_ROWS == 0 && kin % 128 == 0 &&
+                        n % 128 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && al16(x) && al16(dy);
+    if (dma_ok) hipLaunchKernelGGL(wgrad_dma_kernel, wgrid, dim3(256), 0, st, p);
+    else if (x_is_bf16 && dy_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<true, true>), wgrid, dim3(256), 0, st, p);
     else if (x_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<true, false>), wgrid, dim3(256), 0, st, p);
     else if (dy_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<false, true>), wgrid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_rows_kernel<false, false>), wgrid, dim3(256), 0, st, p);
