@@ -143,9 +143,9 @@ KERNEL_OF = {
     'ttsmi_conv1d_dgrad': 'gemm_f32_kernel<A_KC,B_KC> (dgrad)',
     'ttsmi_linear_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
     'ttsmi_conv1d_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
-    'ttsmi_hgemm_tn': 'gemm_bf16_kernel (Dense/Conv1D forward + dgrad, bf16 MFMA)',
+    'ttsmi_hgemm_tn': 'gemm_bf16_kernel / gemm_bf16_dma_kernel (Dense/Conv1D forward + dgrad, bf16 MFMA)',
     'ttsmi_hgemm_wgrad': 'gemm_bf16_kernel<A=bf16> (wgrad, bf16 MFMA, + split reduce)',
-    'ttsmi_hgemm_wgrad_rows': 'wgrad_rows_kernel (wgrad from row-major activations, bf16 MFMA, + split reduce)',
+    'ttsmi_hgemm_wgrad_rows': 'wgrad_dma_kernel / wgrad_rows_kernel (wgrad from row-major activations, bf16 MFMA, + split reduce)',
     'ttsmi_attention_fwd': 'attn_fwd_kernel (exact fp32 MFMA)',
     'ttsmi_attention_bwd': 'attn_bwd_dq_kernel + attn_bwd_dkv_kernel (exact fp32 MFMA)',
 }
@@ -164,11 +164,11 @@ def kernel_family(name, args):
 
 
 PMC_FILE = 'r01_pmc_hbm_traffic_bf16.json'
-PMC_KERNELS = {       # kernel family -> rocprof kernel-name prefixes (bf16 path; the PMC passes ran that path)
-    KERNEL_OF['ttsmi_hgemm_tn']: ['gemm_bf16_kernel'],
-    KERNEL_OF['ttsmi_hgemm_wgrad_rows']: ['wgrad_rows_kernel', 'hsplit_reduce'],
-    HATTN_FWD: ['hattn_fwd_kernel'],
-    HATTN_BWD: ['hattn_bwd_'],
+PMC_KERNELS = {       # kernel family -> (rocprof names of its kernels, names of helper kernels of the same entry point)
+    KERNEL_OF['ttsmi_hgemm_tn']: (['gemm_bf16_kernel', 'gemm_bf16_dma_kernel'], []),
+    KERNEL_OF['ttsmi_hgemm_wgrad_rows']: (['wgrad_rows_kernel', 'wgrad_dma_kernel'], ['hsplit_reduce']),
+    HATTN_FWD: (['hattn_fwd_kernel'], []),
+    HATTN_BWD: (['hattn_bwd_dq_kernel'], ['hattn_bwd_dkv_kernel']),
 }
 
 
@@ -233,15 +233,17 @@ def pmc_traffic(kernel_family: str):
     """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/, collected by
     tools/gpu_profile.sh with separate FETCH_SIZE / WRITE_SIZE runs and the guide's gfx950 correction)."""
     path = os.path.join(ROOT, 'profiles', PMC_FILE)
-    prefixes = PMC_KERNELS.get(kernel_family.replace(SIDE, ''))
-    if not prefixes or not os.path.exists(path):
+    entry = PMC_KERNELS.get(kernel_family.replace(SIDE, ''))
+    if not entry or not os.path.exists(path):
         return None
+    mains, helpers = entry
     ks = json.load(open(path))['kernels']
     n = b = 0.0
     for k, v in ks.items():
-        if any(k.startswith(p) for p in prefixes):
-            if k.startswith(prefixes[0]):      # helper kernels of the same entry point add bytes, not launches
-                n += v['launches']
+        if any(k.startswith(p) for p in mains):
+            n += v['launches']
+            b += v['launches'] * v['hbm_bytes_per_launch']
+        elif any(k.startswith(p) for p in helpers):   # helper kernels add bytes, not launches
             b += v['launches'] * v['hbm_bytes_per_launch']
     return b / n if n else None
 
