@@ -2,6 +2,7 @@
 // HBM-bound: one wave64 owns one row, the row lives in registers between the statistics and the
 // normalisation (each input element is read exactly once, each output written once), row
 // reductions are wave shuffles, loads/stores are 16 B per lane when C % 4 == 0.
+#include <stdlib.h>
 #include "common.h"
 
 #define LN_WAVES 4   // rows per 256-thread block
@@ -314,8 +315,12 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
 }
 
 static int ln_bwd_blocks(int M) {
+    // rows are walked by a wave one after the other (each row is a dependent load -> reduce -> store chain),
+    // so the grid sets how many chains run in parallel; TTSMI_LN_BWD_BLOCKS overrides the cap (measurement)
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("TTSMI_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 1024; if (cap < 1) cap = 1024; }
     int b = ttsmi_cdiv(M, LN_WAVES);
-    return b > 512 ? 512 : (b < 1 ? 1 : b);
+    return b > cap ? cap : (b < 1 ? 1 : b);
 }
 
 template <int VW, int NPL>
