@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Run-to-run determinism of the configs[1] train step: two models from the same seed, 3 steps each, the
+flat parameter buffers must be bit-identical.  Usage (GPU box): python tools/check_determinism.py [--once]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def run():
+    from transformertts_amd.model.models import ForwardTransformer
+    from transformertts_amd.utils.synthetic import synthetic_batch
+    cfg, shape = bench.workload_config('configs[1]')
+    cfg = dict(cfg, dropout_rate=0.1, predictors_dropout=0.1, device='cuda:0', seed=0, precision='bf16')
+    m = ForwardTransformer.from_config(cfg)
+    m._compile(learning_rate=1e-4)
+    batch = [torch.from_numpy(a).cuda() for a in synthetic_batch(shape['B'], shape['Tp'], shape['Tm'], seed=1234)]
+    grads = None
+    for _ in range(3):
+        m.train_step(*batch)
+    torch.cuda.synchronize()
+    return m.params.data.clone(), m.params.grad.clone(), m
+
+
+def main():
+    if '--once' in sys.argv:      # one run, print checksums: compare ACROSS processes / fresh boxes (an uninitialised
+        a, g, _ = run()           # read shows up as a first-process-on-a-fresh-box outlier, a race as jitter)
+        print('checksum', float(a.double().sum()), float(g.double().abs().sum()))
+        return 0
+    a, ga, ma = run()
+    b, gb, _ = run()
+    same = torch.equal(a, b)
+    print('parameters bit-identical after 3 steps:', same)
+    if not same:
+        for name, (o, n) in ma.params.offsets.items():
+            if not torch.equal(ga[o:o + n], gb[o:o + n]):
+                d = (ga[o:o + n] - gb[o:o + n]).abs().max().item()
+                print(f'  grad differs: {name:28s} max |d| = {d:.3e}')
+    return 0 if same else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())
