@@ -305,6 +305,7 @@ def main():
     from transformertts_amd import dp
     rank, local, world = dp.init_process_group()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    local = local % max(1, torch.cuda.device_count())     # (ranks may share a GPU in functional tests)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 

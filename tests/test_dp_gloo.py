@@ -91,3 +91,55 @@ def test_world_size_one_is_degenerate():
     g = torch.ones(4)
     sync(g)
     assert torch.equal(g, torch.ones(4))
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), TTSMI_DIST_BACKEND='gloo')
+    from oracle import ft_oracle as fo
+    from transformertts_amd import dp
+    from transformertts_amd.model.models import ForwardTransformer
+    r, local, w = dp.init_process_group()
+    assert dist.get_backend() == 'gloo' and w == world
+    torch.cuda.set_device(0)                                  # both ranks share the one GPU of the test box
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=1, perturb=0.02)
+    model = ForwardTransformer.from_config(dict(cfg, device='cuda:0', seed=100 + rank, precision='bf16'))
+    if rank == 0:
+        model.load_weights_dict({k: np.asarray(v) for k, v in W.items()})   # rank 1 keeps its own random init
+    model._compile(learning_rate=1e-3)
+    wrapped = dp.DataParallel(model)                          # broadcast must overwrite rank 1's weights
+    assert wrapped.sync.overlap and model.grad_sync is not None
+    batch = fo.synthetic_batch(4, 16, 48, seed=3)
+    shard = dp.shard_batch(batch, rank, world)
+    for _ in range(2):
+        wrapped.train_step(*shard)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f'w{rank}.npy'), model.params.data.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_match_the_global_batch_step(tmp_path):
+    """The whole DP path with the real model (two ranks sharing the GPU over gloo): parameter broadcast, the
+    backward hook, the overlapped two-bucket gradient all-reduce and the replicated Adam step must leave both
+    ranks with identical weights, equal to a single process stepping on the global batch."""
+    from oracle import ft_oracle as fo
+    from transformertts_amd.model.models import ForwardTransformer
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = np.load(tmp_path / 'w0.npy'), np.load(tmp_path / 'w1.npy')
+    np.testing.assert_array_equal(w0, w1)
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=1, perturb=0.02)
+    single = ForwardTransformer.from_config(dict(cfg, device='cuda:0', seed=0, precision='bf16'))
+    single.load_weights_dict({k: np.asarray(v) for k, v in W.items()})
+    single._compile(learning_rate=1e-3)
+    batch = fo.synthetic_batch(4, 16, 48, seed=3)
+    for _ in range(2):
+        single.train_step(*batch)
+    ws = single.params.data.cpu().numpy()
+    # same math up to the summation order of the two half-batch gradients (bf16 GEMM operands): Adam's
+    # lr * sign-like step bounds the difference by a few lr
+    assert np.abs(w0 - ws).max() < 5e-3 and np.abs(w0 - ws).mean() < 2e-4

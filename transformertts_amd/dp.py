@@ -32,7 +32,8 @@ def init_process_group(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # TTSMI_DIST_BACKEND=gloo lets several ranks share one GPU (functional test of the DP path)
+            backend = os.environ.get('TTSMI_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
