@@ -19,7 +19,8 @@ def run():
     m._compile(learning_rate=1e-4)
     batch = [torch.from_numpy(a).cuda() for a in synthetic_batch(shape['B'], shape['Tp'], shape['Tm'], seed=1234)]
     grads = None
-    for _ in range(3):
+    steps = int(sys.argv[sys.argv.index('--steps') + 1]) if '--steps' in sys.argv else 3
+    for _ in range(steps):
         m.train_step(*batch)
     torch.cuda.synchronize()
     return m.params.data.clone(), m.params.grad.clone(), m

@@ -1072,9 +1072,12 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
         TTSMI_CHECK_LAUNCH(name);
         return TTSMI_OK;
     }
-    // LDS-DMA persistent kernel (TTSMI_HGEMM_DMA=0 disables it, measurement only)
+    // LDS-DMA persistent kernel (TTSMI_HGEMM_DMA=1 enables it for decoder-size launches, 2 for all eligible ones)
     static int use_dma = -1;
-    if (use_dma < 0) { const char* e = getenv("TTSMI_HGEMM_DMA"); use_dma = e ? atoi(e) : 1; }
+    // OFF by default: with this kernel enabled, tools/check_determinism.py --once --steps 120 gave differing
+    // checksums (and one NaN) across processes - a rare race in its stage hand-off that round 1 did not find;
+    // with it off (and the DMA wgrad on) the step is bit-reproducible.  It is worth ~1 % of the step.
+    if (use_dma < 0) { const char* e = getenv("TTSMI_HGEMM_DMA"); use_dma = e ? atoi(e) : 0; }
     if (use_dma && !a_f32 && splits == 1 && p.colsum == nullptr && p.a_taps == 1 && p.K % HBK_ == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 &&
         (p.A2 == nullptr || (p.K1 % HBK_ == 0 && p.lda2 % 8 == 0 && al16(p.A2)))) {
         p.tiles_m = ttsmi_cdiv(p.M, DBM);
