@@ -224,12 +224,38 @@ def test_save_load_roundtrip(tiny, tmp_path):
     m._compile(learning_rate=1e-3)
     m.train_step(*batch)
     m.save_model(str(tmp_path / 'ckpt'))
+    assert (tmp_path / 'ckpt' / 'model_weights.hdf5').exists()       # the reference's file name and format
+    assert open(tmp_path / 'ckpt' / 'model_weights.hdf5', 'rb').read(8) == b'\x89HDF\r\n\x1a\n'
     from transformertts_amd.model.models import ForwardTransformer
     m2 = ForwardTransformer.load_model(str(tmp_path / 'ckpt'))
     assert m2.step == 1
     a, b = m.train_step(*batch), m2.train_step(*batch)
     assert float(a['loss']) == float(b['loss'])
     assert torch.equal(m.params.data, m2.params.data)
+
+
+def test_keras_hdf5_weight_file_loads_and_predicts_like_the_oracle():
+    """a Keras-layout `model_weights.hdf5` written by the real libhdf5
+    (tests/golden/make_keras_hdf5_fixture.py; dense + conv block per stack) goes through
+    `load_weights` into the GPU model, whose forward then matches the oracle run on the same values."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.join(here, 'golden'))
+    import make_keras_hdf5_fixture as mk
+    from transformertts_amd.model.models import ForwardTransformer
+    cfg, W = mk.mini_config(), mk.mini_weights()
+    m = ForwardTransformer.from_config(cfg)
+    m.load_weights(os.path.join(here, 'golden', 'keras_mini_model_weights.hdf5'))
+    back = m.weights_dict()
+    for k in W:
+        np.testing.assert_array_equal(back[k], W[k].astype(np.float32))
+    batch = fo.synthetic_batch(3, 25, 110, seed=21, ragged=True)
+    want = fo.ForwardTransformerOracle(cfg, W, torch.float64).val_step(*batch)
+    got = m.val_step(*batch)
+    assert abs(float(got['loss']) - float(want['loss'])) / float(want['loss']) < TOL
+    assert _rel(got['mel'], want['mel']) < TOL
 
 
 # ---------------------------------------------------------------------------------------- mel path

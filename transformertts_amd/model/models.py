@@ -631,9 +631,10 @@ class ForwardTransformer:
 
     # ------------------------------------------------------------------ persistence (models.py:600-642)
     def save_model(self, path: str):
-        """config.yaml + weights.  The reference writes Keras HDF5 (`model_weights.hdf5`); h5py is
-        not available offline, so the variables are written as `model_weights.npz` under the
-        reference's variable layout (SURVEY.md section 8f.2 - HDF5 interchange is a 'next' row)."""
+        """config.yaml + `model_weights.hdf5` in the Keras H5 layout the reference's `load_model` reads
+        (`model/models.py:600-618`; written by `model/keras_weights.py` - no h5py needed), plus the Adam
+        state, which the reference keeps in its tf.train.Checkpoint instead."""
+        from .keras_weights import save_keras_weights
         path = Path(path)
         path.mkdir(parents=True, exist_ok=True)
         cfg = {k: v for k, v in self.config.items() if k != 'device'}
@@ -645,7 +646,8 @@ class ForwardTransformer:
             pass
         with open(path / 'config.yaml', 'w') as f:
             yaml.safe_dump(cfg, f)
-        np.savez(path / 'model_weights.npz', **self.weights_dict())
+        save_keras_weights(path / 'model_weights.hdf5', self.weights_dict(), self.config,
+                           self.text_pipeline.tokenizer.vocab_size)
         torch.save({'m': self.params.m.cpu(), 'v': self.params.v.cpu(), 'step': self.step,
                     'lr': float(self.lr_dev.item())}, path / 'optimizer.pt')
 
@@ -658,7 +660,8 @@ class ForwardTransformer:
             config.pop(k, None)
         config.update(kwargs)
         model = cls.from_config(config)
-        model.load_weights(path / 'model_weights.npz')
+        weights = path / 'model_weights.hdf5'
+        model.load_weights(weights if weights.exists() else path / 'model_weights.npz')
         opt = path / 'optimizer.pt'
         if opt.exists():
             st = torch.load(opt)
@@ -670,10 +673,13 @@ class ForwardTransformer:
         return model
 
     def load_weights(self, path):
+        """`.hdf5` / `.h5`: a Keras `save_weights` file of the reference model with this config (loaded by
+        position with shape checks, exactly as Keras does); `.npz`: this package's variable names."""
         path = str(path)
         if path.endswith('.hdf5') or path.endswith('.h5'):
-            raise NotImplementedError('Keras HDF5 import needs h5py (absent offline); convert the checkpoint '
-                                      'to .npz with the reference variable names (SURVEY.md 8f.2)')
+            from .keras_weights import load_keras_weights
+            self.load_weights_dict(load_keras_weights(path, self.config, self.text_pipeline.tokenizer.vocab_size))
+            return
         with np.load(path) as z:
             self.load_weights_dict({k: z[k] for k in z.files})
 
