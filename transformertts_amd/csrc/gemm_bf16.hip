@@ -295,6 +295,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
 __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_off) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory", "m0");
 }
+// Barrier of the DMA pipelines.  A bare s_barrier (not __syncthreads(), whose fence is vmcnt(0) and would also
+// wait for the stage just put in flight) - but WITH lgkmcnt(0): the "memory" clobber keeps the LDS reads of the
+// finished step above the barrier, it does not keep the wait for their DATA there.  hipcc sinks the last MFMAs
+// of a step (and the s_waitcnt lgkmcnt in front of them) below the barrier, so a wave would arrive with ds_reads
+// still queued while a faster wave already overwrites that stage by DMA - rare wrong operands, found as
+// run-to-run different checksums (tools/check_determinism.py).  The DMA counter (vmcnt) is waited by the caller.
+__device__ __forceinline__ void lds_stage_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ unsigned lds_offset(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
         issue((t0 / p.tiles_n) * DBM, (t0 % p.tiles_n) * DBN, 0, 0);
     }
     __builtin_amdgcn_s_waitcnt(0xF70);
-    asm volatile("s_barrier" ::: "memory");
+    lds_stage_barrier();
 
     for (int ti = slot; ti < len; ti += per) {
         const int tile = base + ti;
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_s_waitcnt(0xF70);    // vmcnt(0): this wave's DMA pieces of the next stage have landed
-            asm volatile("s_barrier" ::: "memory");   // ... everybody's have, and nobody still reads stage `st`
+            lds_stage_barrier();                  // ... everybody's have, and nobody still reads stage `st`
             st ^= 1;
         }
         // ---- epilogue: the stage just consumed (st ^ 1) is free - its first 17 KB hold the four per-wave patches
@@ -813,9 +822,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WRowsP p) {
             // step s_ has landed once at most the newest step's 4 DMA instructions are still outstanding
             if (s_ + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0xF74);      // vmcnt(4), expcnt/lgkmcnt untouched
             else __builtin_amdgcn_s_waitcnt(0xF70);                      // vmcnt(0)
-            // a bare s_barrier: __syncthreads() carries a full fence = vmcnt(0), which would also wait for the
-            // step that was just put in flight.  Everybody's pieces of this step have landed; stage (s_-1)%3 is retired
-            asm volatile("s_barrier" ::: "memory");
+            // not __syncthreads(): its fence is vmcnt(0), which would also wait for the step that was just put in
+            // flight.  Everybody's pieces of this step have landed; stage (s_-1)%3 is retired (its reads returned)
+            lds_stage_barrier();
             if (s_ + 2 < nsteps) issue(s_ + 2, (s_ + 2) % WD_STAGES);
             const unsigned char* Xi = smem + (s_ % WD_STAGES) * WD_STAGE_BYTES;
             const unsigned char* Yi = Xi + WR_ROWS * 256;
