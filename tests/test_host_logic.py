@@ -28,6 +28,26 @@ def test_sparse_filterbank_equals_oracle_dense_basis():
     np.testing.assert_allclose(w[474:474 + 1100], scipy.signal.get_window('hann', 1100, fftbins=True), atol=1e-7)
 
 
+def test_wav_preprocessing_steps_that_fix_the_frame_count():
+    """Reference Audio.preprocess (data/audio.py:132-141): volume normalisation (increase only) and the
+    one-sample pad when len % hop == 0."""
+    from transformertts_amd.data.audio import normalize_volume, pad_for_frame_count
+    y = np.arange(512, dtype=np.float32)
+    assert pad_for_frame_count(y, 256).shape == (513,) and pad_for_frame_count(y, 256)[-1] == 0
+    assert pad_for_frame_count(y[:500], 256) is not None and pad_for_frame_count(y[:500], 256).shape == (500,)
+    assert 1 + len(pad_for_frame_count(y, 256)) // 256 == 3
+    rng = np.random.default_rng(0)
+    w = (0.01 * rng.standard_normal(4000)).astype(np.float32)
+    out = normalize_volume(w, target_dBFS=-30, int16_max=32767, increase_only=True)
+    rms_db = 20 * np.log10(np.sqrt(np.mean((out * 32767) ** 2)) / 32767)
+    assert abs(rms_db + 30) < 1e-4                                 # -40 dBFS clip raised to the target
+    loud = (0.5 * rng.standard_normal(4000)).astype(np.float32)
+    assert normalize_volume(loud, -30, 32767, increase_only=True) is loud      # never attenuated
+    assert normalize_volume(loud, -30, 32767, decrease_only=True) is not loud
+    with pytest.raises(ValueError):
+        normalize_volume(w, -30, 32767, increase_only=True, decrease_only=True)
+
+
 def test_flat_params_layout_and_spec_matches_oracle():
     from transformertts_amd.model.models import FlatParams, _blocks_spec, _predictor_spec
     spec = OrderedDict()

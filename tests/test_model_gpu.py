@@ -286,6 +286,26 @@ def test_mel_matches_oracle_ragged_batch():
         np.testing.assert_array_equal(single, got)
 
 
+def test_audio_preprocess_pads_and_normalises_like_the_reference():
+    """data/audio.py:132-141: a clip of k*hop samples gets one sample appended (so the kernel emits
+    k + 1 frames either way, and the clip it sees matches the one durations were extracted against);
+    the trimming steps are out of scope and refuse loudly."""
+    from transformertts_amd.data.audio import Audio
+    au = Audio(22050, 1024, 80, 256, 1024, 0, 8000, 'MelGAN', norm_wav=True, target_dBFS=-30, int16_max=32767,
+               trim_long_silences=False, trim_silence=False)
+    y = (0.05 * mo.synthetic_clip(256 * 40, seed=3)).astype(np.float32)
+    z = au.preprocess(y)
+    assert np.sqrt(np.mean(z[:-1].astype(np.float64) ** 2)) > 2 * np.sqrt(np.mean(y.astype(np.float64) ** 2))  # raised to -30 dBFS
+    assert z.shape[0] == 256 * 40 + 1 and z[-1] == 0
+    got = au.mel_spectrogram(np.asarray(z, dtype=np.float32))
+    want = mo.mel_spectrogram(np.asarray(z, dtype=np.float32))
+    assert got.shape == (41, 80) == want.shape
+    assert np.abs(got - want).max() < 2e-4          # same bound as the other log-mel comparisons
+    au2 = Audio(22050, 1024, 80, 256, 1024, 0, 8000, 'MelGAN', trim_silence=True)
+    with pytest.raises(NotImplementedError):
+        au2.preprocess(y)
+
+
 def test_mel_analytic_and_wavernn_normalizer():
     audio = _audio()
     sil = audio.mel_spectrogram(np.zeros(5000, np.float32))

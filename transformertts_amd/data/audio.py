@@ -7,9 +7,12 @@ one launch, concatenated with offset tables, device-resident in and out.
 
 Host-side constants (built once, in float64 numpy like librosa does [3P], then cast): the periodic
 Hann window centred in n_fft, and the Slaney/area-normalised mel filterbank in its sparse
-per-filter (first bin, count, weights) form.  Everything else of the reference class (wav loading,
-VAD trimming, pyworld pitch, Griffin-Lim, plotting: data/audio.py:94-194) is outside the hot path
- and intentionally not provided."""
+per-filter (first bin, count, weights) form.  `preprocess` keeps the two steps of the reference's
+wav preparation that decide what the mel kernel sees (data/audio.py:132-141):
+volume normalisation and the one-sample pad that fixes the frame count.  Everything else of the
+reference class (wav loading, VAD / silence trimming, pyworld pitch, Griffin-Lim, plotting:
+data/audio.py:94-194) is outside the hot path and not provided; asking
+for the trimming steps raises instead of silently skipping them."""
 from __future__ import annotations
 
 import sys
@@ -104,6 +107,28 @@ class WaveRNN(Normalizer):                      # reference data/audio.py:222-24
         return np.power(10.0, S * 0.05)
 
 
+def normalize_volume(wav: np.ndarray, target_dBFS: float, int16_max: float, increase_only: bool = False,
+                     decrease_only: bool = False) -> np.ndarray:
+    """Reference Audio.normalize_volume (data/audio.py:154-162): scale to `target_dBFS` RMS."""
+    if increase_only and decrease_only:
+        raise ValueError('Both increase only and decrease only are set')
+    rms = np.sqrt(np.mean((wav * int16_max) ** 2))
+    wave_dBFS = 20 * np.log10(rms / int16_max)
+    dBFS_change = target_dBFS - wave_dBFS
+    if (dBFS_change < 0 and increase_only) or (dBFS_change > 0 and decrease_only):
+        return wav
+    return wav * (10 ** (dBFS_change / 20))
+
+
+def pad_for_frame_count(y: np.ndarray, hop_length: int) -> np.ndarray:
+    """Reference Audio.preprocess, last step (data/audio.py:139-140): a clip whose length is a multiple
+    of the hop gets ONE zero sample appended, so every clip handed to the STFT has len % hop != 0 and its
+    frame count 1 + len // hop is the one the alignment / duration extraction was computed against."""
+    if y.shape[0] % hop_length == 0:
+        y = np.pad(y, (0, 1))
+    return y
+
+
 class Audio:
     def __init__(self, sampling_rate: int, n_fft: int, mel_channels: int, hop_length: int,
                  win_length: int, f_min: int, f_max: int, normalizer: str, norm_wav: bool = None,
@@ -114,6 +139,8 @@ class Audio:
         self.config = {k: v for k, v in locals().items() if k not in ('self', '__class__', 'kwargs')}
         self.sampling_rate, self.n_fft, self.mel_channels = sampling_rate, n_fft, mel_channels
         self.hop_length, self.win_length, self.f_min, self.f_max = hop_length, win_length, f_min, f_max
+        self.norm_wav, self.target_dBFS, self.int16_max = norm_wav, target_dBFS, int16_max
+        self.trim_long_silences, self.trim_silence = trim_long_silences, trim_silence
         self.normalizer = getattr(sys.modules[__name__], normalizer)()
         self.device = torch.device(kwargs.get('device', 'cuda:0'))
         if not torch.cuda.is_available():
@@ -159,6 +186,19 @@ class Audio:
         is_t = torch.is_tensor(wav)
         mel, _ = self.mel_spectrogram_batch([wav])
         return mel if is_t else mel.cpu().numpy()
+
+    def normalize_volume(self, wav, increase_only=False, decrease_only=False):
+        return normalize_volume(wav, self.target_dBFS, self.int16_max, increase_only, decrease_only)
+
+    def preprocess(self, y):
+        """Reference Audio.preprocess (data/audio.py:132-141).  The VAD / silence trimming steps need
+        webrtcvad / librosa and are out of scope: configured on, they raise."""
+        if self.norm_wav:
+            y = self.normalize_volume(y, increase_only=True)
+        if self.trim_long_silences or self.trim_silence:
+            raise NotImplementedError('trim_long_silences / trim_silence (webrtcvad, librosa.effects.trim) are '
+                                      'outside the hot path: trim the clips upstream and configure them off')
+        return pad_for_frame_count(y, self.hop_length)
 
     def _normalize(self, S):
         raise NotImplementedError('normalisation is fused into the STFT->mel kernel')
