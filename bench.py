@@ -294,9 +294,9 @@ def main():
     # BASELINE.json configs[1] is quoted in bf16: bf16 GEMM/attention operands, fp32 accumulate, fp32
     # master weights / activations / optimiser.  --precision f32 runs the exact-fp32 parity path.
     ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16'])
-    # hipGraph replay of the step is implemented and bit-identical to eager (tests/test_model_gpu.py),
-    # but at this workload the eager host loop (~12.3 ms of Python per step) still hides behind the GPU
-    # (~13 ms) while ROCm graph replay adds per-node overhead: eager 12.5 ms vs graph 13.4 ms measured.
+    # hipGraph replay of the step is implemented and bit-identical to eager (tests/test_model_gpu.py), but it
+    # is not the default: ROCm graph replay adds per-node overhead and serialises the weight-gradient stream's
+    # overlap differently - measured 8.9 ms (graph) vs 8.1 ms (eager) per step when last compared.
     ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')

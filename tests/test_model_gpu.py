@@ -217,6 +217,30 @@ def test_dropout_training_step_is_finite_and_reproducible(tiny):
     assert abs(outs[0][0] - l0) / l0 < 0.2         # dropout perturbs, does not destroy, the loss
 
 
+def test_benchmark_shape_training_is_bit_reproducible():
+    """Two models from the same seed, 25 bf16 train steps each at the BASELINE configs[1] shape (dropout on,
+    weight gradients on the second stream): bit-identical parameters, finite loss.  Guards the cross-stream
+    ordering and the LDS pipelines' stage hand-off (tools/check_determinism.py is the long, cross-process form
+    that found the DMA GEMM race documented in DESIGN.md section 4)."""
+    from transformertts_amd.model.models import ForwardTransformer
+    from transformertts_amd.utils.synthetic import synthetic_batch
+    cfg = dict(fo.make_config(), dropout_rate=0.1, predictors_dropout=0.1, seed=0, precision='bf16')
+    batch = [torch.from_numpy(a).cuda() for a in synthetic_batch(32, 200, 900, seed=1234)]
+
+    def run():
+        m = ForwardTransformer.from_config(cfg)
+        m._compile(learning_rate=1e-4)
+        for _ in range(25):
+            out = m.train_step(*batch)
+        torch.cuda.synchronize()
+        assert np.isfinite(float(out['loss']))
+        return m.params.data.clone()
+    a = run()
+    b = run()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b)
+
+
 def test_save_load_roundtrip(tiny, tmp_path):
     cfg, W = tiny
     batch = fo.synthetic_batch(2, 20, 60, seed=14)
