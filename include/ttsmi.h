@@ -139,7 +139,8 @@ int ttsmi_add_layernorm_fwd(const float* x, const float* res, const float* gamma
                             float* y, float* mean, float* rstd, int M, int C, uint16_t* y_bf16,
                             ttsmi_stream_t stream);
 /* dx (grad wrt x), dres (grad wrt res; may alias dx when p_in == 0; NULL if no res),
- * dgamma/dbeta [C], dpe_scale [1] (NULL if no pe).  relu_in != 0 additionally multiplies dx by
+ * dgamma/dbeta [C] (both NULL = deferred, see ttsmi_layernorm_param_reduce_batched), dpe_scale [1] (NULL if
+ * no pe).  relu_in != 0 additionally multiplies dx by
  * (x > 0) - the backward of the ReLU that produced x (predictor conv->relu->LN, layers.py:513).
  * Masks are regenerated, the forward output is not needed.
  * dx_bf16 (may be NULL): dx stored as bf16; when given, dx itself may be NULL (in the dense blocks
@@ -152,6 +153,15 @@ int ttsmi_add_layernorm_bwd(const float* dy, const float* x, const float* res, c
                             const int64_t* step_dev, int relu_in, float* dx, float* dres, float* dgamma, float* dbeta,
                             float* dpe_scale, int M, int C, void* ws, size_t ws_bytes,
                             uint16_t* dx_bf16, ttsmi_stream_t stream);
+/* Deferred parameter gradients: called with dgamma == dbeta == NULL, ttsmi_add_layernorm_bwd leaves its
+ * per-workgroup partial sums in `ws` (which the caller then keeps alive) and this entry finishes any number
+ * of such calls in ONE launch - a training step has ~30 LayerNormalization instances (layers.py:27,96,207,
+ * 295,508), whose dgamma/dbeta reductions are too small to be worth a launch each on the critical path.
+ * HOST arrays of n device pointers / shapes: ws[i] = the workspace of call i, M[i], C[i] = its shape,
+ * dgamma[i], dbeta[i] [C[i]], dpe_scale[i] [1] or NULL.  Same stream as (or ordered after) the bwd calls. */
+int ttsmi_layernorm_param_reduce_batched(const void* const* ws, float* const* dgamma, float* const* dbeta,
+                                         float* const* dpe_scale, const int* M, const int* C, int n,
+                                         ttsmi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small element-wise / gather ops of ForwardTransformer.call (model/models.py:518-550)

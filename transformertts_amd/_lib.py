@@ -45,6 +45,7 @@ SIGNATURES = {
     'ttsmi_add_layernorm_bwd_ws_bytes': (c_size_t, [I, I]),
     'ttsmi_add_layernorm_bwd': (I, [P, P, P, P, P, P, P, P, I, P, F, c_uint32, F, c_uint32,
                                     c_uint64, P, I, P, P, P, P, P, I, I, P, c_size_t, P, S]),
+    'ttsmi_layernorm_param_reduce_batched': (I, [P, P, P, P, P, P, I, S]),
     'ttsmi_token_pad_mask': (I, [P, P, P, I, I, S]),
     'ttsmi_length_pad_mask': (I, [P, P, P, I, I, S]),
     'ttsmi_embedding_fwd': (I, [P, P, P, I, I, I, S]),

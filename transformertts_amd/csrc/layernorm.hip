@@ -314,6 +314,66 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
     }
 }
 
+// The same reduction for up to LN_BATCH_MAX LayerNorm instances in ONE launch: a training step has ~30
+// LayerNorm backward calls whose parameter-gradient reductions are 2 MB reads each - as separate launches they
+// cost ~6.7 us apiece on the critical path (0.2 ms of a 7.7 ms step), batched they are one ~20 us kernel.
+// The descriptors travel by value in the kernel arguments (2.1 KB), so nothing is staged in device memory.
+#define LN_BATCH_MAX 48
+struct LnReduceItem {
+    const float* part;      // [2*nw*C + nw]: partial dgamma rows, partial dbeta rows, partial dscale
+    float* dgamma;
+    float* dbeta;
+    float* dscale;          // NULL when the instance has no positional-encoding scalar
+    int nw, C;
+};
+struct LnReduceBatch {
+    LnReduceItem it[LN_BATCH_MAX];
+    int blk_off[LN_BATCH_MAX + 1];   // first block of each item (16 columns per block)
+    int n;
+};
+
+__global__ __launch_bounds__(256) void ln_param_reduce_batched_kernel(LnReduceBatch b) {
+    __shared__ float red[2][16][17];
+    int item = 0;
+    while (item + 1 < b.n && (int)blockIdx.x >= b.blk_off[item + 1]) ++item;
+    const LnReduceItem I = b.it[item];
+    const int blk = blockIdx.x - b.blk_off[item];
+    const int nw = I.nw, C = I.C;
+    const float* __restrict__ part_g = I.part;
+    const float* __restrict__ part_b = I.part + (long)nw * C;
+    const float* __restrict__ part_s = part_b + (long)nw * C;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blk * 16 + cl;
+    float sg = 0.f, sb = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int w = rl; w < nw; w += 16) {
+            sg += part_g[(long)w * C + c];
+            sb += part_b[(long)w * C + c];
+        }
+    }
+    red[0][rl][cl] = sg;
+    red[1][rl][cl] = sb;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float a = 0.f, bsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a += red[0][r][cl]; bsum += red[1][r][cl]; }
+        I.dgamma[c] = a;
+        I.dbeta[c] = bsum;
+    }
+    if (blk == 0 && I.dscale) {                      // uniform per block: every thread takes the branch
+        __shared__ float ws4[4];
+        __syncthreads();
+        float s = 0.f;
+        for (int w = threadIdx.x; w < nw; w += 256) s += part_s[w];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) ws4[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) I.dscale[0] = ws4[0] + ws4[1] + ws4[2] + ws4[3];
+    }
+}
+
 static int ln_bwd_blocks(int M) {
     // rows are walked by a wave one after the other (each row is a dependent load -> reduce -> store chain),
     // so the grid sets how many chains run in parallel; TTSMI_LN_BWD_BLOCKS overrides the cap (measurement)
@@ -402,8 +462,9 @@ int ttsmi_add_layernorm_bwd(const float* dy, const float* x, const float* res, c
                             const int64_t* step_dev, int relu_in, float* dx, float* dres, float* dgamma, float* dbeta,
                             float* dpe_scale, int M, int C, void* ws, size_t ws_bytes,
                             uint16_t* dx_bf16, ttsmi_stream_t stream) {
-    TTSMI_CHECK_ARG(dy && x && gamma && mean && rstd && (dx || dx_bf16) && dgamma && dbeta,
-                    "add_layernorm_bwd: null pointer");
+    TTSMI_CHECK_ARG(dy && x && gamma && mean && rstd && (dx || dx_bf16), "add_layernorm_bwd: null pointer");
+    TTSMI_CHECK_ARG((dgamma != nullptr) == (dbeta != nullptr),
+                    "add_layernorm_bwd: dgamma and dbeta must both be given or both be NULL (deferred reduction)");
     TTSMI_CHECK_ARG(M > 0 && C > 0, "add_layernorm_bwd: bad shape");
     TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_add_layernorm_bwd_ws_bytes(M, C),
                     "add_layernorm_bwd: workspace too small");
@@ -425,9 +486,41 @@ int ttsmi_add_layernorm_bwd(const float* dy, const float* x, const float* res, c
     int rc = dispatch<false>(p, st);
     if (rc) { ttsmi_set_error("add_layernorm_bwd: C=%d too wide", C); return rc; }
     TTSMI_CHECK_LAUNCH("add_layernorm_bwd");
+    if (!dgamma) return TTSMI_OK;                    // deferred: the partial sums stay in ws for the batched reduce
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ttsmi_cdiv(C, 16)), dim3(256), 0, st, p.part_g,
                        p.part_b, p.part_s, dgamma, dbeta, pe ? dpe_scale : nullptr, (int)nw, C);
     TTSMI_CHECK_LAUNCH("ln_param_reduce");
+    return TTSMI_OK;
+}
+
+int ttsmi_layernorm_param_reduce_batched(const void* const* ws, float* const* dgamma, float* const* dbeta,
+                                         float* const* dpe_scale, const int* M, const int* C, int n,
+                                         ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(ws && dgamma && dbeta && dpe_scale && M && C, "layernorm_param_reduce_batched: null pointer");
+    TTSMI_CHECK_ARG(n >= 0, "layernorm_param_reduce_batched: bad count");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += LN_BATCH_MAX) {
+        LnReduceBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n - base < LN_BATCH_MAX ? n - base : LN_BATCH_MAX;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const int j = base + i;
+            TTSMI_CHECK_ARG(ws[j] && dgamma[j] && dbeta[j] && M[j] > 0 && C[j] > 0,
+                            "layernorm_param_reduce_batched: bad item");
+            b.it[i].part = (const float*)ws[j];
+            b.it[i].dgamma = dgamma[j];
+            b.it[i].dbeta = dbeta[j];
+            b.it[i].dscale = dpe_scale[j];
+            b.it[i].nw = ln_bwd_blocks(M[j]);
+            b.it[i].C = C[j];
+            b.blk_off[i] = blocks;
+            blocks += ttsmi_cdiv(C[j], 16);
+        }
+        b.blk_off[b.n] = blocks;
+        hipLaunchKernelGGL(ln_param_reduce_batched_kernel, dim3(blocks), dim3(256), 0, st, b);
+        TTSMI_CHECK_LAUNCH("ln_param_reduce_batched");
+    }
     return TTSMI_OK;
 }
 

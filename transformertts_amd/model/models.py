@@ -483,7 +483,8 @@ class ForwardTransformer:
             loss, loss_vals = self._losses(model_out, ts, td, tp)
             ops.enable_wgrad_stream(self.overlap_wgrad)
             try:
-                loss.backward()                                                      # :480
+                with ops.ln_param_batch():
+                    loss.backward()                                                  # :480
                 ops.wgrad_join()
             finally:
                 ops.enable_wgrad_stream(False)

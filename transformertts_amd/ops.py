@@ -37,6 +37,59 @@ def _stream():
     return h if h is not None else torch.cuda.current_stream().cuda_stream
 
 
+# LayerNorm parameter gradients of a training step, finished in one launch.  Inside `ln_param_batch()` the
+# LayerNorm backward calls that write into caller-owned gradient sinks leave their per-workgroup partial sums in
+# their workspaces (kept alive here) and `ln_flush()` reduces all of them with ONE kernel
+# (ttsmi_layernorm_param_reduce_batched) - ~30 launches of ~6.7 us less on the critical path of a step.
+# Everything is on the main stream, in program order: nothing to synchronise, results unchanged bit for bit.
+# Outside the context (direct use of the ops, unit tests) every call reduces immediately.
+_LN_PENDING = None
+_LN_BATCHED = os.environ.get('TTSMI_LN_BATCHED', '1') != '0'       # measurement knob: 0 = one reduce launch per call
+
+
+class ln_param_batch:
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled) and _LN_BATCHED
+
+    def __enter__(self):
+        global _LN_PENDING
+        self.prev = _LN_PENDING
+        if self.enabled:
+            _LN_PENDING = []
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        global _LN_PENDING
+        try:
+            if exc_type is None:
+                ln_flush()
+        finally:
+            _LN_PENDING = self.prev
+        return False
+
+
+def _ln_defer(ws, dgamma, dbeta, dps, M, C) -> None:
+    _LN_PENDING.append((ws, dgamma, dbeta, dps, int(M), int(C)))
+
+
+def ln_flush() -> None:
+    """Reduce every pending LayerNorm parameter gradient (no-op when nothing is pending)."""
+    pend = _LN_PENDING
+    if not pend:
+        return
+    n = len(pend)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    ws = PA(*[e[0].data_ptr() for e in pend])
+    dg = PA(*[e[1].data_ptr() for e in pend])
+    db = PA(*[e[2].data_ptr() for e in pend])
+    ds = PA(*[(e[3].data_ptr() if e[3] is not None else None) for e in pend])
+    Ms, Cs = IA(*[e[4] for e in pend]), IA(*[e[5] for e in pend])
+    check(_lib.lib().ttsmi_layernorm_param_reduce_batched(ctypes.addressof(ws), ctypes.addressof(dg), ctypes.addressof(db),
+                                                          ctypes.addressof(ds), ctypes.addressof(Ms), ctypes.addressof(Cs),
+                                                          n, _stream()), 'layernorm_param_reduce_batched')
+    del pend[:]                       # the workspaces go back to the allocator, in stream order
+
+
 class pinned_stream:
     """`with ops.pinned_stream():` - launches inside go to the stream that is current on entry."""
 
@@ -682,10 +735,17 @@ class AddLayerNormFn(torch.autograd.Function):
             dps = gpe if gpe is not None else torch.empty((1,), dtype=torch.float32, device=x.device)
         l = _lib.lib()
         ws = _ws(l.ttsmi_add_layernorm_bwd_ws_bytes(M, C), x.device)
+        # deferred only when every parameter gradient lands in a caller-owned sink (autograd never sees it)
+        defer = (_LN_PENDING is not None and ggamma is not None and gbeta is not None
+                 and (pe is None or gpe is not None))
         check(l.ttsmi_add_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(pe),
                                         _p(pe_scale), T, _p(row_pad), p_in, site_in, p_out, site_out, seed,
-                                        _p(step_dev), int(relu_in), _p(dx), _p(dres), _p(dgamma), _p(dbeta),
-                                        _p(dps), M, C, _p(ws), ws.numel(), None, _stream()), 'add_layernorm_bwd')
+                                        _p(step_dev), int(relu_in), _p(dx), _p(dres),
+                                        None if defer else _p(dgamma), None if defer else _p(dbeta),
+                                        None if defer else _p(dps), M, C, _p(ws), ws.numel(), None, _stream()),
+              'add_layernorm_bwd')
+        if defer:
+            _ln_defer(ws, dgamma, dbeta, dps, M, C)
         n = lambda g, d: None if g is not None else d
         dps_out = None
         if pe is not None and gpe is None:
@@ -884,6 +944,7 @@ class LenRegFn(torch.autograd.Function):
         cum, = ctx.saved_tensors
         B, Tp, cap, C = ctx.shape
         if _lenreg_backward_hook is not None:
+            ln_flush()                      # the decoder's LayerNorm gradients must be final before their all-reduce
             _lenreg_backward_hook()
         dy = _c(dy)
         dx = torch.empty((B, Tp, C), dtype=torch.float32, device=dy.device)
@@ -1008,10 +1069,13 @@ def _ln_bwd(dy, x, res, gamma, mean, rstd, row_pad, p_in, site_in, drop, dgamma,
         dres = torch.empty_like(x) if p_in > 0 else dx
     l = _lib.lib()
     ws = _ws(l.ttsmi_add_layernorm_bwd_ws_bytes(M, C), x.device)
+    defer = _LN_PENDING is not None           # dgamma / dbeta are always gradient sinks of the flat buffer here
     check(l.ttsmi_add_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), None, None, 0,
                                     _p(row_pad), float(p_in), int(site_in), 0.0, 0, drop.seed, _p(drop.step_dev),
-                                    0, _p(dx), _p(dres), _p(dgamma), _p(dbeta), None, M, C, _p(ws), ws.numel(),
-                                    _p(dx_h), _stream()), 'add_layernorm_bwd')
+                                    0, _p(dx), _p(dres), None if defer else _p(dgamma), None if defer else _p(dbeta),
+                                    None, M, C, _p(ws), ws.numel(), _p(dx_h), _stream()), 'add_layernorm_bwd')
+    if defer:
+        _ln_defer(ws, dgamma, dbeta, None, M, C)
     return (dx_h if dx_bf16 else dx), dres
 
 
