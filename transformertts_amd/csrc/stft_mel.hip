@@ -43,7 +43,7 @@ struct MelP {
     int normalizer; float clip_min;
     float* out;
     int groups_per_wg;
-    int ablate;      // measurement only (TTSMI_MEL_ABLATE): 1 = no sample loads, 2 = no mel stage, 4 = no passes 2/3, 8 = no post-processing
+    int ablate;      // measurement only (-DTTSMI_ABLATION_BUILD + TTSMI_MEL_ABLATE): 1 = no sample loads, 2 = no mel stage, 4 = no passes 2/3, 8 = no post-processing
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -367,7 +367,11 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
     p.total_frames = total_frames; p.hop = hop; p.window = window; p.n_mels = n_mels;
     p.mel_lo = mel_lo; p.mel_cnt = mel_cnt; p.mel_ptr = mel_ptr; p.mel_w = mel_w;
     p.normalizer = normalizer; p.clip_min = clip_min; p.out = out;
+#ifdef TTSMI_ABLATION_BUILD      // stage ablation gives wrong results by construction: only in a measurement build
     { const char* e = getenv("TTSMI_MEL_ABLATE"); p.ablate = e ? atoi(e) : 0; }
+#else
+    p.ablate = 0;
+#endif
     long groups = (total_frames + FR_PER_WG - 1) / FR_PER_WG;
     int gpw = 1;
     while (gpw < 16 && groups / (gpw * 2) >= 2048) gpw *= 2;   // amortise the twiddle build
