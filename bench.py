@@ -268,20 +268,20 @@ def cpu_baseline(cfg, shape, threads):
     (a slice of the batch axis of the same workload)."""
     from oracle import ft_oracle as fo
     torch.set_num_threads(threads)
-    Bs = max(1, min(2, shape['B']))
+    Bs = max(1, min(4, shape['B']))
     W = fo.init_weights(cfg, seed=0)
     m = fo.ForwardTransformerOracle(cfg, W, torch.float32)
     batch = fo.synthetic_batch(Bs, shape['Tp'], shape['Tm'], seed=1234)
     m.train_step(*batch)                                  # warm-up
-    n = 2
-    t0 = time.perf_counter()
-    for _ in range(n):
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < 12.0 and n < 40):     # a bounded sample: >= 3 steps, ~12 s of CPU work
         m.train_step(*batch)
+        n += 1
     dt = (time.perf_counter() - t0) / n
     return {'value': Bs * shape['Tm'] / dt, 'unit': 'mel-frames/s', 'cores': threads, 'kind': 'port',
             'sample': f'B={Bs} samples of the same {shape["Tp"]}-phoneme/{shape["Tm"]}-frame workload, '
-                      f'1 warm-up + {n} timed train steps, torch-CPU fp32 restatement of the TF2 graph '
-                      f'(TF2 unavailable offline), {threads} threads, {dt:.2f} s/step'}
+                      f'1 warm-up + {n} timed train steps ({n * dt:.1f} s), torch-CPU fp32 restatement of the TF2 '
+                      f'graph (TF2 unavailable offline), {threads} threads, {dt:.2f} s/step'}
 
 
 def main():
