@@ -10,6 +10,12 @@ installable in the build image and the reference's own tests pin nothing on this
 docstring example (model/layers.py:532-542), which tests/test_oracle.py checks.  Everything else
 here is a line-by-line restatement of the reference *source*, with the Keras defaults it relies on
 restated from the public Keras documentation (marked [3P]).
+What IS pinned against the reference's own code: its plain-NumPy / pure-Python pieces run in the build
+container (tests/golden/make_reference_fixtures.py imports them from /root/reference with empty stand-ins
+for the absent third-party modules) - positional_encoding, the two padding-mask constructors (over a
+five-op NumPy stand-in for TF), the tokenizer, the lr / reduction schedules; tests/test_reference_fixtures.py
+holds this oracle (and the product's host code) to those vectors bit for bit.  The TensorFlow arithmetic
+(layers, losses, gradients, Adam) remains unpinned.
 
 The restatement is written once in torch-CPU and parameterised by dtype:
   * ``torch.float64``  - the truth the 1e-4 relative tolerance is measured against;

@@ -14,6 +14,9 @@ and not vendored under /root/reference.  Its published algorithm is restated bel
       S given  =>  used as is (magnitude, i.e. power=1 semantics), mel_basis (fp32) @ S (fp32)
   librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=False, norm=1)   Slaney scale + area norm
 
+Pinned against the reference's own code (tests/golden/make_reference_fixtures.py ->
+tests/test_reference_fixtures.py): the MelGAN / WaveRNN normalisers (data/audio.py:209-242, plain NumPy in the
+reference) - the STFT and the mel basis (librosa) are not.
 Anchors available without librosa (tests/test_oracle.py): the Slaney mel-frequency table from
 librosa's public documentation, torch.stft(center=True, reflect,
 periodic hann) on CPU, scipy's get_window, and analytic inputs (silence, pure sine).
