@@ -14,8 +14,11 @@ What IS pinned against the reference's own code: its plain-NumPy / pure-Python p
 container (tests/golden/make_reference_fixtures.py imports them from /root/reference with empty stand-ins
 for the absent third-party modules) - positional_encoding, the two padding-mask constructors (over a
 five-op NumPy stand-in for TF), the tokenizer, the lr / reduction schedules; tests/test_reference_fixtures.py
-holds this oracle (and the product's host code) to those vectors bit for bit.  The TensorFlow arithmetic
-(layers, losses, gradients, Adam) remains unpinned.
+holds this oracle (and the product's host code) to those vectors bit for bit.  Beyond that the reference's
+MODEL SOURCE itself (model/models.py, model/layers.py, utils/losses.py) is executed over a torch-float64 stand-in
+for the ~45 TensorFlow names it uses (tests/_tf_shim.py, tests/golden/make_reference_source_run.py): forward
+outputs, losses, the gradient of every variable and predict() agree with this oracle to 1e-10 relative
+(tests/test_reference_source_run.py) - the wiring is pinned, TensorFlow's floating point and its Adam are not.
 
 The restatement is written once in torch-CPU and parameterised by dtype:
   * ``torch.float64``  - the truth the 1e-4 relative tolerance is measured against;

@@ -1,0 +1,90 @@
+"""-m gpu: the HIP path (exact-fp32 precision) against the frozen run of the reference's OWN model source
+(tests/golden/reference_source_run.npz, made by tests/golden/make_reference_source_run.py) - no oracle in
+between: forward outputs, losses and every variable's gradient of the reference's train step, and the
+reference's predict() with a speed regulator and per-symbol duration clamps.  Tolerance as everywhere on this
+path: 1e-4 relative (fp32 MFMA against an fp64 execution of the reference graph)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+
+import make_reference_source_run as gen  # noqa: E402
+from oracle import ft_oracle as fo  # noqa: E402      (config / seeded-weight helpers only)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def frozen():
+    with np.load(os.path.join(HERE, 'golden', 'reference_source_run.npz')) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _model(cfg, W):
+    from transformertts_amd.model.models import ForwardTransformer
+    m = ForwardTransformer.from_config(dict(cfg, precision='f32'))
+    m.load_weights_dict(W)
+    return m
+
+
+@pytest.mark.parametrize('name', list(gen.CASES))
+def test_train_step_equals_the_reference_source_run(frozen, name):
+    c = gen.CASES[name]
+    cfg = fo.make_config(**c['cfg'])
+    W = fo.init_weights(cfg, seed=c['wseed'], perturb=0.05)
+    g = lambda k: frozen[f'{name}/{k}']
+    val = _model(cfg, W).val_step(g('tokens'), g('mel_target'), g('durations'), g('pitch'))
+    # (dropout is 0 in these cases, so the reference's training-mode forward equals the evaluation forward)
+    assert _rel(val['decoder_attention'][str(g('dec_attn_key'))], g('dec_attn')) < TOL
+    assert _rel(val['encoder_attention'][str(g('enc_attn_key'))], g('enc_attn')) < TOL
+    assert abs(float(val['loss']) - float(g('loss'))) / float(g('loss')) < TOL
+    m = _model(cfg, W)
+    m._compile(learning_rate=1e-3)
+    got = m.train_step(g('tokens'), g('mel_target'), g('durations'), g('pitch'))
+    assert abs(float(got['loss']) - float(g('loss'))) / float(g('loss')) < TOL
+    for k, want in zip(('mel', 'duration', 'pitch'), g('losses')):
+        assert abs(float(got['losses'][k]) - float(want)) / max(abs(float(want)), 1e-30) < TOL, k
+    assert _rel(got['mel'][:, :g('out_mel').shape[1]], g('out_mel')) < TOL
+    assert _rel(got['duration'], g('out_duration')) < TOL
+    assert _rel(got['pitch'], g('out_pitch')) < TOL
+    grads = m.grads_dict()
+    names = [k[len(name) + 7:] for k in frozen if k.startswith(f'{name}/grad::')]
+    assert sorted(names) == sorted(grads)
+    gnorm = max(float(np.abs(g(f'grad::{k}')).max()) for k in names)
+    worst = ('', 0.0)
+    for k in names:
+        want = g(f'grad::{k}')
+        scale = max(float(np.abs(want).max()), 1e-3 * gnorm)   # per tensor, floored at 1e-3 of the global scale
+        e = float(np.abs(grads[k].astype(np.float64) - want).max()) / scale
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 2e-4, worst
+
+
+@pytest.mark.parametrize('name', list(gen.CASES))
+def test_predict_equals_the_reference_source_run(frozen, name):
+    c = gen.CASES[name]
+    cfg = fo.make_config(**c['cfg'])
+    W = dict(fo.init_weights(cfg, seed=c['wseed'], perturb=0.05))
+    g = lambda k: frozen[f'{name}/{k}']
+    W['dur.lin.b'] = W['dur.lin.b'] + float(g('pred_bias_shift'))
+    m = _model(cfg, W)
+    got = m.predict(g('pred_tokens'), encode=False, speed_regulator=0.8,
+                    phoneme_max_duration={str(g('pred_sym_max')): 2.0},
+                    phoneme_min_duration={str(g('pred_sym_min')): 4.0})
+    assert _rel(got['duration'], g('pred_duration')) < TOL
+    assert tuple(got['mel'].shape) == g('pred_mel').shape
+    assert _rel(got['mel'], g('pred_mel')) < TOL
