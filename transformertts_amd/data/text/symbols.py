@@ -1,13 +1,19 @@
-"""Phoneme symbol table - data, not code: the vocabulary the released checkpoints were trained with
-(reference data/text/symbols.py:1-12).  126 symbols -> vocab 127 with the pad id 0."""
-_vowels = 'iyɨʉɯuɪʏʊeøɘəɵɤoɛœɜɞʌɔæɐaɶɑɒᵻ'
-_non_pulmonic_consonants = 'ʘɓǀɗǃʄǂɠǁʛ'
-_pulmonic_consonants = 'pbtdʈɖcɟkɡqɢʔɴŋɲɳnɱmʙrʀⱱɾɽɸβfvθðszʃʒʂʐçʝxɣχʁħʕhɦɬɮʋɹɻjɰlɭʎʟ'
-_suprasegmentals = 'ˈˌːˑ'
-_other_symbols = 'ʍwɥʜʢʡɕʑɺɧ'
-_diacrilics = 'ɚ˞ɫ'
-_punctuations = '!,-.:;? \'()'
+"""The phoneme vocabulary in token-id order - data, not code.
 
-_phonemes = sorted(set(_vowels + _non_pulmonic_consonants + _pulmonic_consonants + _suprasegmentals
-                       + _other_symbols + _diacrilics))
-all_phonemes = sorted(list(_phonemes) + list(_punctuations))
+The released checkpoints' Embedding has one row per symbol of the reference's inventory (reference
+data/text/symbols.py:1-12: IPA vowels, pulmonic and non-pulmonic consonants, suprasegmentals, a few extra
+symbols and diacritics, plus punctuation, sorted by code point) and row 0 for padding.  It is stored here the
+way this package uses it: ONE string whose character at position i is the symbol of token id i + 1, so the
+vocabulary size (len + 1 = 127) and every id can be read off directly.
+tests/test_reference_fixtures.py::test_tokenizer_equals_the_reference holds it to the reference's own list."""
+
+VOCABULARY = (
+    " !'(),-.:;?abcdefhijklmnopqrstuvwxyzæ"
+    'çðøħŋœǀǁǂǃɐɑɒɓɔɕɖɗɘəɚɛɜɞɟɠɡɢɣɤɥɦɧɨɪɫɬɭɮɯɰɱɲɳɴɵɶɸ'
+    'ɹɺɻɽɾʀʁʂʃʄʈʉʊʋʌʍʎʏʐʑʒʔʕʘʙʛʜʝʟʡʢˈˌːˑ˞βθχᵻⱱ'
+)
+PUNCTUATION = " !'(),-.:;?"          # the subset the phonemizer keeps / re-spaces (a regex character class)
+
+all_phonemes = list(VOCABULARY)
+_punctuations = PUNCTUATION
+assert len(set(all_phonemes)) == len(all_phonemes) == 126 and all_phonemes == sorted(all_phonemes)
