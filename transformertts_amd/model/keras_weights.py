@@ -30,9 +30,14 @@ the attribute order of its constructors:
 
 The table below spells that order out against this package's variable names (the ones
 `ForwardTransformer.weights_dict()` emits and `oracle/ft_oracle.py:weight_spec` lists).  TensorFlow is
-not available offline, so the order is derived from reading the reference and Keras sources rather than
-from a file TensorFlow wrote ("parity unpinned" for this table; every slot is shape-checked on load,
-which catches any ordering mistake that swaps tensors of different shape).  Variable names written on
+not available offline, so no file written by TensorFlow pins the order; what does check it: (i) the table is
+used to load weights into the reference's OWN `ForwardTransformer`, constructed from the reference source over a
+stand-in for TensorFlow whose layer base class implements Keras' tracking rule (own variables first, then
+sub-layers in attribute-assignment order) - layer count, per-layer weight count and every slot's shape must
+match the layers the reference constructors really create, and the loaded model then reproduces the oracle's
+outputs and gradients to 1e-10 (tests/golden/make_reference_source_run.py, tests/test_reference_source_run.py);
+(ii) an independent longhand transcription of the order agrees (tests/golden/make_keras_hdf5_fixture.py);
+(iii) every slot is shape-checked on load.  Variable names written on
 save follow TensorFlow's naming scheme (`forward_transformer/Encoder/Encoder_SADB_0/.../dense/kernel:0`,
 Keras' `unique_object_name` counters in construction order); Keras never reads them back.
 """
