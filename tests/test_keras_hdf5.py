@@ -228,3 +228,55 @@ def test_load_errors_are_loud(tmp_path):
     W['enc.blk0.wq'] = W['enc.blk0.wq'][:, :8]
     with pytest.raises(ValueError, match='enc.blk0.wq'):
         save_keras_weights(str(tmp_path / 'bad.hdf5'), W, cfg, fo.VOCAB_SIZE)
+
+
+# ------------------------------------------------------------------------------ property test of the container format
+def test_random_trees_roundtrip_and_are_readable_by_real_libhdf5(tmp_path):
+    """Seeded random group trees (nested groups, names with ':' / spaces / non-ASCII, float and integer datasets of
+    rank 0-3, string and numeric attributes): writer -> reader is the identity, and the C library opens every
+    float dataset of the same files."""
+    rng = np.random.default_rng(2024)
+    alphabet = list('abcXYZ_:0189 -') + ['é', 'ß', 'ʃ']
+    L = H.find()
+    for trial in range(12):
+        w = M.Writer()
+        expect = {}
+
+        def name():
+            return ''.join(rng.choice(alphabet, size=int(rng.integers(1, 9)))).strip() or 'n'
+
+        def fill(g, path, depth):
+            for _ in range(int(rng.integers(0, 6 if depth else 9))):
+                nm = name()
+                if nm in g.children or '/' in nm or nm in ('.', '..'):
+                    continue
+                if depth < 3 and rng.random() < 0.35:
+                    sub = g.create_group(nm)
+                    sub.attrs['note'] = np.array([name().encode('utf8') for _ in range(int(rng.integers(1, 4)))])
+                    fill(sub, path + '/' + nm, depth + 1)
+                else:
+                    shape = tuple(int(x) for x in rng.integers(0, 5, size=int(rng.integers(0, 4))))
+                    dt = [np.float32, np.float64, np.int32, np.int64][int(rng.integers(0, 4))]
+                    a = (rng.standard_normal(shape) * 100).astype(dt)
+                    ds = g.create_dataset(nm, a)
+                    ds.attrs['scale'] = np.float64(rng.standard_normal())
+                    expect[path + '/' + nm] = a
+        fill(w.root, '', 0)
+        w.root.attrs['trial'] = np.int64(trial)
+        p = str(tmp_path / f't{trial}.h5')
+        w.save(p)
+        with M.File(p) as f:
+            assert int(f.attrs['trial']) == trial
+            for path, a in expect.items():
+                d = f[path]
+                got = np.asarray(d)
+                assert got.dtype == a.dtype and got.shape == a.shape, path
+                np.testing.assert_array_equal(got, a)
+                assert isinstance(float(d.attrs['scale']), float)
+        if L is not None:
+            fid = L.H5Fopen(p.encode(), 0, 0)
+            assert fid >= 0
+            for path, a in expect.items():
+                if a.dtype == np.float32 and a.size:
+                    np.testing.assert_array_equal(H._read_dataset_f32(fid, path.lstrip('/')), a)
+            L.H5Fclose(fid)
