@@ -90,7 +90,10 @@ __device__ __forceinline__ void stash_a_f32(uint16_t (*S)[HLD_], int tid, const 
     }
 }
 // ---- bf16 source tile of ROWS rows (ROWS/32 uint4 per thread) -----------------------------------
-template <int ROWS>
+// A32: the chunk address is the (wave-uniform) matrix base plus a 32-bit BYTE offset, so the compiler keeps the
+// base in SGPRs and one VGPR per chunk instead of a 64-bit pointer pair per chunk - 9 pointer pairs are what
+// the 128-register build of the kernel spills.  Valid while the operand is smaller than 4 GB (checked at launch).
+template <int ROWS, bool A32 = false>
 __device__ __forceinline__ void fetch_h(const uint16_t* base, long ld, int rows, int r0, int k0,
                                         int kend, int tid, uint4 (&r)[HNH_(ROWS)]) {
 #pragma unroll
@@ -99,7 +102,12 @@ __device__ __forceinline__ void fetch_h(const uint16_t* base, long ld, int rows,
         int row = id / HC8_, c8 = id % HC8_;
         int m = r0 + row, kk = k0 + c8 * 8;
         bool ok = (m < rows) && (kk < kend);
-        r[i] = ok ? *reinterpret_cast<const uint4*>(base + (long)m * ld + kk) : make_uint4(0, 0, 0, 0);
+        if constexpr (A32) {
+            const uint32_t boff = ((uint32_t)m * (uint32_t)ld + (uint32_t)kk) * 2u;
+            r[i] = ok ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + boff) : make_uint4(0, 0, 0, 0);
+        } else {
+            r[i] = ok ? *reinterpret_cast<const uint4*>(base + (long)m * ld + kk) : make_uint4(0, 0, 0, 0);
+        }
     }
 }
 template <int ROWS>
@@ -117,8 +125,12 @@ __device__ __forceinline__ void stash_h(uint16_t (*S)[HLD_], int tid, const uint
 // BM = 128: wave tile 64 rows (2 MFMA tiles); BM = 64: 32 rows - half the registers, twice the resident
 // workgroups.  BN = 128: wave tile 64 columns (2 MFMA tiles); BN = 256: 128 columns (4 tiles).
 // (BN = 256 is a measurement knob, see hlaunch.)
-template <bool A_F32, int BM, int BN = HBN_>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
+// MINB = 4 (measurement knob TTSMI_HGEMM_OCC4=1, bf16 A only): a 128-register build so that four workgroups fit a
+// CU instead of three (LDS allows it: 4 x 36 KB); it uses the 32-bit offset addressing above to get there
+// without spills.  Prepared and checked statically in round 1 (register / spill counts), not yet run.
+template <bool A_F32, int BM, int BN = HBN_, int MINB = 0>
+__global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(HGemmP p) {
+    constexpr bool A32 = MINB >= 4;
     constexpr int MI = BM / 64;
     constexpr int NJ = BN / 64;
     constexpr int TILE_BYTES = (BM + BN) * HLD_ * 2;
@@ -152,14 +164,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
     // step lies wholly inside one segment
     auto fetch_a_h = [&](int k0) {
         if (p.A2 != nullptr && k0 >= p.K1)
-            fetch_h<BM>((const uint16_t*)p.A2, p.lda2, p.M, m0, k0 - p.K1, kend - p.K1, tid, rah);
+            fetch_h<BM, A32>((const uint16_t*)p.A2, p.lda2, p.M, m0, k0 - p.K1, kend - p.K1, tid, rah);
         else
-            fetch_h<BM>((const uint16_t*)p.A, p.lda, p.M, m0, k0, p.A2 != nullptr ? min(kend, p.K1) : kend, tid, rah);
+            fetch_h<BM, A32>((const uint16_t*)p.A, p.lda, p.M, m0, k0, p.A2 != nullptr ? min(kend, p.K1) : kend, tid, rah);
     };
     if (kbeg < kend) {
         if constexpr (A_F32) fetch_a_f32<BM>(p, m0, kbeg, kend, tid, ra);
         else fetch_a_h(kbeg);
-        fetch_h<BN>(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
+        fetch_h<BN, A32>(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
         if constexpr (A_F32) stash_a_f32<BM>(As, tid, ra); else stash_h<BM>(As, tid, rah);
         stash_h<BN>(Bs, tid, rb);
     }
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(HGemmP p) {
         if (more) {
             if constexpr (A_F32) fetch_a_f32<BM>(p, m0, k0 + HBK_, kend, tid, ra);
             else fetch_a_h(k0 + HBK_);
-            fetch_h<BN>(p.B, p.ldb, p.N, n0, k0 + HBK_, kend, tid, rb);
+            fetch_h<BN, A32>(p.B, p.ldb, p.N, n0, k0 + HBK_, kend, tid, rb);
         }
         if (do_colsum) {                       // bias gradient from the dy^T tile (wgrad)
 #pragma unroll
@@ -1083,9 +1095,9 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
     }
     // LDS-DMA persistent kernel (TTSMI_HGEMM_DMA=1 enables it for decoder-size launches, 2 for all eligible ones)
     static int use_dma = -1;
-    // OFF by default: with this kernel enabled, tools/check_determinism.py --once --steps 120 gave differing
-    // checksums (and one NaN) across processes - a rare race in its stage hand-off that round 1 did not find;
-    // with it off (and the DMA wgrad on) the step is bit-reproducible.  It is worth ~1 % of the step.
+    // OFF by default: faster alone, not inside the step (A/B 7.74 vs 7.70 ms).  Its first version had a race
+    // (ds_reads still queued at a bare s_barrier, see lds_stage_barrier) that tools/check_determinism.py found;
+    // fixed, and bit-identical to the register-staged kernel over 6 x 150 steps.
     if (use_dma < 0) { const char* e = getenv("TTSMI_HGEMM_DMA"); use_dma = e ? atoi(e) : 0; }
     if (use_dma && !a_f32 && splits == 1 && p.colsum == nullptr && p.a_taps == 1 && p.K % HBK_ == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 &&
         (p.A2 == nullptr || (p.K1 % HBK_ == 0 && p.lda2 % 8 == 0 && al16(p.A2)))) {
@@ -1103,6 +1115,15 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
     p.tiles_m = ttsmi_cdiv(p.M, bm);
     p.tiles_n = ttsmi_cdiv(p.N, HBN_);
     dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+    static int occ4 = -1;      // measurement knob, default off: the 4-workgroups-per-CU build (see the kernel's comment)
+    if (occ4 < 0) { const char* e = getenv("TTSMI_HGEMM_OCC4"); occ4 = e ? atoi(e) : 0; }
+    const auto fits32 = [](long rows, long ld) { return rows * ld * 2 < (1L << 32); };
+    if (occ4 && !a_f32 && bm == 128 && fits32(p.M, p.lda) && fits32(p.N, p.ldb) &&
+        (p.A2 == nullptr || fits32(p.M, p.lda2))) {
+        hipLaunchKernelGGL((gemm_bf16_kernel<false, 128, HBN_, 4>), grid, dim3(256), 0, st, p);
+        TTSMI_CHECK_LAUNCH(name);
+        return TTSMI_OK;
+    }
     if (a_f32) {
         if (bm == 64) hipLaunchKernelGGL((gemm_bf16_kernel<true, 64>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_bf16_kernel<true, 128>), grid, dim3(256), 0, st, p);
