@@ -281,7 +281,9 @@ def cpu_baseline(cfg, shape, threads):
     return {'value': Bs * shape['Tm'] / dt, 'unit': 'mel-frames/s', 'cores': threads, 'kind': 'port',
             'sample': f'B={Bs} samples of the same {shape["Tp"]}-phoneme/{shape["Tm"]}-frame workload, '
                       f'1 warm-up + {n} timed train steps ({n * dt:.1f} s), torch-CPU fp32 restatement of the TF2 '
-                      f'graph (TF2 unavailable offline), {threads} threads, {dt:.2f} s/step'}
+                      f'graph (TF2 unavailable offline), {threads} threads, {dt:.2f} s/step; like the reference it '
+                      f'materialises and returns the 12 attention maps every step (the GPU `value` does not: compare '
+                      f'with ms_per_step_with_attention_maps)'}
 
 
 def main():
@@ -299,12 +301,27 @@ def main():
     # overlap differently - measured 8.9 ms (graph) vs 8.1 ms (eager) per step when last compared.
     ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-attention-maps', dest='with_attention_maps', action='store_false',
+                    help='skip the extra timed leg that also materialises the 12 attention maps')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` as typed: start one rank per GPU ourselves (the same launcher the driver uses)
+        import socket
+        sock = socket.socket()
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                                  f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+                                  '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     from transformertts_amd import dp
     rank, local, world = dp.init_process_group()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     local = local % max(1, torch.cuda.device_count())     # (ranks may share a GPU in functional tests)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -345,6 +362,35 @@ def main():
     assert np.isfinite(loss), 'non-finite loss'
     frames = shape['B'] * shape['Tm'] * world
     ms = 1e3 * elapsed / args.steps
+    ranks_seen = None
+    if world > 1:
+        # what each rank's collective library saw: backend "nccl" is RCCL on ROCm, one device per rank
+        mine = {'rank': rank, 'backend': torch.distributed.get_backend(), 'world': torch.distributed.get_world_size(),
+                'device': f'cuda:{local} {torch.cuda.get_device_name(local)}'}
+        ranks_seen = [None] * world
+        torch.distributed.all_gather_object(ranks_seen, mine)
+
+    # the same step with the reference's full output dictionary: the 12 attention maps [B,H,T,T] of
+    # model/models.py:544-549 materialised too (train_step leaves them out unless asked: reference_outputs=True)
+    ms_attn = None
+    if args.with_attention_maps and args.precision == 'bf16':
+        model.reference_outputs = True
+        for _ in range(2):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        n_attn = max(3, args.steps // 2)
+        for _ in range(n_attn):
+            out_a = step()
+        sync()
+        ms_attn = 1e3 * (time.perf_counter() - t1) / n_attn
+        if world > 1:
+            t = torch.tensor([ms_attn], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            ms_attn = float(t.item())
+        assert len(out_a['decoder_attention']) == len(cfg['decoder_num_heads'])
+        del out_a
+        model.reference_outputs = False
 
     result = {
         'metric': 'mel-frames/sec (train step)', 'value': frames / (elapsed / args.steps),
@@ -357,7 +403,10 @@ def main():
                                f'(max-shape set), dropout {args.dropout}'
                    if args.workload == 'configs[1]' else args.workload,
                    'global_batch': shape['B'] * world, 'parallelism': f'dp{world}',
-                   'params': model.params.n_params, 'loss_after': loss},
+                   'params': model.params.n_params, 'loss_after': loss, 'ranks_seen': ranks_seen},
+        # value/ms_per_step: train_step without the 12 [B,H,T,T] attention maps in its output (they are
+        # not materialised on the throughput path); the second figure is the same step returning them all
+        'ms_per_step_with_attention_maps': ms_attn,
     }
 
     if rank == 0 and not args.no_roofline:
@@ -388,6 +437,10 @@ def main():
             'per_kernel': {k: {'launches': v[0], 'gflop': v[1] / 1e9, 'algorithmic_mb': v[2] / 1e6, 'ms': v[3],
                                'tflops': (v[1] / v[3] / 1e9 if v[1] else None),
                                'gbs': (v[2] / v[3] / 1e6 if v[2] else None)} for k, v in groups.items()},
+            'c_abi_calls_per_step': sum(v[0] for v in groups.values()),
+            'launch_ms_note': 'sums of per-launch HIP-event times from ONE extra instrumented step (every launch '
+                              'bracketed by two events while the weight-gradient stream contends): slower than the '
+                              'timed steps, so main_stream_launch_ms may exceed ms_per_step',
             'main_stream_launch_ms': sum(v[3] for k, v in groups.items() if not k.endswith(SIDE)),
             'side_stream_launch_ms': sum(v[3] for k, v in groups.items() if k.endswith(SIDE)),
         }

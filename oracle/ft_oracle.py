@@ -296,8 +296,9 @@ def self_attention_block(W, p, x, mask, heads, dense, rate, training, drop):
 
 
 def self_attention_blocks(W, prefix, name, x, mask, heads_list, dense_blocks, pe, rate, training,
-                          drop):
-    """SelfAttentionBlocks.call layers.py:297-310."""
+                          drop, taps=None):
+    """SelfAttentionBlocks.call layers.py:297-310.  taps (test instrumentation): a list that receives
+    (f'{prefix}.blk{i}', block output) for every block - used to report error per layer depth."""
     T = x.shape[1]
     x = layer_norm(x, W[f'{prefix}.ln.gamma'], W[f'{prefix}.ln.beta'])          # layers.py:299
     x = x + W[f'{prefix}.pos_scalar'] * pe[None, :T, :]                         # layers.py:300
@@ -310,6 +311,8 @@ def self_attention_blocks(W, prefix, name, x, mask, heads_list, dense_blocks, pe
             attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = w                 # layers.py:305
         else:
             attn[f'{name}_ConvBlock{i - dense_blocks + 1}_SelfAttention'] = w   # layers.py:308
+        if taps is not None:
+            taps.append((f'{prefix}.blk{i}', x.detach()))
     return x, attn
 
 
@@ -441,7 +444,8 @@ class ForwardTransformerOracle:
         h = W['embedding'][x]                                                          # :522
         h, enc_attn = self_attention_blocks(W, 'enc', 'Encoder', h, encoder_padding_mask,
                                             cfg['encoder_num_heads'], cfg['encoder_dense_blocks'],
-                                            self.pe_enc, rate, training, self.drop)    # :523
+                                            self.pe_enc, rate, training, self.drop,
+                                            getattr(self, 'taps', None))               # :523
         padding_mask = 1. - encoder_padding_mask[:, 0, 0, :, None]                     # :524
         durations = stat_predictor(W, 'dur', h, padding_mask, len(cfg['duration_conv_filters']),
                                    True, prate, training, self.drop)                   # :525
@@ -467,7 +471,8 @@ class ForwardTransformerOracle:
         expanded_mask = create_mel_padding_mask(mels.detach())                         # :541
         mels, dec_attn = self_attention_blocks(W, 'dec', 'Decoder', mels, expanded_mask,
                                                cfg['decoder_num_heads'], cfg['decoder_dense_blocks'],
-                                               self.pe_dec, rate, training, self.drop)  # :542
+                                               self.pe_dec, rate, training, self.drop,
+                                               getattr(self, 'taps', None))            # :542
         mels = mels @ W['out.w'] + W['out.b']                                          # :543
         return {'mel': mels, 'duration': durations, 'pitch': pitch,
                 'expanded_mask': expanded_mask, 'encoder_attention': enc_attn,

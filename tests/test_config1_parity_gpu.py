@@ -1,0 +1,145 @@
+"""-m gpu parity at the BENCHMARKED architecture (BASELINE.json configs[1]: d_model 256, 6+6 dense blocks, 4 heads,
+FFN 1024, predictors [256,226]) - the configuration bench.py times - against the fp64 oracle's frozen results
+(tests/golden/ft_config1.npz, written by tests/golden/make_config1_golden.py; the fp64 run takes ~75 s and 4 GB per
+step, so it is frozen rather than repeated here).  Reference: model/models.py:464-482 (_train_step).
+
+Both precisions, one LJ-dist ragged batch and one max-shape batch of 4 x 200 phonemes x 900 frames:
+  * precision='f32' (the parity path): loss / losses / mel / duration / pitch within 1e-4 relative, every one of
+    the 223 gradients within 2e-4 of its own scale (sampled elements + L2 norm + sum of each tensor);
+  * precision='bf16' (the path bench.py measures): the same quantities against the SAME oracle with the bf16
+    bounds below, and the error of every block's output reported per layer depth (12 stacked bf16 blocks on an
+    fp32 residual stream is where rounding accumulates)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ft_oracle as fo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+import make_config1_golden as g1  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+# precision -> bounds.  'fwd': mel / duration / pitch (max abs error over max abs value); 'loss': the total and the
+# three terms (relative); 'grad': per tensor, max abs error of the sampled elements over max(|g|_max, 1e-3 * the
+# largest |g|_max of the model); 'gnorm': relative error of each tensor's L2 norm (tensors above the same floor);
+# 'tap': per block output, max abs error of the samples over the tensor's max abs value.
+BOUNDS = {
+    'f32': dict(fwd=1e-4, loss=1e-4, grad=2e-4, gnorm=2e-4, tap=1e-4),
+    'bf16': dict(fwd=3e-2, loss=5e-3, grad=1.5e-1, gnorm=5e-2, tap=3e-2),
+}
+
+
+@pytest.fixture(scope='module')
+def gold():
+    with np.load(os.path.join(HERE, 'golden', 'ft_config1.npz')) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope='module')
+def setup():
+    cfg = fo.make_config()
+    return cfg, fo.init_weights(cfg, seed=g1.WEIGHT_SEED, perturb=g1.PERTURB)
+
+
+def _relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _run(cfg, W, tag, precision):
+    from transformertts_amd.model.models import ForwardTransformer
+    batch = fo.synthetic_batch(*g1.SHAPE, **g1.BATCHES[tag])
+    m = ForwardTransformer.from_config(dict(cfg, precision=precision))
+    m.load_weights_dict(W)
+    m._compile(learning_rate=1e-3)
+    m._taps = []
+    out = m.train_step(*batch)
+    torch.cuda.synchronize()
+    return m, out
+
+
+def _compare(gold, tag, m, out, bounds):
+    g = lambda k: gold[f'{tag}::{k}']
+    report = {}
+    # forward
+    report['mel'] = _relmax(out['mel'].float().cpu().numpy(), g('mel'))
+    report['duration'] = _relmax(out['duration'].float().cpu().numpy(), g('duration'))
+    report['pitch'] = _relmax(out['pitch'].float().cpu().numpy(), g('pitch'))
+    report['loss'] = abs(float(out['loss']) - float(g('loss'))) / float(g('loss'))
+    for i, k in enumerate(('mel', 'duration', 'pitch')):
+        report[f'loss_{k}'] = abs(float(out['losses'][k]) - g('losses')[i]) / g('losses')[i]
+    # per-block hidden states, by depth
+    taps = {}
+    for name, t in m._taps:
+        a = t.float().cpu().numpy().reshape(-1)
+        want = g(f'tap::{name}')
+        taps[name] = float(np.abs(a[g1.sample_index('tap::' + name, a.size)] - want).max() / float(g(f'tapmax::{name}')))
+    report['taps'] = taps
+    # gradients
+    grads = m.grads_dict()
+    names = [k[len(tag) + 5:] for k in gold if k.startswith(f'{tag}::g::')]
+    assert sorted(names) == sorted(grads), 'gradient set differs from the oracle variable set'
+    gmax = max(float(g(f'gstat::{k}')[0]) for k in names)
+    worst, worst_norm = ('', 0.0), ('', 0.0)
+    for k in names:
+        a = grads[k].astype(np.float64).reshape(-1)
+        absmax, l2, total = g(f'gstat::{k}')
+        scale = max(absmax, 1e-3 * gmax)
+        e = float(np.abs(a[g1.sample_index(k, a.size)] - g(f'g::{k}')).max() / scale)
+        if e > worst[1]:
+            worst = (k, e)
+        if absmax > 1e-3 * gmax:
+            en = abs(float(np.sqrt((a * a).sum())) - l2) / l2
+            if en > worst_norm[1]:
+                worst_norm = (k, en)
+    report['grad_worst'], report['gnorm_worst'] = worst, worst_norm
+    return report
+
+
+def _check(report, b):
+    for k in ('mel', 'duration', 'pitch'):
+        assert report[k] < b['fwd'], (k, report[k])
+    for k in ('loss', 'loss_mel', 'loss_duration', 'loss_pitch'):
+        assert report[k] < b['loss'], (k, report[k])
+    for name, e in report['taps'].items():
+        assert e < b['tap'], (name, e)
+    assert report['grad_worst'][1] < b['grad'], report['grad_worst']
+    assert report['gnorm_worst'][1] < b['gnorm'], report['gnorm_worst']
+
+
+def _dump(tag, precision, report):
+    """Print the achieved errors (and keep them under gpurun_out/ when that scratch directory exists, so the
+    numbers quoted in DESIGN.md can be copied from a round's own run)."""
+    line = {'batch': tag, 'precision': precision, **{k: v for k, v in report.items()}}
+    print('\nconfig1 parity', json.dumps(line))
+    d = os.path.join(os.path.dirname(HERE), 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'config1_parity.jsonl'), 'a') as f:
+            f.write(json.dumps(line) + '\n')
+
+
+@pytest.mark.parametrize('tag', ['ragged', 'maxshape'])
+def test_f32_path_matches_the_fp64_oracle_at_the_benchmarked_architecture(gold, setup, tag):
+    cfg, W = setup
+    m, out = _run(cfg, W, tag, 'f32')
+    report = _compare(gold, tag, m, out, BOUNDS['f32'])
+    _dump(tag, 'f32', report)
+    _check(report, BOUNDS['f32'])
+
+
+@pytest.mark.parametrize('tag', ['ragged', 'maxshape'])
+def test_bf16_path_tracks_the_fp64_oracle_at_the_benchmarked_architecture(gold, setup, tag):
+    cfg, W = setup
+    m, out = _run(cfg, W, tag, 'bf16')
+    report = _compare(gold, tag, m, out, BOUNDS['bf16'])
+    _dump(tag, 'bf16', report)
+    _check(report, BOUNDS['bf16'])
+    # depth profile: the error of the decoder's last block must not have exploded relative to its first
+    dec = [report['taps'][f'dec.blk{i}'] for i in range(6)]
+    assert dec[-1] < 20 * max(dec[0], 1e-3), dec

@@ -1,4 +1,4 @@
-"""world_size-2 `gloo` test of the data-parallel path on CPU (the model itself needs a GPU, so the
+"""world_size-2 tests of the data-parallel path: `gloo` on CPU (the model itself needs a GPU, so the
 per-rank gradients come from the CPU oracle here; what is under test is transformertts_amd/dp.py:
 sharding, the single flat-buffer all-reduce, parameter broadcast, and the claim that averaging the
 per-rank gradients of equal-shape shards equals the gradient of the global-batch loss)."""
@@ -93,18 +93,20 @@ def test_world_size_one_is_degenerate():
     assert torch.equal(g, torch.ones(4))
 
 
-def _gpu_worker(rank, world, port, out_dir):
+def _gpu_worker(rank, world, port, out_dir, backend='gloo'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
-                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), TTSMI_DIST_BACKEND='gloo')
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), TTSMI_DIST_BACKEND=backend,
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
     from oracle import ft_oracle as fo
     from transformertts_amd import dp
     from transformertts_amd.model.models import ForwardTransformer
     r, local, w = dp.init_process_group()
-    assert dist.get_backend() == 'gloo' and w == world
-    torch.cuda.set_device(0)                                  # both ranks share the one GPU of the test box
+    assert dist.get_backend() == backend and w == world
+    dev = rank if backend == 'nccl' else 0                    # gloo: both ranks share the one GPU of the test box
+    torch.cuda.set_device(dev)
     cfg = fo.tiny_config()
     W = fo.init_weights(cfg, seed=1, perturb=0.02)
-    model = ForwardTransformer.from_config(dict(cfg, device='cuda:0', seed=100 + rank, precision='bf16'))
+    model = ForwardTransformer.from_config(dict(cfg, device=f'cuda:{dev}', seed=100 + rank, precision='bf16'))
     if rank == 0:
         model.load_weights_dict({k: np.asarray(v) for k, v in W.items()})   # rank 1 keeps its own random init
     model._compile(learning_rate=1e-3)
@@ -121,14 +123,18 @@ def _gpu_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_gpu_match_the_global_batch_step(tmp_path):
-    """The whole DP path with the real model (two ranks sharing the GPU over gloo): parameter broadcast, the
-    backward hook, the overlapped two-bucket gradient all-reduce and the replicated Adam step must leave both
-    ranks with identical weights, equal to a single process stepping on the global batch."""
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_two_ranks_match_the_global_batch_step(tmp_path, backend):
+    """The whole DP path with the real model - two ranks sharing the GPU over gloo, and (on a box with >= 2 GPUs,
+    skipped otherwise) one rank per GPU over RCCL (backend "nccl"): parameter broadcast, the backward hook, the
+    overlapped two-bucket gradient all-reduce and the replicated Adam step must leave both ranks with identical
+    weights, equal to a single process stepping on the global batch."""
     from oracle import ft_oracle as fo
     from transformertts_amd.model.models import ForwardTransformer
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('RCCL needs one GPU per rank: fewer than 2 GPUs visible')
     port = _free_port()
-    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path), backend), nprocs=2, join=True)
     w0, w1 = np.load(tmp_path / 'w0.npy'), np.load(tmp_path / 'w1.npy')
     np.testing.assert_array_equal(w0, w1)
     cfg = fo.tiny_config()

@@ -450,10 +450,11 @@ def test_dp_overlap_hook_plumbing_on_one_gpu(tiny):
     wrapped.sync = sync
     m.grad_sync = sync
     wrapped.install_overlap_hook()
-    try:
-        got = wrapped.train_step(*batch)
-    finally:
-        ops.set_lenreg_backward_hook(None)
+    got = wrapped.train_step(*batch)
+    # the hook lives on the wrapped model only: a second model's backward in the same process must not fire it
+    n_calls = len(calls)
+    ref.train_step(*batch)
+    assert len(calls) == n_calls and ref._lenreg_hook is None and m._lenreg_hook is not None
     g = m.params.grad
     split = wrapped.split
     assert 0 < split < g.numel() and m.params.offsets['dec.ln.gamma'][0] == split

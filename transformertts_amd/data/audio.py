@@ -174,10 +174,11 @@ class Audio:
         frame_off = np.zeros(len(lengths) + 1, dtype=np.int64)
         frame_off[1:] = np.cumsum(frames)
         lo, cnt, ptr, w = self._mel
-        out = ops.stft_logmel(cat, torch.from_numpy(clip_off).to(self.device),
-                              torch.from_numpy(frame_off).to(self.device), int(frame_off[-1]), self.n_fft,
-                              self.hop_length, self._window, self.mel_channels, lo, cnt, ptr, w,
-                              self.normalizer.kernel_id, float(self.normalizer.clip_min))
+        with torch.cuda.device(self.device):      # the launch stream follows torch's CURRENT device
+            out = ops.stft_logmel(cat, torch.from_numpy(clip_off).to(self.device),
+                                  torch.from_numpy(frame_off).to(self.device), int(frame_off[-1]), self.n_fft,
+                                  self.hop_length, self._window, self.mel_channels, lo, cnt, ptr, w,
+                                  self.normalizer.kernel_id, float(self.normalizer.clip_min))
         return out, frame_off
 
     def mel_spectrogram(self, wav):

@@ -12,8 +12,7 @@ VOCABULARY = (
     'çðøħŋœǀǁǂǃɐɑɒɓɔɕɖɗɘəɚɛɜɞɟɠɡɢɣɤɥɦɧɨɪɫɬɭɮɯɰɱɲɳɴɵɶɸ'
     'ɹɺɻɽɾʀʁʂʃʄʈʉʊʋʌʍʎʏʐʑʒʔʕʘʙʛʜʝʟʡʢˈˌːˑ˞βθχᵻⱱ'
 )
-PUNCTUATION = " !'(),-.:;?"          # the subset the phonemizer keeps / re-spaces (a regex character class)
+PUNCTUATION = " !'(),-.:;?"          # the punctuation subset of the vocabulary
 
-all_phonemes = list(VOCABULARY)
-_punctuations = PUNCTUATION
-assert len(set(all_phonemes)) == len(all_phonemes) == 126 and all_phonemes == sorted(all_phonemes)
+all_phonemes = list(VOCABULARY)       # the reference's name for the same list (data/text/symbols.py:12)
+assert len(set(VOCABULARY)) == len(VOCABULARY) == 126 and all_phonemes == sorted(all_phonemes)

@@ -45,7 +45,7 @@ class GradAllReduce:
 
     Two buckets on RCCL: the flat buffer is laid out [embedding | encoder | predictors | pitch_embed |
     decoder | mel-out], and backward produces the decoder half first.  `start_tail(flat_grad, split)` is
-    called when backward crosses from the decoder into the encoder (ops.set_lenreg_backward_hook): it
+    called when backward crosses from the decoder into the encoder (model._lenreg_hook, ops.LenRegFn): it
     launches the all-reduce of `flat_grad[split:]` asynchronously, ordered after everything the main and
     the weight-gradient streams have queued so far, so that it runs over xGMI underneath the encoder's
     backward.  `__call__` then reduces the head `[:split]` and joins the tail.  Every rank issues the two
@@ -126,6 +126,10 @@ class DataParallel:
             broadcast_parameters(model.params.data, 0, group)
             if getattr(model, 'shadow', None) and hasattr(model, '_refresh_shadows'):
                 model._refresh_shadows(False)             # bf16 weight copies follow the broadcast weights
+        if self.sync.world > 1 and getattr(model, 'drop', None) is not None:
+            # replicas share the weight-init seed but must not share dropout masks: every rank draws its own stream
+            rank = dist.get_rank(group)
+            model.drop.seed = (model.drop.seed ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
         if self.sync.world > 1 and self.sync.overlap:
             self.install_overlap_hook()
 
@@ -139,7 +143,7 @@ class DataParallel:
         def _hook():
             if model.grad_sync is not None and not getattr(model, 'use_graph', False):
                 self.sync.start_tail(model.params.grad, self.split, ops.wgrad_stream())
-        ops.set_lenreg_backward_hook(_hook)
+        model._lenreg_hook = _hook           # on the model, not global: other models in the process are untouched
 
     def __getattr__(self, name):
         return getattr(self.model, name)

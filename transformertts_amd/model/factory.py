@@ -1,8 +1,8 @@
 """Model factory mirror (reference model/factory.py:10-29).
 
 `tts_custom(config_path, weights_path)` keeps the reference signature.  `tts_ljspeech` downloads a
-released checkpoint from S3 in the reference (model/factory.py:10-19); there is no network here and
-the release is a Keras HDF5 file, so it raises with instructions instead of pretending."""
+released checkpoint from S3 in the reference (model/factory.py:10-19); downloading is out of scope, so it
+raises and points at `tts_custom`, which loads the unpacked release (its Keras HDF5 weights) directly."""
 from __future__ import annotations
 
 from typing import Tuple
@@ -25,6 +25,7 @@ def tts_custom(config_path: str, weights_path: str, **overrides) -> Tuple[Forwar
 
 
 def tts_ljspeech(step='95000'):
-    raise RuntimeError('tts_ljspeech downloads bdf06b9_ljspeech_step_%s.zip (Keras HDF5) from S3 in the '
-                       'reference; offline, convert the checkpoint to .npz with the reference variable '
-                       'names and call tts_custom(config_path, weights_path)' % step)
+    raise RuntimeError('tts_ljspeech downloads bdf06b9_ljspeech_step_%s.zip from S3 in the reference (downloads are '
+                       'out of scope here): unpack the release yourself and call '
+                       'tts_custom("<dir>/config.yaml", "<dir>/model_weights.hdf5") - the Keras HDF5 file loads as is'
+                       % step)

@@ -34,6 +34,20 @@ from ..utils.losses import masked_mean_absolute_error, weighted_sum_losses
 from .transformer_utils import positional_encoding
 
 
+def _on_device(fn):
+    """Run a method with the model's GPU current: `device=` decides where the tensors live, but the launch
+    stream, the weight-gradient side stream and every temporary follow torch's CURRENT device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kw):
+        if torch.cuda.current_device() == self.device.index:
+            return fn(self, *args, **kw)
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kw)
+    return wrapper
+
+
 def _blocks_spec(prefix, d, heads, dense_blocks, ffn, conv_filters, conv_kernel):
     s = OrderedDict()
     s[f'{prefix}.ln.gamma'] = (d,)
@@ -140,6 +154,8 @@ class ForwardTransformer:
         # reference model/models.py:345-440.  Unknown keys are tolerated and echoed in self.config.
         self.config = self._make_config(locals(), kwargs)
         self.device = torch.device(kwargs.get('device', 'cuda:0'))
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device() if torch.cuda.is_available() else 0)
         if self.device.type != 'cuda' or not torch.cuda.is_available():
             raise ops._lib.TtsmiError('ForwardTransformer runs on an MI355X through libttsmi.so; no GPU is '
                                       'visible and there is no CPU fallback')
@@ -189,7 +205,12 @@ class ForwardTransformer:
         self._graphs: Dict[tuple, dict] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
         self.grad_sync = None                # set by transformertts_amd.dp.DataParallel
+        self._lenreg_hook = None             # DataParallel: starts the decoder-half all-reduce (ops.LenRegFn.backward)
+        # reference_outputs=True: train_step returns the 12 attention maps like the reference's _train_step
+        # (models.py:544-549) instead of leaving the dicts empty - see the module docstring
+        self.reference_outputs = bool(kwargs.get('reference_outputs', False))
         self.debug = debug
+        self._taps = None                    # test instrumentation: a list receives (f'{prefix}.blk{i}', block output)
         self._init_weights(int(kwargs.get('seed', 0)))
         self._build_shadows()
 
@@ -201,6 +222,7 @@ class ForwardTransformer:
             elif leaf == 'w' and w.dim() == 3:          # Conv1D weights: predictors and conv blocks
                 yield name
 
+    @_on_device
     def _build_shadows(self):
         """bf16 operand copies of the GEMM weights (precision == 'bf16' only)."""
         self.shadow = {}
@@ -258,6 +280,7 @@ class ForwardTransformer:
                 w.copy_(a.to(self.device))
 
     # ------------------------------------------------------------------ weights interchange
+    @_on_device
     def load_weights_dict(self, weights: Dict[str, np.ndarray]):
         """Load reference-named variables (separate wq/wk/wv, see oracle/ft_oracle.py:weight_spec -
         the Keras variable layout: Dense [in,out], Conv1D [k,in,out])."""
@@ -306,6 +329,10 @@ class ForwardTransformer:
         W, G, drop, S = self.params.w, self.params.g, self.drop, self.shadow.get
         B, T, d = x.shape
         M = B * T
+        if T > pe.shape[0]:
+            # the kernel indexes pe[(row % T) * d]; the reference fails on pos_encoding[:, :seq_len] (layers.py:300)
+            raise ValueError(f'{name}: sequence length {T} exceeds the positional-encoding table '
+                             f'({pe.shape[0]} positions; {prefix}oder_max_position_encoding)')
         h = ops.add_layernorm(x.reshape(M, d), None, W[f'{prefix}.ln.gamma'], W[f'{prefix}.ln.beta'],
                               G[f'{prefix}.ln.gamma'], G[f'{prefix}.ln.beta'], pe=pe,
                               pe_scale=W[f'{prefix}.pos_scalar'], gpe_scale=G[f'{prefix}.pos_scalar'], T=T,
@@ -327,6 +354,8 @@ class ForwardTransformer:
                 if want_attn:
                     attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
                         qkv.float() if qkv.dtype != torch.float32 else qkv, pad, lse, B, H, T, d // H, rate, drop, sites[0])
+                if self._taps is not None:
+                    self._taps.append((p, h.detach().reshape(B, T, d)))
                 continue
             h_bf = None
             qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'],
@@ -357,6 +386,8 @@ class ForwardTransformer:
                 f = ops.ConvStackFn.apply(a.reshape(B, T, d), n, shs, *ps, *gs).reshape(M, d)
             h = ops.add_layernorm(f, a, W[f'{p}.ln2.gamma'], W[f'{p}.ln2.beta'], G[f'{p}.ln2.gamma'],
                                   G[f'{p}.ln2.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop)
+            if self._taps is not None:
+                self._taps.append((p, h.detach().reshape(B, T, d)))
         return h.reshape(B, T, d), attn
 
     _BLOCK_KEYS = ('wqkv', 'bqkv', 'wo', 'bo', 'ln1.gamma', 'ln1.beta', 'ffn.w1', 'ffn.b1', 'ffn.w2', 'ffn.b2',
@@ -390,6 +421,7 @@ class ForwardTransformer:
                                   G[f'{prefix}.lin.b'], pad, relu_head)
 
     # ------------------------------------------------------------------ reference model/models.py:518-550
+    @_on_device
     def call(self, x, target_durations=None, target_pitch=None, training=False, durations_scalar=1.,
              max_durations_mask=None, min_durations_mask=None, mel_len: Optional[int] = None,
              return_attention: Optional[bool] = None):
@@ -431,7 +463,7 @@ class ForwardTransformer:
             _, _, ln = ops.lenreg_index(use, 1)
             mel_len = max(int(ln.max().item()), 1)
         idx, cum, lens = ops.lenreg_index(use, mel_len)                              # :540 Expand
-        mels = ops.LenRegFn.apply(h, idx, cum)
+        mels = ops.LenRegFn.apply(h, idx, cum, self._lenreg_hook)
         pad_d, klen_d = ops.length_pad_mask(lens, mel_len)                           # :541
         expanded_mask = pad_d.to(torch.float32)[:, None, None, :]
         mels, dec_attn = self._self_attention_blocks('dec', 'Decoder', mels, pad_d, klen_d,
@@ -459,6 +491,7 @@ class ForwardTransformer:
         tp = torch.as_tensor(target_pitch, device=dev).to(torch.float32)[..., None].contiguous()     # :466
         return x, ts, td, tp
 
+    @_on_device
     def _train_step(self, input_sequence, target_sequence, target_durations, target_pitch):
         """reference _train_step models.py:464-482: forward(training=True), weighted L1 losses,
         backward, one TF-form Adam step.  Requires sum_b(dur) <= mel_len (the reference data has
@@ -477,7 +510,7 @@ class ForwardTransformer:
         """forward(training=True) + losses + backward into the flat gradient buffer.  No host sync,
         no allocation outside torch's allocator: hipGraph-capturable as one unit."""
         mel_len = int(ts.shape[1])                                                   # :467
-        ra = False if self.return_attention is None else self.return_attention
+        ra = self.reference_outputs if self.return_attention is None else self.return_attention
         with ops.pinned_stream():
             model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra)
             loss, loss_vals = self._losses(model_out, ts, td, tp)
@@ -532,6 +565,7 @@ class ForwardTransformer:
         self._host_step += 1
         return st['out']
 
+    @_on_device
     def _val_step(self, input_sequence, target_sequence, target_durations, target_pitch):
         x, ts, td, tp = self._prep(input_sequence, target_sequence, target_durations, target_pitch)
         mel_len = int(ts.shape[1])
@@ -546,6 +580,7 @@ class ForwardTransformer:
     train_step = _train_step
     val_step = _val_step
 
+    @_on_device
     def _apply_gradients(self):
         """tf.keras Adam(lr, 0.9, 0.98, 1e-9) (utils/training_config_manager.py:102-106) as one fused
         launch over the flat buffers; iteration counter and lr live on the device."""
@@ -590,6 +625,7 @@ class ForwardTransformer:
     def encode_text(self, text):
         return self.text_pipeline(text)
 
+    @_on_device
     def predict(self, inp, encode=True, speed_regulator=1., phoneme_max_duration=None,
                 phoneme_min_duration=None, max_durations_mask=None, min_durations_mask=None,
                 phoneme_durations=None, phoneme_pitch=None):
@@ -665,7 +701,11 @@ class ForwardTransformer:
         model.load_weights(weights if weights.exists() else path / 'model_weights.npz')
         opt = path / 'optimizer.pt'
         if opt.exists():
-            st = torch.load(opt)
+            st = torch.load(opt, map_location='cpu', weights_only=True)
+            for key in ('m', 'v'):
+                if st[key].numel() != model.params.total:
+                    raise ValueError(f'{opt}: Adam state `{key}` has {st[key].numel()} elements, this model\'s flat '
+                                     f'parameter buffer has {model.params.total} (different config or layout version)')
             model.params.m.copy_(st['m'])
             model.params.v.copy_(st['v'])
             model._host_step = int(st['step'])

@@ -433,17 +433,33 @@ def dense_dgrad(dy, w, sh, k0, k1, relu_src=None, out=None, accumulate=False):
     return linear_dgrad(dy, w[k0:k1], relu_src, out=out, accumulate=accumulate)
 
 
+class _WgradState:
+    __slots__ = ('stream', 'handle', 'ws', 'pending', 'keep')
+
+    def __init__(self):
+        self.stream = None          # the side stream (created on first use, on the device that is current then)
+        self.handle = None          # raw hipStream_t of `stream`
+        self.ws = None              # persistent split-K workspace of the side stream (its kernels run in order)
+        self.pending = False
+        self.keep = []
+
+
 class _WgradStream:
     """Weight gradients are off the critical path of backward (nothing downstream reads them until
     the optimiser step), so they are launched on a second HIP stream and overlap the dgrad / attention
     / LayerNorm chain of the main stream: both are HBM-latency bound and fill each other's bubbles.
-    Joined (wgrad_join) before the gradient all-reduce / Adam."""
-    stream = None
-    handle = None           # raw hipStream_t of `stream`
-    ws = None               # persistent split-K workspace of the side stream (its kernels run in order)
+    Joined (wgrad_join) before the gradient all-reduce / Adam.  One state per device: a stream belongs to
+    the device it was created on, so models on different GPUs of one process never share one."""
     enabled = False
-    pending = False
-    keep = []
+    per_device = {}
+
+    @classmethod
+    def cur(cls) -> _WgradState:
+        d = torch.cuda.current_device()
+        st = cls.per_device.get(d)
+        if st is None:
+            st = cls.per_device[d] = _WgradState()
+        return st
 
 
 def enable_wgrad_stream(flag: bool = True):
@@ -453,10 +469,11 @@ def enable_wgrad_stream(flag: bool = True):
 def _on_wgrad_stream(fn, *inputs):
     if not _WgradStream.enabled:
         return fn()
+    W = _WgradStream.cur()
     main = torch.cuda.current_stream()
-    if _WgradStream.stream is None:
-        _WgradStream.stream = torch.cuda.Stream()
-    side = _WgradStream.stream
+    if W.stream is None:
+        W.stream = torch.cuda.Stream()
+    side = W.stream
     side.wait_stream(main)                    # the operands were produced on the main stream
     global _PINNED_STREAM
     prev = _PINNED_STREAM
@@ -474,8 +491,8 @@ def _on_wgrad_stream(fn, *inputs):
     #    exclusively (use_count == 1) - e.g. the LayerNorm backward output that is both this layer's dy
     #    and the residual branch's gradient.  A second owner makes it allocate the sum instead of
     #    mutating a tensor the side stream is still reading.
-    _WgradStream.keep.extend(inputs)
-    _WgradStream.pending = True
+    W.keep.extend(inputs)
+    W.pending = True
 
 
 _WGRAD_GENERIC = os.environ.get('TTSMI_WGRAD_GENERIC', '0') == '1'      # measurement knob: old submission path
@@ -486,9 +503,9 @@ def wgrad_rows_async(x, dy, dw, db, conv=None):
     launch takes the stream handle explicitly and the split-K workspace is one persistent buffer owned by
     that stream (its kernels execute in order, so reuse is safe) - a third of the host cost of the generic
     _on_wgrad_stream path, which matters with ~60 weight gradients per step."""
-    W = _WgradStream
-    if not W.enabled:
+    if not _WgradStream.enabled:
         return hgemm_wgrad_rows(x, dy, dw, db, conv)
+    W = _WgradStream.cur()
     if _WGRAD_GENERIC:
         return _on_wgrad_stream(lambda: hgemm_wgrad_rows(x, dy, dw, db, conv), x, dy)
     if W.stream is None:
@@ -515,10 +532,11 @@ def wgrad_rows_async(x, dy, dw, db, conv=None):
 
 
 def wgrad_join():
-    if _WgradStream.pending:
-        torch.cuda.current_stream().wait_stream(_WgradStream.stream)
-        _WgradStream.pending = False
-    _WgradStream.keep.clear()
+    W = _WgradStream.cur()
+    if W.pending:
+        torch.cuda.current_stream().wait_stream(W.stream)
+        W.pending = False
+    W.keep.clear()
 
 
 def dense_wgrad(x, dy, dw, db, sh, dyT=None):
@@ -909,30 +927,25 @@ class RowMaskFn(torch.autograd.Function):
         return dx, None
 
 
-# Called at the start of LenRegFn.backward, i.e. when backward crosses from the decoder into the encoder:
-# every decoder-side gradient has been launched by then (data parallel uses it to start the all-reduce
-# of the decoder half of the flat gradient buffer underneath the encoder's backward).
-_lenreg_backward_hook = None
-
-
-def set_lenreg_backward_hook(fn):
-    global _lenreg_backward_hook
-    _lenreg_backward_hook = fn
-
-
 def wgrad_stream():
     """The side stream the weight gradients run on (None until the first overlapped launch)."""
-    return _WgradStream.stream if _WgradStream.pending else None
+    W = _WgradStream.cur()
+    return W.stream if W.pending else None
 
 
 class LenRegFn(torch.autograd.Function):
     """Expand (model/layers.py:549-565): y[b,j] = x[b, idx[b,j]] (0 where idx < 0)."""
 
     @staticmethod
-    def forward(ctx, x, idx, cum):
+    def forward(ctx, x, idx, cum, hook=None):
+        # hook (per model, set by dp.DataParallel): called at the start of backward, i.e. when backward crosses
+        # from the decoder into the encoder - every decoder-side gradient has been launched by then, so data
+        # parallel starts the all-reduce of the decoder half of the flat gradient buffer underneath the
+        # encoder's backward.
         x = _c(x)
         B, Tp, C = x.shape
         cap = idx.shape[1]
+        ctx.hook = hook
         y = torch.empty((B, cap, C), dtype=torch.float32, device=x.device)
         check(_lib.lib().ttsmi_lenreg_fwd(_p(x), _p(idx), _p(y), B, Tp, cap, C, _stream()), 'lenreg_fwd')
         ctx.save_for_backward(cum)
@@ -943,13 +956,13 @@ class LenRegFn(torch.autograd.Function):
     def backward(ctx, dy):
         cum, = ctx.saved_tensors
         B, Tp, cap, C = ctx.shape
-        if _lenreg_backward_hook is not None:
+        if ctx.hook is not None:
             ln_flush()                      # the decoder's LayerNorm gradients must be final before their all-reduce
-            _lenreg_backward_hook()
+            ctx.hook()
         dy = _c(dy)
         dx = torch.empty((B, Tp, C), dtype=torch.float32, device=dy.device)
         check(_lib.lib().ttsmi_lenreg_bwd(_p(dy), _p(cum), _p(dx), B, Tp, cap, C, _stream()), 'lenreg_bwd')
-        return dx, None, None
+        return dx, None, None, None
 
 
 class L1LossFn(torch.autograd.Function):
