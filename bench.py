@@ -293,6 +293,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='configs[1]')
     ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (measurement only: value is then '
+                                                            'NOT the configs[1] number)')
     # BASELINE.json configs[1] is quoted in bf16: bf16 GEMM/attention operands, fp32 accumulate, fp32
     # master weights / activations / optimiser.  --precision f32 runs the exact-fp32 parity path.
     ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16'])
@@ -328,6 +330,8 @@ def main():
 
     from transformertts_amd.model.models import ForwardTransformer
     cfg, shape = workload_config(args.workload)
+    if args.batch:
+        shape = dict(shape, B=args.batch)
     cfg = dict(cfg, dropout_rate=args.dropout, predictors_dropout=args.dropout, device=str(dev), seed=0,
                precision=args.precision, use_graph=args.graph)
     model = ForwardTransformer.from_config(cfg)
@@ -352,6 +356,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    host_issue = time.perf_counter() - t0        # the host has ENQUEUED every step by now (no sync inside a step)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -407,6 +412,9 @@ def main():
         # value/ms_per_step: train_step without the 12 [B,H,T,T] attention maps in its output (they are
         # not materialised on the throughput path); the second figure is the same step returning them all
         'ms_per_step_with_attention_maps': ms_attn,
+        # host time to enqueue one step (Python + ctypes launch loop); when it approaches ms_per_step the host, not
+        # the GPU, bounds the step
+        'host_issue_ms_per_step': 1e3 * host_issue / args.steps,
     }
 
     if rank == 0 and not args.no_roofline:

@@ -451,13 +451,13 @@ def test_dp_overlap_hook_plumbing_on_one_gpu(tiny):
     m.grad_sync = sync
     wrapped.install_overlap_hook()
     got = wrapped.train_step(*batch)
-    # the hook lives on the wrapped model only: a second model's backward in the same process must not fire it
-    n_calls = len(calls)
-    ref.train_step(*batch)
-    assert len(calls) == n_calls and ref._lenreg_hook is None and m._lenreg_hook is not None
     g = m.params.grad
     split = wrapped.split
     assert 0 < split < g.numel() and m.params.offsets['dec.ln.gamma'][0] == split
     assert calls == [('async', g[split:].data_ptr(), g.numel() - split), ('sync', g.data_ptr(), split), 'wait']
     assert float(got['loss']) == float(want['loss'])
     torch.testing.assert_close(m.params.data, ref.params.data, rtol=0, atol=0)
+    # the hook lives on the wrapped model only: a second model's backward in the same process must not fire it
+    n_calls = len(calls)
+    ref.train_step(*batch)
+    assert len(calls) == n_calls and ref._lenreg_hook is None and m._lenreg_hook is not None

@@ -240,8 +240,26 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(HGemmP p) {
         if (col + 2 < p.N) bias4.z = p.bias[col + 2];
         if (col + 3 < p.N) bias4.w = p.bias[col + 3];
     }
+    // epilogue operands that come from global memory - the accumulate source and the bf16 ReLU' mask - are fetched
+    // for all 8 row groups of a 32-row slab BEFORE its accumulators are staged through LDS: their latency hides under
+    // the patch round trip.  (Loaded inside the store loop, each was a dependent HBM round trip between a patch read and
+    // its store: the masked dgrad ran 87 us against 42 us for the same shape without a mask.)
+    const bool pre_acc = fuse && vec && p.accumulate && !p.c_bf16;
+    const bool pre_msk = fuse && vec && p.relu_src != nullptr && p.mask_bf16;
+    const bool colok = col < p.N;
+    const int colc = colok ? col : 0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        float4 pre_o[8];
+        uint2 pre_m[8];
+        if (pre_acc || pre_msk) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = min(m0 + wr * (BM / 2) + i * 32 + it * 4 + rl, p.M - 1);
+                if (pre_acc) pre_o[it] = *reinterpret_cast<const float4*>(Cb + (long)row * ldc + colc);
+                if (pre_msk) pre_m[it] = *reinterpret_cast<const uint2*>((const uint16_t*)p.relu_src + (long)row * p.ld_relu + colc);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(HGemmP p) {
         for (int it = 0; it < 8; ++it) {
             const int prow = it * 4 + rl;
             const int row = m0 + wr * (BM / 2) + i * 32 + prow;
-            if (row >= p.M || col >= p.N) continue;
+            if (row >= p.M || !colok) continue;
             float4 v = *reinterpret_cast<const float4*>(patch + prow * EPLD + c4 * 4);
             if (fuse) {
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(HGemmP p) {
             if (vec) {
                 if (fuse && p.relu_src) {
                     if (p.mask_bf16) {      // bf16 activation: > 0  <=>  sign clear and magnitude non-zero
-                        uint2 mb = *reinterpret_cast<const uint2*>((const uint16_t*)p.relu_src + (long)row * p.ld_relu + col);
+                        const uint2 mb = pre_m[it];
                         auto pos = [](uint32_t h) { return ((h & 0x8000u) == 0u) && ((h & 0x7FFFu) != 0u); };
                         v.x = pos(mb.x & 0xFFFFu) ? v.x : 0.f; v.y = pos(mb.x >> 16) ? v.y : 0.f;
                         v.z = pos(mb.y & 0xFFFFu) ? v.z : 0.f; v.w = pos(mb.y >> 16) ? v.w : 0.f;
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(HGemmP p) {
                     continue;
                 }
                 if (fuse && p.accumulate) {
-                    float4 o = *reinterpret_cast<const float4*>(dst);
+                    const float4 o = pre_o[it];
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
                 *reinterpret_cast<float4*>(dst) = v;
@@ -465,6 +483,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                 // registers 8h..8h+7 = rows 16h..16h+15 of the 32-row tile
+                // global-memory epilogue operands first (see gemm_bf16_kernel): their latency hides under the patch round trip
+                float4 pre_o[4];
+                uint2 pre_m[4];
+                const bool pre_acc = vec && p.accumulate && !p.c_bf16;
+                const bool pre_msk = vec && p.relu_src != nullptr && p.mask_bf16;
+                const int colc = col < p.N ? col : 0;
+                if (pre_acc || pre_msk) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = min(m0 + wr * 64 + i * 32 + h * 16 + it * 4 + rl, p.M - 1);
+                        if (pre_acc) pre_o[it] = *reinterpret_cast<const float4*>(p.C + (long)row * ldc + colc);
+                        if (pre_msk) pre_m[it] = *reinterpret_cast<const uint2*>((const uint16_t*)p.relu_src + (long)row * p.ld_relu + colc);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -483,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
                     if (vec) {
                         if (p.relu_src) {
                             if (p.mask_bf16) {
-                                uint2 mb = *reinterpret_cast<const uint2*>((const uint16_t*)p.relu_src + (long)row * p.ld_relu + col);
+                                const uint2 mb = pre_m[it];
                                 auto pos = [](uint32_t hh) { return ((hh & 0x8000u) == 0u) && ((hh & 0x7FFFu) != 0u); };
                                 v.x = pos(mb.x & 0xFFFFu) ? v.x : 0.f; v.y = pos(mb.x >> 16) ? v.y : 0.f;
                                 v.z = pos(mb.y & 0xFFFFu) ? v.z : 0.f; v.w = pos(mb.y >> 16) ? v.w : 0.f;
@@ -498,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
                             continue;
                         }
                         if (p.accumulate) {
-                            float4 o = *reinterpret_cast<const float4*>(dst);
+                            const float4 o = pre_o[it];
                             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                         }
                         *reinterpret_cast<float4*>(dst) = v;
@@ -1093,18 +1125,20 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
         TTSMI_CHECK_LAUNCH(name);
         return TTSMI_OK;
     }
-    // LDS-DMA persistent kernel (TTSMI_HGEMM_DMA=1 enables it for decoder-size launches, 2 for all eligible ones)
+    // LDS-DMA persistent kernel.  TTSMI_HGEMM_DMA: 0 = never, 1 = every eligible decoder-size launch, 2 = every eligible
+    // launch, 3 (default) = decoder-size launches with K >= 512.  Round-2 per-shape A/B (tools/kbench.py, M = 28 800):
+    // K = 512 / 768 / 1024 with N = 256 run 19.6 / 27.4 / 31.5-38.5 us against 24.2 / 30.9 / 39.8-45.5 us register-staged
+    // (a deeper k-loop amortises the persistent pipeline), the K = 256 shapes tie or lose (4 k-steps per tile: the
+    // epilogue dominates either way) and the M = 6 400 launches lose (too few tiles per workgroup).
     static int use_dma = -1;
-    // OFF by default: faster alone, not inside the step (A/B 7.74 vs 7.70 ms).  Its first version had a race
-    // (ds_reads still queued at a bare s_barrier, see lds_stage_barrier) that tools/check_determinism.py found;
-    // fixed, and bit-identical to the register-staged kernel over 6 x 150 steps.
-    if (use_dma < 0) { const char* e = getenv("TTSMI_HGEMM_DMA"); use_dma = e ? atoi(e) : 0; }
+    if (use_dma < 0) { const char* e = getenv("TTSMI_HGEMM_DMA"); use_dma = e ? atoi(e) : 3; }
     if (use_dma && !a_f32 && splits == 1 && p.colsum == nullptr && p.a_taps == 1 && p.K % HBK_ == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 &&
+        (use_dma != 3 || p.K >= 512) &&
         (p.A2 == nullptr || (p.K1 % HBK_ == 0 && p.lda2 % 8 == 0 && al16(p.A2)))) {
         p.tiles_m = ttsmi_cdiv(p.M, DBM);
         p.tiles_n = ttsmi_cdiv(p.N, DBN);
         int nw = p.tiles_m * p.tiles_n;
-        if (nw >= (use_dma > 1 ? 1 : 192)) {          // under-filled launches keep the 64-row register-staged tiles
+        if (nw >= (use_dma == 2 ? 1 : 192)) {         // under-filled launches keep the 64-row register-staged tiles
             if (nw > 512) nw = 512;
             hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3(nw), dim3(256), 0, st, p);
             TTSMI_CHECK_LAUNCH(name);

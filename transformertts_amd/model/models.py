@@ -201,6 +201,8 @@ class ForwardTransformer:
         self.overlap_wgrad = bool(kwargs.get('overlap_wgrad', True))   # wgrad on a second HIP stream
         self.use_graph = bool(kwargs.get('use_graph', False))          # replay train_step from hipGraphs
         self.fused_blocks = bool(kwargs.get('fused_blocks', True))     # one autograd node per dense block
+        self.overlap_predictors = bool(kwargs.get('overlap_predictors', True))   # StatPredictors on a side stream
+        self._pred_stream, self._pred_pending, self._pred_keep = None, False, None
         self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
@@ -424,7 +426,7 @@ class ForwardTransformer:
     @_on_device
     def call(self, x, target_durations=None, target_pitch=None, training=False, durations_scalar=1.,
              max_durations_mask=None, min_durations_mask=None, mel_len: Optional[int] = None,
-             return_attention: Optional[bool] = None):
+             return_attention: Optional[bool] = None, _overlap_predictors: bool = False):
         c, W, G = self.config, self.params.w, self.params.g
         want_attn = (not training) if return_attention is None else return_attention
         rate = c['dropout_rate'] if training else 0.0
@@ -437,8 +439,27 @@ class ForwardTransformer:
         h, enc_attn = self._self_attention_blocks('enc', 'Encoder', h, pad_e, klen_e,
                                                   c['encoder_num_heads'], c['encoder_dense_blocks'],
                                                   self.pe_enc, rate, want_attn)      # :523
-        durations = self._stat_predictor('dur', h, pad_e, len(c['duration_conv_filters']), True, prate)
-        pitch = self._stat_predictor('pitch', h, pad_e, len(c['pitch_conv_filters']), False, prate)
+        # With teacher forcing (training / validation: target durations AND target pitch given) nothing downstream of
+        # the two StatPredictors feeds the decoder - their outputs only meet the losses.  They are ~60 small launches
+        # (M = B*Tp rows) that cannot fill the GPU, so they go to a second HIP stream and run underneath the decoder;
+        # autograd replays each node's backward on the stream its forward ran on, so their backward overlaps too.
+        # (only from _forward_backward, which owns the joins: before the losses, and again after backward)
+        overlap_pred = (_overlap_predictors and self.overlap_predictors and target_durations is not None
+                        and target_pitch is not None)
+        if overlap_pred:
+            main = torch.cuda.current_stream()
+            if self._pred_stream is None:
+                self._pred_stream = torch.cuda.Stream(device=self.device)
+            side = self._pred_stream
+            side.wait_stream(main)                       # the encoder output is complete in main-stream order
+            self._pred_keep = [h, pad_e]                 # the side stream reads them: alive until the join
+            with torch.cuda.stream(side), ops.pin_stream(side.cuda_stream):
+                durations = self._stat_predictor('dur', h, pad_e, len(c['duration_conv_filters']), True, prate)
+                pitch = self._stat_predictor('pitch', h, pad_e, len(c['pitch_conv_filters']), False, prate)
+            self._pred_pending = True
+        else:
+            durations = self._stat_predictor('dur', h, pad_e, len(c['duration_conv_filters']), True, prate)
+            pitch = self._stat_predictor('pitch', h, pad_e, len(c['pitch_conv_filters']), False, prate)
         if target_pitch is not None:                                                 # :527-530
             p_in = torch.as_tensor(target_pitch, device=self.device).to(torch.float32).reshape(B * Tp)
         else:
@@ -477,6 +498,12 @@ class ForwardTransformer:
 
     __call__ = call
 
+    def _join_predictors(self):
+        """Main stream waits for the predictor side stream (no-op when nothing is in flight there)."""
+        if self._pred_pending:
+            torch.cuda.current_stream().wait_stream(self._pred_stream)
+        self._pred_keep = None
+
     # ------------------------------------------------------------------ steps (models.py:464-507)
     def _losses(self, model_out, target_sequence, target_durations, target_pitch):
         return weighted_sum_losses((target_sequence, target_durations, target_pitch),
@@ -512,15 +539,20 @@ class ForwardTransformer:
         mel_len = int(ts.shape[1])                                                   # :467
         ra = self.reference_outputs if self.return_attention is None else self.return_attention
         with ops.pinned_stream():
-            model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra)
+            model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra,
+                                  _overlap_predictors=True)
+            self._join_predictors()              # the duration / pitch losses read the side stream's outputs
             loss, loss_vals = self._losses(model_out, ts, td, tp)
             ops.enable_wgrad_stream(self.overlap_wgrad)
             try:
                 with ops.ln_param_batch():
                     loss.backward()                                                  # :480
+                    self._join_predictors()      # their backward ran on the side stream: join before the final
+                    self._pred_pending = False   # LayerNorm parameter reduce, the all-reduce and Adam
                 ops.wgrad_join()
             finally:
                 ops.enable_wgrad_stream(False)
+                self._pred_pending = False
         model_out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in model_out.items()}
         model_out.update({'loss': loss.detach()})
         model_out.update({'losses': {'mel': loss_vals[0].detach(), 'duration': loss_vals[1].detach(),

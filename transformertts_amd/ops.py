@@ -69,12 +69,21 @@ class ln_param_batch:
 
 
 def _ln_defer(ws, dgamma, dbeta, dps, M, C) -> None:
-    _LN_PENDING.append((ws, dgamma, dbeta, dps, int(M), int(C)))
+    _LN_PENDING.append((ws, dgamma, dbeta, dps, int(M), int(C), _stream()))
 
 
-def ln_flush() -> None:
-    """Reduce every pending LayerNorm parameter gradient (no-op when nothing is pending)."""
-    pend = _LN_PENDING
+def ln_flush(only_this_stream: bool = False) -> None:
+    """Reduce every pending LayerNorm parameter gradient (no-op when nothing is pending) on the current launch
+    stream.  only_this_stream: leave entries whose partial sums were produced on ANOTHER stream (the predictors'
+    side stream) pending - the caller has not joined that stream yet."""
+    if not _LN_PENDING:
+        return
+    if only_this_stream:
+        cur = _stream()
+        pend = [e for e in _LN_PENDING if e[6] == cur]
+        rest = [e for e in _LN_PENDING if e[6] != cur]
+    else:
+        pend, rest = list(_LN_PENDING), []
     if not pend:
         return
     n = len(pend)
@@ -87,7 +96,7 @@ def ln_flush() -> None:
     check(_lib.lib().ttsmi_layernorm_param_reduce_batched(ctypes.addressof(ws), ctypes.addressof(dg), ctypes.addressof(db),
                                                           ctypes.addressof(ds), ctypes.addressof(Ms), ctypes.addressof(Cs),
                                                           n, _stream()), 'layernorm_param_reduce_batched')
-    del pend[:]                       # the workspaces go back to the allocator, in stream order
+    _LN_PENDING[:] = rest             # the reduced workspaces go back to the allocator, in stream order
 
 
 class pinned_stream:
@@ -97,6 +106,24 @@ class pinned_stream:
         global _PINNED_STREAM
         self.prev = _PINNED_STREAM
         _PINNED_STREAM = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        global _PINNED_STREAM
+        _PINNED_STREAM = self.prev
+        return False
+
+
+class pin_stream:
+    """`with ops.pin_stream(handle):` - launches inside go to the given raw hipStream_t (None: ask torch)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __enter__(self):
+        global _PINNED_STREAM
+        self.prev = _PINNED_STREAM
+        _PINNED_STREAM = self.handle
         return self
 
     def __exit__(self, *exc):
@@ -715,6 +742,7 @@ class AddLayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, gamma, beta, ggamma, gbeta, pe, pe_scale, gpe_scale, T, row_pad,
                 p_in, site_in, p_out, site_out, drop, relu_in):
+        ctx.stream_h = _stream()         # backward launches on the stream forward ran on (predictor side stream)
         x = _c(x)
         res = None if res is None else _c(res)
         shp = x.shape
@@ -736,6 +764,11 @@ class AddLayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with pin_stream(ctx.stream_h):
+            return AddLayerNormFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, res, gamma, mean, rstd, pe, pe_scale, row_pad, step_dev = ctx.saved_tensors
         T, p_in, site_in, p_out, site_out, seed, relu_in, M, C = ctx.cfg
         ggamma, gbeta, gpe = ctx.sinks
@@ -876,6 +909,7 @@ class RowDotFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gw, gb, row_pad, relu):
+        ctx.stream_h = _stream()         # backward launches on the stream forward ran on (predictor side stream)
         x = _c(x)
         C = x.shape[-1]
         M = x.numel() // C
@@ -889,6 +923,11 @@ class RowDotFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with pin_stream(ctx.stream_h):
+            return RowDotFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, w, y, row_pad = ctx.saved_tensors
         M, C, relu = ctx.cfg
         gw, gb = ctx.sinks
@@ -908,6 +947,7 @@ class RowMaskFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, row_pad):
+        ctx.stream_h = _stream()         # backward launches on the stream forward ran on (predictor side stream)
         x = _c(x)
         C = x.shape[-1]
         M = x.numel() // C
@@ -918,6 +958,11 @@ class RowMaskFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with pin_stream(ctx.stream_h):
+            return RowMaskFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         row_pad, = ctx.saved_tensors
         dy = _c(dy)
         C = dy.shape[-1]
@@ -957,7 +1002,7 @@ class LenRegFn(torch.autograd.Function):
         cum, = ctx.saved_tensors
         B, Tp, cap, C = ctx.shape
         if ctx.hook is not None:
-            ln_flush()                      # the decoder's LayerNorm gradients must be final before their all-reduce
+            ln_flush(only_this_stream=True)   # the decoder's LayerNorm gradients must be final before their all-reduce
             ctx.hook()
         dy = _c(dy)
         dx = torch.empty((B, Tp, C), dtype=torch.float32, device=dy.device)
@@ -1001,6 +1046,7 @@ class ConvReluPreMaskedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gw, gb, sh=None):
+        ctx.stream_h = _stream()         # backward launches on the stream forward ran on (predictor side stream)
         x = _c(x)
         B, T, Cin = x.shape
         k, _, Cout = w.shape
@@ -1016,6 +1062,11 @@ class ConvReluPreMaskedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dh):
+        with pin_stream(ctx.stream_h):
+            return ConvReluPreMaskedFn._backward(ctx, dh)
+
+    @staticmethod
+    def _backward(ctx, dh):
         x, w = ctx.saved_tensors
         gw, gb = ctx.sinks
         dh = _c(dh)
