@@ -109,6 +109,22 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
                         int H, int T, int dh, float p_drop, uint64_t seed, const int64_t* step_dev,
                         uint32_t site, void* ws, size_t ws_bytes, int dtype,
                         ttsmi_stream_t stream);
+/* Dropout on the attention weights with PRECOMPUTED keep bits (TTSMI_BF16_IO tensors, dh 32/64): evaluating the
+ * counter-based hash inside the attention inner loops costs a third of the forward and is repeated twice by the
+ * backward; ttsmi_attention_dropmask evaluates the SAME keep(seed, step, site, row, key) decisions once per layer
+ * and step into a bit table (uint64 [B*H][T/32 query tiles][T/32 key blocks][16], layout in attention_bf16.hip), and
+ * the *_masked entry points read bits instead.  Results equal ttsmi_attention_fwd/bwd with the same
+ * p_drop / seed / step / site up to fp32 rounding order (model/layers.py:192). */
+size_t ttsmi_attention_dropmask_bytes(int B, int H, int T);
+int ttsmi_attention_dropmask(void* mask, int B, int H, int T, float p_drop, uint64_t seed,
+                             const int64_t* step_dev, uint32_t site, ttsmi_stream_t stream);
+int ttsmi_attention_fwd_masked(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
+                               float* lse, int B, int H, int T, int dh, float p_drop, const void* dropmask,
+                               ttsmi_stream_t stream);
+int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const int32_t* klen,
+                               const void* ctx, const void* dctx, const float* lse, void* dqkv, int B,
+                               int H, int T, int dh, float p_drop, const void* dropmask, void* ws, size_t ws_bytes,
+                               ttsmi_stream_t stream);
 /* Materialise the (post-dropout) attention weights [B,H,T,T] the reference returns from every call
  * (model/layers.py:195,302-310) - only when the caller asks for them. */
 int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float* lse,

@@ -563,6 +563,57 @@ def test_bf16_attention_dropout_matches_fp32_mask():
     assert rel_err(a, b) < 1e-2 and rel_err(c, b) > 5e-2
 
 
+@pytest.mark.parametrize('B,H,T,dh', [(2, 2, 150, 32), (3, 4, 200, 64), (2, 4, 900, 64), (1, 2, 33, 64)])
+def test_attention_keep_bit_table_equals_the_hashed_dropout(B, H, T, dh):
+    """ttsmi_attention_dropmask + the *_masked kernels (bf16 I/O) make the same keep decisions as the kernels that
+    hash in their inner loops: forward context, log-sum-exp and dqkv agree to fp32 rounding order (the 1/keep
+    factor is applied at a different point), with padded keys, ragged klen and T % 32 != 0."""
+    ops = _ops()
+    from transformertts_amd import _lib
+    from transformertts_amd.ops import _p, _stream, check
+    l = _lib.lib()
+    d, pdrop = H * dh, 0.2
+    qkv = (g(B * T, 3 * d, seed=1) * 0.7).to(DEV).to(torch.bfloat16)
+    dctx = (g(B * T, d, seed=2) * 0.3).to(DEV).to(torch.bfloat16)
+    lens = torch.tensor([T] + [max(1, (T * (i + 1)) // (B + 1)) for i in range(B - 1)])
+    pad = (torch.arange(T)[None, :] >= lens[:, None]).to(torch.uint8)
+    if T > 10:
+        pad[0, 3] = 1
+    klen = torch.tensor([T if not (p == 0).any() else int((p == 0).nonzero().max()) + 1 for p in pad], dtype=torch.int32)
+    pad, klen = pad.to(DEV), klen.to(DEV)
+    step = torch.full((1,), 5, dtype=torch.int64, device=DEV)
+    drop = ops.DropCtx(seed=11, step_dev=step)
+    site = 4
+    ws = torch.empty(int(l.ttsmi_attention_bwd_ws_bytes(B, H, T, dh)), dtype=torch.uint8, device=DEV)
+    outs = []
+    for masked in (False, True):
+        ctx = torch.empty(B * T, d, device=DEV, dtype=torch.bfloat16)
+        lse = torch.empty(B, H, T, device=DEV)
+        dqkv = torch.empty_like(qkv)
+        if masked:
+            m = ops.attention_dropmask(B, H, T, pdrop, drop, site, DEV)
+            check(l.ttsmi_attention_fwd_masked(_p(qkv), _p(pad), _p(klen), _p(ctx), _p(lse), B, H, T, dh, pdrop, _p(m),
+                                               _stream()))
+            check(l.ttsmi_attention_bwd_masked(_p(qkv), _p(pad), _p(klen), _p(ctx), _p(dctx), _p(lse), _p(dqkv), B, H, T,
+                                               dh, pdrop, _p(m), _p(ws), ws.numel(), _stream()))
+        else:
+            check(l.ttsmi_attention_fwd(_p(qkv), _p(pad), _p(klen), _p(ctx), _p(lse), B, H, T, dh, pdrop, drop.seed,
+                                        _p(step), site, _lib.TTSMI_BF16_IO, _stream()))
+            check(l.ttsmi_attention_bwd(_p(qkv), _p(pad), _p(klen), _p(ctx), _p(dctx), _p(lse), _p(dqkv), B, H, T, dh,
+                                        pdrop, drop.seed, _p(step), site, _p(ws), ws.numel(), _lib.TTSMI_BF16_IO, _stream()))
+        torch.cuda.synchronize()
+        outs.append((ctx.float().cpu(), lse.cpu(), dqkv.float().cpu()))
+    (c0, l0, g0), (c1, l1, g1) = outs
+    live = (torch.arange(T)[None, :] < lens[:, None]).reshape(-1)          # padded query rows are compared too (finite)
+    assert torch.isfinite(c1).all() and torch.isfinite(g1).all()
+    assert torch.equal(l0, l1)                                             # the softmax statistics do not see dropout
+    assert rel_err(c1, c0) < 1e-2 and rel_err(g1, g0) < 1e-2               # one bf16 ulp where the scaling order differs
+    # a different decision anywhere would move an element by O(1) of its value: the mean error stays at rounding level
+    assert float((c1 - c0).abs().mean()) < 2e-3 * float(c0.abs().mean())
+    assert float((g1 - g0).abs().mean()) < 2e-3 * float(g0.abs().mean())
+    assert live.any()
+
+
 @pytest.mark.parametrize('M,K,N', [(1000, 256, 128), (333, 64, 200), (28800 // 8, 1024, 256), (77, 100, 60)])
 def test_hgemm_wgrad_rows(M, K, N):
     ops = _ops()

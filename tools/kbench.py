@@ -129,6 +129,29 @@ def bench_attn():
             check(l.ttsmi_attention_bwd(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(dctx[j]), _p(lse), _p(dqkv), B, H, T,
                                         dh, pdrop, 7, _p(step), 3, _p(ws), ws.numel(), _lib.TTSMI_BF16_IO, _stream()),
                   'attention_bwd')
+        if pdrop > 0:
+            drop = ops.DropCtx(7, step)
+            dm = ops.attention_dropmask(B, H, T, pdrop, drop, 3, dev)
+
+            def gen():
+                ops.attention_dropmask(B, H, T, pdrop, drop, 3, dev)
+
+            def fwd_m():
+                j = i[0] % R
+                i[0] += 1
+                check(l.ttsmi_attention_fwd_masked(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(lse), B, H, T, dh, pdrop,
+                                                   _p(dm), _stream()), 'attention_fwd_masked')
+
+            def bwd_m():
+                j = i[0] % R
+                i[0] += 1
+                check(l.ttsmi_attention_bwd_masked(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(dctx[j]), _p(lse), _p(dqkv),
+                                                   B, H, T, dh, pdrop, _p(dm), _p(ws), ws.numel(), _stream()),
+                      'attention_bwd_masked')
+            fl = 4.0 * B * H * T * T * dh
+            for nm, fn, mult in (('gen bits', gen, 0), ('fwd bits', fwd_m, 1), ('bwd bits', bwd_m, 2)):
+                t = timeit(fn, n=20)
+                out.append(dict(kind='attn', name=f'{nm} p={pdrop}', M=B * T, K=T, N=dh, us=t, tflops=mult * fl / t / 1e6 + 1e-9, tbs=0.0))
         tf_ = timeit(fwd, n=20)
         tb_ = timeit(bwd, n=20)
         fl = 4.0 * B * H * T * T * dh

@@ -507,7 +507,7 @@ int ttsmi_attention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
                         const int64_t* step_dev, uint32_t site, int dtype, ttsmi_stream_t stream) {
     if (dtype == TTSMI_BF16 || dtype == TTSMI_BF16_IO)
         return ttsmi_hattention_fwd(qkv, key_pad, klen, ctx, lse, B, H, T, dh, p_drop, seed, step_dev, site,
-                                    dtype == TTSMI_BF16_IO, (hipStream_t)stream);
+                                    dtype == TTSMI_BF16_IO, nullptr, (hipStream_t)stream);
     AttnP p;
     int rc = fill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, dtype, "attention_fwd");
     if (rc) return rc;
@@ -534,7 +534,7 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
         TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_attention_bwd_ws_bytes(B, H, T, dh),
                         "attention_bwd: workspace too small");
         return ttsmi_hattention_bwd(qkv, key_pad, klen, ctx, dctx, lse, dqkv, B, H, T, dh, p_drop, seed,
-                                    step_dev, site, ws, dtype == TTSMI_BF16_IO, (hipStream_t)stream);
+                                    step_dev, site, ws, dtype == TTSMI_BF16_IO, nullptr, (hipStream_t)stream);
     }
     AttnP p;
     int rc = fill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, dtype, "attention_bwd");
@@ -551,6 +551,31 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
     DISPATCH_DH(dh, attn_bwd_dkv_kernel, grid, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dkv");
     return TTSMI_OK;
+}
+
+size_t ttsmi_attention_dropmask_bytes(int B, int H, int T) { return ttsmi_hattention_dropmask_bytes(B, H, T); }
+
+int ttsmi_attention_dropmask(void* mask, int B, int H, int T, float p_drop, uint64_t seed,
+                             const int64_t* step_dev, uint32_t site, ttsmi_stream_t stream) {
+    return ttsmi_hattention_dropmask(mask, B, H, T, p_drop, seed, step_dev, site, (hipStream_t)stream);
+}
+
+int ttsmi_attention_fwd_masked(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
+                               float* lse, int B, int H, int T, int dh, float p_drop, const void* dropmask,
+                               ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(dropmask && p_drop > 0.f, "attention_fwd_masked: needs a keep-bit mask and p_drop > 0");
+    return ttsmi_hattention_fwd(qkv, key_pad, klen, ctx, lse, B, H, T, dh, p_drop, 0, nullptr, 0, 1, dropmask,
+                                (hipStream_t)stream);
+}
+
+int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const int32_t* klen,
+                               const void* ctx, const void* dctx, const float* lse, void* dqkv, int B,
+                               int H, int T, int dh, float p_drop, const void* dropmask, void* ws, size_t ws_bytes,
+                               ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(dropmask && p_drop > 0.f, "attention_bwd_masked: needs a keep-bit mask and p_drop > 0");
+    TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_attention_bwd_ws_bytes(B, H, T, dh), "attention_bwd_masked: workspace too small");
+    return ttsmi_hattention_bwd(qkv, key_pad, klen, ctx, dctx, lse, dqkv, B, H, T, dh, p_drop, 0, nullptr, 0, ws, 1,
+                                dropmask, (hipStream_t)stream);
 }
 
 int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float* lse,

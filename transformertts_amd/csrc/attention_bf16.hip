@@ -38,7 +38,49 @@ struct HAttnP {
     int B, H, T;
     float sqrt_dk;
     uint32_t thr; float inv_keep; uint64_t seed; const int64_t* step_dev; uint32_t site;
+    const uint64_t* dmask;          // DROP == 2: precomputed keep bits (hattn_dropmask_kernel), else unused
 };
+
+// DROP template values: 0 = no dropout, 1 = keep decisions hashed in the inner loop (ttsmi_pair_hash), 2 = keep
+// decisions read as BITS that hattn_dropmask_kernel derived from the same hash.  The hash is ~23 VALU cycles per
+// score element (a third of the forward's inner loop, and the backward regenerates it twice: with dropout 0.1 the
+// forward ran 96 us against 73 us without, the backward 244 against 166); as bits it costs one v_cndmask with a
+// scalar lane mask per element in the forward / dQ kernels and a bit-field extract + AND in the dK/dV kernel.
+//
+// Bit layout ("lane-transposed tiles"): uint64 word [(b*H + h)][qt][kb][r], r < 16, for the 32-query tile qt and the
+// 32-key block kb; bit L = l31 + 32*hh of word r is keep(q = 32*qt + l31, key = 32*kb + rowmap16(r, hh)) - i.e.
+// exactly the lane mask of accumulator register r of the wave that owns query tile qt in the forward / dQ kernels,
+// so those kernels feed the word (a scalar load) to v_cndmask unchanged.  The dK/dV kernel (lane = key, registers =
+// queries) fetches per lane the 32-bit half of the one word that holds its key and tests fixed bit positions.
+__device__ __forceinline__ float hmask_sel(float x, uint64_t lane_mask) {
+    float o;
+    asm volatile("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(x), "s"(lane_mask));
+    return o;
+}
+typedef const __attribute__((address_space(4))) uint64_t* hmask_sptr;     // constant address space: scalar loads
+// The 16 words of the NEXT block are requested right after the current block's words were consumed and waited for just
+// before their own first use, so the scalar-load latency (an L2 round trip) hides under a whole block of work.  Both
+// are inline asm so that they stay where they are written (a plain load is hoisted to the block's head - its words were
+// then needed ~500 cycles after the request and the wait for them also drains the LDS queue: the bits version ran no
+// faster than the hash) and the compiler does not count them (its own lgkmcnt waits stay conservative).
+typedef uint64_t hmask_x8 __attribute__((ext_vector_type(8)));
+struct HMaskWords { hmask_x8 lo, hi; };
+__device__ __forceinline__ void hmask_request(HMaskWords& w, hmask_sptr p) {
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(w.lo), "=&s"(w.hi) : "s"(p) : "memory");
+}
+__device__ __forceinline__ void hmask_wait(HMaskWords& w) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.lo), "+s"(w.hi) : : "memory");
+}
+template <int R>
+__device__ __forceinline__ float hmask_apply(float x, const HMaskWords& w) {
+    return hmask_sel(x, R < 8 ? w.lo[R & 7] : w.hi[R & 7]);
+}
+template <int... R>
+__device__ __forceinline__ void hmask_apply_all(f32x16& v, const HMaskWords& w) {
+#define HM(r) v[r] = hmask_apply<r>(v[r], w);
+    HM(0) HM(1) HM(2) HM(3) HM(4) HM(5) HM(6) HM(7) HM(8) HM(9) HM(10) HM(11) HM(12) HM(13) HM(14) HM(15)
+#undef HM
+}
 
 __device__ __forceinline__ int rowmap16(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
@@ -294,7 +336,7 @@ struct HSm {
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int DH, bool DROP, bool QH>
+template <int DH, int DROP, bool QH>
 __global__ __launch_bounds__(256, 3) void hattn_fwd_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
@@ -305,7 +347,8 @@ __global__ __launch_bounds__(256, 3) void hattn_fwd_kernel(HAttnP p) {
     uint16_t* Vs = Ks + SM::ROWS;
     float* padS = reinterpret_cast<float*>(smem + MAIN);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: scalar control flow / addresses
     const int ntile = (p.T + 127) >> 7;                 // 1-D grid: all q/key tiles of one (b, h) on one XCD
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = lid % ntile, h = (lid / ntile) % p.H, b = lid / (ntile * p.H);
@@ -330,8 +373,17 @@ __global__ __launch_bounds__(256, 3) void hattn_fwd_kernel(HAttnP p) {
     const int klen = p.klen[b];
     const float c1 = LOG2E / p.sqrt_dk;
     uint32_t drop_rb = 0;
-    if (DROP) drop_rb = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site),
-                                       (uint32_t)(((long)b * p.H + h) * p.T + q));
+    if (DROP == 1) drop_rb = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site),
+                                            (uint32_t)(((long)b * p.H + h) * p.T + q));
+    // DROP == 2: this wave's row of mask tiles [kb][16 words] (wave-uniform address -> scalar loads)
+    const int ntile32 = (p.T + 31) >> 5;
+    hmask_sptr mrow = nullptr;
+    HMaskWords mw;
+    if (DROP == 2) {
+        const long tile_row = ((long)b * p.H + h) * ntile32 + __builtin_amdgcn_readfirstlane(bx * 4 + wave);
+        mrow = (hmask_sptr)(p.dmask + tile_row * ntile32 * 16);
+        hmask_request(mw, mrow);
+    }
 
     Tile<DH, QH> rk, rv;
     float rpad = 0.f;
@@ -381,13 +433,19 @@ __global__ __launch_bounds__(256, 3) void hattn_fwd_kernel(HAttnP p) {
                 s[r] = EXP2(s[r] - mn);
                 rs += s[r];
             }
-            if (DROP) {
+            // (the 1 / keep factor of inverted dropout is applied once, with the final 1 / l normalisation)
+            if (DROP == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {                // keys of (r, r+1) are (even, odd) neighbours
                     const uint32_t hsh = ttsmi_pair_hash(drop_rb, (uint32_t)(kbase + rowmap16(r, hh)));
-                    s[r] *= ((hsh & 0xFFFFu) >= p.thr) ? p.inv_keep : 0.f;
-                    s[r + 1] *= ((hsh >> 16) >= p.thr) ? p.inv_keep : 0.f;
+                    s[r] = ((hsh & 0xFFFFu) >= p.thr) ? s[r] : 0.f;
+                    s[r + 1] = ((hsh >> 16) >= p.thr) ? s[r + 1] : 0.f;
                 }
+            }
+            if (DROP == 2) {
+                hmask_wait(mw);
+                hmask_apply_all(s, mw);
+                hmask_request(mw, mrow + min((kbase >> 5) + 1, ntile32 - 1) * 16);      // the next block's words
             }
             rs += __shfl_xor(rs, 32, 64);
             l = l * alpha + rs;
@@ -408,14 +466,14 @@ __global__ __launch_bounds__(256, 3) void hattn_fwd_kernel(HAttnP p) {
     float* patch = reinterpret_cast<float*>(smem + wave * (QH ? 32 * (DH + 8) * 2 : 32 * (DH + 1) * 4));
     int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
-    storeT16<DH, QH>(patch, o, 1.0f / l, const_cast<float*>(eptr<QH>(p.ctx, (long)b * p.T * d + h * DH)), d, row0,
-                     nvalid, lane);
+    storeT16<DH, QH>(patch, o, (DROP ? p.inv_keep : 1.0f) / l,
+                     const_cast<float*>(eptr<QH>(p.ctx, (long)b * p.T * d + h * DH)), d, row0, nvalid, lane);
 }
 
 // =================================================================================================
 // backward A: dQ (+ delta)
 // =================================================================================================
-template <int DH, bool DROP, bool QH>
+template <int DH, int DROP, bool QH>
 __global__ __launch_bounds__(256, 2) void hattn_bwd_dq_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
@@ -426,7 +484,8 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dq_kernel(HAttnP p) {
     uint16_t* Vs = Ks + SM::ROWS;
     float* padS = reinterpret_cast<float*>(smem + MAIN);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: scalar control flow / addresses
     const int ntile = (p.T + 127) >> 7;                 // 1-D grid: all q/key tiles of one (b, h) on one XCD
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = lid % ntile, h = (lid / ntile) % p.H, b = lid / (ntile * p.H);
@@ -481,7 +540,15 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dq_kernel(HAttnP p) {
     const float inv_sqrt = 1.0f / p.sqrt_dk;
     const float c1 = LOG2E * inv_sqrt;
     uint32_t drop_rb = 0;
-    if (DROP) drop_rb = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site), (uint32_t)sidx);
+    if (DROP == 1) drop_rb = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site), (uint32_t)sidx);
+    const int ntile32 = (p.T + 31) >> 5;
+    hmask_sptr mrow = nullptr;
+    HMaskWords mw;
+    if (DROP == 2) {
+        const long tile_row = ((long)b * p.H + h) * ntile32 + __builtin_amdgcn_readfirstlane(bx * 4 + wave);
+        mrow = (hmask_sptr)(p.dmask + tile_row * ntile32 * 16);
+        hmask_request(mw, mrow);
+    }
 
     Tile<DH, QH> rk, rv;
     float rpad = 0.f;
@@ -520,16 +587,23 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dq_kernel(HAttnP p) {
                 for (int r = 0; r < 16; ++r)
                     if (kbase + rowmap16(r, hh) >= klen) s[r] = -INFINITY;
             }
-            if (DROP) {
+            if (DROP == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const uint32_t hsh = ttsmi_pair_hash(drop_rb, (uint32_t)(kbase + rowmap16(r, hh)));
-                    dp[r] *= ((hsh & 0xFFFFu) >= p.thr) ? p.inv_keep : 0.f;
-                    dp[r + 1] *= ((hsh >> 16) >= p.thr) ? p.inv_keep : 0.f;
+                    dp[r] = ((hsh & 0xFFFFu) >= p.thr) ? dp[r] : 0.f;
+                    dp[r + 1] = ((hsh >> 16) >= p.thr) ? dp[r + 1] : 0.f;
                 }
             }
+            if (DROP == 2) {
+                hmask_wait(mw);
+                hmask_apply_all(dp, mw);
+                hmask_request(mw, mrow + min((kbase >> 5) + 1, ntile32 - 1) * 16);      // the next block's words
+            }
+            // dS^T = P (keep * dP / (1 - p) - delta) / sqrt(dh): the 1 / keep factor rides in the fma
+            const float ik = DROP ? p.inv_keep : 1.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = EXP2(s[r]) * (dp[r] - delta) * inv_sqrt;   // dS^T
+            for (int r = 0; r < 16; ++r) s[r] = EXP2(s[r]) * fmaf(dp[r], ik, -delta) * inv_sqrt;
             bf16x8 pb[2];
             to_frags(s, pb);
             accumTR<DH>(Ks, kt * 32, lane, pb, dq);                           // dQ^T += K^T.dS^T
@@ -549,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dq_kernel(HAttnP p) {
 // 3 workgroups per CU: caps the allocation at 168 VGPRs (the unconstrained build used 172 = 2 waves/SIMD)
 // min 2 workgroups per CU: without the bound the register allocator takes 332 registers (236 VGPR +
 // 96 AGPR) = ONE wave per SIMD; bounded it needs 236 and no spills
-template <int DH, bool DROP, bool QH>
+template <int DH, int DROP, bool QH>
 __global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
@@ -562,7 +636,8 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
     float* delS = lseS + HKT;
     uint32_t* rbS = reinterpret_cast<uint32_t*>(delS + HKT);     // dropout row bases of the q tile
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: scalar control flow / addresses
     const int ntile = (p.T + 127) >> 7;                 // 1-D grid: all q/key tiles of one (b, h) on one XCD
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = lid % ntile, h = (lid / ntile) % p.H, b = lid / (ntile * p.H);
@@ -592,7 +667,26 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
     const float c1 = LOG2E * inv_sqrt;
     const long stat0 = ((long)b * p.H + h) * p.T;
     uint64_t dkey = 0;
-    if (DROP) dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
+    if (DROP == 1) dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
+    // DROP == 2: this lane's key is bit plane (word r', half hh') of every mask tile of its key block; per 32-query
+    // tile one dword holds the keep bits of its 32 queries for that key.  Fetched one LDS tile (two query tiles) ahead.
+    const int ntile32 = (p.T + 31) >> 5;
+    const uint32_t* mlane = nullptr;
+    uint32_t mnext[HKT / 32] = {0u, 0u};
+    if (DROP == 2) {
+        const int rp = (l31 & 3) + 4 * (l31 >> 3), hp = (l31 >> 2) & 1;
+        mlane = reinterpret_cast<const uint32_t*>(p.dmask) +
+                ((((long)b * p.H + h) * ntile32 * ntile32 + (bx * 4 + wave)) * 16 + rp) * 2 + hp;
+    }
+    auto mask_fetch = [&](int q0) {          // query tile qt = q0 / 32 (+1): element stride between query tiles = ntile32 * 32
+        if (DROP == 2 && kok) {
+#pragma unroll
+            for (int u = 0; u < HKT / 32; ++u) {
+                const int qt = (q0 >> 5) + u;
+                mnext[u] = qt < ntile32 ? mlane[(long)qt * ntile32 * 32] : 0u;
+            }
+        }
+    };
 
     const bool wg_active = bx * 128 < klen;
     if (wg_active) {
@@ -602,6 +696,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
             int nv = min(HKT, p.T);
             rq.fetch(Qb, p.ld, 0, nv, tid);
             ro.fetch(dOb, d, 0, nv, tid);
+            mask_fetch(0);
             if (tid < HKT) {
                 rl = tid < nv ? p.lse[stat0 + tid] * LOG2E : INFINITY;
                 rd = tid < nv ? p.delta[stat0 + tid] : 0.f;
@@ -614,13 +709,17 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
             if (tid < HKT) {
                 lseS[tid] = rl;
                 delS[tid] = rd;
-                if (DROP) rbS[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0 + tid));
+                if (DROP == 1) rbS[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0 + tid));
             }
+            uint32_t mcur[HKT / 32];
+#pragma unroll
+            for (int u = 0; u < HKT / 32; ++u) mcur[u] = mnext[u] >> (4 * hh);      // bit c of mcur = query rowmap16(., hh)
             __syncthreads();
             if (q0 + HKT < p.T) {
                 int nv = min(HKT, p.T - (q0 + HKT));
                 rq.fetch(Qb, p.ld, q0 + HKT, nv, tid);
                 ro.fetch(dOb, d, q0 + HKT, nv, tid);
+                mask_fetch(q0 + HKT);
                 if (tid < HKT) {
                     rl = tid < nv ? p.lse[stat0 + q0 + HKT + tid] * LOG2E : INFINITY;
                     rd = tid < nv ? p.delta[stat0 + q0 + HKT + tid] : 0.f;
@@ -637,15 +736,20 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
                     const int ql = qt * 32 + rowmap16(r, hh);
                     float pr = EXP2(s[r] * c1 + padterm - lseS[ql]);        // lse = +inf for q >= T
                     float dpr = dp[r];
-                    if (DROP) {
+                    // the 1 / keep factor: on dV once at the end, on dS inside the fma
+                    if (DROP == 1) {
                         const uint32_t hsh = ttsmi_pair_hash(rbS[ql], (uint32_t)key);
-                        const float keep = ttsmi_keep_of(hsh, (uint32_t)key, p.thr, p.inv_keep);
-                        dpr *= keep;
-                        pt[r] = pr * keep;
+                        const bool keep = ttsmi_keep_of(hsh, (uint32_t)key, p.thr, 1.0f) != 0.f;
+                        dpr = keep ? dpr : 0.f;
+                        pt[r] = keep ? pr : 0.f;
+                    } else if (DROP == 2) {
+                        const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe(mcur[qt], (r & 3) + 8 * (r >> 2), 1);   // 0 / ~0
+                        dpr = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, dpr) & km);
+                        pt[r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, pr) & km);
                     } else {
                         pt[r] = pr;
                     }
-                    s[r] = pr * (dpr - delS[ql]) * inv_sqrt;                 // dS
+                    s[r] = pr * fmaf(dpr, DROP ? p.inv_keep : 1.0f, -delS[ql]) * inv_sqrt;     // dS
                 }
                 bf16x8 pb[2], sb[2];
                 to_frags(pt, pb);
@@ -661,7 +765,36 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
     int nvalid = min(32, p.T - row0);
     const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH);
     storeT16<DH, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
-    storeT16<DH, QH>(patch, dv, 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
+    storeT16<DH, QH>(patch, dv, DROP ? p.inv_keep : 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
+}
+
+// =================================================================================================
+// keep-bit generator for DROP == 2 (layout: see the top of the file).  One wave per 32-query tile walks the key
+// blocks; the decisions are the SAME hash the DROP == 1 kernels, the exact-fp32 kernels and attention_weights
+// evaluate, so every consumer sees one mask.
+// =================================================================================================
+__global__ __launch_bounds__(256) void hattn_dropmask_kernel(uint64_t* __restrict__ mask, int BH, int T, uint32_t thr,
+                                                             uint64_t seed, const int64_t* step_dev, uint32_t site) {
+    const int nt = (T + 31) >> 5;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+    const long wid = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (wid >= (long)BH * nt) return;
+    const int qt = (int)(wid % nt);
+    const long bh = wid / nt;
+    const uint32_t rb = ttsmi_row_base(ttsmi_drop_key(seed, step_dev, site), (uint32_t)(bh * T + qt * 32 + l31));
+    uint64_t* dst = mask + wid * nt * 16;
+    for (int kb = 0; kb < nt; ++kb) {
+        uint64_t mine = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const uint32_t hsh = ttsmi_pair_hash(rb, (uint32_t)(kb * 32 + rowmap16(r, hh)));
+            const uint64_t b0 = __builtin_amdgcn_ballot_w64((hsh & 0xFFFFu) >= thr);
+            const uint64_t b1 = __builtin_amdgcn_ballot_w64((hsh >> 16) >= thr);
+            if (lane == r) mine = b0;
+            if (lane == r + 1) mine = b1;
+        }
+        if (lane < 16) dst[kb * 16 + lane] = mine;
+    }
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -684,11 +817,12 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
 #define HLAUNCH(KERNEL, DHV, grid, st, p)                                                      \
     do {                                                                                       \
         if (qh) {                                                                              \
-            if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, true, true>), grid, dim3(256), 0, st, p);   \
-            else hipLaunchKernelGGL((KERNEL<DHV, false, true>), grid, dim3(256), 0, st, p);          \
+            if ((p).thr && (p).dmask) hipLaunchKernelGGL((KERNEL<DHV, 2, true>), grid, dim3(256), 0, st, p); \
+            else if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, true>), grid, dim3(256), 0, st, p);  \
+            else hipLaunchKernelGGL((KERNEL<DHV, 0, true>), grid, dim3(256), 0, st, p);          \
         } else {                                                                               \
-            if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, true, false>), grid, dim3(256), 0, st, p);  \
-            else hipLaunchKernelGGL((KERNEL<DHV, false, false>), grid, dim3(256), 0, st, p);         \
+            if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, false>), grid, dim3(256), 0, st, p);  \
+            else hipLaunchKernelGGL((KERNEL<DHV, 0, false>), grid, dim3(256), 0, st, p);         \
         }                                                                                      \
     } while (0)
 
@@ -702,13 +836,32 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
     }
 
 // called from attention.hip's entry points when dtype == TTSMI_BF16
+size_t ttsmi_hattention_dropmask_bytes(int B, int H, int T) {
+    const size_t nt = (size_t)(T + 31) / 32;
+    return (size_t)B * H * nt * nt * 16 * sizeof(uint64_t);
+}
+
+int ttsmi_hattention_dropmask(void* mask, int B, int H, int T, float p_drop, uint64_t seed, const int64_t* step_dev,
+                              uint32_t site, hipStream_t st) {
+    TTSMI_CHECK_ARG(mask && B > 0 && H > 0 && T > 0, "attention_dropmask: bad argument");
+    TTSMI_CHECK_ARG(p_drop > 0.f && p_drop < 1.f, "attention_dropmask: dropout rate must be in (0,1)");
+    TTSMI_CHECK_ARG((((uintptr_t)mask) & 7) == 0, "attention_dropmask: mask must be 8-byte aligned");
+    const long waves = (long)B * H * ((T + 31) / 32);
+    hipLaunchKernelGGL(hattn_dropmask_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (uint64_t*)mask,
+                       B * H, T, ttsmi_drop_threshold(p_drop), seed, step_dev, site);
+    TTSMI_CHECK_LAUNCH("attention_dropmask");
+    return TTSMI_OK;
+}
+
 int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
                          float* lse, int B, int H, int T, int dh, float p_drop, uint64_t seed,
-                         const int64_t* step_dev, uint32_t site, int qh, hipStream_t st) {
+                         const int64_t* step_dev, uint32_t site, int qh, const void* dropmask, hipStream_t st) {
     HAttnP p;
     int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_fwd(bf16)");
     if (rc) return rc;
     TTSMI_CHECK_ARG(ctx && lse, "attention_fwd(bf16): null pointer");
+    TTSMI_CHECK_ARG(!dropmask || qh, "attention_fwd(bf16): the keep-bit mask needs bf16 activations (TTSMI_BF16_IO)");
+    p.dmask = (const uint64_t*)dropmask;
     p.ctx = (float*)ctx; p.lse = lse;
     dim3 grid(ttsmi_cdiv(T, 128) * H * B);
     HDISPATCH(dh, hattn_fwd_kernel, grid, st, p);
@@ -719,11 +872,13 @@ int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t*
 int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
                          const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
                          float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, void* ws,
-                         int qh, hipStream_t st) {
+                         int qh, const void* dropmask, hipStream_t st) {
     HAttnP p;
     int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_bwd(bf16)");
     if (rc) return rc;
     TTSMI_CHECK_ARG(ctx && dctx && lse && dqkv && ws, "attention_bwd(bf16): null pointer");
+    TTSMI_CHECK_ARG(!dropmask || qh, "attention_bwd(bf16): the keep-bit mask needs bf16 activations (TTSMI_BF16_IO)");
+    p.dmask = (const uint64_t*)dropmask;
     p.octx = (const float*)ctx; p.dctx = (const float*)dctx; p.lse = (float*)lse;
     p.dqkv = (float*)dqkv; p.delta = (float*)ws;
     dim3 grid(ttsmi_cdiv(T, 128) * H * B);

@@ -35,11 +35,14 @@ static inline int ttsmi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // dtype == TTSMI_BF16
 int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
                          float* lse, int B, int H, int T, int dh, float p_drop, uint64_t seed,
-                         const int64_t* step_dev, uint32_t site, int qkv_is_bf16, hipStream_t st);
+                         const int64_t* step_dev, uint32_t site, int qkv_is_bf16, const void* dropmask, hipStream_t st);
 int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
                          const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
                          float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, void* ws,
-                         int qkv_is_bf16, hipStream_t st);
+                         int qkv_is_bf16, const void* dropmask, hipStream_t st);
+size_t ttsmi_hattention_dropmask_bytes(int B, int H, int T);
+int ttsmi_hattention_dropmask(void* mask, int B, int H, int T, float p_drop, uint64_t seed, const int64_t* step_dev,
+                              uint32_t site, hipStream_t st);
 
 // ---- wave64 reductions ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

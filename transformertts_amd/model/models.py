@@ -203,6 +203,7 @@ class ForwardTransformer:
         self.fused_blocks = bool(kwargs.get('fused_blocks', True))     # one autograd node per dense block
         self.overlap_predictors = bool(kwargs.get('overlap_predictors', True))   # StatPredictors on a side stream
         self._pred_stream, self._pred_pending, self._pred_keep = None, False, None
+        self._dropmask_plan, self._dropmask_bufs = {}, {}
         self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
@@ -349,8 +350,15 @@ class ForwardTransformer:
                 # one autograd node per block (ops.DenseBlockFn); sites in the per-layer order
                 Pb, Gb, Sb = self._block_views(p)
                 sites = (drop.site(), drop.site(), drop.site())
+                dmask = None
+                pre = self._dropmask_plan.get(p) if self._dropmask_plan else None
+                if pre is not None:                       # generated ahead of time on the side stream
+                    dmask, site_planned, ev = pre
+                    assert site_planned == sites[0], (p, site_planned, sites)
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
                 h, h_bf, qkv, lse = ops.DenseBlockFn.apply(h, h_bf, Pb, Gb, Sb, pad, klen, B, H, T, rate, drop, sites,
-                                                           dtype, want_attn)
+                                                           dtype, want_attn, dmask)
                 if h_bf.numel() == 0:
                     h_bf = None
                 if want_attn:
@@ -498,6 +506,52 @@ class ForwardTransformer:
 
     __call__ = call
 
+    def _launch_dropmasks(self, B, Tp, Tm, rate):
+        """Attention-dropout keep bits of every dense block of this step, generated on the side stream ahead of their
+        use: the generator is pure VALU work (the same hash the kernels would otherwise evaluate in their inner loops,
+        ~35 us per decoder layer) and hides under the encoder's small launches.  Two events: encoder tables first."""
+        self._dropmask_plan = {}
+        c = self.config
+        if not (self.precision == 'bf16' and rate > 0 and ops._ATTN_DROPBITS and self.fused_blocks):
+            return
+        d = c['encoder_model_dimension']
+        l = ops._lib.lib()
+        main = torch.cuda.current_stream()
+        if self._pred_stream is None:
+            self._pred_stream = torch.cuda.Stream(device=self.device)
+        side = self._pred_stream
+        side.wait_stream(main)                 # the step counter was advanced, and last step's readers are done
+        # dropout-site numbering of call(): one site for each stack's entry LayerNorm, three per block (attention,
+        # ln1, ln2), one per predictor layer between the two stacks
+        site = 1
+        plans = []
+        for prefix, heads, nd, T in (('enc', c['encoder_num_heads'], c['encoder_dense_blocks'], Tp),
+                                     ('dec', c['decoder_num_heads'], c['decoder_dense_blocks'], Tm)):
+            if prefix == 'dec':
+                site += len(c['duration_conv_filters']) + len(c['pitch_conv_filters']) + 1
+            for i, H in enumerate(heads):
+                dh = d // H
+                if i < nd and dh in (32, 64) and d % 64 == 0:
+                    plans.append((f'{prefix}.blk{i}', H, T, site + 1))
+                site += 3
+        with torch.cuda.stream(side), ops.pin_stream(side.cuda_stream):
+            for prefix in ('enc', 'dec'):          # encoder tables first, with their own event: the encoder starts
+                ev = None                          # ~50 us into the step, the decoder ~1 ms
+                for name, H, T, st in plans:
+                    if not name.startswith(prefix):
+                        continue
+                    key = (name, B, H, T)
+                    buf = self._dropmask_bufs.get(key)
+                    if buf is None:
+                        buf = self._dropmask_bufs[key] = torch.empty(int(l.ttsmi_attention_dropmask_bytes(B, H, T)),
+                                                                     dtype=torch.uint8, device=self.device)
+                    ops.attention_dropmask(B, H, T, rate, self.drop, st, self.device, out=buf)
+                    if ev is None:
+                        ev = torch.cuda.Event()
+                    self._dropmask_plan[name] = (buf, st, ev)
+                if ev is not None:
+                    ev.record(side)
+
     def _join_predictors(self):
         """Main stream waits for the predictor side stream (no-op when nothing is in flight there)."""
         if self._pred_pending:
@@ -539,8 +593,12 @@ class ForwardTransformer:
         mel_len = int(ts.shape[1])                                                   # :467
         ra = self.reference_outputs if self.return_attention is None else self.return_attention
         with ops.pinned_stream():
-            model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra,
-                                  _overlap_predictors=True)
+            self._launch_dropmasks(int(x.shape[0]), int(x.shape[1]), mel_len, float(self.config['dropout_rate']))
+            try:
+                model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra,
+                                      _overlap_predictors=True)
+            finally:
+                self._dropmask_plan = {}
             self._join_predictors()              # the duration / pitch losses read the side stream's outputs
             loss, loss_vals = self._losses(model_out, ts, td, tp)
             ops.enable_wgrad_stream(self.overlap_wgrad)

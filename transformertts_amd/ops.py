@@ -269,6 +269,19 @@ def attention_weights(qkv, key_pad, lse, B, H, T, dh, p_drop=0.0, drop: Optional
     return w
 
 
+_ATTN_DROPBITS = os.environ.get('TTSMI_ATTN_DROPBITS', '1') != '0'    # measurement knob: 0 = hash in the inner loops
+
+
+def attention_dropmask(B, H, T, p_drop, drop: DropCtx, site, device, out=None):
+    """Keep-bit table of one attention layer for this step (include/ttsmi.h: ttsmi_attention_dropmask)."""
+    l = _lib.lib()
+    mask = out if out is not None else torch.empty(int(l.ttsmi_attention_dropmask_bytes(B, H, T)), dtype=torch.uint8,
+                                                    device=device)
+    check(l.ttsmi_attention_dropmask(_p(mask), B, H, T, float(p_drop), drop.seed, _p(drop.step_dev), int(site),
+                                     _stream()), 'attention_dropmask')
+    return mask
+
+
 def adam_tf(p, g, m, v, lr_dev, step_dev, b1=0.9, b2=0.98, eps=1e-9, shadow=None):
     check(_lib.lib().ttsmi_adam_tf(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), _p(step_dev),
                                    b1, b2, eps, _p(shadow), _stream()), 'adam_tf')
@@ -1156,7 +1169,7 @@ class DenseBlockFn(torch.autograd.Function):
     gradient buffer), S = dict of bf16 shadows (empty for the fp32 path)."""
 
     @staticmethod
-    def forward(ctx, h, h_bf, P, G, S, pad, klen, B, H, T, rate, drop, sites, dtype, want_lse):
+    def forward(ctx, h, h_bf, P, G, S, pad, klen, B, H, T, rate, drop, sites, dtype, want_lse, dmask_pre=None):
         h = _c(h)
         M, d = h.shape
         dh_ = d // H
@@ -1179,9 +1192,18 @@ class DenseBlockFn(torch.autograd.Function):
             qkv = dense_fwd(h, P['wqkv'], P['bqkv'], False, None, S.get('wqkv'))
             cx = torch.empty((M, d), dtype=torch.float32, device=h.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=h.device)
-        check(_lib.lib().ttsmi_attention_fwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(lse), B, H, T, dh_, float(rate),
-                                             drop.seed, _p(drop.step_dev), sites[0], int(dtype), _stream()),
-              'attention_fwd')
+        dmask = None
+        if all_h and rate > 0 and _ATTN_DROPBITS:
+            # dropout decisions of this layer as a bit table, evaluated once: forward and both backward kernels
+            # read bits instead of hashing in their inner loops.  dmask_pre: the model generated the table ahead of
+            # time on a side stream (ForwardTransformer._launch_dropmasks); otherwise it is generated here.
+            dmask = dmask_pre if dmask_pre is not None else attention_dropmask(B, H, T, rate, drop, sites[0], h.device)
+            check(_lib.lib().ttsmi_attention_fwd_masked(_p(qkv), _p(pad), _p(klen), _p(cx), _p(lse), B, H, T, dh_,
+                                                        float(rate), _p(dmask), _stream()), 'attention_fwd_masked')
+        else:
+            check(_lib.lib().ttsmi_attention_fwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(lse), B, H, T, dh_, float(rate),
+                                                 drop.seed, _p(drop.step_dev), sites[0], int(dtype), _stream()),
+                  'attention_fwd')
         if all_h:
             o = hgemm_tn(h_bf, S['wo'].wt, P['bo'], a2=cx)
             a, a_bf, mean1, rstd1 = _ln_fwd(o, h, P['ln1.gamma'], P['ln1.beta'], pad, rate, sites[1], drop, True)
@@ -1194,7 +1216,7 @@ class DenseBlockFn(torch.autograd.Function):
             h1 = dense_fwd(a, P['ffn.w1'], P['ffn.b1'], True, None, S.get('ffn.w1'))
             f = dense_fwd(h1, P['ffn.w2'], P['ffn.b2'], False, None, S.get('ffn.w2'))
             out, out_bf, mean2, rstd2 = _ln_fwd(f, a, P['ln2.gamma'], P['ln2.beta'], pad, rate, sites[2], drop)
-        ctx.save_for_backward(h, h_bf, qkv, cx, lse, o, a, a_bf, h1, f, mean1, rstd1, mean2, rstd2, pad, klen)
+        ctx.save_for_backward(h, h_bf, qkv, cx, lse, o, a, a_bf, h1, f, mean1, rstd1, mean2, rstd2, pad, klen, dmask)
         ctx.cfg = (P, G, S, B, H, T, dh_, float(rate), drop, sites, int(dtype), all_h)
         if out_bf is None:
             out_bf = out.new_empty(0)
@@ -1206,7 +1228,7 @@ class DenseBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dout_bf, _dqkv, _dlse):
-        h, h_bf, qkv, cx, lse, o, a, a_bf, h1, f, mean1, rstd1, mean2, rstd2, pad, klen = ctx.saved_tensors
+        h, h_bf, qkv, cx, lse, o, a, a_bf, h1, f, mean1, rstd1, mean2, rstd2, pad, klen, dmask = ctx.saved_tensors
         P, G, S, B, H, T, dh_, rate, drop, sites, dtype, all_h = ctx.cfg
         d = h.shape[1]
         dout = _c(dout)
@@ -1233,12 +1255,17 @@ class DenseBlockFn(torch.autograd.Function):
             # ---- attention + qkv projection ------------------------------------------------------
             dqkv = torch.empty_like(qkv)
             ws = _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, dh_), h.device)
-            check(l.ttsmi_attention_bwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(dctx), _p(lse), _p(dqkv), B, H, T, dh_,
-                                        rate, drop.seed, _p(drop.step_dev), sites[0], _p(ws), ws.numel(), dtype,
-                                        _stream()), 'attention_bwd')
+            if dmask is not None:
+                check(l.ttsmi_attention_bwd_masked(_p(qkv), _p(pad), _p(klen), _p(cx), _p(dctx), _p(lse), _p(dqkv), B, H,
+                                                   T, dh_, rate, _p(dmask), _p(ws), ws.numel(), _stream()),
+                      'attention_bwd_masked')
+            else:
+                check(l.ttsmi_attention_bwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(dctx), _p(lse), _p(dqkv), B, H, T, dh_,
+                                            rate, drop.seed, _p(drop.step_dev), sites[0], _p(ws), ws.numel(), dtype,
+                                            _stream()), 'attention_bwd')
             wgrad_rows_async(h_bf, dqkv, G['wqkv'], G['bqkv'])
             hgemm_tn(dqkv, shq.wb, out=dh, accumulate=True)                                  # dh += dqkv.Wqkv^T
-            return (dh,) + (None,) * 14
+            return (dh,) + (None,) * 15
         # ---- LN2 + FFN -----------------------------------------------------------------------
         df, da = _ln_bwd(dout, f, a, P['ln2.gamma'], mean2, rstd2, pad, rate, sites[2], drop,
                          G['ln2.gamma'], G['ln2.beta'])
@@ -1270,4 +1297,4 @@ class DenseBlockFn(torch.autograd.Function):
         shq = S.get('wqkv')
         dense_wgrad(h, dqkv, G['wqkv'], G['bqkv'], shq)
         dense_dgrad(dqkv, P['wqkv'], shq, 0, d, out=dh, accumulate=True)                    # dh += dqkv.Wqkv^T
-        return (dh,) + (None,) * 14
+        return (dh,) + (None,) * 15
