@@ -326,6 +326,100 @@ int ttsmi_conv_wdgrad_layout_bf16(const float* w, uint16_t* dst, int k, int Cin,
 /* Utility: fp32 -> bf16 (round to nearest even) for the TTSMI_BF16 weight copies. */
 int ttsmi_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, ttsmi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Full-row bf16 GEMMs (N = 256 output columns = the model width of BASELINE.json configs[1]) with the
+ * neighbouring LayerNormalization fused into the epilogue - csrc/rowgemm.hip.  One 64 x 256 workgroup tile
+ * holds complete rows, so the pre-norm tensor never reaches HBM and the LayerNorm costs no launch.
+ *
+ * ttsmi_hgemm_ln_fwd:  z = keep_in(a . bt^T + bias) + res;  x^ = (z - mean) * rstd;  y = rowmask(x^ * gamma + beta)
+ *   = Dense + dropout + residual add + LayerNormalization + dense_mask (model/layers.py:148-150,211,229 for the
+ *   attention output projection, :100-102,230 for the second FFN layer).  a bf16 [M,K] (+ second K segment a2 from
+ *   column K1, for concat([q_in, ctx])), bt = W^T bf16 [256,K].  Writes y fp32, y as bf16 (the next GEMM's operand),
+ *   x^ as bf16 and rstd [M] for the backward (mean is not needed again).
+ * ttsmi_hgemm_ln_bwd:  dy = dy_part + a . bt^T;  g = rowmask(dy);  t = g * gamma;
+ *   dz = rstd * (t - mean(t) - x^ * mean(t * x^));  dx = keep_in(dz) as bf16, dres = dz fp32, g as bf16.
+ *   = the dgrad GEMM whose result completes the gradient of a LayerNorm output, followed by that LayerNorm's backward.
+ * ttsmi_layernorm_bwd_xhat: the same backward for an upstream gradient that is already complete (dy fp32 [M,256]).
+ * ttsmi_layernorm_param_partials: per-128-row partial sums of dgamma = sum g * x^, dbeta = sum g from the two bf16
+ *   tensors, in the partial layout ttsmi_layernorm_param_reduce_batched_nw reduces (nparts = ..._partials_nw(M));
+ *   nothing on the critical path reads them, so the caller runs it on the weight-gradient stream.
+ * ------------------------------------------------------------------------------------------- */
+int ttsmi_hgemm_ln_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
+                       int64_t ldb, const float* bias, const float* res, const float* gamma, const float* beta,
+                       const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
+                       float eps, float* y, uint16_t* y_bf16, uint16_t* xhat_bf16, float* rstd, int M, int N, int K,
+                       ttsmi_stream_t stream);
+int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64_t ldb, const float* dy_part,
+                       const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
+                       uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres,
+                       uint16_t* g_bf16, int M, int N, int K, ttsmi_stream_t stream);
+int ttsmi_layernorm_bwd_xhat(const float* dy, const uint16_t* xhat_bf16, const float* rstd, const float* gamma,
+                             const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
+                             uint16_t* dx_bf16, float* dres, uint16_t* g_bf16, int M, int C, ttsmi_stream_t stream);
+int ttsmi_layernorm_param_partials_nw(int M);
+size_t ttsmi_layernorm_param_partials_bytes(int M, int C);
+int ttsmi_layernorm_param_partials(const uint16_t* g_bf16, const uint16_t* xhat_bf16, void* ws, size_t ws_bytes, int M, int C,
+                                   ttsmi_stream_t stream);
+/* number of partial rows ttsmi_add_layernorm_bwd leaves in its workspace for M rows */
+int ttsmi_add_layernorm_bwd_nparts(int M);
+/* ttsmi_layernorm_param_reduce_batched with the partial-row count of every item given explicitly */
+int ttsmi_layernorm_param_reduce_batched_nw(const void* const* ws, float* const* dgamma, float* const* dbeta,
+                                            float* const* dpe_scale, const int* nparts, const int* C, int n,
+                                            ttsmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One SelfAttentionDenseBlock (model/layers.py:214-230: MultiHeadAttention + two res-norms + FFN) per call,
+ * TTSMI_BF16 path: the forward enqueues its 8 launches, the backward its 9 main-stream launches and 5 weight
+ * gradients (second stream) from C++.  Driving the same launches one by one from Python costs ~14 us of host
+ * time each - with ~400 launches a step the HOST, not the GPU, bounded the train step (6.1 ms of enqueueing for
+ * 5.0 ms of GPU work); a descriptor is filled once per (block, batch shape) and a step then costs two calls
+ * per block.  Every pointer is a caller-owned device buffer with the element type named in the comment;
+ * nothing is allocated, nothing synchronises.  M = B*T rows, d = H*dh model width, F = FFN width.
+ * ------------------------------------------------------------------------------------------- */
+typedef void* ttsmi_event_t; /* hipEvent_t */
+typedef struct ttsmi_dense_block {
+    int32_t B, H, T, d, F;
+    float rate;                                   /* dropout rate of the block (0 = inference) */
+    uint32_t site_attn, site_ln1, site_ln2;       /* dropout sites, in the order the per-layer path draws them */
+    uint64_t seed;
+    const int64_t* step_dev;                      /* device step counter of the dropout stream */
+    const uint8_t* pad;                           /* [B,T] 1 = padded row / key */
+    const int32_t* klen;                          /* [B] */
+    const void* dropmask;                         /* keep bits of the attention dropout (ttsmi_attention_dropmask) or NULL */
+    /* parameters: fp32 vectors, bf16 matrices in both operand layouts (forward W^T [N][K], dgrad W as stored [K][N]) */
+    const float *bqkv, *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b;
+    const uint16_t *wqkv_t, *wo_t, *w1_t, *w2_t;
+    const uint16_t *wqkv_b, *wo_b, *w1_b, *w2_b;
+    /* gradient sinks (fp32, Keras layouts: wqkv [d,3d], wo [2d,d], w1 [d,F], w2 [F,d]) */
+    float *g_wqkv, *g_bqkv, *g_wo, *g_bo, *g_ln1_g, *g_ln1_b, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2_g, *g_ln2_b;
+    /* activations kept for the backward */
+    uint16_t *qkv /*[M,3d]*/, *cx /*[M,d]*/, *a_bf /*[M,d]*/, *h1 /*[M,F]*/, *out_bf /*[M,d]*/;
+    float *lse /*[B,H,T]*/, *o /*[M,d]*/, *a /*[M,d]*/, *f /*[M,d]*/, *out /*[M,d]*/;
+    float *mean1, *rstd1, *mean2, *rstd2;         /* [M] */
+    /* fuse_ln != 0 (needs d == 256): the two res-norms run in the epilogues of the o-projection / FFN2 GEMMs
+     * (ttsmi_hgemm_ln_fwd) and res-norm 1's backward in the epilogue of the FFN1 dgrad (ttsmi_hgemm_ln_bwd); o, f,
+     * mean1, mean2, ln_ws1, ln_ws2 are then unused and these are required instead: */
+    int32_t fuse_ln, _pad0;
+    uint16_t *xhat1, *xhat2;                      /* [M,d] normalised pre-activations kept for the backward */
+    uint16_t *g1, *g2;                            /* [M,d] masked upstream gradients of the two LayerNorms */
+    void *lnp_ws1, *lnp_ws2;                      /* ttsmi_layernorm_param_partials_bytes each */
+    uint64_t lnp_ws_bytes;
+    /* backward temporaries */
+    uint16_t *df /*[M,d]*/, *dh1 /*[M,F]*/, *d_o /*[M,d]*/, *dctx /*[M,d]*/, *dqkv /*[M,3d]*/;
+    float *da /*[M,d]*/, *dh /*[M,d]: the block's input gradient (output of the backward) */;
+    void *attn_ws, *ln_ws1, *ln_ws2, *wgrad_ws;   /* ttsmi_attention_bwd_ws_bytes / add_layernorm_bwd_ws_bytes /
+                                                     the largest ttsmi_hgemm_wgrad_rows_ws_bytes of the block */
+    uint64_t attn_ws_bytes, ln_ws_bytes, wgrad_ws_bytes;
+    ttsmi_stream_t main_stream, side_stream;      /* side_stream == NULL: weight gradients on the main stream */
+    ttsmi_event_t ev[4];                          /* main -> side hand-offs of the four weight-gradient groups */
+} ttsmi_dense_block;
+/* h [M,d] fp32 block input, h_bf its bf16 copy.  Writes desc->out / out_bf (+ the kept activations). */
+int ttsmi_dense_block_fwd(const ttsmi_dense_block* desc, const float* h, const uint16_t* h_bf);
+/* dout [M,d] fp32 gradient of the block output.  Writes desc->dh, the parameter gradients, and leaves the two
+ * LayerNorm parameter-gradient partials in ln_ws1 / ln_ws2 for ttsmi_layernorm_param_reduce_batched.
+ * The caller joins side_stream before it reads the weight gradients. */
+int ttsmi_dense_block_bwd(const ttsmi_dense_block* desc, const float* h, const uint16_t* h_bf, const float* dout);
+
 #ifdef __cplusplus
 }
 #endif

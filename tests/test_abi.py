@@ -69,3 +69,23 @@ def test_missing_library_fails_loudly(built, monkeypatch):
     monkeypatch.setattr(built, 'LIB_PATH', '/nonexistent/libttsmi.so')
     with pytest.raises(built.TtsmiError):
         built.lib()
+
+
+def test_dense_block_descriptor_layout_matches_the_header(tmp_path):
+    """_lib.DenseBlockDesc (ctypes) must mirror `ttsmi_dense_block` of include/ttsmi.h field for field: compile the
+    header with the host compiler and compare the size and every field offset."""
+    import ctypes
+    import subprocess
+    from transformertts_amd._lib import DenseBlockDesc
+    names = [n for n, _ in DenseBlockDesc._fields_]
+    src = tmp_path / 'layout.c'
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "ttsmi.h")}"',
+             'int main(void) {', '  printf("%zu\\n", sizeof(ttsmi_dense_block));']
+    lines += [f'  printf("%zu\\n", offsetof(ttsmi_dense_block, {n}));' for n in names]
+    lines += ['  return 0;', '}']
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', str(src), '-o', str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(DenseBlockDesc)
+    assert out[1:] == [getattr(DenseBlockDesc, n).offset for n in names]

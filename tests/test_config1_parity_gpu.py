@@ -30,8 +30,11 @@ pytestmark = pytest.mark.gpu
 # largest |g|_max of the model); 'gnorm': relative error of each tensor's L2 norm (tensors above the same floor);
 # 'tap': per block output, max abs error of the samples over the tensor's max abs value.
 BOUNDS = {
-    'f32': dict(fwd=1e-4, loss=1e-4, grad=2e-4, gnorm=2e-4, tap=1e-4),
-    'bf16': dict(fwd=3e-2, loss=5e-3, grad=1.5e-1, gnorm=5e-2, tap=3e-2),
+    # grad_vec: bias / LayerNorm vectors are column sums over all B*T rows with heavy cancellation (the FFN hidden bias
+    # worst of all): fp32 summation itself is at 2-3e-4 of the tensor's scale there - the torch-CPU fp32 run of the
+    # ORACLE differs from its own fp64 run by 2.7e-4 on dec.blk2.ffn.b1 - so vectors get 4e-4, matrices keep 2e-4
+    'f32': dict(fwd=1e-4, loss=1e-4, grad=2e-4, grad_vec=4e-4, gnorm=2e-4, tap=1e-4),
+    'bf16': dict(fwd=3e-2, loss=5e-3, grad=1.5e-1, grad_vec=1.5e-1, gnorm=5e-2, tap=3e-2),
 }
 
 
@@ -86,19 +89,22 @@ def _compare(gold, tag, m, out, bounds):
     names = [k[len(tag) + 5:] for k in gold if k.startswith(f'{tag}::g::')]
     assert sorted(names) == sorted(grads), 'gradient set differs from the oracle variable set'
     gmax = max(float(g(f'gstat::{k}')[0]) for k in names)
-    worst, worst_norm = ('', 0.0), ('', 0.0)
+    worst, worst_vec, worst_norm = ('', 0.0), ('', 0.0), ('', 0.0)
     for k in names:
         a = grads[k].astype(np.float64).reshape(-1)
         absmax, l2, total = g(f'gstat::{k}')
         scale = max(absmax, 1e-3 * gmax)
         e = float(np.abs(a[g1.sample_index(k, a.size)] - g(f'g::{k}')).max() / scale)
-        if e > worst[1]:
+        if grads[k].ndim <= 1:
+            if e > worst_vec[1]:
+                worst_vec = (k, e)
+        elif e > worst[1]:
             worst = (k, e)
         if absmax > 1e-3 * gmax:
             en = abs(float(np.sqrt((a * a).sum())) - l2) / l2
             if en > worst_norm[1]:
                 worst_norm = (k, en)
-    report['grad_worst'], report['gnorm_worst'] = worst, worst_norm
+    report['grad_worst'], report['grad_vec_worst'], report['gnorm_worst'] = worst, worst_vec, worst_norm
     return report
 
 
@@ -110,6 +116,7 @@ def _check(report, b):
     for name, e in report['taps'].items():
         assert e < b['tap'], (name, e)
     assert report['grad_worst'][1] < b['grad'], report['grad_worst']
+    assert report['grad_vec_worst'][1] < b['grad_vec'], report['grad_vec_worst']
     assert report['gnorm_worst'][1] < b['gnorm'], report['gnorm_worst']
 
 

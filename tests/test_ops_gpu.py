@@ -664,3 +664,75 @@ def test_hgemm_bf16_outputs_masks_and_sources():
     da0 = da.clone()
     ops.hgemm_tn(dh1, s1.wb, out=da, accumulate=True)                 # bf16 A + accumulate
     assert rel_err(da, da0.double().cpu() + dh1.double().cpu() @ _bf(w1).T) < 3e-6
+
+
+@pytest.mark.parametrize('M,K,dual,pdrop', [(300, 512, True, 0.0), (1000, 1024, False, 0.15), (64, 256, False, 0.15), (129, 512, True, 0.15)])
+def test_hgemm_with_fused_layernorm_matches_gemm_then_layernorm(M, K, dual, pdrop):
+    """ttsmi_hgemm_ln_fwd == hgemm_tn followed by add_layernorm (same dropout decisions, row mask, bf16 copy), and its
+    x^ / rstd feed ttsmi_layernorm_bwd_xhat + ttsmi_hgemm_ln_bwd to the same gradients as the standalone LayerNorm
+    backward (up to the bf16 rounding of x^)."""
+    ops = _ops()
+    from transformertts_amd import _lib
+    from transformertts_amd.ops import _p, _stream, check
+    l = _lib.lib()
+    N = 256
+    a = g(M, K, seed=1).to(DEV).to(torch.bfloat16)
+    w = (g(K, N, seed=2, scale=0.05)).to(DEV)
+    sh = ops.make_shadow(w)
+    bias, gam, bet = g(N, seed=3).to(DEV), (1 + 0.1 * g(N, seed=4)).to(DEV), (0.1 * g(N, seed=5)).to(DEV)
+    res = g(M, N, seed=6).to(DEV)
+    pad = (torch.arange(M) % 7 == 3).to(torch.uint8).to(DEV)
+    step = torch.full((1,), 3, dtype=torch.int64, device=DEV)
+    drop = ops.DropCtx(seed=21, step_dev=step)
+    site = 5
+    a1, a2 = (a[:, :K // 2].contiguous(), a[:, K // 2:].contiguous()) if dual else (a, None)
+    # reference: unfused kernels
+    o = ops.hgemm_tn(a1, sh.wt, bias, False, a2)
+    y0, y0h, mean0, rstd0 = ops._ln_fwd(o, res, gam, bet, pad, pdrop, site, drop, True)
+    # fused
+    y = torch.empty(M, N, device=DEV)
+    yh = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    xh = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    rstd = torch.empty(M, device=DEV)
+    check(l.ttsmi_hgemm_ln_fwd(_p(a1), a1.stride(0), _p(a2), 0 if a2 is None else a2.stride(0), a1.shape[1] if dual else 0,
+                               _p(sh.wt), sh.wt.stride(0), _p(bias), _p(res), _p(gam), _p(bet), _p(pad), pdrop, site,
+                               drop.seed, _p(step), 1e-6, _p(y), _p(yh), _p(xh), _p(rstd), M, N, K, _stream()))
+    torch.cuda.synchronize()
+    assert rel_err(y, y0) < 2e-5 and rel_err(rstd, rstd0) < 2e-5
+    assert rel_err(yh.float(), y0h.float()) < 1e-2
+    live = (pad == 0)
+    xhat_ref = ((y0 - bet) / gam)[live]
+    assert rel_err(xh.float()[live], xhat_ref) < 1e-2
+    # ---- backward of the same LayerNorm, standalone x^ form vs the classic kernel
+    dy = g(M, N, seed=7).to(DEV)
+    dg0, db0 = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    dx0, dres0 = ops._ln_bwd(dy, o, res, gam, mean0, rstd0, pad, pdrop, site, drop, dg0, db0, dx_bf16=True)
+    dxb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    dres = torch.empty(M, N, device=DEV)
+    gb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    check(l.ttsmi_layernorm_bwd_xhat(_p(dy), _p(xh), _p(rstd), _p(gam), _p(pad), pdrop, site, drop.seed, _p(step), _p(dxb),
+                                     _p(dres), _p(gb), M, N, _stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dres, dres0) < 1.5e-2 and rel_err(dxb.float(), dx0.float()) < 2e-2
+    # parameter gradients from (g, x^)
+    ws = torch.empty(int(l.ttsmi_layernorm_param_partials_bytes(M, N)), dtype=torch.uint8, device=DEV)
+    check(l.ttsmi_layernorm_param_partials(_p(gb), _p(xh), _p(ws), ws.numel(), M, N, _stream()))
+    dg, db = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    with ops.ln_param_batch():
+        ops._ln_defer(ws, dg, db, None, M, N, int(l.ttsmi_layernorm_param_partials_nw(M)))
+    torch.cuda.synchronize()
+    assert rel_err(db, db0) < 1e-2 and rel_err(dg, dg0) < 1.5e-2
+    # ---- GEMM + LayerNorm backward fused: dy = dy_part + a_b . w_b^T
+    Kb = 1024
+    ab = g(M, Kb, seed=8, scale=0.3).to(DEV).to(torch.bfloat16)
+    wb = (g(N, Kb, seed=9, scale=0.05)).to(DEV)                    # "W as stored" [k_in = 256][n_out = Kb]: dgrad operand
+    shb = ops.make_shadow(wb)
+    part = g(M, N, seed=10).to(DEV)
+    full = part.clone()
+    ops.hgemm_tn(ab, shb.wb, out=full, accumulate=True)
+    dx1, dres1 = ops._ln_bwd(full, o, res, gam, mean0, rstd0, pad, pdrop, site, drop, dg0, db0, dx_bf16=True)
+    check(l.ttsmi_hgemm_ln_bwd(_p(ab), ab.stride(0), _p(shb.wb), shb.wb.stride(0), _p(part), _p(xh), _p(rstd), _p(gam), _p(pad),
+                               pdrop, site, drop.seed, _p(step), _p(dxb), _p(dres), _p(gb), M, N, Kb, _stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dres, dres1) < 1.5e-2 and rel_err(dxb.float(), dx1.float()) < 2e-2
+    assert rel_err(gb.float(), (full * live[:, None])) < 1e-2

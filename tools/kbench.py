@@ -192,6 +192,74 @@ def bench_ln():
     return out
 
 
+def bench_rowgemm():
+    import torch
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream, check
+    l = _lib.lib()
+    dev, out = 'cuda:0', []
+    N, R = 256, 3
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    drop = ops.DropCtx(7, step)
+    for M in (28800, 6400):
+        pad = torch.zeros(M, dtype=torch.uint8, device=dev)
+        gam, bet, bias = torch.ones(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+        for name, K in (('o+LN1 fwd', 512), ('ffn2+LN2 fwd', 1024)):
+            As = [torch.randn(M, K, device=dev).bfloat16() for _ in range(R)]
+            res = [torch.randn(M, N, device=dev) for _ in range(R)]
+            wt = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+            y = torch.empty(M, N, device=dev); yh = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            xh = torch.empty(M, N, device=dev, dtype=torch.bfloat16); rstd = torch.empty(M, device=dev)
+            o = torch.empty(M, N, device=dev)
+            i = [0]
+
+            def fused():
+                j = i[0] % R; i[0] += 1
+                check(l.ttsmi_hgemm_ln_fwd(_p(As[j]), K, None, 0, 0, _p(wt), K, _p(bias), _p(res[j]), _p(gam), _p(bet), _p(pad),
+                                           0.1, 5, 7, _p(step), 1e-6, _p(y), _p(yh), _p(xh), _p(rstd), M, N, K, _stream()))
+
+            def unfused():
+                j = i[0] % R; i[0] += 1
+                ops.hgemm_tn(As[j], wt, bias, out=o)
+                ops._ln_fwd(o, res[j], gam, bet, pad, 0.1, 5, drop, True)
+            for nm, fn in ((name + ' fused', fused), (name + ' gemm+ln', unfused)):
+                t = timeit(fn)
+                out.append(dict(kind='rowg', name=nm, M=M, K=K, N=N, us=t, tflops=2.0 * M * N * K / t / 1e6, tbs=0.0))
+        K = 1024
+        As = [torch.randn(M, K, device=dev).bfloat16() for _ in range(R)]
+        part = [torch.randn(M, N, device=dev) for _ in range(R)]
+        wb = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        xh = torch.randn(M, N, device=dev).bfloat16(); rstd = torch.ones(M, device=dev)
+        dxb = torch.empty(M, N, device=dev, dtype=torch.bfloat16); dres = torch.empty(M, N, device=dev)
+        gb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        o = torch.randn(M, N, device=dev); mean = torch.zeros(M, device=dev)
+        dg, db = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+        i = [0]
+
+        def fusedb():
+            j = i[0] % R; i[0] += 1
+            check(l.ttsmi_hgemm_ln_bwd(_p(As[j]), K, _p(wb), K, _p(part[j]), _p(xh), _p(rstd), _p(gam), _p(pad), 0.1, 5, 7,
+                                       _p(step), _p(dxb), _p(dres), _p(gb), M, N, K, _stream()))
+
+        def unfusedb():
+            j = i[0] % R; i[0] += 1
+            ops.hgemm_tn(As[j], wb, out=part[j], accumulate=True)
+            ops._ln_bwd(part[j], o, part[(j + 1) % R], gam, mean, rstd, pad, 0.1, 5, drop, dg, db, dx_bf16=True)
+
+        def xhatb():
+            j = i[0] % R; i[0] += 1
+            check(l.ttsmi_layernorm_bwd_xhat(_p(part[j]), _p(xh), _p(rstd), _p(gam), _p(pad), 0.1, 5, 7, _p(step), _p(dxb),
+                                             _p(dres), _p(gb), M, N, _stream()))
+        ws = torch.empty(int(l.ttsmi_layernorm_param_partials_bytes(M, N)), dtype=torch.uint8, device=dev)
+
+        def lnp():
+            check(l.ttsmi_layernorm_param_partials(_p(gb), _p(xh), _p(ws), ws.numel(), M, N, _stream()))
+        for nm, fn in (('da+LN1 bwd fused', fusedb), ('da+LN1 bwd gemm+ln', unfusedb), ('LN bwd xhat', xhatb), ('LN param part', lnp)):
+            t = timeit(fn)
+            out.append(dict(kind='rowg', name=nm, M=M, K=K, N=N, us=t, tflops=2.0 * M * N * K / t / 1e6, tbs=0.0))
+    return out
+
+
 def run_all(only):
     res = []
     if only in (None, 'gemm'):
@@ -202,6 +270,8 @@ def run_all(only):
         res += bench_attn()
     if only in (None, 'ln'):
         res += bench_ln()
+    if only in (None, 'rowgemm'):
+        res += bench_rowgemm()
     return res
 
 

@@ -78,7 +78,39 @@ SIGNATURES = {
     'ttsmi_hgemm_wgrad_rows': (I, [P, I, L, P, I, L, P, L, P, I, I, I, I, I, I, I, P, c_size_t, S]),
     'ttsmi_conv_wdgrad_layout_bf16': (I, [P, P, I, I, I, I, S]),
     'ttsmi_cast_transpose_bf16_batched': (I, [P, I, I, S]),
+    'ttsmi_hgemm_ln_fwd': (I, [P, L, P, L, I, P, L, P, P, P, P, P, F, c_uint32, c_uint64, P, F, P, P, P, P, I, I, I, S]),
+    'ttsmi_hgemm_ln_bwd': (I, [P, L, P, L, P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, I, I, I, S]),
+    'ttsmi_layernorm_bwd_xhat': (I, [P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, I, I, S]),
+    'ttsmi_layernorm_param_partials_nw': (I, [I]),
+    'ttsmi_layernorm_param_partials_bytes': (c_size_t, [I, I]),
+    'ttsmi_layernorm_param_partials': (I, [P, P, P, c_size_t, I, I, S]),
+    'ttsmi_add_layernorm_bwd_nparts': (I, [I]),
+    'ttsmi_layernorm_param_reduce_batched_nw': (I, [P, P, P, P, P, P, I, S]),
+    'ttsmi_dense_block_fwd': (I, [P, P, P]),
+    'ttsmi_dense_block_bwd': (I, [P, P, P, P]),
 }
+
+
+def _dense_block_fields():
+    i32, u32, u64, f, p = ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float, ctypes.c_void_p
+    ptrs = ('step_dev', 'pad', 'klen', 'dropmask',
+            'bqkv', 'bo', 'ln1_g', 'ln1_b', 'b1', 'b2', 'ln2_g', 'ln2_b',
+            'wqkv_t', 'wo_t', 'w1_t', 'w2_t', 'wqkv_b', 'wo_b', 'w1_b', 'w2_b',
+            'g_wqkv', 'g_bqkv', 'g_wo', 'g_bo', 'g_ln1_g', 'g_ln1_b', 'g_w1', 'g_b1', 'g_w2', 'g_b2', 'g_ln2_g', 'g_ln2_b',
+            'qkv', 'cx', 'a_bf', 'h1', 'out_bf', 'lse', 'o', 'a', 'f', 'out', 'mean1', 'rstd1', 'mean2', 'rstd2')
+    ptrs2 = ('df', 'dh1', 'd_o', 'dctx', 'dqkv', 'da', 'dh', 'attn_ws', 'ln_ws1', 'ln_ws2', 'wgrad_ws')
+    return ([(n, i32) for n in ('B', 'H', 'T', 'd', 'F')] + [('rate', f)] +
+            [(n, u32) for n in ('site_attn', 'site_ln1', 'site_ln2')] + [('seed', u64)] +
+            [(n, p) for n in ptrs] + [('fuse_ln', i32), ('_pad0', i32)] +
+            [(n, p) for n in ('xhat1', 'xhat2', 'g1', 'g2', 'lnp_ws1', 'lnp_ws2')] + [('lnp_ws_bytes', u64)] +
+            [(n, p) for n in ptrs2] + [(n, u64) for n in ('attn_ws_bytes', 'ln_ws_bytes', 'wgrad_ws_bytes')] +
+            [('main_stream', p), ('side_stream', p), ('ev', p * 4)])
+
+
+class DenseBlockDesc(ctypes.Structure):
+    """ctypes mirror of `ttsmi_dense_block` (include/ttsmi.h) - field order and types must match
+    (tests/test_abi.py compares the size and a few offsets with the compiled header)."""
+    _fields_ = _dense_block_fields()
 
 TTSMI_F32, TTSMI_BF16, TTSMI_BF16_IO = 0, 1, 2
 

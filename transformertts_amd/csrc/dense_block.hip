@@ -1,0 +1,152 @@
+// ttsmi_dense_block_fwd / _bwd: the launch sequence of one SelfAttentionDenseBlock (model/layers.py:214-230) issued
+// from C++ through the library's own entry points - the same calls, in the same order, that ops.DenseBlockFn makes
+// from Python (TTSMI_BF16 path), minus ~14 us of interpreter / ctypes / allocator time per launch.
+#include <stdlib.h>
+
+#include "common.h"
+
+#define TRY(call)                 \
+    do {                          \
+        int rc__ = (call);        \
+        if (rc__) return rc__;    \
+    } while (0)
+
+static const float kLnEps = 1e-6f;     // LayerNormalization(epsilon=1e-6), model/layers.py:27,96,207
+
+static int check_desc(const ttsmi_dense_block* D, const char* who) {
+    TTSMI_CHECK_ARG(D, "%s: null descriptor", who);
+    TTSMI_CHECK_ARG(D->B > 0 && D->H > 0 && D->T > 0 && D->d > 0 && D->F > 0 && D->d % D->H == 0,
+                    "%s: bad shape B=%d H=%d T=%d d=%d F=%d", who, D->B, D->H, D->T, D->d, D->F);
+    TTSMI_CHECK_ARG(D->d % 64 == 0 && D->F % 8 == 0, "%s: needs d %% 64 == 0 and F %% 8 == 0", who);
+    TTSMI_CHECK_ARG(D->pad && D->klen, "%s: null mask", who);       // (main_stream == 0 is HIP's default stream)
+    if (D->fuse_ln)
+        TTSMI_CHECK_ARG(D->d == 256 && D->xhat1 && D->xhat2 && D->g1 && D->g2 && D->lnp_ws1 && D->lnp_ws2,
+                        "%s: fuse_ln needs d == 256 and the x^ / g / partial-sum buffers", who);
+    return TTSMI_OK;
+}
+
+extern "C" {
+
+int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf) {
+    TRY(check_desc(D, "dense_block_fwd"));
+    TTSMI_CHECK_ARG(h && h_bf, "dense_block_fwd: null input");
+    const int M = D->B * D->T, d = D->d, F = D->F, dh = d / D->H;
+    ttsmi_stream_t st = D->main_stream;
+    // qkv = h.Wqkv + b                                                     (layers.py:116-118, fused)
+    TRY(ttsmi_hgemm_tn(h_bf, 0, d, nullptr, 0, 0, D->wqkv_t, d, D->bqkv, nullptr, 0, D->qkv, 3L * d, M, 3 * d, d,
+                       TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st));
+    // ctx = softmax(q k^T / sqrt(dh) + mask) v                             (layers.py:176-195)
+    if (D->dropmask && D->rate > 0.f)
+        TRY(ttsmi_attention_fwd_masked(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->dropmask, st));
+    else
+        TRY(ttsmi_attention_fwd(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->seed,
+                                D->step_dev, D->site_attn, TTSMI_BF16_IO, st));
+    if (D->fuse_ln) {
+        // a = LN(drop([h | ctx].Wo + b) + h) * mask in ONE launch            (layers.py:148-150,211,229)
+        TRY(ttsmi_hgemm_ln_fwd(h_bf, d, D->cx, d, d, D->wo_t, 2L * d, D->bo, h, D->ln1_g, D->ln1_b, D->pad, D->rate,
+                               D->site_ln1, D->seed, D->step_dev, kLnEps, D->a, D->a_bf, D->xhat1, D->rstd1, M, d, 2 * d, st));
+        TRY(ttsmi_hgemm_tn(D->a_bf, 0, d, nullptr, 0, 0, D->w1_t, d, D->b1, nullptr, 0, D->h1, F, M, F, d,
+                           TTSMI_GEMM_RELU | TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st));
+        // out = LN(drop(h1.W2 + b2) + a) * mask in ONE launch                (layers.py:100-102,230)
+        TRY(ttsmi_hgemm_ln_fwd(D->h1, F, nullptr, 0, 0, D->w2_t, F, D->b2, D->a, D->ln2_g, D->ln2_b, D->pad, D->rate,
+                               D->site_ln2, D->seed, D->step_dev, kLnEps, D->out, D->out_bf, D->xhat2, D->rstd2, M, d, F, st));
+        return TTSMI_OK;
+    }
+    // o = [h | ctx].Wo + b                                                 (layers.py:148-149)
+    TRY(ttsmi_hgemm_tn(h_bf, 0, d, D->cx, d, d, D->wo_t, 2L * d, D->bo, nullptr, 0, D->o, d, M, d, 2 * d, 0, 1, 0, 0, 0, st));
+    // a = LN(drop(o) + h) * mask                                           (layers.py:150,211,229)
+    TRY(ttsmi_add_layernorm_fwd(D->o, h, D->ln1_g, D->ln1_b, nullptr, nullptr, 0, D->pad, D->rate, D->site_ln1, 0.f, 0,
+                                D->seed, D->step_dev, kLnEps, D->a, D->mean1, D->rstd1, M, d, D->a_bf, st));
+    // f = relu(a.W1 + b1).W2 + b2                                          (layers.py:99-100)
+    TRY(ttsmi_hgemm_tn(D->a_bf, 0, d, nullptr, 0, 0, D->w1_t, d, D->b1, nullptr, 0, D->h1, F, M, F, d,
+                       TTSMI_GEMM_RELU | TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st));
+    TRY(ttsmi_hgemm_tn(D->h1, 0, F, nullptr, 0, 0, D->w2_t, F, D->b2, nullptr, 0, D->f, d, M, d, F, 0, 1, 0, 0, 0, st));
+    // out = LN(drop(f) + a) * mask                                         (layers.py:101-102,230)
+    TRY(ttsmi_add_layernorm_fwd(D->f, D->a, D->ln2_g, D->ln2_b, nullptr, nullptr, 0, D->pad, D->rate, D->site_ln2, 0.f, 0,
+                                D->seed, D->step_dev, kLnEps, D->out, D->mean2, D->rstd2, M, d, D->out_bf, st));
+    return TTSMI_OK;
+}
+
+// weight gradient dW[kin,n] = x^T . dy (+ db) on the side stream, ordered after everything the main stream has
+// enqueued so far (its operands) through one event
+static int wgrad_side(const ttsmi_dense_block* D, int ev, bool record, const uint16_t* x, int ldx, const uint16_t* dy, int lddy,
+                      float* dw, float* db, int kin, int n) {
+    const int M = D->B * D->T;
+    static int skip = -1;      // measurement knob (results are then WRONG: no weight gradients): main-stream-only backward time
+    if (skip < 0) { const char* e = getenv("TTSMI_DEBUG_SKIP_WGRAD"); skip = e ? atoi(e) : 0; }
+    if (skip) return TTSMI_OK;
+    hipStream_t main_st = (hipStream_t)D->main_stream;
+    hipStream_t st = D->side_stream ? (hipStream_t)D->side_stream : main_st;
+    if (D->side_stream && record) {
+        hipEvent_t e = (hipEvent_t)D->ev[ev];
+        TTSMI_CHECK_ARG(e, "dense_block_bwd: null event");
+        if (hipEventRecord(e, main_st) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) {
+            ttsmi_set_error("dense_block_bwd: event hand-off to the weight-gradient stream failed");
+            return TTSMI_ERR_LAUNCH;
+        }
+    }
+    return ttsmi_hgemm_wgrad_rows(x, 1, ldx, dy, 1, lddy, dw, n, db, M, kin, n, 1, 0, 0, 0, D->wgrad_ws, D->wgrad_ws_bytes, st);
+}
+
+// LayerNorm parameter-gradient partial sums, on the weight-gradient stream right behind the weight gradient that
+// shares their operand (the hand-off event of that launch already covers them)
+static int lnp_side(const ttsmi_dense_block* D, const uint16_t* g, const uint16_t* xhat, void* ws) {
+    static int skip = -1;
+    if (skip < 0) { const char* e = getenv("TTSMI_DEBUG_SKIP_WGRAD"); skip = e ? atoi(e) : 0; }
+    if (skip) return TTSMI_OK;
+    ttsmi_stream_t st = D->side_stream ? D->side_stream : D->main_stream;
+    return ttsmi_layernorm_param_partials(g, xhat, ws, D->lnp_ws_bytes, D->B * D->T, D->d, st);
+}
+
+int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf, const float* dout) {
+    TRY(check_desc(D, "dense_block_bwd"));
+    TTSMI_CHECK_ARG(h && h_bf && dout, "dense_block_bwd: null input");
+    const int M = D->B * D->T, d = D->d, F = D->F, dh = d / D->H;
+    ttsmi_stream_t st = D->main_stream;
+    const bool dropout = D->rate > 0.f;
+    // ---- LN2 + FFN: df (bf16) = dLN2/dx, da (fp32) = dLN2/dres
+    if (D->fuse_ln)
+        TRY(ttsmi_layernorm_bwd_xhat(dout, D->xhat2, D->rstd2, D->ln2_g, D->pad, D->rate, D->site_ln2, D->seed, D->step_dev,
+                                     D->df, D->da, D->g2, M, d, st));
+    else
+        TRY(ttsmi_add_layernorm_bwd(dout, D->f, D->a, D->ln2_g, D->mean2, D->rstd2, nullptr, nullptr, 0, D->pad, D->rate,
+                                    D->site_ln2, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->da, D->da, nullptr,
+                                    nullptr, nullptr, M, d, D->ln_ws2, D->ln_ws_bytes, D->df, st));
+    TRY(wgrad_side(D, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
+    if (D->fuse_ln) TRY(lnp_side(D, D->g2, D->xhat2, D->lnp_ws2));
+    TRY(ttsmi_hgemm_tn(D->df, 0, d, nullptr, 0, 0, D->w2_b, d, nullptr, (const float*)D->h1, F, D->dh1, F, M, F, d,
+                       TTSMI_GEMM_OUT_BF16 | TTSMI_GEMM_MASK_BF16, 1, 0, 0, 0, st));                  // relu' fused
+    TRY(wgrad_side(D, 1, true, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
+    if (D->fuse_ln) {
+        // (da + dh1.W1^T) never reaches HBM: res-norm 1's backward runs in the dgrad's epilogue -> d_o (bf16), dh (fp32)
+        TRY(ttsmi_hgemm_ln_bwd(D->dh1, F, D->w1_b, F, D->da, D->xhat1, D->rstd1, D->ln1_g, D->pad, D->rate, D->site_ln1,
+                               D->seed, D->step_dev, D->d_o, D->dh, D->g1, M, d, F, st));
+    } else {
+        TRY(ttsmi_hgemm_tn(D->dh1, 0, F, nullptr, 0, 0, D->w1_b, F, nullptr, nullptr, 0, D->da, d, M, d, F,
+                           TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                   // da += dh1.W1^T
+        // ---- LN1 + output projection: d_o (bf16), dh (fp32)
+        TRY(ttsmi_add_layernorm_bwd(D->da, D->o, h, D->ln1_g, D->mean1, D->rstd1, nullptr, nullptr, 0, D->pad, D->rate,
+                                    D->site_ln1, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->dh, D->dh, nullptr,
+                                    nullptr, nullptr, M, d, D->ln_ws1, D->ln_ws_bytes, D->d_o, st));
+    }
+    TRY(wgrad_side(D, 2, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
+    TRY(wgrad_side(D, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
+    if (D->fuse_ln) TRY(lnp_side(D, D->g1, D->xhat1, D->lnp_ws1));
+    TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b, d, nullptr, nullptr, 0, D->dh, d, M, d, d,
+                       TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                       // dh += do.Wo_top^T
+    TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b + (long)d * d, d, nullptr, nullptr, 0, D->dctx, d, M, d, d,
+                       TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st));
+    // ---- attention + qkv projection
+    if (D->dropmask && dropout)
+        TRY(ttsmi_attention_bwd_masked(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh,
+                                       D->rate, D->dropmask, D->attn_ws, D->attn_ws_bytes, st));
+    else
+        TRY(ttsmi_attention_bwd(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh, D->rate,
+                                D->seed, D->step_dev, D->site_attn, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));
+    TRY(wgrad_side(D, 3, true, h_bf, d, D->dqkv, 3 * d, D->g_wqkv, D->g_bqkv, d, 3 * d));
+    TRY(ttsmi_hgemm_tn(D->dqkv, 0, 3L * d, nullptr, 0, 0, D->wqkv_b, 3L * d, nullptr, nullptr, 0, D->dh, d, M, d, 3 * d,
+                       TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                       // dh += dqkv.Wqkv^T
+    return TTSMI_OK;
+}
+
+}  // extern "C"

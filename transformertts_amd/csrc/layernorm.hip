@@ -493,10 +493,30 @@ int ttsmi_add_layernorm_bwd(const float* dy, const float* x, const float* res, c
     return TTSMI_OK;
 }
 
+int ttsmi_add_layernorm_bwd_nparts(int M) { return ln_bwd_blocks(M); }
+
+static int reduce_batched(const void* const* ws, float* const* dgamma, float* const* dbeta, float* const* dpe_scale,
+                          const int* M, const int* nparts, const int* C, int n, ttsmi_stream_t stream);
+
 int ttsmi_layernorm_param_reduce_batched(const void* const* ws, float* const* dgamma, float* const* dbeta,
                                          float* const* dpe_scale, const int* M, const int* C, int n,
                                          ttsmi_stream_t stream) {
-    TTSMI_CHECK_ARG(ws && dgamma && dbeta && dpe_scale && M && C, "layernorm_param_reduce_batched: null pointer");
+    TTSMI_CHECK_ARG(M, "layernorm_param_reduce_batched: null pointer");
+    return reduce_batched(ws, dgamma, dbeta, dpe_scale, M, nullptr, C, n, stream);
+}
+
+int ttsmi_layernorm_param_reduce_batched_nw(const void* const* ws, float* const* dgamma, float* const* dbeta,
+                                            float* const* dpe_scale, const int* nparts, const int* C, int n,
+                                            ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(nparts, "layernorm_param_reduce_batched_nw: null pointer");
+    return reduce_batched(ws, dgamma, dbeta, dpe_scale, nullptr, nparts, C, n, stream);
+}
+
+}  // extern "C"
+
+static int reduce_batched(const void* const* ws, float* const* dgamma, float* const* dbeta, float* const* dpe_scale,
+                          const int* M, const int* nparts, const int* C, int n, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(ws && dgamma && dbeta && dpe_scale && C, "layernorm_param_reduce_batched: null pointer");
     TTSMI_CHECK_ARG(n >= 0, "layernorm_param_reduce_batched: bad count");
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n; base += LN_BATCH_MAX) {
@@ -506,13 +526,13 @@ int ttsmi_layernorm_param_reduce_batched(const void* const* ws, float* const* dg
         int blocks = 0;
         for (int i = 0; i < b.n; ++i) {
             const int j = base + i;
-            TTSMI_CHECK_ARG(ws[j] && dgamma[j] && dbeta[j] && M[j] > 0 && C[j] > 0,
+            TTSMI_CHECK_ARG(ws[j] && dgamma[j] && dbeta[j] && (M ? M[j] : nparts[j]) > 0 && C[j] > 0,
                             "layernorm_param_reduce_batched: bad item");
             b.it[i].part = (const float*)ws[j];
             b.it[i].dgamma = dgamma[j];
             b.it[i].dbeta = dbeta[j];
             b.it[i].dscale = dpe_scale[j];
-            b.it[i].nw = ln_bwd_blocks(M[j]);
+            b.it[i].nw = M ? ln_bwd_blocks(M[j]) : nparts[j];
             b.it[i].C = C[j];
             b.blk_off[i] = blocks;
             blocks += ttsmi_cdiv(C[j], 16);
@@ -523,5 +543,3 @@ int ttsmi_layernorm_param_reduce_batched(const void* const* ws, float* const* dg
     }
     return TTSMI_OK;
 }
-
-}  // extern "C"

@@ -1,0 +1,517 @@
+// Full-row GEMMs of the dense block with the neighbouring LayerNormalization fused into the epilogue (TTSMI_BF16 path).
+//
+//   forward :  y = rowmask( LN( keep(a . W^T + bias) + res ) * gamma + beta )        (o-projection + res-norm 1,
+//                                                                                     FFN2 + res-norm 2; layers.py:148-150,
+//                                                                                     211,229 and :100-102,230)
+//   backward:  da = dy_part + a . W^T ;  (d_o, dres) = LN'(da)                        (dgrad of FFN1 + backward of res-norm 1)
+//
+// Both GEMMs have N = d = 256 output columns, i.e. one workgroup tile (64 rows x 256 columns) holds COMPLETE rows of the
+// result, so the row statistics of the LayerNorm are available in the epilogue and the pre-norm tensor (o / f forward,
+// da backward) never exists in HBM: per LayerNorm that removes one launch, a 29.5 MB write and a 29.5 MB read at
+// M = 28 800 (the standalone kernels moved 103 MB forward / 133 MB backward).
+//
+// The accumulators are kept TRANSPOSED (C^T = W . A^T: the MFMA A operand is the weight fragment, the B operand the
+// activation fragment), so that a lane owns ONE row m and 64 of its 256 columns (4 column tiles x 16 registers; the
+// other 64 sit in lane ^ 32, the other 128 in the partner wave): the row reductions are 64 local adds, one shuffle and
+// one two-wave LDS exchange instead of a 32-lane shuffle tree per register.  Lane-private rows also mean the residual,
+// gamma / beta and x^ are plain float4 / 8-byte accesses with no LDS staging of the output tile.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define RG_BM 64
+#define RG_N 256
+#define RG_BK 64
+#define RG_LD (RG_BK + 8)          // 144-byte LDS rows: conflict-free ds_read_b128 (see gemm_bf16.hip)
+
+struct RowGemmP {
+    const uint16_t* A; long lda; const uint16_t* A2; long lda2; int K1;     // bf16 rows, optional second K segment
+    const uint16_t* Bt; long ldb;                                           // bf16 [256][K] (W^T forward, W rows backward)
+    int M, K;
+    const float* bias;                 // [256] or NULL
+    const float* res;                  // fwd: residual [M,256];  bwd: the partial gradient the GEMM result is added to
+    const float* gamma; const float* beta;
+    const uint8_t* row_pad;            // [M] 1 = padded row
+    uint32_t thr_in; float inv_in; uint64_t seed; const int64_t* step_dev; uint32_t site_in;
+    float eps;
+    // forward outputs
+    float* y; uint16_t* y_bf; uint16_t* xhat; float* rstd;
+    // backward inputs / outputs
+    const uint16_t* xhat_in; const float* rstd_in;
+    uint16_t* dx_bf; float* dres; uint16_t* g_bf;
+};
+
+__device__ __forceinline__ uint2 rg_pack4(float a, float b, float c, float d) {
+    bf16x4 h;
+    h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
+    return *reinterpret_cast<uint2*>(&h);
+}
+__device__ __forceinline__ void rg_unpack4(uint2 v, float (&o)[4]) {
+    o[0] = __builtin_bit_cast(float, v.x << 16); o[1] = __builtin_bit_cast(float, v.x & 0xFFFF0000u);
+    o[2] = __builtin_bit_cast(float, v.y << 16); o[3] = __builtin_bit_cast(float, v.y & 0xFFFF0000u);
+}
+
+template <int ROWS>
+__device__ __forceinline__ void rg_fetch(const uint16_t* base, long ld, int rows, int r0, int k0, int tid,
+                                         uint4 (&r)[ROWS * RG_BK / 2048]) {
+#pragma unroll
+    for (int i = 0; i < ROWS * RG_BK / 2048; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id >> 3, c8 = id & 7;
+        const int m = r0 + row;                                // (a clamped row index instead of the select sends these
+        r[i] = m < rows ? *reinterpret_cast<const uint4*>(base + (long)m * ld + k0 + c8 * 8)   // arrays to scratch: hipcc 7.2)
+                        : make_uint4(0, 0, 0, 0);
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void rg_stash(uint16_t (*S)[RG_LD], int tid, const uint4 (&r)[ROWS * RG_BK / 2048]) {
+#pragma unroll
+    for (int i = 0; i < ROWS * RG_BK / 2048; ++i) {
+        const int id = tid + 256 * i;
+        *reinterpret_cast<uint4*>(&S[id >> 3][(id & 7) * 8]) = r[i];
+    }
+}
+
+// ---- the LayerNorm epilogues.  The transposed accumulators (lane = row m, 4 consecutive columns per register quad)
+// go to an fp32 LDS tile Z[BM][260] with conflict-free 16-byte writes; then every wave takes whole ROWS of the tile
+// (lane = 4 consecutive columns, exactly the geometry of the standalone LayerNorm kernels): residual / x^ / outputs move
+// as full 1 KB (fp32) or 512 B (bf16) rows - one coalesced wave instruction each - and the row statistics are wave
+// shuffles.  (A first version kept the rows lane-private and accessed global memory straight from the accumulator
+// layout: 32 rows x 32 B per instruction; its epilogue alone took 47 us of a 55 us launch.)
+// EPI: 0 = LayerNorm forward, 1 = LayerNorm backward.  NW = waves of the workgroup, BM = rows of the tile.
+#define RG_ZLD 260
+template <int EPI, int NW, int BM>
+__device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4], int m0, float* Z, int wave, int wm, int wc,
+                                            int lane) {
+    const int l31 = lane & 31, hh = lane >> 5;
+    // ---- accumulators -> Z (all waves finished reading the operand stages: the caller synchronised)
+    {
+        float* zr = Z + (wm * 32 + l31) * RG_ZLD + wc * 128 + 4 * hh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(zr + j * 32 + 8 * g) =
+                    make_float4(acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+    }
+    __syncthreads();
+    constexpr int RPW = BM / NW;                       // rows per wave
+    const int c4 = lane * 4;
+    const uint64_t key_in = p.thr_in ? ttsmi_drop_key(p.seed, p.step_dev, p.site_in) : 0;
+    const float invC = 1.0f / (float)RG_N;
+    if constexpr (EPI == 0) {
+        const float4 bs = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c4);
+        const float4 bt = *reinterpret_cast<const float4*>(p.beta + c4);
+        float4 rs[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {                // every residual row of this wave in flight at once
+            const int row = min(m0 + wave + NW * i, p.M - 1);
+            rs[i] = *reinterpret_cast<const float4*>(p.res + (long)row * RG_N + c4);
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int rl = wave + NW * i, row = m0 + rl;
+            if (row >= p.M) break;                                     // wave-uniform
+            const float4 a = *reinterpret_cast<const float4*>(Z + rl * RG_ZLD + c4);
+            float v[4] = {a.x + bs.x, a.y + bs.y, a.z + bs.z, a.w + bs.w};
+            if (p.thr_in) {
+                const uint32_t rb = ttsmi_row_base(key_in, (uint32_t)row);
+                const uint32_t h0 = ttsmi_pair_hash(rb, (uint32_t)c4), h1 = ttsmi_pair_hash(rb, (uint32_t)(c4 + 2));
+                v[0] *= ((h0 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f;
+                v[1] *= ((h0 >> 16) >= p.thr_in) ? p.inv_in : 0.f;
+                v[2] *= ((h1 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f;
+                v[3] *= ((h1 >> 16) >= p.thr_in) ? p.inv_in : 0.f;
+            }
+            v[0] += rs[i].x; v[1] += rs[i].y; v[2] += rs[i].z; v[3] += rs[i].w;
+            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * invC;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) * invC + p.eps);
+            if (lane == 0) p.rstd[row] = rstd;
+            const bool padded = p.row_pad != nullptr && p.row_pad[row] != 0;
+            float xh[4], yv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xh[e] = v[e] * rstd;
+            yv[0] = xh[0] * gm.x + bt.x; yv[1] = xh[1] * gm.y + bt.y; yv[2] = xh[2] * gm.z + bt.z; yv[3] = xh[3] * gm.w + bt.w;
+            if (padded) { yv[0] = 0.f; yv[1] = 0.f; yv[2] = 0.f; yv[3] = 0.f; }
+            const long o = (long)row * RG_N + c4;
+            *reinterpret_cast<float4*>(p.y + o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+            *reinterpret_cast<uint2*>(p.y_bf + o) = rg_pack4(yv[0], yv[1], yv[2], yv[3]);
+            *reinterpret_cast<uint2*>(p.xhat + o) = rg_pack4(xh[0], xh[1], xh[2], xh[3]);
+        }
+    } else {
+        // dy = acc + partial;  g = dy * rowmask;  t = g * gamma;  dz = rstd (t - mean(t) - x^ mean(t x^));
+        // d_o = keep(dz) (bf16), dres = dz (fp32), g (bf16, for the parameter-gradient kernel)
+        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c4);
+        float4 rs[RPW];
+        uint2 xs[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = min(m0 + wave + NW * i, p.M - 1);
+            rs[i] = *reinterpret_cast<const float4*>(p.res + (long)row * RG_N + c4);
+            xs[i] = *reinterpret_cast<const uint2*>(p.xhat_in + (long)row * RG_N + c4);
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int rl = wave + NW * i, row = m0 + rl;
+            if (row >= p.M) break;
+            const float4 a = *reinterpret_cast<const float4*>(Z + rl * RG_ZLD + c4);
+            const bool padded = p.row_pad != nullptr && p.row_pad[row] != 0;
+            const float rstd = p.rstd_in[row];
+            float gv[4] = {a.x + rs[i].x, a.y + rs[i].y, a.z + rs[i].z, a.w + rs[i].w};
+            if (padded) { gv[0] = 0.f; gv[1] = 0.f; gv[2] = 0.f; gv[3] = 0.f; }
+            float xh[4];
+            rg_unpack4(xs[i], xh);
+            const long o = (long)row * RG_N + c4;
+            *reinterpret_cast<uint2*>(p.g_bf + o) = rg_pack4(gv[0], gv[1], gv[2], gv[3]);
+            const float t[4] = {gv[0] * gm.x, gv[1] * gm.y, gv[2] * gm.z, gv[3] * gm.w};
+            const float m1 = wave_sum(t[0] + t[1] + t[2] + t[3]) * invC;
+            const float m2 = wave_sum(t[0] * xh[0] + t[1] * xh[1] + t[2] * xh[2] + t[3] * xh[3]) * invC;
+            float dz[4], dx[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dz[e] = rstd * (t[e] - m1 - xh[e] * m2);
+            if (p.thr_in) {
+                const uint32_t rb = ttsmi_row_base(key_in, (uint32_t)row);
+                const uint32_t h0 = ttsmi_pair_hash(rb, (uint32_t)c4), h1 = ttsmi_pair_hash(rb, (uint32_t)(c4 + 2));
+                dx[0] = dz[0] * (((h0 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f);
+                dx[1] = dz[1] * (((h0 >> 16) >= p.thr_in) ? p.inv_in : 0.f);
+                dx[2] = dz[2] * (((h1 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f);
+                dx[3] = dz[3] * (((h1 >> 16) >= p.thr_in) ? p.inv_in : 0.f);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dx[e] = dz[e];
+            }
+            *reinterpret_cast<float4*>(p.dres + o) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+            *reinterpret_cast<uint2*>(p.dx_bf + o) = rg_pack4(dx[0], dx[1], dx[2], dx[3]);
+        }
+    }
+}
+
+// EPI: 0 = LayerNorm forward, 1 = LayerNorm backward
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void rowgemm_kernel(RowGemmP p) {
+    constexpr int TILE_BYTES = (RG_BM + RG_N) * RG_LD * 2, Z_BYTES = RG_BM * RG_ZLD * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > Z_BYTES ? TILE_BYTES : Z_BYTES];
+    uint16_t(*As)[RG_LD] = reinterpret_cast<uint16_t(*)[RG_LD]>(smem);
+    uint16_t(*Bs)[RG_LD] = As + RG_BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * RG_BM;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    uint4 ra[RG_BM * RG_BK / 2048], rb[RG_N * RG_BK / 2048];
+#define RG_FETCH(k0_)                                                                                   \
+    do {                                                                                                \
+        const int kk_ = (k0_);                                                                          \
+        const bool second_ = p.A2 != nullptr && kk_ >= p.K1;                                            \
+        rg_fetch<RG_BM>(second_ ? p.A2 : p.A, second_ ? p.lda2 : p.lda, p.M, m0, second_ ? kk_ - p.K1 : kk_, tid, ra); \
+        rg_fetch<RG_N>(p.Bt, p.ldb, RG_N, 0, kk_, tid, rb);                                             \
+    } while (0)
+    RG_FETCH(0);
+    rg_stash<RG_BM>(As, tid, ra);
+    rg_stash<RG_N>(Bs, tid, rb);
+    __syncthreads();
+    for (int k0 = 0; k0 < p.K; k0 += RG_BK) {
+        const bool more = k0 + RG_BK < p.K;
+        if (more) RG_FETCH(k0 + RG_BK);
+#pragma unroll
+        for (int ks = 0; ks < RG_BK / 16; ++ks) {
+            const int ko = ks * 16 + hh * 8;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[wm * 32 + l31][ko]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[wc * 128 + j * 32 + l31][ko]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[j], 0, 0, 0);      // C^T: rows = n, cols = m
+            }
+        }
+        __syncthreads();
+        if (more) {
+            rg_stash<RG_BM>(As, tid, ra);
+            rg_stash<RG_N>(Bs, tid, rb);
+        }
+        __syncthreads();
+    }
+
+    rg_epilogue<EPI, 4, RG_BM>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane);
+}
+
+// =================================================================================================
+// 128-row LDS-DMA variant for the decoder-size launches (M >= 256 * 64): ONE 8-wave workgroup per CU owns a
+// 128 x 256 tile, halving the per-tile re-read of W (the 64-row kernel above pulls all of W through L2 for every 64
+// rows: 289 MB of L2 -> LDS traffic per K = 1024 launch, at which it ran 64 us against 52 us for the unfused pair).
+// With a single workgroup per CU nothing else hides memory latency, so the k-tiles arrive by `global_load_lds_dwordx4`
+// into a THREE-stage ring (48 KB per stage: A 128 x 64, W 256 x 64 bf16), two k-steps in flight while one is
+// multiplied - the structure of wgrad_dma_kernel (gemm_bf16.hip): counted vmcnt, one `lgkmcnt(0) + s_barrier` per step.
+// The DMA image is lane-linear: dense 128-byte rows; chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7)
+// (source-side swizzle, free), which makes the ds_read_b128 fragment reads conflict free (see gemm_bf16_dma_kernel).
+// =================================================================================================
+#define RD_BM 128
+#define RD_STAGE ((RD_BM + RG_N) * RG_BK * 2)      // 49 152 bytes
+#define RD_STAGES 3
+
+__device__ __forceinline__ void rd_dma16(const void* gsrc, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory", "m0");
+}
+__device__ __forceinline__ void rd_stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ unsigned rd_lds_offset(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
+    static_assert(RD_STAGES * RD_STAGE >= RD_BM * RG_ZLD * 4, "the epilogue tile lives in the retired stages");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RD_STAGES * RD_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                      // 0..7
+    const int wm = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * RD_BM;
+    const int nk = p.K / RG_BK;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // DMA: one wave instruction = 8 rows x 8 chunks of 16 bytes.  Per k-step wave w moves rows [16 w, 16 w + 16) of the
+    // A image (2 instructions) and rows [32 w, 32 w + 32) of the W image (4 instructions): 6 per wave and step.
+    const int drow = lane >> 3, dpos = lane & 7;
+    auto issue = [&](int ks, int stage) {
+        unsigned char* As = smem + stage * RD_STAGE;
+        unsigned char* Bs = As + RD_BM * 128;
+        int k0 = ks * RG_BK;
+        const uint16_t* Ab = p.A;
+        long lda = p.lda;
+        if (p.A2 != nullptr && k0 >= p.K1) { Ab = p.A2; lda = p.lda2; k0 -= p.K1; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 16 + i * 8 + drow;
+            const int c = dpos ^ ((row >> 1) & 7);
+            const int gm = min(m0 + row, p.M - 1);                   // rows past M: clamped on load, dropped on store
+            rd_dma16(Ab + (long)gm * lda + k0 + c * 8, rd_lds_offset(As + (wave * 16 + i * 8) * 128));
+        }
+        const int kb = ks * RG_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + drow;
+            const int c = dpos ^ ((row >> 1) & 7);
+            rd_dma16(p.Bt + (long)row * p.ldb + kb + c * 8, rd_lds_offset(Bs + (wave * 32 + i * 8) * 128));
+        }
+    };
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int ks = 0; ks < nk; ++ks) {
+        // step ks has landed once at most the newest step's 6 DMA instructions are outstanding
+        if (ks + 1 < nk) __builtin_amdgcn_s_waitcnt(0xF76);          // vmcnt(6)
+        else __builtin_amdgcn_s_waitcnt(0xF70);                      // vmcnt(0)
+        rd_stage_barrier();                                          // everybody's pieces landed; stage (ks-1)%3 is retired
+        if (ks + 2 < nk) issue(ks + 2, (ks + 2) % RD_STAGES);
+        const unsigned char* As = smem + (ks % RD_STAGES) * RD_STAGE;
+        const unsigned char* Bs = As + RD_BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < RG_BK / 16; ++kk) {
+            const int c = kk * 2 + hh;
+            const int arow = wm * 32 + l31;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + arow * 128 + ((c ^ ((arow >> 1) & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int brow = wc * 128 + j * 32 + l31;
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + brow * 128 + ((c ^ ((brow >> 1) & 7)) << 4));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    rg_epilogue<EPI, 8, RD_BM>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane);
+}
+
+// ---- standalone backward of a LayerNorm whose forward kept x^ (bf16) and rstd: the fused forward's counterpart for the
+// LayerNorms whose upstream gradient is not a full-row GEMM result.  One wave per row (as ln_bwd_kernel), 256 columns:
+// 4 per lane.  Also leaves g = dy * rowmask as bf16 for the parameter-gradient kernel.
+__global__ __launch_bounds__(256) void ln_bwd_xhat_kernel(RowGemmP p, const float* __restrict__ dy) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const long base = (long)row * RG_N + lane * 4;
+    const bool padded = p.row_pad != nullptr && p.row_pad[row] != 0;
+    const float rstd = p.rstd_in[row];
+    float4 g4 = *reinterpret_cast<const float4*>(dy + base);
+    float xh[4];
+    rg_unpack4(*reinterpret_cast<const uint2*>(p.xhat_in + base), xh);
+    const float4 gm = *reinterpret_cast<const float4*>(p.gamma + lane * 4);
+    float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    if (padded) { gv[0] = 0.f; gv[1] = 0.f; gv[2] = 0.f; gv[3] = 0.f; }
+    *reinterpret_cast<uint2*>(p.g_bf + base) = rg_pack4(gv[0], gv[1], gv[2], gv[3]);
+    const float t[4] = {gv[0] * gm.x, gv[1] * gm.y, gv[2] * gm.z, gv[3] * gm.w};
+    float s1 = t[0] + t[1] + t[2] + t[3];
+    float s2 = t[0] * xh[0] + t[1] * xh[1] + t[2] * xh[2] + t[3] * xh[3];
+    s1 = wave_sum(s1) * (1.0f / RG_N);
+    s2 = wave_sum(s2) * (1.0f / RG_N);
+    float dz[4], dx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dz[e] = rstd * (t[e] - s1 - xh[e] * s2);
+    if (p.thr_in) {
+        const uint32_t rb_in = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site_in), (uint32_t)row);
+        const uint32_t h0 = ttsmi_pair_hash(rb_in, (uint32_t)(lane * 4)), h1 = ttsmi_pair_hash(rb_in, (uint32_t)(lane * 4 + 2));
+        dx[0] = dz[0] * (((h0 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f);
+        dx[1] = dz[1] * (((h0 >> 16) >= p.thr_in) ? p.inv_in : 0.f);
+        dx[2] = dz[2] * (((h1 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f);
+        dx[3] = dz[3] * (((h1 >> 16) >= p.thr_in) ? p.inv_in : 0.f);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dx[e] = dz[e];
+    }
+    *reinterpret_cast<float4*>(p.dres + base) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    *reinterpret_cast<uint2*>(p.dx_bf + base) = rg_pack4(dx[0], dx[1], dx[2], dx[3]);
+}
+
+// ---- LayerNorm parameter gradients from the bf16 pair (g, x^): dgamma[c] = sum_m g x^, dbeta[c] = sum_m g.
+// Off the critical path (nothing reads them before the optimiser), so it runs on the weight-gradient stream.
+// Stage 1: workgroup b sums rows [b*RPB, ...) into part[b][2][256]; stage 2 = ttsmi_layernorm_param_reduce_batched
+// (the partial layout is the one ln_bwd_kernel writes: [nw][C] gamma rows, [nw][C] beta rows, [nw] scale).
+#define LNP_ROWS 128
+__global__ __launch_bounds__(256) void ln_param_part_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ xh,
+                                                            float* __restrict__ part, int M, int nw) {
+    // thread = 4 columns (lane & 63) x 4 row phases (wave); each walks its rows with 8-byte loads
+    const int c4 = (threadIdx.x & 63) * 4, ph = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * LNP_ROWS, r1 = min(M, r0 + LNP_ROWS);
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + ph; r < r1; r += 4) {
+        float gv[4], xv[4];
+        rg_unpack4(*reinterpret_cast<const uint2*>(g + (long)r * RG_N + c4), gv);
+        rg_unpack4(*reinterpret_cast<const uint2*>(xh + (long)r * RG_N + c4), xv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ab[e] += gv[e]; ag[e] += gv[e] * xv[e]; }
+    }
+    __shared__ float red[3][2][RG_N];
+    if (ph > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[ph - 1][0][c4 + e] = ag[e]; red[ph - 1][1][c4 + e] = ab[e]; }
+    }
+    __syncthreads();
+    if (ph == 0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ag[e] += red[u][0][c4 + e]; ab[e] += red[u][1][c4 + e]; }
+        *reinterpret_cast<float4*>(part + (long)blockIdx.x * RG_N + c4) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+        *reinterpret_cast<float4*>(part + ((long)nw + blockIdx.x) * RG_N + c4) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+        if (threadIdx.x == 0) part[2L * nw * RG_N + blockIdx.x] = 0.f;
+    }
+}
+
+static bool rg_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static int rg_common(RowGemmP& p, const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
+                     int64_t ldb, int M, int N, int K, const char* who) {
+    TTSMI_CHECK_ARG(a && bt && M > 0, "%s: null pointer / empty", who);
+    TTSMI_CHECK_ARG(N == RG_N, "%s: built for N = %d output columns (got %d)", who, RG_N, N);
+    TTSMI_CHECK_ARG(K > 0 && K % RG_BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && rg_al16(a) && rg_al16(bt),
+                    "%s: K %% 64 == 0, leading dimensions %% 8 == 0 and 16-byte aligned operands required", who);
+    if (a2) TTSMI_CHECK_ARG(K1 > 0 && K1 < K && K1 % RG_BK == 0 && lda2 % 8 == 0 && rg_al16(a2), "%s: bad second K segment", who);
+    memset(&p, 0, sizeof(p));
+    p.A = a; p.lda = lda; p.A2 = a2; p.lda2 = lda2; p.K1 = K1; p.Bt = bt; p.ldb = ldb; p.M = M; p.K = K;
+    return TTSMI_OK;
+}
+
+// TTSMI_ROWGEMM_DMA: 0 = always the 64-row register-staged kernel, 1 = always the 128-row LDS-DMA kernel,
+// default = by size.  Measured (tools/kbench.py --only rowgemm): the LDS-DMA kernel wins at M = 28 800 (32.7 / 45.2 /
+// 44.3 us for o+LN1, FFN2+LN2, dgrad+LN1' against 34.6 / 56.9 / 54.8) and still at M = 6 400, where it fills only 50 CUs
+// (26.5 / 33.4 / 30.7 against 27.9 / 37.2 / 34.1): the 64-row kernel is kept for small batches.
+static bool rg_use_dma(int M) {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("TTSMI_ROWGEMM_DMA"); mode = e ? atoi(e) : 2; }
+    if (mode == 0) return false;
+    if (mode == 1) return true;
+    return M >= 16 * RD_BM;
+}
+
+static void rg_drop(RowGemmP& p, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev) {
+    p.thr_in = p_in > 0.f ? ttsmi_drop_threshold(p_in) : 0;
+    p.inv_in = p_in > 0.f ? 1.0f / (1.0f - p_in) : 1.f;
+    p.seed = seed; p.step_dev = step_dev; p.site_in = site_in;
+}
+
+extern "C" {
+
+int ttsmi_hgemm_ln_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
+                       int64_t ldb, const float* bias, const float* res, const float* gamma, const float* beta,
+                       const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
+                       float eps, float* y, uint16_t* y_bf16, uint16_t* xhat_bf16, float* rstd, int M, int N, int K,
+                       ttsmi_stream_t stream) {
+    RowGemmP p;
+    int rc = rg_common(p, a, lda, a2, lda2, K1, bt, ldb, M, N, K, "hgemm_ln_fwd");
+    if (rc) return rc;
+    TTSMI_CHECK_ARG(res && gamma && beta && y && y_bf16 && xhat_bf16 && rstd, "hgemm_ln_fwd: null pointer");
+    TTSMI_CHECK_ARG(p_in >= 0.f && p_in < 1.f, "hgemm_ln_fwd: dropout rate out of [0,1)");
+    p.bias = bias; p.res = res; p.gamma = gamma; p.beta = beta; p.row_pad = row_pad; p.eps = eps;
+    p.y = y; p.y_bf = y_bf16; p.xhat = xhat_bf16; p.rstd = rstd;
+    rg_drop(p, p_in, site_in, seed, step_dev);
+    if (rg_use_dma(M)) hipLaunchKernelGGL((rowgemm_dma_kernel<0>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((rowgemm_kernel<0>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p);
+    TTSMI_CHECK_LAUNCH("hgemm_ln_fwd");
+    return TTSMI_OK;
+}
+
+int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64_t ldb, const float* dy_part,
+                       const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
+                       uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres,
+                       uint16_t* g_bf16, int M, int N, int K, ttsmi_stream_t stream) {
+    RowGemmP p;
+    int rc = rg_common(p, a, lda, nullptr, 0, 0, bt, ldb, M, N, K, "hgemm_ln_bwd");
+    if (rc) return rc;
+    TTSMI_CHECK_ARG(dy_part && xhat_bf16 && rstd && gamma && dx_bf16 && dres && g_bf16, "hgemm_ln_bwd: null pointer");
+    p.res = dy_part; p.xhat_in = xhat_bf16; p.rstd_in = rstd; p.gamma = gamma; p.row_pad = row_pad;
+    p.dx_bf = dx_bf16; p.dres = dres; p.g_bf = g_bf16;
+    rg_drop(p, p_in, site_in, seed, step_dev);
+    if (rg_use_dma(M)) hipLaunchKernelGGL((rowgemm_dma_kernel<1>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((rowgemm_kernel<1>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p);
+    TTSMI_CHECK_LAUNCH("hgemm_ln_bwd");
+    return TTSMI_OK;
+}
+
+int ttsmi_layernorm_bwd_xhat(const float* dy, const uint16_t* xhat_bf16, const float* rstd, const float* gamma,
+                             const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
+                             uint16_t* dx_bf16, float* dres, uint16_t* g_bf16, int M, int C, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(dy && xhat_bf16 && rstd && gamma && dx_bf16 && dres && g_bf16 && M > 0, "layernorm_bwd_xhat: null pointer");
+    TTSMI_CHECK_ARG(C == RG_N, "layernorm_bwd_xhat: built for C = %d (got %d)", RG_N, C);
+    RowGemmP p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.xhat_in = xhat_bf16; p.rstd_in = rstd; p.gamma = gamma; p.row_pad = row_pad;
+    p.dx_bf = dx_bf16; p.dres = dres; p.g_bf = g_bf16;
+    rg_drop(p, p_in, site_in, seed, step_dev);
+    hipLaunchKernelGGL(ln_bwd_xhat_kernel, dim3(ttsmi_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, p, dy);
+    TTSMI_CHECK_LAUNCH("layernorm_bwd_xhat");
+    return TTSMI_OK;
+}
+
+int ttsmi_layernorm_param_partials_nw(int M) { return ttsmi_cdiv(M, LNP_ROWS); }
+size_t ttsmi_layernorm_param_partials_bytes(int M, int C) {
+    const size_t nw = (size_t)ttsmi_cdiv(M, LNP_ROWS);
+    return (2 * nw * (size_t)C + nw) * sizeof(float) + 256;
+}
+int ttsmi_layernorm_param_partials(const uint16_t* g_bf16, const uint16_t* xhat_bf16, void* ws, size_t ws_bytes, int M, int C,
+                                   ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(g_bf16 && xhat_bf16 && ws && M > 0, "layernorm_param_partials: null pointer");
+    TTSMI_CHECK_ARG(C == RG_N, "layernorm_param_partials: built for C = %d (got %d)", RG_N, C);
+    TTSMI_CHECK_ARG(ws_bytes >= ttsmi_layernorm_param_partials_bytes(M, C), "layernorm_param_partials: workspace too small");
+    const int nw = ttsmi_cdiv(M, LNP_ROWS);
+    hipLaunchKernelGGL(ln_param_part_kernel, dim3(nw), dim3(256), 0, (hipStream_t)stream, g_bf16, xhat_bf16, (float*)ws, M, nw);
+    TTSMI_CHECK_LAUNCH("layernorm_param_partials");
+    return TTSMI_OK;
+}
+
+}  // extern "C"

@@ -204,6 +204,11 @@ class ForwardTransformer:
         self.overlap_predictors = bool(kwargs.get('overlap_predictors', True))   # StatPredictors on a side stream
         self._pred_stream, self._pred_pending, self._pred_keep = None, False, None
         self._dropmask_plan, self._dropmask_bufs = {}, {}
+        # blocks driven from C++ with persistent buffers (ops.DenseBlockPlan); only inside _forward_backward, where one
+        # forward is followed by its backward before the next forward reuses the buffers
+        self.planned_blocks = bool(kwargs.get('planned_blocks', True))
+        self.fuse_ln = bool(kwargs.get('fuse_ln', True))               # res-norms in the GEMM epilogues (d_model 256)
+        self._use_plans, self._plans, self._plan_shared = False, {}, {}
         self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
@@ -213,6 +218,7 @@ class ForwardTransformer:
         # (models.py:544-549) instead of leaving the dicts empty - see the module docstring
         self.reference_outputs = bool(kwargs.get('reference_outputs', False))
         self.debug = debug
+        self._phase_events = None            # measurement instrumentation (_mark)
         self._taps = None                    # test instrumentation: a list receives (f'{prefix}.blk{i}', block output)
         self._init_weights(int(kwargs.get('seed', 0)))
         self._build_shadows()
@@ -346,6 +352,27 @@ class ForwardTransformer:
         for i, H in enumerate(heads):
             p = f'{prefix}.blk{i}'
             dense = i < dense_blocks
+            if dense and self.fused_blocks and self._use_plans and self._plan_ok(p, H, d):
+                # launch sequence of the block issued from C++ (ops.DenseBlockPlan): two host calls per block and step
+                plan = self._block_plan(p, prefix, B, H, T)
+                sites = (drop.site(), drop.site(), drop.site())
+                dmask = None
+                pre = self._dropmask_plan.get(p) if self._dropmask_plan else None
+                if pre is not None:
+                    dmask, site_planned, ev = pre
+                    assert site_planned == sites[0], (p, site_planned, sites)
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+                if h_bf is None:
+                    h_bf = ops.to_bf16(h)
+                plan.bind(pad, klen, rate, drop, sites, dmask)
+                h, h_bf = ops.PlannedDenseBlockFn.apply(h, h_bf, plan)
+                if want_attn:
+                    attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
+                        plan.t['qkv'].float(), pad, plan.t['lse'], B, H, T, d // H, rate, drop, sites[0])
+                if self._taps is not None:
+                    self._taps.append((p, h.detach().reshape(B, T, d)))
+                continue
             if dense and self.fused_blocks:
                 # one autograd node per block (ops.DenseBlockFn); sites in the per-layer order
                 Pb, Gb, Sb = self._block_views(p)
@@ -400,6 +427,32 @@ class ForwardTransformer:
                 self._taps.append((p, h.detach().reshape(B, T, d)))
         return h.reshape(B, T, d), attn
 
+    def _plan_ok(self, p, H, d) -> bool:
+        return (self.precision == 'bf16' and (d // H) in (32, 64) and d % 64 == 0
+                and all(f'{p}.{k}' in self.shadow for k in ('wqkv', 'wo', 'ffn.w1', 'ffn.w2')))
+
+    def _block_plan(self, p, prefix, B, H, T):
+        """ops.DenseBlockPlan of block `p` at this batch shape (built on first use; at most 3 shapes are kept)."""
+        key = (p, B, T)
+        plan = self._plans.get(key)
+        if plan is None:
+            shapes = []
+            for (_, b, t) in self._plans:
+                if (b, t) not in shapes:
+                    shapes.append((b, t))
+            if (B, T) not in shapes and len(shapes) >= 6:          # 3 batch shapes x (encoder T, decoder T)
+                torch.cuda.synchronize()                           # nothing in flight reads the evicted buffers
+                old = shapes[0]
+                for k in [k for k in self._plans if (k[1], k[2]) == old]:
+                    del self._plans[k]
+                for sh in self._plan_shared.values():
+                    for k in [k for k in sh if (k[0], k[2]) == old]:
+                        del sh[k]
+            Pb, Gb, Sb = self._block_views(p)
+            plan = self._plans[key] = ops.DenseBlockPlan(Pb, Gb, Sb, B, H, T, self.device,
+                                                         self._plan_shared.setdefault(prefix, {}), self.fuse_ln)
+        return plan
+
     _BLOCK_KEYS = ('wqkv', 'bqkv', 'wo', 'bo', 'ln1.gamma', 'ln1.beta', 'ffn.w1', 'ffn.b1', 'ffn.w2', 'ffn.b2',
                    'ln2.gamma', 'ln2.beta')
 
@@ -444,9 +497,11 @@ class ForwardTransformer:
         B, Tp = x.shape
         pad_e, klen_e = ops.token_pad_mask(x)                                        # :521
         h = ops.EmbeddingFn.apply(x, W['embedding'], G['embedding'])                 # :522
+        self._mark('start')
         h, enc_attn = self._self_attention_blocks('enc', 'Encoder', h, pad_e, klen_e,
                                                   c['encoder_num_heads'], c['encoder_dense_blocks'],
                                                   self.pe_enc, rate, want_attn)      # :523
+        self._mark('enc_fwd')
         # With teacher forcing (training / validation: target durations AND target pitch given) nothing downstream of
         # the two StatPredictors feeds the decoder - their outputs only meet the losses.  They are ~60 small launches
         # (M = B*Tp rows) that cannot fill the GPU, so they go to a second HIP stream and run underneath the decoder;
@@ -498,6 +553,7 @@ class ForwardTransformer:
         mels, dec_attn = self._self_attention_blocks('dec', 'Decoder', mels, pad_d, klen_d,
                                                      c['decoder_num_heads'], c['decoder_dense_blocks'],
                                                      self.pe_dec, rate, want_attn)   # :542
+        self._mark('dec_fwd')
         out = ops.LinearFn.apply(mels.reshape(B * mel_len, -1), None, W['out.w'], W['out.b'], G['out.w'],
                                  G['out.b'], self.shadow.get('out.w')).reshape(B, mel_len, self.mel_channels)  # :543
         return {'mel': out, 'duration': durations, 'pitch': pitch, 'expanded_mask': expanded_mask,
@@ -552,6 +608,13 @@ class ForwardTransformer:
                 if ev is not None:
                     ev.record(side)
 
+    def _mark(self, name):
+        """Measurement hook (tools/probe_phases.py): a timing event on the main stream at a phase boundary."""
+        if self._phase_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._phase_events.append((name, ev))
+
     def _join_predictors(self):
         """Main stream waits for the predictor side stream (no-op when nothing is in flight there)."""
         if self._pred_pending:
@@ -594,20 +657,24 @@ class ForwardTransformer:
         ra = self.reference_outputs if self.return_attention is None else self.return_attention
         with ops.pinned_stream():
             self._launch_dropmasks(int(x.shape[0]), int(x.shape[1]), mel_len, float(self.config['dropout_rate']))
+            self._use_plans = self.planned_blocks
             try:
                 model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra,
                                       _overlap_predictors=True)
             finally:
                 self._dropmask_plan = {}
+                self._use_plans = False
             self._join_predictors()              # the duration / pitch losses read the side stream's outputs
             loss, loss_vals = self._losses(model_out, ts, td, tp)
             ops.enable_wgrad_stream(self.overlap_wgrad)
             try:
                 with ops.ln_param_batch():
                     loss.backward()                                                  # :480
-                    self._join_predictors()      # their backward ran on the side stream: join before the final
-                    self._pred_pending = False   # LayerNorm parameter reduce, the all-reduce and Adam
-                ops.wgrad_join()
+                    self._mark('bwd')
+                    ops.ln_flush()               # LayerNorm parameter gradients: one reduce per producing stream, then
+                    self._join_predictors()      # the main stream waits for the predictor stream ...
+                    self._pred_pending = False
+                ops.wgrad_join()                 # ... and for the weight-gradient stream, before all-reduce and Adam
             finally:
                 ops.enable_wgrad_stream(False)
                 self._pred_pending = False
@@ -680,6 +747,7 @@ class ForwardTransformer:
         ops.adam_tf(P.data, P.grad, P.m, P.v, self.lr_dev, self.step_dev, self.beta_1, self.beta_2,
                     self.epsilon, shadow=None if ss is None else ss.flat_bf16)
         self._refresh_shadows(wb_is_current=True)
+        self._mark('adam')
 
     def _compile(self, optimizer=None, learning_rate: Optional[float] = None):
         """reference _compile models.py:484-490.  `optimizer` may be any object with

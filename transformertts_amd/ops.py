@@ -68,34 +68,39 @@ class ln_param_batch:
         return False
 
 
-def _ln_defer(ws, dgamma, dbeta, dps, M, C) -> None:
-    _LN_PENDING.append((ws, dgamma, dbeta, dps, int(M), int(C), _stream()))
+def _ln_defer(ws, dgamma, dbeta, dps, M, C, nparts=None, stream=None) -> None:
+    """nparts: partial rows in `ws` (default: what ttsmi_add_layernorm_bwd leaves for M rows); stream: the raw stream
+    the partial sums are produced on (default: the current launch stream)."""
+    if nparts is None:
+        nparts = _lib.lib().ttsmi_add_layernorm_bwd_nparts(int(M))
+    _LN_PENDING.append((ws, dgamma, dbeta, dps, int(nparts), int(C), _stream() if stream is None else stream))
 
 
 def ln_flush(only_this_stream: bool = False) -> None:
-    """Reduce every pending LayerNorm parameter gradient (no-op when nothing is pending) on the current launch
-    stream.  only_this_stream: leave entries whose partial sums were produced on ANOTHER stream (the predictors'
-    side stream) pending - the caller has not joined that stream yet."""
+    """Reduce every pending LayerNorm parameter gradient (no-op when nothing is pending): ONE launch per stream that
+    produced partial sums, issued on THAT stream (program order behind its partials - the caller joins the streams as
+    it does for the weight gradients).  only_this_stream: only the entries of the current launch stream."""
     if not _LN_PENDING:
         return
-    if only_this_stream:
-        cur = _stream()
-        pend = [e for e in _LN_PENDING if e[6] == cur]
-        rest = [e for e in _LN_PENDING if e[6] != cur]
-    else:
-        pend, rest = list(_LN_PENDING), []
-    if not pend:
-        return
-    n = len(pend)
-    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
-    ws = PA(*[e[0].data_ptr() for e in pend])
-    dg = PA(*[e[1].data_ptr() for e in pend])
-    db = PA(*[e[2].data_ptr() for e in pend])
-    ds = PA(*[(e[3].data_ptr() if e[3] is not None else None) for e in pend])
-    Ms, Cs = IA(*[e[4] for e in pend]), IA(*[e[5] for e in pend])
-    check(_lib.lib().ttsmi_layernorm_param_reduce_batched(ctypes.addressof(ws), ctypes.addressof(dg), ctypes.addressof(db),
-                                                          ctypes.addressof(ds), ctypes.addressof(Ms), ctypes.addressof(Cs),
-                                                          n, _stream()), 'layernorm_param_reduce_batched')
+    cur = _stream()
+    groups, rest = {}, []
+    for e in _LN_PENDING:
+        if only_this_stream and e[6] != cur:
+            rest.append(e)
+        else:
+            groups.setdefault(e[6], []).append(e)
+    for handle, pend in groups.items():
+        n = len(pend)
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        ws = PA(*[e[0].data_ptr() for e in pend])
+        dg = PA(*[e[1].data_ptr() for e in pend])
+        db = PA(*[e[2].data_ptr() for e in pend])
+        ds = PA(*[(e[3].data_ptr() if e[3] is not None else None) for e in pend])
+        nw, Cs = IA(*[e[4] for e in pend]), IA(*[e[5] for e in pend])
+        check(_lib.lib().ttsmi_layernorm_param_reduce_batched_nw(ctypes.addressof(ws), ctypes.addressof(dg),
+                                                                 ctypes.addressof(db), ctypes.addressof(ds),
+                                                                 ctypes.addressof(nw), ctypes.addressof(Cs), n, handle),
+              'layernorm_param_reduce_batched')
     _LN_PENDING[:] = rest             # the reduced workspaces go back to the allocator, in stream order
 
 
@@ -1015,7 +1020,9 @@ class LenRegFn(torch.autograd.Function):
         cum, = ctx.saved_tensors
         B, Tp, cap, C = ctx.shape
         if ctx.hook is not None:
-            ln_flush(only_this_stream=True)   # the decoder's LayerNorm gradients must be final before their all-reduce
+            ln_flush()                      # the decoder's LayerNorm gradients must be final before their all-reduce
+                                            # (each reduce runs on the stream that produced its partial sums; the hook's
+                                            # all-reduce is ordered behind the main AND the weight-gradient stream)
             ctx.hook()
         dy = _c(dy)
         dx = torch.empty((B, Tp, C), dtype=torch.float32, device=dy.device)
@@ -1298,3 +1305,147 @@ class DenseBlockFn(torch.autograd.Function):
         dense_wgrad(h, dqkv, G['wqkv'], G['bqkv'], shq)
         dense_dgrad(dqkv, P['wqkv'], shq, 0, d, out=dh, accumulate=True)                    # dh += dqkv.Wqkv^T
         return (dh,) + (None,) * 15
+
+
+# =================================================================================================
+# The same block with its launch sequence issued from C++ (ttsmi_dense_block_fwd / _bwd, include/ttsmi.h)
+# =================================================================================================
+class DenseBlockPlan:
+    """Persistent buffers + the filled `ttsmi_dense_block` descriptor of ONE dense block at ONE batch shape.
+
+    The per-launch Python path (DenseBlockFn) spends ~14 us of host time per kernel launch (allocator, ctypes
+    argument conversion, autograd bookkeeping); at ~400 launches a step that is 6 ms of enqueueing for 5 ms of GPU
+    work.  A plan owns every activation / temporary of its block, so the descriptor is filled once and a training
+    step costs two ctypes calls per block (forward, backward) whose launches are issued from C++.
+    `shared` holds the buffers that blocks of one stack may share (nothing outside the main stream reads them)."""
+
+    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True):
+        l = _lib.lib()
+        d = P['wqkv'].shape[0]
+        F = P['ffn.w1'].shape[1]
+        M = B * T
+        bf, f32 = torch.bfloat16, torch.float32
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
+        self.B, self.H, self.T, self.d, self.F, self.M = B, H, T, d, F, M
+        self.t = t = {}
+        for name, shape, dt in (('qkv', (M, 3 * d), bf), ('cx', (M, d), bf), ('a_bf', (M, d), bf), ('h1', (M, F), bf),
+                                ('out_bf', (M, d), bf), ('lse', (B, H, T), f32), ('o', (M, d), f32), ('a', (M, d), f32),
+                                ('f', (M, d), f32), ('out', (M, d), f32), ('mean1', (M,), f32), ('rstd1', (M,), f32),
+                                ('mean2', (M,), f32), ('rstd2', (M,), f32),
+                                # read by the weight-gradient stream: private to the block
+                                ('df', (M, d), bf), ('dh1', (M, F), bf), ('d_o', (M, d), bf), ('dqkv', (M, 3 * d), bf),
+                                ('dh', (M, d), f32)):
+            t[name] = e(shape, dt)
+        ln_ws = int(l.ttsmi_add_layernorm_bwd_ws_bytes(M, d))
+        t['ln_ws1'], t['ln_ws2'] = _ws(ln_ws, device), _ws(ln_ws, device)
+        # LayerNorms fused into the GEMM epilogues (ttsmi_hgemm_ln_fwd / _bwd): needs the full row in one tile
+        self.fuse_ln = bool(fuse_ln) and d == 256
+        lnp_ws = int(l.ttsmi_layernorm_param_partials_bytes(M, d))
+        self.lnp_nw = int(l.ttsmi_layernorm_param_partials_nw(M))
+        if self.fuse_ln:
+            for name in ('xhat1', 'xhat2', 'g1', 'g2'):
+                t[name] = e((M, d), bf)
+            t['lnp_ws1'], t['lnp_ws2'] = _ws(lnp_ws, device), _ws(lnp_ws, device)
+        key = (B, H, T, d)
+        if key not in shared:
+            shared[key] = {'da': e((M, d), f32), 'dctx': e((M, d), bf),
+                           'attn_ws': _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, d // H), device)}
+        sh = shared[key]
+        self.shared = sh
+        self.wgrad_need = max(int(l.ttsmi_hgemm_wgrad_rows_ws_bytes(M, kin, n))
+                              for kin, n in ((F, d), (d, F), (d, d), (d, 3 * d)))
+        self.events = [torch.cuda.Event() for _ in range(4)]
+        for ev in self.events:
+            ev.record()                                   # materialises the hipEvent_t behind the torch object
+        D = self.desc = _lib.DenseBlockDesc()
+        D.B, D.H, D.T, D.d, D.F = B, H, T, d, F
+        for k, v in (('bqkv', P['bqkv']), ('bo', P['bo']), ('ln1_g', P['ln1.gamma']), ('ln1_b', P['ln1.beta']),
+                     ('b1', P['ffn.b1']), ('b2', P['ffn.b2']), ('ln2_g', P['ln2.gamma']), ('ln2_b', P['ln2.beta']),
+                     ('wqkv_t', S['wqkv'].wt), ('wo_t', S['wo'].wt), ('w1_t', S['ffn.w1'].wt), ('w2_t', S['ffn.w2'].wt),
+                     ('wqkv_b', S['wqkv'].wb), ('wo_b', S['wo'].wb), ('w1_b', S['ffn.w1'].wb), ('w2_b', S['ffn.w2'].wb),
+                     ('g_wqkv', G['wqkv']), ('g_bqkv', G['bqkv']), ('g_wo', G['wo']), ('g_bo', G['bo']),
+                     ('g_ln1_g', G['ln1.gamma']), ('g_ln1_b', G['ln1.beta']), ('g_w1', G['ffn.w1']), ('g_b1', G['ffn.b1']),
+                     ('g_w2', G['ffn.w2']), ('g_b2', G['ffn.b2']), ('g_ln2_g', G['ln2.gamma']), ('g_ln2_b', G['ln2.beta'])):
+            assert v.is_contiguous()
+            setattr(D, k, v.data_ptr())
+        for k in ('qkv', 'cx', 'a_bf', 'h1', 'out_bf', 'lse', 'o', 'a', 'f', 'out', 'mean1', 'rstd1', 'mean2', 'rstd2',
+                  'df', 'dh1', 'd_o', 'dqkv', 'dh', 'ln_ws1', 'ln_ws2'):
+            setattr(D, k, t[k].data_ptr())
+        if self.fuse_ln:
+            D.fuse_ln, D.lnp_ws_bytes = 1, lnp_ws
+            for k in ('xhat1', 'xhat2', 'g1', 'g2', 'lnp_ws1', 'lnp_ws2'):
+                setattr(D, k, t[k].data_ptr())
+        D.da, D.dctx, D.attn_ws = sh['da'].data_ptr(), sh['dctx'].data_ptr(), sh['attn_ws'].data_ptr()
+        D.attn_ws_bytes, D.ln_ws_bytes = sh['attn_ws'].numel(), ln_ws
+        for i, ev in enumerate(self.events):
+            D.ev[i] = ev.cuda_event
+        self.G = G
+        self._dref = ctypes.byref(D)
+
+    def bind(self, pad, klen, rate, drop, sites, dmask):
+        """Per-step inputs of the descriptor (masks are new tensors every step; the rest rarely changes)."""
+        D = self.desc
+        D.pad, D.klen = pad.data_ptr(), klen.data_ptr()
+        D.rate, D.seed, D.step_dev = float(rate), drop.seed, _p(drop.step_dev)
+        D.site_attn, D.site_ln1, D.site_ln2 = sites
+        D.dropmask = _p(dmask)
+        D.main_stream = _stream()
+        self.keep = (pad, klen, dmask)                    # alive until the next bind
+
+    def fwd(self, h, h_bf):
+        check(_lib.lib().ttsmi_dense_block_fwd(self._dref, _p(h), _p(h_bf)), 'dense_block_fwd')
+
+    def bwd(self, h, h_bf, dout):
+        D = self.desc
+        if _WgradStream.enabled:
+            W = _WgradStream.cur()
+            if W.stream is None:
+                W.stream = torch.cuda.Stream()
+            if W.handle is None:
+                W.handle = W.stream.cuda_stream
+            if W.ws is None or W.ws.numel() < self.wgrad_need:
+                with torch.cuda.stream(W.stream):
+                    W.ws = torch.empty(int(max(self.wgrad_need, 1 << 26)), dtype=torch.uint8, device=h.device)
+            D.side_stream, D.wgrad_ws, D.wgrad_ws_bytes = W.handle, W.ws.data_ptr(), W.ws.numel()
+            W.pending = True
+        else:
+            ws = _ws(self.wgrad_need, h.device)
+            self.keep = self.keep + (ws,)
+            D.side_stream, D.wgrad_ws, D.wgrad_ws_bytes = None, ws.data_ptr(), ws.numel()
+        check(_lib.lib().ttsmi_dense_block_bwd(self._dref, _p(h), _p(h_bf), _p(dout)), 'dense_block_bwd')
+        t, G, M, d = self.t, self.G, self.M, self.d
+
+        def defer():
+            if self.fuse_ln:       # partial sums by ttsmi_layernorm_param_partials on the weight-gradient stream
+                side = D.side_stream if D.side_stream is not None else D.main_stream
+                side = 0 if side is None else side
+                _ln_defer(t['lnp_ws2'], G['ln2.gamma'], G['ln2.beta'], None, M, d, self.lnp_nw, side)
+                _ln_defer(t['lnp_ws1'], G['ln1.gamma'], G['ln1.beta'], None, M, d, self.lnp_nw, side)
+            else:
+                _ln_defer(t['ln_ws2'], G['ln2.gamma'], G['ln2.beta'], None, M, d)
+                _ln_defer(t['ln_ws1'], G['ln1.gamma'], G['ln1.beta'], None, M, d)
+        if _LN_PENDING is not None:
+            defer()
+        else:
+            with ln_param_batch():
+                defer()
+
+
+class PlannedDenseBlockFn(torch.autograd.Function):
+    """DenseBlockFn on a DenseBlockPlan: forward / backward are one C++ call each; the block's activations live in
+    the plan (valid until the plan's next forward - ForwardTransformer uses it inside one train step only)."""
+
+    @staticmethod
+    def forward(ctx, h, h_bf, plan):
+        plan.fwd(h, h_bf)
+        ctx.plan, ctx.h, ctx.h_bf = plan, h, h_bf
+        out, out_bf = plan.t['out'].detach(), plan.t['out_bf'].detach()       # fresh aliases of the persistent buffers
+        ctx.mark_non_differentiable(out_bf)
+        ctx.set_materialize_grads(False)
+        return out, out_bf
+
+    @staticmethod
+    def backward(ctx, dout, _dout_bf):
+        plan = ctx.plan
+        plan.bwd(ctx.h, ctx.h_bf, _c(dout))
+        return plan.t['dh'].detach(), None, None
