@@ -337,29 +337,29 @@ int ttsmi_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, ttsmi_str
  *   column K1, for concat([q_in, ctx])), bt = W^T bf16 [256,K].  Writes y fp32, y as bf16 (the next GEMM's operand),
  *   x^ as bf16 and rstd [M] for the backward (mean is not needed again).
  * ttsmi_hgemm_ln_bwd:  dy = dy_part + a . bt^T;  g = rowmask(dy);  t = g * gamma;
- *   dz = rstd * (t - mean(t) - x^ * mean(t * x^));  dx = keep_in(dz) as bf16, dres = dz fp32, g as bf16.
+ *   dz = rstd * (t - mean(t) - x^ * mean(t * x^));  dx = keep_in(dz) as bf16, dres = dz fp32.
  *   = the dgrad GEMM whose result completes the gradient of a LayerNorm output, followed by that LayerNorm's backward.
- * ttsmi_layernorm_bwd_xhat: the same backward for an upstream gradient that is already complete (dy fp32 [M,256]).
- * ttsmi_layernorm_param_partials: per-128-row partial sums of dgamma = sum g * x^, dbeta = sum g from the two bf16
- *   tensors, in the partial layout ttsmi_layernorm_param_reduce_batched_nw reduces (nparts = ..._partials_nw(M));
- *   nothing on the critical path reads them, so the caller runs it on the weight-gradient stream.
+ *   The parameter gradients dgamma = sum g * x^, dbeta = sum g leave as one partial row per workgroup in part_ws
+ *   (ttsmi_hgemm_ln_bwd_nparts(M) rows; ttsmi_layernorm_partials_bytes) for ttsmi_layernorm_param_reduce_batched_nw.
+ * ttsmi_layernorm_bwd_xhat: the same backward for an upstream gradient that is already complete (dy fp32 [M,256]);
+ *   ttsmi_layernorm_bwd_xhat_nparts(M) partial rows.
  * ------------------------------------------------------------------------------------------- */
 int ttsmi_hgemm_ln_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
                        int64_t ldb, const float* bias, const float* res, const float* gamma, const float* beta,
                        const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
                        float eps, float* y, uint16_t* y_bf16, uint16_t* xhat_bf16, float* rstd, int M, int N, int K,
                        ttsmi_stream_t stream);
+size_t ttsmi_layernorm_partials_bytes(int nparts, int C);
+int ttsmi_hgemm_ln_bwd_nparts(int M);
 int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64_t ldb, const float* dy_part,
                        const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
                        uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres,
-                       uint16_t* g_bf16, int M, int N, int K, ttsmi_stream_t stream);
+                       void* part_ws, size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream);
+int ttsmi_layernorm_bwd_xhat_nparts(int M);
 int ttsmi_layernorm_bwd_xhat(const float* dy, const uint16_t* xhat_bf16, const float* rstd, const float* gamma,
                              const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
-                             uint16_t* dx_bf16, float* dres, uint16_t* g_bf16, int M, int C, ttsmi_stream_t stream);
-int ttsmi_layernorm_param_partials_nw(int M);
-size_t ttsmi_layernorm_param_partials_bytes(int M, int C);
-int ttsmi_layernorm_param_partials(const uint16_t* g_bf16, const uint16_t* xhat_bf16, void* ws, size_t ws_bytes, int M, int C,
-                                   ttsmi_stream_t stream);
+                             uint16_t* dx_bf16, float* dres, void* part_ws, size_t part_ws_bytes, int M, int C,
+                             ttsmi_stream_t stream);
 /* number of partial rows ttsmi_add_layernorm_bwd leaves in its workspace for M rows */
 int ttsmi_add_layernorm_bwd_nparts(int M);
 /* ttsmi_layernorm_param_reduce_batched with the partial-row count of every item given explicitly */
@@ -401,9 +401,9 @@ typedef struct ttsmi_dense_block {
      * mean1, mean2, ln_ws1, ln_ws2 are then unused and these are required instead: */
     int32_t fuse_ln, _pad0;
     uint16_t *xhat1, *xhat2;                      /* [M,d] normalised pre-activations kept for the backward */
-    uint16_t *g1, *g2;                            /* [M,d] masked upstream gradients of the two LayerNorms */
-    void *lnp_ws1, *lnp_ws2;                      /* ttsmi_layernorm_param_partials_bytes each */
-    uint64_t lnp_ws_bytes;
+    void *lnp_ws1, *lnp_ws2;                      /* parameter-gradient partial rows of res-norm 1 (ttsmi_hgemm_ln_bwd) /
+                                                     res-norm 2 (ttsmi_layernorm_bwd_xhat) */
+    uint64_t lnp_ws1_bytes, lnp_ws2_bytes;
     /* backward temporaries */
     uint16_t *df /*[M,d]*/, *dh1 /*[M,F]*/, *d_o /*[M,d]*/, *dctx /*[M,d]*/, *dqkv /*[M,3d]*/;
     float *da /*[M,d]*/, *dh /*[M,d]: the block's input gradient (output of the backward) */;

@@ -709,19 +709,18 @@ def test_hgemm_with_fused_layernorm_matches_gemm_then_layernorm(M, K, dual, pdro
     dx0, dres0 = ops._ln_bwd(dy, o, res, gam, mean0, rstd0, pad, pdrop, site, drop, dg0, db0, dx_bf16=True)
     dxb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
     dres = torch.empty(M, N, device=DEV)
-    gb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    nw = int(l.ttsmi_layernorm_bwd_xhat_nparts(M))
+    ws = torch.empty(int(l.ttsmi_layernorm_partials_bytes(nw, N)), dtype=torch.uint8, device=DEV)
     check(l.ttsmi_layernorm_bwd_xhat(_p(dy), _p(xh), _p(rstd), _p(gam), _p(pad), pdrop, site, drop.seed, _p(step), _p(dxb),
-                                     _p(dres), _p(gb), M, N, _stream()))
+                                     _p(dres), _p(ws), ws.numel(), M, N, _stream()))
     torch.cuda.synchronize()
     assert rel_err(dres, dres0) < 1.5e-2 and rel_err(dxb.float(), dx0.float()) < 2e-2
-    # parameter gradients from (g, x^)
-    ws = torch.empty(int(l.ttsmi_layernorm_param_partials_bytes(M, N)), dtype=torch.uint8, device=DEV)
-    check(l.ttsmi_layernorm_param_partials(_p(gb), _p(xh), _p(ws), ws.numel(), M, N, _stream()))
+    # parameter gradients from the partial rows the kernel left
     dg, db = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
     with ops.ln_param_batch():
-        ops._ln_defer(ws, dg, db, None, M, N, int(l.ttsmi_layernorm_param_partials_nw(M)))
+        ops._ln_defer(ws, dg, db, None, M, N, nw)
     torch.cuda.synchronize()
-    assert rel_err(db, db0) < 1e-2 and rel_err(dg, dg0) < 1.5e-2
+    assert rel_err(db, db0) < 1e-4 and rel_err(dg, dg0) < 1.5e-2
     # ---- GEMM + LayerNorm backward fused: dy = dy_part + a_b . w_b^T
     Kb = 1024
     ab = g(M, Kb, seed=8, scale=0.3).to(DEV).to(torch.bfloat16)
@@ -730,9 +729,15 @@ def test_hgemm_with_fused_layernorm_matches_gemm_then_layernorm(M, K, dual, pdro
     part = g(M, N, seed=10).to(DEV)
     full = part.clone()
     ops.hgemm_tn(ab, shb.wb, out=full, accumulate=True)
-    dx1, dres1 = ops._ln_bwd(full, o, res, gam, mean0, rstd0, pad, pdrop, site, drop, dg0, db0, dx_bf16=True)
+    dg1, db1 = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    dx1, dres1 = ops._ln_bwd(full, o, res, gam, mean0, rstd0, pad, pdrop, site, drop, dg1, db1, dx_bf16=True)
+    nw = int(l.ttsmi_hgemm_ln_bwd_nparts(M))
+    ws = torch.empty(int(l.ttsmi_layernorm_partials_bytes(nw, N)), dtype=torch.uint8, device=DEV)
     check(l.ttsmi_hgemm_ln_bwd(_p(ab), ab.stride(0), _p(shb.wb), shb.wb.stride(0), _p(part), _p(xh), _p(rstd), _p(gam), _p(pad),
-                               pdrop, site, drop.seed, _p(step), _p(dxb), _p(dres), _p(gb), M, N, Kb, _stream()))
+                               pdrop, site, drop.seed, _p(step), _p(dxb), _p(dres), _p(ws), ws.numel(), M, N, Kb, _stream()))
+    dg, db = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    with ops.ln_param_batch():
+        ops._ln_defer(ws, dg, db, None, M, N, nw)
     torch.cuda.synchronize()
     assert rel_err(dres, dres1) < 1.5e-2 and rel_err(dxb.float(), dx1.float()) < 2e-2
-    assert rel_err(gb.float(), (full * live[:, None])) < 1e-2
+    assert rel_err(db, db1) < 1e-4 and rel_err(dg, dg1) < 1.5e-2

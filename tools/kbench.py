@@ -231,7 +231,8 @@ def bench_rowgemm():
         wb = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
         xh = torch.randn(M, N, device=dev).bfloat16(); rstd = torch.ones(M, device=dev)
         dxb = torch.empty(M, N, device=dev, dtype=torch.bfloat16); dres = torch.empty(M, N, device=dev)
-        gb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ws1 = torch.empty(int(l.ttsmi_layernorm_partials_bytes(l.ttsmi_hgemm_ln_bwd_nparts(M), N)), dtype=torch.uint8, device=dev)
+        ws2 = torch.empty(int(l.ttsmi_layernorm_partials_bytes(l.ttsmi_layernorm_bwd_xhat_nparts(M), N)), dtype=torch.uint8, device=dev)
         o = torch.randn(M, N, device=dev); mean = torch.zeros(M, device=dev)
         dg, db = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
         i = [0]
@@ -239,7 +240,7 @@ def bench_rowgemm():
         def fusedb():
             j = i[0] % R; i[0] += 1
             check(l.ttsmi_hgemm_ln_bwd(_p(As[j]), K, _p(wb), K, _p(part[j]), _p(xh), _p(rstd), _p(gam), _p(pad), 0.1, 5, 7,
-                                       _p(step), _p(dxb), _p(dres), _p(gb), M, N, K, _stream()))
+                                       _p(step), _p(dxb), _p(dres), _p(ws1), ws1.numel(), M, N, K, _stream()))
 
         def unfusedb():
             j = i[0] % R; i[0] += 1
@@ -249,12 +250,8 @@ def bench_rowgemm():
         def xhatb():
             j = i[0] % R; i[0] += 1
             check(l.ttsmi_layernorm_bwd_xhat(_p(part[j]), _p(xh), _p(rstd), _p(gam), _p(pad), 0.1, 5, 7, _p(step), _p(dxb),
-                                             _p(dres), _p(gb), M, N, _stream()))
-        ws = torch.empty(int(l.ttsmi_layernorm_param_partials_bytes(M, N)), dtype=torch.uint8, device=dev)
-
-        def lnp():
-            check(l.ttsmi_layernorm_param_partials(_p(gb), _p(xh), _p(ws), ws.numel(), M, N, _stream()))
-        for nm, fn in (('da+LN1 bwd fused', fusedb), ('da+LN1 bwd gemm+ln', unfusedb), ('LN bwd xhat', xhatb), ('LN param part', lnp)):
+                                             _p(dres), _p(ws2), ws2.numel(), M, N, _stream()))
+        for nm, fn in (('da+LN1 bwd fused', fusedb), ('da+LN1 bwd gemm+ln', unfusedb), ('LN bwd xhat', xhatb)):
             t = timeit(fn)
             out.append(dict(kind='rowg', name=nm, M=M, K=K, N=N, us=t, tflops=2.0 * M * N * K / t / 1e6, tbs=0.0))
     return out

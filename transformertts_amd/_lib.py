@@ -79,11 +79,11 @@ SIGNATURES = {
     'ttsmi_conv_wdgrad_layout_bf16': (I, [P, P, I, I, I, I, S]),
     'ttsmi_cast_transpose_bf16_batched': (I, [P, I, I, S]),
     'ttsmi_hgemm_ln_fwd': (I, [P, L, P, L, I, P, L, P, P, P, P, P, F, c_uint32, c_uint64, P, F, P, P, P, P, I, I, I, S]),
-    'ttsmi_hgemm_ln_bwd': (I, [P, L, P, L, P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, I, I, I, S]),
-    'ttsmi_layernorm_bwd_xhat': (I, [P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, I, I, S]),
-    'ttsmi_layernorm_param_partials_nw': (I, [I]),
-    'ttsmi_layernorm_param_partials_bytes': (c_size_t, [I, I]),
-    'ttsmi_layernorm_param_partials': (I, [P, P, P, c_size_t, I, I, S]),
+    'ttsmi_layernorm_partials_bytes': (c_size_t, [I, I]),
+    'ttsmi_hgemm_ln_bwd_nparts': (I, [I]),
+    'ttsmi_hgemm_ln_bwd': (I, [P, L, P, L, P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, c_size_t, I, I, I, S]),
+    'ttsmi_layernorm_bwd_xhat_nparts': (I, [I]),
+    'ttsmi_layernorm_bwd_xhat': (I, [P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, c_size_t, I, I, S]),
     'ttsmi_add_layernorm_bwd_nparts': (I, [I]),
     'ttsmi_layernorm_param_reduce_batched_nw': (I, [P, P, P, P, P, P, I, S]),
     'ttsmi_dense_block_fwd': (I, [P, P, P]),
@@ -102,7 +102,7 @@ def _dense_block_fields():
     return ([(n, i32) for n in ('B', 'H', 'T', 'd', 'F')] + [('rate', f)] +
             [(n, u32) for n in ('site_attn', 'site_ln1', 'site_ln2')] + [('seed', u64)] +
             [(n, p) for n in ptrs] + [('fuse_ln', i32), ('_pad0', i32)] +
-            [(n, p) for n in ('xhat1', 'xhat2', 'g1', 'g2', 'lnp_ws1', 'lnp_ws2')] + [('lnp_ws_bytes', u64)] +
+            [(n, p) for n in ('xhat1', 'xhat2', 'lnp_ws1', 'lnp_ws2')] + [('lnp_ws1_bytes', u64), ('lnp_ws2_bytes', u64)] +
             [(n, p) for n in ptrs2] + [(n, u64) for n in ('attn_ws_bytes', 'ln_ws_bytes', 'wgrad_ws_bytes')] +
             [('main_stream', p), ('side_stream', p), ('ev', p * 4)])
 

@@ -20,8 +20,8 @@ static int check_desc(const ttsmi_dense_block* D, const char* who) {
     TTSMI_CHECK_ARG(D->d % 64 == 0 && D->F % 8 == 0, "%s: needs d %% 64 == 0 and F %% 8 == 0", who);
     TTSMI_CHECK_ARG(D->pad && D->klen, "%s: null mask", who);       // (main_stream == 0 is HIP's default stream)
     if (D->fuse_ln)
-        TTSMI_CHECK_ARG(D->d == 256 && D->xhat1 && D->xhat2 && D->g1 && D->g2 && D->lnp_ws1 && D->lnp_ws2,
-                        "%s: fuse_ln needs d == 256 and the x^ / g / partial-sum buffers", who);
+        TTSMI_CHECK_ARG(D->d == 256 && D->xhat1 && D->xhat2 && D->lnp_ws1 && D->lnp_ws2,
+                        "%s: fuse_ln needs d == 256 and the x^ / partial-sum buffers", who);
     return TTSMI_OK;
 }
 
@@ -88,16 +88,6 @@ static int wgrad_side(const ttsmi_dense_block* D, int ev, bool record, const uin
     return ttsmi_hgemm_wgrad_rows(x, 1, ldx, dy, 1, lddy, dw, n, db, M, kin, n, 1, 0, 0, 0, D->wgrad_ws, D->wgrad_ws_bytes, st);
 }
 
-// LayerNorm parameter-gradient partial sums, on the weight-gradient stream right behind the weight gradient that
-// shares their operand (the hand-off event of that launch already covers them)
-static int lnp_side(const ttsmi_dense_block* D, const uint16_t* g, const uint16_t* xhat, void* ws) {
-    static int skip = -1;
-    if (skip < 0) { const char* e = getenv("TTSMI_DEBUG_SKIP_WGRAD"); skip = e ? atoi(e) : 0; }
-    if (skip) return TTSMI_OK;
-    ttsmi_stream_t st = D->side_stream ? D->side_stream : D->main_stream;
-    return ttsmi_layernorm_param_partials(g, xhat, ws, D->lnp_ws_bytes, D->B * D->T, D->d, st);
-}
-
 int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf, const float* dout) {
     TRY(check_desc(D, "dense_block_bwd"));
     TTSMI_CHECK_ARG(h && h_bf && dout, "dense_block_bwd: null input");
@@ -107,20 +97,19 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     // ---- LN2 + FFN: df (bf16) = dLN2/dx, da (fp32) = dLN2/dres
     if (D->fuse_ln)
         TRY(ttsmi_layernorm_bwd_xhat(dout, D->xhat2, D->rstd2, D->ln2_g, D->pad, D->rate, D->site_ln2, D->seed, D->step_dev,
-                                     D->df, D->da, D->g2, M, d, st));
+                                     D->df, D->da, D->lnp_ws2, D->lnp_ws2_bytes, M, d, st));
     else
         TRY(ttsmi_add_layernorm_bwd(dout, D->f, D->a, D->ln2_g, D->mean2, D->rstd2, nullptr, nullptr, 0, D->pad, D->rate,
                                     D->site_ln2, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->da, D->da, nullptr,
                                     nullptr, nullptr, M, d, D->ln_ws2, D->ln_ws_bytes, D->df, st));
     TRY(wgrad_side(D, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
-    if (D->fuse_ln) TRY(lnp_side(D, D->g2, D->xhat2, D->lnp_ws2));
     TRY(ttsmi_hgemm_tn(D->df, 0, d, nullptr, 0, 0, D->w2_b, d, nullptr, (const float*)D->h1, F, D->dh1, F, M, F, d,
                        TTSMI_GEMM_OUT_BF16 | TTSMI_GEMM_MASK_BF16, 1, 0, 0, 0, st));                  // relu' fused
     TRY(wgrad_side(D, 1, true, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
     if (D->fuse_ln) {
         // (da + dh1.W1^T) never reaches HBM: res-norm 1's backward runs in the dgrad's epilogue -> d_o (bf16), dh (fp32)
         TRY(ttsmi_hgemm_ln_bwd(D->dh1, F, D->w1_b, F, D->da, D->xhat1, D->rstd1, D->ln1_g, D->pad, D->rate, D->site_ln1,
-                               D->seed, D->step_dev, D->d_o, D->dh, D->g1, M, d, F, st));
+                               D->seed, D->step_dev, D->d_o, D->dh, D->lnp_ws1, D->lnp_ws1_bytes, M, d, F, st));
     } else {
         TRY(ttsmi_hgemm_tn(D->dh1, 0, F, nullptr, 0, 0, D->w1_b, F, nullptr, nullptr, 0, D->da, d, M, d, F,
                            TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                   // da += dh1.W1^T
@@ -131,7 +120,6 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     }
     TRY(wgrad_side(D, 2, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
     TRY(wgrad_side(D, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
-    if (D->fuse_ln) TRY(lnp_side(D, D->g1, D->xhat1, D->lnp_ws1));
     TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b, d, nullptr, nullptr, 0, D->dh, d, M, d, d,
                        TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                       // dh += do.Wo_top^T
     TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b + (long)d * d, d, nullptr, nullptr, 0, D->dctx, d, M, d, d,

@@ -42,7 +42,8 @@ struct RowGemmP {
     float* y; uint16_t* y_bf; uint16_t* xhat; float* rstd;
     // backward inputs / outputs
     const uint16_t* xhat_in; const float* rstd_in;
-    uint16_t* dx_bf; float* dres; uint16_t* g_bf;
+    uint16_t* dx_bf; float* dres;
+    float* part; int nparts;           // per-workgroup partial sums of dgamma / dbeta: [nparts][256] + [nparts][256] (+ [nparts])
 };
 
 __device__ __forceinline__ uint2 rg_pack4(float a, float b, float c, float d) {
@@ -147,8 +148,9 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4],
         }
     } else {
         // dy = acc + partial;  g = dy * rowmask;  t = g * gamma;  dz = rstd (t - mean(t) - x^ mean(t x^));
-        // d_o = keep(dz) (bf16), dres = dz (fp32), g (bf16, for the parameter-gradient kernel)
+        // d_o = keep(dz) (bf16), dres = dz (fp32); dgamma += g x^, dbeta += g summed over the tile's rows
         const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c4);
+        float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
         float4 rs[RPW];
         uint2 xs[RPW];
 #pragma unroll
@@ -169,7 +171,8 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4],
             float xh[4];
             rg_unpack4(xs[i], xh);
             const long o = (long)row * RG_N + c4;
-            *reinterpret_cast<uint2*>(p.g_bf + o) = rg_pack4(gv[0], gv[1], gv[2], gv[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ab[e] += gv[e]; ag[e] += gv[e] * xh[e]; }
             const float t[4] = {gv[0] * gm.x, gv[1] * gm.y, gv[2] * gm.z, gv[3] * gm.w};
             const float m1 = wave_sum(t[0] + t[1] + t[2] + t[3]) * invC;
             const float m2 = wave_sum(t[0] * xh[0] + t[1] * xh[1] + t[2] * xh[2] + t[3] * xh[3]) * invC;
@@ -189,6 +192,27 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4],
             }
             *reinterpret_cast<float4*>(p.dres + o) = make_float4(dz[0], dz[1], dz[2], dz[3]);
             *reinterpret_cast<uint2*>(p.dx_bf + o) = rg_pack4(dx[0], dx[1], dx[2], dx[3]);
+        }
+        // parameter-gradient partials of the tile: waves summed through LDS in wave order (deterministic), one partial
+        // row per workgroup in the layout ttsmi_layernorm_param_reduce_batched_nw reads
+        __syncthreads();                                   // every wave is done with its rows of Z
+        float* red = Z;                                    // [NW - 1][2][256]
+        if (wave > 0) {
+            *reinterpret_cast<float4*>(red + ((wave - 1) * 2 + 0) * RG_N + c4) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+            *reinterpret_cast<float4*>(red + ((wave - 1) * 2 + 1) * RG_N + c4) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int u = 0; u < NW - 1; ++u) {
+                const float4 a = *reinterpret_cast<const float4*>(red + (u * 2 + 0) * RG_N + c4);
+                const float4 b = *reinterpret_cast<const float4*>(red + (u * 2 + 1) * RG_N + c4);
+                ag[0] += a.x; ag[1] += a.y; ag[2] += a.z; ag[3] += a.w;
+                ab[0] += b.x; ab[1] += b.y; ab[2] += b.z; ab[3] += b.w;
+            }
+            const int blk = m0 / BM;
+            *reinterpret_cast<float4*>(p.part + (long)blk * RG_N + c4) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+            *reinterpret_cast<float4*>(p.part + ((long)p.nparts + blk) * RG_N + c4) = make_float4(ab[0], ab[1], ab[2], ab[3]);
         }
     }
 }
@@ -339,77 +363,65 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
 }
 
 // ---- standalone backward of a LayerNorm whose forward kept x^ (bf16) and rstd: the fused forward's counterpart for the
-// LayerNorms whose upstream gradient is not a full-row GEMM result.  One wave per row (as ln_bwd_kernel), 256 columns:
-// 4 per lane.  Also leaves g = dy * rowmask as bf16 for the parameter-gradient kernel.
-__global__ __launch_bounds__(256) void ln_bwd_xhat_kernel(RowGemmP p, const float* __restrict__ dy) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.M) return;
-    const long base = (long)row * RG_N + lane * 4;
-    const bool padded = p.row_pad != nullptr && p.row_pad[row] != 0;
-    const float rstd = p.rstd_in[row];
-    float4 g4 = *reinterpret_cast<const float4*>(dy + base);
-    float xh[4];
-    rg_unpack4(*reinterpret_cast<const uint2*>(p.xhat_in + base), xh);
-    const float4 gm = *reinterpret_cast<const float4*>(p.gamma + lane * 4);
-    float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-    if (padded) { gv[0] = 0.f; gv[1] = 0.f; gv[2] = 0.f; gv[3] = 0.f; }
-    *reinterpret_cast<uint2*>(p.g_bf + base) = rg_pack4(gv[0], gv[1], gv[2], gv[3]);
-    const float t[4] = {gv[0] * gm.x, gv[1] * gm.y, gv[2] * gm.z, gv[3] * gm.w};
-    float s1 = t[0] + t[1] + t[2] + t[3];
-    float s2 = t[0] * xh[0] + t[1] * xh[1] + t[2] * xh[2] + t[3] * xh[3];
-    s1 = wave_sum(s1) * (1.0f / RG_N);
-    s2 = wave_sum(s2) * (1.0f / RG_N);
-    float dz[4], dx[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dz[e] = rstd * (t[e] - s1 - xh[e] * s2);
-    if (p.thr_in) {
-        const uint32_t rb_in = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site_in), (uint32_t)row);
-        const uint32_t h0 = ttsmi_pair_hash(rb_in, (uint32_t)(lane * 4)), h1 = ttsmi_pair_hash(rb_in, (uint32_t)(lane * 4 + 2));
-        dx[0] = dz[0] * (((h0 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f);
-        dx[1] = dz[1] * (((h0 >> 16) >= p.thr_in) ? p.inv_in : 0.f);
-        dx[2] = dz[2] * (((h1 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f);
-        dx[3] = dz[3] * (((h1 >> 16) >= p.thr_in) ? p.inv_in : 0.f);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dx[e] = dz[e];
-    }
-    *reinterpret_cast<float4*>(p.dres + base) = make_float4(dz[0], dz[1], dz[2], dz[3]);
-    *reinterpret_cast<uint2*>(p.dx_bf + base) = rg_pack4(dx[0], dx[1], dx[2], dx[3]);
-}
+// LayerNorms whose upstream gradient is not a full-row GEMM result.  A wave walks rows (as ln_bwd_kernel), 256 columns:
+// 4 per lane; dgamma / dbeta partial sums stay in registers across its rows and leave as one partial row per workgroup.
+#define LNX_MAX_BLOCKS 1024
+static int lnx_blocks(int M) { int b = ttsmi_cdiv(M, 4); return b > LNX_MAX_BLOCKS ? LNX_MAX_BLOCKS : (b < 1 ? 1 : b); }
 
-// ---- LayerNorm parameter gradients from the bf16 pair (g, x^): dgamma[c] = sum_m g x^, dbeta[c] = sum_m g.
-// Off the critical path (nothing reads them before the optimiser), so it runs on the weight-gradient stream.
-// Stage 1: workgroup b sums rows [b*RPB, ...) into part[b][2][256]; stage 2 = ttsmi_layernorm_param_reduce_batched
-// (the partial layout is the one ln_bwd_kernel writes: [nw][C] gamma rows, [nw][C] beta rows, [nw] scale).
-#define LNP_ROWS 128
-__global__ __launch_bounds__(256) void ln_param_part_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ xh,
-                                                            float* __restrict__ part, int M, int nw) {
-    // thread = 4 columns (lane & 63) x 4 row phases (wave); each walks its rows with 8-byte loads
-    const int c4 = (threadIdx.x & 63) * 4, ph = threadIdx.x >> 6;
-    const int r0 = blockIdx.x * LNP_ROWS, r1 = min(M, r0 + LNP_ROWS);
+__global__ __launch_bounds__(256) void ln_bwd_xhat_kernel(RowGemmP p, const float* __restrict__ dy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * 4;
+    const int c4 = lane * 4;
+    const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c4);
+    const uint64_t key_in = p.thr_in ? ttsmi_drop_key(p.seed, p.step_dev, p.site_in) : 0;
     float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + ph; r < r1; r += 4) {
-        float gv[4], xv[4];
-        rg_unpack4(*reinterpret_cast<const uint2*>(g + (long)r * RG_N + c4), gv);
-        rg_unpack4(*reinterpret_cast<const uint2*>(xh + (long)r * RG_N + c4), xv);
+    for (int row = blockIdx.x * 4 + wave; row < p.M; row += nwaves) {
+        const long base = (long)row * RG_N + c4;
+        const bool padded = p.row_pad != nullptr && p.row_pad[row] != 0;
+        const float rstd = p.rstd_in[row];
+        const float4 g4 = *reinterpret_cast<const float4*>(dy + base);
+        float xh[4];
+        rg_unpack4(*reinterpret_cast<const uint2*>(p.xhat_in + base), xh);
+        float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        if (padded) { gv[0] = 0.f; gv[1] = 0.f; gv[2] = 0.f; gv[3] = 0.f; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ab[e] += gv[e]; ag[e] += gv[e] * xv[e]; }
+        for (int e = 0; e < 4; ++e) { ab[e] += gv[e]; ag[e] += gv[e] * xh[e]; }
+        const float t[4] = {gv[0] * gm.x, gv[1] * gm.y, gv[2] * gm.z, gv[3] * gm.w};
+        const float s1 = wave_sum(t[0] + t[1] + t[2] + t[3]) * (1.0f / RG_N);
+        const float s2 = wave_sum(t[0] * xh[0] + t[1] * xh[1] + t[2] * xh[2] + t[3] * xh[3]) * (1.0f / RG_N);
+        float dz[4], dx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dz[e] = rstd * (t[e] - s1 - xh[e] * s2);
+        if (p.thr_in) {
+            const uint32_t rb_in = ttsmi_row_base(key_in, (uint32_t)row);
+            const uint32_t h0 = ttsmi_pair_hash(rb_in, (uint32_t)c4), h1 = ttsmi_pair_hash(rb_in, (uint32_t)(c4 + 2));
+            dx[0] = dz[0] * (((h0 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f);
+            dx[1] = dz[1] * (((h0 >> 16) >= p.thr_in) ? p.inv_in : 0.f);
+            dx[2] = dz[2] * (((h1 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f);
+            dx[3] = dz[3] * (((h1 >> 16) >= p.thr_in) ? p.inv_in : 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dx[e] = dz[e];
+        }
+        *reinterpret_cast<float4*>(p.dres + base) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        *reinterpret_cast<uint2*>(p.dx_bf + base) = rg_pack4(dx[0], dx[1], dx[2], dx[3]);
     }
     __shared__ float red[3][2][RG_N];
-    if (ph > 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { red[ph - 1][0][c4 + e] = ag[e]; red[ph - 1][1][c4 + e] = ab[e]; }
+    if (wave > 0) {
+        *reinterpret_cast<float4*>(&red[wave - 1][0][c4]) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+        *reinterpret_cast<float4*>(&red[wave - 1][1][c4]) = make_float4(ab[0], ab[1], ab[2], ab[3]);
     }
     __syncthreads();
-    if (ph == 0) {
+    if (wave == 0) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { ag[e] += red[u][0][c4 + e]; ab[e] += red[u][1][c4 + e]; }
-        *reinterpret_cast<float4*>(part + (long)blockIdx.x * RG_N + c4) = make_float4(ag[0], ag[1], ag[2], ag[3]);
-        *reinterpret_cast<float4*>(part + ((long)nw + blockIdx.x) * RG_N + c4) = make_float4(ab[0], ab[1], ab[2], ab[3]);
-        if (threadIdx.x == 0) part[2L * nw * RG_N + blockIdx.x] = 0.f;
+        for (int u = 0; u < 3; ++u) {
+            const float4 a = *reinterpret_cast<const float4*>(&red[u][0][c4]);
+            const float4 b = *reinterpret_cast<const float4*>(&red[u][1][c4]);
+            ag[0] += a.x; ag[1] += a.y; ag[2] += a.z; ag[3] += a.w;
+            ab[0] += b.x; ab[1] += b.y; ab[2] += b.z; ab[3] += b.w;
+        }
+        *reinterpret_cast<float4*>(p.part + (long)blockIdx.x * RG_N + c4) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+        *reinterpret_cast<float4*>(p.part + ((long)p.nparts + blockIdx.x) * RG_N + c4) = make_float4(ab[0], ab[1], ab[2], ab[3]);
     }
 }
 
@@ -466,16 +478,22 @@ int ttsmi_hgemm_ln_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64
     return TTSMI_OK;
 }
 
+size_t ttsmi_layernorm_partials_bytes(int nparts, int C) { return (2 * (size_t)nparts * C + nparts) * sizeof(float) + 256; }
+
+int ttsmi_hgemm_ln_bwd_nparts(int M) { return rg_use_dma(M) ? ttsmi_cdiv(M, RD_BM) : ttsmi_cdiv(M, RG_BM); }
+
 int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64_t ldb, const float* dy_part,
                        const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
                        uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres,
-                       uint16_t* g_bf16, int M, int N, int K, ttsmi_stream_t stream) {
+                       void* part_ws, size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream) {
     RowGemmP p;
     int rc = rg_common(p, a, lda, nullptr, 0, 0, bt, ldb, M, N, K, "hgemm_ln_bwd");
     if (rc) return rc;
-    TTSMI_CHECK_ARG(dy_part && xhat_bf16 && rstd && gamma && dx_bf16 && dres && g_bf16, "hgemm_ln_bwd: null pointer");
+    TTSMI_CHECK_ARG(dy_part && xhat_bf16 && rstd && gamma && dx_bf16 && dres && part_ws, "hgemm_ln_bwd: null pointer");
+    p.nparts = ttsmi_hgemm_ln_bwd_nparts(M);
+    TTSMI_CHECK_ARG(part_ws_bytes >= ttsmi_layernorm_partials_bytes(p.nparts, N), "hgemm_ln_bwd: partial-sum workspace too small");
     p.res = dy_part; p.xhat_in = xhat_bf16; p.rstd_in = rstd; p.gamma = gamma; p.row_pad = row_pad;
-    p.dx_bf = dx_bf16; p.dres = dres; p.g_bf = g_bf16;
+    p.dx_bf = dx_bf16; p.dres = dres; p.part = (float*)part_ws;
     rg_drop(p, p_in, site_in, seed, step_dev);
     if (rg_use_dma(M)) hipLaunchKernelGGL((rowgemm_dma_kernel<1>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((rowgemm_kernel<1>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p);
@@ -483,34 +501,23 @@ int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64
     return TTSMI_OK;
 }
 
+int ttsmi_layernorm_bwd_xhat_nparts(int M) { return lnx_blocks(M); }
+
 int ttsmi_layernorm_bwd_xhat(const float* dy, const uint16_t* xhat_bf16, const float* rstd, const float* gamma,
                              const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
-                             uint16_t* dx_bf16, float* dres, uint16_t* g_bf16, int M, int C, ttsmi_stream_t stream) {
-    TTSMI_CHECK_ARG(dy && xhat_bf16 && rstd && gamma && dx_bf16 && dres && g_bf16 && M > 0, "layernorm_bwd_xhat: null pointer");
+                             uint16_t* dx_bf16, float* dres, void* part_ws, size_t part_ws_bytes, int M, int C,
+                             ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(dy && xhat_bf16 && rstd && gamma && dx_bf16 && dres && part_ws && M > 0, "layernorm_bwd_xhat: null pointer");
     TTSMI_CHECK_ARG(C == RG_N, "layernorm_bwd_xhat: built for C = %d (got %d)", RG_N, C);
     RowGemmP p;
     memset(&p, 0, sizeof(p));
+    p.nparts = lnx_blocks(M);
+    TTSMI_CHECK_ARG(part_ws_bytes >= ttsmi_layernorm_partials_bytes(p.nparts, C), "layernorm_bwd_xhat: partial-sum workspace too small");
     p.M = M; p.xhat_in = xhat_bf16; p.rstd_in = rstd; p.gamma = gamma; p.row_pad = row_pad;
-    p.dx_bf = dx_bf16; p.dres = dres; p.g_bf = g_bf16;
+    p.dx_bf = dx_bf16; p.dres = dres; p.part = (float*)part_ws;
     rg_drop(p, p_in, site_in, seed, step_dev);
-    hipLaunchKernelGGL(ln_bwd_xhat_kernel, dim3(ttsmi_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, p, dy);
+    hipLaunchKernelGGL(ln_bwd_xhat_kernel, dim3(p.nparts), dim3(256), 0, (hipStream_t)stream, p, dy);
     TTSMI_CHECK_LAUNCH("layernorm_bwd_xhat");
-    return TTSMI_OK;
-}
-
-int ttsmi_layernorm_param_partials_nw(int M) { return ttsmi_cdiv(M, LNP_ROWS); }
-size_t ttsmi_layernorm_param_partials_bytes(int M, int C) {
-    const size_t nw = (size_t)ttsmi_cdiv(M, LNP_ROWS);
-    return (2 * nw * (size_t)C + nw) * sizeof(float) + 256;
-}
-int ttsmi_layernorm_param_partials(const uint16_t* g_bf16, const uint16_t* xhat_bf16, void* ws, size_t ws_bytes, int M, int C,
-                                   ttsmi_stream_t stream) {
-    TTSMI_CHECK_ARG(g_bf16 && xhat_bf16 && ws && M > 0, "layernorm_param_partials: null pointer");
-    TTSMI_CHECK_ARG(C == RG_N, "layernorm_param_partials: built for C = %d (got %d)", RG_N, C);
-    TTSMI_CHECK_ARG(ws_bytes >= ttsmi_layernorm_param_partials_bytes(M, C), "layernorm_param_partials: workspace too small");
-    const int nw = ttsmi_cdiv(M, LNP_ROWS);
-    hipLaunchKernelGGL(ln_param_part_kernel, dim3(nw), dim3(256), 0, (hipStream_t)stream, g_bf16, xhat_bf16, (float*)ws, M, nw);
-    TTSMI_CHECK_LAUNCH("layernorm_param_partials");
     return TTSMI_OK;
 }
 

@@ -1340,12 +1340,12 @@ class DenseBlockPlan:
         t['ln_ws1'], t['ln_ws2'] = _ws(ln_ws, device), _ws(ln_ws, device)
         # LayerNorms fused into the GEMM epilogues (ttsmi_hgemm_ln_fwd / _bwd): needs the full row in one tile
         self.fuse_ln = bool(fuse_ln) and d == 256
-        lnp_ws = int(l.ttsmi_layernorm_param_partials_bytes(M, d))
-        self.lnp_nw = int(l.ttsmi_layernorm_param_partials_nw(M))
+        self.lnp_nw1, self.lnp_nw2 = int(l.ttsmi_hgemm_ln_bwd_nparts(M)), int(l.ttsmi_layernorm_bwd_xhat_nparts(M))
         if self.fuse_ln:
-            for name in ('xhat1', 'xhat2', 'g1', 'g2'):
+            for name in ('xhat1', 'xhat2'):
                 t[name] = e((M, d), bf)
-            t['lnp_ws1'], t['lnp_ws2'] = _ws(lnp_ws, device), _ws(lnp_ws, device)
+            t['lnp_ws1'] = _ws(l.ttsmi_layernorm_partials_bytes(self.lnp_nw1, d), device)
+            t['lnp_ws2'] = _ws(l.ttsmi_layernorm_partials_bytes(self.lnp_nw2, d), device)
         key = (B, H, T, d)
         if key not in shared:
             shared[key] = {'da': e((M, d), f32), 'dctx': e((M, d), bf),
@@ -1372,8 +1372,8 @@ class DenseBlockPlan:
                   'df', 'dh1', 'd_o', 'dqkv', 'dh', 'ln_ws1', 'ln_ws2'):
             setattr(D, k, t[k].data_ptr())
         if self.fuse_ln:
-            D.fuse_ln, D.lnp_ws_bytes = 1, lnp_ws
-            for k in ('xhat1', 'xhat2', 'g1', 'g2', 'lnp_ws1', 'lnp_ws2'):
+            D.fuse_ln, D.lnp_ws1_bytes, D.lnp_ws2_bytes = 1, t['lnp_ws1'].numel(), t['lnp_ws2'].numel()
+            for k in ('xhat1', 'xhat2', 'lnp_ws1', 'lnp_ws2'):
                 setattr(D, k, t[k].data_ptr())
         D.da, D.dctx, D.attn_ws = sh['da'].data_ptr(), sh['dctx'].data_ptr(), sh['attn_ws'].data_ptr()
         D.attn_ws_bytes, D.ln_ws_bytes = sh['attn_ws'].numel(), ln_ws
@@ -1416,11 +1416,9 @@ class DenseBlockPlan:
         t, G, M, d = self.t, self.G, self.M, self.d
 
         def defer():
-            if self.fuse_ln:       # partial sums by ttsmi_layernorm_param_partials on the weight-gradient stream
-                side = D.side_stream if D.side_stream is not None else D.main_stream
-                side = 0 if side is None else side
-                _ln_defer(t['lnp_ws2'], G['ln2.gamma'], G['ln2.beta'], None, M, d, self.lnp_nw, side)
-                _ln_defer(t['lnp_ws1'], G['ln1.gamma'], G['ln1.beta'], None, M, d, self.lnp_nw, side)
+            if self.fuse_ln:       # partial rows left by ttsmi_layernorm_bwd_xhat / the epilogue of ttsmi_hgemm_ln_bwd
+                _ln_defer(t['lnp_ws2'], G['ln2.gamma'], G['ln2.beta'], None, M, d, self.lnp_nw2)
+                _ln_defer(t['lnp_ws1'], G['ln1.gamma'], G['ln1.beta'], None, M, d, self.lnp_nw1)
             else:
                 _ln_defer(t['ln_ws2'], G['ln2.gamma'], G['ln2.beta'], None, M, d)
                 _ln_defer(t['ln_ws1'], G['ln1.gamma'], G['ln1.beta'], None, M, d)
