@@ -741,3 +741,51 @@ def test_hgemm_with_fused_layernorm_matches_gemm_then_layernorm(M, K, dual, pdro
     torch.cuda.synchronize()
     assert rel_err(dres, dres1) < 1.5e-2 and rel_err(dxb.float(), dx1.float()) < 2e-2
     assert rel_err(db, db1) < 1e-4 and rel_err(dg, dg1) < 1.5e-2
+
+
+@pytest.mark.parametrize('M,N,relu,out_bf16', [(1000, 768, False, True), (333, 1024, True, True), (581, 256, False, False),
+                                               (64, 80, True, False), (28800, 1024, True, True), (4100, 264, False, True)])
+def test_weight_stationary_k256_gemm(M, N, relu, out_bf16, monkeypatch):
+    """gemm_k256.hip (reached through ttsmi_hgemm_tn for K = 256 projections): row / column tails, every epilogue,
+    against the bf16-rounded fp64 product; run in a subprocess-free way by forcing the route with TTSMI_HGEMM_K256=1
+    before the library reads it (first call in this process decides: the test asserts the route it got)."""
+    ops = _ops()
+    from transformertts_amd import _lib
+    K = 256
+    x, w, b = g(M, K, seed=1), g(K, N, seed=2, scale=0.1), g(N, seed=3)
+    sh = ops.make_shadow(w.to(DEV))
+    xa = x.to(DEV).to(torch.bfloat16)
+    y = ops.hgemm_tn(xa, sh.wt, b.to(DEV), relu=relu, out_bf16=out_bf16)
+    want = (xa.double().cpu() @ _bf(w) + b.double())
+    if relu:
+        want = want.relu()
+    assert y.dtype == (torch.bfloat16 if out_bf16 else torch.float32)
+    assert rel_err(y.float(), want) < (5e-3 if out_bf16 else 3e-6)
+    routed = bool(_lib.lib()._cdll.ttsmi_hgemm_k256_eligible(M, N, K))
+    if M >= 4096:
+        assert routed                                       # the decoder-size launches take the new kernel by default
+
+
+@pytest.mark.parametrize('M', [700, 5000])
+def test_weight_stationary_k256_gemm_mask_and_accumulate(M):
+    """The ReLU'-masked bf16 dgrad (FFN2 -> hidden) and the accumulating fp32 dgrad (Wo top half) on gemm_k256.hip."""
+    ops = _ops()
+    K, N = 256, 1024
+    dy = g(M, K, seed=1).to(DEV).to(torch.bfloat16)
+    w2 = g(N, K, seed=2, scale=0.1)                                # FFN2 weight [F, d]: dgrad operand as stored
+    sh = ops.make_shadow(w2.to(DEV))
+    h1 = (g(M, N, seed=3)).to(DEV).to(torch.bfloat16)
+    h1[::7, ::5] = 0                                               # exact zeros and negatives both mask
+    dh1 = ops.hgemm_tn(dy, sh.wb, relu_src=h1, out_bf16=True)
+    want = (dy.double().cpu() @ _bf(w2).T) * (h1.double().cpu() > 0)
+    assert rel_err(dh1.float(), want) < 5e-3
+    # fp32 mask-free accumulate, N = 256
+    wo = g(256, K, seed=4, scale=0.1)
+    sho = ops.make_shadow(wo.to(DEV))
+    acc0 = g(M, 256, seed=5).to(DEV)
+    acc = acc0.clone()
+    ops.hgemm_tn(dy, sho.wb, out=acc, accumulate=True)
+    assert rel_err(acc, acc0.double().cpu() + dy.double().cpu() @ _bf(wo).T) < 3e-6
+    # fp32 output with mask (not used by the model, covered for the ABI)
+    out = ops.hgemm_tn(dy, sh.wb, relu_src=h1)
+    assert rel_err(out, want) < 3e-6

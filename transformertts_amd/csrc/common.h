@@ -44,6 +44,11 @@ size_t ttsmi_hattention_dropmask_bytes(int B, int H, int T);
 int ttsmi_hattention_dropmask(void* mask, int B, int H, int T, float p_drop, uint64_t seed, const int64_t* step_dev,
                               uint32_t site, hipStream_t st);
 
+// weight-stationary K = 256 GEMM (gemm_k256.hip), reached through ttsmi_hgemm_tn
+extern "C" int ttsmi_hgemm_k256_eligible(int M, int N, int K);
+int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, long ldb, const float* bias, void* c, long ldc,
+                            int M, int N, int relu, int out_bf16, hipStream_t st);
+
 // ---- wave64 reductions ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1216,6 +1216,14 @@ int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int
     if (mask_bf16) TTSMI_CHECK_ARG(N % 4 == 0 && ld_relu % 4 == 0, "hgemm_tn: bf16 mask needs N %% 4 == 0");
     p.M = M; p.N = N; p.K = K; p.relu = relu ? 1 : 0; p.accumulate = accumulate ? 1 : 0; p.k_per_split = K;
     if (conv_taps > 1) { p.a_taps = conv_taps; p.T = conv_T; p.Cw = conv_C; p.pad = conv_pad; }
+    // K = 256 projections without a second segment / mask / accumulation: weight-stationary kernel (gemm_k256.hip)
+    if (!a_is_f32 && !a2 && !relu_src && !accumulate && conv_taps <= 1 && lda % 8 == 0 && ldc % 4 == 0 &&
+        (c_bf16 ? ldc % 8 == 0 : true) && al16(c) && ttsmi_hgemm_k256_eligible(M, N, K)) {
+        ttsmi_hgemm_k256_launch((const uint16_t*)a, (long)lda, b, (long)ldb, bias, c, (long)ldc, M, N, relu ? 1 : 0,
+                                c_bf16 ? 1 : 0, (hipStream_t)stream);
+        TTSMI_CHECK_LAUNCH("hgemm_tn(k256)");
+        return TTSMI_OK;
+    }
     return hlaunch(p, a_is_f32 != 0, 1, (hipStream_t)stream, "hgemm_tn");
 }
 
