@@ -48,6 +48,11 @@ def workload_config(name: str):
     from transformertts_amd.utils.synthetic import make_config
     if name == 'configs[1]':
         return make_config(), dict(B=32, Tp=200, Tm=900)
+    if name == 'ref-default':
+        # the reference's shipped configuration (config/training_config.yaml:104-118): d_model 384, 2 heads (dh = 192),
+        # 6+6 self-attention CONV blocks with filters [1536, 384], kernel 3 - the architecture of the released weights
+        return make_config(d_model=384, enc_heads=(2,) * 6, dec_heads=(2,) * 6, ffn=None, enc_dense_blocks=0,
+                           dec_dense_blocks=0, conv_filters=(1536, 384)), dict(B=32, Tp=200, Tm=900)
     if name == 'configs[0]':
         return make_config(d_model=64, enc_heads=(2, 2), dec_heads=(2, 2), ffn=256, dur_filters=(64, 64),
                            pitch_filters=(64, 64)), dict(B=4, Tp=50, Tm=200)
@@ -143,7 +148,7 @@ KERNEL_OF = {
     'ttsmi_conv1d_dgrad': 'gemm_f32_kernel<A_KC,B_KC> (dgrad)',
     'ttsmi_linear_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
     'ttsmi_conv1d_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
-    'ttsmi_hgemm_tn': 'gemm_bf16_kernel / gemm_bf16_dma_kernel (Dense/Conv1D forward + dgrad, bf16 MFMA)',
+    'ttsmi_hgemm_tn': 'gemm_bf16_kernel / gemm_bf16_dma_kernel / gemm_k256_kernel (Dense/Conv1D forward + dgrad, bf16 MFMA)',
     'ttsmi_hgemm_wgrad': 'gemm_bf16_kernel<A=bf16> (wgrad, bf16 MFMA, + split reduce)',
     'ttsmi_hgemm_wgrad_rows': 'wgrad_dma_kernel / wgrad_rows_kernel (wgrad from row-major activations, bf16 MFMA, + split reduce)',
     'ttsmi_attention_fwd': 'attn_fwd_kernel (exact fp32 MFMA)',
@@ -153,6 +158,11 @@ RIDERS = 'hbm-bound riders (LN, lenreg, loss, Adam, ...)'
 SIDE = ' [side stream]'
 HATTN_FWD = 'hattn_fwd_kernel (bf16 MFMA flash attention forward)'
 HATTN_BWD = 'hattn_bwd_dq_kernel + hattn_bwd_dkv_kernel (bf16 MFMA flash attention backward)'
+ROWGEMM = 'rowgemm_dma_kernel / rowgemm_kernel (full-row GEMM + fused LayerNorm forward / backward, bf16 MFMA)'
+# launch groups announced by the C++ block launcher (ttsmi_set_launch_observer) -> kernel family
+OBSERVED = {'ttsmi_hgemm_tn': KERNEL_OF['ttsmi_hgemm_tn'], 'ttsmi_hgemm_ln_fwd': ROWGEMM, 'ttsmi_hgemm_ln_bwd': ROWGEMM,
+            'ttsmi_attention_fwd': HATTN_FWD, 'ttsmi_attention_bwd': HATTN_BWD,
+            'ttsmi_hgemm_wgrad_rows': KERNEL_OF['ttsmi_hgemm_wgrad_rows']}
 
 
 def kernel_family(name, args):
@@ -163,9 +173,10 @@ def kernel_family(name, args):
     return KERNEL_OF.get(name, RIDERS)
 
 
-PMC_FILE = 'r01_pmc_hbm_traffic_bf16.json'
+PMC_FILE = 'r02_pmc_hbm_traffic_bf16.json'
 PMC_KERNELS = {       # kernel family -> (rocprof names of its kernels, names of helper kernels of the same entry point)
-    KERNEL_OF['ttsmi_hgemm_tn']: (['gemm_bf16_kernel', 'gemm_bf16_dma_kernel'], []),
+    KERNEL_OF['ttsmi_hgemm_tn']: (['gemm_bf16_kernel', 'gemm_bf16_dma_kernel', 'gemm_k256_kernel'], []),
+    ROWGEMM: (['rowgemm_dma_kernel', 'rowgemm_kernel'], []),
     KERNEL_OF['ttsmi_hgemm_wgrad_rows']: (['wgrad_rows_kernel', 'wgrad_dma_kernel'], ['hsplit_reduce']),
     HATTN_FWD: (['hattn_fwd_kernel'], []),
     HATTN_BWD: (['hattn_bwd_dq_kernel'], ['hattn_bwd_dkv_kernel']),
@@ -186,8 +197,10 @@ def instrumented_step(step_fn):
     ext = {}
 
     def hook(name, args, fn):
-        if name.endswith('_ws_bytes') or name in ('ttsmi_last_error', 'ttsmi_version'):
-            return fn(*args)
+        if (name.endswith('_bytes') or name.endswith('_nparts') or
+                name in ('ttsmi_last_error', 'ttsmi_version', 'ttsmi_dense_block_fwd', 'ttsmi_dense_block_bwd',
+                         'ttsmi_set_launch_observer')):
+            return fn(*args)          # queries; the block launchers announce their launches through the observer
         # the launch stream is the entry point's last argument (the weight gradients pass the side
         # stream's handle explicitly while torch's current stream stays the main one)
         h = args[-1] if isinstance(args[-1], int) else None
@@ -208,12 +221,35 @@ def instrumented_step(step_fn):
         recs.append((fam, name, _flops(name, args), _bytes(name, args), key, e0, e1))
         return rc
 
+    # launches issued from C++ (ttsmi_dense_block_fwd / _bwd) announce themselves through the library's observer hook
+    open_ev = {}
+
+    def observe(phase, name, flops, byt, stream):
+        name = name.decode()
+        h = stream or 0
+        side = h != main_stream
+        st = None
+        if side:
+            st = ext.get(h)
+            if st is None:
+                st = ext[h] = torch.cuda.ExternalStream(h)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(st) if st is not None else ev.record()
+        if phase == 0:
+            open_ev[(name, h)] = ev
+            return
+        fam = OBSERVED.get(name, RIDERS) + (SIDE if side else '')
+        recs.append((fam, name, flops, byt, (int(flops), int(byt)), open_ev.pop((name, h)), ev))
+
+    cb = _lib.LAUNCH_OBSERVER(observe)
     _lib.set_trace(hook)
+    _lib.lib()._cdll.ttsmi_set_launch_observer(cb)
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
         _lib.set_trace(None)
+        _lib.lib()._cdll.ttsmi_set_launch_observer(None)
     return [(fam, n, fl, by, key, e0.elapsed_time(e1)) for fam, n, fl, by, key, e0, e1 in recs]
 
 
@@ -286,6 +322,56 @@ def cpu_baseline(cfg, shape, threads):
                       f'with ms_per_step_with_attention_maps)'}
 
 
+def predict_bench(args):
+    """BASELINE.json configs[4]: inference-only ForwardTransformer.predict, batch 1 and batch 64, long sentences (400
+    phonemes), hipGraph-captured (model.graph_inference), 1 GPU: p50 / p90 latency and RTF = latency / seconds of audio
+    (hop 256 @ 22.05 kHz).  Durations are forced (synthetic, mean 5.7 frames per phoneme -> ~2 280 frames) so that the
+    decoder length is realistic with random-init weights.  Two lines per batch size: without the attention maps and -
+    as the reference's predict returns them - with all 12 maps materialised."""
+    from transformertts_amd.model.models import ForwardTransformer
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    cfg, _ = workload_config('configs[1]')
+    rng = np.random.default_rng(1234)
+    Tp = 400
+    cases = []
+    for graph in (True, False):
+        model = ForwardTransformer.from_config(dict(cfg, device=str(dev), seed=0, precision=args.precision,
+                                                    graph_inference=graph))
+        for B in (1, 64):
+            tok = torch.from_numpy(rng.integers(1, 127, size=(B, Tp)).astype(np.int32)).to(dev)
+            dur = torch.from_numpy(rng.multinomial(int(5.7 * Tp), np.ones(Tp) / Tp, size=B).astype(np.int32)).to(dev)
+            for maps in (False, True):
+                if maps and (B > 1 or not graph):
+                    continue              # 12 maps of [64, 4, 2280, 2280] fp32 are 63 GB: batch 1 only
+                model.return_attention = maps
+                fn = lambda: model.predict(tok, encode=False, phoneme_durations=dur)   # noqa: E731
+                for _ in range(4):
+                    o = fn()
+                torch.cuda.synchronize()
+                lat = []
+                for _ in range(max(20, args.steps * 3)):
+                    t0 = time.perf_counter()
+                    o = fn()
+                    torch.cuda.synchronize()
+                    lat.append(time.perf_counter() - t0)
+                frames = int(o['expanded_lengths'].sum().item())
+                audio_s = frames * 256 / 22050.0
+                lat = np.sort(np.array(lat))
+                p50, p90 = float(lat[len(lat) // 2]), float(lat[int(len(lat) * 0.9)])
+                cases.append({'batch': B, 'hipgraph': graph, 'attention_maps': maps, 'frames': frames,
+                              'audio_seconds': audio_s, 'p50_ms': p50 * 1e3, 'p90_ms': p90 * 1e3, 'rtf_p50': p50 / audio_s,
+                              'mel_frames_per_s': frames / p50})
+        del model
+    head = next(c for c in cases if c['batch'] == 1 and c['hipgraph'] and not c['attention_maps'])
+    print(json.dumps({'metric': 'predict p50 latency, batch 1, 400 phonemes, hipGraph-captured', 'value': head['p50_ms'],
+                      'unit': 'ms', 'n_gpus': 1, 'steps': len(lat), 'warmup': 4, 'higher_is_better': False,
+                      'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+                      'config': {'workload': 'BASELINE.json configs[4]: ForwardTransformer.predict, d_model=256 6+6 dense '
+                                             'blocks, 400 phonemes, forced durations (mean 5.7 frames)'},
+                      'rtf_p50': head['rtf_p50'], 'cases': cases}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -307,6 +393,9 @@ def main():
                     help='skip the extra timed leg that also materialises the 12 attention maps')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
+
+    if args.workload == 'predict':
+        return predict_bench(args)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` as typed: start one rank per GPU ourselves (the same launcher the driver uses)

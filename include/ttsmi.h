@@ -413,6 +413,11 @@ typedef struct ttsmi_dense_block {
     ttsmi_stream_t main_stream, side_stream;      /* side_stream == NULL: weight gradients on the main stream */
     ttsmi_event_t ev[4];                          /* main -> side hand-offs of the four weight-gradient groups */
 } ttsmi_dense_block;
+/* Measurement hook: when set, ttsmi_dense_block_fwd/_bwd announce every launch group they issue - phase 0 before, 1 after
+ * it is enqueued - with the entry point's name, its algorithmic FLOPs and bytes and the stream it goes to, so a profiler
+ * can bracket the launches with HIP events.  NULL (the default) disables it.  Process-wide, for measurement only. */
+typedef void (*ttsmi_launch_observer)(int phase, const char* name, double flops, double bytes, ttsmi_stream_t stream);
+int ttsmi_set_launch_observer(ttsmi_launch_observer cb);
 /* h [M,d] fp32 block input, h_bf its bf16 copy.  Writes desc->out / out_bf (+ the kept activations). */
 int ttsmi_dense_block_fwd(const ttsmi_dense_block* desc, const float* h, const uint16_t* h_bf);
 /* dout [M,d] fp32 gradient of the block output.  Writes desc->dh, the parameter gradients, and leaves the two

@@ -154,7 +154,7 @@ def test_reference_default_head_dim_192_conv_blocks():
 
 def test_conv_blocks_bf16_path_tracks_oracle():
     """Conv blocks on the bf16 implicit-GEMM path (forward, dgrad with fused ReLU', wgrad_rows with the conv
-    window) at the reference-default channel counts; dh = 192 keeps the exact-fp32 attention kernels."""
+    window) at the reference-default channel counts; attention with dh = 192 on the bf16 MFMA kernels."""
     cfg = fo.make_config(d_model=384, enc_heads=(2,), dec_heads=(2,), ffn=1536, enc_dense_blocks=0,
                          dec_dense_blocks=0, conv_filters=(1536, 384), dur_filters=(256, 226),
                          pitch_filters=(256, 226))
@@ -176,6 +176,36 @@ def test_conv_blocks_bf16_path_tracks_oracle():
                       ('enc.blk0.conv0.w', 0.15), ('enc.blk0.conv1.w', 0.15)):
         a, b = torch.as_tensor(g[name]).double(), torch.as_tensor(np.asarray(want['grads'][name])).double()
         assert (a - b).norm() / b.norm() < tol, name
+
+
+def test_graph_captured_predict_equals_eager_predict(tiny):
+    """graph_inference=True (two hipGraphs: encoder side per input shape, decoder side per length bucket) returns what
+    the eager predict returns - predicted durations (data-dependent length, speed regulator, per-symbol clamps) and
+    forced durations - on several sentences that reuse the captured graphs, with and without attention maps."""
+    cfg, W = tiny
+    W = dict(W)
+    W['dur.lin.b'] = W['dur.lin.b'] + 2.3
+    rng = np.random.default_rng(3)
+    for prec, tol in (('f32', 1e-6), ('bf16', 1e-6)):
+        eager = _model(cfg, W, precision=prec)
+        graph = _model(cfg, W, precision=prec, graph_inference=True)
+        for trial in range(4):
+            tok = rng.integers(1, 127, size=(2, 12)).astype(np.int32)
+            tok[1, 9:] = 0
+            kw = dict(encode=False, speed_regulator=0.8, phoneme_max_duration={'a': 2.0})
+            if trial == 3:
+                kw['phoneme_durations'] = rng.integers(0, 6, size=(2, 12)).astype(np.int32)
+            e = eager.predict(tok, **kw)
+            g_ = graph.predict(tok, **kw)
+            assert g_['mel'].shape == e['mel'].shape
+            assert _rel(g_['mel'], e['mel']) < tol and _rel(g_['duration'], e['duration']) < tol
+            np.testing.assert_array_equal(g_['expanded_mask'].cpu().numpy(), e['expanded_mask'].cpu().numpy())
+            for k in e['decoder_attention']:
+                assert _rel(g_['decoder_attention'][k], e['decoder_attention'][k]) < tol
+        assert len(graph._infer_graphs) == 2                  # predicted-duration graph + forced-duration graph
+        graph.return_attention = eager.return_attention = False
+        e, g_ = eager.predict(tok, encode=False), graph.predict(tok, encode=False)
+        assert _rel(g_['mel'], e['mel']) < tol and len(g_['decoder_attention']) == 0
 
 
 def test_predict_matches_oracle(tiny):

@@ -517,7 +517,8 @@ def test_bf16_conv_predictor_layer_autograd(Cout):
     assert rel_err(ts[2].grad, _bf(dh).sum((0, 1))) < 1e-5
 
 
-@pytest.mark.parametrize('B,H,T,dh', [(2, 2, 50, 32), (3, 4, 200, 64), (2, 4, 333, 64), (1, 4, 900, 64)])
+@pytest.mark.parametrize('B,H,T,dh', [(2, 2, 50, 32), (3, 4, 200, 64), (2, 4, 333, 64), (1, 4, 900, 64), (2, 2, 150, 192),
+                                      (1, 2, 333, 192)])
 def test_bf16_attention_fwd_bwd(B, H, T, dh):
     """TTSMI_BF16 attention vs the fp64 reference evaluated on bf16-rounded q/k/v: what remains is
     the bf16 rounding of P (and dS / dO), i.e. ~2^-9 relative per element, averaged by the sums."""
@@ -563,7 +564,7 @@ def test_bf16_attention_dropout_matches_fp32_mask():
     assert rel_err(a, b) < 1e-2 and rel_err(c, b) > 5e-2
 
 
-@pytest.mark.parametrize('B,H,T,dh', [(2, 2, 150, 32), (3, 4, 200, 64), (2, 4, 900, 64), (1, 2, 33, 64)])
+@pytest.mark.parametrize('B,H,T,dh', [(2, 2, 150, 32), (3, 4, 200, 64), (2, 4, 900, 64), (1, 2, 33, 64), (2, 2, 100, 192)])
 def test_attention_keep_bit_table_equals_the_hashed_dropout(B, H, T, dh):
     """ttsmi_attention_dropmask + the *_masked kernels (bf16 I/O) make the same keep decisions as the kernels that
     hash in their inner loops: forward context, log-sum-exp and dqkv agree to fp32 rounding order (the 1/keep

@@ -86,6 +86,7 @@ SIGNATURES = {
     'ttsmi_layernorm_bwd_xhat': (I, [P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, c_size_t, I, I, S]),
     'ttsmi_add_layernorm_bwd_nparts': (I, [I]),
     'ttsmi_layernorm_param_reduce_batched_nw': (I, [P, P, P, P, P, P, I, S]),
+    'ttsmi_set_launch_observer': (I, [P]),
     'ttsmi_dense_block_fwd': (I, [P, P, P]),
     'ttsmi_dense_block_bwd': (I, [P, P, P, P]),
 }
@@ -113,6 +114,7 @@ class DenseBlockDesc(ctypes.Structure):
     _fields_ = _dense_block_fields()
 
 TTSMI_F32, TTSMI_BF16, TTSMI_BF16_IO = 0, 1, 2
+LAUNCH_OBSERVER = ctypes.CFUNCTYPE(None, c_int, c_char_p, ctypes.c_double, ctypes.c_double, c_void_p)
 
 _lib = None
 

@@ -260,19 +260,20 @@ __device__ __forceinline__ void accumT16(const uint16_t* St, int k0, int l31, in
 // re-layout pass, no transposed image, one barrier less per tile.
 typedef short as16x4 __attribute__((ext_vector_type(4)));
 typedef short as16x8 __attribute__((ext_vector_type(8)));
-template <int DH>
+// (NCB column blocks of 32 starting at block cb0: the dK/dV kernel accumulates a head dim of 192 in three passes of 64)
+template <int DH, int NCB = DH / 32>
 __device__ __forceinline__ void accumTR(const uint16_t* S, int k0, int lane, const bf16x8 (&pb)[2],
-                                        f32x16 (&out)[DH / 32]) {
+                                        f32x16 (&out)[NCB], int cb0 = 0) {
     typedef __attribute__((address_space(3))) as16x4* lds_ptr;
     constexpr int LD = DH + 8;
     // this lane's share of its group's block: row (lane&15)>>2, columns 4*(lane&3).. ; group = lane>>4:
     // (group&1) selects the 16-column half, lane>>5 (= hh) the +4 row offset of rowmap16
     const uint16_t* base = S + (k0 + 4 * (lane >> 5) + ((lane & 15) >> 2)) * LD + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
 #pragma unroll
-    for (int cb = 0; cb < DH / 32; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const uint16_t* a = base + (16 * t) * LD + cb * 32;
+            const uint16_t* a = base + (16 * t) * LD + (cb0 + cb) * 32;
             as16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
             as16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 8 * LD));
             as16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -336,8 +337,10 @@ struct HSm {
 // =================================================================================================
 // forward
 // =================================================================================================
+// head dims above 64 (dh = 192: the reference's shipped configuration, d_model 384 / 2 heads) keep 3x the accumulators
+// and operand fragments: they get the whole register file (one workgroup per CU) instead of spilling
 template <int DH, int DROP, bool QH>
-__global__ __launch_bounds__(256, 3) void hattn_fwd_kernel(HAttnP p) {
+__global__ __launch_bounds__(256, DH > 64 ? 1 : 3) void hattn_fwd_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(256, 3) void hattn_fwd_kernel(HAttnP p) {
 // backward A: dQ (+ delta)
 // =================================================================================================
 template <int DH, int DROP, bool QH>
-__global__ __launch_bounds__(256, 2) void hattn_bwd_dq_kernel(HAttnP p) {
+__global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dq_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dq_kernel(HAttnP p) {
 // min 2 workgroups per CU: without the bound the register allocator takes 332 registers (236 VGPR +
 // 96 AGPR) = ONE wave per SIMD; bounded it needs 236 and no spills
 template <int DH, int DROP, bool QH>
-__global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
+__global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
@@ -658,9 +661,13 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
     // keys that took no part in the forward (>= klen) get probability 0 through a -inf logit
     const float padterm = !kact ? -INFINITY : ((p.key_pad[(long)b * p.T + key]) ? -1e9f * LOG2E : 0.f);
 
-    f32x16 dk[DH / 32], dv[DH / 32];
+    // head dims above 64: one pass (blockIdx.y) per 64 output columns of dK / dV - the score tiles are recomputed in
+    // every pass, the 2 x 6 accumulator tiles of dh = 192 at once would not leave registers for the operands
+    constexpr int NCB = DH > 64 ? 2 : DH / 32;
+    const int cb0 = blockIdx.y * NCB;
+    f32x16 dk[NCB], dv[NCB];
 #pragma unroll
-    for (int cb = 0; cb < DH / 32; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[cb][r] = 0.f; dv[cb][r] = 0.f; }
     const float inv_sqrt = 1.0f / p.sqrt_dk;
@@ -754,8 +761,8 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
                 bf16x8 pb[2], sb[2];
                 to_frags(pt, pb);
                 to_frags(s, sb);
-                accumTR<DH>(Os, qt * 32, lane, pb, dv);                       // dV^T += dO^T.P
-                accumTR<DH>(Qs, qt * 32, lane, sb, dk);                       // dK^T += Q^T.dS
+                accumTR<DH, NCB>(Os, qt * 32, lane, pb, dv, cb0);             // dV^T += dO^T.P
+                accumTR<DH, NCB>(Qs, qt * 32, lane, sb, dk, cb0);             // dK^T += Q^T.dS
             }
         }
     }
@@ -763,9 +770,9 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_dkv_kernel(HAttnP p) {
     float* patch = reinterpret_cast<float*>(smem + wave * (QH ? 32 * (DH + 8) * 2 : 32 * (DH + 1) * 4));
     int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
-    const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH);
-    storeT16<DH, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
-    storeT16<DH, QH>(patch, dv, DROP ? p.inv_keep : 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
+    const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH + cb0 * 32);
+    storeT16<NCB * 32, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
+    storeT16<NCB * 32, QH>(patch, dv, DROP ? p.inv_keep : 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
 }
 
 // =================================================================================================
@@ -830,8 +837,9 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
     switch (dh) {                                                                              \
         case 32: HLAUNCH(KERNEL, 32, grid, st, p); break;                                      \
         case 64: HLAUNCH(KERNEL, 64, grid, st, p); break;                                      \
+        case 192: HLAUNCH(KERNEL, 192, grid, st, p); break;                                    \
         default:                                                                               \
-            ttsmi_set_error("bf16 attention: head dim %d not built (32/64)", dh);              \
+            ttsmi_set_error("bf16 attention: head dim %d not built (32/64/192)", dh);          \
             return TTSMI_ERR_UNSUPPORTED;                                                      \
     }
 
@@ -884,7 +892,8 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     dim3 grid(ttsmi_cdiv(T, 128) * H * B);
     HDISPATCH(dh, hattn_bwd_dq_kernel, grid, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dq(bf16)");
-    HDISPATCH(dh, hattn_bwd_dkv_kernel, grid, st, p);
+    dim3 grid_kv(grid.x, dh > 64 ? dh / 64 : 1);
+    HDISPATCH(dh, hattn_bwd_dkv_kernel, grid_kv, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dkv(bf16)");
     return TTSMI_OK;
 }

@@ -13,6 +13,23 @@
 
 static const float kLnEps = 1e-6f;     // LayerNormalization(epsilon=1e-6), model/layers.py:27,96,207
 
+// Measurement hook (bench.py's instrumented step): when set, every launch group issued from here is announced to the
+// observer before and after it is enqueued, with its stream and its algorithmic FLOPs / bytes, so that the caller can
+// bracket it with HIP events exactly as it brackets the entry points it calls itself.  Process-wide, not thread-safe:
+// a measurement facility, unset in normal operation.
+static ttsmi_launch_observer g_observer = nullptr;
+extern "C" int ttsmi_set_launch_observer(ttsmi_launch_observer cb) { g_observer = cb; return 0; }
+struct Obs {
+    const char* name; double flops, bytes; ttsmi_stream_t st;
+    Obs(const char* n, double f, double b, ttsmi_stream_t s) : name(n), flops(f), bytes(b), st(s) { if (g_observer) g_observer(0, name, flops, bytes, st); }
+    ~Obs() { if (g_observer) g_observer(1, name, flops, bytes, st); }
+};
+// algorithmic bytes: every operand read once, every result written once (bench.py:_bytes)
+static double gemm_bytes(double M, double N, double K, int out_bytes, bool acc, double extra = 0) {
+    return M * K * 2 + 2 * K * N + M * N * out_bytes * (acc ? 2 : 1) + extra;
+}
+#define OBS(name, flops, bytes, st) Obs obs__(name, flops, bytes, st)
+
 static int check_desc(const ttsmi_dense_block* D, const char* who) {
     TTSMI_CHECK_ARG(D, "%s: null descriptor", who);
     TTSMI_CHECK_ARG(D->B > 0 && D->H > 0 && D->T > 0 && D->d > 0 && D->F > 0 && D->d % D->H == 0,
@@ -33,20 +50,28 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
     const int M = D->B * D->T, d = D->d, F = D->F, dh = d / D->H;
     ttsmi_stream_t st = D->main_stream;
     // qkv = h.Wqkv + b                                                     (layers.py:116-118, fused)
-    TRY(ttsmi_hgemm_tn(h_bf, 0, d, nullptr, 0, 0, D->wqkv_t, d, D->bqkv, nullptr, 0, D->qkv, 3L * d, M, 3 * d, d,
-                       TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st));
+    { OBS("ttsmi_hgemm_tn", 2.0 * M * 3 * d * d, gemm_bytes(M, 3 * d, d, 2, false), st);
+      TRY(ttsmi_hgemm_tn(h_bf, 0, d, nullptr, 0, 0, D->wqkv_t, d, D->bqkv, nullptr, 0, D->qkv, 3L * d, M, 3 * d, d,
+                         TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
     // ctx = softmax(q k^T / sqrt(dh) + mask) v                             (layers.py:176-195)
-    if (D->dropmask && D->rate > 0.f)
-        TRY(ttsmi_attention_fwd_masked(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->dropmask, st));
-    else
-        TRY(ttsmi_attention_fwd(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->seed,
-                                D->step_dev, D->site_attn, TTSMI_BF16_IO, st));
+    {
+        const double T2 = (double)D->T * D->T;
+        OBS("ttsmi_attention_fwd", 4.0 * D->B * D->H * T2 * dh, (double)M * 3 * d * 2 + (double)M * d * 2 + 4.0 * D->B * D->H * D->T, st);
+        if (D->dropmask && D->rate > 0.f)
+            TRY(ttsmi_attention_fwd_masked(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->dropmask, st));
+        else
+            TRY(ttsmi_attention_fwd(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->seed,
+                                    D->step_dev, D->site_attn, TTSMI_BF16_IO, st));
+    }
     if (D->fuse_ln) {
         // a = LN(drop([h | ctx].Wo + b) + h) * mask in ONE launch            (layers.py:148-150,211,229)
-        TRY(ttsmi_hgemm_ln_fwd(h_bf, d, D->cx, d, d, D->wo_t, 2L * d, D->bo, h, D->ln1_g, D->ln1_b, D->pad, D->rate,
-                               D->site_ln1, D->seed, D->step_dev, kLnEps, D->a, D->a_bf, D->xhat1, D->rstd1, M, d, 2 * d, st));
-        TRY(ttsmi_hgemm_tn(D->a_bf, 0, d, nullptr, 0, 0, D->w1_t, d, D->b1, nullptr, 0, D->h1, F, M, F, d,
-                           TTSMI_GEMM_RELU | TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st));
+        { OBS("ttsmi_hgemm_ln_fwd", 2.0 * M * d * 2 * d, gemm_bytes(M, d, 2 * d, 4, false, (double)M * d * (4 + 2 + 2)), st);
+          TRY(ttsmi_hgemm_ln_fwd(h_bf, d, D->cx, d, d, D->wo_t, 2L * d, D->bo, h, D->ln1_g, D->ln1_b, D->pad, D->rate,
+                                 D->site_ln1, D->seed, D->step_dev, kLnEps, D->a, D->a_bf, D->xhat1, D->rstd1, M, d, 2 * d, st)); }
+        { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false), st);
+          TRY(ttsmi_hgemm_tn(D->a_bf, 0, d, nullptr, 0, 0, D->w1_t, d, D->b1, nullptr, 0, D->h1, F, M, F, d,
+                             TTSMI_GEMM_RELU | TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
+        OBS("ttsmi_hgemm_ln_fwd", 2.0 * M * d * F, gemm_bytes(M, d, F, 4, false, (double)M * d * (4 + 2 + 2)), st);
         // out = LN(drop(h1.W2 + b2) + a) * mask in ONE launch                (layers.py:100-102,230)
         TRY(ttsmi_hgemm_ln_fwd(D->h1, F, nullptr, 0, 0, D->w2_t, F, D->b2, D->a, D->ln2_g, D->ln2_b, D->pad, D->rate,
                                D->site_ln2, D->seed, D->step_dev, kLnEps, D->out, D->out_bf, D->xhat2, D->rstd2, M, d, F, st));
@@ -85,6 +110,7 @@ static int wgrad_side(const ttsmi_dense_block* D, int ev, bool record, const uin
             return TTSMI_ERR_LAUNCH;
         }
     }
+    OBS("ttsmi_hgemm_wgrad_rows", 2.0 * M * kin * n, (double)M * (kin + n) * 2 + 4.0 * kin * n, (ttsmi_stream_t)st);
     return ttsmi_hgemm_wgrad_rows(x, 1, ldx, dy, 1, lddy, dw, n, db, M, kin, n, 1, 0, 0, 0, D->wgrad_ws, D->wgrad_ws_bytes, st);
 }
 
@@ -95,19 +121,22 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     ttsmi_stream_t st = D->main_stream;
     const bool dropout = D->rate > 0.f;
     // ---- LN2 + FFN: df (bf16) = dLN2/dx, da (fp32) = dLN2/dres
-    if (D->fuse_ln)
+    if (D->fuse_ln) {
+        OBS("ttsmi_layernorm_bwd_xhat", 0.0, (double)M * d * (4 + 2 + 2 + 4), st);
         TRY(ttsmi_layernorm_bwd_xhat(dout, D->xhat2, D->rstd2, D->ln2_g, D->pad, D->rate, D->site_ln2, D->seed, D->step_dev,
                                      D->df, D->da, D->lnp_ws2, D->lnp_ws2_bytes, M, d, st));
-    else
+    } else
         TRY(ttsmi_add_layernorm_bwd(dout, D->f, D->a, D->ln2_g, D->mean2, D->rstd2, nullptr, nullptr, 0, D->pad, D->rate,
                                     D->site_ln2, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->da, D->da, nullptr,
                                     nullptr, nullptr, M, d, D->ln_ws2, D->ln_ws_bytes, D->df, st));
     TRY(wgrad_side(D, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
-    TRY(ttsmi_hgemm_tn(D->df, 0, d, nullptr, 0, 0, D->w2_b, d, nullptr, (const float*)D->h1, F, D->dh1, F, M, F, d,
-                       TTSMI_GEMM_OUT_BF16 | TTSMI_GEMM_MASK_BF16, 1, 0, 0, 0, st));                  // relu' fused
+    { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false, (double)M * F * 2), st);
+      TRY(ttsmi_hgemm_tn(D->df, 0, d, nullptr, 0, 0, D->w2_b, d, nullptr, (const float*)D->h1, F, D->dh1, F, M, F, d,
+                         TTSMI_GEMM_OUT_BF16 | TTSMI_GEMM_MASK_BF16, 1, 0, 0, 0, st)); }               // relu' fused
     TRY(wgrad_side(D, 1, true, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
     if (D->fuse_ln) {
         // (da + dh1.W1^T) never reaches HBM: res-norm 1's backward runs in the dgrad's epilogue -> d_o (bf16), dh (fp32)
+        OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * F, gemm_bytes(M, d, F, 4, true, (double)M * d * (2 + 2)), st);
         TRY(ttsmi_hgemm_ln_bwd(D->dh1, F, D->w1_b, F, D->da, D->xhat1, D->rstd1, D->ln1_g, D->pad, D->rate, D->site_ln1,
                                D->seed, D->step_dev, D->d_o, D->dh, D->lnp_ws1, D->lnp_ws1_bytes, M, d, F, st));
     } else {
@@ -120,18 +149,25 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     }
     TRY(wgrad_side(D, 2, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
     TRY(wgrad_side(D, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
-    TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b, d, nullptr, nullptr, 0, D->dh, d, M, d, d,
-                       TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                       // dh += do.Wo_top^T
-    TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b + (long)d * d, d, nullptr, nullptr, 0, D->dctx, d, M, d, d,
-                       TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st));
+    { OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 4, true), st);
+      TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b, d, nullptr, nullptr, 0, D->dh, d, M, d, d,
+                         TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st)); }                                     // dh += do.Wo_top^T
+    { OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 2, false), st);
+      TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b + (long)d * d, d, nullptr, nullptr, 0, D->dctx, d, M, d, d,
+                         TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
     // ---- attention + qkv projection
+    {
+    const double T2 = (double)D->T * D->T;
+    OBS("ttsmi_attention_bwd", 8.0 * D->B * D->H * T2 * dh, (double)M * 3 * d * 2 * 3 + (double)M * d * 2 * 3 + 16.0 * D->B * D->H * D->T, st);
     if (D->dropmask && dropout)
         TRY(ttsmi_attention_bwd_masked(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh,
                                        D->rate, D->dropmask, D->attn_ws, D->attn_ws_bytes, st));
     else
         TRY(ttsmi_attention_bwd(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh, D->rate,
                                 D->seed, D->step_dev, D->site_attn, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));
+    }
     TRY(wgrad_side(D, 3, true, h_bf, d, D->dqkv, 3 * d, D->g_wqkv, D->g_bqkv, d, 3 * d));
+    OBS("ttsmi_hgemm_tn", 2.0 * M * d * 3 * d, gemm_bytes(M, d, 3 * d, 4, true), st);
     TRY(ttsmi_hgemm_tn(D->dqkv, 0, 3L * d, nullptr, 0, 0, D->wqkv_b, 3L * d, nullptr, nullptr, 0, D->dh, d, M, d, 3 * d,
                        TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                       // dh += dqkv.Wqkv^T
     return TTSMI_OK;

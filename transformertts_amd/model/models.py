@@ -206,6 +206,9 @@ class ForwardTransformer:
         self._dropmask_plan, self._dropmask_bufs = {}, {}
         # blocks driven from C++ with persistent buffers (ops.DenseBlockPlan); only inside _forward_backward, where one
         # forward is followed by its backward before the next forward reuses the buffers
+        # predict() replayed from hipGraphs (outputs are the graphs' static buffers: consume them before the next call)
+        self.graph_inference = bool(kwargs.get('graph_inference', False))
+        self._infer_graphs: Dict[tuple, dict] = {}
         self.planned_blocks = bool(kwargs.get('planned_blocks', True))
         self.fuse_ln = bool(kwargs.get('fuse_ln', True))               # res-norms in the GEMM epilogues (d_model 256)
         self._use_plans, self._plans, self._plan_shared = False, {}, {}
@@ -433,11 +436,13 @@ class ForwardTransformer:
 
     def _block_plan(self, p, prefix, B, H, T):
         """ops.DenseBlockPlan of block `p` at this batch shape (built on first use; at most 3 shapes are kept)."""
-        key = (p, B, T)
+        backward = torch.is_grad_enabled()
+        key = (p, B, T) if backward else (p, B, T, 'fwd')
         plan = self._plans.get(key)
         if plan is None:
             shapes = []
-            for (_, b, t) in self._plans:
+            for k in self._plans:
+                b, t = k[1], k[2]
                 if (b, t) not in shapes:
                     shapes.append((b, t))
             if (B, T) not in shapes and len(shapes) >= 6:          # 3 batch shapes x (encoder T, decoder T)
@@ -449,8 +454,11 @@ class ForwardTransformer:
                     for k in [k for k in sh if (k[0], k[2]) == old]:
                         del sh[k]
             Pb, Gb, Sb = self._block_views(p)
+            # fuse_ln needs o / f only in the unfused path; a forward-only plan with unfused LayerNorms keeps them
             plan = self._plans[key] = ops.DenseBlockPlan(Pb, Gb, Sb, B, H, T, self.device,
-                                                         self._plan_shared.setdefault(prefix, {}), self.fuse_ln)
+                                                         self._plan_shared.setdefault(prefix, {}), self.fuse_ln,
+                                                         backward=backward or not (self.fuse_ln and
+                                                                                   Pb['wqkv'].shape[0] == 256))
         return plan
 
     _BLOCK_KEYS = ('wqkv', 'bqkv', 'wo', 'bo', 'ln1.gamma', 'ln1.beta', 'ffn.w1', 'ffn.b1', 'ffn.w2', 'ffn.b2',
@@ -488,8 +496,22 @@ class ForwardTransformer:
     def call(self, x, target_durations=None, target_pitch=None, training=False, durations_scalar=1.,
              max_durations_mask=None, min_durations_mask=None, mel_len: Optional[int] = None,
              return_attention: Optional[bool] = None, _overlap_predictors: bool = False):
-        c, W, G = self.config, self.params.w, self.params.g
         want_attn = (not training) if return_attention is None else return_attention
+        a = self._call_front(x, target_durations, target_pitch, training, durations_scalar, max_durations_mask,
+                             min_durations_mask, want_attn, _overlap_predictors, need_total=mel_len is None)
+        if mel_len is None:
+            # inference: the output length max_b sum(round(dur)) is data dependent (one host sync,
+            # like the reference's eager call)
+            mel_len = max(int(a['total'].max().item()), 1)
+        b = self._call_back(a['h'], a['use'], mel_len, training, want_attn)
+        return {'mel': b['mel'], 'duration': a['duration'], 'pitch': a['pitch'], 'expanded_mask': b['expanded_mask'],
+                'encoder_attention': a['encoder_attention'], 'decoder_attention': b['decoder_attention'],
+                'expanded_lengths': b['expanded_lengths']}
+
+    def _call_front(self, x, target_durations, target_pitch, training, durations_scalar, max_durations_mask,
+                    min_durations_mask, want_attn, _overlap_predictors=False, need_total=True):
+        """models.py:521-539: masks, embedding, encoder, predictors, pitch embedding, the durations to expand by."""
+        c, W, G = self.config, self.params.w, self.params.g
         rate = c['dropout_rate'] if training else 0.0
         prate = c['predictors_dropout'] if training else 0.0
         self.drop.reset()
@@ -541,11 +563,14 @@ class ForwardTransformer:
         if min_durations_mask is not None:                                           # :538-539
             use = torch.maximum(use.to(torch.float32),
                                 torch.as_tensor(min_durations_mask, device=self.device).to(torch.float32))
-        if mel_len is None:
-            # inference: the output length max_b sum(round(dur)) is data dependent (one host sync,
-            # like the reference's eager call)
-            _, _, ln = ops.lenreg_index(use, 1)
-            mel_len = max(int(ln.max().item()), 1)
+        total = ops.lenreg_index(use, 1)[2] if need_total else None      # [B] sum(round(dur)): the output length
+        return {'h': h, 'use': use, 'total': total, 'duration': durations, 'pitch': pitch, 'encoder_attention': enc_attn}
+
+    def _call_back(self, h, use, mel_len, training, want_attn):
+        """models.py:540-543: Expand, decoder mask, decoder, mel projection (dropout sites continue _call_front's)."""
+        c, W, G = self.config, self.params.w, self.params.g
+        rate = c['dropout_rate'] if training else 0.0
+        B = h.shape[0]
         idx, cum, lens = ops.lenreg_index(use, mel_len)                              # :540 Expand
         mels = ops.LenRegFn.apply(h, idx, cum, self._lenreg_hook)
         pad_d, klen_d = ops.length_pad_mask(lens, mel_len)                           # :541
@@ -556,9 +581,7 @@ class ForwardTransformer:
         self._mark('dec_fwd')
         out = ops.LinearFn.apply(mels.reshape(B * mel_len, -1), None, W['out.w'], W['out.b'], G['out.w'],
                                  G['out.b'], self.shadow.get('out.w')).reshape(B, mel_len, self.mel_channels)  # :543
-        return {'mel': out, 'duration': durations, 'pitch': pitch, 'expanded_mask': expanded_mask,
-                'encoder_attention': enc_attn, 'decoder_attention': dec_attn,
-                'expanded_lengths': lens}
+        return {'mel': out, 'expanded_mask': expanded_mask, 'decoder_attention': dec_attn, 'expanded_lengths': lens}
 
     __call__ = call
 
@@ -797,12 +820,81 @@ class ForwardTransformer:
         max_durations_mask = self._make_max_duration_mask(inp, phoneme_max_duration)
         min_durations_mask = self._make_min_duration_mask(inp, phoneme_min_duration)
         ra = True if self.return_attention is None else self.return_attention
-        with torch.no_grad():
-            out = self.call(inp, target_durations=phoneme_durations, target_pitch=phoneme_pitch,
-                            training=False, durations_scalar=duration_scalar,
-                            max_durations_mask=max_durations_mask, min_durations_mask=min_durations_mask,
-                            return_attention=ra)
+        # forward-only use of the C++-driven blocks (persistent per-shape buffers: the outputs of the previous predict
+        # of the same shape are overwritten)
+        self._use_plans = self.planned_blocks and self.precision == 'bf16'
+        try:
+            if self.graph_inference:
+                out = self._predict_graphed(inp, duration_scalar, max_durations_mask, min_durations_mask,
+                                            phoneme_durations, phoneme_pitch, ra)
+            else:
+                with torch.no_grad():
+                    out = self.call(inp, target_durations=phoneme_durations, target_pitch=phoneme_pitch,
+                                    training=False, durations_scalar=duration_scalar,
+                                    max_durations_mask=max_durations_mask, min_durations_mask=min_durations_mask,
+                                    return_attention=ra)
+        finally:
+            self._use_plans = False
         out['mel'] = out['mel'].squeeze()                                            # :576
+        return out
+
+    MEL_BUCKET = 64        # graph_inference: decoder lengths are rounded up to a multiple of this many frames
+
+    def _predict_graphed(self, inp, duration_scalar, max_mask, min_mask, phoneme_durations, phoneme_pitch, ra):
+        """predict() replayed from two captured hipGraphs (BASELINE.json configs[4]): the eager forward is ~250
+        launches driven from Python - at batch 1 the host loop, not the GPU, is the latency.  The output length is data
+        dependent (sum of the rounded durations), so the forward is cut where the reference's eager call synchronises
+        anyway: graph A = masks .. encoder .. predictors .. pitch embedding .. total lengths (per input shape), one host
+        read of the maximum length, graph B = Expand .. decoder .. mel projection per decoder-length BUCKET (multiples
+        of MEL_BUCKET frames; rows past the true length are padding: masked keys, sliced off the outputs)."""
+        B, Tp = inp.shape
+        dev = self.device
+        f32 = lambda t: None if t is None else torch.as_tensor(t, device=dev).to(torch.float32).reshape(B, Tp).contiguous()
+        durs = None
+        if phoneme_durations is not None:
+            durs = torch.as_tensor(phoneme_durations, device=dev).reshape(B, Tp)
+            durs = durs.to(torch.float32 if durs.dtype.is_floating_point else torch.int32).contiguous()
+        pit = f32(phoneme_pitch)
+        keyA = ('A', B, Tp, float(duration_scalar), None if durs is None else durs.dtype, pit is not None, bool(ra))
+        A = self._infer_graphs.get(keyA)
+        if A is None:
+            A = {'tok': inp.clone(), 'maxm': max_mask.clone(), 'minm': min_mask.clone(),
+                 'dur': None if durs is None else durs.clone(), 'pit': None if pit is None else pit.clone(), 'B': {}}
+            run = lambda: self._call_front(A['tok'], A['dur'], A['pit'], False, duration_scalar, A['maxm'], A['minm'], ra)
+            with torch.no_grad():
+                run()                                        # warm-up: lazy allocations happen outside the capture
+                torch.cuda.synchronize()
+                A['graph'] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(A['graph']):
+                    A['out'] = run()
+            self._infer_graphs[keyA] = A
+        for dst, src in ((A['tok'], inp), (A['maxm'], max_mask), (A['minm'], min_mask), (A['dur'], durs), (A['pit'], pit)):
+            if dst is not None:
+                dst.copy_(src, non_blocking=True)
+        A['graph'].replay()
+        a = A['out']
+        L = max(int(a['total'].max().item()), 1)             # the one host sync of the call (as in the eager reference)
+        cap = int(self.pe_dec.shape[0])
+        if L > cap:
+            raise ValueError(f'Decoder: sequence length {L} exceeds the positional-encoding table ({cap} positions)')
+        bucket = min((L + self.MEL_BUCKET - 1) // self.MEL_BUCKET * self.MEL_BUCKET, cap)
+        Bg = A['B'].get(bucket)
+        if Bg is None:
+            run = lambda: self._call_back(a['h'], a['use'], bucket, False, ra)
+            with torch.no_grad():
+                run()
+                torch.cuda.synchronize()
+                Bg = {'graph': torch.cuda.CUDAGraph()}
+                with torch.cuda.graph(Bg['graph'], pool=A['graph'].pool()):
+                    Bg['out'] = run()
+            Bg['plans'] = [pl for k, pl in self._plans.items() if k[1] == B]     # their buffers are baked into the graphs
+            A['B'][bucket] = Bg
+        Bg['graph'].replay()
+        b = Bg['out']
+        out = {'mel': b['mel'][:, :L], 'duration': a['duration'], 'pitch': a['pitch'],
+               'expanded_mask': b['expanded_mask'][..., :L], 'encoder_attention': a['encoder_attention'],
+               'decoder_attention': OrderedDict((k, v[:, :, :L, :L]) for k, v in b['decoder_attention'].items()),
+               'expanded_lengths': b['expanded_lengths']}
         return out
 
     def _make_max_duration_mask(self, encoded_text, phoneme_max_duration):           # :579-586

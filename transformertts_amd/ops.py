@@ -837,8 +837,8 @@ class AttentionFn(torch.autograd.Function):
     def forward(ctx, qkv, key_pad, klen, B, H, T, dh, p_drop, drop, site, dtype=TTSMI_F32):
         qkv = _c(qkv)
         d = H * dh
-        if dtype != TTSMI_F32 and dh not in (32, 64):
-            dtype = TTSMI_F32                  # bf16 kernels are built for head dims 32 / 64
+        if dtype != TTSMI_F32 and dh not in (32, 64, 192):
+            dtype = TTSMI_F32                  # bf16 kernels are built for head dims 32 / 64 / 192
         out = torch.empty((B * T, d), dtype=torch.float32, device=qkv.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
         seed = drop.seed if drop is not None else 0
@@ -1181,7 +1181,7 @@ class DenseBlockFn(torch.autograd.Function):
         M, d = h.shape
         dh_ = d // H
         F = P['ffn.w1'].shape[1]
-        if dtype != TTSMI_F32 and dh_ not in (32, 64):
+        if dtype != TTSMI_F32 and dh_ not in (32, 64, 192):
             dtype = TTSMI_F32
         all_h = (dtype != TTSMI_F32 and all(S.get(k) is not None for k in ('wqkv', 'wo', 'ffn.w1', 'ffn.w2'))
                  and d % 64 == 0 and F % 8 == 0)
@@ -1319,8 +1319,10 @@ class DenseBlockPlan:
     step costs two ctypes calls per block (forward, backward) whose launches are issued from C++.
     `shared` holds the buffers that blocks of one stack may share (nothing outside the main stream reads them)."""
 
-    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True):
+    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True, backward=True):
+        """backward=False: a forward-only plan (inference) - the backward temporaries are not allocated."""
         l = _lib.lib()
+        self.backward = bool(backward)
         d = P['wqkv'].shape[0]
         F = P['ffn.w1'].shape[1]
         M = B * T
@@ -1335,7 +1337,7 @@ class DenseBlockPlan:
                                 # read by the weight-gradient stream: private to the block
                                 ('df', (M, d), bf), ('dh1', (M, F), bf), ('d_o', (M, d), bf), ('dqkv', (M, 3 * d), bf),
                                 ('dh', (M, d), f32)):
-            t[name] = e(shape, dt)
+            t[name] = e(shape if backward or name not in ('df', 'dh1', 'd_o', 'dqkv', 'dh', 'o', 'f') else (8,), dt)
         ln_ws = int(l.ttsmi_add_layernorm_bwd_ws_bytes(M, d))
         t['ln_ws1'], t['ln_ws2'] = _ws(ln_ws, device), _ws(ln_ws, device)
         # LayerNorms fused into the GEMM epilogues (ttsmi_hgemm_ln_fwd / _bwd): needs the full row in one tile
@@ -1346,10 +1348,11 @@ class DenseBlockPlan:
                 t[name] = e((M, d), bf)
             t['lnp_ws1'] = _ws(l.ttsmi_layernorm_partials_bytes(self.lnp_nw1, d), device)
             t['lnp_ws2'] = _ws(l.ttsmi_layernorm_partials_bytes(self.lnp_nw2, d), device)
-        key = (B, H, T, d)
+        key = (B, H, T, d, self.backward)
         if key not in shared:
-            shared[key] = {'da': e((M, d), f32), 'dctx': e((M, d), bf),
-                           'attn_ws': _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, d // H), device)}
+            shared[key] = ({'da': e((M, d), f32), 'dctx': e((M, d), bf),
+                            'attn_ws': _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, d // H), device)} if backward else
+                           {'da': e((8,), f32), 'dctx': e((8,), bf), 'attn_ws': _ws(256, device)})
         sh = shared[key]
         self.shared = sh
         self.wgrad_need = max(int(l.ttsmi_hgemm_wgrad_rows_ws_bytes(M, kin, n))
@@ -1396,6 +1399,7 @@ class DenseBlockPlan:
         check(_lib.lib().ttsmi_dense_block_fwd(self._dref, _p(h), _p(h_bf)), 'dense_block_fwd')
 
     def bwd(self, h, h_bf, dout):
+        assert self.backward, 'forward-only plan'
         D = self.desc
         if _WgradStream.enabled:
             W = _WgradStream.cur()
