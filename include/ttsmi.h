@@ -125,6 +125,14 @@ int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const in
                                const void* ctx, const void* dctx, const float* lse, void* dqkv, int B,
                                int H, int T, int dh, float p_drop, const void* dropmask, void* ws, size_t ws_bytes,
                                ttsmi_stream_t stream);
+/* Inference forward (no dropout, TTSMI_BF16_IO tensors) for launches too small to fill the GPU - batch 1, a few heads:
+ * the keys are split over extra workgroups, each split writes a normalised partial context + log-sum-exp into `ws`, and a
+ * combine pass forms the result (model/layers.py:176-195 with training=False).  _ws_bytes returns 0 when B*H*T already
+ * fills the GPU; the call then runs the plain forward and ignores ws.  Results equal ttsmi_attention_fwd up to the bf16
+ * rounding of the partial contexts. */
+size_t ttsmi_attention_fwd_splitkeys_ws_bytes(int B, int H, int T, int dh);
+int ttsmi_attention_fwd_splitkeys(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx, float* lse,
+                                  int B, int H, int T, int dh, void* ws, size_t ws_bytes, ttsmi_stream_t stream);
 /* Materialise the (post-dropout) attention weights [B,H,T,T] the reference returns from every call
  * (model/layers.py:195,302-310) - only when the caller asks for them. */
 int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float* lse,
@@ -399,7 +407,9 @@ typedef struct ttsmi_dense_block {
     /* fuse_ln != 0 (needs d == 256): the two res-norms run in the epilogues of the o-projection / FFN2 GEMMs
      * (ttsmi_hgemm_ln_fwd) and res-norm 1's backward in the epilogue of the FFN1 dgrad (ttsmi_hgemm_ln_bwd); o, f,
      * mean1, mean2, ln_ws1, ln_ws2 are then unused and these are required instead: */
-    int32_t fuse_ln, _pad0;
+    int32_t fuse_ln;
+    int32_t attn_split;                           /* != 0 and rate == 0: the forward may split the keys
+                                                     (ttsmi_attention_fwd_splitkeys) with attn_ws as its scratch */
     uint16_t *xhat1, *xhat2;                      /* [M,d] normalised pre-activations kept for the backward */
     void *lnp_ws1, *lnp_ws2;                      /* parameter-gradient partial rows of res-norm 1 (ttsmi_hgemm_ln_bwd) /
                                                      res-norm 2 (ttsmi_layernorm_bwd_xhat) */

@@ -36,8 +36,9 @@ BOUNDS = {
     'f32': dict(fwd=1e-4, loss=1e-4, grad=2e-4, grad_vec=4e-4, gnorm=2e-4, tap=1e-4),
     # bf16 bounds = about twice what the path achieves on these two batches (round 2, fused-LayerNorm build: mel /
     # duration / pitch 0.9-1.0 %, loss 2e-4, block outputs 0.2 % at depth 1 growing to 0.7 % at depth 12, matrices
-    # <= 3.1 % (embedding), vectors <= 5.4 % (the positional-encoding scalars: one number, a sum with cancellation))
-    'bf16': dict(fwd=2e-2, loss=1e-3, grad=6e-2, grad_vec=1e-1, gnorm=1e-1, tap=1.5e-2),
+    # <= 3.7 % (embedding), vectors <= 5.4 % (the positional-encoding scalars: one number, a sum with cancellation);
+    # on the max-shape batch: duration 1.6 %, pitch 1.3 %, total loss 5.3e-4, the small pitch-loss component 2.0e-3)
+    'bf16': dict(fwd=3e-2, loss=4e-3, grad=7e-2, grad_vec=1e-1, gnorm=1e-1, tap=1.5e-2),
 }
 
 

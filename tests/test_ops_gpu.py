@@ -615,6 +615,48 @@ def test_attention_keep_bit_table_equals_the_hashed_dropout(B, H, T, dh):
     assert live.any()
 
 
+@pytest.mark.parametrize('B,H,T,dh', [(1, 4, 2304, 64), (1, 4, 400, 64), (2, 2, 333, 32), (1, 2, 700, 192), (3, 4, 100, 64),
+                                      (32, 4, 900, 64)])
+def test_split_key_attention_forward_equals_the_plain_forward(B, H, T, dh):
+    """ttsmi_attention_fwd_splitkeys (inference, small launches: keys split over extra workgroups + combine) against
+    ttsmi_attention_fwd on the same bf16 qkv: contexts within the bf16 rounding of the partial contexts, log-sum-exp to
+    fp32 rounding; ragged klen (one sequence ends inside the first split, so later splits are EMPTY for it), a padded
+    key in the middle, T not a multiple of the tile.  The last case is big enough that no split is made."""
+    ops = _ops()
+    from transformertts_amd import _lib
+    from transformertts_amd.ops import _p, _stream, check
+    l = _lib.lib()
+    d = H * dh
+    qkv = (g(B * T, 3 * d, seed=1) * 0.7).to(DEV).to(torch.bfloat16)
+    lens = torch.tensor([T] + [max(1, (T * (i + 1)) // (B + 7)) for i in range(B - 1)])
+    if B == 1:
+        lens[0] = T - 5
+    pad = (torch.arange(T)[None, :] >= lens[:, None]).to(torch.uint8)
+    pad[0, 3] = 1
+    klen = torch.tensor([int((p == 0).nonzero().max()) + 1 for p in pad], dtype=torch.int32)
+    pad, klen = pad.to(DEV), klen.to(DEV)
+    need = int(l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, dh))
+    assert (need == 0) == (B == 32 or T <= 128)             # one staged pair of key tiles is not split either
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=DEV)
+    c0 = torch.empty(B * T, d, device=DEV, dtype=torch.bfloat16)
+    c1 = torch.full_like(c0, float('nan'))
+    l0 = torch.empty(B, H, T, device=DEV)
+    l1 = torch.full_like(l0, float('nan'))
+    check(l.ttsmi_attention_fwd(_p(qkv), _p(pad), _p(klen), _p(c0), _p(l0), B, H, T, dh, 0.0, 0, None, 0,
+                                _lib.TTSMI_BF16_IO, _stream()))
+    check(l.ttsmi_attention_fwd_splitkeys(_p(qkv), _p(pad), _p(klen), _p(c1), _p(l1), B, H, T, dh, _p(ws), ws.numel(),
+                                          _stream()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(c1.float()).all() and torch.isfinite(l1).all()
+    assert rel_err(l1, l0) < 1e-6
+    assert rel_err(c1.float(), c0.float()) < (1e-2 if need else 1e-9)
+    assert float((c1.float() - c0.float()).abs().mean()) < 3e-3 * float(c0.float().abs().mean()) + 1e-12
+    if need:
+        with pytest.raises(_lib.TtsmiError):
+            check(l.ttsmi_attention_fwd_splitkeys(_p(qkv), _p(pad), _p(klen), _p(c1), _p(l1), B, H, T, dh, _p(ws), 16,
+                                                  _stream()))
+
+
 @pytest.mark.parametrize('M,K,N', [(1000, 256, 128), (333, 64, 200), (28800 // 8, 1024, 256), (77, 100, 60)])
 def test_hgemm_wgrad_rows(M, K, N):
     ops = _ops()

@@ -261,6 +261,8 @@ def run_all(only):
     res = []
     if only in (None, 'gemm'):
         res += bench_gemm()
+    if only == 'gemm-small':                 # inference (batch 1: 2304 frames / 400 phonemes) and encoder-side rows
+        res += bench_gemm((6400, 2304, 400))
     if only in (None, 'wgrad'):
         res += bench_wgrad()
     if only in (None, 'attn'):

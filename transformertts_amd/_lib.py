@@ -43,6 +43,8 @@ SIGNATURES = {
     'ttsmi_attention_dropmask_bytes': (c_size_t, [I, I, I]),
     'ttsmi_attention_dropmask': (I, [P, I, I, I, F, c_uint64, P, c_uint32, S]),
     'ttsmi_attention_fwd_masked': (I, [P, P, P, P, P, I, I, I, I, F, P, S]),
+    'ttsmi_attention_fwd_splitkeys_ws_bytes': (c_size_t, [I, I, I, I]),
+    'ttsmi_attention_fwd_splitkeys': (I, [P, P, P, P, P, I, I, I, I, P, c_size_t, S]),
     'ttsmi_attention_bwd_masked': (I, [P, P, P, P, P, P, P, I, I, I, I, F, P, P, c_size_t, S]),
     'ttsmi_add_layernorm_fwd': (I, [P, P, P, P, P, P, I, P, F, c_uint32, F, c_uint32, c_uint64, P,
                                     F, P, P, P, I, I, P, S]),
@@ -102,7 +104,7 @@ def _dense_block_fields():
     ptrs2 = ('df', 'dh1', 'd_o', 'dctx', 'dqkv', 'da', 'dh', 'attn_ws', 'ln_ws1', 'ln_ws2', 'wgrad_ws')
     return ([(n, i32) for n in ('B', 'H', 'T', 'd', 'F')] + [('rate', f)] +
             [(n, u32) for n in ('site_attn', 'site_ln1', 'site_ln2')] + [('seed', u64)] +
-            [(n, p) for n in ptrs] + [('fuse_ln', i32), ('_pad0', i32)] +
+            [(n, p) for n in ptrs] + [('fuse_ln', i32), ('attn_split', i32)] +
             [(n, p) for n in ('xhat1', 'xhat2', 'lnp_ws1', 'lnp_ws2')] + [('lnp_ws1_bytes', u64), ('lnp_ws2_bytes', u64)] +
             [(n, p) for n in ptrs2] + [(n, u64) for n in ('attn_ws_bytes', 'ln_ws_bytes', 'wgrad_ws_bytes')] +
             [('main_stream', p), ('side_stream', p), ('ev', p * 4)])

@@ -553,6 +553,15 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
     return TTSMI_OK;
 }
 
+size_t ttsmi_attention_fwd_splitkeys_ws_bytes(int B, int H, int T, int dh) {
+    return ttsmi_hattention_fwd_split_ws_bytes(B, H, T, dh);
+}
+
+int ttsmi_attention_fwd_splitkeys(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx, float* lse,
+                                  int B, int H, int T, int dh, void* ws, size_t ws_bytes, ttsmi_stream_t stream) {
+    return ttsmi_hattention_fwd_split(qkv, key_pad, klen, ctx, lse, B, H, T, dh, ws, ws_bytes, (hipStream_t)stream);
+}
+
 size_t ttsmi_attention_dropmask_bytes(int B, int H, int T) { return ttsmi_hattention_dropmask_bytes(B, H, T); }
 
 int ttsmi_attention_dropmask(void* mask, int B, int H, int T, float p_drop, uint64_t seed,

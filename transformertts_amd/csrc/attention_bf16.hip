@@ -39,6 +39,9 @@ struct HAttnP {
     float sqrt_dk;
     uint32_t thr; float inv_keep; uint64_t seed; const int64_t* step_dev; uint32_t site;
     const uint64_t* dmask;          // DROP == 2: precomputed keep bits (hattn_dropmask_kernel), else unused
+    // forward only, split_keys != 0: blockIdx.y = key split s owns keys [s*split_keys, (s+1)*split_keys) and writes its
+    // own softmax-normalised partial context / log-sum-exp at ctx + s*ctx_split (elements) / lse + s*lse_split
+    int split_keys; long ctx_split, lse_split;
 };
 
 // DROP template values: 0 = no dropout, 1 = keep decisions hashed in the inner loop (ttsmi_pair_hash), 2 = keep
@@ -373,7 +376,11 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 3) void hattn_fwd_kernel(HAttnP 
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
     float m = -INFINITY, l = 0.f;                 // running max (log2 units) and sum
-    const int klen = p.klen[b];
+    int kbeg = 0, klen = p.klen[b];               // this workgroup's key range [kbeg, klen)
+    if (p.split_keys) {
+        kbeg = blockIdx.y * p.split_keys;
+        klen = min(klen, kbeg + p.split_keys);
+    }
     const float c1 = LOG2E / p.sqrt_dk;
     uint32_t drop_rb = 0;
     if (DROP == 1) drop_rb = ttsmi_row_base(ttsmi_drop_key(p.seed, p.step_dev, p.site),
@@ -391,12 +398,12 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 3) void hattn_fwd_kernel(HAttnP 
     Tile<DH, QH> rk, rv;
     float rpad = 0.f;
     {
-        int nv = min(HKT, klen);
-        rk.fetch(Kb, p.ld, 0, nv, tid);
-        rv.fetch(Vb, p.ld, 0, nv, tid);
-        if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + tid]) ? 1.f : 0.f;
+        int nv = min(HKT, klen - kbeg);
+        rk.fetch(Kb, p.ld, kbeg, nv, tid);
+        rv.fetch(Vb, p.ld, kbeg, nv, tid);
+        if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + kbeg + tid]) ? 1.f : 0.f;
     }
-    for (int k0 = 0; k0 < klen; k0 += HKT) {
+    for (int k0 = kbeg; k0 < klen; k0 += HKT) {
         __syncthreads();
         rk.stash(Ks, tid);
         rv.stash(Vs, tid);
@@ -465,12 +472,14 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 3) void hattn_fwd_kernel(HAttnP 
         }
     }
     __syncthreads();
-    if (qok && hh == 0) p.lse[((long)b * p.H + h) * p.T + q] = (m + log2f(l)) * LN2;
+    // (an empty key range - a split past the last unpadded key - leaves l = 0: weight 0 in the combine)
+    const long sp = p.split_keys ? blockIdx.y : 0;
+    if (qok && hh == 0) p.lse[sp * p.lse_split + ((long)b * p.H + h) * p.T + q] = l > 0.f ? (m + log2f(l)) * LN2 : -INFINITY;
     float* patch = reinterpret_cast<float*>(smem + wave * (QH ? 32 * (DH + 8) * 2 : 32 * (DH + 1) * 4));
     int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
-    storeT16<DH, QH>(patch, o, (DROP ? p.inv_keep : 1.0f) / l,
-                     const_cast<float*>(eptr<QH>(p.ctx, (long)b * p.T * d + h * DH)), d, row0, nvalid, lane);
+    storeT16<DH, QH>(patch, o, l > 0.f ? (DROP ? p.inv_keep : 1.0f) / l : 0.f,
+                     const_cast<float*>(eptr<QH>(p.ctx, sp * p.ctx_split + (long)b * p.T * d + h * DH)), d, row0, nvalid, lane);
 }
 
 // =================================================================================================
@@ -842,6 +851,93 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
             ttsmi_set_error("bf16 attention: head dim %d not built (32/64/192)", dh);          \
             return TTSMI_ERR_UNSUPPORTED;                                                      \
     }
+
+// ---- split-key forward (inference at small batch) ------------------------------------------------------------------
+// A forward whose B*H*ceil(T/128) workgroups do not fill the 256 CUs (batch 1, 2304 frames, 4 heads: 72 workgroups,
+// each wave walking all 2304 keys serially - 69 us) is latency bound by that serial walk.  Splitting the keys over
+// blockIdx.y gives every split its own softmax-normalised partial context o_s (bf16) and log-sum-exp lse_s; the combine
+// below forms lse = log sum_s exp(lse_s) and ctx = sum_s exp(lse_s - lse) o_s (the flash-decoding reduction).
+__global__ __launch_bounds__(256) void hattn_split_combine_kernel(const uint16_t* __restrict__ part_o,
+                                                                  const float* __restrict__ part_lse,
+                                                                  uint16_t* __restrict__ ctx, float* __restrict__ lse,
+                                                                  int nsplit, int B, int H, int T, int dh) {
+    const int d = H * dh, c8n = d >> 3;
+    const long M = (long)B * T, total = M * c8n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / c8n;
+        const int c8 = (int)(i - row * c8n) * 8, h = c8 / dh;
+        const long b = row / T, t = row - b * T;
+        const long li = (b * H + h) * T + t;
+        float mx = -INFINITY;
+        for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, part_lse[(long)s * B * H * T + li]);
+        float den = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nsplit; ++s) {
+            const float w = __expf(part_lse[(long)s * B * H * T + li] - mx);        // exp(-inf) = 0 for an empty split
+            den += w;
+            const uint4 v = *reinterpret_cast<const uint4*>(part_o + ((long)s * M + row) * d + c8);
+            const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += w * __uint_as_float(u[e] << 16);
+                acc[2 * e + 1] += w * __uint_as_float(u[e] & 0xFFFF0000u);
+            }
+        }
+        const float inv = 1.0f / den;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(acc[e] * inv);
+        *reinterpret_cast<uint4*>(ctx + row * d + c8) = *reinterpret_cast<uint4*>(&o);
+        if (c8 % dh == 0) lse[li] = mx + __logf(den);
+    }
+}
+
+// keys per split (a multiple of the staged tile) and number of splits; nsplit = 1: not worth splitting
+static void hsplit_plan(int B, int H, int T, int* split_keys, int* nsplit) {
+    const int wgs = ttsmi_cdiv(T, 128) * H * B, tiles = ttsmi_cdiv(T, HKT);
+    int n = 1;
+    if (wgs < 160) n = min(ttsmi_cdiv(512, wgs), max(1, tiles / 2));
+    const int per = ttsmi_cdiv(tiles, n);
+    *split_keys = per * HKT;
+    *nsplit = ttsmi_cdiv(tiles, per);
+}
+size_t ttsmi_hattention_fwd_split_ws_bytes(int B, int H, int T, int dh) {
+    int sk, n;
+    hsplit_plan(B, H, T, &sk, &n);
+    if (n <= 1) return 0;
+    return (size_t)n * ((size_t)B * T * H * dh * 2 + (size_t)B * H * T * 4);
+}
+int ttsmi_hattention_fwd_split(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx, float* lse,
+                               int B, int H, int T, int dh, void* ws, size_t ws_bytes, hipStream_t st) {
+    HAttnP p;
+    int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, 0.f, 0, nullptr, 0, "attention_fwd_splitkeys");
+    if (rc) return rc;
+    TTSMI_CHECK_ARG(ctx && lse, "attention_fwd_splitkeys: null pointer");
+    int sk, n;
+    hsplit_plan(B, H, T, &sk, &n);
+    const int qh = 1;
+    dim3 grid(ttsmi_cdiv(T, 128) * H * B);
+    if (n <= 1) {                                                      // enough workgroups already: the plain forward
+        p.ctx = (float*)ctx; p.lse = lse;
+        HDISPATCH(dh, hattn_fwd_kernel, grid, st, p);
+        TTSMI_CHECK_LAUNCH("attention_fwd_splitkeys");
+        return TTSMI_OK;
+    }
+    TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_hattention_fwd_split_ws_bytes(B, H, T, dh) && (((uintptr_t)ws) & 15) == 0,
+                    "attention_fwd_splitkeys: workspace too small / unaligned (ttsmi_attention_fwd_splitkeys_ws_bytes)");
+    const size_t M = (size_t)B * T, d = (size_t)H * dh;
+    uint16_t* part_o = (uint16_t*)ws;
+    float* part_lse = (float*)(part_o + (size_t)n * M * d);
+    p.ctx = (float*)part_o; p.lse = part_lse;
+    p.split_keys = sk; p.ctx_split = (long)(M * d); p.lse_split = (long)B * H * T;
+    grid.y = n;
+    HDISPATCH(dh, hattn_fwd_kernel, grid, st, p);
+    TTSMI_CHECK_LAUNCH("attention_fwd_splitkeys");
+    const long items = (long)M * (d / 8);
+    hipLaunchKernelGGL(hattn_split_combine_kernel, dim3((unsigned)min((long)2048, (items + 255) / 256)), dim3(256), 0, st,
+                       part_o, part_lse, (uint16_t*)ctx, lse, n, B, H, T, dh);
+    TTSMI_CHECK_LAUNCH("attention_fwd_splitkeys(combine)");
+    return TTSMI_OK;
+}
 
 // called from attention.hip's entry points when dtype == TTSMI_BF16
 size_t ttsmi_hattention_dropmask_bytes(int B, int H, int T) {

@@ -59,6 +59,9 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
         OBS("ttsmi_attention_fwd", 4.0 * D->B * D->H * T2 * dh, (double)M * 3 * d * 2 + (double)M * d * 2 + 4.0 * D->B * D->H * D->T, st);
         if (D->dropmask && D->rate > 0.f)
             TRY(ttsmi_attention_fwd_masked(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->dropmask, st));
+        else if (D->attn_split && D->rate == 0.f)
+            TRY(ttsmi_attention_fwd_splitkeys(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->attn_ws,
+                                              D->attn_ws_bytes, st));
         else
             TRY(ttsmi_attention_fwd(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->seed,
                                     D->step_dev, D->site_attn, TTSMI_BF16_IO, st));

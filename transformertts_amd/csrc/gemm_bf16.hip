@@ -554,6 +554,109 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
 }
 
 // =================================================================================================
+// Deep-ring variant for launches that cannot fill the GPU (inference at batch 1: M = 400 / 2304 rows; the encoder side
+// of a training step: M = 6400).  There the k-loop is a chain of exposed memory round trips - measured ~1 us per 64-wide
+// k-step whatever M is (K = 256 / 512 / 1024 at M = 400: 7.6 / 10.9 / 20 us) - because a workgroup has nothing
+// else resident on its CU to hide behind and the register-staged kernel keeps ONE k-tile in flight.  This kernel keeps
+// NST - 1 = 3 k-tiles in flight through an LDS-DMA ring (a whole K = 256 problem is requested before the first multiply)
+// and cuts the tile to 64 x 64 so that four times as many CUs take part.  Same swizzled 128-byte-row image as the
+// persistent DMA kernel above; one barrier per k-step; the accumulators leave straight from registers (lane = column:
+// a register row is 32 consecutive floats = 128-byte segments - fine for a kernel that is latency, not store, bound).
+// =================================================================================================
+#define SBM 64
+#define SBN 64
+#define SSTAGE ((SBM + SBN) * HBK_ * 2)
+template <int NST>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(HGemmP p) {
+    static_assert(HBK_ == 64, "the swizzled image assumes 8 chunks of 8 bf16 per row");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * SSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int m0 = tm * SBM, n0 = tn * SBN;
+    const int nk = p.K / HBK_;
+    const uint16_t* A = (const uint16_t*)p.A;
+    const uint16_t* A2 = (const uint16_t*)p.A2;
+    const int drow = lane >> 3, dpos = lane & 7;
+    auto issue = [&](int ks, int st) {                      // 4 DMA instructions per wave and stage
+        unsigned char* As = smem + st * SSTAGE;
+        unsigned char* Bs = As + SBM * HBK_ * 2;
+        const int k0 = ks * HBK_;
+        const uint16_t* Ab = A;
+        long lda = p.lda;
+        int ka = k0;
+        if (A2 != nullptr && k0 >= p.K1) { Ab = A2; lda = p.lda2; ka = k0 - p.K1; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 16 + i * 8 + drow;
+            const int c = dpos ^ ((row >> 1) & 7);
+            const int gm = min(m0 + row, p.M - 1);
+            lds_dma16(Ab + (long)gm * lda + ka + c * 8, lds_offset(As + (wave * 16 + i * 8) * 128));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 16 + i * 8 + drow;
+            const int c = dpos ^ ((row >> 1) & 7);
+            const int gn = min(n0 + row, p.N - 1);
+            lds_dma16(p.B + (long)gn * p.ldb + k0 + c * 8, lds_offset(Bs + (wave * 16 + i * 8) * 128));
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) issue(s, s);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ks = 0; ks < nk; ++ks) {
+        // k-tiles requested after tile ks and possibly still in flight: min(NST - 2, nk - 1 - ks) of them, 4 DMAs each
+        const int newer = min(NST - 2, nk - 1 - ks);
+        if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_stage_barrier();          // everybody's pieces of tile ks have landed, nobody still reads tile ks - 1 ...
+        if (ks + NST - 1 < nk) issue(ks + NST - 1, (ks + NST - 1) % NST);       // ... whose stage is refilled
+        const unsigned char* As = smem + (ks % NST) * SSTAGE;
+        const unsigned char* Bs = As + SBM * HBK_ * 2;
+#pragma unroll
+        for (int kk = 0; kk < HBK_ / 16; ++kk) {
+            const int c = kk * 2 + kg;
+            const int ra = wr * 32 + l31, rb = wc * 32 + l31;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4));
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    }
+    const int col = n0 + wc * 32 + l31;
+    if (col >= p.N) return;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (row >= p.M) continue;
+        float v = acc[r] + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.relu_src) {
+            bool on;
+            if (p.mask_bf16) {
+                const uint32_t h = ((const uint16_t*)p.relu_src)[(long)row * p.ld_relu + col];
+                on = ((h & 0x8000u) == 0u) && ((h & 0x7FFFu) != 0u);
+            } else
+                on = p.relu_src[(long)row * p.ld_relu + col] > 0.f;
+            v = on ? v : 0.f;
+        }
+        if (p.c_bf16) {
+            ((__bf16*)p.C)[(long)row * p.ldc + col] = (__bf16)v;
+        } else {
+            float* dst = p.C + (long)row * p.ldc + col;
+            *dst = p.accumulate ? *dst + v : v;
+        }
+    }
+}
+
+// =================================================================================================
 // wgrad straight from the row-major fp32 activations: dW[K_in, N] = X[M, K_in]^T . dY[M, N].
 // Both operands are fetched as [32 rows][128 cols] tiles (coalesced 512-byte fp32 / 256-byte bf16 rows)
 // and rounded to bf16 into row-major LDS images.  The MFMA fragments need 8 consecutive REDUCTION
@@ -1144,6 +1247,23 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
             TTSMI_CHECK_LAUNCH(name);
             return TTSMI_OK;
         }
+    }
+    // Under-filled launches (fewer 64 x 128 workgroups than 1.5 per CU): the deep-ring 64 x 64 kernel.  TTSMI_HGEMM_DEEP=0
+    // keeps the register-staged kernel (A/B knob).
+    static int use_deep = -1;
+    if (use_deep < 0) { const char* e = getenv("TTSMI_HGEMM_DEEP"); use_deep = e ? atoi(e) : 1; }
+    // Round-2 A/B (tools/kbench.py --only gemm-small, M = 6400 / 2304 / 400): K = 1024 runs 13.2 / 10.3 / 9.9 us against
+    // 20.7 / 16.0 / 15.9 us register-staged, K = 768 15.5 / 10.1 / 9.8 against 17.1 / 13.4 / 13.2; the K = 256 shapes (a
+    // single round trip either way) tie or lose, so they stay where they were.  Batch-1 predict: 1.14 -> 0.95 ms.
+    if (use_deep && !a_f32 && splits == 1 && p.colsum == nullptr && p.a_taps == 1 && p.K % HBK_ == 0 && p.lda % 8 == 0 &&
+        (p.K >= 512 || use_deep > 2) &&
+        p.ldb % 8 == 0 && al16(p.A) && al16(p.B) && (long)ttsmi_cdiv(p.M, 64) * ttsmi_cdiv(p.N, HBN_) < (use_deep > 1 ? (1L << 40) : 384) &&
+        (p.A2 == nullptr || (p.K1 % HBK_ == 0 && p.lda2 % 8 == 0 && al16(p.A2)))) {
+        p.tiles_m = ttsmi_cdiv(p.M, SBM);
+        p.tiles_n = ttsmi_cdiv(p.N, SBN);
+        hipLaunchKernelGGL(gemm_bf16_deep_kernel<4>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+        TTSMI_CHECK_LAUNCH(name);
+        return TTSMI_OK;
     }
     const int bm = hgemm_bm(a_f32, p.M, p.N, splits);
     p.tiles_m = ttsmi_cdiv(p.M, bm);

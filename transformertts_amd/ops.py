@@ -1310,6 +1310,9 @@ class DenseBlockFn(torch.autograd.Function):
 # =================================================================================================
 # The same block with its launch sequence issued from C++ (ttsmi_dense_block_fwd / _bwd, include/ttsmi.h)
 # =================================================================================================
+FUSE_LN_MIN_ROWS_INFERENCE = int(os.environ.get('TTSMI_FUSE_LN_MIN_ROWS', '8192'))
+
+
 class DenseBlockPlan:
     """Persistent buffers + the filled `ttsmi_dense_block` descriptor of ONE dense block at ONE batch shape.
 
@@ -1330,6 +1333,11 @@ class DenseBlockPlan:
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
         self.B, self.H, self.T, self.d, self.F, self.M = B, H, T, d, F, M
         self.t = t = {}
+        # LayerNorms fused into the GEMM epilogues (ttsmi_hgemm_ln_fwd / _bwd): needs the full row in one tile, so
+        # few, tall workgroups - at inference with few rows (batch 1: 2304 rows = 18..36 workgroups, 29 us against
+        # 9.5 + 5 us for GEMM + LayerNorm measured) the unfused pair is faster; training always fuses (the x-hat
+        # backward is where most of the gain is)
+        self.fuse_ln = bool(fuse_ln) and d == 256 and (backward or M >= FUSE_LN_MIN_ROWS_INFERENCE)
         for name, shape, dt in (('qkv', (M, 3 * d), bf), ('cx', (M, d), bf), ('a_bf', (M, d), bf), ('h1', (M, F), bf),
                                 ('out_bf', (M, d), bf), ('lse', (B, H, T), f32), ('o', (M, d), f32), ('a', (M, d), f32),
                                 ('f', (M, d), f32), ('out', (M, d), f32), ('mean1', (M,), f32), ('rstd1', (M,), f32),
@@ -1337,11 +1345,11 @@ class DenseBlockPlan:
                                 # read by the weight-gradient stream: private to the block
                                 ('df', (M, d), bf), ('dh1', (M, F), bf), ('d_o', (M, d), bf), ('dqkv', (M, 3 * d), bf),
                                 ('dh', (M, d), f32)):
-            t[name] = e(shape if backward or name not in ('df', 'dh1', 'd_o', 'dqkv', 'dh', 'o', 'f') else (8,), dt)
+            unused = (not backward and name in ('df', 'dh1', 'd_o', 'dqkv', 'dh')) or (self.fuse_ln and not backward and
+                                                                                        name in ('o', 'f'))
+            t[name] = e((8,) if unused else shape, dt)
         ln_ws = int(l.ttsmi_add_layernorm_bwd_ws_bytes(M, d))
         t['ln_ws1'], t['ln_ws2'] = _ws(ln_ws, device), _ws(ln_ws, device)
-        # LayerNorms fused into the GEMM epilogues (ttsmi_hgemm_ln_fwd / _bwd): needs the full row in one tile
-        self.fuse_ln = bool(fuse_ln) and d == 256
         self.lnp_nw1, self.lnp_nw2 = int(l.ttsmi_hgemm_ln_bwd_nparts(M)), int(l.ttsmi_layernorm_bwd_xhat_nparts(M))
         if self.fuse_ln:
             for name in ('xhat1', 'xhat2'):
@@ -1352,7 +1360,8 @@ class DenseBlockPlan:
         if key not in shared:
             shared[key] = ({'da': e((M, d), f32), 'dctx': e((M, d), bf),
                             'attn_ws': _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, d // H), device)} if backward else
-                           {'da': e((8,), f32), 'dctx': e((8,), bf), 'attn_ws': _ws(256, device)})
+                           {'da': e((8,), f32), 'dctx': e((8,), bf),      # forward only: scratch of the split-key attention
+                            'attn_ws': _ws(max(256, int(l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, d // H))), device)})
         sh = shared[key]
         self.shared = sh
         self.wgrad_need = max(int(l.ttsmi_hgemm_wgrad_rows_ws_bytes(M, kin, n))
@@ -1380,6 +1389,8 @@ class DenseBlockPlan:
                 setattr(D, k, t[k].data_ptr())
         D.da, D.dctx, D.attn_ws = sh['da'].data_ptr(), sh['dctx'].data_ptr(), sh['attn_ws'].data_ptr()
         D.attn_ws_bytes, D.ln_ws_bytes = sh['attn_ws'].numel(), ln_ws
+        D.attn_split = int(not backward and os.environ.get('TTSMI_ATTN_SPLIT', '1') != '0' and
+                           l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, d // H) > 0)
         for i, ev in enumerate(self.events):
             D.ev[i] = ev.cuda_event
         self.G = G
