@@ -148,7 +148,7 @@ KERNEL_OF = {
     'ttsmi_conv1d_dgrad': 'gemm_f32_kernel<A_KC,B_KC> (dgrad)',
     'ttsmi_linear_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
     'ttsmi_conv1d_wgrad': 'gemm_f32_kernel<A_MC,B_NC> (wgrad, + split reduce + bias colsum)',
-    'ttsmi_hgemm_tn': 'gemm_bf16_kernel / gemm_bf16_dma_kernel / gemm_k256_kernel (Dense/Conv1D forward + dgrad, bf16 MFMA)',
+    'ttsmi_hgemm_tn': 'gemm_bf16_kernel / gemm_bf16_dma_kernel / gemm_bf16_deep_kernel / gemm_k256_kernel (Dense/Conv1D forward + dgrad, bf16 MFMA)',
     'ttsmi_hgemm_wgrad': 'gemm_bf16_kernel<A=bf16> (wgrad, bf16 MFMA, + split reduce)',
     'ttsmi_hgemm_wgrad_rows': 'wgrad_dma_kernel / wgrad_rows_kernel (wgrad from row-major activations, bf16 MFMA, + split reduce)',
     'ttsmi_attention_fwd': 'attn_fwd_kernel (exact fp32 MFMA)',
@@ -175,7 +175,7 @@ def kernel_family(name, args):
 
 PMC_FILE = 'r02_pmc_hbm_traffic_bf16.json'
 PMC_KERNELS = {       # kernel family -> (rocprof names of its kernels, names of helper kernels of the same entry point)
-    KERNEL_OF['ttsmi_hgemm_tn']: (['gemm_bf16_kernel', 'gemm_bf16_dma_kernel', 'gemm_k256_kernel'], []),
+    KERNEL_OF['ttsmi_hgemm_tn']: (['gemm_bf16_kernel', 'gemm_bf16_dma_kernel', 'gemm_bf16_deep_kernel', 'gemm_k256_kernel'], []),
     ROWGEMM: (['rowgemm_dma_kernel', 'rowgemm_kernel'], []),
     KERNEL_OF['ttsmi_hgemm_wgrad_rows']: (['wgrad_rows_kernel', 'wgrad_dma_kernel'], ['hsplit_reduce']),
     HATTN_FWD: (['hattn_fwd_kernel'], []),
@@ -282,6 +282,19 @@ def pmc_traffic(kernel_family: str):
         elif any(k.startswith(p) for p in helpers):   # helper kernels add bytes, not launches
             b += v['launches'] * v['hbm_bytes_per_launch']
     return b / n if n else None
+
+
+def pmc_step_totals():
+    """Whole-step HBM bytes and kernel launches from the same committed PMC passes (None when absent)."""
+    path = os.path.join(ROOT, 'profiles', PMC_FILE)
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    if 'hbm_bytes_per_step' not in d:
+        return None
+    return {'hbm_gb_per_step': d['hbm_bytes_per_step'] / 1e9, 'kernel_launches_per_step': d['launches_per_step'],
+            'source': 'profiles/' + PMC_FILE + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at the '
+                      'commit the file was collected on, all kernels of a step, both streams)'}
 
 
 def usable_cpus() -> int:
@@ -538,6 +551,7 @@ def main():
             'launch_ms_note': 'sums of per-launch HIP-event times from ONE extra instrumented step (every launch '
                               'bracketed by two events while the weight-gradient stream contends): slower than the '
                               'timed steps, so main_stream_launch_ms may exceed ms_per_step',
+            'step_totals': pmc_step_totals() if args.precision == 'bf16' and args.workload == 'configs[1]' else None,
             'main_stream_launch_ms': sum(v[3] for k, v in groups.items() if not k.endswith(SIDE)),
             'side_stream_launch_ms': sum(v[3] for k, v in groups.items() if k.endswith(SIDE)),
         }

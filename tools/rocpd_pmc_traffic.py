@@ -42,8 +42,14 @@ def main():
                   'write_size_kib_per_launch': wv / max(wn, 1),
                   'hbm_bytes_per_launch': (2.0 * fv / n + wv / max(wn, 1)) * 1024.0}
     out = dict(sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches']))
+    # whole-step totals: the trace holds `steps` train steps (one adam_tf_kernel each) plus a few one-off
+    # initialisation launches (weight shadows), which are counted in - a slight over-estimate
+    steps = max(1, out.get('adam_tf_kernel', {}).get('launches', 1))
+    total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in out.values())
+    launches = sum(v['launches'] for v in out.values())
     json.dump({'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950, 16 B/lane loads; '
                              'calibrated on adam_tf_kernel and cast_bf16_kernel in this trace)',
+               'steps_in_trace': steps, 'hbm_bytes_per_step': total / steps, 'launches_per_step': launches / steps,
                'kernels': out}, open(sys.argv[3], 'w'), indent=1)
 
 

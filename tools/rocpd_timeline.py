@@ -44,6 +44,14 @@ def main():
                     busy += en - end
                     end = en
             big = sorted(gaps, reverse=True)[:5]
+            if q == main_q and '--gaps' in sys.argv:
+                named = sorted((r for r in seg if r[3] == q), key=lambda r: r[1])
+                found = []
+                for a_, b_ in zip(named, named[1:]):
+                    if b_[1] - a_[2] > 8000:
+                        found.append((b_[1] - a_[2], a_[2] - t0, short(a_[0])[:34], short(b_[0])[:34]))
+                for g_, at, pa, nb in sorted(found, reverse=True)[:14]:
+                    print(f'      gap {g_ / 1e3:7.1f} us at +{at / 1e6:6.3f} ms  after {pa:34s} before {nb}')
             print(f'  queue {q}{" (main)" if q == main_q else ""}: {len(ks)} kernels, busy {1e-6 * busy:.3f} ms, '
                   f'sum of gaps {1e-6 * sum(gaps):.3f} ms, gaps > 5 us: {sum(g > 5000 for g in gaps)} '
                   f'({1e-6 * sum(g for g in gaps if g > 5000):.3f} ms), largest {[round(g / 1e3, 1) for g in big]} us')

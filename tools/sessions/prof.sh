@@ -6,5 +6,5 @@ export TMPDIR=/tmp
 cd /tmp
 env "$@" timeout 280 rocprofv3 --kernel-trace -d $O/prof_tmp -o trace -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-roofline --no-attention-maps > $O/prof_tmp.log 2>&1
 echo "trace rc=$?"
-python $R/tools/rocpd_timeline.py $O/prof_tmp/trace_results.db --steps 2 --top 45
+python $R/tools/rocpd_timeline.py $O/prof_tmp/trace_results.db --steps 2 --top 45 $TIMELINE_ARGS
 rm -rf $O/prof_tmp

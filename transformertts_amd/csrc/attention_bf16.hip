@@ -21,6 +21,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -120,12 +121,27 @@ template <int DH>
 __device__ __forceinline__ void rows_fetch_h(const uint16_t* base, long ld, int row0, int nvalid, int tid,
                                              uint2 (&r)[DH / 16]) {
     constexpr int V4 = DH / 4;
+    if constexpr (256 % V4 == 0) {
+        // item i of this thread is row (tid / V4) + (256 / V4) i, the same 8-byte column every time: ONE 32-bit lane
+        // offset (loop invariant in every caller) + a wave-uniform 64-bit base that the scalar unit advances.  Written
+        // the plain way (below) each item cost a 64-bit multiply-add chain per k-tile: ~100 of the ~300 vector
+        // instructions a staged K/V tile costs the forward kernel.
+        constexpr int RPI = 256 / V4;
+        const int row_t = tid / V4, c4 = tid - row_t * V4;
+        const uint32_t voff = ((uint32_t)row_t * (uint32_t)ld + (uint32_t)c4 * 4u) * 2u;        // bytes, < T * ld * 2
+        const char* sb = reinterpret_cast<const char*>(base) + (long)row0 * ld * 2;
 #pragma unroll
-    for (int i = 0; i < DH / 16; ++i) {
-        int id = tid + 256 * i;
-        int row = id / V4, c4 = id - row * V4;
-        r[i] = (row < nvalid) ? *reinterpret_cast<const uint2*>(base + (long)(row0 + row) * ld + c4 * 4)
-                              : make_uint2(0u, 0u);
+        for (int i = 0; i < DH / 16; ++i)
+            r[i] = (row_t + RPI * i < nvalid) ? *reinterpret_cast<const uint2*>(sb + (long)(RPI * i) * ld * 2 + voff)
+                                              : make_uint2(0u, 0u);
+    } else {
+#pragma unroll
+        for (int i = 0; i < DH / 16; ++i) {
+            int id = tid + 256 * i;
+            int row = id / V4, c4 = id - row * V4;
+            r[i] = (row < nvalid) ? *reinterpret_cast<const uint2*>(base + (long)(row0 + row) * ld + c4 * 4)
+                                  : make_uint2(0u, 0u);
+        }
     }
 }
 template <int DH>
@@ -343,7 +359,7 @@ struct HSm {
 // head dims above 64 (dh = 192: the reference's shipped configuration, d_model 384 / 2 heads) keep 3x the accumulators
 // and operand fragments: they get the whole register file (one workgroup per CU) instead of spilling
 template <int DH, int DROP, bool QH>
-__global__ __launch_bounds__(256, DH > 64 ? 1 : 3) void hattn_fwd_kernel(HAttnP p) {
+__global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP p) {
     using SM = HSm<DH>;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
@@ -420,29 +436,35 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 3) void hattn_fwd_kernel(HAttnP 
             const int kbase = k0 + kt * 32;
             if (kbase >= klen || !wave_live) break;
             f32x16 s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                 // S^T[key][q]
+            // The 1 / sqrt(dh) scale (c1, log2 units) rides in the exponent's fma: p = 2^(s c1 - m).  Only a block with a
+            // padded key or the ragged tail needs the logits themselves scaled first (wave-uniform branch, rare).
+            float cs = c1;
+            if (anypad || kbase + 32 > klen) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] *= c1;
-            if (anypad) {
+                for (int r = 0; r < 16; ++r) s[r] *= c1;
+                if (anypad) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] += padS[kt * 32 + rowmap16(r, hh)] * (-1e9f * LOG2E);
-            }
-            if (kbase + 32 > klen) {
+                    for (int r = 0; r < 16; ++r) s[r] += padS[kt * 32 + rowmap16(r, hh)] * (-1e9f * LOG2E);
+                }
+                if (kbase + 32 > klen) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kbase + rowmap16(r, hh) >= klen) s[r] = -INFINITY;
+                    for (int r = 0; r < 16; ++r)
+                        if (kbase + rowmap16(r, hh) >= klen) s[r] = -INFINITY;
+                }
+                cs = 1.0f;
             }
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * cs;              // cs > 0: max commutes with the scale
             const float mn = fmaxf(m, mx);
             const float alpha = EXP2(m - mn);
-            float rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = EXP2(s[r] - mn);
-                rs += s[r];
-            }
+            for (int r = 0; r < 16; ++r) s[r] = EXP2(fmaf(s[r], cs, -mn));
+            f32x2 rs2 = {s[0], s[1]};                                 // pairwise: packed adds
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) rs2 += f32x2{s[r], s[r + 1]};
+            float rs = rs2[0] + rs2[1];
             // (the 1 / keep factor of inverted dropout is applied once, with the final 1 / l normalisation)
             if (DROP == 1) {
 #pragma unroll
@@ -613,9 +635,10 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dq_kernel(HAtt
                 hmask_request(mw, mrow + min((kbase >> 5) + 1, ntile32 - 1) * 16);      // the next block's words
             }
             // dS^T = P (keep * dP / (1 - p) - delta) / sqrt(dh): the 1 / keep factor rides in the fma
-            const float ik = DROP ? p.inv_keep : 1.0f;
+            // (the 1 / sqrt(dh) of dS is folded into both fma operands)
+            const float ik = (DROP ? p.inv_keep : 1.0f) * inv_sqrt, dl = delta * inv_sqrt;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = EXP2(s[r]) * fmaf(dp[r], ik, -delta) * inv_sqrt;
+            for (int r = 0; r < 16; ++r) s[r] = EXP2(s[r]) * fmaf(dp[r], ik, -dl);
             bf16x8 pb[2];
             to_frags(s, pb);
             accumTR<DH>(Ks, kt * 32, lane, pb, dq);                           // dQ^T += K^T.dS^T
@@ -724,7 +747,7 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
             ro.stash(Os, tid);
             if (tid < HKT) {
                 lseS[tid] = rl;
-                delS[tid] = rd;
+                delS[tid] = rd * inv_sqrt;                  // dS = P (keep dP / (1 - p) - delta) / sqrt(dh): scale folded in
                 if (DROP == 1) rbS[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0 + tid));
             }
             uint32_t mcur[HKT / 32];
@@ -747,6 +770,7 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
                 f32x16 s = dot16<DH>(Qs, qt * 32 + l31, hh, kf);             // S[q][key]
                 f32x16 dp = dot16<DH>(Os, qt * 32 + l31, hh, vf);            // dP = dO.V^T
                 f32x16 pt;
+                const float ik2 = (DROP ? p.inv_keep : 1.0f) * inv_sqrt;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = qt * 32 + rowmap16(r, hh);
@@ -765,7 +789,7 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
                     } else {
                         pt[r] = pr;
                     }
-                    s[r] = pr * fmaf(dpr, DROP ? p.inv_keep : 1.0f, -delS[ql]) * inv_sqrt;     // dS
+                    s[r] = pr * fmaf(dpr, ik2, -delS[ql]);                                     // dS
                 }
                 bf16x8 pb[2], sb[2];
                 to_frags(pt, pb);
@@ -830,27 +854,34 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
     return TTSMI_OK;
 }
 
-#define HLAUNCH(KERNEL, DHV, grid, st, p)                                                      \
+// `pad_lds`: dynamic LDS nobody touches, requested only to cap the workgroups per CU (see ttsmi_hattention_bwd)
+#define HLAUNCH(KERNEL, DHV, grid, pad_lds, st, p)                                             \
     do {                                                                                       \
         if (qh) {                                                                              \
-            if ((p).thr && (p).dmask) hipLaunchKernelGGL((KERNEL<DHV, 2, true>), grid, dim3(256), 0, st, p); \
-            else if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, true>), grid, dim3(256), 0, st, p);  \
-            else hipLaunchKernelGGL((KERNEL<DHV, 0, true>), grid, dim3(256), 0, st, p);          \
+            if ((p).thr && (p).dmask) hipLaunchKernelGGL((KERNEL<DHV, 2, true>), grid, dim3(256), pad_lds, st, p); \
+            else if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, true>), grid, dim3(256), pad_lds, st, p);  \
+            else hipLaunchKernelGGL((KERNEL<DHV, 0, true>), grid, dim3(256), pad_lds, st, p);          \
         } else {                                                                               \
-            if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, false>), grid, dim3(256), 0, st, p);  \
-            else hipLaunchKernelGGL((KERNEL<DHV, 0, false>), grid, dim3(256), 0, st, p);         \
+            if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, false>), grid, dim3(256), pad_lds, st, p);  \
+            else hipLaunchKernelGGL((KERNEL<DHV, 0, false>), grid, dim3(256), pad_lds, st, p);         \
         }                                                                                      \
     } while (0)
 
-#define HDISPATCH(dh, KERNEL, grid, st, p)                                                     \
+#define HDISPATCH_LDS(dh, KERNEL, grid, pad_lds, st, p)                                        \
     switch (dh) {                                                                              \
-        case 32: HLAUNCH(KERNEL, 32, grid, st, p); break;                                      \
-        case 64: HLAUNCH(KERNEL, 64, grid, st, p); break;                                      \
-        case 192: HLAUNCH(KERNEL, 192, grid, st, p); break;                                    \
+        case 32: HLAUNCH(KERNEL, 32, grid, pad_lds, st, p); break;                             \
+        case 64: HLAUNCH(KERNEL, 64, grid, pad_lds, st, p); break;                             \
+        case 192: HLAUNCH(KERNEL, 192, grid, 0, st, p); break;                                 \
         default:                                                                               \
             ttsmi_set_error("bf16 attention: head dim %d not built (32/64/192)", dh);          \
             return TTSMI_ERR_UNSUPPORTED;                                                      \
     }
+#define HDISPATCH(dh, KERNEL, grid, st, p) HDISPATCH_LDS(dh, KERNEL, grid, 0, st, p)
+
+static int henv(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 
 // ---- split-key forward (inference at small batch) ------------------------------------------------------------------
 // A forward whose B*H*ceil(T/128) workgroups do not fill the 256 CUs (batch 1, 2304 frames, 4 heads: 72 workgroups,
@@ -968,7 +999,8 @@ int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     p.dmask = (const uint64_t*)dropmask;
     p.ctx = (float*)ctx; p.lse = lse;
     dim3 grid(ttsmi_cdiv(T, 128) * H * B);
-    HDISPATCH(dh, hattn_fwd_kernel, grid, st, p);
+    static const int fwd_pad = henv("TTSMI_ATTN_FWD_LDS", 0);        // A/B knob: 24576 caps the forward at 3 workgroups per CU
+    HDISPATCH_LDS(dh, hattn_fwd_kernel, grid, fwd_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_fwd(bf16)");
     return TTSMI_OK;
 }
@@ -986,10 +1018,15 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     p.octx = (const float*)ctx; p.dctx = (const float*)dctx; p.lse = (float*)lse;
     p.dqkv = (float*)dqkv; p.delta = (float*)ws;
     dim3 grid(ttsmi_cdiv(T, 128) * H * B);
-    HDISPATCH(dh, hattn_bwd_dq_kernel, grid, st, p);
+    // Occupancy A/B knobs (untouched dynamic LDS caps the workgroups per CU).  Round 2, decoder shape, keep-bit dropout:
+    // forward 4 / 3 workgroups per CU = 69.0 / 86.9 us, dQ+dKV with dQ at 3 / 2 / 1 = 189.7 / 193.5 / 243.3 us - every
+    // kernel here wants all the waves its registers allow.
+    static const int dq_pad = henv("TTSMI_ATTN_DQ_LDS", 0);
+    HDISPATCH_LDS(dh, hattn_bwd_dq_kernel, grid, dq_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dq(bf16)");
     dim3 grid_kv(grid.x, dh > 64 ? dh / 64 : 1);
-    HDISPATCH(dh, hattn_bwd_dkv_kernel, grid_kv, st, p);
+    static const int dkv_pad = henv("TTSMI_ATTN_DKV_LDS", 0);
+    HDISPATCH_LDS(dh, hattn_bwd_dkv_kernel, grid_kv, dkv_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dkv(bf16)");
     return TTSMI_OK;
 }

@@ -1295,8 +1295,8 @@ static int hpick_splits(long rows, int tiles) {
     static int target = -1;
     if (target < 0) {
         const char* e = getenv("TTSMI_WGRAD_WGS");
-        target = e ? atoi(e) : 256;
-        if (target < 8) target = 256;
+        target = e ? atoi(e) : 128;
+        if (target < 8) target = 128;
     }
     int want = (target + tiles - 1) / tiles;
     if (want > 8) want = (want + 7) / 8 * 8;

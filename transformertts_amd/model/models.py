@@ -533,7 +533,7 @@ class ForwardTransformer:
         if overlap_pred:
             main = torch.cuda.current_stream()
             if self._pred_stream is None:
-                self._pred_stream = torch.cuda.Stream(device=self.device)
+                self._pred_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('TTSMI_PRED_PRIO', '0')))
             side = self._pred_stream
             side.wait_stream(main)                       # the encoder output is complete in main-stream order
             self._pred_keep = [h, pad_e]                 # the side stream reads them: alive until the join
@@ -596,7 +596,7 @@ class ForwardTransformer:
         l = ops._lib.lib()
         main = torch.cuda.current_stream()
         if self._pred_stream is None:
-            self._pred_stream = torch.cuda.Stream(device=self.device)
+            self._pred_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('TTSMI_PRED_PRIO', '0')))
         side = self._pred_stream
         side.wait_stream(main)                 # the step counter was advanced, and last step's readers are done
         # dropout-site numbering of call(): one site for each stack's entry LayerNorm, three per block (attention,

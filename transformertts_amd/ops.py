@@ -517,7 +517,7 @@ def _on_wgrad_stream(fn, *inputs):
     W = _WgradStream.cur()
     main = torch.cuda.current_stream()
     if W.stream is None:
-        W.stream = torch.cuda.Stream()
+        W.stream = torch.cuda.Stream(priority=_WGRAD_PRIO)
     side = W.stream
     side.wait_stream(main)                    # the operands were produced on the main stream
     global _PINNED_STREAM
@@ -554,7 +554,7 @@ def wgrad_rows_async(x, dy, dw, db, conv=None):
     if _WGRAD_GENERIC:
         return _on_wgrad_stream(lambda: hgemm_wgrad_rows(x, dy, dw, db, conv), x, dy)
     if W.stream is None:
-        W.stream = torch.cuda.Stream()
+        W.stream = torch.cuda.Stream(priority=_WGRAD_PRIO)
     if W.handle is None:
         W.handle = W.stream.cuda_stream
     ev = torch.cuda.Event()
@@ -1310,6 +1310,8 @@ class DenseBlockFn(torch.autograd.Function):
 # =================================================================================================
 # The same block with its launch sequence issued from C++ (ttsmi_dense_block_fwd / _bwd, include/ttsmi.h)
 # =================================================================================================
+# stream priority of the weight-gradient side stream (torch: -1 = high, 0 = default)
+_WGRAD_PRIO = int(os.environ.get('TTSMI_WGRAD_PRIO', '0'))
 FUSE_LN_MIN_ROWS_INFERENCE = int(os.environ.get('TTSMI_FUSE_LN_MIN_ROWS', '8192'))
 
 
@@ -1415,7 +1417,7 @@ class DenseBlockPlan:
         if _WgradStream.enabled:
             W = _WgradStream.cur()
             if W.stream is None:
-                W.stream = torch.cuda.Stream()
+                W.stream = torch.cuda.Stream(priority=_WGRAD_PRIO)
             if W.handle is None:
                 W.handle = W.stream.cuda_stream
             if W.ws is None or W.ws.numel() < self.wgrad_need:
