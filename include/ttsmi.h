@@ -299,6 +299,12 @@ int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int
                    const uint16_t* b, int64_t ldb, const float* bias, const float* relu_src,
                    int64_t ld_relu, void* c, int64_t ldc, int M, int N, int K, int flags,
                    int conv_taps, int conv_T, int conv_C, int conv_pad, ttsmi_stream_t stream);
+/* One launch for a K = 256 projection whose output columns go two ways (the output-projection dgrad of a dense block:
+ * d(h) += d_o . Wo_top^T in fp32 and d(ctx) = d_o . Wo_ctx^T in bf16 share the operand d_o - model/layers.py:148-150
+ * differentiated):  c_acc[M, :n_acc] += a[M, 256] . bt[:n_acc, 256]^T;  c_bf16[M, N - n_acc] = a . bt[n_acc:, 256]^T.
+ * a / bt bf16, n_acc a multiple of 128, 16-byte aligned operands and row pitches. */
+int ttsmi_hgemm_k256_split(const void* a, int64_t lda, const uint16_t* bt, int64_t ldb, float* c_acc, int64_t ldc_acc,
+                           int n_acc, void* c_bf16, int64_t ldc_bf16, int M, int N, ttsmi_stream_t stream);
 size_t ttsmi_hgemm_wgrad_ws_bytes(int rows, int kin, int n);
 int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, float* dw, int64_t lddw,
                       float* db, int rows, int kin, int n, void* ws, size_t ws_bytes,

@@ -819,6 +819,7 @@ def test_weight_stationary_k256_gemm_mask_and_accumulate(M):
     sh = ops.make_shadow(w2.to(DEV))
     h1 = (g(M, N, seed=3)).to(DEV).to(torch.bfloat16)
     h1[::7, ::5] = 0                                               # exact zeros and negatives both mask
+    h1[1::11, 3::7] = -0.0
     dh1 = ops.hgemm_tn(dy, sh.wb, relu_src=h1, out_bf16=True)
     want = (dy.double().cpu() @ _bf(w2).T) * (h1.double().cpu() > 0)
     assert rel_err(dh1.float(), want) < 5e-3
@@ -832,3 +833,27 @@ def test_weight_stationary_k256_gemm_mask_and_accumulate(M):
     # fp32 output with mask (not used by the model, covered for the ABI)
     out = ops.hgemm_tn(dy, sh.wb, relu_src=h1)
     assert rel_err(out, want) < 3e-6
+
+
+@pytest.mark.parametrize('M', [700, 5000, 28800])
+def test_k256_split_output_gemm(M):
+    """ttsmi_hgemm_k256_split: one launch for d(h) += d_o.Wo_top^T (fp32 accumulate) and d(ctx) = d_o.Wo_ctx^T (bf16),
+    against the two products computed in fp64 from the same bf16 operands; row tail (M % 64 != 0)."""
+    ops = _ops()
+    from transformertts_amd import _lib
+    from transformertts_amd.ops import _p, _stream, check
+    l = _lib.lib()
+    d = 256
+    d_o = g(M, d, seed=1).to(DEV).to(torch.bfloat16)
+    wo = g(2 * d, d, seed=2, scale=0.1)                              # Wo as stored [2d, d]
+    sh = ops.make_shadow(wo.to(DEV))
+    dh0 = g(M, d, seed=3).to(DEV)
+    dh = dh0.clone()
+    dctx = torch.full((M, d), float('nan'), device=DEV, dtype=torch.bfloat16)
+    check(l.ttsmi_hgemm_k256_split(_p(d_o), d, _p(sh.wb), d, _p(dh), d, d, _p(dctx), d, M, 2 * d, _stream()))
+    torch.cuda.synchronize()
+    a = d_o.double().cpu()
+    assert rel_err(dh, dh0.double().cpu() + a @ _bf(wo[:d]).T) < 3e-6
+    assert rel_err(dctx.float(), a @ _bf(wo[d:]).T) < 5e-3
+    with pytest.raises(_lib.TtsmiError):
+        check(l.ttsmi_hgemm_k256_split(_p(d_o), d, _p(sh.wb), d, _p(dh), d, 100, _p(dctx), d, M, 2 * d, _stream()))

@@ -73,6 +73,7 @@ SIGNATURES = {
     'ttsmi_stft_logmel': (I, [P, P, P, I, L, I, I, P, I, P, P, P, P, I, F, P, S]),
     'ttsmi_cast_f32_to_bf16': (I, [P, P, L, S]),
     'ttsmi_hgemm_tn': (I, [P, I, L, P, L, I, P, L, P, P, L, P, L, I, I, I, I, I, I, I, I, S]),
+    'ttsmi_hgemm_k256_split': (I, [P, L, P, L, P, L, I, P, L, I, I, S]),
     'ttsmi_hgemm_wgrad_ws_bytes': (c_size_t, [I, I, I]),
     'ttsmi_hgemm_wgrad': (I, [P, P, L, P, L, P, I, I, I, P, c_size_t, S]),
     'ttsmi_cast_transpose_bf16': (I, [P, L, P, L, I, I, I, I, I, S]),

@@ -50,7 +50,7 @@ int ttsmi_hattention_dropmask(void* mask, int B, int H, int T, float p_drop, uin
 // weight-stationary K = 256 GEMM (gemm_k256.hip), reached through ttsmi_hgemm_tn
 extern "C" int ttsmi_hgemm_k256_eligible(int M, int N, int K);
 int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, long ldb, const float* bias, void* c, long ldc,
-                            int M, int N, int relu, int out_bf16, hipStream_t st);
+                            int M, int N, int relu, int out_bf16, const uint16_t* mask, long ldmask, hipStream_t st);
 
 // ---- wave64 reductions ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -152,12 +152,21 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     }
     TRY(wgrad_side(D, 2, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
     TRY(wgrad_side(D, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
-    { OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 4, true), st);
-      TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b, d, nullptr, nullptr, 0, D->dh, d, M, d, d,
-                         TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st)); }                                     // dh += do.Wo_top^T
-    { OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 2, false), st);
-      TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b + (long)d * d, d, nullptr, nullptr, 0, D->dctx, d, M, d, d,
-                         TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
+    // dh += do.Wo_top^T (fp32) and dctx = do.Wo_ctx^T (bf16): Wo as stored is [2d][d] = both weight halves back to back,
+    // and both products read d_o - one weight-stationary launch when the shape suits it (d = 256, decoder-size M)
+    static int split_ok = -1;           // TTSMI_DENSE_SPLIT_DGRAD=0: two launches (A/B knob)
+    if (split_ok < 0) { const char* e = getenv("TTSMI_DENSE_SPLIT_DGRAD"); split_ok = e ? atoi(e) : 1; }
+    if (split_ok && d == 256 && ttsmi_hgemm_k256_eligible(M, 2 * d, d)) {
+        OBS("ttsmi_hgemm_tn", 2.0 * M * d * 2 * d, gemm_bytes(M, d, d, 4, true) + gemm_bytes(M, d, d, 2, false) - (double)M * d * 2, st);
+        TRY(ttsmi_hgemm_k256_split(D->d_o, d, D->wo_b, d, D->dh, d, d, D->dctx, d, M, 2 * d, st));
+    } else {
+        { OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 4, true), st);
+          TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b, d, nullptr, nullptr, 0, D->dh, d, M, d, d,
+                             TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st)); }                                 // dh += do.Wo_top^T
+        { OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 2, false), st);
+          TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b + (long)d * d, d, nullptr, nullptr, 0, D->dctx, d, M, d, d,
+                             TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
+    }
     // ---- attention + qkv projection
     {
     const double T2 = (double)D->T * D->T;

@@ -1336,11 +1336,15 @@ int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int
     if (mask_bf16) TTSMI_CHECK_ARG(N % 4 == 0 && ld_relu % 4 == 0, "hgemm_tn: bf16 mask needs N %% 4 == 0");
     p.M = M; p.N = N; p.K = K; p.relu = relu ? 1 : 0; p.accumulate = accumulate ? 1 : 0; p.k_per_split = K;
     if (conv_taps > 1) { p.a_taps = conv_taps; p.T = conv_T; p.Cw = conv_C; p.pad = conv_pad; }
-    // K = 256 projections without a second segment / mask / accumulation: weight-stationary kernel (gemm_k256.hip)
-    if (!a_is_f32 && !a2 && !relu_src && !accumulate && conv_taps <= 1 && lda % 8 == 0 && ldc % 4 == 0 &&
+    // K = 256 projections without a second segment / accumulation: weight-stationary kernel (gemm_k256.hip); a ReLU' mask
+    // is supported in its bf16 -> bf16 form (the masked FFN1 dgrad)
+    const bool k256_mask_ok = !relu_src || (mask_bf16 && c_bf16 && !bias && !relu && ld_relu % 8 == 0 && al16(relu_src));
+    static int k256_mask = -1;          // TTSMI_HGEMM_K256_MASK=0: masked launches stay on the general kernel (A/B knob)
+    if (k256_mask < 0) { const char* e = getenv("TTSMI_HGEMM_K256_MASK"); k256_mask = e ? atoi(e) : 1; }
+    if (!a_is_f32 && !a2 && k256_mask_ok && (!relu_src || k256_mask) && !accumulate && conv_taps <= 1 && lda % 8 == 0 && ldc % 4 == 0 &&
         (c_bf16 ? ldc % 8 == 0 : true) && al16(c) && ttsmi_hgemm_k256_eligible(M, N, K)) {
         ttsmi_hgemm_k256_launch((const uint16_t*)a, (long)lda, b, (long)ldb, bias, c, (long)ldc, M, N, relu ? 1 : 0,
-                                c_bf16 ? 1 : 0, (hipStream_t)stream);
+                                c_bf16 ? 1 : 0, (const uint16_t*)relu_src, (long)ld_relu, (hipStream_t)stream);
         TTSMI_CHECK_LAUNCH("hgemm_tn(k256)");
         return TTSMI_OK;
     }

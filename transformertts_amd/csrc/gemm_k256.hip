@@ -40,6 +40,9 @@ struct K256P {
     int relu;
     int M, N;
     int nchunks, ngroups, ntiles;
+    const uint16_t* mask; long ldmask;      // MODE 2: bf16 [M, N], output kept where mask > 0 (ReLU' of the saved activation)
+    void* C2; long ldc2; int n_acc;         // MODE 3: columns < n_acc (a multiple of 128) are ADDED to the fp32 C, the
+                                            // rest leave as bf16 into C2 (column n -> C2[., n - n_acc])
 };
 
 __device__ __forceinline__ void kw_dma16(const void* gsrc, unsigned lds_off) {
@@ -55,10 +58,14 @@ __device__ __forceinline__ uint2 kw_pack4(float a, float b, float c, float d) {
     return *reinterpret_cast<uint2*>(&h);
 }
 
-template <bool OUT_H>
+// MODE 0: fp32 C; 1: bf16 C; 2: bf16 C with a bf16 ReLU' mask (the masked FFN1 dgrad); 3: fp32 accumulate for the first
+// n_acc columns, bf16 C2 for the rest (one launch for the two halves of the output-projection dgrad: d(h) += and d(ctx))
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
-    constexpr int SLD = OUT_H ? (KW_BN + 8) : (KW_BN + 4);                 // staging row stride (elements)
-    constexpr int STAGING = KW_BM * SLD * (OUT_H ? 2 : 4);
+    constexpr bool OUT_H = MODE == 1 || MODE == 2;
+    constexpr int SLD_H = KW_BN + 8, SLD_F = KW_BN + 4;                    // staging row strides (elements)
+    constexpr int SLD = OUT_H ? SLD_H : SLD_F;
+    constexpr int STAGING = KW_BM * (OUT_H ? SLD_H * 2 : SLD_F * 4);        // MODE 3 stages either type in the fp32-sized tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[KW_STAGES * KW_STAGE + STAGING];
     unsigned char* stg = smem + KW_STAGES * KW_STAGE;
 
@@ -123,6 +130,32 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
         }
         kw_barrier();                    // everybody's pieces landed; stage (it-1)%3 and the staging tile are retired
         if (loader && it + 2 < my_tiles) issue(it + 2, (it + 2) % KW_STAGES);
+        // epilogue operands from global memory (the mask / the accumulate target) are requested by the storing waves NOW,
+        // a whole multiply ahead of their use; everything older on their vmcnt is the previous tile's stores
+        uint4 pre_m[4];
+        float4 pre_c[8];
+        const bool acc_chunk = MODE == 3 && chunk * KW_BN < p.n_acc;       // workgroup-uniform
+        if (MODE >= 2 && !loader) {
+            const int st_tid = tid - 256;
+            const int m0 = (group + it * p.ngroups) * KW_BM, ncol0 = chunk * KW_BN;
+            if (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = (st_tid >> 4) + 16 * j, c8 = (st_tid & 15) * 8;
+                    pre_m[j] = (m0 + row < p.M && ncol0 + c8 < p.N)
+                                   ? *reinterpret_cast<const uint4*>(p.mask + (long)(m0 + row) * p.ldmask + ncol0 + c8)
+                                   : make_uint4(0u, 0u, 0u, 0u);
+                }
+            } else if (acc_chunk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int row = (st_tid >> 5) + 8 * j, c4 = (st_tid & 31) * 4;
+                    pre_c[j] = (m0 + row < p.M && ncol0 + c4 < p.N)
+                                   ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + (long)(m0 + row) * p.ldc + ncol0 + c4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
         const unsigned char* As = smem + (it % KW_STAGES) * KW_STAGE;
         f32x16 acc;
 #pragma unroll
@@ -138,13 +171,13 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
             for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
         }
         // ---- C^T -> row-major staging tile [64][128]
-        if constexpr (OUT_H) {
-            uint16_t* st = reinterpret_cast<uint16_t*>(stg) + arow * SLD + wn * 32 + 4 * hh;
+        if (OUT_H || (MODE == 3 && !acc_chunk)) {
+            uint16_t* st = reinterpret_cast<uint16_t*>(stg) + arow * SLD_H + wn * 32 + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<uint2*>(st + 8 * g) = kw_pack4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
         } else {
-            float* st = reinterpret_cast<float*>(stg) + arow * SLD + wn * 32 + 4 * hh;
+            float* st = reinterpret_cast<float*>(stg) + arow * SLD_F + wn * 32 + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(st + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
@@ -155,21 +188,35 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
         const int st_tid = tid - 256;
         const int m0 = (group + it * p.ngroups) * KW_BM;
         const int ncol0 = chunk * KW_BN;
-        if constexpr (OUT_H) {
+        if (MODE >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the prefetched epilogue operands
+        if (OUT_H || (MODE == 3 && !acc_chunk)) {
+            uint16_t* dstb = MODE == 3 ? reinterpret_cast<uint16_t*>(p.C2) : reinterpret_cast<uint16_t*>(p.C);
+            const long ldd = MODE == 3 ? p.ldc2 : p.ldc;
+            const int cd0 = MODE == 3 ? ncol0 - p.n_acc : ncol0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = (st_tid >> 4) + 16 * j, c8 = (st_tid & 15) * 8;
-                if (m0 + row < p.M && ncol0 + c8 < p.N)
-                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + (long)(m0 + row) * p.ldc + ncol0 + c8) =
-                        *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(stg) + row * SLD + c8);
+                if (m0 + row < p.M && ncol0 + c8 < p.N) {
+                    uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(stg) + row * SLD_H + c8);
+                    if (MODE == 2) {
+                        // bf16 halves of a word: > 0  <=>  the half, moved to the top of an int32, is > 0
+                        auto sel = [](uint32_t m) {
+                            return (((int32_t)(m << 16) > 0) ? 0x0000FFFFu : 0u) | (((int32_t)(m & 0xFFFF0000u) > 0) ? 0xFFFF0000u : 0u);
+                        };
+                        v.x &= sel(pre_m[j].x); v.y &= sel(pre_m[j].y); v.z &= sel(pre_m[j].z); v.w &= sel(pre_m[j].w);
+                    }
+                    *reinterpret_cast<uint4*>(dstb + (long)(m0 + row) * ldd + cd0 + c8) = v;
+                }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int row = (st_tid >> 5) + 8 * j, c4 = (st_tid & 31) * 4;
-                if (m0 + row < p.M && ncol0 + c4 < p.N)
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)(m0 + row) * p.ldc + ncol0 + c4) =
-                        *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(stg) + row * SLD + c4);
+                if (m0 + row < p.M && ncol0 + c4 < p.N) {
+                    float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(stg) + row * SLD_F + c4);
+                    if (MODE == 3) { v.x += pre_c[j].x; v.y += pre_c[j].y; v.z += pre_c[j].z; v.w += pre_c[j].w; }
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)(m0 + row) * p.ldc + ncol0 + c4) = v;
+                }
             }
         }
     }
@@ -188,21 +235,45 @@ int ttsmi_hgemm_k256_eligible(int M, int N, int K) {
 
 }  // extern "C"
 
-int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, long ldb, const float* bias, void* c, long ldc,
-                            int M, int N, int relu, int out_bf16, hipStream_t st) {
-    K256P p;
-    memset(&p, 0, sizeof(p));
-    p.A = a; p.lda = lda; p.Bt = bt; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.relu = relu; p.M = M; p.N = N;
-    p.nchunks = ttsmi_cdiv(N, KW_BN);
-    p.ntiles = ttsmi_cdiv(M, KW_BM);
+static void kw_plan(K256P& p) {
+    p.nchunks = ttsmi_cdiv(p.N, KW_BN);
+    p.ntiles = ttsmi_cdiv(p.M, KW_BM);
     // one workgroup per CU: groups = a multiple of 8 with chunks x groups <= 256 (at least 8)
     int groups = (256 / p.nchunks) / 8 * 8;
     if (groups < 8) groups = 8;
     const int need = (p.ntiles + 7) / 8 * 8;
     if (groups > need) groups = need;
     p.ngroups = groups;
+}
+
+// mask != nullptr: bf16 output (out_bf16 must be set) kept where the bf16 mask[M, N] is > 0
+int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, long ldb, const float* bias, void* c, long ldc,
+                            int M, int N, int relu, int out_bf16, const uint16_t* mask, long ldmask, hipStream_t st) {
+    K256P p;
+    memset(&p, 0, sizeof(p));
+    p.A = a; p.lda = lda; p.Bt = bt; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.relu = relu; p.M = M; p.N = N;
+    p.mask = mask; p.ldmask = ldmask;
+    kw_plan(p);
     dim3 grid(p.nchunks * p.ngroups);
-    if (out_bf16) hipLaunchKernelGGL((gemm_k256_kernel<true>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((gemm_k256_kernel<false>), grid, dim3(512), 0, st, p);
+    if (mask) hipLaunchKernelGGL((gemm_k256_kernel<2>), grid, dim3(512), 0, st, p);
+    else if (out_bf16) hipLaunchKernelGGL((gemm_k256_kernel<1>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gemm_k256_kernel<0>), grid, dim3(512), 0, st, p);
     return 0;
+}
+
+extern "C" int ttsmi_hgemm_k256_split(const void* a, int64_t lda, const uint16_t* bt, int64_t ldb, float* c_acc, int64_t ldc_acc,
+                                      int n_acc, void* c_bf16, int64_t ldc_bf16, int M, int N, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(a && bt && c_acc && c_bf16, "hgemm_k256_split: null pointer");
+    TTSMI_CHECK_ARG(M > 0 && N > n_acc && n_acc > 0 && n_acc % KW_BN == 0 && N % 8 == 0, "hgemm_k256_split: bad shape M=%d N=%d n_acc=%d", M, N, n_acc);
+    TTSMI_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc_acc % 4 == 0 && ldc_bf16 % 8 == 0 &&
+                    ((((uintptr_t)a) | ((uintptr_t)bt) | ((uintptr_t)c_acc) | ((uintptr_t)c_bf16)) & 15) == 0,
+                    "hgemm_k256_split: operands must be 16-byte aligned with 16-byte row pitches");
+    K256P p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const uint16_t*)a; p.lda = lda; p.Bt = bt; p.ldb = ldb; p.C = c_acc; p.ldc = ldc_acc; p.M = M; p.N = N;
+    p.C2 = c_bf16; p.ldc2 = ldc_bf16; p.n_acc = n_acc;
+    kw_plan(p);
+    hipLaunchKernelGGL((gemm_k256_kernel<3>), dim3(p.nchunks * p.ngroups), dim3(512), 0, (hipStream_t)stream, p);
+    TTSMI_CHECK_LAUNCH("hgemm_k256_split");
+    return TTSMI_OK;
 }
