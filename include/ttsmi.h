@@ -428,6 +428,15 @@ typedef struct ttsmi_dense_block {
     uint64_t attn_ws_bytes, ln_ws_bytes, wgrad_ws_bytes;
     ttsmi_stream_t main_stream, side_stream;      /* side_stream == NULL: weight gradients on the main stream */
     ttsmi_event_t ev[4];                          /* main -> side hand-offs of the four weight-gradient groups */
+    /* Backward chaining of consecutive blocks of a stack (both fuse_ln): the gradient of THIS block's input is the
+     * upstream gradient of res-norm 2 of the block below, and this block's last dgrad (dqkv . Wqkv^T) completes it - with
+     * `below` set that GEMM runs as ttsmi_hgemm_ln_bwd on the lower block's x^2 / rstd2 / gamma2 and writes ITS df, da and
+     * res-norm-2 parameter partials (lnp_ws2, ttsmi_hgemm_ln_bwd_nparts rows), so the input gradient never reaches HBM
+     * and the lower block's own ttsmi_layernorm_bwd_xhat launch disappears.  The lower block is then run with
+     * ln2_done != 0: its `dout` argument is ignored.  Only valid when this block is the sole consumer of the lower
+     * block's output. */
+    const struct ttsmi_dense_block* below;
+    int32_t ln2_done, _pad1;
 } ttsmi_dense_block;
 /* Measurement hook: when set, ttsmi_dense_block_fwd/_bwd announce every launch group they issue - phase 0 before, 1 after
  * it is enqueued - with the entry point's name, its algorithmic FLOPs and bytes and the stream it goes to, so a profiler

@@ -108,7 +108,7 @@ def _dense_block_fields():
             [(n, p) for n in ptrs] + [('fuse_ln', i32), ('attn_split', i32)] +
             [(n, p) for n in ('xhat1', 'xhat2', 'lnp_ws1', 'lnp_ws2')] + [('lnp_ws1_bytes', u64), ('lnp_ws2_bytes', u64)] +
             [(n, p) for n in ptrs2] + [(n, u64) for n in ('attn_ws_bytes', 'ln_ws_bytes', 'wgrad_ws_bytes')] +
-            [('main_stream', p), ('side_stream', p), ('ev', p * 4)])
+            [('main_stream', p), ('side_stream', p), ('ev', p * 4), ('below', p), ('ln2_done', i32), ('_pad1', i32)])
 
 
 class DenseBlockDesc(ctypes.Structure):

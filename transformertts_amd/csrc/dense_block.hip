@@ -119,15 +119,18 @@ static int wgrad_side(const ttsmi_dense_block* D, int ev, bool record, const uin
 
 int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf, const float* dout) {
     TRY(check_desc(D, "dense_block_bwd"));
-    TTSMI_CHECK_ARG(h && h_bf && dout, "dense_block_bwd: null input");
+    TTSMI_CHECK_ARG(h && h_bf && (dout || (D->fuse_ln && D->ln2_done)), "dense_block_bwd: null input");
     const int M = D->B * D->T, d = D->d, F = D->F, dh = d / D->H;
     ttsmi_stream_t st = D->main_stream;
     const bool dropout = D->rate > 0.f;
     // ---- LN2 + FFN: df (bf16) = dLN2/dx, da (fp32) = dLN2/dres
     if (D->fuse_ln) {
-        OBS("ttsmi_layernorm_bwd_xhat", 0.0, (double)M * d * (4 + 2 + 2 + 4), st);
-        TRY(ttsmi_layernorm_bwd_xhat(dout, D->xhat2, D->rstd2, D->ln2_g, D->pad, D->rate, D->site_ln2, D->seed, D->step_dev,
-                                     D->df, D->da, D->lnp_ws2, D->lnp_ws2_bytes, M, d, st));
+        if (!D->ln2_done) {         // (chained: the block above already left df / da / the parameter partials)
+            TTSMI_CHECK_ARG(dout, "dense_block_bwd: null dout");
+            OBS("ttsmi_layernorm_bwd_xhat", 0.0, (double)M * d * (4 + 2 + 2 + 4), st);
+            TRY(ttsmi_layernorm_bwd_xhat(dout, D->xhat2, D->rstd2, D->ln2_g, D->pad, D->rate, D->site_ln2, D->seed, D->step_dev,
+                                         D->df, D->da, D->lnp_ws2, D->lnp_ws2_bytes, M, d, st));
+        }
     } else
         TRY(ttsmi_add_layernorm_bwd(dout, D->f, D->a, D->ln2_g, D->mean2, D->rstd2, nullptr, nullptr, 0, D->pad, D->rate,
                                     D->site_ln2, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->da, D->da, nullptr,
@@ -179,6 +182,16 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
                                 D->seed, D->step_dev, D->site_attn, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));
     }
     TRY(wgrad_side(D, 3, true, h_bf, d, D->dqkv, 3 * d, D->g_wqkv, D->g_bqkv, d, 3 * d));
+    const ttsmi_dense_block* L = D->below;
+    if (D->fuse_ln && L != nullptr) {
+        // dh + dqkv.Wqkv^T is the upstream gradient of the lower block's res-norm 2: its backward runs in this epilogue
+        TTSMI_CHECK_ARG(L->fuse_ln && L->ln2_done && L->B == D->B && L->T == D->T && L->d == d,
+                        "dense_block_bwd: `below` is not a chained block of the same shape");
+        OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * 3 * d, gemm_bytes(M, d, 3 * d, 4, true, (double)M * d * (2 + 2)), st);
+        TRY(ttsmi_hgemm_ln_bwd(D->dqkv, 3L * d, D->wqkv_b, 3L * d, D->dh, L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate,
+                               L->site_ln2, L->seed, L->step_dev, L->df, L->da, L->lnp_ws2, L->lnp_ws2_bytes, M, d, 3 * d, st));
+        return TTSMI_OK;
+    }
     OBS("ttsmi_hgemm_tn", 2.0 * M * d * 3 * d, gemm_bytes(M, d, 3 * d, 4, true), st);
     TRY(ttsmi_hgemm_tn(D->dqkv, 0, 3L * d, nullptr, 0, 0, D->wqkv_b, 3L * d, nullptr, nullptr, 0, D->dh, d, M, d, 3 * d,
                        TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                       // dh += dqkv.Wqkv^T

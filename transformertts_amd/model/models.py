@@ -212,6 +212,8 @@ class ForwardTransformer:
         self._const_masks: Dict[tuple, torch.Tensor] = {}
         self.planned_blocks = bool(kwargs.get('planned_blocks', True))
         self.fuse_ln = bool(kwargs.get('fuse_ln', True))               # res-norms in the GEMM epilogues (d_model 256)
+        # consecutive planned blocks: the upper block's last dgrad runs the lower block's res-norm-2 backward in its epilogue
+        self.chain_ln = bool(kwargs.get('chain_ln', True)) and os.environ.get('TTSMI_LN_CHAIN', '1') != '0'
         self._use_plans, self._plans, self._plan_shared = False, {}, {}
         self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}
@@ -353,12 +355,16 @@ class ForwardTransformer:
         attn = OrderedDict()
         dtype = ops._lib.TTSMI_BF16 if self.precision == 'bf16' else ops.TTSMI_F32
         h_bf = None                      # bf16 copy of h written by the previous block's LayerNorm (TTSMI_BF16)
+        below = None                     # the planned block whose output feeds the current one (backward chaining)
         for i, H in enumerate(heads):
             p = f'{prefix}.blk{i}'
             dense = i < dense_blocks
             if dense and self.fused_blocks and self._use_plans and self._plan_ok(p, H, d):
                 # launch sequence of the block issued from C++ (ops.DenseBlockPlan): two host calls per block and step
                 plan = self._block_plan(p, prefix, B, H, T)
+                if below is not None:    # this block is the only consumer of the lower block's output (taps are detached)
+                    below.chain_above(plan if self.chain_ln and torch.is_grad_enabled() else None)
+                below = plan
                 sites = (drop.site(), drop.site(), drop.site())
                 dmask = None
                 pre = self._dropmask_plan.get(p) if self._dropmask_plan else None
@@ -377,6 +383,9 @@ class ForwardTransformer:
                 if self._taps is not None:
                     self._taps.append((p, h.detach().reshape(B, T, d)))
                 continue
+            if below is not None:
+                below.chain_above(None)
+                below = None
             if dense and self.fused_blocks:
                 # one autograd node per block (ops.DenseBlockFn); sites in the per-layer order
                 Pb, Gb, Sb = self._block_views(p)
@@ -429,6 +438,8 @@ class ForwardTransformer:
                                   G[f'{p}.ln2.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop)
             if self._taps is not None:
                 self._taps.append((p, h.detach().reshape(B, T, d)))
+        if below is not None:
+            below.chain_above(None)          # the stack's last block: its output gradient comes from outside
         return h.reshape(B, T, d), attn
 
     def _plan_ok(self, p, H, d) -> bool:

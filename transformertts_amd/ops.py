@@ -1357,7 +1357,8 @@ class DenseBlockPlan:
             for name in ('xhat1', 'xhat2'):
                 t[name] = e((M, d), bf)
             t['lnp_ws1'] = _ws(l.ttsmi_layernorm_partials_bytes(self.lnp_nw1, d), device)
-            t['lnp_ws2'] = _ws(l.ttsmi_layernorm_partials_bytes(self.lnp_nw2, d), device)
+            # (res-norm 2's partials come from ttsmi_layernorm_bwd_xhat, or - chained - from the GEMM epilogue of the block above)
+            t['lnp_ws2'] = _ws(l.ttsmi_layernorm_partials_bytes(max(self.lnp_nw1, self.lnp_nw2), d), device)
         key = (B, H, T, d, self.backward)
         if key not in shared:
             shared[key] = ({'da': e((M, d), f32), 'dctx': e((M, d), bf),
@@ -1396,7 +1397,21 @@ class DenseBlockPlan:
         for i, ev in enumerate(self.events):
             D.ev[i] = ev.cuda_event
         self.G = G
+        self.above = None
         self._dref = ctypes.byref(D)
+
+    def chain_above(self, above):
+        """`above` consumes this block's output and nothing else does: its backward finishes this block's res-norm-2
+        backward in the epilogue of its last dgrad (ttsmi_dense_block.below).  None unlinks."""
+        ok = (above is not None and self.fuse_ln and above.fuse_ln and self.backward and above.backward and
+              (above.B, above.T, above.d) == (self.B, self.T, self.d))
+        if self.above is not None and self.above is not above:
+            self.above.desc.below = None
+        self.above = above if ok else None
+        self.desc.ln2_done = int(ok)
+        if ok:
+            above.desc.below = ctypes.addressof(self.desc)
+        return ok
 
     def bind(self, pad, klen, rate, drop, sites, dmask):
         """Per-step inputs of the descriptor (masks are new tensors every step; the rest rarely changes)."""
@@ -1434,7 +1449,8 @@ class DenseBlockPlan:
 
         def defer():
             if self.fuse_ln:       # partial rows left by ttsmi_layernorm_bwd_xhat / the epilogue of ttsmi_hgemm_ln_bwd
-                _ln_defer(t['lnp_ws2'], G['ln2.gamma'], G['ln2.beta'], None, M, d, self.lnp_nw2)
+                _ln_defer(t['lnp_ws2'], G['ln2.gamma'], G['ln2.beta'], None, M, d,
+                          self.lnp_nw1 if D.ln2_done else self.lnp_nw2)
                 _ln_defer(t['lnp_ws1'], G['ln1.gamma'], G['ln1.beta'], None, M, d, self.lnp_nw1)
             else:
                 _ln_defer(t['ln_ws2'], G['ln2.gamma'], G['ln2.beta'], None, M, d)
