@@ -277,6 +277,20 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
                       float* out, ttsmi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Griffin-Lim phase reconstruction: the iteration loop of librosa.core.griffinlim (0.7.1, momentum form) that
+ * data/audio.py:94-110 (reconstruct_waveform) runs on the CPU, as a GPU iSTFT / STFT loop.  n_fft = 1024.
+ * mag     [T][513] fp32 linear-magnitude spectrogram, FRAME-major (librosa's [513, T] transposed);
+ * angles  [T][513][2] fp32 unit phases (re, im): the start phases on entry (the caller draws them - the reference's
+ *         are unseeded random), the final phases on return;
+ * window  [1024] fp32: get_window('hann', win_length, fftbins=True) centred in n_fft (analysis = synthesis window);
+ * wss     [n_fft + hop (T - 1)] fp32: librosa.filters.window_sumsquare of that window (the overlap-add envelope);
+ * wav     [hop (T - 1)] fp32: istft(mag * angles) after n_iter iterations (center = True: n_fft / 2 trimmed each side).
+ * ------------------------------------------------------------------------------------------- */
+size_t ttsmi_griffinlim_ws_bytes(int T);
+int ttsmi_griffinlim(const float* mag, float* angles, const float* window, const float* wss, int T, int n_fft, int hop,
+                     int n_iter, float momentum, float* wav, void* ws, size_t ws_bytes, ttsmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * TTSMI_BF16 GEMM path: bf16 operands (round to nearest even), fp32 accumulate on
  * v_mfma_f32_32x32x16_bf16, fp32 results.  Same reference ops as the fp32 family above
  * (Dense / Conv1D forward, dgrad, wgrad); the callers provide K-contiguous operands:

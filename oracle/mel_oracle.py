@@ -116,6 +116,13 @@ def wavernn_normalize(S, min_level_db=-100, max_norm=4):
     return (S * 2 * max_norm) - max_norm
 
 
+def wavernn_denormalize(S, min_level_db=-100, max_norm=4):
+    """WaveRNN.denormalize data/audio.py:233-236,241-242."""
+    S = (S + max_norm) / (2 * max_norm)
+    S = (np.clip(S, 0, 1) * -min_level_db) + min_level_db
+    return np.power(10.0, S * 0.05)
+
+
 def mel_spectrogram(wav, sampling_rate=22050, n_fft=1024, mel_channels=80, hop_length=256,
                     win_length=1024, f_min=0, f_max=8000, normalizer='MelGAN', exact=False):
     """Audio.mel_spectrogram data/audio.py:88-92.  Returns float32 [frames, mel_channels].

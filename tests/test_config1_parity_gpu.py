@@ -33,12 +33,16 @@ BOUNDS = {
     # grad_vec: bias / LayerNorm vectors are column sums over all B*T rows with heavy cancellation (the FFN hidden bias
     # worst of all): fp32 summation itself is at 2-3e-4 of the tensor's scale there - the torch-CPU fp32 run of the
     # ORACLE differs from its own fp64 run by 2.7e-4 on dec.blk2.ffn.b1 - so vectors get 4e-4, matrices keep 2e-4
-    'f32': dict(fwd=1e-4, loss=1e-4, grad=2e-4, grad_vec=4e-4, gnorm=2e-4, tap=1e-4),
+    'f32': dict(fwd=1e-4, loss=1e-4, grad=2e-4, grad_embedding=2e-4, grad_vec=4e-4, gnorm=2e-4, tap=1e-4),
     # bf16 bounds = about twice what the path achieves on these two batches (round 2, fused-LayerNorm build: mel /
     # duration / pitch 0.9-1.0 %, loss 2e-4, block outputs 0.2 % at depth 1 growing to 0.7 % at depth 12, matrices
     # <= 3.7 % (embedding), vectors <= 5.4 % (the positional-encoding scalars: one number, a sum with cancellation);
     # on the max-shape batch: duration 1.6 %, pitch 1.3 %, total loss 5.3e-4, the small pitch-loss component 2.0e-3)
-    'bf16': dict(fwd=3e-2, loss=4e-3, grad=7e-2, grad_vec=1e-1, gnorm=1e-1, tap=1.5e-2),
+    # The embedding table's gradient is judged on its own: it sits below all 6 encoder blocks AND is a scatter-sum over the
+    # ~6 occurrences of each token, so it carries the most bf16 noise of any tensor - 3.1 % / 6.6 % (max element error
+    # over max element) on the two batches, moving by a factor of two when a kernel's rounding order changes; every
+    # other matrix stays below 3 %.
+    'bf16': dict(fwd=3e-2, loss=4e-3, grad=6e-2, grad_embedding=1.3e-1, grad_vec=1e-1, gnorm=1e-1, tap=1.5e-2),
 }
 
 
@@ -99,7 +103,9 @@ def _compare(gold, tag, m, out, bounds):
         absmax, l2, total = g(f'gstat::{k}')
         scale = max(absmax, 1e-3 * gmax)
         e = float(np.abs(a[g1.sample_index(k, a.size)] - g(f'g::{k}')).max() / scale)
-        if grads[k].ndim <= 1:
+        if k == 'embedding':
+            report['grad_embedding'] = e
+        elif grads[k].ndim <= 1:
             if e > worst_vec[1]:
                 worst_vec = (k, e)
         elif e > worst[1]:
@@ -120,6 +126,7 @@ def _check(report, b):
     for name, e in report['taps'].items():
         assert e < b['tap'], (name, e)
     assert report['grad_worst'][1] < b['grad'], report['grad_worst']
+    assert report['grad_embedding'] < b['grad_embedding'], report['grad_embedding']
     assert report['grad_vec_worst'][1] < b['grad_vec'], report['grad_vec_worst']
     assert report['gnorm_worst'][1] < b['gnorm'], report['gnorm_worst']
 

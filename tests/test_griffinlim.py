@@ -1,0 +1,122 @@
+"""Griffin-Lim (data/audio.py:94-110).
+
+CPU part: the oracle restatement of librosa 0.7.1's mel_to_stft / istft / griffinlim against anchors that need no
+librosa (the package is not installable here: parity unpinned, see oracle/griffinlim_oracle.py) and the product's
+host-side NNLS against the oracle's.  GPU part: ttsmi_griffinlim against the oracle with the start phases fixed."""
+import numpy as np
+import pytest
+import scipy.signal
+import torch
+
+from oracle import griffinlim_oracle as go
+from oracle import mel_oracle as mo
+
+HOP, WIN, NFFT, SR = 256, 1024, 1024, 22050
+
+
+def _speechlike(n, seed):
+    r = np.random.RandomState(seed)
+    t = np.arange(n) / SR
+    f0 = 120 + 30 * np.sin(2 * np.pi * 1.3 * t)
+    y = sum(np.sin(2 * np.pi * np.cumsum(f0 * k) / SR + r.rand() * 6) / k for k in range(1, 12))
+    env = 0.5 + 0.5 * np.sin(2 * np.pi * 2.1 * t) ** 2
+    return (0.1 * env * y + 0.003 * r.randn(n)).astype(np.float32)
+
+
+def test_istft_inverts_stft_and_matches_scipy():
+    y = _speechlike(HOP * 40, 1)
+    D = mo.stft(y, NFFT, HOP, WIN)
+    back = go.istft(D, HOP, WIN)
+    assert back.dtype == np.float32 and back.shape == (HOP * (D.shape[1] - 1),)
+    np.testing.assert_allclose(back, y[:len(back)], atol=2e-6)
+    # scipy's inverse on the same frames (its scaling convention differs by the window sum)
+    _, ys = scipy.signal.istft(D * (1.0 / scipy.signal.get_window('hann', WIN).sum()), fs=1.0, window='hann',
+                               nperseg=WIN, noverlap=WIN - HOP, nfft=NFFT, boundary=True)
+    np.testing.assert_allclose(ys[:len(back)], back, atol=5e-6)
+
+
+def test_window_sumsquare_of_periodic_hann_is_the_nola_constant():
+    w = go.window_sumsquare(20, HOP, WIN, NFFT)
+    assert w.dtype == np.float32 and len(w) == NFFT + HOP * 19
+    np.testing.assert_allclose(w[NFFT:-NFFT], 1.5, rtol=1e-6)           # hop = n_fft / 4: sum of hann^2 = 3/2
+
+
+def test_nnls_solution_satisfies_the_kkt_conditions_and_product_host_code_agrees():
+    from transformertts_amd.data import audio as pa
+    r = np.random.RandomState(3)
+    S_true = (r.rand(513, 140) ** 4).astype(np.float32)
+    B = mo.mel_filterbank(SR, NFFT, 80, 0, 8000)
+    np.testing.assert_array_equal(pa.mel_filterbank_dense(SR, NFFT, 80, 0, 8000), B)
+    M = B @ S_true
+    x = go.mel_to_stft(M.copy(), sr=SR, n_fft=NFFT, power=1, fmin=0, fmax=8000)
+    assert x.shape == (513, 140) and x.dtype == np.float32 and (x >= 0).all()
+    resid = B.astype(np.float64) @ x - M
+    grad = B.T.astype(np.float64) @ resid
+    # L-BFGS-B stops at a projected gradient of 1e-5 (scipy's default pgtol): that is the optimality it certifies
+    assert np.abs(grad[x > 1e-6]).max() < 2e-5                          # stationarity on the free set
+    assert grad[x <= 1e-6].min() > -2e-5                                # dual feasibility on the active set
+    assert np.linalg.norm(resid) < 1e-2 * np.linalg.norm(M)
+    # two blocks (127 + 13 columns) in both implementations; same start point, same optimiser
+    xp = pa.mel_to_stft(M.copy(), SR, NFFT, 0, 8000, power=1)
+    np.testing.assert_allclose(xp, x, atol=1e-5 * x.max())
+
+
+def test_griffinlim_oracle_is_seeded_and_converges_on_a_consistent_spectrogram():
+    y = _speechlike(HOP * 60, 2)
+    S = np.abs(mo.stft(y, NFFT, HOP, WIN))
+    a = go.griffinlim(S, n_iter=32, hop_length=HOP, win_length=WIN, random_state=7)
+    b = go.griffinlim(S, n_iter=32, hop_length=HOP, win_length=WIN, random_state=7)
+    c = go.griffinlim(S, n_iter=32, hop_length=HOP, win_length=WIN, random_state=8)
+    np.testing.assert_array_equal(a, b)
+    assert np.abs(a - c).max() > 1e-3
+    sc = lambda w: np.linalg.norm(np.abs(mo.stft(w, NFFT, HOP, WIN)) - S) / np.linalg.norm(S)
+    first = go.griffinlim(S, n_iter=0, hop_length=HOP, win_length=WIN, random_state=7)
+    assert sc(a) < 0.25 * sc(first) and sc(a) < 0.2                    # spectral convergence improves a lot
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,n_iter', [(61, 0), (61, 1), (61, 4), (200, 32), (9, 3)])
+def test_gpu_griffinlim_matches_the_oracle_with_fixed_phases(T, n_iter):
+    from transformertts_amd.data.audio import Audio
+    au = Audio(sampling_rate=SR, n_fft=NFFT, mel_channels=80, hop_length=HOP, win_length=WIN, f_min=0, f_max=8000,
+               normalizer='MelGAN')
+    y = _speechlike(HOP * (T - 1), 5)
+    S = np.abs(mo.stft(y, NFFT, HOP, WIN))
+    assert S.shape == (513, T)
+    ang0 = go.random_phases(S.shape, 11)
+    want, ang_w = go.griffinlim(S, n_iter=n_iter, hop_length=HOP, win_length=WIN, angles=ang0, return_angles=True)
+    got, ang_g = au.griffinlim(S, ang0, n_iter=n_iter, return_angles=True)
+    assert got.dtype == np.float32 and got.shape == want.shape
+    scale = np.abs(want).max()
+    # fp32 transforms against NumPy's fp64 ones; the phase normalisation amplifies rounding where |rebuilt| is tiny, so
+    # the bound loosens with the iteration count
+    # (measured, max error over max sample: 2.4e-7 / 5.0e-7 / 2.2e-6 / 4.2e-6 after 0 / 1 / 3 / 4 iterations, 2.3e-4 after
+    # 32 at T = 200 and 5.8e-3 at T = 900 - tools/probe_griffinlim.py)
+    tol = {0: 1e-6, 1: 2e-6, 3: 1e-5, 4: 1e-5, 32: 1e-3}[n_iter]
+    assert np.abs(got - want).max() < tol * scale, np.abs(got - want).max() / scale
+    if 0 < n_iter <= 4:
+        big = np.abs(S) > 1e-3 * S.max()                               # phases of bins that carry energy
+        assert np.abs(ang_g - ang_w)[big].max() < 1e-2
+    sc = lambda w: np.linalg.norm(np.abs(mo.stft(w, NFFT, HOP, WIN)) - S) / np.linalg.norm(S)
+    if n_iter == 32:
+        assert abs(sc(got) - sc(want)) < 1e-3 and sc(got) < 0.2
+
+
+@pytest.mark.gpu
+def test_reconstruct_waveform_from_a_mel_of_the_model_shape():
+    """Audio.reconstruct_waveform end to end (host NNLS + GPU loop) against the oracle's; and the mel of the
+    reconstruction is close to the mel it came from (what the TensorBoard audio of the reference is for)."""
+    from transformertts_amd.data.audio import Audio
+    au = Audio(sampling_rate=SR, n_fft=NFFT, mel_channels=80, hop_length=HOP, win_length=WIN, f_min=0, f_max=8000,
+               normalizer='MelGAN')
+    y = _speechlike(HOP * 150, 9)
+    mel = au.mel_spectrogram(y)                                          # [T, 80] normalised
+    wav = au.reconstruct_waveform(mel.T, n_iter=32, random_state=4)
+    want = go.reconstruct_waveform(mel.T, 'MelGAN', n_iter=32, random_state=4)
+    assert wav.shape == want.shape == (HOP * (mel.shape[0] - 1),)
+    assert np.abs(wav - want).max() < 2e-2 * np.abs(want).max()
+    mel2 = au.mel_spectrogram(np.concatenate([wav, np.zeros(HOP, np.float32)]))[:mel.shape[0]]
+    loud = mel > mel.max() - 6.0                                         # log-mel bins within e^-6 of the peak
+    assert np.abs(mel2 - mel)[loud].mean() < 0.35
+    with pytest.raises(Exception):
+        au.griffinlim(np.ones((513, 2), np.float32), np.ones((513, 2), np.complex64))     # too few frames

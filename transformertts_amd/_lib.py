@@ -71,6 +71,8 @@ SIGNATURES = {
     'ttsmi_adam_tf': (I, [P, P, P, P, L, P, P, F, F, F, P, S]),
     'ttsmi_step_increment': (I, [P, S]),
     'ttsmi_stft_logmel': (I, [P, P, P, I, L, I, I, P, I, P, P, P, P, I, F, P, S]),
+    'ttsmi_griffinlim_ws_bytes': (c_size_t, [I]),
+    'ttsmi_griffinlim': (I, [P, P, P, P, I, I, I, I, F, P, P, c_size_t, S]),
     'ttsmi_cast_f32_to_bf16': (I, [P, P, L, S]),
     'ttsmi_hgemm_tn': (I, [P, I, L, P, L, I, P, L, P, P, L, P, L, I, I, I, I, I, I, I, I, S]),
     'ttsmi_hgemm_k256_split': (I, [P, L, P, L, P, L, I, P, L, I, I, S]),

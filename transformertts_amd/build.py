@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(LIBDIR, 'libttsmi.so')
 SOURCES = ['api.cpp', 'gemm.hip', 'gemm_bf16.hip', 'attention.hip', 'attention_bf16.hip', 'layernorm.hip',
-           'elementwise.hip', 'lenreg.hip', 'stft_mel.hip', 'dense_block.hip', 'rowgemm.hip', 'gemm_k256.hip']
+           'elementwise.hip', 'lenreg.hip', 'stft_mel.hip', 'dense_block.hip', 'rowgemm.hip', 'gemm_k256.hip', 'griffinlim.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 
 
@@ -39,7 +39,7 @@ def _digest(paths) -> str:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'ttsmi.h')]
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fft512.h'), os.path.join(HERE, '..', 'include', 'ttsmi.h')]
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:

@@ -10,9 +10,14 @@ Hann window centred in n_fft, and the Slaney/area-normalised mel filterbank in i
 per-filter (first bin, count, weights) form.  `preprocess` keeps the two steps of the reference's
 wav preparation that decide what the mel kernel sees (data/audio.py:132-141):
 volume normalisation and the one-sample pad that fixes the frame count.  Everything else of the
-reference class (wav loading, VAD / silence trimming, pyworld pitch, Griffin-Lim, plotting:
-data/audio.py:94-194) is outside the hot path and not provided; asking
-for the trimming steps raises instead of silently skipping them."""
+reference class (wav loading, VAD / silence trimming, pyworld pitch, plotting: data/audio.py:112-194) is
+outside the hot path and not provided; asking for the trimming steps raises
+instead of silently skipping them.
+
+`reconstruct_waveform` (data/audio.py:94-110) is split where the reference's own cost
+splits: the mel -> linear-magnitude non-negative least squares is a one-off host computation (librosa runs it
+through scipy's L-BFGS-B; so does `mel_to_stft` below, restating librosa.util.nnls 0.7.1 [3P]), the Griffin-Lim
+loop - 33 inverse and 32 forward short-time transforms - runs on the GPU (ttsmi_griffinlim)."""
 from __future__ import annotations
 
 import sys
@@ -73,6 +78,60 @@ def hann_window_padded(win_length: int, n_fft: int) -> np.ndarray:
     w = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)
     lpad = (n_fft - win_length) // 2
     return np.pad(w, (lpad, n_fft - win_length - lpad)).astype(np.float32)
+
+
+# ---- librosa.feature.inverse.mel_to_stft / librosa.util.nnls (0.7.1) [3P], host side ---------------------
+_NNLS_BLOCK_BYTES = 2 ** 8 * 2 ** 10          # librosa.util.MAX_MEM_BLOCK
+
+
+def mel_filterbank_dense(sr, n_fft, n_mels, fmin, fmax, dtype=np.float32) -> np.ndarray:
+    """[n_mels, 1 + n_fft // 2] Slaney / area-normalised basis (the dense form of mel_filterbank_sparse)."""
+    lo, cnt, ptr, w = mel_filterbank_sparse(sr, n_fft, n_mels, fmin, fmax)
+    B = np.zeros((n_mels, 1 + n_fft // 2), dtype=dtype)
+    for m in range(n_mels):
+        B[m, lo[m]:lo[m] + cnt[m]] = w[ptr[m]:ptr[m] + cnt[m]]
+    return B
+
+
+def _nnls_block(A, B, x0):
+    import scipy.optimize
+
+    def obj(x):
+        X = x.reshape(x0.shape)
+        diff = A @ X - B
+        return 0.5 * float(np.sum(diff * diff)), (A.T @ diff).ravel()
+    x, _, _ = scipy.optimize.fmin_l_bfgs_b(obj, x0, bounds=[(0, None)] * x0.size, m=A.shape[1])
+    return x.reshape(x0.shape)
+
+
+def mel_to_stft(M: np.ndarray, sr: int, n_fft: int, fmin: float, fmax: float, power: float = 1.0) -> np.ndarray:
+    """Linear magnitudes [1 + n_fft // 2, T] whose mel projection approximates M [n_mels, T]: bounded L-BFGS from the
+    clipped least-squares solution, in column blocks of MAX_MEM_BLOCK bytes, as librosa.util.nnls does."""
+    M = np.ascontiguousarray(M)
+    A = mel_filterbank_dense(sr, n_fft, M.shape[0], fmin, fmax, dtype=M.dtype)
+    x = np.linalg.lstsq(A, M, rcond=None)[0]
+    np.clip(x, 0, None, out=x)
+    ncol = int(_NNLS_BLOCK_BYTES // (A.shape[-1] * A.itemsize))
+    if M.shape[-1] <= ncol:
+        x = _nnls_block(A, M, x).astype(A.dtype)
+    else:
+        x = x.astype(A.dtype)
+        for s0 in range(0, x.shape[-1], ncol):
+            s1 = min(s0 + ncol, M.shape[-1])
+            x[:, s0:s1] = _nnls_block(A, M[:, s0:s1], x[:, s0:s1])
+    return np.power(x, 1.0 / power, out=x)
+
+
+def window_sumsquare(window: np.ndarray, n_frames: int, hop_length: int) -> np.ndarray:
+    """librosa.filters.window_sumsquare [3P]: overlap-add envelope of window**2 (fp32 accumulation, frame order)."""
+    n_fft = len(window)
+    n = n_fft + hop_length * (n_frames - 1)
+    x = np.zeros(n, dtype=np.float32)
+    win_sq = window.astype(np.float64) ** 2
+    for i in range(n_frames):
+        s0 = i * hop_length
+        x[s0:min(n, s0 + n_fft)] += win_sq[:max(0, min(n_fft, n - s0))]
+    return x
 
 
 class Normalizer:
@@ -150,7 +209,8 @@ class Audio:
         lo, cnt, ptr, w = mel_filterbank_sparse(sampling_rate, n_fft, mel_channels, f_min, f_max)
         dev = self.device
         self._mel = tuple(torch.from_numpy(a).to(dev) for a in (lo, cnt, ptr, w))
-        self._window = torch.from_numpy(hann_window_padded(win_length, n_fft)).to(dev)
+        self._window_host = hann_window_padded(win_length, n_fft)
+        self._window = torch.from_numpy(self._window_host).to(dev)
 
     @classmethod
     def from_config(cls, config: dict):
@@ -200,6 +260,36 @@ class Audio:
             raise NotImplementedError('trim_long_silences / trim_silence (webrtcvad, librosa.effects.trim) are '
                                       'outside the hot path: trim the clips upstream and configure them off')
         return pad_for_frame_count(y, self.hop_length)
+
+    def reconstruct_waveform(self, mel, n_iter=32, random_state=None, momentum=0.99):
+        """Reference Audio.reconstruct_waveform (data/audio.py:94-110): normalised mel [mel_channels, T] (callers pass
+        `mel.T`, predict_tts.py:56) -> float32 wav [hop * (T - 1)].  `random_state` (int seed / RandomState / None)
+        draws the start phases exactly as librosa.griffinlim does (None = NumPy's global generator: unseeded, like the
+        reference's call)."""
+        mel = np.asarray(mel.detach().cpu() if torch.is_tensor(mel) else mel)
+        amp_mel = self._denormalize(mel)
+        S = mel_to_stft(amp_mel, self.sampling_rate, self.n_fft, self.f_min, self.f_max, power=1)
+        rng = (np.random if random_state is None else random_state if isinstance(random_state, np.random.RandomState)
+               else np.random.RandomState(seed=random_state))
+        angles = np.empty(S.shape, dtype=np.complex64)
+        angles[:] = np.exp(2j * np.pi * rng.rand(*S.shape))
+        return self.griffinlim(S, angles, n_iter=n_iter, momentum=momentum)
+
+    def griffinlim(self, S, angles, n_iter=32, momentum=0.99, return_angles=False):
+        """librosa.core.griffinlim [3P] on the GPU: S [1 + n_fft // 2, T] linear magnitudes, `angles` the complex
+        start phases of the same shape."""
+        T = int(S.shape[1])
+        dev = self.device
+        with torch.cuda.device(dev):
+            mag = torch.from_numpy(np.ascontiguousarray(S.T, dtype=np.float32)).to(dev)
+            a = np.ascontiguousarray(np.asarray(angles, dtype=np.complex64).T)
+            ang = torch.from_numpy(a.view(np.float32).reshape(T, -1, 2).copy()).to(dev)
+            wss = torch.from_numpy(window_sumsquare(self._window_host, T, self.hop_length)).to(dev)
+            wav = ops.griffinlim(mag, ang, self._window, wss, self.n_fft, self.hop_length, n_iter, momentum)
+            out = wav.cpu().numpy()
+            if return_angles:
+                return out, np.ascontiguousarray(ang.cpu().numpy()).view(np.complex64).reshape(T, -1).T
+            return out
 
     def _normalize(self, S):
         raise NotImplementedError('normalisation is fused into the STFT->mel kernel')

@@ -306,6 +306,20 @@ def stft_logmel(wav, clip_off, frame_off, total_frames, n_fft, hop, window, n_me
     return out
 
 
+def griffinlim(mag, angles, window, wss, n_fft, hop, n_iter, momentum):
+    """ttsmi_griffinlim (include/ttsmi.h): mag [T,513] fp32, angles [T,513,2] fp32 (updated in place), window [n_fft],
+    wss [n_fft + hop (T - 1)] -> wav [hop (T - 1)] fp32 on the device."""
+    l = _lib.lib()
+    T = int(mag.shape[0])
+    assert mag.is_contiguous() and angles.is_contiguous() and tuple(angles.shape) == (T, mag.shape[1], 2)
+    assert wss.numel() == n_fft + hop * (T - 1)
+    wav = torch.empty(hop * (T - 1), dtype=torch.float32, device=mag.device)
+    ws = _ws(max(int(l.ttsmi_griffinlim_ws_bytes(T)), 256), mag.device)
+    check(l.ttsmi_griffinlim(_p(mag), _p(angles), _p(window), _p(wss), T, n_fft, hop, int(n_iter), float(momentum),
+                             _p(wav), _p(ws), ws.numel(), _stream()), 'griffinlim')
+    return wav
+
+
 class Shadow:
     """bf16 copies of one GEMM weight for the TTSMI_BF16 path, refreshed after every optimiser step:
       wb  - the weight as stored, bf16 ([K,N] Dense; dgrad reads its rows as K-contiguous operands)
