@@ -178,6 +178,41 @@ def test_conv_blocks_bf16_path_tracks_oracle():
         assert (a - b).norm() / b.norm() < tol, name
 
 
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_reference_default_config_at_full_depth_6_plus_6(precision):
+    """The reference's shipped architecture at its real depth (config/training_config.yaml:104-118: d_model 384, 2 heads
+    = dh 192, SIX + SIX conv blocks with filters [1536, 384], k = 3, predictors [256, 226]) against the fp64 oracle on a
+    ragged batch: exact-fp32 path to the 1e-4 contract, bf16 path (dh-192 bf16 attention, bf16 implicit-GEMM convs) to
+    bf16 accuracy, with the hidden-state error read per block so that a depth-dependent blow-up would show."""
+    cfg = fo.make_config(d_model=384, enc_heads=(2,) * 6, dec_heads=(2,) * 6, ffn=1536, enc_dense_blocks=0,
+                         dec_dense_blocks=0, conv_filters=(1536, 384), dur_filters=(256, 226), pitch_filters=(256, 226))
+    W = fo.init_weights(cfg, seed=14, perturb=0.02)
+    batch = fo.synthetic_batch(2, 30, 130, seed=16, ragged=True)
+    ref = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    ref.taps = []
+    want = ref.train_step(*batch, apply=False)
+    m = _model(cfg, W, precision=precision)
+    m._compile(learning_rate=1e-3)
+    m._taps = []
+    got = m.train_step(*batch)
+    f32 = precision == 'f32'
+    assert abs(float(got['loss']) - float(want['loss'])) / float(want['loss']) < (1e-4 if f32 else 5e-3)
+    assert _rel(got['mel'], want['mel']) < (1e-4 if f32 else 3e-2)
+    assert len(m._taps) == len(ref.taps) == 12
+    depth = []
+    for (na, a), (nb, b) in zip(m._taps, ref.taps):
+        assert na == nb
+        depth.append(_rel(a, b))
+    assert max(depth) < (1e-4 if f32 else 2e-2), depth
+    assert depth[-1] < 20 * max(depth[0], 1e-6 if f32 else 1e-3), depth
+    g = m.grads_dict()
+    worst = 0.0
+    for name in ('dec.blk5.conv0.w', 'dec.blk0.conv1.w', 'dec.blk3.wk', 'enc.blk5.conv0.w', 'enc.blk0.wo', 'dec.blk2.ln2.gamma'):
+        a, b = torch.as_tensor(g[name]).double(), torch.as_tensor(np.asarray(want['grads'][name])).double()
+        worst = max(worst, float((a - b).norm() / b.norm()))
+    assert worst < (2e-4 if f32 else 0.15), worst
+
+
 def test_graph_captured_predict_equals_eager_predict(tiny):
     """graph_inference=True (two hipGraphs: encoder side per input shape, decoder side per length bucket) returns what
     the eager predict returns - predicted durations (data-dependent length, speed regulator, per-symbol clamps) and

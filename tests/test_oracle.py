@@ -199,3 +199,53 @@ def test_mel_silence_and_sine():
     # fp32 pipeline agrees with an all-fp64 evaluation to ~1e-6 relative on linear mel
     me = mo.mel_spectrogram(y, exact=True)
     np.testing.assert_allclose(np.exp(m), np.exp(me), rtol=2e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------- second, independent derivations of the mel path
+def test_stft_matches_scipy_shorttimefft():
+    """A second STFT implementation that shares nothing with the restatement (no frame gather, no np.fft call of ours):
+    scipy.signal.ShortTimeFFT with the window start as phase origin, on the same reflect-padded signal."""
+    import scipy.signal
+    y = mo.synthetic_clip(7001, seed=3)
+    D = mo.stft(y, 1024, 256, 1024)
+    sft = scipy.signal.ShortTimeFFT(scipy.signal.get_window('hann', 1024, fftbins=True), hop=256, fs=1.0,
+                                    fft_mode='onesided', mfft=1024, phase_shift=None)
+    yp = np.pad(y.astype(np.float64), 512, mode='reflect')
+    # slice p of ShortTimeFFT is centred on sample p * hop of its input = frame p - 2 of the padded signal
+    S = sft.stft(yp, p0=2, p1=2 + D.shape[1])
+    assert S.shape == D.shape
+    np.testing.assert_allclose(D, S.astype(np.complex64), rtol=0, atol=3e-5)
+
+
+# (mel filter, FFT bin, weight) of librosa.filters.mel(22050, 1024, n_mels=80, fmin=0, fmax=8000): derived a second time
+# from the published definition with scalar arithmetic only - Slaney scale (200/3 Hz per mel below 1 kHz, log steps of
+# ln(6.4)/27 above), 82 equally spaced mel points, triangle between neighbours, area normalisation 2 / (right - left) -
+# and typed in; the zero entries pin the supports (which bins each filter may touch).
+MEL_BASIS_SPOTS = [
+    (0, 1, 1.5527720767e-02), (0, 2, 2.2651390211e-02), (1, 2, 4.2020256617e-03), (1, 3, 1.9729746429e-02),
+    (10, 16, 0.0), (10, 17, 0.0), (39, 69, 0.0), (40, 72, 0.0), (40, 75, 0.0), (55, 140, 4.9497502311e-03),
+    (60, 180, 0.0), (70, 262, 4.5833129691e-04), (79, 350, 1.4931705440e-03), (79, 360, 2.7828318605e-03),
+    (79, 371, 1.2544655434e-04),
+]
+
+
+def test_mel_basis_spot_table_and_scalar_rederivation():
+    B = mo.mel_filterbank(22050, 1024, 80, 0, 8000)
+    for m, k, v in MEL_BASIS_SPOTS:
+        assert abs(float(B[m, k]) - v) < 5e-9, (m, k, float(B[m, k]), v)
+    # the whole matrix from the scalar form (no outer products, no vectorised ramps)
+    h2m = lambda f: f / (200.0 / 3) if f < 1000.0 else 15.0 + math.log(f / 1000.0) * 27.0 / math.log(6.4)
+    m2h = lambda m: m * (200.0 / 3) if m < 15.0 else 1000.0 * math.exp((m - 15.0) * math.log(6.4) / 27.0)
+    hi = h2m(8000.0)
+    pts = [m2h(hi * i / 81) for i in range(82)]
+    worst = 0.0
+    for m in range(80):
+        l, c, r = pts[m], pts[m + 1], pts[m + 2]
+        for k in range(513):
+            f = k * 22050 / 1024
+            w = 0.0 if (f <= l or f >= r) else ((f - l) / (c - l) if f <= c else (r - f) / (r - c)) * 2.0 / (r - l)
+            worst = max(worst, abs(w - float(B[m, k])))
+    assert worst < 5e-9
+    # and the product's sparse form is the same matrix
+    from transformertts_amd.data.audio import mel_filterbank_dense
+    np.testing.assert_array_equal(mel_filterbank_dense(22050, 1024, 80, 0, 8000), B)
