@@ -526,3 +526,35 @@ def test_dp_overlap_hook_plumbing_on_one_gpu(tiny):
     n_calls = len(calls)
     ref.train_step(*batch)
     assert len(calls) == n_calls and ref._lenreg_hook is None and m._lenreg_hook is not None
+
+
+def test_sequences_longer_than_the_positional_table_raise_before_any_launch(tiny):
+    """The reference fails with a shape error on pos_encoding[:, :seq_len] (model/layers.py:300); here the kernel would
+    index past the table, so the host refuses: encoder side (tokens) and decoder side (data-dependent mel length in
+    predict, eager and graph-captured)."""
+    cfg, W = tiny
+    cfg = dict(cfg, encoder_max_position_encoding=16, decoder_max_position_encoding=40)
+    W = {k: v for k, v in W.items()}
+    for graph in (False, True):
+        m = _model(cfg, W, graph_inference=graph)
+        tok = np.ones((1, 17), np.int32)
+        with pytest.raises(ValueError, match='positional-encoding'):
+            m.predict(tok, encode=False)
+        tok = np.ones((1, 12), np.int32)
+        with pytest.raises(ValueError, match='positional-encoding'):
+            m.predict(tok, encode=False, phoneme_durations=np.full((1, 12), 4, np.int32))      # 48 frames > 40
+        out = m.predict(tok, encode=False, phoneme_durations=np.full((1, 12), 3, np.int32))    # 36 frames fit
+        assert out['mel'].shape[0] == 36
+
+
+def test_optimizer_state_of_another_layout_is_refused_with_a_clear_message(tiny, tmp_path):
+    cfg, W = tiny
+    m = _model(cfg, W)
+    m._compile(learning_rate=1e-3)
+    m.save_model(tmp_path / 'ckpt')
+    st = torch.load(tmp_path / 'ckpt' / 'optimizer.pt', weights_only=True)
+    st['m'] = st['m'][:-8]
+    torch.save(st, tmp_path / 'ckpt' / 'optimizer.pt')
+    from transformertts_amd.model.models import ForwardTransformer
+    with pytest.raises(ValueError, match='Adam state'):
+        ForwardTransformer.load_model(tmp_path / 'ckpt')

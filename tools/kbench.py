@@ -199,6 +199,7 @@ def bench_rowgemm():
     l = _lib.lib()
     dev, out = 'cuda:0', []
     N, R = 256, 3
+    PD = float(os.environ.get('KBENCH_PDROP', '0.1'))          # dropout rate of the fused res-norms (0 = no hash)
     step = torch.zeros(1, dtype=torch.int64, device=dev)
     drop = ops.DropCtx(7, step)
     for M in (28800, 6400):
@@ -216,12 +217,12 @@ def bench_rowgemm():
             def fused():
                 j = i[0] % R; i[0] += 1
                 check(l.ttsmi_hgemm_ln_fwd(_p(As[j]), K, None, 0, 0, _p(wt), K, _p(bias), _p(res[j]), _p(gam), _p(bet), _p(pad),
-                                           0.1, 5, 7, _p(step), 1e-6, _p(y), _p(yh), _p(xh), _p(rstd), M, N, K, _stream()))
+                                           PD, 5, 7, _p(step), 1e-6, _p(y), _p(yh), _p(xh), _p(rstd), M, N, K, _stream()))
 
             def unfused():
                 j = i[0] % R; i[0] += 1
                 ops.hgemm_tn(As[j], wt, bias, out=o)
-                ops._ln_fwd(o, res[j], gam, bet, pad, 0.1, 5, drop, True)
+                ops._ln_fwd(o, res[j], gam, bet, pad, PD, 5, drop, True)
             for nm, fn in ((name + ' fused', fused), (name + ' gemm+ln', unfused)):
                 t = timeit(fn)
                 out.append(dict(kind='rowg', name=nm, M=M, K=K, N=N, us=t, tflops=2.0 * M * N * K / t / 1e6, tbs=0.0))
@@ -239,17 +240,17 @@ def bench_rowgemm():
 
         def fusedb():
             j = i[0] % R; i[0] += 1
-            check(l.ttsmi_hgemm_ln_bwd(_p(As[j]), K, _p(wb), K, _p(part[j]), _p(xh), _p(rstd), _p(gam), _p(pad), 0.1, 5, 7,
+            check(l.ttsmi_hgemm_ln_bwd(_p(As[j]), K, _p(wb), K, _p(part[j]), _p(xh), _p(rstd), _p(gam), _p(pad), PD, 5, 7,
                                        _p(step), _p(dxb), _p(dres), _p(ws1), ws1.numel(), M, N, K, _stream()))
 
         def unfusedb():
             j = i[0] % R; i[0] += 1
             ops.hgemm_tn(As[j], wb, out=part[j], accumulate=True)
-            ops._ln_bwd(part[j], o, part[(j + 1) % R], gam, mean, rstd, pad, 0.1, 5, drop, dg, db, dx_bf16=True)
+            ops._ln_bwd(part[j], o, part[(j + 1) % R], gam, mean, rstd, pad, PD, 5, drop, dg, db, dx_bf16=True)
 
         def xhatb():
             j = i[0] % R; i[0] += 1
-            check(l.ttsmi_layernorm_bwd_xhat(_p(part[j]), _p(xh), _p(rstd), _p(gam), _p(pad), 0.1, 5, 7, _p(step), _p(dxb),
+            check(l.ttsmi_layernorm_bwd_xhat(_p(part[j]), _p(xh), _p(rstd), _p(gam), _p(pad), PD, 5, 7, _p(step), _p(dxb),
                                              _p(dres), _p(ws2), ws2.numel(), M, N, _stream()))
         for nm, fn in (('da+LN1 bwd fused', fusedb), ('da+LN1 bwd gemm+ln', unfusedb), ('LN bwd xhat', xhatb)):
             t = timeit(fn)
