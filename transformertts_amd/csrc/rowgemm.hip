@@ -85,9 +85,46 @@ __device__ __forceinline__ void rg_stash(uint16_t (*S)[RG_LD], int tid, const ui
 // layout: 32 rows x 32 B per instruction; its epilogue alone took 47 us of a 55 us launch.)
 // EPI: 0 = LayerNorm forward, 1 = LayerNorm backward.  NW = waves of the workgroup, BM = rows of the tile.
 #define RG_ZLD 260
+// The epilogue's global-memory operands of one wave: its RPW residual rows (fp32, 4 columns per lane) and, for the
+// backward form, the x^ rows.  The LDS-DMA kernel requests them BEFORE its k-loop (rg_prefetch) so that these 30-44 MB
+// per launch stream in underneath the loop, which is bound by the L2 -> LDS fill and leaves HBM two thirds idle; left
+// to the epilogue they queue behind nothing and in front of 59 MB of stores, and every workgroup of the launch reaches
+// that phase at the same moment.
+// A wave owns the CONTIGUOUS rows [wave * RPW, (wave + 1) * RPW) of the tile, so their per-row scalars (padding flag, and
+// rstd for the backward) are one load by lanes 0..RPW-1 each, read back per row with a lane broadcast: no global load is
+// left inside the row loop - a load there meant an `s_waitcnt vmcnt(0)` per row, which also waited for the previous
+// row's STORES (vmcnt counts both) and serialised the store latency of all 16 rows.
+template <int EPI, int RPW>
+struct RgPre {
+    float4 rs[RPW];
+    uint2 xs[EPI == 1 ? RPW : 1];
+    float rstd_l;            // lane i < RPW: rstd of row i (EPI 1)
+    int pad_l;               // lane i < RPW: padding flag of row i
+};
+#define RG_NPRE(EPI, RPW) ((RPW) * ((EPI) == 1 ? 2 : 1) + ((EPI) == 1 ? 2 : 1))      // vector-memory instructions of rg_prefetch
+template <int EPI, int NW, int BM>
+__device__ __forceinline__ void rg_prefetch(const RowGemmP& p, int m0, int wave, int lane, RgPre<EPI, BM / NW>& pre) {
+    constexpr int RPW = BM / NW;
+    const int c4 = lane * 4;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {                    // every row of this wave in flight at once
+        const int row = min(m0 + wave * RPW + i, p.M - 1);
+        pre.rs[i] = *reinterpret_cast<const float4*>(p.res + (long)row * RG_N + c4);
+        if constexpr (EPI == 1) pre.xs[i] = *reinterpret_cast<const uint2*>(p.xhat_in + (long)row * RG_N + c4);
+    }
+    // (always the same number of instructions - the LDS-DMA kernel counts them on vmcnt: without a padding mask the
+    // load reads a valid dummy and is ignored)
+    const int rowl = min(m0 + wave * RPW + (lane & (RPW - 1)), p.M - 1);
+    const uint8_t* padp = p.row_pad ? p.row_pad + rowl : reinterpret_cast<const uint8_t*>(p.gamma);
+    pre.pad_l = (int)*padp;
+    if (p.row_pad == nullptr) pre.pad_l = 0;
+    if constexpr (EPI == 1) pre.rstd_l = p.rstd_in[rowl];
+    else pre.rstd_l = 0.f;
+}
+
 template <int EPI, int NW, int BM>
 __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4], int m0, float* Z, int wave, int wm, int wc,
-                                            int lane) {
+                                            int lane, const RgPre<EPI, BM / NW>& pre) {
     const int l31 = lane & 31, hh = lane >> 5;
     // ---- accumulators -> Z (all waves finished reading the operand stages: the caller synchronised)
     {
@@ -108,15 +145,10 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4],
         const float4 bs = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c4);
         const float4 bt = *reinterpret_cast<const float4*>(p.beta + c4);
-        float4 rs[RPW];
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {                // every residual row of this wave in flight at once
-            const int row = min(m0 + wave + NW * i, p.M - 1);
-            rs[i] = *reinterpret_cast<const float4*>(p.res + (long)row * RG_N + c4);
-        }
+        const float4 (&rs)[RPW] = pre.rs;
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            const int rl = wave + NW * i, row = m0 + rl;
+            const int rl = wave * RPW + i, row = m0 + rl;
             if (row >= p.M) break;                                     // wave-uniform
             const float4 a = *reinterpret_cast<const float4*>(Z + rl * RG_ZLD + c4);
             float v[4] = {a.x + bs.x, a.y + bs.y, a.z + bs.z, a.w + bs.w};
@@ -135,7 +167,7 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4],
             for (int e = 0; e < 4; ++e) { v[e] -= mean; q += v[e] * v[e]; }
             const float rstd = 1.0f / sqrtf(wave_sum(q) * invC + p.eps);
             if (lane == 0) p.rstd[row] = rstd;
-            const bool padded = p.row_pad != nullptr && p.row_pad[row] != 0;
+            const bool padded = __builtin_amdgcn_readlane(pre.pad_l, i) != 0;
             float xh[4], yv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) xh[e] = v[e] * rstd;
@@ -151,21 +183,15 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4],
         // d_o = keep(dz) (bf16), dres = dz (fp32); dgamma += g x^, dbeta += g summed over the tile's rows
         const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c4);
         float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
-        float4 rs[RPW];
-        uint2 xs[RPW];
+        const float4 (&rs)[RPW] = pre.rs;
+        const uint2 (&xs)[RPW] = pre.xs;
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            const int row = min(m0 + wave + NW * i, p.M - 1);
-            rs[i] = *reinterpret_cast<const float4*>(p.res + (long)row * RG_N + c4);
-            xs[i] = *reinterpret_cast<const uint2*>(p.xhat_in + (long)row * RG_N + c4);
-        }
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int rl = wave + NW * i, row = m0 + rl;
+            const int rl = wave * RPW + i, row = m0 + rl;
             if (row >= p.M) break;
             const float4 a = *reinterpret_cast<const float4*>(Z + rl * RG_ZLD + c4);
-            const bool padded = p.row_pad != nullptr && p.row_pad[row] != 0;
-            const float rstd = p.rstd_in[row];
+            const bool padded = __builtin_amdgcn_readlane(pre.pad_l, i) != 0;
+            const float rstd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.rstd_l), i));
             float gv[4] = {a.x + rs[i].x, a.y + rs[i].y, a.z + rs[i].z, a.w + rs[i].w};
             if (padded) { gv[0] = 0.f; gv[1] = 0.f; gv[2] = 0.f; gv[3] = 0.f; }
             float xh[4];
@@ -269,7 +295,9 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(RowGemmP p) {
         __syncthreads();
     }
 
-    rg_epilogue<EPI, 4, RG_BM>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane);
+    RgPre<EPI, RG_BM / 4> pre;
+    rg_prefetch<EPI, 4, RG_BM>(p, m0, wave, lane, pre);
+    rg_epilogue<EPI, 4, RG_BM>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
 }
 
 // =================================================================================================
@@ -337,10 +365,18 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
     };
     issue(0, 0);
     if (nk > 1) issue(1, 1);
+    // the epilogue's residual / x^ rows, requested now: NPRE more instructions on this wave's vmcnt, YOUNGER than k-steps
+    // 0 and 1 and older than every later one
+    constexpr int NPRE = RG_NPRE(EPI, RD_BM / 8);
+    static_assert(6 + NPRE <= 63, "vmcnt is a 6-bit counter");
+    RgPre<EPI, RD_BM / 8> pre;
+    rg_prefetch<EPI, 8, RD_BM>(p, m0, wave, lane, pre);
     for (int ks = 0; ks < nk; ++ks) {
-        // step ks has landed once at most the newest step's 6 DMA instructions are outstanding
-        if (ks + 1 < nk) __builtin_amdgcn_s_waitcnt(0xF76);          // vmcnt(6)
-        else __builtin_amdgcn_s_waitcnt(0xF70);                      // vmcnt(0)
+        // step ks has landed once at most the newest step's 6 DMA instructions (and, for the first two steps, the
+        // prefetch behind them) are outstanding
+        if (ks + 1 >= nk) __builtin_amdgcn_s_waitcnt(0xF70);         // vmcnt(0)
+        else if (ks < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NPRE) : "memory");
+        else __builtin_amdgcn_s_waitcnt(0xF76);                      // vmcnt(6)
         rd_stage_barrier();                                          // everybody's pieces landed; stage (ks-1)%3 is retired
         if (ks + 2 < nk) issue(ks + 2, (ks + 2) % RD_STAGES);
         const unsigned char* As = smem + (ks % RD_STAGES) * RD_STAGE;
@@ -359,7 +395,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
         }
     }
     __syncthreads();
-    rg_epilogue<EPI, 8, RD_BM>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane);
+    rg_epilogue<EPI, 8, RD_BM>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
 }
 
 // ---- standalone backward of a LayerNorm whose forward kept x^ (bf16) and rstd: the fused forward's counterpart for the
