@@ -787,7 +787,8 @@ def test_hgemm_with_fused_layernorm_matches_gemm_then_layernorm(M, K, dual, pdro
 
 
 @pytest.mark.parametrize('M,N,relu,out_bf16', [(1000, 768, False, True), (333, 1024, True, True), (581, 256, False, False),
-                                               (64, 80, True, False), (28800, 1024, True, True), (4100, 264, False, True)])
+                                               (64, 80, True, False), (28800, 1024, True, True), (4100, 264, False, True),
+                                               (20000, 768, False, True), (16500, 256, True, True)])
 def test_weight_stationary_k256_gemm(M, N, relu, out_bf16, monkeypatch):
     """gemm_k256.hip (reached through ttsmi_hgemm_tn for K = 256 projections): row / column tails, every epilogue,
     against the bf16-rounded fp64 product; run in a subprocess-free way by forcing the route with TTSMI_HGEMM_K256=1
@@ -809,7 +810,7 @@ def test_weight_stationary_k256_gemm(M, N, relu, out_bf16, monkeypatch):
         assert routed                                       # the decoder-size launches take the new kernel by default
 
 
-@pytest.mark.parametrize('M', [700, 5000])
+@pytest.mark.parametrize('M', [700, 5000, 17001])
 def test_weight_stationary_k256_gemm_mask_and_accumulate(M):
     """The ReLU'-masked bf16 dgrad (FFN2 -> hidden) and the accumulating fp32 dgrad (Wo top half) on gemm_k256.hip."""
     ops = _ops()

@@ -41,6 +41,7 @@ struct K256P {
     int M, N;
     int nchunks, ngroups, ntiles;
     const uint16_t* mask; long ldmask;      // MODE 2: bf16 [M, N], output kept where mask > 0 (ReLU' of the saved activation)
+    int ablate;                             // measurement only (TTSMI_K256_ABLATE, wide kernel): 1 no stores, 2 no MFMA, 4 no DMA
     void* C2; long ldc2; int n_acc;         // MODE 3: columns < n_acc (a multiple of 128) are ADDED to the fp32 C, the
                                             // rest leave as bf16 into C2 (column n -> C2[., n - n_acc])
 };
@@ -222,6 +223,185 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
     }
 }
 
+// ---- 256-column variant with separated roles (bf16 output, MODE 1 / 2) ----------------------------------------------
+// Stage ablation of the kernel above on the FFN1 shape (TTSMI_K256_ABLATE, 28.7 us): without the stores 22.7, without
+// the multiply 19.3, without the DMA 27.2, with none of them 11.5 - the phases ADD UP.  Every wave multiplies, then every
+// workgroup of the launch reaches its store phase at the same moment: 59 MB of stores are issued in bursts that cover a
+// third of the run (HBM alone writes them in 10 us).  Here the roles are separated:
+//   waves 0-3 ("compute"): issue the tile DMAs, own 64 columns of W^T each (128 registers of MFMA fragments: a workgroup
+//              covers 256 columns, so the activation tile passes the LDS-DMA path N / 256 times instead of N / 128),
+//              multiply the whole 64-row tile and leave it in the bf16 staging tile;
+//   waves 4-7 ("store"):   copy the staging tile of step t - 1 into registers right after it is published, and issue
+//              its global stores (under the prefetched ReLU' mask in MODE 2) WHILE the compute waves multiply tile t.
+// Two barriers per tile as before, but the store stream now runs underneath the multiply, and the LDS reads of the
+// activation fragments are halved (4 reading waves instead of 8).
+#define KWW_BN 256
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_k256_wide_kernel(K256P p) {
+    static_assert(MODE == 1 || MODE == 2, "bf16 output only");
+    constexpr int SLD = KWW_BN + 8;                                        // staging row stride (bf16 elements)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[KW_STAGES * KW_STAGE + KW_BM * SLD * 2];
+    __shared__ float biasS[KWW_BN];
+    uint16_t* stg = reinterpret_cast<uint16_t*>(smem + KW_STAGES * KW_STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool compute = wave < 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int group = xcd + 8 * (slot / p.nchunks), chunk = slot % p.nchunks;
+    const int ncol0 = chunk * KWW_BN;
+    const int my_tiles = group < p.ntiles ? (p.ntiles - group + p.ngroups - 1) / p.ngroups : 0;
+    const int ab = p.ablate;
+
+    if (tid < KWW_BN) biasS[tid] = (p.bias != nullptr && ncol0 + tid < p.N) ? p.bias[ncol0 + tid] : 0.f;
+    // ---- compute waves: 64 columns of W^T as MFMA A-operand fragments, bfrag[cb][s] = Bt[n0 + 32 cb + l31][16 s + 8 hh ..]
+    bf16x8 bfrag[2][KW_K / 16];
+    if (compute) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int n = ncol0 + wave * 64 + cb * 32 + l31;
+            const uint16_t* src = p.Bt + (long)min(n, p.N - 1) * p.ldb + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < KW_K / 16; ++s) {
+                uint4 v = *reinterpret_cast<const uint4*>(src + 16 * s);
+                if (n >= p.N) v = make_uint4(0, 0, 0, 0);
+                bfrag[cb][s] = *reinterpret_cast<bf16x8*>(&v);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto issue = [&](int it, int stage) {                 // compute waves only: 8 DMA instructions per wave and tile
+        const int m0 = (group + it * p.ngroups) * KW_BM;
+        unsigned char* base = smem + stage * KW_STAGE;
+#pragma unroll
+        for (int i = 0; i < KW_DMA_PER_WAVE; ++i) {
+            const int q = wave * KW_DMA_PER_WAVE + i;
+            const int row = 2 * q + hh;
+            const int c = l31 ^ (row & 15);
+            const int gm = min(m0 + row, p.M - 1);
+            kw_dma16(p.A + (long)gm * p.lda + c * 8, kw_lds_offset(base + q * 1024));
+        }
+    };
+    const bool dma_on = !(ab & 4);
+    if (compute && dma_on) {
+        if (my_tiles > 0) issue(0, 0);
+        if (my_tiles > 1) issue(1, 1);
+    }
+    __syncthreads();                                      // bias table
+    // Two loops with the same barrier sequence (T, Y per iteration; iterations 0 .. my_tiles) - one per role, so that the
+    // register allocator sees two disjoint live sets (128 weight + 64 accumulator registers on one side, 96 of staging /
+    // mask data on the other) instead of their union.  In iteration `it` the compute waves work on tile `it`
+    // (it < my_tiles) while the store waves write out tile it - 1 (it >= 1).
+    if (compute) {
+        for (int it = 0; it <= my_tiles; ++it) {
+            if (it < my_tiles) {
+                if (it + 1 < my_tiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            kw_barrier();                // T: tile `it` landed, ring stage (it-1)%3 retired; staging(it-1) is in registers
+            if (it < my_tiles) {
+                if (dma_on && it + 2 < my_tiles) issue(it + 2, (it + 2) % KW_STAGES);
+                const unsigned char* As = smem + (it % KW_STAGES) * KW_STAGE;
+                f32x16 acc[2][2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const float* bsrc = biasS + wave * 64 + cb * 32 + 4 * hh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bsrc + 8 * g);
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) {
+                            acc[cb][rb][4 * g + 0] = b4.x; acc[cb][rb][4 * g + 1] = b4.y;
+                            acc[cb][rb][4 * g + 2] = b4.z; acc[cb][rb][4 * g + 3] = b4.w;
+                        }
+                    }
+                }
+                if (!(ab & 2)) {
+#pragma unroll
+                    for (int s = 0; s < KW_K / 16; ++s) {
+                        bf16x8 a[2];
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) {
+                            const int arow = rb * 32 + l31;
+                            const int pos = (2 * s + hh) ^ (arow & 15);
+                            a[rb] = *reinterpret_cast<const bf16x8*>(As + arow * 512 + pos * 16);
+                        }
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb)
+                                acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag[cb][s], a[rb], acc[cb][rb], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        if (p.relu) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[cb][rb][r] = fmaxf(acc[cb][rb][r], 0.f);
+                        }
+                        uint16_t* st = stg + (rb * 32 + l31) * SLD + wave * 64 + cb * 32 + 4 * hh;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<uint2*>(st + 8 * g) = kw_pack4(acc[cb][rb][4 * g], acc[cb][rb][4 * g + 1],
+                                                                             acc[cb][rb][4 * g + 2], acc[cb][rb][4 * g + 3]);
+                    }
+            }
+            kw_barrier();                // Y: staging(it) published
+        }
+        return;
+    }
+    // ---- store waves: thread -> rows srow + 8 j (j < 8), 8 columns at sc8
+    const int st_tid = tid - 256;
+    const int srow = st_tid >> 5, sc8 = (st_tid & 31) * 8;
+    uint4 outv[8], pre_m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { outv[j] = make_uint4(0u, 0u, 0u, 0u); pre_m[j] = make_uint4(0u, 0u, 0u, 0u); }
+    auto mask_of = [&](int it, int j) {
+        const int row = min((group + it * p.ngroups) * KW_BM + srow + 8 * j, p.M - 1), col = min(ncol0 + sc8, p.N - 8);
+        return *reinterpret_cast<const uint4*>(p.mask + (long)row * p.ldmask + col);
+    };
+    for (int it = 0; it <= my_tiles; ++it) {
+        kw_barrier();                    // T
+        if (it >= 1 && !(ab & 1)) {
+            // tile it - 1 (already in outv) leaves while the compute waves multiply tile it
+            const int m0 = (group + (it - 1) * p.ngroups) * KW_BM;
+            if (MODE == 2) {
+                // request the NEXT tile's mask first, then wait for everything older than those 8 loads: this tile's mask
+                // (requested an iteration ago) and the stores of the tile before
+                uint4 nxt[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nxt[j] = mask_of(it, j);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                auto sel = [](uint32_t m) {
+                    return (((int32_t)(m << 16) > 0) ? 0x0000FFFFu : 0u) | (((int32_t)(m & 0xFFFF0000u) > 0) ? 0xFFFF0000u : 0u);
+                };
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    outv[j].x &= sel(pre_m[j].x); outv[j].y &= sel(pre_m[j].y);
+                    outv[j].z &= sel(pre_m[j].z); outv[j].w &= sel(pre_m[j].w);
+                    pre_m[j] = nxt[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = srow + 8 * j;
+                if (m0 + row < p.M && ncol0 + sc8 < p.N)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + (long)(m0 + row) * p.ldc + ncol0 + sc8) = outv[j];
+            }
+        } else if (MODE == 2 && it == 0 && my_tiles > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pre_m[j] = mask_of(0, j);          // the first tile's mask
+        }
+        kw_barrier();                    // Y: staging(it) published
+        if (it < my_tiles) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) outv[j] = *reinterpret_cast<const uint4*>(stg + (srow + 8 * j) * SLD + sc8);
+        }
+    }
+}
+
 extern "C" {
 
 // 1 if ttsmi_hgemm_tn would route this launch to the weight-stationary kernel (exposed for tests / benchmarks)
@@ -253,6 +433,25 @@ int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, lon
     memset(&p, 0, sizeof(p));
     p.A = a; p.lda = lda; p.Bt = bt; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.relu = relu; p.M = M; p.N = N;
     p.mask = mask; p.ldmask = ldmask;
+    // bf16 output, whole 256-column chunks, enough row tiles per workgroup to amortise its 128 KB of weights: wide variant
+    static int wide = -1;               // TTSMI_HGEMM_K256_WIDE=0: always the 128-column kernel (A/B knob)
+    if (wide < 0) { const char* e = getenv("TTSMI_HGEMM_K256_WIDE"); wide = e ? atoi(e) : 1; }
+    if (wide && out_bf16 && N % KWW_BN == 0 && (M >= 16384 || wide > 1)) {
+        p.nchunks = N / KWW_BN;
+        p.ntiles = ttsmi_cdiv(M, KW_BM);
+        int groups = (256 / p.nchunks) / 8 * 8;
+        if (groups < 8) groups = 8;
+        const int need = (p.ntiles + 7) / 8 * 8;
+        if (groups > need) groups = need;
+        p.ngroups = groups;
+        static int ablate = -1;
+        if (ablate < 0) { const char* e = getenv("TTSMI_K256_ABLATE"); ablate = e ? atoi(e) : 0; }
+        p.ablate = ablate;
+        dim3 gridw(p.nchunks * p.ngroups);
+        if (mask) hipLaunchKernelGGL((gemm_k256_wide_kernel<2>), gridw, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((gemm_k256_wide_kernel<1>), gridw, dim3(512), 0, st, p);
+        return 0;
+    }
     kw_plan(p);
     dim3 grid(p.nchunks * p.ngroups);
     if (mask) hipLaunchKernelGGL((gemm_k256_kernel<2>), grid, dim3(512), 0, st, p);
