@@ -1,0 +1,7 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+export TMPDIR=/tmp
+run() { env "$@" python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-attention-maps 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('$*', round(d['ms_per_step'],3))"; }
+for i in 1 2 3; do run A=1; run TTSMI_HGEMM_K256_WIDE=2; done
