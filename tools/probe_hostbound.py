@@ -1,3 +1,6 @@
+"""SUPERSEDED - kept only because DESIGN.md section 4 cites it.  This probe queued a GPU-side sleep in front of a step to take
+the host out of the picture, but calibrated torch.cuda._sleep at idle clocks: its "host-bound" reading was wrong.
+tools/probe_phases.py (timing events on the main stream at the phase boundaries) is the measurement to use."""
 import torch, time, sys
 sys.path.insert(0, '/root/repo')
 import bench
