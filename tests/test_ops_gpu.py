@@ -858,3 +858,31 @@ def test_k256_split_output_gemm(M):
     assert rel_err(dctx.float(), a @ _bf(wo[d:]).T) < 5e-3
     with pytest.raises(_lib.TtsmiError):
         check(l.ttsmi_hgemm_k256_split(_p(d_o), d, _p(sh.wb), d, _p(dh), d, 100, _p(dctx), d, M, 2 * d, _stream()))
+
+
+@pytest.mark.parametrize('B,H,T,dh,pdrop', [(2, 4, 333, 64, 0.0), (2, 2, 200, 32, 0.2), (1, 2, 150, 192, 0.1), (3, 4, 900, 64, 0.1)])
+def test_bf16_attention_maps_equal_the_fp32_recomputation(B, H, T, dh, pdrop):
+    """ttsmi_attention_weights with TTSMI_BF16_IO (bf16 MFMA on the bf16 qkv the forward read) against the exact-fp32 kernel
+    on the widened copy of the same tensor: same softmax (the forward's log-sum-exp), same keep decisions - dropped
+    entries are exactly 0 in both - ragged padding, T not a multiple of the tile."""
+    ops = _ops()
+    from transformertts_amd import _lib
+    d = H * dh
+    qkv = (g(B * T, 3 * d, seed=1) * 0.6).to(DEV).to(torch.bfloat16)
+    lens = torch.tensor([T] + [max(1, (T * (i + 1)) // (B + 1)) for i in range(B - 1)])
+    pad = (torch.arange(T)[None, :] >= lens[:, None]).to(torch.uint8)
+    pad[0, 3] = 1
+    klen = torch.tensor([int((p == 0).nonzero().max()) + 1 for p in pad], dtype=torch.int32)
+    pad, klen = pad.to(DEV), klen.to(DEV)
+    step = torch.full((1,), 3, dtype=torch.int64, device=DEV)
+    drop = ops.DropCtx(seed=5, step_dev=step)
+    _ctx, lse = ops.AttentionFn.apply(qkv.float(), pad, klen, B, H, T, dh, 0.0, None, 0, _lib.TTSMI_BF16)
+    w16 = ops.attention_weights(qkv, pad, lse, B, H, T, dh, pdrop, drop, 7, _lib.TTSMI_BF16_IO)
+    w32 = ops.attention_weights(qkv.float(), pad, lse, B, H, T, dh, pdrop, drop, 7)
+    torch.cuda.synchronize()
+    assert w16.shape == (B, H, T, T) and torch.isfinite(w16).all()
+    assert torch.equal(w16 == 0, w32 == 0)                                  # identical keep decisions / padded keys
+    assert rel_err(w16, w32) < 2e-5                                          # same products, different summation order
+    if pdrop == 0.0:
+        rows = w16.sum(-1)
+        assert float((rows - 1).abs().max()) < 2e-2                          # lse comes from the bf16 forward

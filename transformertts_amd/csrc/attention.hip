@@ -591,10 +591,13 @@ int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float
                             float* weights, int B, int H, int T, int dh, float p_drop,
                             uint64_t seed, const int64_t* step_dev, uint32_t site, int dtype,
                             ttsmi_stream_t stream) {
+    // TTSMI_BF16_IO: qkv is the bf16 tensor the forward read - recomputed on the bf16 MFMA (attention_bf16.hip).
+    // TTSMI_BF16 (fp32 qkv, bf16 forward): recomputed from the fp32 q/k with the exact-fp32 MFMA (the maps are a logging
+    // output; rows sum to 1 up to the bf16 rounding of the forward's log-sum-exp)
+    if (dtype == TTSMI_BF16_IO)
+        return ttsmi_hattention_weights(qkv, key_pad, lse, weights, B, H, T, dh, p_drop, seed, step_dev, site,
+                                        (hipStream_t)stream);
     AttnP p;
-    // TTSMI_BF16 callers get the maps recomputed from the fp32 q/k with the exact-fp32 MFMA (they are
-    // a logging output; rows sum to 1 up to the bf16 rounding of the forward's log-sum-exp)
-    (void)dtype;
     int rc = fill(p, qkv, key_pad, nullptr, B, H, T, dh, p_drop, seed, step_dev, site, TTSMI_F32, "attention_weights");
     if (rc) return rc;
     TTSMI_CHECK_ARG(lse && weights, "attention_weights: null pointer");

@@ -883,6 +883,66 @@ static int henv(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// ---- attention maps on request (model/layers.py:195,302-310: the reference returns the post-dropout weights of every layer)
+// One workgroup = 32 queries x 128 keys (wave = 32 keys): S = Q.K^T straight from the bf16 rows the forward used (4 MFMAs per
+// wave), P = exp(S / sqrt(dh) + pad - lse) with the forward's log-sum-exp, the same counter-hash keep decisions, and the
+// accumulator layout (lane = key, register = query) stores 128-byte row segments without a transpose.  The kernel is
+// bound by its 4 T^2 bytes of output per (b, h): 415 MB per decoder layer at the benchmark shape.  (The fp32 kernel of
+// attention.hip - 32 fp32 MFMAs per tile on a widened copy of qkv - took 2.4 x the write time.)
+template <int DH>
+__global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __restrict__ weights) {
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.z, b = bh / p.H, h = bh - b * p.H;
+    const int d = p.H * DH;
+    const int key = (blockIdx.x * 4 + wave) * 32 + l31;
+    const int q0 = blockIdx.y * 32;
+    if ((blockIdx.x * 4 + wave) * 32 >= p.T) return;
+    const float* Qb = eptr<true>(p.qkv, (long)b * p.T * p.ld + h * DH);
+    const float* Kb = eptr<true>(Qb, d);
+    bf16x8 qf[DH / 16], kf[DH / 16];
+    frags_of<DH, true>(Qb, p.ld, q0 + l31, q0 + l31 < p.T, hh, qf);
+    frags_of<DH, true>(Kb, p.ld, key, key < p.T, hh, kf);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[i], kf[i], s, 0, 0, 0);   // S[q][key]
+    const float padterm = (key < p.T && p.key_pad[(long)b * p.T + key]) ? -1e9f : 0.f;
+    const long stat0 = (long)bh * p.T;
+    const uint64_t dkey = p.thr ? ttsmi_drop_key(p.seed, p.step_dev, p.site) : 0;
+    const float inv_sqrt = 1.0f / p.sqrt_dk;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + rowmap16(r, hh);
+        if (q >= p.T || key >= p.T) continue;
+        float pr = __expf(s[r] * inv_sqrt + padterm - p.lse[stat0 + q]);
+        if (p.thr) pr *= ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q), (uint32_t)key, p.thr, p.inv_keep);
+        weights[(stat0 + q) * (long)p.T + key] = pr;
+    }
+}
+
+int ttsmi_hattention_weights(const void* qkv, const uint8_t* key_pad, const float* lse, float* weights, int B, int H, int T,
+                             int dh, float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, hipStream_t st) {
+    HAttnP p;
+    static const int32_t* no_klen = reinterpret_cast<const int32_t*>(1);          // (not read by this kernel)
+    int rc = hfill(p, qkv, key_pad, no_klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_weights(bf16)");
+    if (rc) return rc;
+    TTSMI_CHECK_ARG(lse && weights, "attention_weights(bf16): null pointer");
+    p.lse = const_cast<float*>(lse);
+    dim3 grid(ttsmi_cdiv(T, 128), ttsmi_cdiv(T, 32), B * H);
+    switch (dh) {
+        case 32: hipLaunchKernelGGL((hattn_weights_kernel<32>), grid, dim3(256), 0, st, p, weights); break;
+        case 64: hipLaunchKernelGGL((hattn_weights_kernel<64>), grid, dim3(256), 0, st, p, weights); break;
+        case 192: hipLaunchKernelGGL((hattn_weights_kernel<192>), grid, dim3(256), 0, st, p, weights); break;
+        default:
+            ttsmi_set_error("bf16 attention: head dim %d not built (32/64/192)", dh);
+            return TTSMI_ERR_UNSUPPORTED;
+    }
+    TTSMI_CHECK_LAUNCH("attention_weights(bf16)");
+    return TTSMI_OK;
+}
+
 // ---- split-key forward (inference at small batch) ------------------------------------------------------------------
 // A forward whose B*H*ceil(T/128) workgroups do not fill the 256 CUs (batch 1, 2304 frames, 4 heads: 72 workgroups,
 // each wave walking all 2304 keys serially - 69 us) is latency bound by that serial walk.  Splitting the keys over

@@ -379,7 +379,7 @@ class ForwardTransformer:
                 h, h_bf = ops.PlannedDenseBlockFn.apply(h, h_bf, plan)
                 if want_attn:
                     attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
-                        plan.t['qkv'].float(), pad, plan.t['lse'], B, H, T, d // H, rate, drop, sites[0])
+                        plan.t['qkv'], pad, plan.t['lse'], B, H, T, d // H, rate, drop, sites[0], ops._lib.TTSMI_BF16_IO)
                 if self._taps is not None:
                     self._taps.append((p, h.detach().reshape(B, T, d)))
                 continue
@@ -403,7 +403,8 @@ class ForwardTransformer:
                     h_bf = None
                 if want_attn:
                     attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
-                        qkv.float() if qkv.dtype != torch.float32 else qkv, pad, lse, B, H, T, d // H, rate, drop, sites[0])
+                        qkv, pad, lse, B, H, T, d // H, rate, drop, sites[0],
+                        ops._lib.TTSMI_BF16_IO if qkv.dtype == torch.bfloat16 else ops.TTSMI_F32)
                 if self._taps is not None:
                     self._taps.append((p, h.detach().reshape(B, T, d)))
                 continue
