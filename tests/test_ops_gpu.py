@@ -709,7 +709,9 @@ def test_hgemm_bf16_outputs_masks_and_sources():
     assert rel_err(da, da0.double().cpu() + dh1.double().cpu() @ _bf(w1).T) < 3e-6
 
 
-@pytest.mark.parametrize('M,K,dual,pdrop', [(300, 512, True, 0.0), (1000, 1024, False, 0.15), (64, 256, False, 0.15), (129, 512, True, 0.15)])
+# (M >= 2048 takes the 128-row LDS-DMA kernel with its prefetched epilogue operands; below, the 64-row kernel)
+@pytest.mark.parametrize('M,K,dual,pdrop', [(300, 512, True, 0.0), (1000, 1024, False, 0.15), (64, 256, False, 0.15), (129, 512, True, 0.15),
+                                            (2100, 512, True, 0.15), (4000, 1024, False, 0.0), (3001, 768, False, 0.1)])
 def test_hgemm_with_fused_layernorm_matches_gemm_then_layernorm(M, K, dual, pdrop):
     """ttsmi_hgemm_ln_fwd == hgemm_tn followed by add_layernorm (same dropout decisions, row mask, bf16 copy), and its
     x^ / rstd feed ttsmi_layernorm_bwd_xhat + ttsmi_hgemm_ln_bwd to the same gradients as the standalone LayerNorm
