@@ -109,7 +109,8 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
                         int H, int T, int dh, float p_drop, uint64_t seed, const int64_t* step_dev,
                         uint32_t site, void* ws, size_t ws_bytes, int dtype,
                         ttsmi_stream_t stream);
-/* Dropout on the attention weights with PRECOMPUTED keep bits (TTSMI_BF16_IO tensors, dh 32/64): evaluating the
+/* Dropout on the attention weights with PRECOMPUTED keep bits (bf16 MFMA kernels, dh 32/64/192; dtype TTSMI_BF16_IO =
+ * bf16 tensors, TTSMI_BF16 = fp32 tensors): evaluating the
  * counter-based hash inside the attention inner loops costs a third of the forward and is repeated twice by the
  * backward; ttsmi_attention_dropmask evaluates the SAME keep(seed, step, site, row, key) decisions once per layer
  * and step into a bit table (uint64 [B*H][T/32 query tiles][T/32 key blocks][16], layout in attention_bf16.hip), and
@@ -119,12 +120,12 @@ size_t ttsmi_attention_dropmask_bytes(int B, int H, int T);
 int ttsmi_attention_dropmask(void* mask, int B, int H, int T, float p_drop, uint64_t seed,
                              const int64_t* step_dev, uint32_t site, ttsmi_stream_t stream);
 int ttsmi_attention_fwd_masked(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
-                               float* lse, int B, int H, int T, int dh, float p_drop, const void* dropmask,
+                               float* lse, int B, int H, int T, int dh, float p_drop, const void* dropmask, int dtype,
                                ttsmi_stream_t stream);
 int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const int32_t* klen,
                                const void* ctx, const void* dctx, const float* lse, void* dqkv, int B,
                                int H, int T, int dh, float p_drop, const void* dropmask, void* ws, size_t ws_bytes,
-                               ttsmi_stream_t stream);
+                               int dtype, ttsmi_stream_t stream);
 /* Inference forward (no dropout, TTSMI_BF16_IO tensors) for launches too small to fill the GPU - batch 1, a few heads:
  * the keys are split over extra workgroups, each split writes a normalised partial context + log-sum-exp into `ws`, and a
  * combine pass forms the result (model/layers.py:176-195 with training=False).  _ws_bytes returns 0 when B*H*T already

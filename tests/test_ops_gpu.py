@@ -594,9 +594,9 @@ def test_attention_keep_bit_table_equals_the_hashed_dropout(B, H, T, dh):
         if masked:
             m = ops.attention_dropmask(B, H, T, pdrop, drop, site, DEV)
             check(l.ttsmi_attention_fwd_masked(_p(qkv), _p(pad), _p(klen), _p(ctx), _p(lse), B, H, T, dh, pdrop, _p(m),
-                                               _stream()))
+                                               _lib.TTSMI_BF16_IO, _stream()))
             check(l.ttsmi_attention_bwd_masked(_p(qkv), _p(pad), _p(klen), _p(ctx), _p(dctx), _p(lse), _p(dqkv), B, H, T,
-                                               dh, pdrop, _p(m), _p(ws), ws.numel(), _stream()))
+                                               dh, pdrop, _p(m), _p(ws), ws.numel(), _lib.TTSMI_BF16_IO, _stream()))
         else:
             check(l.ttsmi_attention_fwd(_p(qkv), _p(pad), _p(klen), _p(ctx), _p(lse), B, H, T, dh, pdrop, drop.seed,
                                         _p(step), site, _lib.TTSMI_BF16_IO, _stream()))
@@ -888,3 +888,32 @@ def test_bf16_attention_maps_equal_the_fp32_recomputation(B, H, T, dh, pdrop):
     if pdrop == 0.0:
         rows = w16.sum(-1)
         assert float((rows - 1).abs().max()) < 2e-2                          # lse comes from the bf16 forward
+
+
+@pytest.mark.parametrize('B,H,T,dh', [(2, 2, 150, 192), (2, 4, 333, 64)])
+def test_keep_bit_table_with_fp32_tensors_equals_the_hashed_dropout(B, H, T, dh):
+    """AttentionFn on fp32 tensors with the bf16 MFMA kernels (TTSMI_BF16: the conv-block path of the reference-default
+    architecture): the keep-bit table and the in-kernel hash make the same decisions - context, log-sum-exp and dqkv
+    agree to rounding order."""
+    ops = _ops()
+    from transformertts_amd._lib import TTSMI_BF16
+    d, pdrop = H * dh, 0.2
+    qkv = (g(B * T, 3 * d, seed=1) * 0.6).to(torch.bfloat16).float()
+    dctx = g(B * T, d, seed=2).to(torch.bfloat16).float().to(DEV)
+    lens = torch.tensor([T] + [max(1, (T * (i + 1)) // (B + 1)) for i in range(B - 1)])
+    pad = (torch.arange(T)[None, :] >= lens[:, None]).to(torch.uint8)
+    klen = torch.tensor([int((p == 0).nonzero().max()) + 1 for p in pad], dtype=torch.int32)
+    pad, klen = pad.to(DEV), klen.to(DEV)
+    step = torch.full((1,), 2, dtype=torch.int64, device=DEV)
+    drop = ops.DropCtx(seed=9, step_dev=step)
+    outs = []
+    for masked in (False, True):
+        q = qkv.to(DEV).requires_grad_()
+        m = ops.attention_dropmask(B, H, T, pdrop, drop, 6, DEV) if masked else None
+        ctx, lse = ops.AttentionFn.apply(q, pad, klen, B, H, T, dh, pdrop, drop, 6, TTSMI_BF16, m)
+        ctx.backward(dctx)
+        outs.append((ctx.detach().cpu(), lse.cpu(), q.grad.cpu()))
+    (c0, l0, g0), (c1, l1, g1) = outs
+    assert torch.equal(l0, l1)
+    assert rel_err(c1, c0) < 1e-5 and rel_err(g1, g0) < 1e-2
+    assert float((g1 - g0).abs().mean()) < 2e-3 * float(g0.abs().mean())

@@ -140,14 +140,14 @@ def bench_attn():
                 j = i[0] % R
                 i[0] += 1
                 check(l.ttsmi_attention_fwd_masked(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(lse), B, H, T, dh, pdrop,
-                                                   _p(dm), _stream()), 'attention_fwd_masked')
+                                                   _p(dm), _lib.TTSMI_BF16_IO, _stream()), 'attention_fwd_masked')
 
             def bwd_m():
                 j = i[0] % R
                 i[0] += 1
                 check(l.ttsmi_attention_bwd_masked(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(dctx[j]), _p(lse), _p(dqkv),
-                                                   B, H, T, dh, pdrop, _p(dm), _p(ws), ws.numel(), _stream()),
-                      'attention_bwd_masked')
+                                                   B, H, T, dh, pdrop, _p(dm), _p(ws), ws.numel(), _lib.TTSMI_BF16_IO,
+                                                   _stream()), 'attention_bwd_masked')
             fl = 4.0 * B * H * T * T * dh
             for nm, fn, mult in (('gen bits', gen, 0), ('fwd bits', fwd_m, 1), ('bwd bits', bwd_m, 2)):
                 t = timeit(fn, n=20)

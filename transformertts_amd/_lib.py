@@ -42,10 +42,10 @@ SIGNATURES = {
     'ttsmi_attention_weights': (I, [P, P, P, P, I, I, I, I, F, c_uint64, P, c_uint32, I, S]),
     'ttsmi_attention_dropmask_bytes': (c_size_t, [I, I, I]),
     'ttsmi_attention_dropmask': (I, [P, I, I, I, F, c_uint64, P, c_uint32, S]),
-    'ttsmi_attention_fwd_masked': (I, [P, P, P, P, P, I, I, I, I, F, P, S]),
+    'ttsmi_attention_fwd_masked': (I, [P, P, P, P, P, I, I, I, I, F, P, I, S]),
     'ttsmi_attention_fwd_splitkeys_ws_bytes': (c_size_t, [I, I, I, I]),
     'ttsmi_attention_fwd_splitkeys': (I, [P, P, P, P, P, I, I, I, I, P, c_size_t, S]),
-    'ttsmi_attention_bwd_masked': (I, [P, P, P, P, P, P, P, I, I, I, I, F, P, P, c_size_t, S]),
+    'ttsmi_attention_bwd_masked': (I, [P, P, P, P, P, P, P, I, I, I, I, F, P, P, c_size_t, I, S]),
     'ttsmi_add_layernorm_fwd': (I, [P, P, P, P, P, P, I, P, F, c_uint32, F, c_uint32, c_uint64, P,
                                     F, P, P, P, I, I, P, S]),
     'ttsmi_add_layernorm_bwd_ws_bytes': (c_size_t, [I, I]),

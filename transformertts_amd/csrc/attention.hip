@@ -570,21 +570,23 @@ int ttsmi_attention_dropmask(void* mask, int B, int H, int T, float p_drop, uint
 }
 
 int ttsmi_attention_fwd_masked(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
-                               float* lse, int B, int H, int T, int dh, float p_drop, const void* dropmask,
+                               float* lse, int B, int H, int T, int dh, float p_drop, const void* dropmask, int dtype,
                                ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(dropmask && p_drop > 0.f, "attention_fwd_masked: needs a keep-bit mask and p_drop > 0");
-    return ttsmi_hattention_fwd(qkv, key_pad, klen, ctx, lse, B, H, T, dh, p_drop, 0, nullptr, 0, 1, dropmask,
-                                (hipStream_t)stream);
+    TTSMI_CHECK_ARG(dtype == TTSMI_BF16 || dtype == TTSMI_BF16_IO, "attention_fwd_masked: dtype %d (TTSMI_BF16 / TTSMI_BF16_IO)", dtype);
+    return ttsmi_hattention_fwd(qkv, key_pad, klen, ctx, lse, B, H, T, dh, p_drop, 0, nullptr, 0, dtype == TTSMI_BF16_IO,
+                                dropmask, (hipStream_t)stream);
 }
 
 int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const int32_t* klen,
                                const void* ctx, const void* dctx, const float* lse, void* dqkv, int B,
                                int H, int T, int dh, float p_drop, const void* dropmask, void* ws, size_t ws_bytes,
-                               ttsmi_stream_t stream) {
+                               int dtype, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(dropmask && p_drop > 0.f, "attention_bwd_masked: needs a keep-bit mask and p_drop > 0");
+    TTSMI_CHECK_ARG(dtype == TTSMI_BF16 || dtype == TTSMI_BF16_IO, "attention_bwd_masked: dtype %d (TTSMI_BF16 / TTSMI_BF16_IO)", dtype);
     TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_attention_bwd_ws_bytes(B, H, T, dh), "attention_bwd_masked: workspace too small");
-    return ttsmi_hattention_bwd(qkv, key_pad, klen, ctx, dctx, lse, dqkv, B, H, T, dh, p_drop, 0, nullptr, 0, ws, 1,
-                                dropmask, (hipStream_t)stream);
+    return ttsmi_hattention_bwd(qkv, key_pad, klen, ctx, dctx, lse, dqkv, B, H, T, dh, p_drop, 0, nullptr, 0, ws,
+                                dtype == TTSMI_BF16_IO, dropmask, (hipStream_t)stream);
 }
 
 int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float* lse,

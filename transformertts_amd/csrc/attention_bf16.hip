@@ -862,7 +862,8 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
             else if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, true>), grid, dim3(256), pad_lds, st, p);  \
             else hipLaunchKernelGGL((KERNEL<DHV, 0, true>), grid, dim3(256), pad_lds, st, p);          \
         } else {                                                                               \
-            if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, false>), grid, dim3(256), pad_lds, st, p);  \
+            if ((p).thr && (p).dmask) hipLaunchKernelGGL((KERNEL<DHV, 2, false>), grid, dim3(256), pad_lds, st, p); \
+            else if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, false>), grid, dim3(256), pad_lds, st, p);  \
             else hipLaunchKernelGGL((KERNEL<DHV, 0, false>), grid, dim3(256), pad_lds, st, p);         \
         }                                                                                      \
     } while (0)
@@ -1055,7 +1056,6 @@ int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_fwd(bf16)");
     if (rc) return rc;
     TTSMI_CHECK_ARG(ctx && lse, "attention_fwd(bf16): null pointer");
-    TTSMI_CHECK_ARG(!dropmask || qh, "attention_fwd(bf16): the keep-bit mask needs bf16 activations (TTSMI_BF16_IO)");
     p.dmask = (const uint64_t*)dropmask;
     p.ctx = (float*)ctx; p.lse = lse;
     dim3 grid(ttsmi_cdiv(T, 128) * H * B);
@@ -1073,7 +1073,6 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_bwd(bf16)");
     if (rc) return rc;
     TTSMI_CHECK_ARG(ctx && dctx && lse && dqkv && ws, "attention_bwd(bf16): null pointer");
-    TTSMI_CHECK_ARG(!dropmask || qh, "attention_bwd(bf16): the keep-bit mask needs bf16 activations (TTSMI_BF16_IO)");
     p.dmask = (const uint64_t*)dropmask;
     p.octx = (const float*)ctx; p.dctx = (const float*)dctx; p.lse = (float*)lse;
     p.dqkv = (float*)dqkv; p.delta = (float*)ws;

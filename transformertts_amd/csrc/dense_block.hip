@@ -58,7 +58,7 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
         const double T2 = (double)D->T * D->T;
         OBS("ttsmi_attention_fwd", 4.0 * D->B * D->H * T2 * dh, (double)M * 3 * d * 2 + (double)M * d * 2 + 4.0 * D->B * D->H * D->T, st);
         if (D->dropmask && D->rate > 0.f)
-            TRY(ttsmi_attention_fwd_masked(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->dropmask, st));
+            TRY(ttsmi_attention_fwd_masked(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->dropmask, TTSMI_BF16_IO, st));
         else if (D->attn_split && D->rate == 0.f)
             TRY(ttsmi_attention_fwd_splitkeys(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->attn_ws,
                                               D->attn_ws_bytes, st));
@@ -176,7 +176,7 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     OBS("ttsmi_attention_bwd", 8.0 * D->B * D->H * T2 * dh, (double)M * 3 * d * 2 * 3 + (double)M * d * 2 * 3 + 16.0 * D->B * D->H * D->T, st);
     if (D->dropmask && dropout)
         TRY(ttsmi_attention_bwd_masked(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh,
-                                       D->rate, D->dropmask, D->attn_ws, D->attn_ws_bytes, st));
+                                       D->rate, D->dropmask, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));
     else
         TRY(ttsmi_attention_bwd(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh, D->rate,
                                 D->seed, D->step_dev, D->site_attn, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));

@@ -34,6 +34,9 @@ from ..utils.losses import masked_mean_absolute_error, weighted_sum_losses
 from .transformer_utils import positional_encoding
 
 
+_DROPBITS_CONV = os.environ.get('TTSMI_ATTN_DROPBITS_CONV', '0') == '1'
+
+
 def _on_device(fn):
     """Run a method with the model's GPU current: `device=` decides where the tensors live, but the launch
     stream, the weight-gradient side stream and every temporary follow torch's CURRENT device."""
@@ -412,8 +415,15 @@ class ForwardTransformer:
             qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'],
                                      S(f'{p}.wqkv'))
             site = drop.site()
+            dmask = None
+            pre = self._dropmask_plan.get(p) if self._dropmask_plan else None
+            if pre is not None:                  # keep-bit table generated ahead on the side stream (_launch_dropmasks)
+                dmask, site_planned, ev = pre
+                assert site_planned == site, (p, site_planned, site)
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
             ctx, lse = ops.AttentionFn.apply(qkv, pad, klen, B, H, T, d // H, rate, drop, site,
-                                             ops._lib.TTSMI_BF16 if self.precision == 'bf16' else ops.TTSMI_F32)
+                                             ops._lib.TTSMI_BF16 if self.precision == 'bf16' else ops.TTSMI_F32, dmask)
             if want_attn:
                 key = (f'{name}_DenseBlock{i + 1}_SelfAttention' if dense
                        else f'{name}_ConvBlock{i - dense_blocks + 1}_SelfAttention')
@@ -621,7 +631,10 @@ class ForwardTransformer:
                 site += len(c['duration_conv_filters']) + len(c['pitch_conv_filters']) + 1
             for i, H in enumerate(heads):
                 dh = d // H
-                if i < nd and dh in (32, 64) and d % 64 == 0:
+                # dense blocks only: for the conv blocks' attention sub-layer (fp32 tensors, dh = 192: three dK/dV passes)
+                # the table was measured and does NOT pay - 31.8 vs 31.1 ms per ref-default step - although
+                # ops.AttentionFn accepts one (TTSMI_ATTN_DROPBITS_CONV=1 turns it on)
+                if (i < nd and dh in (32, 64) and d % 64 == 0) or (i >= nd and dh in (32, 64, 192) and _DROPBITS_CONV):
                     plans.append((f'{prefix}.blk{i}', H, T, site + 1))
                 site += 3
         with torch.cuda.stream(side), ops.pin_stream(side.cuda_stream):

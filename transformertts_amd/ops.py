@@ -848,19 +848,29 @@ class AttentionFn(torch.autograd.Function):
     (model/layers.py:123-129,176-195,144-147).  Returns (ctx [M, H*dh], lse [B,H,T])."""
 
     @staticmethod
-    def forward(ctx, qkv, key_pad, klen, B, H, T, dh, p_drop, drop, site, dtype=TTSMI_F32):
+    def forward(ctx, qkv, key_pad, klen, B, H, T, dh, p_drop, drop, site, dtype=TTSMI_F32, dmask=None):
+        """dmask: the layer's keep-bit table (attention_dropmask) for the bf16 kernels on fp32 tensors (TTSMI_BF16) - the
+        same decisions as the in-kernel hash, read as bits by the forward and both backward kernels."""
         qkv = _c(qkv)
         d = H * dh
         if dtype != TTSMI_F32 and dh not in (32, 64, 192):
             dtype = TTSMI_F32                  # bf16 kernels are built for head dims 32 / 64 / 192
+        if dtype != _lib.TTSMI_BF16 or not p_drop > 0:
+            dmask = None
         out = torch.empty((B * T, d), dtype=torch.float32, device=qkv.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
         seed = drop.seed if drop is not None else 0
         step_dev = drop.step_dev if drop is not None else None
-        check(_lib.lib().ttsmi_attention_fwd(_p(qkv), _p(key_pad), _p(klen), _p(out), _p(lse), B, H, T, dh,
-                                             float(p_drop), seed, _p(step_dev), int(site), int(dtype),
-                                             _stream()), 'attention_fwd')
+        if dmask is not None:
+            check(_lib.lib().ttsmi_attention_fwd_masked(_p(qkv), _p(key_pad), _p(klen), _p(out), _p(lse), B, H, T, dh,
+                                                        float(p_drop), _p(dmask), int(dtype), _stream()),
+                  'attention_fwd_masked')
+        else:
+            check(_lib.lib().ttsmi_attention_fwd(_p(qkv), _p(key_pad), _p(klen), _p(out), _p(lse), B, H, T, dh,
+                                                 float(p_drop), seed, _p(step_dev), int(site), int(dtype),
+                                                 _stream()), 'attention_fwd')
         ctx.save_for_backward(qkv, key_pad, klen, out, lse, step_dev)
+        ctx.dmask = dmask
         ctx.cfg = (B, H, T, dh, float(p_drop), seed, int(site), int(dtype))
         ctx.mark_non_differentiable(lse)
         ctx.set_materialize_grads(False)      # no zero tensor for the unused d(lse)
@@ -874,10 +884,15 @@ class AttentionFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         l = _lib.lib()
         ws = _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, dh), qkv.device)
-        check(l.ttsmi_attention_bwd(_p(qkv), _p(key_pad), _p(klen), _p(out), _p(dout), _p(lse), _p(dqkv),
-                                    B, H, T, dh, p_drop, seed, _p(step_dev), site, _p(ws), ws.numel(),
-                                    dtype, _stream()), 'attention_bwd')
-        return dqkv, None, None, None, None, None, None, None, None, None, None
+        if ctx.dmask is not None:
+            check(l.ttsmi_attention_bwd_masked(_p(qkv), _p(key_pad), _p(klen), _p(out), _p(dout), _p(lse), _p(dqkv),
+                                               B, H, T, dh, p_drop, _p(ctx.dmask), _p(ws), ws.numel(), dtype, _stream()),
+                  'attention_bwd_masked')
+        else:
+            check(l.ttsmi_attention_bwd(_p(qkv), _p(key_pad), _p(klen), _p(out), _p(dout), _p(lse), _p(dqkv),
+                                        B, H, T, dh, p_drop, seed, _p(step_dev), site, _p(ws), ws.numel(),
+                                        dtype, _stream()), 'attention_bwd')
+        return dqkv, None, None, None, None, None, None, None, None, None, None, None
 
 
 class EmbeddingFn(torch.autograd.Function):
@@ -1220,7 +1235,8 @@ class DenseBlockFn(torch.autograd.Function):
             # time on a side stream (ForwardTransformer._launch_dropmasks); otherwise it is generated here.
             dmask = dmask_pre if dmask_pre is not None else attention_dropmask(B, H, T, rate, drop, sites[0], h.device)
             check(_lib.lib().ttsmi_attention_fwd_masked(_p(qkv), _p(pad), _p(klen), _p(cx), _p(lse), B, H, T, dh_,
-                                                        float(rate), _p(dmask), _stream()), 'attention_fwd_masked')
+                                                        float(rate), _p(dmask), _lib.TTSMI_BF16_IO, _stream()),
+                  'attention_fwd_masked')
         else:
             check(_lib.lib().ttsmi_attention_fwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(lse), B, H, T, dh_, float(rate),
                                                  drop.seed, _p(drop.step_dev), sites[0], int(dtype), _stream()),
@@ -1278,8 +1294,8 @@ class DenseBlockFn(torch.autograd.Function):
             ws = _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, dh_), h.device)
             if dmask is not None:
                 check(l.ttsmi_attention_bwd_masked(_p(qkv), _p(pad), _p(klen), _p(cx), _p(dctx), _p(lse), _p(dqkv), B, H,
-                                                   T, dh_, rate, _p(dmask), _p(ws), ws.numel(), _stream()),
-                      'attention_bwd_masked')
+                                                   T, dh_, rate, _p(dmask), _p(ws), ws.numel(), _lib.TTSMI_BF16_IO,
+                                                   _stream()), 'attention_bwd_masked')
             else:
                 check(l.ttsmi_attention_bwd(_p(qkv), _p(pad), _p(klen), _p(cx), _p(dctx), _p(lse), _p(dqkv), B, H, T, dh_,
                                             rate, drop.seed, _p(drop.step_dev), sites[0], _p(ws), ws.numel(), dtype,
