@@ -55,6 +55,15 @@ int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, lon
                             int M, int N, int relu, int out_bf16, const uint16_t* mask, long ldmask, hipStream_t st);
 
 // ---- wave64 reductions ------------------------------------------------------------------------
+// wave_sum / wave_max: the xor butterfly.  hipcc lowers each __shfl_xor to ds_bpermute_b32 (an LDS-pipe round trip of
+// ~100 cycles; six dependent ones per reduction) - irrelevant in the HBM-bound LayerNorm / loss kernels that use them.
+// Every lane ends with its OWN association order of the 64 terms, i.e. the rounding error of the total differs from
+// lane to lane.  That matters in one place: the LayerNorm backward forms dz = rstd (t - mean(t) - x^ mean(t x^)), and
+// where the two means cancel t almost completely (the pitch predictor's last LayerNorm, whose upstream gradient is a
+// rank-one dout * w) dz is the rounding error of the means.  Lane-dependent errors average out in the weight gradient
+// that sums dz over rows and columns; a lane-UNIFORM total (wave_sum_dpp below) leaves a systematic per-row error:
+// measured on the exact-fp32 path at the benchmark architecture, pitch.conv1.w moved from 1e-4 to 1.5e-3 of the fp64
+// oracle and the whole encoder behind it to 1e-3.  So the fp32 kernels keep the butterfly.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -64,6 +73,31 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+// wave_sum_dpp: DPP data-parallel-primitive moves - quad / row mirrors sum each row of 16 lanes in four VALU-rate steps,
+// two row broadcasts carry the row totals up, lane 63 holds the wave total and is read back as a scalar (every lane gets
+// the same bits).  Used by the fused GEMM + LayerNorm epilogues of the bf16 path (rowgemm.hip: two reductions per row, 16
+// rows per wave, one after the other = 192 dependent permutes with the butterfly).  Checked against the butterfly by
+// tools/probes/dpp_reduce_probe.hip.
+#define TTSMI_DPP_QUAD_1032 0xB1
+#define TTSMI_DPP_QUAD_2301 0x4E
+#define TTSMI_DPP_ROW_HALF_MIRROR 0x141
+#define TTSMI_DPP_ROW_MIRROR 0x140
+#define TTSMI_DPP_ROW_BCAST15 0x142
+#define TTSMI_DPP_ROW_BCAST31 0x143
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ttsmi_dpp(float v, float fill) {      // lanes outside ROW_MASK receive `fill`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += ttsmi_dpp<TTSMI_DPP_QUAD_1032, 0xF>(v, 0.f);
+    v += ttsmi_dpp<TTSMI_DPP_QUAD_2301, 0xF>(v, 0.f);
+    v += ttsmi_dpp<TTSMI_DPP_ROW_HALF_MIRROR, 0xF>(v, 0.f);
+    v += ttsmi_dpp<TTSMI_DPP_ROW_MIRROR, 0xF>(v, 0.f);                  // every lane: the sum of its row of 16
+    v += ttsmi_dpp<TTSMI_DPP_ROW_BCAST15, 0xA>(v, 0.f);                 // rows 1, 3 += rows 0, 2
+    v += ttsmi_dpp<TTSMI_DPP_ROW_BCAST31, 0xC>(v, 0.f);                 // rows 2, 3 += rows 0 + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---- counter-based dropout RNG ----------------------------------------------------------------

@@ -44,6 +44,7 @@ struct RowGemmP {
     const uint16_t* xhat_in; const float* rstd_in;
     uint16_t* dx_bf; float* dres;
     float* part; int nparts;           // per-workgroup partial sums of dgamma / dbeta: [nparts][256] + [nparts][256] (+ [nparts])
+    int ablate;                        // measurement only (TTSMI_ROWGEMM_ABLATE, LDS-DMA kernel): 1 no multiply, 2 no DMA, 4 no epilogue, 8 no forward-epilogue stores
 };
 
 __device__ __forceinline__ uint2 rg_pack4(float a, float b, float c, float d) {
@@ -161,11 +162,11 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4],
                 v[3] *= ((h1 >> 16) >= p.thr_in) ? p.inv_in : 0.f;
             }
             v[0] += rs[i].x; v[1] += rs[i].y; v[2] += rs[i].z; v[3] += rs[i].w;
-            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * invC;
+            const float mean = wave_sum_dpp(v[0] + v[1] + v[2] + v[3]) * invC;
             float q = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] -= mean; q += v[e] * v[e]; }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) * invC + p.eps);
+            const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) * invC + p.eps);
             if (lane == 0) p.rstd[row] = rstd;
             const bool padded = __builtin_amdgcn_readlane(pre.pad_l, i) != 0;
             float xh[4], yv[4];
@@ -174,6 +175,7 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4],
             yv[0] = xh[0] * gm.x + bt.x; yv[1] = xh[1] * gm.y + bt.y; yv[2] = xh[2] * gm.z + bt.z; yv[3] = xh[3] * gm.w + bt.w;
             if (padded) { yv[0] = 0.f; yv[1] = 0.f; yv[2] = 0.f; yv[3] = 0.f; }
             const long o = (long)row * RG_N + c4;
+            if (p.ablate & 8) continue;                     // (measurement: the epilogue without its global stores)
             *reinterpret_cast<float4*>(p.y + o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
             *reinterpret_cast<uint2*>(p.y_bf + o) = rg_pack4(yv[0], yv[1], yv[2], yv[3]);
             *reinterpret_cast<uint2*>(p.xhat + o) = rg_pack4(xh[0], xh[1], xh[2], xh[3]);
@@ -200,8 +202,8 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4],
 #pragma unroll
             for (int e = 0; e < 4; ++e) { ab[e] += gv[e]; ag[e] += gv[e] * xh[e]; }
             const float t[4] = {gv[0] * gm.x, gv[1] * gm.y, gv[2] * gm.z, gv[3] * gm.w};
-            const float m1 = wave_sum(t[0] + t[1] + t[2] + t[3]) * invC;
-            const float m2 = wave_sum(t[0] * xh[0] + t[1] * xh[1] + t[2] * xh[2] + t[3] * xh[3]) * invC;
+            const float m1 = wave_sum_dpp(t[0] + t[1] + t[2] + t[3]) * invC;
+            const float m2 = wave_sum_dpp(t[0] * xh[0] + t[1] * xh[1] + t[2] * xh[2] + t[3] * xh[3]) * invC;
             float dz[4], dx[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) dz[e] = rstd * (t[e] - m1 - xh[e] * m2);
@@ -363,8 +365,11 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
             rd_dma16(p.Bt + (long)row * p.ldb + kb + c * 8, rd_lds_offset(Bs + (wave * 32 + i * 8) * 128));
         }
     };
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
+    const bool dma_on = !(p.ablate & 2);
+    if (dma_on) {
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+    }
     // the epilogue's residual / x^ rows, requested now: NPRE more instructions on this wave's vmcnt, YOUNGER than k-steps
     // 0 and 1 and older than every later one
     constexpr int NPRE = RG_NPRE(EPI, RD_BM / 8);
@@ -378,23 +383,36 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
         else if (ks < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NPRE) : "memory");
         else __builtin_amdgcn_s_waitcnt(0xF76);                      // vmcnt(6)
         rd_stage_barrier();                                          // everybody's pieces landed; stage (ks-1)%3 is retired
-        if (ks + 2 < nk) issue(ks + 2, (ks + 2) % RD_STAGES);
+        if (dma_on && ks + 2 < nk) issue(ks + 2, (ks + 2) % RD_STAGES);
         const unsigned char* As = smem + (ks % RD_STAGES) * RD_STAGE;
         const unsigned char* Bs = As + RD_BM * 128;
+        if (p.ablate & 1) continue;
+        // Fragments of TWO 16-wide k-slices (10 x 16 B per lane) are requested before the first of their 8 MFMAs issues:
+        // written one fragment at a time, hipcc keeps a single ds_read ahead of each MFMA and the matrix pipe waits out an
+        // LDS round trip per multiply (23 % busy in the k-loop: it, not the fill, was what bounded this kernel).
 #pragma unroll
-        for (int kk = 0; kk < RG_BK / 16; ++kk) {
-            const int c = kk * 2 + hh;
+        for (int k2 = 0; k2 < RG_BK / 32; ++k2) {
+            bf16x8 a[2], b[2][4];
             const int arow = wm * 32 + l31;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + arow * 128 + ((c ^ ((arow >> 1) & 7)) << 4));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int brow = wc * 128 + j * 32 + l31;
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + brow * 128 + ((c ^ ((brow >> 1) & 7)) << 4));
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[j], 0, 0, 0);
+            for (int u = 0; u < 2; ++u) {
+                const int c = (k2 * 2 + u) * 2 + hh;
+                a[u] = *reinterpret_cast<const bf16x8*>(As + arow * 128 + ((c ^ ((arow >> 1) & 7)) << 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int brow = wc * 128 + j * 32 + l31;
+                    b[u][j] = *reinterpret_cast<const bf16x8*>(Bs + brow * 128 + ((c ^ ((brow >> 1) & 7)) << 4));
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);            // all ten reads are in flight before the multiplies start
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[u][j], a[u], acc[j], 0, 0, 0);
         }
     }
     __syncthreads();
+    if (p.ablate & 4) return;
     rg_epilogue<EPI, 8, RD_BM>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
 }
 
@@ -423,8 +441,8 @@ __global__ __launch_bounds__(256) void ln_bwd_xhat_kernel(RowGemmP p, const floa
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ab[e] += gv[e]; ag[e] += gv[e] * xh[e]; }
         const float t[4] = {gv[0] * gm.x, gv[1] * gm.y, gv[2] * gm.z, gv[3] * gm.w};
-        const float s1 = wave_sum(t[0] + t[1] + t[2] + t[3]) * (1.0f / RG_N);
-        const float s2 = wave_sum(t[0] * xh[0] + t[1] * xh[1] + t[2] * xh[2] + t[3] * xh[3]) * (1.0f / RG_N);
+        const float s1 = wave_sum_dpp(t[0] + t[1] + t[2] + t[3]) * (1.0f / RG_N);
+        const float s2 = wave_sum_dpp(t[0] * xh[0] + t[1] * xh[1] + t[2] * xh[2] + t[3] * xh[3]) * (1.0f / RG_N);
         float dz[4], dx[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) dz[e] = rstd * (t[e] - s1 - xh[e] * s2);
@@ -472,6 +490,9 @@ static int rg_common(RowGemmP& p, const uint16_t* a, int64_t lda, const uint16_t
     if (a2) TTSMI_CHECK_ARG(K1 > 0 && K1 < K && K1 % RG_BK == 0 && lda2 % 8 == 0 && rg_al16(a2), "%s: bad second K segment", who);
     memset(&p, 0, sizeof(p));
     p.A = a; p.lda = lda; p.A2 = a2; p.lda2 = lda2; p.K1 = K1; p.Bt = bt; p.ldb = ldb; p.M = M; p.K = K;
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("TTSMI_ROWGEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+    p.ablate = ablate;
     return TTSMI_OK;
 }
 
