@@ -22,17 +22,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// The value of the other half-wave's lane (lane ^ 32), by gfx950's v_permlane32_swap: one VALU instruction where
-// __shfl_xor(v, 32) is a ds_bpermute round trip through the LDS pipe (~100 cycles in the softmax's dependency chain).
-// swap(v, v) exchanges the upper 32 lanes of its first operand with the lower 32 of the second: the two results hold
-// the lower-half values and the upper-half values in BOTH halves.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void halves_of(float v, float& lo, float& hi) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    lo = __builtin_bit_cast(float, r[0]);
-    hi = __builtin_bit_cast(float, r[1]);
-}
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -467,11 +456,7 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            {
-                float lo, hi;
-                halves_of(mx, lo, hi);
-                mx = fmaxf(lo, hi) * cs;                               // cs > 0: max commutes with the scale
-            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * cs;              // cs > 0: max commutes with the scale
             const float mn = fmaxf(m, mx);
             const float alpha = EXP2(m - mn);
 #pragma unroll
@@ -494,11 +479,7 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
                 hmask_apply_all(s, mw);
                 hmask_request(mw, mrow + min((kbase >> 5) + 1, ntile32 - 1) * 16);      // the next block's words
             }
-            {
-                float lo, hi;
-                halves_of(rs, lo, hi);
-                rs = lo + hi;
-            }
+            rs += __shfl_xor(rs, 32, 64);
             l = l * alpha + rs;
             m = mn;
             if (!__all(alpha == 1.0f)) {
