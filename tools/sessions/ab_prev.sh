@@ -7,7 +7,7 @@ R=$PWD
 export TMPDIR=/tmp
 python -m pytest tests/test_ops_gpu.py tests/test_config1_parity_gpu.py tests/test_model_gpu.py -q -m gpu -x -k "${1:-gemm or layernorm or config1 or parity}" 2>&1 | tail -3
 if [ -n "$2" ]; then
-  for d in $R/_ab/prev $R; do echo "== $d"; ( cd $d && python tools/kbench.py --only $2 2>&1 | grep -v amdgpu.ids | grep "28800" ); done
+  for d in $R/_ab/prev $R; do echo "== $d"; ( cd $d && python tools/kbench.py --only $2 2>&1 | grep -v amdgpu.ids | grep "28800\|6400" ); done
 fi
 run() { ( cd $1 && python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-attention-maps 2>/dev/null | python -c "
 import sys,json

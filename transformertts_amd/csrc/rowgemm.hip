@@ -123,15 +123,16 @@ __device__ __forceinline__ void rg_prefetch(const RowGemmP& p, int m0, int wave,
     else pre.rstd_l = 0.f;
 }
 
-template <int EPI, int NW, int BM>
-__device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[4], int m0, float* Z, int wave, int wm, int wc,
+// NJ = 32-column blocks of a wave's accumulator tile (4: waves 2-wide over the 256 columns; 2: 4-wide)
+template <int EPI, int NW, int BM, int NJ = 4>
+__device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ], int m0, float* Z, int wave, int wm, int wc,
                                             int lane, const RgPre<EPI, BM / NW>& pre) {
     const int l31 = lane & 31, hh = lane >> 5;
     // ---- accumulators -> Z (all waves finished reading the operand stages: the caller synchronised)
     {
-        float* zr = Z + (wm * 32 + l31) * RG_ZLD + wc * 128 + 4 * hh;
+        float* zr = Z + (wm * 32 + l31) * RG_ZLD + wc * (NJ * 32) + 4 * hh;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(zr + j * 32 + 8 * g) =
@@ -324,19 +325,26 @@ __device__ __forceinline__ unsigned rd_lds_offset(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-template <int EPI>
+// BM = 128: waves 4 (rows) x 2 (columns), wave tile 32 x 128.  BM = 64: waves 2 x 4, wave tile 32 x 64 - for launches whose
+// 128-row tiles would occupy fewer than half the CUs (the encoder side, M = 6 400: 50 workgroups): twice the workgroups,
+// each with a shorter fill per k-step (40 KB) and half the epilogue.
+template <int EPI, int BM>
 __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
-    static_assert(RD_STAGES * RD_STAGE >= RD_BM * RG_ZLD * 4, "the epilogue tile lives in the retired stages");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[RD_STAGES * RD_STAGE];
+    constexpr int NJ = BM == 128 ? 4 : 2;                  // 32-column blocks per wave
+    constexpr int STAGE = (BM + RG_N) * RG_BK * 2;
+    constexpr int DMA_A = BM / 64;                         // A-image DMA instructions per wave and k-step (+ 4 for W)
+    static_assert(BM == 128 || BM == 64, "row tiles of 128 or 64");
+    static_assert(RD_STAGES * STAGE >= BM * RG_ZLD * 4, "the epilogue tile lives in the retired stages");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RD_STAGES * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                      // 0..7
-    const int wm = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * RD_BM;
+    const int wm = BM == 128 ? wave >> 1 : wave >> 2, wc = BM == 128 ? wave & 1 : wave & 3;
+    const int m0 = blockIdx.x * BM;
     const int nk = p.K / RG_BK;
 
-    f32x16 acc[4];
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
@@ -344,18 +352,18 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
     // A image (2 instructions) and rows [32 w, 32 w + 32) of the W image (4 instructions): 6 per wave and step.
     const int drow = lane >> 3, dpos = lane & 7;
     auto issue = [&](int ks, int stage) {
-        unsigned char* As = smem + stage * RD_STAGE;
-        unsigned char* Bs = As + RD_BM * 128;
+        unsigned char* As = smem + stage * STAGE;
+        unsigned char* Bs = As + BM * 128;
         int k0 = ks * RG_BK;
         const uint16_t* Ab = p.A;
         long lda = p.lda;
         if (p.A2 != nullptr && k0 >= p.K1) { Ab = p.A2; lda = p.lda2; k0 -= p.K1; }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = wave * 16 + i * 8 + drow;
+        for (int i = 0; i < DMA_A; ++i) {
+            const int row = wave * (8 * DMA_A) + i * 8 + drow;
             const int c = dpos ^ ((row >> 1) & 7);
             const int gm = min(m0 + row, p.M - 1);                   // rows past M: clamped on load, dropped on store
-            rd_dma16(Ab + (long)gm * lda + k0 + c * 8, rd_lds_offset(As + (wave * 16 + i * 8) * 128));
+            rd_dma16(Ab + (long)gm * lda + k0 + c * 8, rd_lds_offset(As + (wave * (8 * DMA_A) + i * 8) * 128));
         }
         const int kb = ks * RG_BK;
 #pragma unroll
@@ -372,35 +380,35 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
     }
     // the epilogue's residual / x^ rows, requested now: NPRE more instructions on this wave's vmcnt, YOUNGER than k-steps
     // 0 and 1 and older than every later one
-    constexpr int NPRE = RG_NPRE(EPI, RD_BM / 8);
-    static_assert(6 + NPRE <= 63, "vmcnt is a 6-bit counter");
-    RgPre<EPI, RD_BM / 8> pre;
-    rg_prefetch<EPI, 8, RD_BM>(p, m0, wave, lane, pre);
+    constexpr int NPRE = RG_NPRE(EPI, BM / 8), NDMA = 4 + DMA_A;
+    static_assert(NDMA + NPRE <= 63, "vmcnt is a 6-bit counter");
+    RgPre<EPI, BM / 8> pre;
+    rg_prefetch<EPI, 8, BM>(p, m0, wave, lane, pre);
     for (int ks = 0; ks < nk; ++ks) {
         // step ks has landed once at most the newest step's 6 DMA instructions (and, for the first two steps, the
         // prefetch behind them) are outstanding
         if (ks + 1 >= nk) __builtin_amdgcn_s_waitcnt(0xF70);         // vmcnt(0)
-        else if (ks < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NPRE) : "memory");
-        else __builtin_amdgcn_s_waitcnt(0xF76);                      // vmcnt(6)
+        else if (ks < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + NPRE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         rd_stage_barrier();                                          // everybody's pieces landed; stage (ks-1)%3 is retired
         if (dma_on && ks + 2 < nk) issue(ks + 2, (ks + 2) % RD_STAGES);
-        const unsigned char* As = smem + (ks % RD_STAGES) * RD_STAGE;
-        const unsigned char* Bs = As + RD_BM * 128;
+        const unsigned char* As = smem + (ks % RD_STAGES) * STAGE;
+        const unsigned char* Bs = As + BM * 128;
         if (p.ablate & 1) continue;
         // Fragments of TWO 16-wide k-slices (10 x 16 B per lane) are requested before the first of their 8 MFMAs issues:
         // written one fragment at a time, hipcc keeps a single ds_read ahead of each MFMA and the matrix pipe waits out an
         // LDS round trip per multiply (23 % busy in the k-loop: it, not the fill, was what bounded this kernel).
 #pragma unroll
         for (int k2 = 0; k2 < RG_BK / 32; ++k2) {
-            bf16x8 a[2], b[2][4];
+            bf16x8 a[2], b[2][NJ];
             const int arow = wm * 32 + l31;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int c = (k2 * 2 + u) * 2 + hh;
                 a[u] = *reinterpret_cast<const bf16x8*>(As + arow * 128 + ((c ^ ((arow >> 1) & 7)) << 4));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int brow = wc * 128 + j * 32 + l31;
+                for (int j = 0; j < NJ; ++j) {
+                    const int brow = wc * (NJ * 32) + j * 32 + l31;
                     b[u][j] = *reinterpret_cast<const bf16x8*>(Bs + brow * 128 + ((c ^ ((brow >> 1) & 7)) << 4));
                 }
             }
@@ -408,12 +416,12 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[u][j], a[u], acc[j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[u][j], a[u], acc[j], 0, 0, 0);
         }
     }
     __syncthreads();
     if (p.ablate & 4) return;
-    rg_epilogue<EPI, 8, RD_BM>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
+    rg_epilogue<EPI, 8, BM, NJ>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
 }
 
 // ---- standalone backward of a LayerNorm whose forward kept x^ (bf16) and rstd: the fused forward's counterpart for the
@@ -500,6 +508,13 @@ static int rg_common(RowGemmP& p, const uint16_t* a, int64_t lda, const uint16_t
 // default = by size.  Measured (tools/kbench.py --only rowgemm): the LDS-DMA kernel wins at M = 28 800 (32.7 / 45.2 /
 // 44.3 us for o+LN1, FFN2+LN2, dgrad+LN1' against 34.6 / 56.9 / 54.8) and still at M = 6 400, where it fills only 50 CUs
 // (26.5 / 33.4 / 30.7 against 27.9 / 37.2 / 34.1): the 64-row kernel is kept for small batches.
+// rows per tile of the LDS-DMA kernel: 64 when 128-row tiles would leave more than half of the 256 CUs without a workgroup
+static int rg_dma_bm(int M) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("TTSMI_ROWGEMM_BM"); forced = e ? atoi(e) : 0; }
+    if (forced == 64 || forced == 128) return forced;
+    return ttsmi_cdiv(M, RD_BM) < 128 ? 64 : RD_BM;
+}
 static bool rg_use_dma(int M) {
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("TTSMI_ROWGEMM_DMA"); mode = e ? atoi(e) : 2; }
@@ -529,7 +544,10 @@ int ttsmi_hgemm_ln_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64
     p.bias = bias; p.res = res; p.gamma = gamma; p.beta = beta; p.row_pad = row_pad; p.eps = eps;
     p.y = y; p.y_bf = y_bf16; p.xhat = xhat_bf16; p.rstd = rstd;
     rg_drop(p, p_in, site_in, seed, step_dev);
-    if (rg_use_dma(M)) hipLaunchKernelGGL((rowgemm_dma_kernel<0>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
+    if (rg_use_dma(M)) {
+        if (rg_dma_bm(M) == 64) hipLaunchKernelGGL((rowgemm_dma_kernel<0, 64>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((rowgemm_dma_kernel<0, RD_BM>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
+    }
     else hipLaunchKernelGGL((rowgemm_kernel<0>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("hgemm_ln_fwd");
     return TTSMI_OK;
@@ -537,7 +555,7 @@ int ttsmi_hgemm_ln_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64
 
 size_t ttsmi_layernorm_partials_bytes(int nparts, int C) { return (2 * (size_t)nparts * C + nparts) * sizeof(float) + 256; }
 
-int ttsmi_hgemm_ln_bwd_nparts(int M) { return rg_use_dma(M) ? ttsmi_cdiv(M, RD_BM) : ttsmi_cdiv(M, RG_BM); }
+int ttsmi_hgemm_ln_bwd_nparts(int M) { return rg_use_dma(M) ? ttsmi_cdiv(M, rg_dma_bm(M)) : ttsmi_cdiv(M, RG_BM); }
 
 int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64_t ldb, const float* dy_part,
                        const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
@@ -552,7 +570,10 @@ int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64
     p.res = dy_part; p.xhat_in = xhat_bf16; p.rstd_in = rstd; p.gamma = gamma; p.row_pad = row_pad;
     p.dx_bf = dx_bf16; p.dres = dres; p.part = (float*)part_ws;
     rg_drop(p, p_in, site_in, seed, step_dev);
-    if (rg_use_dma(M)) hipLaunchKernelGGL((rowgemm_dma_kernel<1>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
+    if (rg_use_dma(M)) {
+        if (rg_dma_bm(M) == 64) hipLaunchKernelGGL((rowgemm_dma_kernel<1, 64>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((rowgemm_dma_kernel<1, RD_BM>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
+    }
     else hipLaunchKernelGGL((rowgemm_kernel<1>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("hgemm_ln_bwd");
     return TTSMI_OK;
