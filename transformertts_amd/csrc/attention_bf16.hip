@@ -892,34 +892,50 @@ static int henv(const char* name, int dflt) {
 // attention.hip - 32 fp32 MFMAs per tile on a widened copy of qkv - took 2.4 x the write time.)
 template <int DH>
 __global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __restrict__ weights) {
+    // A workgroup owns 32 queries of one (b, h) - their fragments stay in registers - and walks along the keys, 128 per
+    // pass (32 per wave): its output is ONE contiguous block of 32 rows x T floats, written left to right.  (First
+    // version: one workgroup per 32 x 128 tile, 29 700 workgroups per decoder layer, 227 us; keys resident and a walk down
+    // the queries, which scatters every row over eight workgroups: 202 us.)
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.z, b = bh / p.H, h = bh - b * p.H;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int d = p.H * DH;
-    const int key = (blockIdx.x * 4 + wave) * 32 + l31;
-    const int q0 = blockIdx.y * 32;
-    if ((blockIdx.x * 4 + wave) * 32 >= p.T) return;
+    const int q0 = blockIdx.x * 32;
     const float* Qb = eptr<true>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<true>(Qb, d);
-    bf16x8 qf[DH / 16], kf[DH / 16];
+    bf16x8 qf[DH / 16], kf[DH / 16], kn[DH / 16];
     frags_of<DH, true>(Qb, p.ld, q0 + l31, q0 + l31 < p.T, hh, qf);
-    frags_of<DH, true>(Kb, p.ld, key, key < p.T, hh, kf);
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < DH / 16; ++i) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[i], kf[i], s, 0, 0, 0);   // S[q][key]
-    const float padterm = (key < p.T && p.key_pad[(long)b * p.T + key]) ? -1e9f : 0.f;
+    frags_of<DH, true>(Kb, p.ld, wave * 32 + l31, wave * 32 + l31 < p.T, hh, kf);
     const long stat0 = (long)bh * p.T;
     const uint64_t dkey = p.thr ? ttsmi_drop_key(p.seed, p.step_dev, p.site) : 0;
     const float inv_sqrt = 1.0f / p.sqrt_dk;
+    float lse_r[16];                                         // this lane's 16 query rows
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = q0 + rowmap16(r, hh);
-        if (q >= p.T || key >= p.T) continue;
-        float pr = __expf(s[r] * inv_sqrt + padterm - p.lse[stat0 + q]);
-        if (p.thr) pr *= ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q), (uint32_t)key, p.thr, p.inv_keep);
-        weights[(stat0 + q) * (long)p.T + key] = pr;
+    for (int r = 0; r < 16; ++r) lse_r[r] = p.lse[stat0 + min(q0 + rowmap16(r, hh), p.T - 1)];
+    for (int k0 = 0; k0 < p.T; k0 += 128) {
+        const int key = k0 + wave * 32 + l31;
+        const bool more = k0 + 128 < p.T;
+        if (more) frags_of<DH, true>(Kb, p.ld, key + 128, key + 128 < p.T, hh, kn);           // next pass's rows, a pass ahead
+        if (k0 + wave * 32 < p.T) {                          // wave-uniform
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < DH / 16; ++i) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[i], kf[i], s, 0, 0, 0);   // S[q][key]
+            const float padterm = (key < p.T && p.key_pad[(long)b * p.T + key]) ? -1e9f : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + rowmap16(r, hh);
+                if (q >= p.T || key >= p.T) continue;
+                float pr = __expf(s[r] * inv_sqrt + padterm - lse_r[r]);
+                if (p.thr) pr *= ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q), (uint32_t)key, p.thr, p.inv_keep);
+                weights[(stat0 + q) * (long)p.T + key] = pr;
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < DH / 16; ++i) kf[i] = kn[i];
+        }
     }
 }
 
@@ -931,7 +947,7 @@ int ttsmi_hattention_weights(const void* qkv, const uint8_t* key_pad, const floa
     if (rc) return rc;
     TTSMI_CHECK_ARG(lse && weights, "attention_weights(bf16): null pointer");
     p.lse = const_cast<float*>(lse);
-    dim3 grid(ttsmi_cdiv(T, 128), ttsmi_cdiv(T, 32), B * H);
+    dim3 grid(ttsmi_cdiv(T, 32), B * H);
     switch (dh) {
         case 32: hipLaunchKernelGGL((hattn_weights_kernel<32>), grid, dim3(256), 0, st, p, weights); break;
         case 64: hipLaunchKernelGGL((hattn_weights_kernel<64>), grid, dim3(256), 0, st, p, weights); break;
