@@ -909,6 +909,8 @@ __global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __r
     const long stat0 = (long)bh * p.T;
     const uint64_t dkey = p.thr ? ttsmi_drop_key(p.seed, p.step_dev, p.site) : 0;
     const float inv_sqrt = 1.0f / p.sqrt_dk;
+    __shared__ __attribute__((aligned(16))) float tile[32][132];
+    const bool vec = (p.T & 3) == 0 && (((uintptr_t)weights) & 15) == 0;      // rows are 16-byte aligned
     float lse_r[16];                                         // this lane's 16 query rows
 #pragma unroll
     for (int r = 0; r < 16; ++r) lse_r[r] = p.lse[stat0 + min(q0 + rowmap16(r, hh), p.T - 1)];
@@ -926,11 +928,27 @@ __global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = q0 + rowmap16(r, hh);
-                if (q >= p.T || key >= p.T) continue;
-                float pr = __expf(s[r] * inv_sqrt + padterm - lse_r[r]);
-                if (p.thr) pr *= ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q), (uint32_t)key, p.thr, p.inv_keep);
-                weights[(stat0 + q) * (long)p.T + key] = pr;
+                float pr = 0.f;
+                if (q < p.T && key < p.T) {
+                    pr = __expf(s[r] * inv_sqrt + padterm - lse_r[r]);
+                    if (p.thr) pr *= ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q), (uint32_t)key, p.thr, p.inv_keep);
+                    if (!vec) weights[(stat0 + q) * (long)p.T + key] = pr;
+                }
+                if (vec) tile[rowmap16(r, hh)][wave * 32 + l31] = pr;
             }
+        }
+        if (vec) {
+            // rows leave as 16 bytes per lane: a wave instruction writes two rows x 512 contiguous bytes (the direct form
+            // above is 4 bytes per lane, two rows x 128 bytes)
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl = wave * 8 + it * 2 + hh, c4 = l31 * 4;
+                const int q = q0 + rl, kc = k0 + c4;
+                if (q < p.T && kc < p.T)                       // T % 4 == 0: a quad is inside the row or outside it
+                    *reinterpret_cast<float4*>(weights + (stat0 + q) * (long)p.T + kc) = *reinterpret_cast<const float4*>(&tile[rl][c4]);
+            }
+            __syncthreads();
         }
         if (more) {
 #pragma unroll
