@@ -914,9 +914,12 @@ __global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __r
     float lse_r[16];                                         // this lane's 16 query rows
 #pragma unroll
     for (int r = 0; r < 16; ++r) lse_r[r] = p.lse[stat0 + min(q0 + rowmap16(r, hh), p.T - 1)];
-    for (int k0 = 0; k0 < p.T; k0 += 128) {
+    // (small launches - batch-1 inference - split the key range over blockIdx.z so that the GPU still fills)
+    const int kbeg = blockIdx.z * p.split_keys, kend = min(p.T, kbeg + p.split_keys);
+    if (kbeg > 0) frags_of<DH, true>(Kb, p.ld, kbeg + wave * 32 + l31, kbeg + wave * 32 + l31 < p.T, hh, kf);
+    for (int k0 = kbeg; k0 < kend; k0 += 128) {
         const int key = k0 + wave * 32 + l31;
-        const bool more = k0 + 128 < p.T;
+        const bool more = k0 + 128 < kend;
         if (more) frags_of<DH, true>(Kb, p.ld, key + 128, key + 128 < p.T, hh, kn);           // next pass's rows, a pass ahead
         if (k0 + wave * 32 < p.T) {                          // wave-uniform
             f32x16 s;
@@ -966,6 +969,12 @@ int ttsmi_hattention_weights(const void* qkv, const uint8_t* key_pad, const floa
     TTSMI_CHECK_ARG(lse && weights, "attention_weights(bf16): null pointer");
     p.lse = const_cast<float*>(lse);
     dim3 grid(ttsmi_cdiv(T, 32), B * H);
+    const int passes = ttsmi_cdiv(T, 128);
+    int nz = ttsmi_cdiv(2048, (int)(grid.x * grid.y));                 // >= 2048 workgroups when the problem allows
+    if (nz > passes) nz = passes;
+    if (nz < 1) nz = 1;
+    p.split_keys = ttsmi_cdiv(passes, nz) * 128;
+    grid.z = ttsmi_cdiv(passes * 128, p.split_keys);
     switch (dh) {
         case 32: hipLaunchKernelGGL((hattn_weights_kernel<32>), grid, dim3(256), 0, st, p, weights); break;
         case 64: hipLaunchKernelGGL((hattn_weights_kernel<64>), grid, dim3(256), 0, st, p, weights); break;
