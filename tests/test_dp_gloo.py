@@ -20,6 +20,20 @@ def _free_port():
     return p
 
 
+def _spawn(fn, args, nprocs, seconds=240):
+    """mp.spawn with a deadline: a collective that deadlocks must fail the test, not hang the suite (the workers are
+    killed by PID)."""
+    import time
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    deadline = time.time() + seconds
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for proc in ctx.processes:
+                if proc.is_alive():
+                    proc.kill()
+            pytest.fail(f'{fn.__name__}: {nprocs} ranks did not finish within {seconds} s')
+
+
 def _flat(grads):
     return torch.cat([g.reshape(-1) for g in grads.values()])
 
@@ -66,7 +80,7 @@ def _worker(rank, world, port, out_dir):
 def test_gradient_allreduce_equals_global_batch_gradient(tmp_path):
     from oracle import ft_oracle as fo
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _spawn(_worker, (2, port, str(tmp_path)), 2)
     avg = np.load(tmp_path / 'avg.npy')
     cfg = fo.tiny_config()
     W = fo.init_weights(cfg, seed=1, perturb=0.02)
@@ -134,7 +148,7 @@ def test_two_ranks_match_the_global_batch_step(tmp_path, backend):
     if backend == 'nccl' and torch.cuda.device_count() < 2:
         pytest.skip('RCCL needs one GPU per rank: fewer than 2 GPUs visible')
     port = _free_port()
-    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path), backend), nprocs=2, join=True)
+    _spawn(_gpu_worker, (2, port, str(tmp_path), backend), 2)
     w0, w1 = np.load(tmp_path / 'w0.npy'), np.load(tmp_path / 'w1.npy')
     np.testing.assert_array_equal(w0, w1)
     cfg = fo.tiny_config()
