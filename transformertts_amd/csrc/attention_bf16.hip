@@ -879,11 +879,6 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
     }
 #define HDISPATCH(dh, KERNEL, grid, st, p) HDISPATCH_LDS(dh, KERNEL, grid, 0, st, p)
 
-static int henv(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 // ---- attention maps on request (model/layers.py:195,302-310: the reference returns the post-dropout weights of every layer)
 // One workgroup = 32 queries x 128 keys (wave = 32 keys): S = Q.K^T straight from the bf16 rows the forward used (4 MFMAs per
 // wave), P = exp(S / sqrt(dh) + pad - lse) with the forward's log-sum-exp, the same counter-hash keep decisions, and the
@@ -1102,7 +1097,7 @@ int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     p.dmask = (const uint64_t*)dropmask;
     p.ctx = (float*)ctx; p.lse = lse;
     dim3 grid(ttsmi_cdiv(T, 128) * H * B);
-    static const int fwd_pad = henv("TTSMI_ATTN_FWD_LDS", 0);        // A/B knob: 24576 caps the forward at 3 workgroups per CU
+    TTSMI_KNOB(fwd_pad, "TTSMI_ATTN_FWD_LDS", 0);        // A/B knob: 24576 caps the forward at 3 workgroups per CU
     HDISPATCH_LDS(dh, hattn_fwd_kernel, grid, fwd_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_fwd(bf16)");
     return TTSMI_OK;
@@ -1123,11 +1118,11 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     // Occupancy A/B knobs (untouched dynamic LDS caps the workgroups per CU).  Round 2, decoder shape, keep-bit dropout:
     // forward 4 / 3 workgroups per CU = 69.0 / 86.9 us, dQ+dKV with dQ at 3 / 2 / 1 = 189.7 / 193.5 / 243.3 us - every
     // kernel here wants all the waves its registers allow.
-    static const int dq_pad = henv("TTSMI_ATTN_DQ_LDS", 0);
+    TTSMI_KNOB(dq_pad, "TTSMI_ATTN_DQ_LDS", 0);
     HDISPATCH_LDS(dh, hattn_bwd_dq_kernel, grid, dq_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dq(bf16)");
     dim3 grid_kv(grid.x, dh > 64 ? dh / 64 : 1);
-    static const int dkv_pad = henv("TTSMI_ATTN_DKV_LDS", 0);
+    TTSMI_KNOB(dkv_pad, "TTSMI_ATTN_DKV_LDS", 0);
     HDISPATCH_LDS(dh, hattn_bwd_dkv_kernel, grid_kv, dkv_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dkv(bf16)");
     return TTSMI_OK;

@@ -31,6 +31,23 @@ void ttsmi_set_error(const char* fmt, ...);
 
 static inline int ttsmi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- tuning knobs ------------------------------------------------------------------------------
+// Environment variables are read ONCE per process, through a function-local `static const` (C++11: initialised by exactly
+// one thread), so concurrent first calls do not race.  TTSMI_KNOB: A/B knobs that choose between equivalent kernels.
+// TTSMI_ABLATE_KNOB: stage-ablation / skip knobs whose results are WRONG by construction - they only exist in a library
+// built with -DTTSMI_ABLATION_BUILD (TTSMI_EXTRA_HIPCC_FLAGS, build.py); the shipped library ignores the variable.
+#include <stdlib.h>
+static inline int ttsmi_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#define TTSMI_KNOB(var, name, dflt) static const int var = ttsmi_env_int(name, dflt)
+#ifdef TTSMI_ABLATION_BUILD
+#define TTSMI_ABLATE_KNOB(var, name) static const int var = ttsmi_env_int(name, 0)
+#else
+#define TTSMI_ABLATE_KNOB(var, name) static const int var = 0
+#endif
+
 // bf16-operand attention kernels (attention_bf16.hip), reached through ttsmi_attention_fwd/bwd with
 // dtype == TTSMI_BF16
 int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,

@@ -100,8 +100,7 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
 static int wgrad_side(const ttsmi_dense_block* D, int ev, bool record, const uint16_t* x, int ldx, const uint16_t* dy, int lddy,
                       float* dw, float* db, int kin, int n) {
     const int M = D->B * D->T;
-    static int skip = -1;      // measurement knob (results are then WRONG: no weight gradients): main-stream-only backward time
-    if (skip < 0) { const char* e = getenv("TTSMI_DEBUG_SKIP_WGRAD"); skip = e ? atoi(e) : 0; }
+    TTSMI_ABLATE_KNOB(skip, "TTSMI_DEBUG_SKIP_WGRAD");      // measurement knob (results are then WRONG: no weight gradients): main-stream-only backward time
     if (skip) return TTSMI_OK;
     hipStream_t main_st = (hipStream_t)D->main_stream;
     hipStream_t st = D->side_stream ? (hipStream_t)D->side_stream : main_st;
@@ -157,8 +156,7 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     TRY(wgrad_side(D, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
     // dh += do.Wo_top^T (fp32) and dctx = do.Wo_ctx^T (bf16): Wo as stored is [2d][d] = both weight halves back to back,
     // and both products read d_o - one weight-stationary launch when the shape suits it (d = 256, decoder-size M)
-    static int split_ok = -1;           // TTSMI_DENSE_SPLIT_DGRAD=0: two launches (A/B knob)
-    if (split_ok < 0) { const char* e = getenv("TTSMI_DENSE_SPLIT_DGRAD"); split_ok = e ? atoi(e) : 1; }
+    TTSMI_KNOB(split_ok, "TTSMI_DENSE_SPLIT_DGRAD", 1);           // TTSMI_DENSE_SPLIT_DGRAD=0: two launches (A/B knob)
     if (split_ok && d == 256 && ttsmi_hgemm_k256_eligible(M, 2 * d, d)) {
         OBS("ttsmi_hgemm_tn", 2.0 * M * d * 2 * d, gemm_bytes(M, d, d, 4, true) + gemm_bytes(M, d, d, 2, false) - (double)M * d * 2, st);
         TRY(ttsmi_hgemm_k256_split(D->d_o, d, D->wo_b, d, D->dh, d, d, D->dctx, d, M, 2 * d, st));

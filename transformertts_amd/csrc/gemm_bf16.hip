@@ -1196,11 +1196,7 @@ static void hinit(HGemmP& p) {
 
 static int hgemm_bm(bool a_f32, int M, int N, int splits) {
     // tuning knob (measurement only): TTSMI_HGEMM_BM=64|128 overrides the default tile height
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("TTSMI_HGEMM_BM");
-        forced = e ? atoi(e) : 0;
-    }
+    TTSMI_KNOB(forced, "TTSMI_HGEMM_BM", 0);
     if (forced == 64 || forced == 128) return forced;
     if (a_f32) return 64;
     // bf16 A: 128-row tiles halve the B re-reads, but a launch that cannot give every CU a workgroup
@@ -1214,11 +1210,7 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
     // (TTSMI_HGEMM_BN=256): on the decoder shapes they are 0-35 % SLOWER than 128x128 / 64x128
     // (tools/probe_gemm_variants.py) - 252 VGPRs halve the resident workgroups, and these short-K GEMMs
     // live on latency hiding across workgroups, not on L2 re-read volume.
-    static int forced_bn = -1;
-    if (forced_bn < 0) {
-        const char* e = getenv("TTSMI_HGEMM_BN");
-        forced_bn = e ? atoi(e) : 0;
-    }
+    TTSMI_KNOB(forced_bn, "TTSMI_HGEMM_BN", 0);
     const bool wide = forced_bn == 256 && !a_f32 && splits == 1 && p.N % 256 == 0;
     if (wide) {
         p.tiles_m = ttsmi_cdiv(p.M, 128);
@@ -1233,8 +1225,7 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
     // K = 512 / 768 / 1024 with N = 256 run 19.6 / 27.4 / 31.5-38.5 us against 24.2 / 30.9 / 39.8-45.5 us register-staged
     // (a deeper k-loop amortises the persistent pipeline), the K = 256 shapes tie or lose (4 k-steps per tile: the
     // epilogue dominates either way) and the M = 6 400 launches lose (too few tiles per workgroup).
-    static int use_dma = -1;
-    if (use_dma < 0) { const char* e = getenv("TTSMI_HGEMM_DMA"); use_dma = e ? atoi(e) : 3; }
+    TTSMI_KNOB(use_dma, "TTSMI_HGEMM_DMA", 3);
     if (use_dma && !a_f32 && splits == 1 && p.colsum == nullptr && p.a_taps == 1 && p.K % HBK_ == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 &&
         (use_dma != 3 || p.K >= 512) &&
         (p.A2 == nullptr || (p.K1 % HBK_ == 0 && p.lda2 % 8 == 0 && al16(p.A2)))) {
@@ -1250,8 +1241,7 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
     }
     // Under-filled launches (fewer 64 x 128 workgroups than 1.5 per CU): the deep-ring 64 x 64 kernel.  TTSMI_HGEMM_DEEP=0
     // keeps the register-staged kernel (A/B knob).
-    static int use_deep = -1;
-    if (use_deep < 0) { const char* e = getenv("TTSMI_HGEMM_DEEP"); use_deep = e ? atoi(e) : 1; }
+    TTSMI_KNOB(use_deep, "TTSMI_HGEMM_DEEP", 1);
     // Round-2 A/B (tools/kbench.py --only gemm-small, M = 6400 / 2304 / 400): K = 1024 runs 13.2 / 10.3 / 9.9 us against
     // 20.7 / 16.0 / 15.9 us register-staged, K = 768 15.5 / 10.1 / 9.8 against 17.1 / 13.4 / 13.2; the K = 256 shapes (a
     // single round trip either way) tie or lose, so they stay where they were.  Batch-1 predict: 1.14 -> 0.95 ms.
@@ -1269,8 +1259,7 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
     p.tiles_m = ttsmi_cdiv(p.M, bm);
     p.tiles_n = ttsmi_cdiv(p.N, HBN_);
     dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-    static int occ4 = -1;      // measurement knob, default off: the 4-workgroups-per-CU build (see the kernel's comment)
-    if (occ4 < 0) { const char* e = getenv("TTSMI_HGEMM_OCC4"); occ4 = e ? atoi(e) : 0; }
+    TTSMI_KNOB(occ4, "TTSMI_HGEMM_OCC4", 0);      // measurement knob, default off: the 4-workgroups-per-CU build (see the kernel's comment)
     const auto fits32 = [](long rows, long ld) { return rows * ld * 2 < (1L << 32); };
     if (occ4 && !a_f32 && bm == 128 && fits32(p.M, p.lda) && fits32(p.N, p.ldb) &&
         (p.A2 == nullptr || fits32(p.M, p.lda2))) {
@@ -1292,12 +1281,8 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
 static int hpick_splits(long rows, int tiles) {
     // ~1 workgroup per CU: wgrad overlaps the main stream, and fewer splits = less slab traffic.
     // Splits come in multiples of 8 so that the XCD-aware 1-D grid gives every XCD whole splits.
-    static int target = -1;
-    if (target < 0) {
-        const char* e = getenv("TTSMI_WGRAD_WGS");
-        target = e ? atoi(e) : 128;
-        if (target < 8) target = 128;
-    }
+    TTSMI_KNOB(target_env, "TTSMI_WGRAD_WGS", 128);
+    const int target = target_env < 8 ? 128 : target_env;
     int want = (target + tiles - 1) / tiles;
     if (want > 8) want = (want + 7) / 8 * 8;
     int maxs = (int)((rows + 511) / 512);
@@ -1339,8 +1324,7 @@ int ttsmi_hgemm_tn(const void* a, int a_is_f32, int64_t lda, const void* a2, int
     // K = 256 projections without a second segment / accumulation: weight-stationary kernel (gemm_k256.hip); a ReLU' mask
     // is supported in its bf16 -> bf16 form (the masked FFN1 dgrad)
     const bool k256_mask_ok = !relu_src || (mask_bf16 && c_bf16 && !bias && !relu && ld_relu % 8 == 0 && al16(relu_src));
-    static int k256_mask = -1;          // TTSMI_HGEMM_K256_MASK=0: masked launches stay on the general kernel (A/B knob)
-    if (k256_mask < 0) { const char* e = getenv("TTSMI_HGEMM_K256_MASK"); k256_mask = e ? atoi(e) : 1; }
+    TTSMI_KNOB(k256_mask, "TTSMI_HGEMM_K256_MASK", 1);          // TTSMI_HGEMM_K256_MASK=0: masked launches stay on the general kernel (A/B knob)
     if (!a_is_f32 && !a2 && k256_mask_ok && (!relu_src || k256_mask) && !accumulate && conv_taps <= 1 && lda % 8 == 0 && ldc % 4 == 0 &&
         (c_bf16 ? ldc % 8 == 0 : true) && al16(c) && ttsmi_hgemm_k256_eligible(M, N, K)) {
         ttsmi_hgemm_k256_launch((const uint16_t*)a, (long)lda, b, (long)ldb, bias, c, (long)ldc, M, N, relu ? 1 : 0,
@@ -1419,8 +1403,7 @@ int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void
     p.k_per_split = kps;
     p.ws = (float*)ws; p.colsum = db; p.colsum_ws = p.ws + (size_t)splits * kin * n;
     dim3 wgrid(tiles * splits);
-    static int wdma = -1;
-    if (wdma < 0) { const char* e = getenv("TTSMI_WGRAD_DMA"); wdma = e ? atoi(e) : 1; }
+    TTSMI_KNOB(wdma, "TTSMI_WGRAD_DMA", 1);
     const bool dma_ok = wdma && x_is_bf16 && dy_is_bf16 && conv_taps <= 1 && rows % WR_ROWS == 0 && kin % 128 == 0 &&
                         n % 128 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && al16(x) && al16(dy);
     if (dma_ok) hipLaunchKernelGGL(wgrad_dma_kernel, wgrid, dim3(256), 0, st, p);

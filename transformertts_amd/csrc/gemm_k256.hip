@@ -406,8 +406,7 @@ extern "C" {
 
 // 1 if ttsmi_hgemm_tn would route this launch to the weight-stationary kernel (exposed for tests / benchmarks)
 int ttsmi_hgemm_k256_eligible(int M, int N, int K) {
-    static int mode = -1;      // TTSMI_HGEMM_K256: 0 = never, 1 = every eligible launch, default = by size
-    if (mode < 0) { const char* e = getenv("TTSMI_HGEMM_K256"); mode = e ? atoi(e) : 2; }
+    TTSMI_KNOB(mode, "TTSMI_HGEMM_K256", 2);      // TTSMI_HGEMM_K256: 0 = never, 1 = every eligible launch, default = by size
     if (mode == 0 || K != KW_K || N % 8 != 0) return 0;
     if (mode == 1) return 1;
     return M >= 4096 && N >= 256;
@@ -434,8 +433,7 @@ int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, lon
     p.A = a; p.lda = lda; p.Bt = bt; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.relu = relu; p.M = M; p.N = N;
     p.mask = mask; p.ldmask = ldmask;
     // bf16 output, whole 256-column chunks, enough row tiles per workgroup to amortise its 128 KB of weights: wide variant
-    static int wide = -1;               // TTSMI_HGEMM_K256_WIDE=0: always the 128-column kernel (A/B knob)
-    if (wide < 0) { const char* e = getenv("TTSMI_HGEMM_K256_WIDE"); wide = e ? atoi(e) : 1; }
+    TTSMI_KNOB(wide, "TTSMI_HGEMM_K256_WIDE", 1);               // TTSMI_HGEMM_K256_WIDE=0: always the 128-column kernel (A/B knob)
     if (wide && out_bf16 && N % KWW_BN == 0 && (M >= 16384 || wide > 1)) {
         p.nchunks = N / KWW_BN;
         p.ntiles = ttsmi_cdiv(M, KW_BM);
@@ -444,8 +442,7 @@ int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, lon
         const int need = (p.ntiles + 7) / 8 * 8;
         if (groups > need) groups = need;
         p.ngroups = groups;
-        static int ablate = -1;
-        if (ablate < 0) { const char* e = getenv("TTSMI_K256_ABLATE"); ablate = e ? atoi(e) : 0; }
+        TTSMI_ABLATE_KNOB(ablate, "TTSMI_K256_ABLATE");
         p.ablate = ablate;
         dim3 gridw(p.nchunks * p.ngroups);
         if (mask) hipLaunchKernelGGL((gemm_k256_wide_kernel<2>), gridw, dim3(512), 0, st, p);

@@ -377,8 +377,8 @@ __global__ __launch_bounds__(256) void ln_param_reduce_batched_kernel(LnReduceBa
 static int ln_bwd_blocks(int M) {
     // rows are walked by a wave one after the other (each row is a dependent load -> reduce -> store chain),
     // so the grid sets how many chains run in parallel; TTSMI_LN_BWD_BLOCKS overrides the cap (measurement)
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("TTSMI_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 1024; if (cap < 1) cap = 1024; }
+    TTSMI_KNOB(cap_env, "TTSMI_LN_BWD_BLOCKS", 1024);
+    const int cap = cap_env < 1 ? 1024 : cap_env;
     int b = ttsmi_cdiv(M, LN_WAVES);
     return b > cap ? cap : (b < 1 ? 1 : b);
 }

@@ -498,8 +498,7 @@ static int rg_common(RowGemmP& p, const uint16_t* a, int64_t lda, const uint16_t
     if (a2) TTSMI_CHECK_ARG(K1 > 0 && K1 < K && K1 % RG_BK == 0 && lda2 % 8 == 0 && rg_al16(a2), "%s: bad second K segment", who);
     memset(&p, 0, sizeof(p));
     p.A = a; p.lda = lda; p.A2 = a2; p.lda2 = lda2; p.K1 = K1; p.Bt = bt; p.ldb = ldb; p.M = M; p.K = K;
-    static int ablate = -1;
-    if (ablate < 0) { const char* e = getenv("TTSMI_ROWGEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+    TTSMI_ABLATE_KNOB(ablate, "TTSMI_ROWGEMM_ABLATE");
     p.ablate = ablate;
     return TTSMI_OK;
 }
@@ -510,14 +509,12 @@ static int rg_common(RowGemmP& p, const uint16_t* a, int64_t lda, const uint16_t
 // (26.5 / 33.4 / 30.7 against 27.9 / 37.2 / 34.1): the 64-row kernel is kept for small batches.
 // rows per tile of the LDS-DMA kernel: 64 when 128-row tiles would leave more than half of the 256 CUs without a workgroup
 static int rg_dma_bm(int M) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("TTSMI_ROWGEMM_BM"); forced = e ? atoi(e) : 0; }
+    TTSMI_KNOB(forced, "TTSMI_ROWGEMM_BM", 0);
     if (forced == 64 || forced == 128) return forced;
     return ttsmi_cdiv(M, RD_BM) < 128 ? 64 : RD_BM;
 }
 static bool rg_use_dma(int M) {
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("TTSMI_ROWGEMM_DMA"); mode = e ? atoi(e) : 2; }
+    TTSMI_KNOB(mode, "TTSMI_ROWGEMM_DMA", 2);
     if (mode == 0) return false;
     if (mode == 1) return true;
     return M >= 16 * RD_BM;

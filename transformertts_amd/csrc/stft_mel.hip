@@ -273,11 +273,8 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
     p.total_frames = total_frames; p.hop = hop; p.window = window; p.n_mels = n_mels;
     p.mel_lo = mel_lo; p.mel_cnt = mel_cnt; p.mel_ptr = mel_ptr; p.mel_w = mel_w;
     p.normalizer = normalizer; p.clip_min = clip_min; p.out = out;
-#ifdef TTSMI_ABLATION_BUILD      // stage ablation gives wrong results by construction: only in a measurement build
-    { const char* e = getenv("TTSMI_MEL_ABLATE"); p.ablate = e ? atoi(e) : 0; }
-#else
-    p.ablate = 0;
-#endif
+    TTSMI_ABLATE_KNOB(ablate, "TTSMI_MEL_ABLATE");      // wrong results by construction: only in a measurement build
+    p.ablate = ablate;
     long groups = (total_frames + FR_PER_WG - 1) / FR_PER_WG;
     int gpw = 1;
     while (gpw < 16 && groups / (gpw * 2) >= 2048) gpw *= 2;   // amortise the twiddle build
