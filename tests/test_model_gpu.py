@@ -241,6 +241,14 @@ def test_graph_captured_predict_equals_eager_predict(tiny):
         graph.return_attention = eager.return_attention = False
         e, g_ = eager.predict(tok, encode=False), graph.predict(tok, encode=False)
         assert _rel(g_['mel'], e['mel']) < tol and len(g_['decoder_attention']) == 0
+        # the graph cache is bounded: least recently used input shapes are dropped, and come back by re-capture
+        graph.GRAPH_CACHE_SHAPES = 2
+        for Tp in (7, 9, 11, 7):
+            tok = rng.integers(1, 127, size=(1, Tp)).astype(np.int32)
+            e, g_ = eager.predict(tok, encode=False), graph.predict(tok, encode=False)
+            assert g_['mel'].shape == e['mel'].shape and _rel(g_['mel'], e['mel']) < tol
+            assert len(graph._infer_graphs) <= 2
+        assert [k[2] for k in graph._infer_graphs] == [11, 7]
 
 
 def test_predict_matches_oracle(tiny):

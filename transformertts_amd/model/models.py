@@ -864,6 +864,9 @@ class ForwardTransformer:
         return out
 
     MEL_BUCKET = 64        # graph_inference: decoder lengths are rounded up to a multiple of this many frames
+    GRAPH_CACHE_SHAPES = 32   # graph_inference: input shapes whose graphs (and the buffers baked into them) are kept;
+    #                           the least recently used shape is dropped beyond that, so a server fed arbitrary sentence
+    #                           lengths holds a bounded amount of HBM
 
     def _predict_graphed(self, inp, duration_scalar, max_mask, min_mask, phoneme_durations, phoneme_pitch, ra):
         """predict() replayed from two captured hipGraphs (BASELINE.json configs[4]): the eager forward is ~250
@@ -871,7 +874,9 @@ class ForwardTransformer:
         dependent (sum of the rounded durations), so the forward is cut where the reference's eager call synchronises
         anyway: graph A = masks .. encoder .. predictors .. pitch embedding .. total lengths (per input shape), one host
         read of the maximum length, graph B = Expand .. decoder .. mel projection per decoder-length BUCKET (multiples
-        of MEL_BUCKET frames; rows past the true length are padding: masked keys, sliced off the outputs)."""
+        of MEL_BUCKET frames; rows past the true length are padding: masked keys, sliced off the outputs).
+        The returned tensors are views of the graphs' static output buffers: they are valid until the next predict()
+        of the same input shape (clone what must outlive it) - the price of a launch-free replay."""
         B, Tp = inp.shape
         dev = self.device
         f32 = lambda t: None if t is None else torch.as_tensor(t, device=dev).to(torch.float32).reshape(B, Tp).contiguous()
@@ -893,6 +898,11 @@ class ForwardTransformer:
                 with torch.cuda.graph(A['graph']):
                     A['out'] = run()
             self._infer_graphs[keyA] = A
+            while len(self._infer_graphs) > max(1, int(self.GRAPH_CACHE_SHAPES)):
+                torch.cuda.synchronize()                     # no replay in flight still reads the dropped buffers
+                self._infer_graphs.pop(next(iter(self._infer_graphs)))
+        else:
+            self._infer_graphs[keyA] = self._infer_graphs.pop(keyA)      # most recently used last
         for dst, src in ((A['tok'], inp), (A['maxm'], max_mask), (A['minm'], min_mask), (A['dur'], durs), (A['pit'], pit)):
             if dst is not None:
                 dst.copy_(src, non_blocking=True)
