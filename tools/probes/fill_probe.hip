@@ -4,6 +4,8 @@
 //   V0  LDS-DMA (global_load_lds_dwordx4), 3-stage ring, counted vmcnt            - what rowgemm_dma_kernel does
 //   V1  registers -> ds_write_b128, prefetch distance 1 (6 x 16 B per thread), one LDS buffer, 2 barriers per step
 //   V2  registers -> ds_write_b128, prefetch distance 2 (12 x 16 B per thread), two LDS buffers, 1 barrier per step
+//   V0r LDS-DMA as V0, but both slabs addressed the way the kernel sees them: rows of row-major [M][1024] / [256][1024]
+//       bf16 matrices, 128 bytes (one k-step) from each row per step, instead of contiguous 16 KB / 32 KB pieces
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/fill_probe.hip -o /tmp/fill && /tmp/fill
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -24,6 +26,14 @@ __device__ __forceinline__ const char* item(const char* a, const char* b, int ks
     return i < AB / 16 ? a + (long)ks * AB + i * 16 : b + (long)ks * (SLAB - AB) + (i - AB / 16) * 16;
 }
 
+// the same item when both slabs are what the kernel reads: 128 activation rows / 256 weight rows of row-major matrices
+// with 2 KB rows (K = 1024 bf16), 128 bytes of each row per k-step
+__device__ __forceinline__ const char* item_rows(const char* a, const char* b, int ks, int i) {
+    const int j = i < AB / 16 ? i : i - AB / 16;          // 8 items = the 128 bytes of one row in this k-step
+    return (i < AB / 16 ? a : b) + (long)(j >> 3) * (STEPS * 128) + ks * 128 + (j & 7) * 16;
+}
+
+template <bool ROWS>
 __global__ __launch_bounds__(512, 1) void v0(const char* A, const char* B, unsigned* sink) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SLAB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -32,7 +42,7 @@ __global__ __launch_bounds__(512, 1) void v0(const char* A, const char* B, unsig
 #pragma unroll
         for (int i = 0; i < 6; ++i) {                      // 6 instructions x 1 KB per wave = 48 KB per workgroup
             const int q = wave * 6 + i;
-            dma16(item(a, B, ks, q * 64 + lane), lds_off(smem + st * SLAB + q * 1024));
+            dma16(ROWS ? item_rows(a, B, ks, q * 64 + lane) : item(a, B, ks, q * 64 + lane), lds_off(smem + st * SLAB + q * 1024));
         }
     };
     issue(0, 0); issue(1, 1);
@@ -100,10 +110,11 @@ int main() {
     char *A, *B; unsigned* sink;
     hipMalloc(&A, (size_t)grid * STEPS * AB); hipMalloc(&B, (size_t)STEPS * (SLAB - AB)); hipMalloc(&sink, 4096);
     hipMemset(A, 1, (size_t)grid * STEPS * AB); hipMemset(B, 2, (size_t)STEPS * (SLAB - AB));
-    const double t0 = run(v0, A, B, sink, grid), t1 = run(vreg<1>, A, B, sink, grid), t2 = run(vreg<2>, A, B, sink, grid);
+    const double t0 = run(v0<false>, A, B, sink, grid), t0r = run(v0<true>, A, B, sink, grid), t1 = run(vreg<1>, A, B, sink, grid), t2 = run(vreg<2>, A, B, sink, grid);
     const double kb = STEPS * SLAB / 1024.0;
     printf("225 workgroups x %d steps x 48 KB:\n", STEPS);
     printf("  V0 LDS-DMA 3-stage ring      %6.1f us  (%.2f us/step, %.1f GB/s per CU)\n", t0, t0 / STEPS, kb * 1024 / t0 / 1e3);
+    printf("  V0r same, row-major A slab   %6.1f us  (%.2f us/step, %.1f GB/s per CU)\n", t0r, t0r / STEPS, kb * 1024 / t0r / 1e3);
     printf("  V1 registers, distance 1     %6.1f us  (%.2f us/step, %.1f GB/s per CU)\n", t1, t1 / STEPS, kb * 1024 / t1 / 1e3);
     printf("  V2 registers, distance 2     %6.1f us  (%.2f us/step, %.1f GB/s per CU)\n", t2, t2 / STEPS, kb * 1024 / t2 / 1e3);
     return 0;

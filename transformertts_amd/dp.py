@@ -54,6 +54,9 @@ class GradAllReduce:
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a one-rank group normally issues no collective; TTSMI_DP_FORCE_COLLECTIVES=1 issues them anyway (sum over one
+        # rank = identity), which lets a 1-GPU box exercise the RCCL stream ordering of this file (tools/probe_rccl_world1.py)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('TTSMI_DP_FORCE_COLLECTIVES') == '1')
         # SUM + one 1/world scaling pass on every backend: ReduceOp.AVG is NCCL-only and not worth a
         # backend-dependent code path (the scaling pass is one 44 MB stream, ~15 us)
         self.use_avg = False
@@ -67,7 +70,7 @@ class GradAllReduce:
         return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
 
     def start_tail(self, flat_grad: torch.Tensor, split: int, side_stream=None) -> None:
-        if not self.overlap or self.world == 1 or self._tail is not None or split <= 0 or split >= flat_grad.numel():
+        if not self.overlap or not self.active or self._tail is not None or split <= 0 or split >= flat_grad.numel():
             return
         tail = flat_grad[split:]
         if flat_grad.is_cuda:
@@ -85,7 +88,7 @@ class GradAllReduce:
         self._tail = (work, split)
 
     def __call__(self, flat_grad: torch.Tensor) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         if self._tail is not None:
             work, split = self._tail
@@ -121,7 +124,7 @@ class DataParallel:
     def __init__(self, model, group=None, broadcast: bool = True):
         self.model = model
         self.sync = GradAllReduce(group)
-        model.grad_sync = self.sync if self.sync.world > 1 else None
+        model.grad_sync = self.sync if self.sync.active else None
         if broadcast:
             broadcast_parameters(model.params.data, 0, group)
             if getattr(model, 'shadow', None) and hasattr(model, '_refresh_shadows'):
@@ -130,7 +133,7 @@ class DataParallel:
             # replicas share the weight-init seed but must not share dropout masks: every rank draws its own stream
             rank = dist.get_rank(group)
             model.drop.seed = (model.drop.seed ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
-        if self.sync.world > 1 and self.sync.overlap:
+        if self.sync.active and self.sync.overlap:
             self.install_overlap_hook()
 
     def install_overlap_hook(self):
