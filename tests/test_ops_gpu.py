@@ -338,6 +338,14 @@ def test_masks_embedding_pitch_rowdot():
     td = table.double().requires_grad_()
     td[tok.long()].backward(dy.double())
     assert rel_err(tg.grad, td.grad) < 1e-6
+    # benchmark-size token matrix: several scan chunks, one id (padding) with thousands of positions, unused ids
+    tok_l = torch.randint(1, 40, (32, 200), generator=torch.Generator().manual_seed(5)).int()
+    tok_l[:, 60:] = 0
+    tl = g(V, 256, seed=12).to(DEV).requires_grad_()
+    dyl = g(32, 200, 256, seed=13)
+    ops.EmbeddingFn.apply(tok_l.to(DEV), tl, None).backward(dyl.to(DEV))
+    want = torch.zeros(V, 256, dtype=torch.float64).index_add_(0, tok_l.reshape(-1).long(), dyl.reshape(-1, 256).double())
+    assert rel_err(tl.grad, want) < 2e-5 and float(tl.grad[40:].abs().max()) == 0.0      # fp32 running sums of 4 480 rows
     # pitch embed
     x, p, w, b = g(B * T, C, seed=3), g(B * T, seed=4), g(C, seed=5), g(C, seed=6)
     ts = [t.to(DEV).requires_grad_() for t in (x, p, w, b)]
