@@ -440,6 +440,29 @@ def test_l1_loss_and_adam():
     pr = g(4, 50, 1, seed=4)
     li = ops.L1LossFn.apply(pr.to(DEV), ti.to(DEV))
     assert abs(float(li) - float((ti.double() - pr.double()).abs().mean())) < 1e-6
+    # weighted_sum_losses as one op: bit-identical to the three separate losses + the Python-level weighted sum
+    from transformertts_amd.utils.losses import masked_mean_absolute_error as mae, weighted_sum_losses
+    mel_p, mel_t = g(4, 50, 80, seed=20), g(4, 50, 80, seed=21)
+    dur_p, pit_p, pit_t = g(4, 50, 1, seed=22), g(4, 50, 1, seed=23), g(4, 50, 1, seed=24)
+    for unit_seed in (False, True):
+        a = [t.to(DEV).requires_grad_() for t in (mel_p, dur_p, pit_p)]
+        b = [t.to(DEV).requires_grad_() for t in (mel_p, dur_p, pit_p)]
+        tg = (mel_t.to(DEV), ti.to(DEV), pit_t.to(DEV))
+        total, vals = weighted_sum_losses(tg, a, [mae] * 3, [1., 1., 3.], unit_seed=unit_seed)
+        sep = [ops.L1LossFn.apply(b[i], tg[i]) for i in range(3)]
+        want = 0
+        for c, l in zip([1., 1., 3.], sep):
+            want = want + c * l
+        assert [float(v) for v in vals] == [float(v) for v in sep] and float(total) == float(want)
+        assert not any(v.requires_grad for v in vals) and total.requires_grad
+        total.backward()
+        want.backward()
+        for x, y in zip(a, b):
+            assert torch.equal(x.grad, y.grad)
+    a = [t.to(DEV).requires_grad_() for t in (mel_p, dur_p, pit_p)]
+    total, _ = weighted_sum_losses(tg, a, [mae] * 3, [1., 1., 3.])
+    (2.0 * total).backward()                       # a seed other than 1 goes through the general path
+    assert torch.equal(a[0].grad, 2.0 * b[0].grad) and torch.equal(a[2].grad, 2.0 * b[2].grad)
     # TF-form Adam, three steps, against the oracle's hand restatement
     n = 1000
     p0, grads = g(n, seed=5), [g(n, seed=6 + i) for i in range(3)]

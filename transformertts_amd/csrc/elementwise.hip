@@ -452,6 +452,62 @@ int ttsmi_l1_loss(const float* pred, int64_t ld_pred, const void* target, int ta
     return TTSMI_OK;
 }
 
+// utils/losses.py:63-70 in one call: every term's partial sums are finished by ONE block, which also forms
+// total = ((0 + c0 l0) + c1 l1) + ... in the reference's order (products and sums rounded separately, as eager TF does).
+#define L1_MAX_TERMS 8
+struct L1FinalP {
+    int n;
+    int nb[L1_MAX_TERMS];
+    float inv_n[L1_MAX_TERMS], coeff[L1_MAX_TERMS];
+};
+__global__ __launch_bounds__(256) void l1_final_multi_kernel(const float* __restrict__ part, L1FinalP q,
+                                                             float* __restrict__ losses, float* __restrict__ total) {
+    __shared__ float red[4];
+    float tot = 0.f;
+    for (int t = 0; t < q.n; ++t) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < q.nb[t]; i += 256) s += part[(long)t * L1_BLOCKS + i];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float loss = (red[0] + red[1] + red[2] + red[3]) * q.inv_n[t];
+        __syncthreads();
+        tot = __fadd_rn(tot, __fmul_rn(q.coeff[t], loss));
+        if (threadIdx.x == 0) losses[t] = loss;
+    }
+    if (threadIdx.x == 0) total[0] = tot;
+}
+
+size_t ttsmi_l1_losses_weighted_ws_bytes(int n_terms) {
+    return (size_t)(n_terms > 0 ? n_terms : 1) * L1_BLOCKS * sizeof(float) + 256;
+}
+int ttsmi_l1_losses_weighted(int n_terms, const float* const* pred, const int64_t* ld_pred, const void* const* target,
+                             const int32_t* target_is_int, const int64_t* rows, const int64_t* cols, const float* coeff,
+                             float* const* grad, const int64_t* ld_grad, float* losses_out, float* total_out, void* ws,
+                             size_t ws_bytes, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(n_terms >= 1 && n_terms <= L1_MAX_TERMS, "l1_losses_weighted: %d terms (1..%d)", n_terms, L1_MAX_TERMS);
+    TTSMI_CHECK_ARG(pred && ld_pred && target && target_is_int && rows && cols && coeff && grad && ld_grad && losses_out &&
+                    total_out, "l1_losses_weighted: null pointer");
+    TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_l1_losses_weighted_ws_bytes(n_terms), "l1_losses_weighted: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    L1FinalP q;
+    q.n = n_terms;
+    for (int t = 0; t < n_terms; ++t) {
+        TTSMI_CHECK_ARG(pred[t] && target[t] && rows[t] > 0 && cols[t] > 0, "l1_losses_weighted: bad term %d", t);
+        const long n = rows[t] * cols[t];
+        int nb = ew_blocks(n);
+        if (nb > L1_BLOCKS) nb = L1_BLOCKS;
+        q.nb[t] = nb; q.inv_n[t] = 1.0f / (float)n; q.coeff[t] = coeff[t];
+        hipLaunchKernelGGL(l1_loss_kernel, dim3(nb), dim3(256), 0, st, pred[t], (long)ld_pred[t], target[t], (int)target_is_int[t],
+                           (long)rows[t], (long)cols[t], coeff[t] / (float)n, grad[t], (long)ld_grad[t],
+                           (float*)ws + (size_t)t * L1_BLOCKS);
+        TTSMI_CHECK_LAUNCH("l1_losses_weighted(term)");
+    }
+    hipLaunchKernelGGL(l1_final_multi_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, q, losses_out, total_out);
+    TTSMI_CHECK_LAUNCH("l1_losses_weighted(final)");
+    return TTSMI_OK;
+}
+
 __global__ void step_increment_kernel(int64_t* s) { s[0] += 1; }
 int ttsmi_step_increment(int64_t* step_dev, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(step_dev, "step_increment: null pointer");

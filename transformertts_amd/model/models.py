@@ -669,10 +669,10 @@ class ForwardTransformer:
         self._pred_keep = None
 
     # ------------------------------------------------------------------ steps (models.py:464-507)
-    def _losses(self, model_out, target_sequence, target_durations, target_pitch):
+    def _losses(self, model_out, target_sequence, target_durations, target_pitch, unit_seed=False):
         return weighted_sum_losses((target_sequence, target_durations, target_pitch),
                                    (model_out['mel'], model_out['duration'], model_out['pitch']),
-                                   self.loss, self.loss_weights)
+                                   self.loss, self.loss_weights, unit_seed=unit_seed)
 
     def _prep(self, input_sequence, target_sequence, target_durations, target_pitch):
         dev = self.device
@@ -712,7 +712,7 @@ class ForwardTransformer:
                 self._dropmask_plan = {}
                 self._use_plans = False
             self._join_predictors()              # the duration / pitch losses read the side stream's outputs
-            loss, loss_vals = self._losses(model_out, ts, td, tp)
+            loss, loss_vals = self._losses(model_out, ts, td, tp, unit_seed=True)    # seeded by loss.backward() below
             ops.enable_wgrad_stream(self.overlap_wgrad)
             try:
                 with ops.ln_param_batch():

@@ -1088,6 +1088,59 @@ class L1LossFn(torch.autograd.Function):
         return (grad.reshape(ctx.shape) * dl), None
 
 
+class WeightedL1LossesFn(torch.autograd.Function):
+    """weighted_sum_losses over L1 terms (utils/losses.py:63-70) as ONE op: apply(coeffs, unit_seed, pred0, target0,
+    pred1, target1, ...) -> (total, loss0, loss1, ...).  One launch per term plus one that finishes every mean and the
+    weighted total (ttsmi_l1_losses_weighted); the terms' gradients coeff_i sign(p - t) / n_i are written by the same
+    pass.  The three separate losses and the Python-level weighted sum were ~18 launches of scalar glue per step between
+    the end of the forward and the start of the backward, where nothing else keeps the GPU busy.
+    Only `total` is differentiable.  unit_seed=True promises that backward is seeded with 1 (loss.backward()): the saved
+    gradients are then returned as they are instead of being multiplied by the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, coeffs, unit_seed, *pt):
+        assert len(pt) % 2 == 0 and 2 <= len(pt) <= 16 and len(coeffs) == len(pt) // 2
+        n = len(pt) // 2
+        preds, targets, grads, shapes = [], [], [], []
+        for i in range(n):
+            pred, target = pt[2 * i], _c(pt[2 * i + 1])
+            assert pred.dim() >= 2 and pred.stride(-1) == 1
+            cols = pred.shape[-1]
+            rows = pred.numel() // cols
+            p2 = pred.reshape(rows, cols) if pred.is_contiguous() else _c(pred).reshape(rows, cols)
+            assert target.numel() == rows * cols, (target.shape, pred.shape)
+            assert target.dtype in (torch.float32, torch.int32)
+            preds.append(p2)
+            targets.append(target)
+            grads.append(torch.empty((rows, cols), dtype=torch.float32, device=pred.device))
+            shapes.append(pred.shape)
+        dev = preds[0].device
+        out = torch.empty((n + 1,), dtype=torch.float32, device=dev)          # [loss_0 .. loss_{n-1}, total]
+        l = _lib.lib()
+        ws = _ws(l.ttsmi_l1_losses_weighted_ws_bytes(n), dev)
+        ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        i64 = lambda vs: (ctypes.c_int64 * n)(*[int(v) for v in vs])
+        check(l.ttsmi_l1_losses_weighted(
+            n, ptrs(preds), i64(t.stride(0) for t in preds), ptrs(targets),
+            (ctypes.c_int32 * n)(*[int(t.dtype == torch.int32) for t in targets]), i64(t.shape[0] for t in preds),
+            i64(t.shape[1] for t in preds), (ctypes.c_float * n)(*[float(c) for c in coeffs]), ptrs(grads),
+            i64(t.stride(0) for t in grads), _p(out), out.data_ptr() + 4 * n, _p(ws), ws.numel(), _stream()),
+            'l1_losses_weighted')
+        ctx.save_for_backward(*grads)
+        ctx.shapes, ctx.unit_seed = shapes, bool(unit_seed)
+        losses = [out[i] for i in range(n)]
+        ctx.mark_non_differentiable(*losses)
+        return (out[n], *losses)
+
+    @staticmethod
+    def backward(ctx, dtotal, *_):
+        res = [None, None]
+        for g, shape in zip(ctx.saved_tensors, ctx.shapes):
+            g = g.reshape(shape)
+            res += [g if ctx.unit_seed else g * dtotal, None]
+        return tuple(res)
+
+
 class ConvReluPreMaskedFn(torch.autograd.Function):
     """h = relu(conv1d(x)).  INTERNAL to the predictor layer (layers.py:512-513): its backward
     expects dy ALREADY multiplied by (h > 0) - the following AddLayerNormFn(relu_in=True) does that

@@ -13,8 +13,16 @@ def masked_mean_absolute_error(targets, logits, mask_value=0, mask=None):
     return ops.L1LossFn.apply(logits, targets)
 
 
-def weighted_sum_losses(targets, pred, loss_functions, coeffs):
-    """Reference utils/losses.py:63-70."""
+def weighted_sum_losses(targets, pred, loss_functions, coeffs, unit_seed=False):
+    """Reference utils/losses.py:63-70: total = sum_i coeffs[i] * loss_i (accumulated from 0 in list order), and the
+    list of the unweighted losses.  When every term is the unmasked MAE above (the ForwardTransformer's three losses)
+    the whole sum is one fused op (ops.WeightedL1LossesFn: same values, same accumulation order; only the total carries
+    a gradient); `unit_seed=True` is the train step's promise that it calls total.backward() with the default seed."""
+    if (1 <= len(loss_functions) <= 8 and all(f is masked_mean_absolute_error for f in loss_functions)
+            and all(getattr(p, 'is_cuda', False) for p in pred)):
+        flat = [t for i in range(len(loss_functions)) for t in (pred[i], targets[i])]
+        total, *loss_vals = ops.WeightedL1LossesFn.apply(tuple(float(c) for c in coeffs), unit_seed, *flat)
+        return total, loss_vals
     total_loss = 0
     loss_vals = []
     for i in range(len(loss_functions)):
