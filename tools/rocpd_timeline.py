@@ -5,7 +5,7 @@ For every complete step (delimited by adam_tf_kernel) and per HIP queue it print
 kernel intervals), the idle time between kernels, the number of launches and the largest gaps - a step whose main
 queue shows idle gaps well above the ~1.5 us dependent-launch boundary is waiting for the HOST, not the GPU.  Also
 prints the per-kernel totals of the measured steps (main queue) sorted by time.
-Usage: python tools/rocpd_timeline.py <trace_results.db> [--steps N] [--top K]"""
+Usage: python tools/rocpd_timeline.py <trace_results.db> [--steps N] [--top K] [--gaps] [--sequence]"""
 import re
 import sqlite3
 import sys
@@ -55,6 +55,16 @@ def main():
             print(f'  queue {q}{" (main)" if q == main_q else ""}: {len(ks)} kernels, busy {1e-6 * busy:.3f} ms, '
                   f'sum of gaps {1e-6 * sum(gaps):.3f} ms, gaps > 5 us: {sum(g > 5000 for g in gaps)} '
                   f'({1e-6 * sum(g for g in gaps if g > 5000):.3f} ms), largest {[round(g / 1e3, 1) for g in big]} us')
+    if '--sequence' in sys.argv:                      # every kernel of the last step in start order, both queues
+        a, b = adam[-2], adam[-1]
+        t0, t1 = rows[a][2], rows[b][2]
+        last_end = {}
+        print(f'--- sequence of the last step ({1e-6 * (t1 - t0):.3f} ms): start offset us, duration us, idle before (same queue) us')
+        for n, st, en, q in rows:
+            if t0 <= st < t1:
+                gap = st - last_end.get(q, t0)
+                print(f'  {"main" if q == main_q else "side"} {1e-3 * (st - t0):9.1f} {1e-3 * (en - st):8.1f} {1e-3 * gap:8.1f}  {short(n)}')
+                last_end[q] = max(en, last_end.get(q, t0))
     a, b = adam[-(nsteps + 1)], adam[-1]
     t0, t1 = rows[a][2], rows[b][2]
     agg = {}

@@ -48,6 +48,25 @@ static inline int ttsmi_env_int(const char* name, int dflt) {
 #define TTSMI_ABLATE_KNOB(var, name) static const int var = 0
 #endif
 
+// weight gradient with the slab reduction deferred to a batched launch (gemm_bf16.hip; used by dense_block.hip -
+// library-internal, not part of include/ttsmi.h)
+#define TTSMI_WGRAD_MAX_JOBS 8
+struct ttsmi_wgrad_job {
+    const float* ws;
+    float* dw;
+    long lddw;
+    int kin, n, splits, pad_;
+    const float* cs_ws;
+    float* db;
+};
+extern "C" {
+size_t ttsmi_hgemm_wgrad_rows_exact_bytes(int rows, int kin, int n, int has_db);
+int ttsmi_hgemm_wgrad_rows_deferred(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
+                                    float* dw, int64_t lddw, float* db, int rows, int kin, int n, void* ws, size_t ws_bytes,
+                                    ttsmi_stream_t stream, ttsmi_wgrad_job* job);
+int ttsmi_hgemm_wgrad_reduce_jobs(const ttsmi_wgrad_job* jobs, int njobs, ttsmi_stream_t stream);
+}
+
 // bf16-operand attention kernels (attention_bf16.hip), reached through ttsmi_attention_fwd/bwd with
 // dtype == TTSMI_BF16
 int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,

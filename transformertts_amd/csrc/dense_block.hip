@@ -95,10 +95,27 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
     return TTSMI_OK;
 }
 
+// The block's weight gradients leave their slab reductions to ONE batched launch at the end of the block's backward
+// (five 4-8 us launches otherwise, on a stream whose tail is exposed at the end of the step): every call carves its
+// slabs out of the shared workspace, and the batch is flushed early if the workspace or the job table runs out.
+struct WgradBatch {
+    ttsmi_wgrad_job jobs[TTSMI_WGRAD_MAX_JOBS];
+    int n;
+    size_t used;
+};
+static int wgrad_flush(const ttsmi_dense_block* D, WgradBatch* wb) {
+    if (wb->n == 0) return TTSMI_OK;
+    hipStream_t st = D->side_stream ? (hipStream_t)D->side_stream : (hipStream_t)D->main_stream;
+    const int rc = ttsmi_hgemm_wgrad_reduce_jobs(wb->jobs, wb->n, (ttsmi_stream_t)st);
+    wb->n = 0;
+    wb->used = 0;                      // (stream order: the next slabs are written after this reduction has read these)
+    return rc;
+}
+
 // weight gradient dW[kin,n] = x^T . dy (+ db) on the side stream, ordered after everything the main stream has
 // enqueued so far (its operands) through one event
-static int wgrad_side(const ttsmi_dense_block* D, int ev, bool record, const uint16_t* x, int ldx, const uint16_t* dy, int lddy,
-                      float* dw, float* db, int kin, int n) {
+static int wgrad_side(const ttsmi_dense_block* D, WgradBatch* wb, int ev, bool record, const uint16_t* x, int ldx,
+                      const uint16_t* dy, int lddy, float* dw, float* db, int kin, int n) {
     const int M = D->B * D->T;
     TTSMI_ABLATE_KNOB(skip, "TTSMI_DEBUG_SKIP_WGRAD");      // measurement knob (results are then WRONG: no weight gradients): main-stream-only backward time
     if (skip) return TTSMI_OK;
@@ -113,7 +130,21 @@ static int wgrad_side(const ttsmi_dense_block* D, int ev, bool record, const uin
         }
     }
     OBS("ttsmi_hgemm_wgrad_rows", 2.0 * M * kin * n, (double)M * (kin + n) * 2 + 4.0 * kin * n, (ttsmi_stream_t)st);
-    return ttsmi_hgemm_wgrad_rows(x, 1, ldx, dy, 1, lddy, dw, n, db, M, kin, n, 1, 0, 0, 0, D->wgrad_ws, D->wgrad_ws_bytes, st);
+    TTSMI_KNOB(batched, "TTSMI_WGRAD_BATCH_REDUCE", 1);     // 0: every weight gradient reduces its own slabs (A/B knob)
+    const size_t need = ttsmi_hgemm_wgrad_rows_exact_bytes(M, kin, n, db != nullptr);
+    if (!batched || need > D->wgrad_ws_bytes) {
+        TRY(wgrad_flush(D, wb));
+        return ttsmi_hgemm_wgrad_rows(x, 1, ldx, dy, 1, lddy, dw, n, db, M, kin, n, 1, 0, 0, 0, D->wgrad_ws, D->wgrad_ws_bytes, st);
+    }
+    if (wb->n == TTSMI_WGRAD_MAX_JOBS || wb->used + need > D->wgrad_ws_bytes) TRY(wgrad_flush(D, wb));
+    ttsmi_wgrad_job* job = &wb->jobs[wb->n];
+    TRY(ttsmi_hgemm_wgrad_rows_deferred(x, 1, ldx, dy, 1, lddy, dw, n, db, M, kin, n, (char*)D->wgrad_ws + wb->used,
+                                        D->wgrad_ws_bytes - wb->used, st, job));
+    if (job->splits > 0) {
+        wb->n += 1;
+        wb->used += need;
+    }
+    return TTSMI_OK;
 }
 
 int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf, const float* dout) {
@@ -122,6 +153,9 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     const int M = D->B * D->T, d = D->d, F = D->F, dh = d / D->H;
     ttsmi_stream_t st = D->main_stream;
     const bool dropout = D->rate > 0.f;
+    WgradBatch wb;
+    wb.n = 0;
+    wb.used = 0;
     // ---- LN2 + FFN: df (bf16) = dLN2/dx, da (fp32) = dLN2/dres
     if (D->fuse_ln) {
         if (!D->ln2_done) {         // (chained: the block above already left df / da / the parameter partials)
@@ -134,11 +168,11 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         TRY(ttsmi_add_layernorm_bwd(dout, D->f, D->a, D->ln2_g, D->mean2, D->rstd2, nullptr, nullptr, 0, D->pad, D->rate,
                                     D->site_ln2, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->da, D->da, nullptr,
                                     nullptr, nullptr, M, d, D->ln_ws2, D->ln_ws_bytes, D->df, st));
-    TRY(wgrad_side(D, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
+    TRY(wgrad_side(D, &wb, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
     { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false, (double)M * F * 2), st);
       TRY(ttsmi_hgemm_tn(D->df, 0, d, nullptr, 0, 0, D->w2_b, d, nullptr, (const float*)D->h1, F, D->dh1, F, M, F, d,
                          TTSMI_GEMM_OUT_BF16 | TTSMI_GEMM_MASK_BF16, 1, 0, 0, 0, st)); }               // relu' fused
-    TRY(wgrad_side(D, 1, true, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
+    TRY(wgrad_side(D, &wb, 1, true, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
     if (D->fuse_ln) {
         // (da + dh1.W1^T) never reaches HBM: res-norm 1's backward runs in the dgrad's epilogue -> d_o (bf16), dh (fp32)
         OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * F, gemm_bytes(M, d, F, 4, true, (double)M * d * (2 + 2)), st);
@@ -152,8 +186,8 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
                                     D->site_ln1, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->dh, D->dh, nullptr,
                                     nullptr, nullptr, M, d, D->ln_ws1, D->ln_ws_bytes, D->d_o, st));
     }
-    TRY(wgrad_side(D, 2, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
-    TRY(wgrad_side(D, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
+    TRY(wgrad_side(D, &wb, 2, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
+    TRY(wgrad_side(D, &wb, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
     // dh += do.Wo_top^T (fp32) and dctx = do.Wo_ctx^T (bf16): Wo as stored is [2d][d] = both weight halves back to back,
     // and both products read d_o - one weight-stationary launch when the shape suits it (d = 256, decoder-size M)
     TTSMI_KNOB(split_ok, "TTSMI_DENSE_SPLIT_DGRAD", 1);           // TTSMI_DENSE_SPLIT_DGRAD=0: two launches (A/B knob)
@@ -179,7 +213,8 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         TRY(ttsmi_attention_bwd(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh, D->rate,
                                 D->seed, D->step_dev, D->site_attn, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));
     }
-    TRY(wgrad_side(D, 3, true, h_bf, d, D->dqkv, 3 * d, D->g_wqkv, D->g_bqkv, d, 3 * d));
+    TRY(wgrad_side(D, &wb, 3, true, h_bf, d, D->dqkv, 3 * d, D->g_wqkv, D->g_bqkv, d, 3 * d));
+    TRY(wgrad_flush(D, &wb));            // the block's five slab reductions, one launch on the weight-gradient stream
     const ttsmi_dense_block* L = D->below;
     if (D->fuse_ln && L != nullptr) {
         // dh + dqkv.Wqkv^T is the upstream gradient of the lower block's res-norm 2: its backward runs in this epilogue

@@ -1044,13 +1044,13 @@ __global__ void hsplit_reduce_kernel(const float* __restrict__ ws, float* __rest
 // partial sums in wave order - a fixed association, so the result is run-to-run deterministic.  The
 // one-element-per-thread loop above is a serial chain of S dependent-latency loads on a handful of
 // waves (15-25 us per weight); this one keeps ~S/4 x 16 B per lane in flight on 4x the waves.
-__global__ __launch_bounds__(256) void hsplit_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                                             long ldo, int M, int N, int splits,
-                                                             const float* __restrict__ cs_ws,
-                                                             float* __restrict__ cs_out) {
-    __shared__ float4 part[3][64];
+__device__ __forceinline__ void hsplit_reduce4_body(const float* __restrict__ ws, float* __restrict__ out,
+                                                    long ldo, int M, int N, int splits,
+                                                    const float* __restrict__ cs_ws,
+                                                    float* __restrict__ cs_out, float4 (*part)[64]) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const long n = (long)M * N, nq = n >> 2, ncs = cs_out ? (N >> 2) : 0;
+    if (blockIdx.x * 64L >= nq + ncs) return;               // (block-uniform: the batched launch sizes its grid for the largest job)
     const long q = blockIdx.x * 64L + l;
     const bool ok = q < nq + ncs;
     const bool main_part = q < nq;
@@ -1088,6 +1088,26 @@ __global__ __launch_bounds__(256) void hsplit_reduce4_kernel(const float* __rest
             *reinterpret_cast<float4*>(cs_out + (q - nq) * 4) = s;
         }
     }
+}
+__global__ __launch_bounds__(256) void hsplit_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                             long ldo, int M, int N, int splits,
+                                                             const float* __restrict__ cs_ws,
+                                                             float* __restrict__ cs_out) {
+    __shared__ float4 part[3][64];
+    hsplit_reduce4_body(ws, out, ldo, M, N, splits, cs_ws, cs_out, part);
+}
+// the slab reductions of several weight gradients in ONE launch (blockIdx.y = job): a dense block's backward leaves five
+// of them on the weight-gradient stream, each a 4-8 us launch that cannot fill the GPU on its own
+struct WJobs { ttsmi_wgrad_job j[TTSMI_WGRAD_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void hsplit_reduce4_jobs_kernel(WJobs J) {
+    __shared__ float4 part[3][64];
+    const ttsmi_wgrad_job& b = J.j[blockIdx.y];
+    hsplit_reduce4_body(b.ws, b.dw, b.lddw, b.kin, b.n, b.splits, b.cs_ws, b.db, part);
+}
+
+static bool hsplit_vec_ok(const float* ws, const float* dw, long lddw, int n, const float* db) {
+    return (n % 4 == 0) && (lddw % 4 == 0) && (((uintptr_t)dw & 15) == 0) && (((uintptr_t)ws & 15) == 0) &&
+           (!db || ((uintptr_t)db & 15) == 0);
 }
 
 static void hsplit_reduce_launch(hipStream_t st, const float* ws, float* dw, long lddw, int kin, int n, int splits,
@@ -1373,10 +1393,70 @@ int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, floa
 
 size_t ttsmi_hgemm_wgrad_rows_ws_bytes(int rows, int kin, int n) { return ttsmi_hgemm_wgrad_ws_bytes(rows, kin, n); }
 
+static int wgrad_rows_splits(int rows, int kin, int n, int* kps_out) {
+    const int tiles = ttsmi_cdiv(kin, 128) * ttsmi_cdiv(n, 128);
+    int splits = hpick_splits(rows, tiles);
+    int kps = ttsmi_cdiv(rows, splits);
+    kps = ((kps + WR_ROWS - 1) / WR_ROWS) * WR_ROWS;
+    if (kps_out) *kps_out = kps;
+    return ttsmi_cdiv(rows, kps);
+}
+
+// bytes of slab workspace this call really uses (ttsmi_hgemm_wgrad_ws_bytes is the shape-independent upper bound)
+size_t ttsmi_hgemm_wgrad_rows_exact_bytes(int rows, int kin, int n, int has_db) {
+    const size_t splits = (size_t)wgrad_rows_splits(rows, kin, n, nullptr);
+    return ((splits * kin * n + (has_db ? splits * n : 0)) * sizeof(float) + 255) & ~(size_t)255;
+}
+
+static int wgrad_rows_impl(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
+                           float* dw, int64_t lddw, float* db, int rows, int kin, int n, int conv_taps,
+                           int conv_T, int conv_C, int conv_pad, void* ws, size_t ws_bytes,
+                           ttsmi_stream_t stream, ttsmi_wgrad_job* job);
+
 int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
                            float* dw, int64_t lddw, float* db, int rows, int kin, int n, int conv_taps,
                            int conv_T, int conv_C, int conv_pad, void* ws, size_t ws_bytes,
                            ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_hgemm_wgrad_ws_bytes(rows, kin, n), "hgemm_wgrad_rows: workspace too small");
+    return wgrad_rows_impl(x, x_is_bf16, ldx, dy, dy_is_bf16, lddy, dw, lddw, db, rows, kin, n, conv_taps, conv_T, conv_C,
+                           conv_pad, ws, ws_bytes, stream, nullptr);
+}
+
+// The same launch with the slab reduction left to the caller: *job describes it (job->splits == 0: nothing is pending -
+// a single split wrote dw directly, or the operands do not suit the vector reduce and it ran here).  ws only has to
+// hold ttsmi_hgemm_wgrad_rows_exact_bytes, and must stay untouched until ttsmi_hgemm_wgrad_reduce_jobs has run.
+int ttsmi_hgemm_wgrad_rows_deferred(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
+                                    float* dw, int64_t lddw, float* db, int rows, int kin, int n, void* ws, size_t ws_bytes,
+                                    ttsmi_stream_t stream, ttsmi_wgrad_job* job) {
+    TTSMI_CHECK_ARG(job, "hgemm_wgrad_rows_deferred: null job");
+    TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_hgemm_wgrad_rows_exact_bytes(rows, kin, n, db != nullptr),
+                    "hgemm_wgrad_rows_deferred: workspace too small");
+    return wgrad_rows_impl(x, x_is_bf16, ldx, dy, dy_is_bf16, lddy, dw, lddw, db, rows, kin, n, 1, 0, 0, 0, ws, ws_bytes,
+                           stream, job);
+}
+
+int ttsmi_hgemm_wgrad_reduce_jobs(const ttsmi_wgrad_job* jobs, int njobs, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(jobs && njobs >= 0 && njobs <= TTSMI_WGRAD_MAX_JOBS, "hgemm_wgrad_reduce_jobs: bad job list");
+    if (njobs == 0) return TTSMI_OK;
+    WJobs J;
+    memset(&J, 0, sizeof(J));
+    long blocks = 1;
+    for (int i = 0; i < njobs; ++i) {
+        J.j[i] = jobs[i];
+        const long quads = (long)jobs[i].kin * jobs[i].n / 4 + (jobs[i].db ? jobs[i].n / 4 : 0);
+        blocks = blocks > (quads + 63) / 64 ? blocks : (quads + 63) / 64;
+    }
+    hipLaunchKernelGGL(hsplit_reduce4_jobs_kernel, dim3((unsigned)blocks, njobs), dim3(256), 0, (hipStream_t)stream, J);
+    TTSMI_CHECK_LAUNCH("hgemm_wgrad_reduce_jobs");
+    return TTSMI_OK;
+}
+
+static int wgrad_rows_impl(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
+                           float* dw, int64_t lddw, float* db, int rows, int kin, int n, int conv_taps,
+                           int conv_T, int conv_C, int conv_pad, void* ws, size_t ws_bytes,
+                           ttsmi_stream_t stream, ttsmi_wgrad_job* job) {
+    (void)ws_bytes;
+    if (job) job->splits = 0;
     TTSMI_CHECK_ARG(!(x_is_bf16 && conv_taps > 1), "hgemm_wgrad_rows: conv needs an fp32 x");
     TTSMI_CHECK_ARG(x && dy && dw, "hgemm_wgrad_rows: null pointer");
     TTSMI_CHECK_ARG(rows > 0 && kin > 0 && n > 0, "hgemm_wgrad_rows: bad shape");
@@ -1387,7 +1467,6 @@ int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void
                         "hgemm_wgrad_rows: conv needs Cin %% 128 == 0");
     else
         TTSMI_CHECK_ARG(kin % 4 == 0, "hgemm_wgrad_rows: K %% 4 != 0");
-    TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_hgemm_wgrad_ws_bytes(rows, kin, n), "hgemm_wgrad_rows: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     WRowsP p;
     memset(&p, 0, sizeof(p));
@@ -1396,10 +1475,8 @@ int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void
     p.taps = conv_taps > 1 ? conv_taps : 1; p.T = conv_T; p.Cin = conv_C; p.pad = conv_pad;
     p.tiles_k = ttsmi_cdiv(kin, 128); p.tiles_n = ttsmi_cdiv(n, 128);
     int tiles = p.tiles_k * p.tiles_n;
-    int splits = hpick_splits(rows, tiles);
-    int kps = ttsmi_cdiv(rows, splits);
-    kps = ((kps + WR_ROWS - 1) / WR_ROWS) * WR_ROWS;
-    splits = ttsmi_cdiv(rows, kps);
+    int kps = 0;
+    const int splits = wgrad_rows_splits(rows, kin, n, &kps);
     p.k_per_split = kps;
     p.ws = (float*)ws; p.colsum = db; p.colsum_ws = p.ws + (size_t)splits * kin * n;
     dim3 wgrid(tiles * splits);
@@ -1413,6 +1490,11 @@ int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void
     else hipLaunchKernelGGL((wgrad_rows_kernel<false, false>), wgrid, dim3(256), 0, st, p);
     TTSMI_CHECK_LAUNCH("hgemm_wgrad_rows");
     if (splits > 1) {
+        if (job && hsplit_vec_ok(p.ws, dw, (long)lddw, n, db)) {          // the caller reduces (batched with its other jobs)
+            job->ws = p.ws; job->dw = dw; job->lddw = (long)lddw; job->kin = kin; job->n = n; job->splits = splits;
+            job->cs_ws = p.colsum_ws; job->db = db;
+            return TTSMI_OK;
+        }
         hsplit_reduce_launch(st, p.ws, dw, (long)lddw, kin, n, splits, p.colsum_ws, db);
         TTSMI_CHECK_LAUNCH("hgemm_wgrad_rows_reduce");
     }

@@ -1130,10 +1130,13 @@ class WeightedL1LossesFn(torch.autograd.Function):
         ctx.shapes, ctx.unit_seed = shapes, bool(unit_seed)
         losses = [out[i] for i in range(n)]
         ctx.mark_non_differentiable(*losses)
+        ctx.set_materialize_grads(False)          # no zero tensors (a fill launch each) for the terms' unused gradients
         return (out[n], *losses)
 
     @staticmethod
     def backward(ctx, dtotal, *_):
+        if dtotal is None:
+            return (None, None) + (None,) * (2 * len(ctx.shapes))
         res = [None, None]
         for g, shape in zip(ctx.saved_tensors, ctx.shapes):
             g = g.reshape(shape)
