@@ -418,9 +418,13 @@ def test_expand_docstring_example_on_gpu():
     ops = _ops()
     x = torch.tensor([[[0.54710746, 0.8943467], [0.7140938, 0.97968304], [0.5347662, 0.15213418]]])
     idx, cum, ln = ops.lenreg_index(torch.tensor([[1, 3, 2]], dtype=torch.int32, device=DEV), 6)
-    y = ops.LenRegFn.apply(x.to(DEV), idx, cum).cpu()
+    xg = x.to(DEV).requires_grad_()
+    yg = ops.LenRegFn.apply(xg, idx, cum)
+    y = yg.detach().cpu()
     assert idx.cpu().tolist() == [[0, 1, 1, 1, 2, 2]] and int(ln[0]) == 6
     assert torch.equal(y, x[:, [0, 1, 1, 1, 2, 2]])
+    yg.backward(torch.ones_like(yg))               # two channels: the scalar (C % 4 != 0) segment-sum path
+    assert xg.grad.cpu().tolist() == [[[1., 1.], [3., 3.], [2., 2.]]]
 
 
 # ------------------------------------------------------------------------------------ loss + optimiser

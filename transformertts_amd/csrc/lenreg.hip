@@ -91,6 +91,19 @@ __global__ __launch_bounds__(256) void lenreg_bwd_kernel(const float* __restrict
     int j0 = cb[i], j1 = cb[i + 1];
     if (j1 > cap) j1 = cap;
     const float* src = dy + (long)b * cap * C;
+    if ((C & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0) {
+        // 16 bytes per lane: a 256-channel row is ONE wave-wide load, four frames in flight (same ascending-frame sums)
+        for (int c = lane * 4; c < C; c += 256) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int j = j0; j < j1; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (long)j * C + c);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            *reinterpret_cast<float4*>(dx + row * C + c) = s;
+        }
+        return;
+    }
     for (int c = lane; c < C; c += 64) {
         float s = 0.f;
         for (int j = j0; j < j1; ++j) s += src[(long)j * C + c];
