@@ -56,13 +56,18 @@ class GradAllReduce:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # a one-rank group normally issues no collective; TTSMI_DP_FORCE_COLLECTIVES=1 issues them anyway (sum over one
         # rank = identity), which lets a 1-GPU box exercise the RCCL stream ordering of this file (tools/probe_rccl_world1.py)
-        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('TTSMI_DP_FORCE_COLLECTIVES') == '1')
+        self._forced = dist.is_initialized() and os.environ.get('TTSMI_DP_FORCE_COLLECTIVES') == '1'
         # SUM + one 1/world scaling pass on every backend: ReduceOp.AVG is NCCL-only and not worth a
         # backend-dependent code path (the scaling pass is one 44 MB stream, ~15 us)
         self.use_avg = False
         self.overlap = dist.is_initialized() and os.environ.get('TTSMI_DP_OVERLAP', '1') != '0'
         self._tail = None                   # (work handle, split) of the in-flight decoder bucket
         self._launch_stream = None
+
+    @property
+    def active(self) -> bool:
+        """Collectives are issued: more than one rank, or a forced one-rank group."""
+        return self.world > 1 or self._forced
 
     def _reduce(self, t: torch.Tensor, async_op: bool = False):
         """Average over ranks (gloo has no AVG: SUM now, the caller scales once the sum has landed)."""
