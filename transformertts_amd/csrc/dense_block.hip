@@ -156,6 +156,10 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     WgradBatch wb;
     wb.n = 0;
     wb.used = 0;
+    // TTSMI_WGRAD_EVENTS=2 (A/B knob): two hand-offs to the weight-gradient stream per block instead of four - the FFN
+    // pair after dh1, the attention-side three after dqkv (fewer event packets on both queues, later starts on the side stream)
+    TTSMI_KNOB(wev, "TTSMI_WGRAD_EVENTS", 4);
+    const bool lazy = wev == 2;
     // ---- LN2 + FFN: df (bf16) = dLN2/dx, da (fp32) = dLN2/dres
     if (D->fuse_ln) {
         if (!D->ln2_done) {         // (chained: the block above already left df / da / the parameter partials)
@@ -168,11 +172,12 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         TRY(ttsmi_add_layernorm_bwd(dout, D->f, D->a, D->ln2_g, D->mean2, D->rstd2, nullptr, nullptr, 0, D->pad, D->rate,
                                     D->site_ln2, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->da, D->da, nullptr,
                                     nullptr, nullptr, M, d, D->ln_ws2, D->ln_ws_bytes, D->df, st));
-    TRY(wgrad_side(D, &wb, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
+    if (!lazy) TRY(wgrad_side(D, &wb, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
     { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false, (double)M * F * 2), st);
       TRY(ttsmi_hgemm_tn(D->df, 0, d, nullptr, 0, 0, D->w2_b, d, nullptr, (const float*)D->h1, F, D->dh1, F, M, F, d,
                          TTSMI_GEMM_OUT_BF16 | TTSMI_GEMM_MASK_BF16, 1, 0, 0, 0, st)); }               // relu' fused
-    TRY(wgrad_side(D, &wb, 1, true, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
+    if (lazy) TRY(wgrad_side(D, &wb, 1, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
+    TRY(wgrad_side(D, &wb, 1, !lazy, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
     if (D->fuse_ln) {
         // (da + dh1.W1^T) never reaches HBM: res-norm 1's backward runs in the dgrad's epilogue -> d_o (bf16), dh (fp32)
         OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * F, gemm_bytes(M, d, F, 4, true, (double)M * d * (2 + 2)), st);
@@ -186,8 +191,10 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
                                     D->site_ln1, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->dh, D->dh, nullptr,
                                     nullptr, nullptr, M, d, D->ln_ws1, D->ln_ws_bytes, D->d_o, st));
     }
-    TRY(wgrad_side(D, &wb, 2, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
-    TRY(wgrad_side(D, &wb, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
+    if (!lazy) {
+        TRY(wgrad_side(D, &wb, 2, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
+        TRY(wgrad_side(D, &wb, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
+    }
     // dh += do.Wo_top^T (fp32) and dctx = do.Wo_ctx^T (bf16): Wo as stored is [2d][d] = both weight halves back to back,
     // and both products read d_o - one weight-stationary launch when the shape suits it (d = 256, decoder-size M)
     TTSMI_KNOB(split_ok, "TTSMI_DENSE_SPLIT_DGRAD", 1);           // TTSMI_DENSE_SPLIT_DGRAD=0: two launches (A/B knob)
@@ -213,7 +220,11 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         TRY(ttsmi_attention_bwd(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh, D->rate,
                                 D->seed, D->step_dev, D->site_attn, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));
     }
-    TRY(wgrad_side(D, &wb, 3, true, h_bf, d, D->dqkv, 3 * d, D->g_wqkv, D->g_bqkv, d, 3 * d));
+    if (lazy) {
+        TRY(wgrad_side(D, &wb, 3, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
+        TRY(wgrad_side(D, &wb, 3, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
+    }
+    TRY(wgrad_side(D, &wb, 3, !lazy, h_bf, d, D->dqkv, 3 * d, D->g_wqkv, D->g_bqkv, d, 3 * d));
     TRY(wgrad_flush(D, &wb));            // the block's five slab reductions, one launch on the weight-gradient stream
     const ttsmi_dense_block* L = D->below;
     if (D->fuse_ln && L != nullptr) {
