@@ -399,6 +399,29 @@ def masked_mean_absolute_error(targets, pred):
     return (targets.to(pred.dtype) - pred).abs().mean()
 
 
+def keras_weighted_loss_mean(per_sample, sample_weight=None):
+    """The reduction every Keras loss OBJECT of utils/losses.py applies (`Loss.__call__`, reduction
+    SUM_OVER_BATCH_SIZE [3P]): the per-sample losses (already averaged over the last axis) are multiplied by
+    sample_weight and their SUM is divided by the NUMBER of per-sample losses - not by the sum of the weights.  With
+    sample_weight=None (how the ForwardTransformer's MAE losses are called, utils/losses.py:41-49) that is the plain
+    mean above; the weighted form is pinned by the reference's own known answers (tests/test_loss.py:10-26, the
+    crossentropy losses of the same file), which fix the convention rather than leave it to memory."""
+    per_sample = per_sample if sample_weight is None else per_sample * sample_weight.to(per_sample.dtype)
+    return per_sample.sum() / per_sample.numel()
+
+
+def masked_crossentropy(targets, logits, index=None, scaling=1.0):
+    """utils/losses.py:4-29 (not on the ForwardTransformer path - restated only because the reference's tests pin the
+    Keras reduction with it): sparse categorical crossentropy from logits, weight 0 at padding targets (id 0), weight
+    `scaling` at targets == index."""
+    logp = torch.log_softmax(logits.to(torch.float64), dim=-1)
+    ce = -torch.gather(logp, -1, targets.long()[..., None])[..., 0]
+    w = (targets != 0).to(torch.float64)
+    if index is not None:
+        w = w + (targets == index).to(torch.float64) * (scaling - 1.0)
+    return keras_weighted_loss_mean(ce, w)
+
+
 def weighted_sum_losses(targets, pred, coeffs):
     """utils/losses.py:63-70."""
     total = 0

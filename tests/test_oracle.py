@@ -103,6 +103,21 @@ def test_unmasked_mae_counts_padding():
     assert float(fo.masked_mean_absolute_error(ti, p)) == pytest.approx((1.5 + 0.25) / 2)
 
 
+def test_keras_loss_reduction_matches_the_reference_known_answers():
+    """tests/test_loss.py:10-26 of the reference: the three known answers of its crossentropy losses.  They pin what a
+    Keras loss object does with sample weights - the weighted sum is divided by the number of samples, not by the sum
+    of the weights - which is the reduction the oracle's MAE uses with no weights."""
+    targets = torch.tensor([[0, 1, 2]])
+    logits = torch.tensor([[[.3, .2, .1], [.3, .2, .1], [.3, .2, .1]]])
+    assert float(fo.masked_crossentropy(targets, logits, index=2, scaling=5)) == pytest.approx(2.3705523014068604, abs=1e-6)
+    assert float(fo.masked_crossentropy(targets, logits, index=2, scaling=1)) == pytest.approx(0.7679619193077087, abs=1e-6)
+    assert float(fo.masked_crossentropy(targets, logits)) == pytest.approx(0.7679619193077087, abs=1e-6)
+    # dividing by the sum of the weights instead would give 1.15194...: the known answers exclude it
+    assert abs(0.7679619193077087 * 3 / 2 - 1.1519428789615631) < 1e-12
+    x = torch.randn(4, 7, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    assert float(fo.keras_weighted_loss_mean(x.abs().mean(-1))) == pytest.approx(float(x.abs().mean()))
+
+
 def test_tf_adam_hand_values():
     cfg = fo.tiny_config()
     W = fo.init_weights(cfg, seed=0)
