@@ -42,16 +42,28 @@ def main():
                   'write_size_kib_per_launch': wv / max(wn, 1),
                   'hbm_bytes_per_launch': (2.0 * fv / n + wv / max(wn, 1)) * 1024.0}
     out = dict(sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches']))
-    # whole-step totals: the trace holds `steps` train steps (one adam_tf_kernel each) plus a few one-off
-    # initialisation launches (weight shadows), which are counted in - a slight over-estimate
+    json.dump(with_totals(out), open(sys.argv[3], 'w'), indent=1)
+
+
+def with_totals(out):
+    """Whole-step totals: the trace holds `steps` train steps (one adam_tf_kernel each).  The runtime's own copy
+    kernels (__amd_rocclr_*: the parameter uploads of the model construction - a step issues none) are left out of
+    both totals and reported separately; the few one-off initialisation launches of libttsmi kernels (weight shadows)
+    stay in - a slight over-estimate."""
     steps = max(1, out.get('adam_tf_kernel', {}).get('launches', 1))
-    total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in out.values())
-    launches = sum(v['launches'] for v in out.values())
-    json.dump({'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950, 16 B/lane loads; '
-                             'calibrated on adam_tf_kernel and cast_bf16_kernel in this trace)',
-               'steps_in_trace': steps, 'hbm_bytes_per_step': total / steps, 'launches_per_step': launches / steps,
-               'kernels': out}, open(sys.argv[3], 'w'), indent=1)
+    step_k = {k: v for k, v in out.items() if not k.startswith('__amd_rocclr')}
+    total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in step_k.values())
+    launches = sum(v['launches'] for v in step_k.values())
+    return {'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950, 16 B/lane loads; '
+                          'calibrated on adam_tf_kernel and cast_bf16_kernel in this trace)',
+            'steps_in_trace': steps, 'hbm_bytes_per_step': total / steps, 'launches_per_step': launches / steps,
+            'runtime_copy_launches_in_trace': sum(v['launches'] for k, v in out.items() if k.startswith('__amd_rocclr')),
+            'kernels': out}
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == '--recompute':      # totals of an existing file from its own kernel table
+        d = json.load(open(sys.argv[2]))
+        json.dump(with_totals(d['kernels']), open(sys.argv[2], 'w'), indent=1)
+    else:
+        main()
