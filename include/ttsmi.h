@@ -11,10 +11,15 @@
  * Conventions
  *   - every function returns 0 (TTSMI_OK) or a negative TTSMI_ERR_* code; the message is
  *     available from ttsmi_last_error() (thread-local).  No exception crosses the ABI.
- *   - no allocation, no synchronisation, no mutable global state: every buffer is a caller-owned
- *     DEVICE pointer, scratch is passed as (ws, ws_bytes) with a *_ws_bytes() query, every launch
- *     is asynchronous on the explicit stream (a hipStream_t passed as void*).  All entry points
- *     are therefore hipGraph-capturable.
+ *   - no allocation, no synchronisation: every buffer is a caller-owned DEVICE pointer, scratch is
+ *     passed as (ws, ws_bytes) with a *_ws_bytes() query, every launch is asynchronous on the
+ *     explicit stream (a hipStream_t passed as void*).  All entry points are therefore
+ *     hipGraph-capturable.
+ *   - state: compute entry points keep NO mutable state between calls.  The exceptions are all
+ *     measurement / diagnostics and never change a result: the thread-local strings behind
+ *     ttsmi_last_error() and ttsmi_last_kernel(); the process-wide profiling callback of
+ *     ttsmi_set_launch_observer() (set it before the threads that launch, clear it after); and the
+ *     TTSMI_* environment knobs, each read once into a function-local static const.
  *   - layout: row-major, channels-last [B, T, C]; matrices are [rows, cols] with a leading
  *     dimension in ELEMENTS.  Keras kernel layouts are kept: Dense [in, out], Conv1D [k, in, out].
  *   - dtype: TTSMI_F32 = everything fp32 (exact-fp32 MFMA, the 1e-4 parity path);
@@ -48,6 +53,11 @@ typedef void* ttsmi_stream_t; /* hipStream_t */
 
 int ttsmi_version(void);
 const char* ttsmi_last_error(void);
+/* Diagnostics: the name of the kernel variant the most recent size-routed entry point on THIS thread launched
+ * (ttsmi_hgemm_tn, ttsmi_hgemm_ln_fwd/_bwd, ttsmi_hgemm_wgrad_rows, ttsmi_hgemm_k256_split, the bf16 attention entry
+ * points), e.g. "rowgemm_dma_kernel<0, 128>"; "" before the first such call.  Lets a parity test assert that it
+ * exercised the variant a given launch size selects.  The string is a literal owned by the library. */
+const char* ttsmi_last_kernel(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers.  Replaces tf.keras.layers.Dense at model/layers.py:93-94,116-120,479 and

@@ -264,3 +264,30 @@ def test_mel_basis_spot_table_and_scalar_rederivation():
     # and the product's sparse form is the same matrix
     from transformertts_amd.data.audio import mel_filterbank_dense
     np.testing.assert_array_equal(mel_filterbank_dense(22050, 1024, 80, 0, 8000), B)
+
+
+def test_group_assembly_equals_the_whole_batch():
+    """tests/golden/make_config1_b32_golden.py builds the B = 32 golden from eight 4-sample fp64 runs (outputs
+    concatenated, losses and gradients averaged, every group's expanded sequence zero-padded to the batch's
+    `max_b sum(dur)`): the same assembly must equal ONE oracle run on the whole batch (reference
+    model/models.py:464-482; the loss is an unmasked mean over the padded batch, utils/losses.py:41-49)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_config1_b32_golden as g32
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=5, perturb=0.02)
+    batch = fo.synthetic_batch(8, 30, 120, seed=9, ragged=True)
+    whole = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    whole.taps = []
+    tr = whole.train_step(*batch, apply=False)
+    parts = g32.run_groups(cfg, W, batch, group=2)
+    assert parts['mel'].shape == tuple(tr['mel'].shape)
+    np.testing.assert_allclose(parts['mel'], tr['mel'].numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(parts['duration'], tr['duration'].numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(parts['loss'], float(tr['loss']), rtol=1e-12)
+    np.testing.assert_allclose(parts['losses'], [float(tr['losses'][k]) for k in ('mel', 'duration', 'pitch')], rtol=1e-12)
+    for (name, t) in whole.taps:
+        np.testing.assert_allclose(parts['taps'][name], t.numpy(), rtol=0, atol=1e-12)
+    for k, g in tr['grads'].items():
+        np.testing.assert_allclose(parts['grads'][k], g.numpy(), rtol=0, atol=1e-12 + 1e-10 * float(g.abs().max()))

@@ -27,6 +27,7 @@ S = c_void_p          # stream
 SIGNATURES = {
     'ttsmi_version': (I, []),
     'ttsmi_last_error': (c_char_p, []),
+    'ttsmi_last_kernel': (c_char_p, []),
     'ttsmi_linear_fwd': (I, [P, L, P, L, I, P, L, P, P, L, I, I, I, I, I, S]),
     'ttsmi_linear_dgrad': (I, [P, L, P, L, P, L, P, L, I, I, I, I, I, S]),
     'ttsmi_linear_wgrad_ws_bytes': (c_size_t, [I, I, I]),

@@ -857,6 +857,8 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
 // `pad_lds`: dynamic LDS nobody touches, requested only to cap the workgroups per CU (see ttsmi_hattention_bwd)
 #define HLAUNCH(KERNEL, DHV, grid, pad_lds, st, p)                                             \
     do {                                                                                       \
+        ttsmi_note_kernel(qh ? ((p).thr && (p).dmask ? #KERNEL "<" #DHV ", 2, true>" : (p).thr ? #KERNEL "<" #DHV ", 1, true>" : #KERNEL "<" #DHV ", 0, true>") \
+                             : ((p).thr && (p).dmask ? #KERNEL "<" #DHV ", 2, false>" : (p).thr ? #KERNEL "<" #DHV ", 1, false>" : #KERNEL "<" #DHV ", 0, false>")); \
         if (qh) {                                                                              \
             if ((p).thr && (p).dmask) hipLaunchKernelGGL((KERNEL<DHV, 2, true>), grid, dim3(256), pad_lds, st, p); \
             else if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, true>), grid, dim3(256), pad_lds, st, p);  \

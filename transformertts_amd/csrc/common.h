@@ -29,6 +29,11 @@ void ttsmi_set_error(const char* fmt, ...);
         }                                                                               \
     } while (0)
 
+// Routers that choose between kernel variants by launch size note the variant they took (a string literal, thread-local
+// like the error message): tests assert through ttsmi_last_kernel() that a parity case really ran the variant the
+// benchmark launches.
+void ttsmi_note_kernel(const char* name);
+
 static inline int ttsmi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- tuning knobs ------------------------------------------------------------------------------

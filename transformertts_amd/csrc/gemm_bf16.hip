@@ -1236,6 +1236,7 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
         p.tiles_m = ttsmi_cdiv(p.M, 128);
         p.tiles_n = ttsmi_cdiv(p.N, 256);
         dim3 grid(p.tiles_m * p.tiles_n, 1, 1);
+        ttsmi_note_kernel("gemm_bf16_kernel<false, 128, 256>");
         hipLaunchKernelGGL((gemm_bf16_kernel<false, 128, 256>), grid, dim3(256), 0, st, p);
         TTSMI_CHECK_LAUNCH(name);
         return TTSMI_OK;
@@ -1254,6 +1255,7 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
         int nw = p.tiles_m * p.tiles_n;
         if (nw >= (use_dma == 2 ? 1 : 192)) {         // under-filled launches keep the 64-row register-staged tiles
             if (nw > 512) nw = 512;
+            ttsmi_note_kernel("gemm_bf16_dma_kernel");
             hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3(nw), dim3(256), 0, st, p);
             TTSMI_CHECK_LAUNCH(name);
             return TTSMI_OK;
@@ -1271,6 +1273,7 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
         (p.A2 == nullptr || (p.K1 % HBK_ == 0 && p.lda2 % 8 == 0 && al16(p.A2)))) {
         p.tiles_m = ttsmi_cdiv(p.M, SBM);
         p.tiles_n = ttsmi_cdiv(p.N, SBN);
+        ttsmi_note_kernel("gemm_bf16_deep_kernel<4>");
         hipLaunchKernelGGL(gemm_bf16_deep_kernel<4>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
         TTSMI_CHECK_LAUNCH(name);
         return TTSMI_OK;
@@ -1283,10 +1286,13 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
     const auto fits32 = [](long rows, long ld) { return rows * ld * 2 < (1L << 32); };
     if (occ4 && !a_f32 && bm == 128 && fits32(p.M, p.lda) && fits32(p.N, p.ldb) &&
         (p.A2 == nullptr || fits32(p.M, p.lda2))) {
+        ttsmi_note_kernel("gemm_bf16_kernel<false, 128, 128, 4>");
         hipLaunchKernelGGL((gemm_bf16_kernel<false, 128, HBN_, 4>), grid, dim3(256), 0, st, p);
         TTSMI_CHECK_LAUNCH(name);
         return TTSMI_OK;
     }
+    ttsmi_note_kernel(a_f32 ? (bm == 64 ? "gemm_bf16_kernel<true, 64>" : "gemm_bf16_kernel<true, 128>")
+                            : (bm == 64 ? "gemm_bf16_kernel<false, 64>" : "gemm_bf16_kernel<false, 128>"));
     if (a_f32) {
         if (bm == 64) hipLaunchKernelGGL((gemm_bf16_kernel<true, 64>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_bf16_kernel<true, 128>), grid, dim3(256), 0, st, p);
@@ -1483,6 +1489,7 @@ static int wgrad_rows_impl(const void* x, int x_is_bf16, int64_t ldx, const void
     TTSMI_KNOB(wdma, "TTSMI_WGRAD_DMA", 1);
     const bool dma_ok = wdma && x_is_bf16 && dy_is_bf16 && conv_taps <= 1 && rows % WR_ROWS == 0 && kin % 128 == 0 &&
                         n % 128 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && al16(x) && al16(dy);
+    ttsmi_note_kernel(dma_ok ? "wgrad_dma_kernel" : "wgrad_rows_kernel");
     if (dma_ok) hipLaunchKernelGGL(wgrad_dma_kernel, wgrid, dim3(256), 0, st, p);
     else if (x_is_bf16 && dy_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<true, true>), wgrid, dim3(256), 0, st, p);
     else if (x_is_bf16) hipLaunchKernelGGL((wgrad_rows_kernel<true, false>), wgrid, dim3(256), 0, st, p);

@@ -542,10 +542,11 @@ int ttsmi_hgemm_ln_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64
     p.y = y; p.y_bf = y_bf16; p.xhat = xhat_bf16; p.rstd = rstd;
     rg_drop(p, p_in, site_in, seed, step_dev);
     if (rg_use_dma(M)) {
+        ttsmi_note_kernel(rg_dma_bm(M) == 64 ? "rowgemm_dma_kernel<0, 64>" : "rowgemm_dma_kernel<0, 128>");
         if (rg_dma_bm(M) == 64) hipLaunchKernelGGL((rowgemm_dma_kernel<0, 64>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((rowgemm_dma_kernel<0, RD_BM>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
     }
-    else hipLaunchKernelGGL((rowgemm_kernel<0>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p);
+    else { ttsmi_note_kernel("rowgemm_kernel<0>"); hipLaunchKernelGGL((rowgemm_kernel<0>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p); }
     TTSMI_CHECK_LAUNCH("hgemm_ln_fwd");
     return TTSMI_OK;
 }
@@ -568,10 +569,11 @@ int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64
     p.dx_bf = dx_bf16; p.dres = dres; p.part = (float*)part_ws;
     rg_drop(p, p_in, site_in, seed, step_dev);
     if (rg_use_dma(M)) {
+        ttsmi_note_kernel(rg_dma_bm(M) == 64 ? "rowgemm_dma_kernel<1, 64>" : "rowgemm_dma_kernel<1, 128>");
         if (rg_dma_bm(M) == 64) hipLaunchKernelGGL((rowgemm_dma_kernel<1, 64>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((rowgemm_dma_kernel<1, RD_BM>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
     }
-    else hipLaunchKernelGGL((rowgemm_kernel<1>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p);
+    else { ttsmi_note_kernel("rowgemm_kernel<1>"); hipLaunchKernelGGL((rowgemm_kernel<1>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p); }
     TTSMI_CHECK_LAUNCH("hgemm_ln_bwd");
     return TTSMI_OK;
 }
