@@ -266,12 +266,15 @@ int ttsmi_l1_loss(const float* pred, int64_t ld_pred, const void* target, int ta
 /* utils/losses.py:63-70 (weighted_sum_losses) over n_terms <= 8 L1 terms in one call: term t is ttsmi_l1_loss with
  * coeff[t] (grad[t] may be NULL), losses_out[t] = its unweighted mean, and
  * total_out[0] = ((0 + coeff[0] losses[0]) + coeff[1] losses[1]) + ... in that order.  The arrays of pointers and
- * sizes are HOST arrays; pred / target / grad entries, losses_out, total_out and ws are device pointers. */
+ * sizes are HOST arrays; pred / target / grad entries, losses_out, total_out and ws are device pointers.
+ * denom (HOST array, may be NULL): denom[t] > 0 replaces rows[t]*cols[t] as the divisor of term t's mean and of its
+ * gradient - the element count of the GLOBAL padded batch when the batch is sharded over data-parallel ranks, so that the
+ * SUM of the ranks' losses / gradients is the single-device mean of utils/losses.py:41-49 (0 / NULL = the term's own count). */
 size_t ttsmi_l1_losses_weighted_ws_bytes(int n_terms);
 int ttsmi_l1_losses_weighted(int n_terms, const float* const* pred, const int64_t* ld_pred, const void* const* target,
                              const int32_t* target_is_int, const int64_t* rows, const int64_t* cols, const float* coeff,
-                             float* const* grad, const int64_t* ld_grad, float* losses_out, float* total_out, void* ws,
-                             size_t ws_bytes, ttsmi_stream_t stream);
+                             const int64_t* denom, float* const* grad, const int64_t* ld_grad, float* losses_out,
+                             float* total_out, void* ws, size_t ws_bytes, ttsmi_stream_t stream);
 int ttsmi_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
                   const int64_t* step_dev, float b1, float b2, float eps, uint16_t* bf16_copy,
                   ttsmi_stream_t stream);

@@ -65,9 +65,9 @@ def test_invalid_arguments_return_error_codes_not_crashes(built):
     # the fused weighted-loss entry refuses term counts outside 1..8 and null tables before touching anything
     arr = (ctypes.c_void_p * 9)(*[16] * 9)
     for n_terms in (0, 9):
-        rc = l.ttsmi_l1_losses_weighted(n_terms, arr, arr, arr, arr, arr, arr, arr, arr, arr, one, one, one, 1 << 20, None)
+        rc = l.ttsmi_l1_losses_weighted(n_terms, arr, arr, arr, arr, arr, arr, arr, None, arr, arr, one, one, one, 1 << 20, None)
         assert rc == -1 and b'terms' in l.ttsmi_last_error()
-    rc = l.ttsmi_l1_losses_weighted(3, None, arr, arr, arr, arr, arr, arr, arr, arr, one, one, one, 1 << 20, None)
+    rc = l.ttsmi_l1_losses_weighted(3, None, arr, arr, arr, arr, arr, arr, None, arr, arr, one, one, one, 1 << 20, None)
     assert rc == -1 and b'null' in l.ttsmi_last_error()
     assert l.ttsmi_l1_losses_weighted_ws_bytes(3) >= 3 * 512 * 4
     assert l.ttsmi_griffinlim_ws_bytes(2) == 0 and l.ttsmi_griffinlim_ws_bytes(900) > 900 * 513 * 8

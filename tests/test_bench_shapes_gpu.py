@@ -107,9 +107,10 @@ def test_fused_gemm_layernorm_forward_at_the_benchmark_rows(M, K, dual):
     yh = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
     xh = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
     rstd = torch.empty(M, device=DEV)
+    bias_d, res_d, gam_d, bet_d, pad_d = (t.to(DEV) for t in (bias, res, gam, bet, pad))     # (kept alive over the launch)
     check(l.ttsmi_hgemm_ln_fwd(_p(a1), a1.stride(0), _p(a2), 0 if a2 is None else a2.stride(0), a1.shape[1] if dual else 0,
-                               _p(sh.wt), sh.wt.stride(0), _p(bias.to(DEV)), _p(res.to(DEV)), _p(gam.to(DEV)), _p(bet.to(DEV)),
-                               _p(pad.to(DEV)), pdrop, site, seed, _p(step), EPS, _p(y), _p(yh), _p(xh), _p(rstd), M, N, K,
+                               _p(sh.wt), sh.wt.stride(0), _p(bias_d), _p(res_d), _p(gam_d), _p(bet_d),
+                               _p(pad_d), pdrop, site, seed, _p(step), EPS, _p(y), _p(yh), _p(xh), _p(rstd), M, N, K,
                                _stream()))
     torch.cuda.synchronize()
     assert last_kernel(l) == 'rowgemm_dma_kernel<0, 128>'
@@ -153,9 +154,9 @@ def test_fused_dgrad_layernorm_backward_at_the_benchmark_rows(M, K):
     dres = torch.empty(M, N, device=DEV)
     nw = int(l.ttsmi_hgemm_ln_bwd_nparts(M))
     ws = torch.empty(int(l.ttsmi_layernorm_partials_bytes(nw, N)), dtype=torch.uint8, device=DEV)
-    abd = ab.to(DEV)
-    check(l.ttsmi_hgemm_ln_bwd(_p(abd), abd.stride(0), _p(sh.wb), sh.wb.stride(0), _p(part.to(DEV)), _p(xh.to(DEV)),
-                               _p(rstd.to(DEV)), _p(gam.to(DEV)), _p(pad.to(DEV)), pdrop, site, seed, _p(step), _p(dxb),
+    abd, part_d, xh_d, rstd_d, gam_d, pad_d = (t.to(DEV) for t in (ab, part, xh, rstd, gam, pad))   # (kept alive over the launch)
+    check(l.ttsmi_hgemm_ln_bwd(_p(abd), abd.stride(0), _p(sh.wb), sh.wb.stride(0), _p(part_d), _p(xh_d),
+                               _p(rstd_d), _p(gam_d), _p(pad_d), pdrop, site, seed, _p(step), _p(dxb),
                                _p(dres), _p(ws), ws.numel(), M, N, K, _stream()))
     assert last_kernel(l) == 'rowgemm_dma_kernel<1, 128>'
     dg, db = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)

@@ -224,10 +224,20 @@ def test_bf16_path_at_the_benchmarked_batch_of_32(gold32, setup, tag):
     assert bool(l._cdll.ttsmi_hgemm_k256_eligible(32 * 900, 1024, 256))
 
 
+# Gradient bounds of the exact-fp32 path at B = 32.  Outputs, hidden states and losses keep the 1e-4 contract (measured
+# 1e-6 / 4e-8).  The GRADIENTS are sums over 8 x more rows than at B = 4 and the encoder side sits behind the pitch
+# predictor's last LayerNorm, whose backward cancels (csrc/common.h): the fp32 rounding of those sums is a property of
+# fp32, not of this implementation - the torch-CPU oracle run in FLOAT32 on the same batches
+# (tests/golden/calibrate_fp32_oracle_b32.py) is off the fp64 golden by embedding 3.2e-4 / 1.28e-3, matrices 1.1e-4 /
+# 2.2e-4, vectors 2.6e-4 / 3.6e-4 (maxshape / ragged); the HIP path measures 7.8e-4 / 1.29e-3, 2.1e-4 / 2.1e-4,
+# 3.3e-4 / 5.7e-4.  Bounds = about twice the larger of the two.
+BOUNDS_F32_B32 = dict(BOUNDS['f32'], grad=5e-4, grad_embedding=3e-3, grad_vec=1.2e-3, gnorm=4e-4)
+
+
 @pytest.mark.parametrize('tag', ['maxshape', 'ragged'])
 def test_f32_path_at_the_benchmarked_batch_of_32(gold32, setup, tag):
     cfg, W = setup
     m, out = _run32(cfg, W, tag, 'f32')
-    report = _compare32(gold32, tag, m, out, BOUNDS['f32'])
+    report = _compare32(gold32, tag, m, out, BOUNDS_F32_B32)
     _dump(tag + '_b32', 'f32', report)
-    _check(report, BOUNDS['f32'])
+    _check(report, BOUNDS_F32_B32)

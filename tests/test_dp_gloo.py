@@ -163,3 +163,137 @@ def test_two_ranks_match_the_global_batch_step(tmp_path, backend):
     # same math up to the summation order of the two half-batch gradients (bf16 GEMM operands): Adam's
     # lr * sign-like step bounds the difference by a few lr
     assert np.abs(w0 - ws).max() < 5e-3 and np.abs(w0 - ws).mean() < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Ragged global batches: ranks with DIFFERENT local maxima and DIFFERENT local batch sizes must
+# reproduce the single-device step on the concatenated, globally padded batch - the reference's loss is an unmasked mean
+# over [B, T_max, C] (utils/losses.py:41-49), so padded positions carry loss and gradient and the divisor is global.
+# ---------------------------------------------------------------------------------------------------------------------
+RAGGED = dict(B=4, Tp=16, Tm=48, seed=5)
+
+
+def _ragged_shards():
+    """Global ragged batch of 4 (sample 0 at both maxima) -> rank 0: samples 1..3 trimmed to THEIR maxima,
+    rank 1: sample 0 alone (1 sample, global maxima)."""
+    from oracle import ft_oracle as fo
+    tokens, mel, durs, pitch = fo.synthetic_batch(RAGGED['B'], RAGGED['Tp'], RAGGED['Tm'], seed=RAGGED['seed'], ragged=True)
+
+    def trim(sl):
+        tp = int((tokens[sl] != 0).sum(1).max())
+        tm = int(durs[sl].sum(1).max())
+        return tokens[sl, :tp], mel[sl, :tm], durs[sl, :tp], pitch[sl, :tp]
+    shards = [trim(slice(1, 4)), trim(slice(0, 1))]
+    assert shards[0][0].shape[1] < RAGGED['Tp'] and shards[0][1].shape[1] < RAGGED['Tm']
+    # the single-device batch in rank order
+    order = [1, 2, 3, 0]
+    return (tokens, mel, durs, pitch), shards, tuple(a[order] for a in (tokens, mel, durs, pitch))
+
+
+def _ragged_cpu_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import torch.nn.functional as F
+    from oracle import ft_oracle as fo
+    from transformertts_amd import dp
+    dp.init_process_group(backend='gloo')
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=1, perturb=0.02)
+    _, shards, _ = _ragged_shards()
+    x, ts, td, tp = shards[rank]
+
+    class _Stub:                      # DataParallel only needs these of the model on the CPU
+        device = 'cpu'
+        params = type('P', (), {'data': torch.zeros(4), 'offsets': {}})()
+        grad_sync = None
+    wrapped = dp.DataParallel(_Stub(), broadcast=False)
+    Bg, Tpg, Tmg = wrapped.global_shape(x.shape[0], x.shape[1], ts.shape[1])
+    assert (Bg, Tpg, Tmg) == (RAGGED['B'], RAGGED['Tp'], RAGGED['Tm'])
+    x, ts, td, tp = (wrapped._pad_to(a, n) for a, n in ((x, Tpg), (ts, Tmg), (td, Tpg), (tp, Tpg)))
+    # the oracle's Expand stops at the shard's own max sum(dur): pad it to the global length like the model does
+    real = fo.expand_torch
+    fo.expand_torch = lambda h, d: F.pad(real(h, d), (0, 0, 0, Tmg - real(h, d).shape[1]))
+    model = fo.ForwardTransformerOracle(cfg, W, torch.float64)
+    tr = model.train_step(x, ts, td, tp, apply=False)
+    share = x.shape[0] / Bg                                   # local mean * B_local / B_global = local sum / global count
+    g = _flat(tr['grads']) * share
+    wrapped.sync.scale = False                                # what DataParallel.train_step sets: plain SUM
+    wrapped.sync(g)
+    loss = torch.tensor([float(tr['loss']) * share], dtype=torch.float64)
+    dist.all_reduce(loss)
+    if rank == 0:
+        np.save(os.path.join(out_dir, 'sum.npy'), g.numpy())
+        np.save(os.path.join(out_dir, 'loss.npy'), loss.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_shards_with_global_counts_equal_the_single_device_step(tmp_path):
+    """gloo world 2 on the CPU oracle: shards of 3 and 1 samples, trimmed to their own maxima, go through
+    DataParallel.global_shape / _pad_to and the un-scaled SUM all-reduce; the result is the gradient and the loss of
+    ONE step on the whole padded batch (reference model/models.py:464-482)."""
+    from oracle import ft_oracle as fo
+    port = _free_port()
+    _spawn(_ragged_cpu_worker, (2, port, str(tmp_path)), 2)
+    _, _, whole = _ragged_shards()
+    cfg = fo.tiny_config()
+    W = fo.init_weights(cfg, seed=1, perturb=0.02)
+    tr = fo.ForwardTransformerOracle(cfg, W, torch.float64).train_step(*whole, apply=False)
+    np.testing.assert_allclose(np.load(tmp_path / 'sum.npy'), _flat(tr['grads']).numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.load(tmp_path / 'loss.npy')[0], float(tr['loss']), rtol=1e-12)
+
+
+def _ragged_gpu_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), TTSMI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from oracle import ft_oracle as fo
+    from transformertts_amd import dp
+    from transformertts_amd.model.models import ForwardTransformer
+    dp.init_process_group()
+    torch.cuda.set_device(0)
+    cfg = dict(fo.tiny_config(), dropout_rate=0.0, predictors_dropout=0.0)     # ranks draw their own dropout streams
+    W = fo.init_weights(cfg, seed=1, perturb=0.02)
+    model = ForwardTransformer.from_config(dict(cfg, device='cuda:0', seed=100 + rank, precision='f32'))
+    model.load_weights_dict({k: np.asarray(v) for k, v in W.items()})
+    model._compile(learning_rate=1e-3)
+    wrapped = dp.DataParallel(model)
+    _, shards, _ = _ragged_shards()
+    out = wrapped.train_step(*shards[rank])                   # global shape found by the all-gather
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f'w{rank}.npy'), model.params.data.cpu().numpy())
+    np.save(os.path.join(out_dir, f'g{rank}.npy'), model.params.grad.cpu().numpy())
+    np.save(os.path.join(out_dir, f'loss{rank}.npy'), np.array([float(out['loss']), float(out['losses']['mel']),
+                                                                float(out['losses']['duration']), float(out['losses']['pitch'])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ragged_two_rank_step_on_the_gpu_equals_the_single_process_step(tmp_path):
+    """The real model (exact-fp32 path, dropout off) as two gloo ranks on one GPU with ragged shards (3 samples with
+    shorter maxima / 1 sample at the global maxima) against ONE process stepping on the whole padded batch: gradients,
+    the four loss values and the post-Adam weights."""
+    from oracle import ft_oracle as fo
+    from transformertts_amd.model.models import ForwardTransformer
+    port = _free_port()
+    _spawn(_ragged_gpu_worker, (2, port, str(tmp_path)), 2)
+    w0, w1 = np.load(tmp_path / 'w0.npy'), np.load(tmp_path / 'w1.npy')
+    np.testing.assert_array_equal(w0, w1)
+    np.testing.assert_array_equal(np.load(tmp_path / 'loss0.npy'), np.load(tmp_path / 'loss1.npy'))
+    _, _, whole = _ragged_shards()
+    cfg = dict(fo.tiny_config(), dropout_rate=0.0, predictors_dropout=0.0)
+    W = fo.init_weights(cfg, seed=1, perturb=0.02)
+    single = ForwardTransformer.from_config(dict(cfg, device='cuda:0', seed=0, precision='f32'))
+    single.load_weights_dict({k: np.asarray(v) for k, v in W.items()})
+    single._compile(learning_rate=1e-3)
+    out = single.train_step(*whole)
+    torch.cuda.synchronize()
+    want = np.array([float(out['loss']), float(out['losses']['mel']), float(out['losses']['duration']), float(out['losses']['pitch'])])
+    np.testing.assert_allclose(np.load(tmp_path / 'loss0.npy'), want, rtol=2e-6)
+    gs = single.params.grad.cpu().numpy()
+    g0 = np.load(tmp_path / 'g0.npy')
+    assert np.abs(g0 - gs).max() < 2e-5 * np.abs(gs).max()           # fp32 summation order of the two shards only
+    # Adam turns a gradient into a step of about lr whatever its size, so weights can differ by ~2 lr where the
+    # gradient is at the noise floor; everywhere else they agree closely
+    ws = single.params.data.cpu().numpy()
+    assert np.abs(w0 - ws).max() < 2.5e-3 and np.abs(w0 - ws).mean() < 2e-5

@@ -70,7 +70,7 @@ SIGNATURES = {
     'ttsmi_l1_loss_ws_bytes': (c_size_t, [L]),
     'ttsmi_l1_loss': (I, [P, L, P, I, L, L, F, P, L, P, P, c_size_t, S]),
     'ttsmi_l1_losses_weighted_ws_bytes': (c_size_t, [I]),
-    'ttsmi_l1_losses_weighted': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, S]),
+    'ttsmi_l1_losses_weighted': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, S]),
     'ttsmi_adam_tf': (I, [P, P, P, P, L, P, P, F, F, F, P, S]),
     'ttsmi_step_increment': (I, [P, S]),
     'ttsmi_stft_logmel': (I, [P, P, P, I, L, I, I, P, I, P, P, P, P, I, F, P, S]),

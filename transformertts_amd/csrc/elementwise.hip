@@ -487,8 +487,8 @@ size_t ttsmi_l1_losses_weighted_ws_bytes(int n_terms) {
 }
 int ttsmi_l1_losses_weighted(int n_terms, const float* const* pred, const int64_t* ld_pred, const void* const* target,
                              const int32_t* target_is_int, const int64_t* rows, const int64_t* cols, const float* coeff,
-                             float* const* grad, const int64_t* ld_grad, float* losses_out, float* total_out, void* ws,
-                             size_t ws_bytes, ttsmi_stream_t stream) {
+                             const int64_t* denom, float* const* grad, const int64_t* ld_grad, float* losses_out,
+                             float* total_out, void* ws, size_t ws_bytes, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(n_terms >= 1 && n_terms <= L1_MAX_TERMS, "l1_losses_weighted: %d terms (1..%d)", n_terms, L1_MAX_TERMS);
     TTSMI_CHECK_ARG(pred && ld_pred && target && target_is_int && rows && cols && coeff && grad && ld_grad && losses_out &&
                     total_out, "l1_losses_weighted: null pointer");
@@ -499,11 +499,15 @@ int ttsmi_l1_losses_weighted(int n_terms, const float* const* pred, const int64_
     for (int t = 0; t < n_terms; ++t) {
         TTSMI_CHECK_ARG(pred[t] && target[t] && rows[t] > 0 && cols[t] > 0, "l1_losses_weighted: bad term %d", t);
         const long n = rows[t] * cols[t];
+        // the mean's divisor: the term's own element count, or the GLOBAL count of a batch sharded over ranks
+        // (batch data parallelism: every rank divides its partial sum by B_global * T_max_global * C)
+        TTSMI_CHECK_ARG(!denom || denom[t] >= 0, "l1_losses_weighted: negative divisor for term %d", t);
+        const double div = denom && denom[t] > 0 ? (double)denom[t] : (double)n;
         int nb = ew_blocks(n);
         if (nb > L1_BLOCKS) nb = L1_BLOCKS;
-        q.nb[t] = nb; q.inv_n[t] = 1.0f / (float)n; q.coeff[t] = coeff[t];
+        q.nb[t] = nb; q.inv_n[t] = (float)(1.0 / div); q.coeff[t] = coeff[t];
         hipLaunchKernelGGL(l1_loss_kernel, dim3(nb), dim3(256), 0, st, pred[t], (long)ld_pred[t], target[t], (int)target_is_int[t],
-                           (long)rows[t], (long)cols[t], coeff[t] / (float)n, grad[t], (long)ld_grad[t],
+                           (long)rows[t], (long)cols[t], (float)((double)coeff[t] / div), grad[t], (long)ld_grad[t],
                            (float*)ws + (size_t)t * L1_BLOCKS);
         TTSMI_CHECK_LAUNCH("l1_losses_weighted(term)");
     }

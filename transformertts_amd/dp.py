@@ -4,10 +4,14 @@ step - an all-reduce of the flat fp32 gradient buffer (RCCL over xGMI; torch.dis
 is the only parallelism the path needs: samples are independent, parameters
 and Adam state are replicated, every rank applies the identical fused Adam step.
 
-Loss normalisation: each rank's L1 losses are means over ITS [B_local, T_max, C] block.  With equal
-per-rank shapes (how the trainer forms a global batch: one bucket, split evenly) the average of the
-per-rank gradients equals the gradient of the global-batch mean, so the all-reduce is a SUM followed by
-one 1/world scaling pass.
+Loss normalisation (reference utils/losses.py:41-49 is an UNMASKED mean over the
+whole padded batch [B, T_max, C]): `DataParallel.train_step` pads every rank's shard to the GLOBAL
+(Tp_max, Tm_max) - padded positions carry loss and gradient in the reference - and hands the model the
+GLOBAL element counts as the divisors of its three means (`ttsmi_l1_losses_weighted(denom=...)`), so a
+rank's loss / gradient is its share of the global-batch mean and the all-reduce is a plain SUM: ragged
+shards (different local maxima, different local batch sizes) reproduce the single-device step exactly.
+`GradAllReduce` on its own (no global counts known) keeps the older contract: equal-shape shards, SUM
+followed by one 1/world scaling pass.
 
 The gradient buffer is a single contiguous tensor, so the collective is one large message: on the
 xGMI full mesh RCCL can spread it over all 7 links per GPU (direct reduce-scatter + all-gather)
@@ -60,6 +64,7 @@ class GradAllReduce:
         # SUM + one 1/world scaling pass on every backend: ReduceOp.AVG is NCCL-only and not worth a
         # backend-dependent code path (the scaling pass is one 44 MB stream, ~15 us)
         self.use_avg = False
+        self.scale = True                   # False: the ranks' gradients are already shares of the global mean (plain SUM)
         self.overlap = dist.is_initialized() and os.environ.get('TTSMI_DP_OVERLAP', '1') != '0'
         self._tail = None                   # (work handle, split) of the in-flight decoder bucket
         self._launch_stream = None
@@ -102,7 +107,7 @@ class GradAllReduce:
             work.wait()                               # (CUDA: the current stream waits for the decoder bucket)
         else:
             self._reduce(flat_grad)
-        if not self.use_avg:
+        if not self.use_avg and self.scale:
             flat_grad.mul_(1.0 / self.world)
 
 
@@ -156,5 +161,57 @@ class DataParallel:
     def __getattr__(self, name):
         return getattr(self.model, name)
 
-    def train_step(self, *args, **kw):
-        return self.model.train_step(*args, **kw)
+    def global_shape(self, B: int, Tp: int, Tm: int) -> tuple:
+        """(sum of the ranks' batch sizes, max phoneme length, max frame count) - one small all-gather.  A trainer that
+        forms the batch globally knows these on the host and passes them to train_step instead (no collective, no sync)."""
+        if self.sync.world == 1:
+            return int(B), int(Tp), int(Tm)
+        dev = self.model.device if dist.get_backend(self.sync.group) == 'nccl' else 'cpu'
+        mine = torch.tensor([B, Tp, Tm], dtype=torch.int64, device=dev)
+        every = [torch.empty_like(mine) for _ in range(self.sync.world)]
+        dist.all_gather(every, mine, group=self.sync.group)
+        every = torch.stack(every).cpu()
+        return int(every[:, 0].sum()), int(every[:, 1].max()), int(every[:, 2].max())
+
+    @staticmethod
+    def _pad_to(a, length: int, axis: int = 1):
+        n = a.shape[axis]
+        if n == length:
+            return a
+        assert n < length, f'local length {n} exceeds the global maximum {length}'
+        if torch.is_tensor(a):
+            pad = [0, 0] * (a.dim() - 1 - axis) + [0, length - n]
+            return torch.nn.functional.pad(a, pad)
+        import numpy as np
+        width = [(0, 0)] * a.ndim
+        width[axis] = (0, length - n)
+        return np.pad(a, width)
+
+    def train_step(self, input_sequence, target_sequence, target_durations, target_pitch, global_shape=None,
+                   reduce_losses: bool = True):
+        """One data-parallel step on this rank's shard, equal to the single-device step on the concatenated batch.
+        global_shape = (B_global, Tp_max_global, Tm_max_global); None -> all-gathered from the ranks' local shapes.
+        The returned `loss` / `losses` are the GLOBAL batch values when reduce_losses (one 4-float all-reduce),
+        otherwise this rank's share of them."""
+        B, Tp = int(input_sequence.shape[0]), int(input_sequence.shape[1])
+        Tm = int(target_sequence.shape[1])
+        Bg, Tpg, Tmg = global_shape if global_shape is not None else self.global_shape(B, Tp, Tm)
+        x = self._pad_to(input_sequence, Tpg)
+        ts = self._pad_to(target_sequence, Tmg)
+        td = self._pad_to(target_durations, Tpg)
+        tp = self._pad_to(target_pitch, Tpg)
+        model = self.model
+        mel_channels = int(target_sequence.shape[2])
+        model.loss_denominators = (Bg * Tmg * mel_channels, Bg * Tpg, Bg * Tpg)
+        self.sync.scale = False
+        try:
+            out = model.train_step(x, ts, td, tp)
+        finally:
+            model.loss_denominators = None
+            self.sync.scale = True
+        if reduce_losses and self.sync.active:
+            vals = torch.stack([out['loss'].reshape(()), out['losses']['mel'].reshape(()),
+                                out['losses']['duration'].reshape(()), out['losses']['pitch'].reshape(())])
+            dist.all_reduce(vals, op=dist.ReduceOp.SUM, group=self.sync.group)
+            out = dict(out, loss=vals[0], losses={'mel': vals[1], 'duration': vals[2], 'pitch': vals[3]})
+        return out

@@ -222,6 +222,7 @@ class ForwardTransformer:
         self._graphs: Dict[tuple, dict] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
         self.grad_sync = None                # set by transformertts_amd.dp.DataParallel
+        self.loss_denominators = None        # (mel, duration, pitch) element counts of the GLOBAL batch, set per step by dp.DataParallel
         self._lenreg_hook = None             # DataParallel: starts the decoder-half all-reduce (ops.LenRegFn.backward)
         # reference_outputs=True: train_step returns the 12 attention maps like the reference's _train_step
         # (models.py:544-549) instead of leaving the dicts empty - see the module docstring
@@ -672,7 +673,8 @@ class ForwardTransformer:
     def _losses(self, model_out, target_sequence, target_durations, target_pitch, unit_seed=False):
         return weighted_sum_losses((target_sequence, target_durations, target_pitch),
                                    (model_out['mel'], model_out['duration'], model_out['pitch']),
-                                   self.loss, self.loss_weights, unit_seed=unit_seed)
+                                   self.loss, self.loss_weights, unit_seed=unit_seed,
+                                   denominators=self.loss_denominators)
 
     def _prep(self, input_sequence, target_sequence, target_durations, target_pitch):
         dev = self.device
@@ -740,7 +742,7 @@ class ForwardTransformer:
         optimiser step counter and, derived from it, the dropout stream.
         First call of a shape runs eagerly (warm-up), the second captures, later ones replay.  The
         returned tensors are the graph's static outputs: consume them before the next step."""
-        key = (tuple(x.shape), tuple(ts.shape))
+        key = (tuple(x.shape), tuple(ts.shape), self.loss_denominators)      # the divisors are baked into a capture
         st = self._graphs.get(key)
         if st is None:
             self._graphs[key] = {'calls': 1}

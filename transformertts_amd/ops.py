@@ -1099,8 +1099,14 @@ class WeightedL1LossesFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, coeffs, unit_seed, *pt):
+        """coeffs: tuple of weights, optionally followed by ONE tuple of per-term divisors (global element counts of a
+        batch sharded over data-parallel ranks; 0 = the term's own count): ((c0, c1, ...), (n0, n1, ...))."""
+        denoms = None
+        if len(coeffs) == 2 and isinstance(coeffs[0], (tuple, list)):
+            coeffs, denoms = coeffs
         assert len(pt) % 2 == 0 and 2 <= len(pt) <= 16 and len(coeffs) == len(pt) // 2
         n = len(pt) // 2
+        assert denoms is None or len(denoms) == n
         preds, targets, grads, shapes = [], [], [], []
         for i in range(n):
             pred, target = pt[2 * i], _c(pt[2 * i + 1])
@@ -1123,7 +1129,8 @@ class WeightedL1LossesFn(torch.autograd.Function):
         check(l.ttsmi_l1_losses_weighted(
             n, ptrs(preds), i64(t.stride(0) for t in preds), ptrs(targets),
             (ctypes.c_int32 * n)(*[int(t.dtype == torch.int32) for t in targets]), i64(t.shape[0] for t in preds),
-            i64(t.shape[1] for t in preds), (ctypes.c_float * n)(*[float(c) for c in coeffs]), ptrs(grads),
+            i64(t.shape[1] for t in preds), (ctypes.c_float * n)(*[float(c) for c in coeffs]),
+            None if denoms is None else i64(denoms), ptrs(grads),
             i64(t.stride(0) for t in grads), _p(out), out.data_ptr() + 4 * n, _p(ws), ws.numel(), _stream()),
             'l1_losses_weighted')
         ctx.save_for_backward(*grads)
