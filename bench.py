@@ -385,6 +385,154 @@ def predict_bench(args):
                       'rtf_p50': head['rtf_p50'], 'cases': cases}))
 
 
+MEL_PMC_FILE = 'r03_pmc_hbm_traffic_mel.json'
+
+
+def _mel_cpu_clip(args):
+    """One clip through the NumPy restatement of data/audio.py:81-92 (pool worker: one process per clip, like the
+    reference's p_uimap over wav files in create_training_data.py:63)."""
+    from oracle import mel_oracle as mo
+    return mo.mel_spectrogram(args).shape[0]
+
+
+def mel_cpu_baseline(clips, bytes_per_clip, cores):
+    """NumPy restatement (oracle/mel_oracle.py: rfft + dense mel matmul, what librosa does) timed on the host: one core,
+    and a pool of `cores` single-threaded processes (the reference extracts features with a process pool).  Bounded
+    sample: the pool works for ~10 s."""
+    import multiprocessing as mp
+    from threadpoolctl import threadpool_limits
+    from oracle import mel_oracle as mo
+    with threadpool_limits(1):                             # ONE core: no BLAS threads behind the mel matmul
+        mo.mel_spectrogram(clips[0])                       # filterbank construction / FFT plan warm-up
+        n1, t0 = 0, time.perf_counter()
+        while n1 < 4 or time.perf_counter() - t0 < 3.0:
+            mo.mel_spectrogram(clips[n1 % len(clips)])
+            n1 += 1
+        dt1 = time.perf_counter() - t0
+        gbs1 = sum(bytes_per_clip[i % len(clips)] for i in range(n1)) / dt1 / 1e9
+        with mp.get_context('fork').Pool(cores) as pool:   # (forked inside the limit: every worker is single-threaded)
+            t0 = time.perf_counter()
+            pool.map(_mel_cpu_clip, clips, chunksize=1)    # workers warm + a timing of one pass
+            one_pass = time.perf_counter() - t0
+            reps = max(1, min(512, int(10.0 / max(one_pass, 1e-3))))
+            work = clips * reps
+            t0 = time.perf_counter()
+            pool.map(_mel_cpu_clip, work, chunksize=1)
+            dtp = time.perf_counter() - t0
+    gbsp = sum(bytes_per_clip) * reps / dtp / 1e9
+    return {'value': gbsp, 'unit': 'GB/s', 'cores': cores, 'kind': 'port',
+            'clips_per_s': len(work) / dtp,
+            'single_core': {'value': gbs1, 'unit': 'GB/s', 'clips_per_s': n1 / dt1},
+            'sample': f'{len(work)} clip extractions ({len(clips)} distinct LJSpeech-length clips of the same workload x '
+                      f'{reps}) on a pool of {cores} single-threaded processes in {dtp:.1f} s; single_core = {n1} clips '
+                      f'in {dt1:.1f} s; NumPy rfft + dense 80x513 mel matmul restatement of data/audio.py:81-92 '
+                      f'(librosa unavailable offline); same algorithmic bytes per clip as the GPU figure'}
+
+
+def mel_bench(args):
+    """BASELINE.json configs[3]: wav -> 1024-pt STFT (hop 256, periodic Hann, reflect padding) -> 80-bin Slaney mel
+    -> log, data/audio.py:72-92, as ONE batched launch over 10 000 LJSpeech-length clips generated on the device.
+    A step = one pass over the rank's 10 000 clips.  value = algorithmic GB/s (4 N bytes of samples in + 320 bytes per
+    frame out) summed over ranks / max-over-ranks time, against the 8 TB/s HBM roof.  Replicas only:
+    every rank extracts its own clips, no collective on the data path."""
+    from transformertts_amd import dp, ops
+    from transformertts_amd.data.audio import Audio
+    rank, local, world = dp.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    n_clips = args.clips
+    audio = Audio(22050, 1024, 80, 256, 1024, 0, 8000, 'MelGAN', device=str(dev))
+    rng = np.random.default_rng(1234 + rank)
+    lens = np.clip(rng.normal(145000, 48000, n_clips), 24000, 222000).astype(np.int64)      # SURVEY.md 8d
+    total = int(lens.sum())
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    wav = torch.randn(total, device=dev, generator=gen) * 0.1
+    t = torch.arange(total, device=dev, dtype=torch.float32) / 22050.0
+    wav += 0.3 * torch.sin(2 * np.pi * 220.0 * t) + 0.2 * torch.sin(2 * np.pi * 1760.0 * t)
+    del t
+    clip_off = np.zeros(n_clips + 1, dtype=np.int64)
+    clip_off[1:] = np.cumsum(lens)
+    frame_off = np.zeros(n_clips + 1, dtype=np.int64)
+    frame_off[1:] = np.cumsum(1 + lens // 256)
+    frames = int(frame_off[-1])
+    coff, foff = torch.from_numpy(clip_off).to(dev), torch.from_numpy(frame_off).to(dev)
+    lo, cnt, ptr, w = audio._mel
+    out = torch.empty((frames, 80), dtype=torch.float32, device=dev)
+
+    def step():
+        return ops.stft_logmel(wav, coff, foff, frames, 1024, 256, audio._window, 80, lo, cnt, ptr, w, 0, 1e-5, out=out)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                       # (the launch goes to torch's current stream: these events bracket the kernels)
+    for _ in range(args.steps):
+        mel = step()
+    ev1.record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert bool(torch.isfinite(mel[:4096]).all())
+    byt = 4.0 * total + 4.0 * 80 * frames              # algorithmic bytes of one pass of one rank
+    sec = elapsed / args.steps
+    result = {
+        'metric': 'mel feature extraction, algorithmic GB/s (wav -> 1024-pt STFT -> 80-bin log-mel)',
+        'value': byt * world / sec / 1e9, 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * sec, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': f'BASELINE.json configs[3]: mel microbench, {n_clips} LJSpeech-length clips per GPU '
+                               f'(lengths ~ clip(N(145000, 48000^2), 24000, 222000) samples, noise + 2 sines, generated '
+                               f'on the device), 22.05 kHz, n_fft 1024, hop 256, 80 mels, fmax 8000, MelGAN log '
+                               f'normaliser; one batched launch per step',
+                   'clips': n_clips * world, 'frames': frames * world, 'samples': total * world,
+                   'algorithmic_bytes_per_step': byt * world, 'parallelism': f'replicas x{world}'},
+        'clips_per_s': n_clips * world / sec, 'frames_per_s': frames * world / sec,
+    }
+    if rank == 0 and not args.no_roofline:
+        gbs = byt / kernel_ms / 1e6
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', MEL_PMC_FILE)) as f:
+                traffic = json.load(f).get('hbm_bytes_per_launch')
+        except (OSError, ValueError):
+            pass
+        result['roofline'] = {
+            'bound': 'hbm', 'kernel': 'stft_logmel_kernel<1024>', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+            'frac': gbs / PEAK_HBM_GBS, 'traffic': traffic,
+            'traffic_note': (f'HBM bytes per launch from the committed PMC passes (profiles/{MEL_PMC_FILE})' if traffic else None),
+            'avg_launch_ms': kernel_ms, 'algorithmic_mb_per_launch': byt / 1e6,
+            'algorithmic_gflop_per_launch': frames * 28.6e3 / 1e9,
+            'flop_per_byte': frames * 28.6e3 / byt,
+            'note': 'HIP events on the launch stream around the timed launches; algorithmic FLOPs = 25.6 k (1024-pt rFFT) + '
+                    '3 k (sparse mel) per frame (SURVEY.md 8d): ~21 FLOP/B, at the fp32 vector ridge - the kernel is '
+                    'bound by VALU issue, the HBM fraction is what BASELINE.json asks to be reported',
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_cpu = 32
+        clips = [wav[int(clip_off[i]):int(clip_off[i + 1])].cpu().numpy() for i in range(n_cpu)]
+        bpc = [4.0 * int(lens[i]) + 320.0 * (1 + int(lens[i]) // 256) for i in range(n_cpu)]
+        result['cpu_baseline'] = mel_cpu_baseline(clips, bpc, usable_cpus())
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        sync()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -405,6 +553,7 @@ def main():
     ap.add_argument('--no-attention-maps', dest='with_attention_maps', action='store_false',
                     help='skip the extra timed leg that also materialises the 12 attention maps')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--clips', type=int, default=10000, help='--workload mel: clips per GPU (BASELINE configs[3]: 10 000)')
     args = ap.parse_args()
 
     if args.workload == 'predict':
@@ -421,6 +570,9 @@ def main():
         os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
                                   f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
                                   '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
+    if args.workload == 'mel':
+        return mel_bench(args)
 
     from transformertts_amd import dp
     rank, local, world = dp.init_process_group()
@@ -444,8 +596,12 @@ def main():
     tok, mel, dur, pit = synthetic_batch(shape['B'], shape['Tp'], shape['Tm'], seed=1234 + rank)
     batch = [torch.from_numpy(a).to(dev) for a in (tok, mel, dur, pit)]      # resident in HBM
 
-    def step():
-        return wrapped.train_step(*batch)
+    # the batch is formed globally (equal shards of one bucket): the global shape is known on the host, so no per-step
+    # shape exchange; the four loss scalars are summed over ranks only for the value reported at the end
+    gshape = (shape['B'] * world, shape['Tp'], shape['Tm'])
+
+    def step(reduce_losses=False):
+        return wrapped.train_step(*batch, global_shape=gshape, reduce_losses=reduce_losses)
 
     def sync():
         if world > 1:
@@ -465,7 +621,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = float(out['loss'])
+    loss = float(out['loss']) * world      # a rank's share of the global-batch mean (equal shards) -> the mean
     assert np.isfinite(loss), 'non-finite loss'
     frames = shape['B'] * shape['Tm'] * world
     ms = 1e3 * elapsed / args.steps

@@ -297,8 +297,9 @@ def step_increment(step_dev):
 
 
 def stft_logmel(wav, clip_off, frame_off, total_frames, n_fft, hop, window, n_mels, mel_lo, mel_cnt,
-                mel_ptr, mel_w, normalizer, clip_min):
-    out = torch.empty((int(total_frames), n_mels), dtype=torch.float32, device=wav.device)
+                mel_ptr, mel_w, normalizer, clip_min, out=None):
+    if out is None:
+        out = torch.empty((int(total_frames), n_mels), dtype=torch.float32, device=wav.device)
     check(_lib.lib().ttsmi_stft_logmel(_p(wav), _p(clip_off), _p(frame_off), clip_off.numel() - 1,
                                        int(total_frames), n_fft, hop, _p(window), n_mels, _p(mel_lo),
                                        _p(mel_cnt), _p(mel_ptr), _p(mel_w), normalizer, clip_min, _p(out),
