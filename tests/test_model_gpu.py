@@ -523,7 +523,9 @@ def test_dp_overlap_hook_plumbing_on_one_gpu(tiny):
     wrapped.sync = sync
     m.grad_sync = sync
     wrapped.install_overlap_hook()
-    got = wrapped.train_step(*batch)
+    # (no process group behind the fake two-rank sync: the global shape is given, the loss values are not reduced)
+    got = wrapped.train_step(*batch, global_shape=(batch[0].shape[0], batch[0].shape[1], batch[1].shape[1]),
+                             reduce_losses=False)
     g = m.params.grad
     split = wrapped.split
     assert 0 < split < g.numel() and m.params.offsets['dec.ln.gamma'][0] == split

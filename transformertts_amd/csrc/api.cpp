@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/ttsmi.h"
 
 static thread_local char g_err[512] = "";
@@ -15,6 +17,15 @@ void ttsmi_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// cross-stream hand-off riding on a kernel's completion signal (csrc/common.h: TTSMI_LAUNCH_EV)
+static thread_local hipEvent_t g_stop_event = nullptr;
+void ttsmi_arm_stop_event(hipEvent_t e) { g_stop_event = e; }
+hipEvent_t ttsmi_take_stop_event() {
+    hipEvent_t e = g_stop_event;
+    g_stop_event = nullptr;
+    return e;
 }
 
 extern "C" {

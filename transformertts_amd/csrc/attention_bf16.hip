@@ -860,13 +860,13 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
         ttsmi_note_kernel(qh ? ((p).thr && (p).dmask ? #KERNEL "<" #DHV ", 2, true>" : (p).thr ? #KERNEL "<" #DHV ", 1, true>" : #KERNEL "<" #DHV ", 0, true>") \
                              : ((p).thr && (p).dmask ? #KERNEL "<" #DHV ", 2, false>" : (p).thr ? #KERNEL "<" #DHV ", 1, false>" : #KERNEL "<" #DHV ", 0, false>")); \
         if (qh) {                                                                              \
-            if ((p).thr && (p).dmask) hipLaunchKernelGGL((KERNEL<DHV, 2, true>), grid, dim3(256), pad_lds, st, p); \
-            else if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, true>), grid, dim3(256), pad_lds, st, p);  \
-            else hipLaunchKernelGGL((KERNEL<DHV, 0, true>), grid, dim3(256), pad_lds, st, p);          \
+            if ((p).thr && (p).dmask) TTSMI_LAUNCH_EV((KERNEL<DHV, 2, true>), grid, dim3(256), pad_lds, st, p); \
+            else if ((p).thr) TTSMI_LAUNCH_EV((KERNEL<DHV, 1, true>), grid, dim3(256), pad_lds, st, p);  \
+            else TTSMI_LAUNCH_EV((KERNEL<DHV, 0, true>), grid, dim3(256), pad_lds, st, p);          \
         } else {                                                                               \
-            if ((p).thr && (p).dmask) hipLaunchKernelGGL((KERNEL<DHV, 2, false>), grid, dim3(256), pad_lds, st, p); \
-            else if ((p).thr) hipLaunchKernelGGL((KERNEL<DHV, 1, false>), grid, dim3(256), pad_lds, st, p);  \
-            else hipLaunchKernelGGL((KERNEL<DHV, 0, false>), grid, dim3(256), pad_lds, st, p);         \
+            if ((p).thr && (p).dmask) TTSMI_LAUNCH_EV((KERNEL<DHV, 2, false>), grid, dim3(256), pad_lds, st, p); \
+            else if ((p).thr) TTSMI_LAUNCH_EV((KERNEL<DHV, 1, false>), grid, dim3(256), pad_lds, st, p);  \
+            else TTSMI_LAUNCH_EV((KERNEL<DHV, 0, false>), grid, dim3(256), pad_lds, st, p);         \
         }                                                                                      \
     } while (0)
 
@@ -1121,10 +1121,12 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     // forward 4 / 3 workgroups per CU = 69.0 / 86.9 us, dQ+dKV with dQ at 3 / 2 / 1 = 189.7 / 193.5 / 243.3 us - every
     // kernel here wants all the waves its registers allow.
     TTSMI_KNOB(dq_pad, "TTSMI_ATTN_DQ_LDS", 0);
+    hipEvent_t armed = ttsmi_take_stop_event();          // a hand-off event belongs to the LAST kernel of this entry point
     HDISPATCH_LDS(dh, hattn_bwd_dq_kernel, grid, dq_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dq(bf16)");
     dim3 grid_kv(grid.x, dh > 64 ? dh / 64 : 1);
     TTSMI_KNOB(dkv_pad, "TTSMI_ATTN_DKV_LDS", 0);
+    ttsmi_arm_stop_event(armed);
     HDISPATCH_LDS(dh, hattn_bwd_dkv_kernel, grid_kv, dkv_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dkv(bf16)");
     return TTSMI_OK;

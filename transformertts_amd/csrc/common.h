@@ -34,6 +34,22 @@ void ttsmi_set_error(const char* fmt, ...);
 // benchmark launches.
 void ttsmi_note_kernel(const char* name);
 
+// Cross-stream hand-off WITHOUT a marker packet.  hipEventRecord between two kernels of a stream costs the stream ~5 us
+// (tools/probes/event_gap_probe.hip: 34.6 us per 29.6 us kernel with record + wait, 30.8 us when the event rides on the
+// producing kernel's own completion signal); the dense block's backward hands four tensors per block to the
+// weight-gradient stream.  The block launcher ARMS the event (thread-local), the launcher of the producing entry point's
+// LAST kernel takes it and launches through hipExtLaunchKernelGGL(..., stopEvent); an event nobody took is recorded the
+// ordinary way by the block launcher.
+#include <hip/hip_ext.h>
+void ttsmi_arm_stop_event(hipEvent_t e);
+hipEvent_t ttsmi_take_stop_event();
+#define TTSMI_LAUNCH_EV(kernel, grid, block, lds, st, ...)                                                     \
+    do {                                                                                                       \
+        hipEvent_t ev__ = ttsmi_take_stop_event();                                                             \
+        if (ev__) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, nullptr, ev__, 0, __VA_ARGS__);          \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                    \
+    } while (0)
+
 static inline int ttsmi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- tuning knobs ------------------------------------------------------------------------------

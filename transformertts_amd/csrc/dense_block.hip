@@ -42,6 +42,27 @@ static int check_desc(const ttsmi_dense_block* D, const char* who) {
     return TTSMI_OK;
 }
 
+// TTSMI_WGRAD_KERNEL_EVENTS=0 (A/B knob): every hand-off to the weight-gradient stream is a hipEventRecord marker again
+static bool kernel_events() {
+    TTSMI_KNOB(on, "TTSMI_WGRAD_KERNEL_EVENTS", 1);
+    return on != 0;
+}
+// arm hand-off `ev` of block D before the entry point whose last kernel produces the tensor handed over
+static thread_local hipEvent_t t_armed = nullptr, t_prerecorded = nullptr;
+// (a stream that is being captured into a hipGraph takes the ordinary event record: the graph's cross-stream edge is
+// built from hipEventRecord / hipStreamWaitEvent pairs, a kernel's stop event is not captured as a dependency)
+static thread_local bool t_capturing = false;
+static void note_capture(const ttsmi_dense_block* D) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    t_capturing = hipStreamIsCapturing((hipStream_t)D->main_stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+}
+static void arm(const ttsmi_dense_block* D, int ev) {
+    if (D->side_stream && kernel_events() && !t_capturing) {
+        t_armed = (hipEvent_t)D->ev[ev];
+        ttsmi_arm_stop_event(t_armed);
+    }
+}
+
 extern "C" {
 
 int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf) {
@@ -124,7 +145,17 @@ static int wgrad_side(const ttsmi_dense_block* D, WgradBatch* wb, int ev, bool r
     if (D->side_stream && record) {
         hipEvent_t e = (hipEvent_t)D->ev[ev];
         TTSMI_CHECK_ARG(e, "dense_block_bwd: null event");
-        if (hipEventRecord(e, main_st) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) {
+        // the producing entry point may have taken the armed event onto its last kernel (TTSMI_LAUNCH_EV): then it is
+        // already recorded; an event still armed was not taken and is recorded the ordinary way
+        bool recorded = false;
+        if (t_prerecorded == e) {                // (recorded by the block above, on the kernel that produced df)
+            recorded = true;
+            t_prerecorded = nullptr;
+        } else if (t_armed == e) {
+            recorded = ttsmi_take_stop_event() != e;
+            t_armed = nullptr;
+        }
+        if ((!recorded && hipEventRecord(e, main_st) != hipSuccess) || hipStreamWaitEvent(st, e, 0) != hipSuccess) {
             ttsmi_set_error("dense_block_bwd: event hand-off to the weight-gradient stream failed");
             return TTSMI_ERR_LAUNCH;
         }
@@ -153,6 +184,7 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     const int M = D->B * D->T, d = D->d, F = D->F, dh = d / D->H;
     ttsmi_stream_t st = D->main_stream;
     const bool dropout = D->rate > 0.f;
+    note_capture(D);
     WgradBatch wb;
     wb.n = 0;
     wb.used = 0;
@@ -165,6 +197,7 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         if (!D->ln2_done) {         // (chained: the block above already left df / da / the parameter partials)
             TTSMI_CHECK_ARG(dout, "dense_block_bwd: null dout");
             OBS("ttsmi_layernorm_bwd_xhat", 0.0, (double)M * d * (4 + 2 + 2 + 4), st);
+            if (!lazy) arm(D, 0);
             TRY(ttsmi_layernorm_bwd_xhat(dout, D->xhat2, D->rstd2, D->ln2_g, D->pad, D->rate, D->site_ln2, D->seed, D->step_dev,
                                          D->df, D->da, D->lnp_ws2, D->lnp_ws2_bytes, M, d, st));
         }
@@ -174,6 +207,7 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
                                     nullptr, nullptr, M, d, D->ln_ws2, D->ln_ws_bytes, D->df, st));
     if (!lazy) TRY(wgrad_side(D, &wb, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
     { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false, (double)M * F * 2), st);
+      arm(D, 1);
       TRY(ttsmi_hgemm_tn(D->df, 0, d, nullptr, 0, 0, D->w2_b, d, nullptr, (const float*)D->h1, F, D->dh1, F, M, F, d,
                          TTSMI_GEMM_OUT_BF16 | TTSMI_GEMM_MASK_BF16, 1, 0, 0, 0, st)); }               // relu' fused
     if (lazy) TRY(wgrad_side(D, &wb, 1, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
@@ -181,6 +215,7 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     if (D->fuse_ln) {
         // (da + dh1.W1^T) never reaches HBM: res-norm 1's backward runs in the dgrad's epilogue -> d_o (bf16), dh (fp32)
         OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * F, gemm_bytes(M, d, F, 4, true, (double)M * d * (2 + 2)), st);
+        if (!lazy) arm(D, 2);
         TRY(ttsmi_hgemm_ln_bwd(D->dh1, F, D->w1_b, F, D->da, D->xhat1, D->rstd1, D->ln1_g, D->pad, D->rate, D->site_ln1,
                                D->seed, D->step_dev, D->d_o, D->dh, D->lnp_ws1, D->lnp_ws1_bytes, M, d, F, st));
     } else {
@@ -213,6 +248,7 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     {
     const double T2 = (double)D->T * D->T;
     OBS("ttsmi_attention_bwd", 8.0 * D->B * D->H * T2 * dh, (double)M * 3 * d * 2 * 3 + (double)M * d * 2 * 3 + 16.0 * D->B * D->H * D->T, st);
+    arm(D, 3);
     if (D->dropmask && dropout)
         TRY(ttsmi_attention_bwd_masked(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh,
                                        D->rate, D->dropmask, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));
@@ -232,6 +268,22 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         TTSMI_CHECK_ARG(L->fuse_ln && L->ln2_done && L->B == D->B && L->T == D->T && L->d == d,
                         "dense_block_bwd: `below` is not a chained block of the same shape");
         OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * 3 * d, gemm_bytes(M, d, 3 * d, 4, true, (double)M * d * (2 + 2)), st);
+        // this launch produces the lower block's df: its hand-off 0 rides on this kernel (recorded here either way, so
+        // the lower block only waits)
+        if (L->side_stream && kernel_events() && !lazy && !t_capturing) {
+            arm(L, 0);
+            const int rc_ = ttsmi_hgemm_ln_bwd(D->dqkv, 3L * d, D->wqkv_b, 3L * d, D->dh, L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate,
+                                               L->site_ln2, L->seed, L->step_dev, L->df, L->da, L->lnp_ws2, L->lnp_ws2_bytes, M, d, 3 * d, st);
+            hipEvent_t left = ttsmi_take_stop_event();
+            t_armed = nullptr;
+            if (rc_) return rc_;
+            if (left && hipEventRecord(left, (hipStream_t)st) != hipSuccess) {
+                ttsmi_set_error("dense_block_bwd: event record failed");
+                return TTSMI_ERR_LAUNCH;
+            }
+            t_prerecorded = (hipEvent_t)L->ev[0];
+            return TTSMI_OK;
+        }
         TRY(ttsmi_hgemm_ln_bwd(D->dqkv, 3L * d, D->wqkv_b, 3L * d, D->dh, L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate,
                                L->site_ln2, L->seed, L->step_dev, L->df, L->da, L->lnp_ws2, L->lnp_ws2_bytes, M, d, 3 * d, st));
         return TTSMI_OK;

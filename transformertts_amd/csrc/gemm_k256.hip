@@ -446,16 +446,16 @@ int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, lon
         p.ablate = ablate;
         dim3 gridw(p.nchunks * p.ngroups);
         ttsmi_note_kernel(mask ? "gemm_k256_wide_kernel<2>" : "gemm_k256_wide_kernel<1>");
-        if (mask) hipLaunchKernelGGL((gemm_k256_wide_kernel<2>), gridw, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((gemm_k256_wide_kernel<1>), gridw, dim3(512), 0, st, p);
+        if (mask) TTSMI_LAUNCH_EV((gemm_k256_wide_kernel<2>), gridw, dim3(512), 0, st, p);
+        else TTSMI_LAUNCH_EV((gemm_k256_wide_kernel<1>), gridw, dim3(512), 0, st, p);
         return 0;
     }
     kw_plan(p);
     dim3 grid(p.nchunks * p.ngroups);
     ttsmi_note_kernel(mask ? "gemm_k256_kernel<2>" : out_bf16 ? "gemm_k256_kernel<1>" : "gemm_k256_kernel<0>");
-    if (mask) hipLaunchKernelGGL((gemm_k256_kernel<2>), grid, dim3(512), 0, st, p);
-    else if (out_bf16) hipLaunchKernelGGL((gemm_k256_kernel<1>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((gemm_k256_kernel<0>), grid, dim3(512), 0, st, p);
+    if (mask) TTSMI_LAUNCH_EV((gemm_k256_kernel<2>), grid, dim3(512), 0, st, p);
+    else if (out_bf16) TTSMI_LAUNCH_EV((gemm_k256_kernel<1>), grid, dim3(512), 0, st, p);
+    else TTSMI_LAUNCH_EV((gemm_k256_kernel<0>), grid, dim3(512), 0, st, p);
     return 0;
 }
 
@@ -472,7 +472,7 @@ extern "C" int ttsmi_hgemm_k256_split(const void* a, int64_t lda, const uint16_t
     p.C2 = c_bf16; p.ldc2 = ldc_bf16; p.n_acc = n_acc;
     kw_plan(p);
     ttsmi_note_kernel("gemm_k256_kernel<3>");
-    hipLaunchKernelGGL((gemm_k256_kernel<3>), dim3(p.nchunks * p.ngroups), dim3(512), 0, (hipStream_t)stream, p);
+    TTSMI_LAUNCH_EV((gemm_k256_kernel<3>), dim3(p.nchunks * p.ngroups), dim3(512), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("hgemm_k256_split");
     return TTSMI_OK;
 }

@@ -543,10 +543,10 @@ int ttsmi_hgemm_ln_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64
     rg_drop(p, p_in, site_in, seed, step_dev);
     if (rg_use_dma(M)) {
         ttsmi_note_kernel(rg_dma_bm(M) == 64 ? "rowgemm_dma_kernel<0, 64>" : "rowgemm_dma_kernel<0, 128>");
-        if (rg_dma_bm(M) == 64) hipLaunchKernelGGL((rowgemm_dma_kernel<0, 64>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((rowgemm_dma_kernel<0, RD_BM>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
+        if (rg_dma_bm(M) == 64) TTSMI_LAUNCH_EV((rowgemm_dma_kernel<0, 64>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
+        else TTSMI_LAUNCH_EV((rowgemm_dma_kernel<0, RD_BM>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
     }
-    else { ttsmi_note_kernel("rowgemm_kernel<0>"); hipLaunchKernelGGL((rowgemm_kernel<0>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p); }
+    else { ttsmi_note_kernel("rowgemm_kernel<0>"); TTSMI_LAUNCH_EV((rowgemm_kernel<0>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p); }
     TTSMI_CHECK_LAUNCH("hgemm_ln_fwd");
     return TTSMI_OK;
 }
@@ -570,10 +570,10 @@ int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64
     rg_drop(p, p_in, site_in, seed, step_dev);
     if (rg_use_dma(M)) {
         ttsmi_note_kernel(rg_dma_bm(M) == 64 ? "rowgemm_dma_kernel<1, 64>" : "rowgemm_dma_kernel<1, 128>");
-        if (rg_dma_bm(M) == 64) hipLaunchKernelGGL((rowgemm_dma_kernel<1, 64>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((rowgemm_dma_kernel<1, RD_BM>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
+        if (rg_dma_bm(M) == 64) TTSMI_LAUNCH_EV((rowgemm_dma_kernel<1, 64>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
+        else TTSMI_LAUNCH_EV((rowgemm_dma_kernel<1, RD_BM>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
     }
-    else { ttsmi_note_kernel("rowgemm_kernel<1>"); hipLaunchKernelGGL((rowgemm_kernel<1>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p); }
+    else { ttsmi_note_kernel("rowgemm_kernel<1>"); TTSMI_LAUNCH_EV((rowgemm_kernel<1>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p); }
     TTSMI_CHECK_LAUNCH("hgemm_ln_bwd");
     return TTSMI_OK;
 }
@@ -593,7 +593,7 @@ int ttsmi_layernorm_bwd_xhat(const float* dy, const uint16_t* xhat_bf16, const f
     p.M = M; p.xhat_in = xhat_bf16; p.rstd_in = rstd; p.gamma = gamma; p.row_pad = row_pad;
     p.dx_bf = dx_bf16; p.dres = dres; p.part = (float*)part_ws;
     rg_drop(p, p_in, site_in, seed, step_dev);
-    hipLaunchKernelGGL(ln_bwd_xhat_kernel, dim3(p.nparts), dim3(256), 0, (hipStream_t)stream, p, dy);
+    TTSMI_LAUNCH_EV(ln_bwd_xhat_kernel, dim3(p.nparts), dim3(256), 0, (hipStream_t)stream, p, dy);
     TTSMI_CHECK_LAUNCH("layernorm_bwd_xhat");
     return TTSMI_OK;
 }

@@ -34,6 +34,7 @@ from ..utils.losses import masked_mean_absolute_error, weighted_sum_losses
 from .transformer_utils import positional_encoding
 
 
+_PRED_LATE = os.environ.get('TTSMI_PRED_LATE', '1') != '0'      # A/B knob: 0 = predictors issued before the decoder (round 2)
 _DROPBITS_CONV = os.environ.get('TTSMI_ATTN_DROPBITS_CONV', '0') == '1'
 
 
@@ -205,7 +206,7 @@ class ForwardTransformer:
         self.use_graph = bool(kwargs.get('use_graph', False))          # replay train_step from hipGraphs
         self.fused_blocks = bool(kwargs.get('fused_blocks', True))     # one autograd node per dense block
         self.overlap_predictors = bool(kwargs.get('overlap_predictors', True))   # StatPredictors on a side stream
-        self._pred_stream, self._pred_pending, self._pred_keep = None, False, None
+        self._pred_stream, self._pred_pending, self._pred_keep, self._deferred_pred = None, False, None, None
         self._dropmask_plan, self._dropmask_bufs = {}, {}
         # blocks driven from C++ with persistent buffers (ops.DenseBlockPlan); only inside _forward_backward, where one
         # forward is followed by its backward before the next forward reuses the buffers
@@ -526,6 +527,9 @@ class ForwardTransformer:
             # like the reference's eager call)
             mel_len = max(int(a['total'].max().item()), 1)
         b = self._call_back(a['h'], a['use'], mel_len, training, want_attn)
+        if self._deferred_pred is not None:          # teacher-forced training: the predictors, issued after the decoder
+            a['duration'], a['pitch'] = self._deferred_pred()
+            self._deferred_pred = None
         return {'mel': b['mel'], 'duration': a['duration'], 'pitch': a['pitch'], 'expanded_mask': b['expanded_mask'],
                 'encoder_attention': a['encoder_attention'], 'decoder_attention': b['decoder_attention'],
                 'expanded_lengths': b['expanded_lengths']}
@@ -553,6 +557,7 @@ class ForwardTransformer:
         # (only from _forward_backward, which owns the joins: before the losses, and again after backward)
         overlap_pred = (_overlap_predictors and self.overlap_predictors and target_durations is not None
                         and target_pitch is not None)
+        self._deferred_pred = None
         if overlap_pred:
             main = torch.cuda.current_stream()
             if self._pred_stream is None:
@@ -560,10 +565,36 @@ class ForwardTransformer:
             side = self._pred_stream
             side.wait_stream(main)                       # the encoder output is complete in main-stream order
             self._pred_keep = [h, pad_e]                 # the side stream reads them: alive until the join
-            with torch.cuda.stream(side), ops.pin_stream(side.cuda_stream):
-                durations = self._stat_predictor('dur', h, pad_e, len(c['duration_conv_filters']), True, prate)
-                pitch = self._stat_predictor('pitch', h, pad_e, len(c['pitch_conv_filters']), False, prate)
-            self._pred_pending = True
+            n_dur, n_pit = len(c['duration_conv_filters']), len(c['pitch_conv_filters'])
+
+            def run_predictors(h=h, pad_e=pad_e):
+                with torch.cuda.stream(side), ops.pin_stream(side.cuda_stream):
+                    hb = ops.BranchFn.apply(h) if h.requires_grad else h      # one gradient edge, summed on the side stream
+                    d_ = self._stat_predictor('dur', hb, pad_e, n_dur, True, prate)
+                    p_ = self._stat_predictor('pitch', hb, pad_e, n_pit, False, prate)
+                self._pred_pending = True
+                return d_, p_
+            if _PRED_LATE:
+                # ISSUED after the decoder (call() runs the closure once _call_back has enqueued it): the autograd engine
+                # replays nodes newest-first, so the predictors' backward - ~60 small launches on the side stream - is then
+                # issued at the START of the backward pass and hides under the decoder's, instead of starting when the
+                # decoder's backward is nearly done and leaving the main stream ~0.25 ms idle at the encoder boundary,
+                # where d(encoder output) needs all three of its consumers (kernel trace).  The
+                # dropout sites keep their numbers: they are reserved here and restored for the deferred call.
+                site0 = self.drop._site
+                self.drop._site += n_dur + n_pit
+
+                def deferred():
+                    keep = self.drop._site
+                    self.drop._site = site0
+                    try:
+                        return run_predictors()
+                    finally:
+                        self.drop._site = keep
+                self._deferred_pred = deferred
+                durations = pitch = None
+            else:
+                durations, pitch = run_predictors()
         else:
             durations = self._stat_predictor('dur', h, pad_e, len(c['duration_conv_filters']), True, prate)
             pitch = self._stat_predictor('pitch', h, pad_e, len(c['pitch_conv_filters']), False, prate)

@@ -1020,6 +1020,22 @@ class RowMaskFn(torch.autograd.Function):
         return dx, None
 
 
+class BranchFn(torch.autograd.Function):
+    """Identity that gives a side-stream branch ONE gradient edge back to the tensor it forks from.  Called inside the
+    side stream's context, its backward node belongs to that stream, so the gradients of the branch's several consumers
+    (the two StatPredictors) are summed there; without it autograd sums them on the stream of the tensor's PRODUCER'S
+    consumer - the main stream, which then has to wait for the whole side chain at the moment the second gradient
+    arrives (before the decoder's backward has been issued when the branch's backward is replayed first)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 def wgrad_stream():
     """The side stream the weight gradients run on (None until the first overlapped launch)."""
     W = _WgradStream.cur()
