@@ -290,6 +290,38 @@ def test_dropout_training_step_is_finite_and_reproducible(tiny):
     assert abs(outs[0][0] - l0) / l0 < 0.2         # dropout perturbs, does not destroy, the loss
 
 
+def test_variable_batch_shapes_reuse_capacity_plans(tiny):
+    """Length-bucketed training data brings a new (B, Tp, Tm) almost every step: the C++-driven dense blocks keep ONE
+    plan per block sized for the largest batch so far and re-bind it (ops.DenseBlockPlan.rebind) - results equal a
+    model that builds everything per step (planned_blocks=False), the plan / keep-bit caches stay bounded, a smaller
+    batch allocates nothing, a larger one rebuilds the stack once, and predict()'s forward-only plans do not disturb
+    the training plans."""
+    cfg, W = tiny
+    shapes = [(4, 50, 200), (2, 33, 120), (3, 41, 160), (6, 50, 230), (4, 50, 200), (1, 7, 40)]
+    batches = [fo.synthetic_batch(*sh, seed=40 + i, ragged=True) for i, sh in enumerate(shapes)]
+    kw = dict(dropout_rate=0.1, predictors_dropout=0.1, seed=9, precision='bf16')
+    a = _model(cfg, W, **kw)
+    b = _model(cfg, W, planned_blocks=False, **kw)
+    for m in (a, b):
+        m._compile(learning_rate=1e-3)
+    n_blocks = len(cfg['encoder_num_heads']) + len(cfg['decoder_num_heads'])
+    caps = []
+    for i, batch in enumerate(batches):
+        la, lb = float(a.train_step(*batch)['loss']), float(b.train_step(*batch)['loss'])
+        assert abs(la - lb) <= 1e-5 * abs(lb), (i, la, lb)
+        assert len(a._plans) == n_blocks and len(a._dropmask_bufs) <= n_blocks
+        caps.append({k: pl.cap for k, pl in a._plans.items()})
+        if i == 2:                                                   # forward-only plans are a separate set
+            mel = a.predict(batch[0][:1], encode=False)['mel']
+            assert torch.isfinite(mel).all() and len(a._plans) == 2 * n_blocks
+            for k in [k for k in a._plans if k[1] == 'fwd']:
+                del a._plans[k]
+    assert caps[1] == caps[0] and caps[2] == caps[0]                 # smaller batches: the same buffers
+    assert all(caps[3][k] > caps[0][k] for k in caps[0])             # 6 x 230 rows needed a bigger decoder / encoder stack
+    assert caps[4] == caps[3] and caps[5] == caps[3]
+    torch.testing.assert_close(a.params.data, b.params.data, rtol=0, atol=2e-6)
+
+
 def test_benchmark_shape_training_is_bit_reproducible():
     """Two models from the same seed, 25 bf16 train steps each at the BASELINE configs[1] shape (dropout on,
     weight gradients on the second stream): bit-identical parameters, finite loss.  Guards the cross-stream

@@ -15,7 +15,9 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32, c_uint
 import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libttsmi.so')
+# TTSMI_LIB (measurement only): another build of the same library, for same-box A/Bs of a source change
+# (tools/kbench.py --variants base TTSMI_LIB=<path>); the product and the tests always load the in-tree build
+LIB_PATH = os.environ.get('TTSMI_LIB') or os.path.join(_HERE, 'lib', 'libttsmi.so')
 
 P = c_void_p          # every device pointer
 I = c_int

@@ -218,7 +218,7 @@ class ForwardTransformer:
         self.fuse_ln = bool(kwargs.get('fuse_ln', True))               # res-norms in the GEMM epilogues (d_model 256)
         # consecutive planned blocks: the upper block's last dgrad runs the lower block's res-norm-2 backward in its epilogue
         self.chain_ln = bool(kwargs.get('chain_ln', True)) and os.environ.get('TTSMI_LN_CHAIN', '1') != '0'
-        self._use_plans, self._plans, self._plan_shared = False, {}, {}
+        self._use_plans, self._plans, self._plan_shared, self._plans_grown = False, {}, {}, {}
         self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
@@ -460,28 +460,32 @@ class ForwardTransformer:
                 and all(f'{p}.{k}' in self.shadow for k in ('wqkv', 'wo', 'ffn.w1', 'ffn.w2')))
 
     def _block_plan(self, p, prefix, B, H, T):
-        """ops.DenseBlockPlan of block `p` at this batch shape (built on first use; at most 3 shapes are kept)."""
+        """ops.DenseBlockPlan of block `p`, re-targeted at this batch shape.  One plan per block and mode (training /
+        forward-only) sized for the largest row count seen so far: a new (B, T) only re-binds it.  When a batch needs
+        more rows than the capacity the whole stack's plans are rebuilt (after a device synchronisation: nothing in
+        flight reads the dropped buffers; captured graphs keep the plans they baked in alive themselves)."""
         backward = torch.is_grad_enabled()
-        key = (p, B, T) if backward else (p, B, T, 'fwd')
+        key = (p, 'bwd' if backward else 'fwd')
         plan = self._plans.get(key)
+        M = B * T
+        if plan is not None and plan.cap < M:
+            torch.cuda.synchronize()
+            for k in [k for k in self._plans if k[0].startswith(prefix + '.') and k[1] == key[1]]:
+                del self._plans[k]
+            self._plan_shared.get((prefix, key[1]), {}).clear()
+            plan = None
         if plan is None:
-            shapes = []
-            for k in self._plans:
-                b, t = k[1], k[2]
-                if (b, t) not in shapes:
-                    shapes.append((b, t))
-            if (B, T) not in shapes and len(shapes) >= 6:          # 3 batch shapes x (encoder T, decoder T)
-                torch.cuda.synchronize()                           # nothing in flight reads the evicted buffers
-                old = shapes[0]
-                for k in [k for k in self._plans if (k[1], k[2]) == old]:
-                    del self._plans[k]
-                for sh in self._plan_shared.values():
-                    for k in [k for k in sh if (k[0], k[2]) == old]:
-                        del sh[k]
             Pb, Gb, Sb = self._block_views(p)
+            # every block of a stack gets the same capacity (the first one to be built decides; a little headroom so
+            # that a slowly growing maximum does not rebuild the stack every few steps)
+            cap = max([pl.cap for k, pl in self._plans.items() if k[0].startswith(prefix + '.') and k[1] == key[1]] +
+                      [M if not self._plans_grown.get((prefix, key[1])) else (M * 9 + 7) // 8])
+            self._plans_grown[(prefix, key[1])] = True
             plan = self._plans[key] = ops.DenseBlockPlan(Pb, Gb, Sb, B, H, T, self.device,
-                                                         self._plan_shared.setdefault(prefix, {}), self.fuse_ln,
-                                                         backward=backward)
+                                                         self._plan_shared.setdefault((prefix, key[1]), {}), self.fuse_ln,
+                                                         backward=backward, cap_rows=cap)
+        else:
+            plan.rebind(B, T)
         return plan
 
     _BLOCK_KEYS = ('wqkv', 'bqkv', 'wo', 'bo', 'ln1.gamma', 'ln1.beta', 'ffn.w1', 'ffn.b1', 'ffn.w2', 'ffn.b2',
@@ -675,11 +679,14 @@ class ForwardTransformer:
                 for name, H, T, st in plans:
                     if not name.startswith(prefix):
                         continue
-                    key = (name, B, H, T)
-                    buf = self._dropmask_bufs.get(key)
-                    if buf is None:
-                        buf = self._dropmask_bufs[key] = torch.empty(int(l.ttsmi_attention_dropmask_bytes(B, H, T)),
-                                                                     dtype=torch.uint8, device=self.device)
+                    # one table per block, sized for the largest (B, H, T) seen: a smaller shape uses a prefix (length-
+                    # bucketed data brings a new shape almost every step - a table per exact shape grew without bound)
+                    need = int(l.ttsmi_attention_dropmask_bytes(B, H, T))
+                    buf = self._dropmask_bufs.get(name)
+                    if buf is None or buf.numel() < need:
+                        # (the old table may still be read by the previous step: it is freed in stream order on the side
+                        # stream that wrote it, and captured graphs pin their own, see _train_step_graphed)
+                        buf = self._dropmask_bufs[name] = torch.empty(need, dtype=torch.uint8, device=self.device)
                     ops.attention_dropmask(B, H, T, rate, self.drop, st, self.device, out=buf)
                     if ev is None:
                         ev = torch.cuda.Event()
@@ -792,6 +799,9 @@ class ForwardTransformer:
             st['opt'] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(st['opt'], pool=st['fb'].pool()):
                 self._apply_gradients()
+            # the captured launches hold raw pointers into the plans' and the keep-bit tables' buffers: the graph keeps
+            # them alive whatever the model's own caches do later (growth replaces a plan, it never frees under a graph)
+            st['pinned'] = (list(self._plans.values()), list(self._dropmask_bufs.values()))
         for dst, src in zip(st['in'], (x, ts, td, tp)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
@@ -930,6 +940,7 @@ class ForwardTransformer:
                 A['graph'] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(A['graph']):
                     A['out'] = run()
+            A['plans'] = list(self._plans.values())          # the encoder plans' buffers are baked into graph A
             self._infer_graphs[keyA] = A
             while len(self._infer_graphs) > max(1, int(self.GRAPH_CACHE_SHAPES)):
                 torch.cuda.synchronize()                     # no replay in flight still reads the dropped buffers
@@ -955,7 +966,7 @@ class ForwardTransformer:
                 Bg = {'graph': torch.cuda.CUDAGraph()}
                 with torch.cuda.graph(Bg['graph'], pool=A['graph'].pool()):
                     Bg['out'] = run()
-            Bg['plans'] = [pl for k, pl in self._plans.items() if k[1] == B]     # their buffers are baked into the graphs
+            Bg['plans'] = list(self._plans.values())     # their buffers are baked into the graphs: alive as long as the graph
             A['B'][bucket] = Bg
         Bg['graph'].replay()
         b = Bg['out']
@@ -971,10 +982,12 @@ class ForwardTransformer:
         the token ids (three copies and three host waits per call otherwise - 0.25 ms of a 1.2 ms batch-1 predict)."""
         if not per_symbol:
             key = (tuple(encoded_text.shape), fill)
-            m = self._const_masks.get(key)
+            m = self._const_masks.pop(key, None)
             if m is None:
-                m = self._const_masks[key] = torch.full(tuple(encoded_text.shape), fill, dtype=torch.float32,
-                                                        device=self.device)
+                m = torch.full(tuple(encoded_text.shape), fill, dtype=torch.float32, device=self.device)
+                while len(self._const_masks) >= 32:              # bounded: least recently used shape goes
+                    self._const_masks.pop(next(iter(self._const_masks)))
+            self._const_masks[key] = m                           # most recently used last
             return m
         np_text = encoded_text.cpu().numpy()
         new_mask = np.full(np_text.shape, fill, dtype=np.float64)

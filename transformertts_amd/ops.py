@@ -1426,64 +1426,69 @@ FUSE_LN_MIN_ROWS_INFERENCE = int(os.environ.get('TTSMI_FUSE_LN_MIN_ROWS', '8192'
 
 
 class DenseBlockPlan:
-    """Persistent buffers + the filled `ttsmi_dense_block` descriptor of ONE dense block at ONE batch shape.
+    """Persistent buffers + the filled `ttsmi_dense_block` descriptor of ONE dense block, sized for a CAPACITY of rows.
 
     The per-launch Python path (DenseBlockFn) spends ~14 us of host time per kernel launch (allocator, ctypes
     argument conversion, autograd bookkeeping); at ~400 launches a step that is 6 ms of enqueueing for 5 ms of GPU
     work.  A plan owns every activation / temporary of its block, so the descriptor is filled once and a training
     step costs two ctypes calls per block (forward, backward) whose launches are issued from C++.
-    `shared` holds the buffers that blocks of one stack may share (nothing outside the main stream reads them)."""
+    `shared` holds the buffers that blocks of one stack may share (nothing outside the main stream reads them).
 
-    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True, backward=True):
+    Every buffer is a row-major [rows, C] matrix (or a flat per-row vector), so a batch with fewer rows than the
+    capacity uses a prefix of it: `rebind(B, T)` re-targets the plan at a new batch shape without allocating - with
+    length-bucketed training data almost every batch has its own (B, Tp, Tm), and a plan per exact shape meant a
+    device synchronisation plus ~30 allocations per block on almost every step (round-2 advisor finding)."""
+
+    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True, backward=True, cap_rows=0):
         """backward=False: a forward-only plan (inference) - the backward temporaries are not allocated."""
         l = _lib.lib()
         self.backward = bool(backward)
         d = P['wqkv'].shape[0]
         F = P['ffn.w1'].shape[1]
-        M = B * T
+        cap = self.cap = max(int(cap_rows), B * T)
         bf, f32 = torch.bfloat16, torch.float32
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
-        self.B, self.H, self.T, self.d, self.F, self.M = B, H, T, d, F, M
+        self.H, self.d, self.F = H, d, F
         self.t = t = {}
-        # LayerNorms fused into the GEMM epilogues (ttsmi_hgemm_ln_fwd / _bwd): needs the full row in one tile, so
-        # few, tall workgroups - at inference with few rows (batch 1: 2304 rows = 18..36 workgroups, 29 us against
-        # 9.5 + 5 us for GEMM + LayerNorm measured) the unfused pair is faster; training always fuses (the x-hat
-        # backward is where most of the gain is)
-        self.fuse_ln = bool(fuse_ln) and d == 256 and (backward or M >= FUSE_LN_MIN_ROWS_INFERENCE)
-        for name, shape, dt in (('qkv', (M, 3 * d), bf), ('cx', (M, d), bf), ('a_bf', (M, d), bf), ('h1', (M, F), bf),
-                                ('out_bf', (M, d), bf), ('lse', (B, H, T), f32), ('o', (M, d), f32), ('a', (M, d), f32),
-                                ('f', (M, d), f32), ('out', (M, d), f32), ('mean1', (M,), f32), ('rstd1', (M,), f32),
-                                ('mean2', (M,), f32), ('rstd2', (M,), f32),
+        self.want_fuse = bool(fuse_ln) and d == 256
+        for name, shape, dt in (('qkv', (cap, 3 * d), bf), ('cx', (cap, d), bf), ('a_bf', (cap, d), bf), ('h1', (cap, F), bf),
+                                ('out_bf', (cap, d), bf), ('lse', (cap * H,), f32), ('o', (cap, d), f32), ('a', (cap, d), f32),
+                                ('f', (cap, d), f32), ('out', (cap, d), f32), ('mean1', (cap,), f32), ('rstd1', (cap,), f32),
+                                ('mean2', (cap,), f32), ('rstd2', (cap,), f32),
                                 # read by the weight-gradient stream: private to the block
-                                ('df', (M, d), bf), ('dh1', (M, F), bf), ('d_o', (M, d), bf), ('dqkv', (M, 3 * d), bf),
-                                ('dh', (M, d), f32)):
-            unused = (not backward and name in ('df', 'dh1', 'd_o', 'dqkv', 'dh')) or (self.fuse_ln and not backward and
+                                ('df', (cap, d), bf), ('dh1', (cap, F), bf), ('d_o', (cap, d), bf), ('dqkv', (cap, 3 * d), bf),
+                                ('dh', (cap, d), f32)):
+            unused = (not backward and name in ('df', 'dh1', 'd_o', 'dqkv', 'dh')) or (self.want_fuse and backward and
                                                                                         name in ('o', 'f'))
             t[name] = e((8,) if unused else shape, dt)
-        ln_ws = int(l.ttsmi_add_layernorm_bwd_ws_bytes(M, d))
+        # workspaces at their largest over every row count <= cap (tile heights switch with the row count)
+        parts_cap = max((cap + 63) // 64 + 8, int(l.ttsmi_layernorm_bwd_xhat_nparts(cap)), int(l.ttsmi_hgemm_ln_bwd_nparts(cap)),
+                        int(l.ttsmi_add_layernorm_bwd_nparts(cap)))
+        ln_ws = int(max(l.ttsmi_add_layernorm_bwd_ws_bytes(cap, d), l.ttsmi_layernorm_partials_bytes(parts_cap, d)))
         t['ln_ws1'], t['ln_ws2'] = _ws(ln_ws, device), _ws(ln_ws, device)
-        self.lnp_nw1, self.lnp_nw2 = int(l.ttsmi_hgemm_ln_bwd_nparts(M)), int(l.ttsmi_layernorm_bwd_xhat_nparts(M))
-        if self.fuse_ln:
+        self.ln_ws_bytes = ln_ws
+        if self.want_fuse:
             for name in ('xhat1', 'xhat2'):
-                t[name] = e((M, d), bf)
-            t['lnp_ws1'] = _ws(l.ttsmi_layernorm_partials_bytes(self.lnp_nw1, d), device)
+                t[name] = e((cap, d), bf)
+            t['lnp_ws1'] = _ws(l.ttsmi_layernorm_partials_bytes(parts_cap, d), device)
             # (res-norm 2's partials come from ttsmi_layernorm_bwd_xhat, or - chained - from the GEMM epilogue of the block above)
-            t['lnp_ws2'] = _ws(l.ttsmi_layernorm_partials_bytes(max(self.lnp_nw1, self.lnp_nw2), d), device)
-        key = (B, H, T, d, self.backward)
-        if key not in shared:
-            shared[key] = ({'da': e((M, d), f32), 'dctx': e((M, d), bf),
-                            'attn_ws': _ws(l.ttsmi_attention_bwd_ws_bytes(B, H, T, d // H), device)} if backward else
-                           {'da': e((8,), f32), 'dctx': e((8,), bf),      # forward only: scratch of the split-key attention
-                            'attn_ws': _ws(max(256, int(l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, d // H))), device)})
+            t['lnp_ws2'] = _ws(l.ttsmi_layernorm_partials_bytes(parts_cap, d), device)
+        key = (H, d, self.backward)
+        if key not in shared or shared[key]['cap'] < cap:
+            # (the model drops a stack's plans together when one of them has to grow, so nobody holds the old entry)
+            shared[key] = ({'cap': cap, 'da': e((cap, d), f32), 'dctx': e((cap, d), bf),
+                            'attn_ws': _ws(4 * cap * H + 1024, device)} if backward else
+                           {'cap': cap, 'da': e((8,), f32), 'dctx': e((8,), bf),  # forward only: scratch of the split-key attention
+                            'attn_ws': None})
         sh = shared[key]
         self.shared = sh
-        self.wgrad_need = max(int(l.ttsmi_hgemm_wgrad_rows_ws_bytes(M, kin, n))
+        self.wgrad_need = max(int(l.ttsmi_hgemm_wgrad_rows_ws_bytes(cap, kin, n))
                               for kin, n in ((F, d), (d, F), (d, d), (d, 3 * d)))
         self.events = [torch.cuda.Event() for _ in range(4)]
         for ev in self.events:
             ev.record()                                   # materialises the hipEvent_t behind the torch object
         D = self.desc = _lib.DenseBlockDesc()
-        D.B, D.H, D.T, D.d, D.F = B, H, T, d, F
+        D.H, D.d, D.F = H, d, F
         for k, v in (('bqkv', P['bqkv']), ('bo', P['bo']), ('ln1_g', P['ln1.gamma']), ('ln1_b', P['ln1.beta']),
                      ('b1', P['ffn.b1']), ('b2', P['ffn.b2']), ('ln2_g', P['ln2.gamma']), ('ln2_b', P['ln2.beta']),
                      ('wqkv_t', S['wqkv'].wt), ('wo_t', S['wo'].wt), ('w1_t', S['ffn.w1'].wt), ('w2_t', S['ffn.w2'].wt),
@@ -1496,19 +1501,52 @@ class DenseBlockPlan:
         for k in ('qkv', 'cx', 'a_bf', 'h1', 'out_bf', 'lse', 'o', 'a', 'f', 'out', 'mean1', 'rstd1', 'mean2', 'rstd2',
                   'df', 'dh1', 'd_o', 'dqkv', 'dh', 'ln_ws1', 'ln_ws2'):
             setattr(D, k, t[k].data_ptr())
-        if self.fuse_ln:
-            D.fuse_ln, D.lnp_ws1_bytes, D.lnp_ws2_bytes = 1, t['lnp_ws1'].numel(), t['lnp_ws2'].numel()
+        if self.want_fuse:
+            D.lnp_ws1_bytes, D.lnp_ws2_bytes = t['lnp_ws1'].numel(), t['lnp_ws2'].numel()
             for k in ('xhat1', 'xhat2', 'lnp_ws1', 'lnp_ws2'):
                 setattr(D, k, t[k].data_ptr())
-        D.da, D.dctx, D.attn_ws = sh['da'].data_ptr(), sh['dctx'].data_ptr(), sh['attn_ws'].data_ptr()
-        D.attn_ws_bytes, D.ln_ws_bytes = sh['attn_ws'].numel(), ln_ws
-        D.attn_split = int(not backward and os.environ.get('TTSMI_ATTN_SPLIT', '1') != '0' and
-                           l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, d // H) > 0)
+        D.da, D.dctx = sh['da'].data_ptr(), sh['dctx'].data_ptr()
+        D.ln_ws_bytes = ln_ws
         for i, ev in enumerate(self.events):
             D.ev[i] = ev.cuda_event
         self.G = G
         self.above = None
         self._dref = ctypes.byref(D)
+        self.B = self.T = self.M = 0
+        self.rebind(B, T)
+
+    def rebind(self, B, T):
+        """Point the plan at a batch of B x T rows (<= the capacity): shape fields, the row-count dependent workgroup
+        counts and workspace sizes.  No allocation except the forward-only split-key scratch when it has to grow."""
+        if (B, T) == (self.B, self.T):
+            return
+        l = _lib.lib()
+        M = B * T
+        assert M <= self.cap, (B, T, self.cap)
+        H, d = self.H, self.d
+        D, sh = self.desc, self.shared
+        self.B, self.T, self.M = B, T, M
+        D.B, D.T = B, T
+        # LayerNorms fused into the GEMM epilogues (ttsmi_hgemm_ln_fwd / _bwd): needs the full row in one tile, so
+        # few, tall workgroups - at inference with few rows (batch 1: 2304 rows = 18..36 workgroups, 29 us against
+        # 9.5 + 5 us for GEMM + LayerNorm measured) the unfused pair is faster; training always fuses (the x-hat
+        # backward is where most of the gain is)
+        self.fuse_ln = self.want_fuse and (self.backward or M >= FUSE_LN_MIN_ROWS_INFERENCE)
+        D.fuse_ln = int(self.fuse_ln)
+        self.lnp_nw1, self.lnp_nw2 = int(l.ttsmi_hgemm_ln_bwd_nparts(M)), int(l.ttsmi_layernorm_bwd_xhat_nparts(M))
+        if self.backward:
+            need = int(l.ttsmi_attention_bwd_ws_bytes(B, H, T, d // H))
+            assert need <= sh['attn_ws'].numel(), (need, sh['attn_ws'].numel())
+        else:
+            need = max(256, int(l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, d // H)))
+            if sh['attn_ws'] is None or sh['attn_ws'].numel() < need:
+                sh['attn_ws'] = _ws(need, self.t['qkv'].device)       # (inference: the old scratch stays alive in captured graphs' plans)
+            self._attn_ws = sh['attn_ws']
+        D.attn_ws, D.attn_ws_bytes = sh['attn_ws'].data_ptr(), sh['attn_ws'].numel()
+        D.attn_split = int(not self.backward and os.environ.get('TTSMI_ATTN_SPLIT', '1') != '0' and
+                           l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, d // H) > 0)
+        if self.above is not None and (self.above.B, self.above.T) != (B, T):
+            self.chain_above(None)
 
     def chain_above(self, above):
         """`above` consumes this block's output and nothing else does: its backward finishes this block's res-norm-2
@@ -1580,7 +1618,8 @@ class PlannedDenseBlockFn(torch.autograd.Function):
     def forward(ctx, h, h_bf, plan):
         plan.fwd(h, h_bf)
         ctx.plan, ctx.h, ctx.h_bf = plan, h, h_bf
-        out, out_bf = plan.t['out'].detach(), plan.t['out_bf'].detach()       # fresh aliases of the persistent buffers
+        M = plan.M                                                              # fresh aliases of the persistent buffers' live rows
+        out, out_bf = plan.t['out'][:M].detach(), plan.t['out_bf'][:M].detach()
         ctx.mark_non_differentiable(out_bf)
         ctx.set_materialize_grads(False)
         return out, out_bf
@@ -1589,4 +1628,4 @@ class PlannedDenseBlockFn(torch.autograd.Function):
     def backward(ctx, dout, _dout_bf):
         plan = ctx.plan
         plan.bwd(ctx.h, ctx.h_bf, _c(dout))
-        return plan.t['dh'].detach(), None, None
+        return plan.t['dh'][:plan.M].detach(), None, None
