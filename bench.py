@@ -711,6 +711,22 @@ def main():
             'main_stream_launch_ms': sum(v[3] for k, v in groups.items() if not k.endswith(SIDE)),
             'side_stream_launch_ms': sum(v[3] for k, v in groups.items() if k.endswith(SIDE)),
         }
+        # SURVEY 8d names the MFMA roof for the STEP (a dense contraction): algorithmic matmul FLOPs of the whole step
+        # (entry points' 2 per MAC, no recompute) over the timed step, against the dense bf16 / fp32 MFMA peak
+        step_flops = sum(v[1] for v in groups.values())
+        peak_step = PEAK_BF16_MFMA_TFLOPS if args.precision == 'bf16' else PEAK_F32_MFMA_TFLOPS
+        result['roofline']['step_gflop'] = step_flops / 1e9
+        result['roofline']['step_tflops'] = step_flops / ms / 1e9
+        result['roofline']['step_mfma_frac'] = step_flops / ms / 1e9 / peak_step
+        # `kernel` above is the dominant family of the MAIN stream (the critical path).  The family with the most GPU
+        # time overall may be the weight gradients on the second stream, which run underneath it: reported as well
+        gdom, (gn, gfl, gby, gms_) = max(((k, v) for k, v in groups.items() if k.replace(SIDE, '') != RIDERS),
+                                         key=lambda kv: kv[1][3])
+        result['roofline']['dominant_by_gpu_time'] = {
+            'kernel': gdom, 'launches_per_step': gn, 'launch_ms_per_step': gms_, 'tflops': gfl / gms_ / 1e9,
+            'mfma_frac': gfl / gms_ / 1e9 / peak_of(gdom), 'gbs': gby / gms_ / 1e6, 'hbm_frac': gby / gms_ / 1e6 / PEAK_HBM_GBS,
+            'stream': 'weight-gradient side stream (overlaps the main stream)' if gdom.endswith(SIDE) else 'main',
+            'traffic': pmc_traffic(gdom) if args.precision == 'bf16' and args.workload == 'configs[1]' else None}
     elif world > 1 and not args.no_roofline:
         model.use_graph = False
         step()          # keep the collective count equal on every rank

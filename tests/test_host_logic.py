@@ -116,3 +116,42 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), os.path.join(dp, f)
+
+
+def test_phonemizer_adapter_uses_the_dependency_when_present_and_raises_without_it(monkeypatch):
+    """The reference's text entry point (data/text/tokenizer.py:50-104, data/text/__init__.py:18-21): with
+    `phonemizer` importable the adapter calls it with the reference's arguments and cleans the result; without it (this
+    image) a clear error, not an ImportError at module import."""
+    import sys
+    import types
+    from transformertts_amd.data.text import Phonemizer, TextToTokens
+    for name in ('phonemizer', 'phonemizer.phonemize'):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    tt = TextToTokens.default('en', True, True, True)
+    assert isinstance(tt.phonemizer, Phonemizer)
+    try:
+        import phonemizer  # noqa: F401
+        have = True
+    except ImportError:
+        have = False
+    if not have:
+        with pytest.raises(RuntimeError, match='phonemizer'):
+            tt('hello')
+    seen = {}
+
+    def fake(texts, **kw):
+        seen.update(kw, texts=list(texts))
+        return ['h ə l oʊ  ,  w ɜː l d — X 9 !'] * len(texts)
+    pkg, mod = types.ModuleType('phonemizer'), types.ModuleType('phonemizer.phonemize')
+    mod.phonemize = fake
+    monkeypatch.setitem(sys.modules, 'phonemizer', pkg)
+    monkeypatch.setitem(sys.modules, 'phonemizer.phonemize', mod)
+    ph = Phonemizer('en-us', with_stress=True, njobs=2)
+    assert ph('well-known, world!') == 'h ə l oʊ,w ɜː l d-!'          # unknown symbols dropped, spaces around marks gone
+    assert seen['texts'] == ['well—known, world!'] and seen['backend'] == 'espeak' and seen['language'] == 'en-us'
+    assert seen['with_stress'] is True and seen['njobs'] == 2 and seen['preserve_punctuation'] and seen['strip']
+    assert ph(['a', 'b']) == ['h ə l oʊ,w ɜː l d-!'] * 2
+    ids = tt('hello')
+    assert ids[0] == tt.tokenizer.start_token_index and ids[-1] == tt.tokenizer.end_token_index
+    with pytest.raises(TypeError):
+        ph(3)

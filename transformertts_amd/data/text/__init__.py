@@ -14,13 +14,17 @@ reference's callers read (data/text/tokenizer.py:9-47: alphabet, vocab_size, idx
 start/end/breathing_token_index); tests/test_reference_fixtures.py::test_tokenizer_equals_the_reference
 holds ids, decode() and vocab sizes to the reference's own tokenizer for every flag combination.
 
-Grapheme -> phoneme conversion (espeak through the third-party `phonemizer` package) is OUT OF SCOPE
-(SURVEY.md section 2): callers pass phoneme strings or token ids (`predict(..., encode=False)`)."""
+Grapheme -> phoneme conversion (espeak through the third-party `phonemizer` package) is OUT OF SCOPE as a
+component and neither dependency exists offline; `Phonemizer` is a thin adapter that keeps the
+reference's text entry point working WHERE THEY ARE INSTALLED (`model.predict("some text")`, reference
+data/text/tokenizer.py:50-104) and raises a clear error where they are not.  Callers without espeak pass phoneme
+strings to the tokenizer or token ids to `predict(..., encode=False)`."""
 from __future__ import annotations
 
-from typing import Callable, List, Optional
+import re
+from typing import Callable, List, Optional, Union
 
-from .symbols import VOCABULARY
+from .symbols import PUNCTUATION, VOCABULARY
 
 
 class Tokenizer:
@@ -55,9 +59,45 @@ class Tokenizer:
         return ''.join(self.idx_to_token[int(t)] for t in sequence)
 
 
+class Phonemizer:
+    """text -> IPA phoneme string through `phonemizer.phonemize` (espeak backend), imported on first use.  Same
+    constructor and call signature as the reference's class (data/text/tokenizer.py:50-76).  Around the third-party
+    call: '-' travels as an em dash (espeak drops hyphens), symbols outside the model's vocabulary are removed from
+    the result, runs of white space collapse and white space next to punctuation disappears."""
+    _EM_DASH = '\u2014'
+    _MARKS = ';:,.!?\u00a1\u00bf\u2014\u2026"\u00ab\u00bb\u201c\u201d'
+
+    def __init__(self, language: str, with_stress: bool, njobs=4):
+        self.language, self.with_stress, self.njobs = language, with_stress, njobs
+        self._known = frozenset(VOCABULARY)
+        self._spaces = re.compile(r'\s+')
+        self._around_marks = re.compile(r'\s*([' + re.escape(PUNCTUATION.strip()) + r'])\s*')
+
+    def _clean(self, phonemes: str) -> str:
+        kept = ''.join(ch for ch in phonemes.replace(self._EM_DASH, '-') if ch in self._known)
+        return self._around_marks.sub(r'\1', self._spaces.sub(' ', kept)).strip()
+
+    def __call__(self, text: Union[str, list], with_stress=None, njobs=None, language=None) -> Union[str, list]:
+        if not isinstance(text, (str, list)):
+            raise TypeError(f'Phonemizer input must be list or str, not {type(text)}')
+        try:
+            from phonemizer.phonemize import phonemize
+        except ImportError as e:
+            raise RuntimeError('text input needs the `phonemizer` package and the espeak binary (not installed here): '
+                               'pass a phoneme string to model.text_pipeline.tokenizer, or token ids to '
+                               'predict(ids, encode=False)') from e
+        many = isinstance(text, list)
+        raw = phonemize([t.replace('-', self._EM_DASH) for t in (text if many else [text])],
+                        language=language or self.language, backend='espeak', strip=True, preserve_punctuation=True,
+                        with_stress=with_stress or self.with_stress, punctuation_marks=self._MARKS,
+                        njobs=njobs or self.njobs, language_switch='remove-flags')
+        out = [self._clean(r) for r in raw]
+        return out if many else out[0]
+
+
 class TextToTokens:
-    """`model.text_pipeline` (reference data/text/__init__.py:7-21): phonemes -> ids.  `phonemizer` is any
-    callable text -> phoneme string the application supplies; none is bundled."""
+    """`model.text_pipeline` (reference data/text/__init__.py:7-21): text -> phonemes -> ids.  `phonemizer` is any
+    callable text -> phoneme string; `default` attaches the espeak adapter above."""
 
     def __init__(self, phonemizer: Optional[Callable[[str], str]], tokenizer: Tokenizer):
         self.phonemizer, self.tokenizer = phonemizer, tokenizer
@@ -72,4 +112,6 @@ class TextToTokens:
     @classmethod
     def default(cls, language: str, add_start_end: bool, with_stress: bool, model_breathing: bool, njobs=1,
                 phonemizer=None):
+        if phonemizer is None:
+            phonemizer = Phonemizer(language=language, with_stress=with_stress, njobs=njobs)
         return cls(phonemizer, Tokenizer(add_start_end=add_start_end, model_breathing=model_breathing))
