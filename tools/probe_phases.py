@@ -30,7 +30,7 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); torch.cuda._sleep(10_000_000); e1.record(); torch.cuda.synchronize()
     cyc_per_ms = 10_000_000 / e0.elapsed_time(e1)
-    for S in (0.0, 9.0):
+    for S in (0.0, float(os.environ.get("PROBE_SLEEP_MS", "9.0"))):
         n = 8
         allev = []
         for _ in range(n):

@@ -190,8 +190,12 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     wb.used = 0;
     // TTSMI_WGRAD_EVENTS=2 (A/B knob): two hand-offs to the weight-gradient stream per block instead of four - the FFN
     // pair after dh1, the attention-side three after dqkv (fewer event packets on both queues, later starts on the side stream)
+    // TTSMI_WGRAD_EVENTS=1: ONE hand-off for the FFN pair and the output projection, placed right before the attention
+    // backward - the full-row GEMM+LN kernels own a CU's LDS (144 KB), so a weight-gradient workgroup sitting on a CU
+    // (48 KB) keeps their workgroups off it, while the attention kernels (19 KB, latency bound) share a CU with it
     TTSMI_KNOB(wev, "TTSMI_WGRAD_EVENTS", 4);
-    const bool lazy = wev == 2;
+    const bool lazy = wev == 2 || wev == 1;
+    const bool pre_attn = wev == 1;
     // ---- LN2 + FFN: df (bf16) = dLN2/dx, da (fp32) = dLN2/dres
     if (D->fuse_ln) {
         if (!D->ln2_done) {         // (chained: the block above already left df / da / the parameter partials)
@@ -207,11 +211,11 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
                                     nullptr, nullptr, M, d, D->ln_ws2, D->ln_ws_bytes, D->df, st));
     if (!lazy) TRY(wgrad_side(D, &wb, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
     { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false, (double)M * F * 2), st);
-      arm(D, 1);
+      if (!pre_attn) arm(D, 1);
       TRY(ttsmi_hgemm_tn(D->df, 0, d, nullptr, 0, 0, D->w2_b, d, nullptr, (const float*)D->h1, F, D->dh1, F, M, F, d,
                          TTSMI_GEMM_OUT_BF16 | TTSMI_GEMM_MASK_BF16, 1, 0, 0, 0, st)); }               // relu' fused
-    if (lazy) TRY(wgrad_side(D, &wb, 1, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
-    TRY(wgrad_side(D, &wb, 1, !lazy, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
+    if (lazy && !pre_attn) TRY(wgrad_side(D, &wb, 1, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
+    if (!pre_attn) TRY(wgrad_side(D, &wb, 1, !lazy, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
     if (D->fuse_ln) {
         // (da + dh1.W1^T) never reaches HBM: res-norm 1's backward runs in the dgrad's epilogue -> d_o (bf16), dh (fp32)
         OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * F, gemm_bytes(M, d, F, 4, true, (double)M * d * (2 + 2)), st);
@@ -235,6 +239,7 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     TTSMI_KNOB(split_ok, "TTSMI_DENSE_SPLIT_DGRAD", 1);           // TTSMI_DENSE_SPLIT_DGRAD=0: two launches (A/B knob)
     if (split_ok && d == 256 && ttsmi_hgemm_k256_eligible(M, 2 * d, d)) {
         OBS("ttsmi_hgemm_tn", 2.0 * M * d * 2 * d, gemm_bytes(M, d, d, 4, true) + gemm_bytes(M, d, d, 2, false) - (double)M * d * 2, st);
+        if (pre_attn) arm(D, 2);
         TRY(ttsmi_hgemm_k256_split(D->d_o, d, D->wo_b, d, D->dh, d, d, D->dctx, d, M, 2 * d, st));
     } else {
         { OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 4, true), st);
@@ -243,6 +248,12 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         { OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 2, false), st);
           TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b + (long)d * d, d, nullptr, nullptr, 0, D->dctx, d, M, d, d,
                              TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
+    }
+    if (pre_attn) {      // everything the weight-gradient stream can do before dqkv exists, handed over in one go
+        TRY(wgrad_side(D, &wb, 2, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
+        TRY(wgrad_side(D, &wb, 2, false, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
+        TRY(wgrad_side(D, &wb, 2, false, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
+        TRY(wgrad_side(D, &wb, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
     }
     // ---- attention + qkv projection
     {
@@ -256,11 +267,11 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         TRY(ttsmi_attention_bwd(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh, D->rate,
                                 D->seed, D->step_dev, D->site_attn, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));
     }
-    if (lazy) {
+    if (lazy && !pre_attn) {
         TRY(wgrad_side(D, &wb, 3, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
         TRY(wgrad_side(D, &wb, 3, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
     }
-    TRY(wgrad_side(D, &wb, 3, !lazy, h_bf, d, D->dqkv, 3 * d, D->g_wqkv, D->g_bqkv, d, 3 * d));
+    TRY(wgrad_side(D, &wb, 3, !lazy || pre_attn, h_bf, d, D->dqkv, 3 * d, D->g_wqkv, D->g_bqkv, d, 3 * d));
     TRY(wgrad_flush(D, &wb));            // the block's five slab reductions, one launch on the weight-gradient stream
     const ttsmi_dense_block* L = D->below;
     if (D->fuse_ln && L != nullptr) {

@@ -104,10 +104,17 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     }
     const int n_items = mel_in_lds ? itFirst[p.n_mels] : 0;
     const bool mel_items = mel_in_lds && n_items <= MEL_ITEMS;
+    // last bin any filter reads (filters are stored in ascending order of their first bin; without the LDS copy: all)
+    int bin_hi = NC;
+    if (mel_in_lds) {
+        bin_hi = 0;
+        for (int m = 0; m < p.n_mels; ++m) bin_hi = max(bin_hi, melloS[m] + melcntS[m] - 1);
+        bin_hi = __builtin_amdgcn_readfirstlane(bin_hi);
+    }
 
     float2* zb = buf[wave][0];
     float* mg = mag[wave];
-    for (int i = NC + 1 + lane; i < NC + 8 + MEL_IT; i += 64) mg[i] = 0.f;
+    for (int i = lane; i < NC + 8 + MEL_IT; i += 64) mg[i] = 0.f;       // bins no round writes (above the bank, the padding) read as 0
     // the lane's 2 * PPL window taps never change: keep them in registers
     float2 win[PPL];
 #pragma unroll
@@ -193,16 +200,27 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         // X[k] = (e - i w o)/2 with e = Z[k] + conj(Z[NC-k]), o = Z[k] - conj(Z[NC-k]), w = exp(-2 pi i k/NFFT);
         // the mirror bin shares everything: X[NC-k] = (conj(e) - i conj(w o))/2.  One pass over k = 0..NC/2
         // yields both magnitudes (half the LDS reads and complex multiplies of a pass over all bins).
-        for (int k = lane; k <= NC / 2 && !(p.ablate & 8); k += 64) {
+        // (v_sqrt_f32 is accurate to 1 ulp; the library sqrtf adds a denormal rescale and a correctly-rounded fix-up -
+        // ~15 instructions each, 10 square roots per lane and frame were a sixth of the kernel's VALU work.  Bins above
+        // the highest filter's last bin - 371 of 512 for the LJSpeech bank - feed nothing: their mirror is skipped.)
+#pragma unroll
+        for (int it = 0; it < NC / 128; ++it) {                 // k = 0 .. NC/2 - 1 in full waves; k = NC/2 below
+            if (p.ablate & 8) break;
+            const int k = lane + 64 * it;
             float2 zk = Z(k);
             float2 zc = Z((NC - k) & (NC - 1));
             zc.y = -zc.y;
             float2 e = cadd(zk, zc), o = csub(zk, zc);
             float2 wo = cmul(tw[k], o);
             float xr = e.x + wo.y, xi = e.y - wo.x;            // 2 X[k]
+            mg[k] = 0.5f * __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+            if (NC - 64 * it - 63 > bin_hi + MEL_IT) continue;  // wave-uniform: no mirror bin of this round is read (they stay 0)
             float yr = e.x - wo.y, yi = e.y + wo.x;            // 2 conj-mirrored X[NC-k]
-            mg[k] = 0.5f * sqrtf(xr * xr + xi * xi);
-            mg[NC - k] = 0.5f * sqrtf(yr * yr + yi * yi);
+            mg[NC - k] = 0.5f * __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
+        }
+        if (lane == 0 && !(p.ablate & 8)) {                    // k = NC/2 is its own mirror: X = conj(Z)
+            const float2 zh = Z(NC / 2);
+            mg[NC / 2] = __builtin_amdgcn_sqrtf(zh.x * zh.x + zh.y * zh.y);
         }
         WAVE_SYNC();
         // ---- sparse mel + normalisation ---------------------------------------------------------
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
             }
             float o;
             if (p.normalizer == 0) {
-                o = logf(fmaxf(s, p.clip_min));
+                o = __logf(fmaxf(s, p.clip_min));            // v_log_f32 (1 ulp in log2) x ln 2; the argument is >= clip_min > 0
             } else {
                 float db = 20.f * log10f(fmaxf(1e-5f, s));
                 float nz = fminf(fmaxf((db + 100.f) / 100.f, 0.f), 1.f);
@@ -276,8 +294,16 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
     TTSMI_ABLATE_KNOB(ablate, "TTSMI_MEL_ABLATE");      // wrong results by construction: only in a measurement build
     p.ablate = ablate;
     long groups = (total_frames + FR_PER_WG - 1) / FR_PER_WG;
-    int gpw = 1;
-    while (gpw < 16 && groups / (gpw * 2) >= 2048) gpw *= 2;   // amortise the twiddle build
+    // A workgroup's set-up (1024 sincospi, the filterbank copy, a SERIAL 80-step prefix over the filters, the weight
+    // item table) costs ~10 us: with 64 frames per workgroup (round 1/2: gpw <= 16) that was ~13 % of a 10 000-clip
+    // launch.  Few, long-lived workgroups instead: ~32 per CU (3 resident, ~10 rounds: measured best of 768 .. 87 000), each a contiguous range of
+    // frames, so the set-up is amortised over hundreds of frames.  TTSMI_MEL_WGS overrides the target (A/B knob).
+    TTSMI_KNOB(target_env, "TTSMI_MEL_WGS", 8192);
+    const long target = target_env > 0 ? target_env : 8192;
+    long gpw_l = (groups + target - 1) / target;
+    if (gpw_l < 1) gpw_l = 1;
+    if (gpw_l > (1 << 20)) gpw_l = 1 << 20;
+    int gpw = (int)gpw_l;
     p.groups_per_wg = gpw;
     long blocks = (groups + gpw - 1) / gpw;
     if (n_fft == 1024)
