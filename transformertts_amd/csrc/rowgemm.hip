@@ -167,7 +167,9 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
             float q = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] -= mean; q += v[e] * v[e]; }
-            const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) * invC + p.eps);
+            // v_rsq_f32 (1 ulp) instead of 1 / sqrtf: the library pair is ~25 dependent instructions in a row loop that is a
+            // dependency chain (sum -> statistics -> normalise), 16 rows per wave; this is the bf16 path (bf16 outputs)
+            const float rstd = __builtin_amdgcn_rsqf(wave_sum_dpp(q) * invC + p.eps);
             if (lane == 0) p.rstd[row] = rstd;
             const bool padded = __builtin_amdgcn_readlane(pre.pad_l, i) != 0;
             float xh[4], yv[4];
