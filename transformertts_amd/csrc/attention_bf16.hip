@@ -89,6 +89,23 @@ __device__ __forceinline__ void hmask_apply_all(f32x16& v, const HMaskWords& w) 
 __device__ __forceinline__ int rowmap16(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 #define HKT 64                 // rows (keys or queries) per staged tile
+// key-padding flags of a staged tile (forward / dQ kernels; locals rpad_raw, rpad_nv, padS, b, tid, p in scope).
+// padS[HKT] holds the flag of "any padded key" of the tile.
+#define HPAD_FETCH(k0f_, nv_)                                                                              \
+    do {                                                                                                   \
+        rpad_nv = (nv_);                                                                                   \
+        if (tid < HKT) rpad_raw = p.key_pad[(long)b * p.T + min((k0f_) + tid, p.T - 1)];                   \
+    } while (0)
+#define HPAD_STASH()                                                                                       \
+    do {                                                                                                   \
+        if (tid < HKT) {                                      /* exactly wave 0 */                           \
+            const bool pd_ = tid < rpad_nv && rpad_raw != 0;                                               \
+            padS[tid] = pd_ ? 1.f : 0.f;                                                                   \
+            const unsigned long long any_ = __ballot(pd_);                                                 \
+            if (tid == 0) padS[HKT] = any_ ? 1.f : 0.f;                                                    \
+        }                                                                                                  \
+    } while (0)
+#define HPAD_ANY() (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, padS[HKT])) != 0)
 #define TLD (HKT + 4)          // transposed image row stride (bf16 elements)
 
 // ---- row-major staging: [HKT][DH] fp32 rows -> bf16 [HKT][DH+8] ----------------------------------
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
     constexpr int MAIN = TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + HKT * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + (HKT + 4) * 4];
     uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vs = Ks + SM::ROWS;
     float* padS = reinterpret_cast<float*>(smem + MAIN);
@@ -412,24 +429,32 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
     }
 
     Tile<DH, QH> rk, rv;
-    float rpad = 0.f;
+    // The padding byte of the NEXT tile is only LOADED in the fetch phase and turned into a float when the tile is
+    // stashed (HPAD_*): any arithmetic on it right after the load put an `s_waitcnt vmcnt(0)` behind the K / V prefetch
+    // of the same phase - wave 0 then sat out a full memory round trip per key tile before multiplying anything, and
+    // the other three waves waited for it at the next barrier (ISA reading, round 3: the waves of the three attention
+    // kernels spent ~50 % of their cycles in s_waitcnt).  "Any padded key in this tile" is wave 0's ballot passed
+    // through LDS under the barrier that publishes the tile - `__syncthreads_or` cost three barriers of its own.
+    uint32_t rpad_raw = 0;
+    int rpad_nv = 0;
     {
         int nv = min(HKT, klen - kbeg);
         rk.fetch(Kb, p.ld, kbeg, nv, tid);
         rv.fetch(Vb, p.ld, kbeg, nv, tid);
-        if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + kbeg + tid]) ? 1.f : 0.f;
+        HPAD_FETCH(kbeg, nv);
     }
     for (int k0 = kbeg; k0 < klen; k0 += HKT) {
         __syncthreads();
         rk.stash(Ks, tid);
         rv.stash(Vs, tid);
-        if (tid < HKT) padS[tid] = rpad;
-        const int anypad = __syncthreads_or(tid < HKT && rpad != 0.f);
+        HPAD_STASH();
+        __syncthreads();
+        const int anypad = HPAD_ANY();
         if (k0 + HKT < klen) {
             int nv = min(HKT, klen - (k0 + HKT));
             rk.fetch(Kb, p.ld, k0 + HKT, nv, tid);
             rv.fetch(Vb, p.ld, k0 + HKT, nv, tid);
-            if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + k0 + HKT + tid]) ? 1.f : 0.f;
+            HPAD_FETCH(k0 + HKT, nv);
         }
 #pragma unroll
         for (int kt = 0; kt < HKT / 32; ++kt) {
@@ -513,7 +538,7 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dq_kernel(HAtt
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
     constexpr int MAIN = TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + HKT * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + (HKT + 4) * 4];
     uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vs = Ks + SM::ROWS;
     float* padS = reinterpret_cast<float*>(smem + MAIN);
@@ -585,24 +610,26 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dq_kernel(HAtt
     }
 
     Tile<DH, QH> rk, rv;
-    float rpad = 0.f;
+    uint32_t rpad_raw = 0;                       // (see the forward kernel: load now, convert when the tile is stashed)
+    int rpad_nv = 0;
     {
         int nv = min(HKT, klen);
         rk.fetch(Kb, p.ld, 0, nv, tid);
         rv.fetch(Vb, p.ld, 0, nv, tid);
-        if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + tid]) ? 1.f : 0.f;
+        HPAD_FETCH(0, nv);
     }
     for (int k0 = 0; k0 < klen; k0 += HKT) {
         __syncthreads();
         rk.stash(Ks, tid);
         rv.stash(Vs, tid);
-        if (tid < HKT) padS[tid] = rpad;
-        const int anypad = __syncthreads_or(tid < HKT && rpad != 0.f);
+        HPAD_STASH();
+        __syncthreads();
+        const int anypad = HPAD_ANY();
         if (k0 + HKT < klen) {
             int nv = min(HKT, klen - (k0 + HKT));
             rk.fetch(Kb, p.ld, k0 + HKT, nv, tid);
             rv.fetch(Vb, p.ld, k0 + HKT, nv, tid);
-            if (tid < HKT) rpad = (tid < nv && p.key_pad[(long)b * p.T + k0 + HKT + tid]) ? 1.f : 0.f;
+            HPAD_FETCH(k0 + HKT, nv);
         }
 #pragma unroll
         for (int kt = 0; kt < HKT / 32; ++kt) {
@@ -731,14 +758,16 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
     if (wg_active) {
         Tile<DH, QH> rq, ro;
         float rl = 0.f, rd = 0.f;
+        int rnv = 0;
         {
             int nv = min(HKT, p.T);
             rq.fetch(Qb, p.ld, 0, nv, tid);
             ro.fetch(dOb, d, 0, nv, tid);
             mask_fetch(0);
-            if (tid < HKT) {
-                rl = tid < nv ? p.lse[stat0 + tid] * LOG2E : INFINITY;
-                rd = tid < nv ? p.delta[stat0 + tid] : 0.f;
+            rnv = nv;
+            if (tid < HKT) {                                 // raw loads: converted when stashed (see the forward kernel)
+                rl = p.lse[stat0 + min(tid, p.T - 1)];
+                rd = p.delta[stat0 + min(tid, p.T - 1)];
             }
         }
         for (int q0 = 0; q0 < p.T; q0 += HKT) {
@@ -746,8 +775,8 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
             rq.stash(Qs, tid);
             ro.stash(Os, tid);
             if (tid < HKT) {
-                lseS[tid] = rl;
-                delS[tid] = rd * inv_sqrt;                  // dS = P (keep dP / (1 - p) - delta) / sqrt(dh): scale folded in
+                lseS[tid] = tid < rnv ? rl * LOG2E : INFINITY;
+                delS[tid] = tid < rnv ? rd * inv_sqrt : 0.f;  // dS = P (keep dP / (1 - p) - delta) / sqrt(dh): scale folded in
                 if (DROP == 1) rbS[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0 + tid));
             }
             uint32_t mcur[HKT / 32];
@@ -759,9 +788,10 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
                 rq.fetch(Qb, p.ld, q0 + HKT, nv, tid);
                 ro.fetch(dOb, d, q0 + HKT, nv, tid);
                 mask_fetch(q0 + HKT);
+                rnv = nv;
                 if (tid < HKT) {
-                    rl = tid < nv ? p.lse[stat0 + q0 + HKT + tid] * LOG2E : INFINITY;
-                    rd = tid < nv ? p.delta[stat0 + q0 + HKT + tid] : 0.f;
+                    rl = p.lse[stat0 + min(q0 + HKT + tid, p.T - 1)];
+                    rd = p.delta[stat0 + min(q0 + HKT + tid, p.T - 1)];
                 }
             }
 #pragma unroll

@@ -63,10 +63,16 @@ static inline int ttsmi_env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 #define TTSMI_KNOB(var, name, dflt) static const int var = ttsmi_env_int(name, dflt)
+// Device side: TTSMI_ABLATE_BITS(p.ablate) is the run-time bit field in a measurement build and the CONSTANT 0 in the
+// shipped library - a run-time `if (p.ablate & 8) continue;` inside an unrolled row loop gave the compiler a path
+// around the loop's first use of two loaded registers, so its wait-count pass put `s_waitcnt vmcnt(0)` in front of every
+// row of the fused GEMM + LayerNorm epilogue: each row then waited for the previous row's stores (ISA reading, round 3).
 #ifdef TTSMI_ABLATION_BUILD
 #define TTSMI_ABLATE_KNOB(var, name) static const int var = ttsmi_env_int(name, 0)
+#define TTSMI_ABLATE_BITS(x) (x)
 #else
 #define TTSMI_ABLATE_KNOB(var, name) static const int var = 0
+#define TTSMI_ABLATE_BITS(x) 0
 #endif
 
 // weight gradient with the slab reduction deferred to a batched launch (gemm_bf16.hip; used by dense_block.hip -

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_wide_kernel(K256P p) {
     const int group = xcd + 8 * (slot / p.nchunks), chunk = slot % p.nchunks;
     const int ncol0 = chunk * KWW_BN;
     const int my_tiles = group < p.ntiles ? (p.ntiles - group + p.ngroups - 1) / p.ngroups : 0;
-    const int ab = p.ablate;
+    const int ab = TTSMI_ABLATE_BITS(p.ablate);
 
     if (tid < KWW_BN) biasS[tid] = (p.bias != nullptr && ncol0 + tid < p.N) ? p.bias[ncol0 + tid] : 0.f;
     // ---- compute waves: 64 columns of W^T as MFMA A-operand fragments, bfrag[cb][s] = Bt[n0 + 32 cb + l31][16 s + 8 hh ..]

@@ -178,7 +178,7 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
             yv[0] = xh[0] * gm.x + bt.x; yv[1] = xh[1] * gm.y + bt.y; yv[2] = xh[2] * gm.z + bt.z; yv[3] = xh[3] * gm.w + bt.w;
             if (padded) { yv[0] = 0.f; yv[1] = 0.f; yv[2] = 0.f; yv[3] = 0.f; }
             const long o = (long)row * RG_N + c4;
-            if (p.ablate & 8) continue;                     // (measurement: the epilogue without its global stores)
+            if (TTSMI_ABLATE_BITS(p.ablate) & 8) continue;                     // (measurement: the epilogue without its global stores)
             *reinterpret_cast<float4*>(p.y + o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
             *reinterpret_cast<uint2*>(p.y_bf + o) = rg_pack4(yv[0], yv[1], yv[2], yv[3]);
             *reinterpret_cast<uint2*>(p.xhat + o) = rg_pack4(xh[0], xh[1], xh[2], xh[3]);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
             rd_dma16(p.Bt + (long)row * p.ldb + kb + c * 8, rd_lds_offset(Bs + (wave * 32 + i * 8) * 128));
         }
     };
-    const bool dma_on = !(p.ablate & 2);
+    const bool dma_on = !(TTSMI_ABLATE_BITS(p.ablate) & 2);
     if (dma_on) {
         issue(0, 0);
         if (nk > 1) issue(1, 1);
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
         if (dma_on && ks + 2 < nk) issue(ks + 2, (ks + 2) % RD_STAGES);
         const unsigned char* As = smem + (ks % RD_STAGES) * STAGE;
         const unsigned char* Bs = As + BM * 128;
-        if (p.ablate & 1) continue;
+        if (TTSMI_ABLATE_BITS(p.ablate) & 1) continue;
         // Fragments of TWO 16-wide k-slices (10 x 16 B per lane) are requested before the first of their 8 MFMAs issues:
         // written one fragment at a time, hipcc keeps a single ds_read ahead of each MFMA and the matrix pipe waits out an
         // LDS round trip per multiply (23 % busy in the k-loop: it, not the fill, was what bounded this kernel).
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
         }
     }
     __syncthreads();
-    if (p.ablate & 4) return;
+    if (TTSMI_ABLATE_BITS(p.ablate) & 4) return;
     rg_epilogue<EPI, 8, BM, NJ>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
 }
 

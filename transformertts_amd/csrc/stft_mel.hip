@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     // raw samples of frame f -> x[PPL] (pairs z[i + 64 r]); issued one iteration ahead of their use so
     // the HBM/L2 latency of frame g+1 hides under the FFT of frame g
     auto load_frame = [&](long f, float2 (&x)[PPL]) {
-        const bool act = (f < p.total_frames) && !(p.ablate & 1);
+        const bool act = (f < p.total_frames) && !(TTSMI_ABLATE_BITS(p.ablate) & 1);
         long base = 0;
         int L = 1, t = 0;
         if (act) {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
 #pragma unroll
         for (int r = 0; r < PPL; ++r) w[r] = make_float2(xs[r].x * win[r].x, xs[r].y * win[r].y);
         if (g + 1 < p.groups_per_wg) load_frame(f + FR_PER_WG, xs);
-        const bool full = !(p.ablate & 4);
+        const bool full = !(TTSMI_ABLATE_BITS(p.ablate) & 4);
         if constexpr (NSUB == 1) {
             fft512<NFFT>(w, zb, tw, lane, full);           // Z[k] in zb[ZP(k)]
         } else {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         // the highest filter's last bin - 371 of 512 for the LJSpeech bank - feed nothing: their mirror is skipped.)
 #pragma unroll
         for (int it = 0; it < NC / 128; ++it) {                 // k = 0 .. NC/2 - 1 in full waves; k = NC/2 below
-            if (p.ablate & 8) break;
+            if (TTSMI_ABLATE_BITS(p.ablate) & 8) break;
             const int k = lane + 64 * it;
             float2 zk = Z(k);
             float2 zc = Z((NC - k) & (NC - 1));
@@ -218,13 +218,13 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
             float yr = e.x - wo.y, yi = e.y + wo.x;            // 2 conj-mirrored X[NC-k]
             mg[NC - k] = 0.5f * __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
         }
-        if (lane == 0 && !(p.ablate & 8)) {                    // k = NC/2 is its own mirror: X = conj(Z)
+        if (lane == 0 && !(TTSMI_ABLATE_BITS(p.ablate) & 8)) {                    // k = NC/2 is its own mirror: X = conj(Z)
             const float2 zh = Z(NC / 2);
             mg[NC / 2] = __builtin_amdgcn_sqrtf(zh.x * zh.x + zh.y * zh.y);
         }
         WAVE_SYNC();
         // ---- sparse mel + normalisation ---------------------------------------------------------
-        if (mel_items && !(p.ablate & 2)) {
+        if (mel_items && !(TTSMI_ABLATE_BITS(p.ablate) & 2)) {
             float* part = partS[wave];
             for (int it = lane; it < n_items; it += 64) {
                 const float4* w4 = reinterpret_cast<const float4*>(itWt[it]);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
             }
             WAVE_SYNC();
         }
-        for (int m = lane; m < p.n_mels && !(p.ablate & 2); m += 64) {
+        for (int m = lane; m < p.n_mels && !(TTSMI_ABLATE_BITS(p.ablate) & 2); m += 64) {
             float s = 0.f;
             if (mel_items) {
                 const float* part = partS[wave];
