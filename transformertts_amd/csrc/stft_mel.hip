@@ -126,13 +126,18 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     int cur = -1;
     long cur_f0 = 0, cur_f1 = 0, cur_base = 0;
     int cur_L = 1;
-    // raw samples of frame f -> x[PPL] (pairs z[i + 64 r]); issued one iteration ahead of their use so
-    // the HBM/L2 latency of frame g+1 hides under the FFT of frame g
-    auto load_frame = [&](long f, float2 (&x)[PPL]) {
-        const bool act = (f < p.total_frames) && !(TTSMI_ABLATE_BITS(p.ablate) & 1);
-        long base = 0;
-        int L = 1, t = 0;
-        if (act) {
+    // Raw samples of frame f -> x[PPL] (pairs z[i + 64 r]), requested one iteration ahead of their use so that the HBM / L2
+    // latency of frame g+1 hides under the FFT of frame g.  The prefetch is ALWAYS the reflection-free pattern (from a
+    // clamped, in-bounds address) and is only kept for interior frames; the ~4 edge frames of a clip are loaded with
+    // reflection when they are consumed.  (Round 1/2 chose between the two patterns in the prefetch: the merge of the two
+    // paths copied the loaded registers, i.e. `s_waitcnt vmcnt(0)` right behind the prefetch - nothing overlapped.)
+    const long total_samples = p.clip_off[p.n_clips];
+    struct Pending { bool act, interior; long base; int L, start; } nx = {false, true, 0, 1, 0};
+    auto prefetch_frame = [&](long f, float2 (&x)[PPL]) {
+        nx.act = (f < p.total_frames) && !(TTSMI_ABLATE_BITS(p.ablate) & 1);
+        nx.base = 0; nx.L = 1;
+        int t = 0;
+        if (nx.act) {
             if (cur < 0 || f < cur_f0 || f >= cur_f1) {   // wave-uniform: one dependent search per clip change
                 cur = clip_of_frame(p.frame_off, p.n_clips, f);
                 cur_f0 = p.frame_off[cur];
@@ -140,42 +145,51 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
                 cur_base = p.clip_off[cur];
                 cur_L = (int)(p.clip_off[cur + 1] - cur_base);
             }
-            base = cur_base;
-            L = cur_L;
+            nx.base = cur_base;
+            nx.L = cur_L;
             t = (int)(f - cur_f0);
         }
-        const int start = t * p.hop - NFFT / 2;
-        if (act && start >= 0 && start + NFFT <= L) {     // wave-uniform: an interior frame needs no reflection
-            const float* src = p.wav + base + start + 2 * lane;
+        nx.start = t * p.hop - NFFT / 2;
+        nx.interior = nx.act && nx.start >= 0 && nx.start + NFFT <= nx.L && total_samples >= NFFT;
+        if (total_samples >= NFFT) {                      // (always, except on toy inputs)
+            long s0 = nx.base + nx.start;
+            s0 = s0 < 0 ? 0 : (s0 > total_samples - NFFT ? total_samples - NFFT : s0);
+            const float* src = p.wav + s0 + 2 * lane;
 #pragma unroll
             for (int r = 0; r < PPL; ++r) x[r] = make_float2(src[128 * r], src[128 * r + 1]);
-            return;
         }
+    };
+    // at consumption: an edge frame (or an inactive slot) replaces the speculative prefetch
+    auto fix_frame = [&](float2 (&x)[PPL]) {
+        if (nx.interior) return;                          // wave-uniform
 #pragma unroll
         for (int r = 0; r < PPL; ++r) {
             int n = 2 * (lane + 64 * r);
             float v[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                int gi = start + n + e;
+                int gi = nx.start + n + e;
                 if (gi < 0) gi = -gi;                     // np.pad(mode='reflect')
-                if (gi >= L) gi = 2 * (L - 1) - gi;
+                if (gi >= nx.L) gi = 2 * (nx.L - 1) - gi;
                 gi = gi < 0 ? 0 : gi;
-                v[e] = act ? p.wav[base + gi] : 0.f;
+                v[e] = nx.act ? p.wav[nx.base + gi] : 0.f;
             }
             x[r] = make_float2(v[0], v[1]);
         }
     };
     const long f_first = (long)blockIdx.x * p.groups_per_wg * FR_PER_WG + wave;
     float2 xs[PPL];
-    load_frame(f_first, xs);
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) xs[r] = make_float2(0.f, 0.f);
+    prefetch_frame(f_first, xs);
     for (int g = 0; g < p.groups_per_wg; ++g) {
         const long f = f_first + (long)g * FR_PER_WG;
         const bool active = f < p.total_frames;
+        fix_frame(xs);
         float2 w[PPL];
 #pragma unroll
         for (int r = 0; r < PPL; ++r) w[r] = make_float2(xs[r].x * win[r].x, xs[r].y * win[r].y);
-        if (g + 1 < p.groups_per_wg) load_frame(f + FR_PER_WG, xs);
+        if (g + 1 < p.groups_per_wg) prefetch_frame(f + FR_PER_WG, xs);
         const bool full = !(TTSMI_ABLATE_BITS(p.ablate) & 4);
         if constexpr (NSUB == 1) {
             fft512<NFFT>(w, zb, tw, lane, full);           // Z[k] in zb[ZP(k)]
