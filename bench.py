@@ -173,7 +173,7 @@ def kernel_family(name, args):
     return KERNEL_OF.get(name, RIDERS)
 
 
-PMC_FILE = 'r02_pmc_hbm_traffic_bf16.json'
+PMC_FILE = 'r03_pmc_hbm_traffic_bf16.json'
 PMC_KERNELS = {       # kernel family -> (rocprof names of its kernels, names of helper kernels of the same entry point)
     KERNEL_OF['ttsmi_hgemm_tn']: (['gemm_bf16_kernel', 'gemm_bf16_dma_kernel', 'gemm_bf16_deep_kernel', 'gemm_k256_kernel'], []),
     ROWGEMM: (['rowgemm_dma_kernel', 'rowgemm_kernel'], []),
@@ -507,7 +507,9 @@ def mel_bench(args):
         traffic = None
         try:
             with open(os.path.join(ROOT, 'profiles', MEL_PMC_FILE)) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')
+                ks = json.load(f).get('kernels', {})
+            hit = [v for k, v in ks.items() if k.startswith('stft_logmel_kernel')]
+            traffic = hit[0]['hbm_bytes_per_launch'] if hit else None
         except (OSError, ValueError):
             pass
         result['roofline'] = {

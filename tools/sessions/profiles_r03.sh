@@ -1,0 +1,34 @@
+#!/bin/bash
+# The round-3 artefact set for profiles/: bash tools/sessions/profiles_r03.sh [tag]   (ONE gpurun call, one box)
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r03}
+R=$PWD; O=$R/gpurun_out; mkdir -p $O
+export TMPDIR=/tmp
+echo "== train step: kernel trace + PMC passes"
+bash tools/gpu_profile.sh ${TAG}_bf16 --no-attention-maps
+cp $O/${TAG}_bf16_pmc_traffic.json $R/profiles/${TAG}_pmc_hbm_traffic_bf16.json
+python tools/rocpd_timeline.py $O/prof_${TAG}_bf16/trace_results.db --steps 1 --top 50 > $O/${TAG}_timeline_bf16.txt 2>&1
+echo "== train step: SQ counters"
+bash tools/gpu_sq_counters.sh ${TAG}_bf16 --no-attention-maps
+python tools/rocpd_sq_summary.py $O/sq_${TAG}_bf16_1/pmc_results.db $O/sq_${TAG}_bf16_2/pmc_results.db > $O/${TAG}_sq_counters_bf16.txt 2>&1
+echo "== mel: kernel trace + PMC passes (BASELINE configs[3])"
+MARGS="--workload mel --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
+( cd /tmp
+  timeout 280 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_mel -o trace -- python $R/bench.py $MARGS > $O/prof_${TAG}_mel.log 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 280 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${TAG}_mel_$c -o pmc -- python $R/bench.py $MARGS > /dev/null 2>&1; echo mel $c rc=$?
+  done )
+python tools/rocpd_kernel_stats.py $O/prof_${TAG}_mel/trace_results.db $O/${TAG}_mel_kernel_stats.csv
+python tools/rocpd_pmc_traffic.py $O/pmc_${TAG}_mel_FETCH_SIZE/pmc_results.db $O/pmc_${TAG}_mel_WRITE_SIZE/pmc_results.db $O/${TAG}_mel_pmc_traffic.json
+cp $O/${TAG}_mel_pmc_traffic.json $R/profiles/${TAG}_pmc_hbm_traffic_mel.json
+echo "== bench lines (the committed PMC files feed the traffic fields)"
+python bench.py > $O/${TAG}_bench_bf16.json 2> $O/${TAG}_bench_bf16.err; echo rc=$?
+python bench.py --workload mel > $O/${TAG}_bench_mel.json 2>/dev/null; echo rc=$?
+python bench.py --precision f32 --no-attention-maps > $O/${TAG}_bench_f32.json 2>/dev/null; echo rc=$?
+python bench.py --workload predict > $O/${TAG}_predict_latency.json 2>/dev/null; echo rc=$?
+python bench.py --workload ref-default --no-cpu-baseline > $O/${TAG}_bench_refdefault.json 2>/dev/null; echo rc=$?
+python bench.py --graph --no-cpu-baseline --no-roofline --no-attention-maps --steps 30 --warmup 6 > $O/${TAG}_bench_graph.json 2>/dev/null; echo rc=$?
+python tools/kbench.py --json $O/${TAG}_kbench.jsonl > $O/${TAG}_kbench.txt 2>&1
+tools/probes/event_gap_probe > $O/${TAG}_event_gap_probe.txt 2>&1
+rm -rf $O/prof_${TAG}_bf16 $O/pmc_${TAG}_bf16_* $O/sq_${TAG}_bf16_* $O/prof_${TAG}_mel $O/pmc_${TAG}_mel_*
+ls -la $O | tail -24
