@@ -475,6 +475,23 @@ typedef struct ttsmi_dense_block {
     const struct ttsmi_dense_block* below;
     int32_t ln2_done, _pad1;
 } ttsmi_dense_block;
+/* ---------------------------------------------------------------------------------------------
+ * Batch data parallelism for a binding WITHOUT a collective library of its own (one all-reduce of the
+ * flat fp32 gradient buffer per step; the reference itself has no distributed code).  The Python host side of this
+ * repository uses torch.distributed (backend "nccl" = RCCL) instead; these four are the same collective behind the C
+ * ABI.  RCCL is resolved at first use with dlopen (the copy already loaded in the process, else librccl.so.1):
+ * TTSMI_ERR_UNSUPPORTED when it is absent.  One process per GPU:
+ *   rank 0: ttsmi_comm_unique_id(id) -> 128 bytes, shipped to the other ranks by the caller's own means;
+ *   every rank: hipSetDevice(local_rank); ttsmi_comm_init_rank(&comm, nranks, id, rank);
+ *   every step: ttsmi_allreduce_sum_f32(comm, flat_grad, n, stream)  - in place, asynchronous on `stream`
+ *               (the global-count loss divisors of ttsmi_l1_losses_weighted make SUM the right reduction);
+ *   ttsmi_comm_destroy(comm).
+ * ------------------------------------------------------------------------------------------- */
+int ttsmi_comm_unique_id(void* id128);
+int ttsmi_comm_init_rank(void** comm, int nranks, const void* id128, int rank);
+int ttsmi_comm_destroy(void* comm);
+int ttsmi_allreduce_sum_f32(void* comm, float* buf, int64_t n, ttsmi_stream_t stream);
+
 /* Measurement hook: when set, ttsmi_dense_block_fwd/_bwd announce every launch group they issue - phase 0 before, 1 after
  * it is enqueued - with the entry point's name, its algorithmic FLOPs and bytes and the stream it goes to, so a profiler
  * can bracket the launches with HIP events.  NULL (the default) disables it.  Process-wide, for measurement only. */

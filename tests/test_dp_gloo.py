@@ -297,3 +297,52 @@ def test_ragged_two_rank_step_on_the_gpu_equals_the_single_process_step(tmp_path
     # gradient is at the noise floor; everywhere else they agree closely
     ws = single.params.data.cpu().numpy()
     assert np.abs(w0 - ws).max() < 2.5e-3 and np.abs(w0 - ws).mean() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The collective behind the C ABI (ttsmi_comm_* / ttsmi_allreduce_sum_f32: a thin RCCL wrapper for bindings without
+# torch.distributed).  One rank on a 1-GPU box (sum over one rank = identity, but the call goes through RCCL's stream
+# ordering); one rank per GPU when >= 2 are visible.
+# ---------------------------------------------------------------------------------------------------------------------
+def _abi_rank(rank, world, id_bytes, out_dir):
+    import ctypes
+    os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    from transformertts_amd import _lib
+    from transformertts_amd._lib import check
+    torch.cuda.set_device(rank)
+    l = _lib.lib()
+    comm = ctypes.c_void_p()
+    idbuf = ctypes.create_string_buffer(bytes(id_bytes), 128)
+    check(l.ttsmi_comm_init_rank(ctypes.byref(comm), world, idbuf, rank), 'comm_init_rank')
+    g = torch.arange(1 << 20, dtype=torch.float32, device=f'cuda:{rank}') * (rank + 1)
+    st = torch.cuda.current_stream().cuda_stream
+    check(l.ttsmi_allreduce_sum_f32(comm, g.data_ptr(), g.numel(), st), 'allreduce')
+    g2 = g * 2                                   # consumer on the same stream: ordered after the collective
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f'abi{rank}.npy'), g2[:4096].cpu().numpy())
+    check(l.ttsmi_comm_destroy(comm), 'comm_destroy')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [1, 2])
+def test_c_abi_allreduce(tmp_path, world):
+    import ctypes
+    from transformertts_amd import _lib
+    if torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs')
+    l = _lib.lib()
+    idbuf = ctypes.create_string_buffer(128)
+    rc = l.ttsmi_comm_unique_id(idbuf)
+    if rc == -3:
+        pytest.skip('librccl not loadable here: ' + l.ttsmi_last_error().decode())
+    assert rc == 0, l.ttsmi_last_error()
+    if world == 1:
+        _abi_rank(0, 1, idbuf.raw, str(tmp_path))
+    else:
+        _spawn(_abi_rank, (world, idbuf.raw, str(tmp_path)), world)
+    want = np.arange(4096, dtype=np.float32) * sum(r + 1 for r in range(world)) * 2
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f'abi{r}.npy'), want)
+    # argument checks
+    assert l.ttsmi_allreduce_sum_f32(None, None, 4, None) == -1 and b'bad argument' in l.ttsmi_last_error()
+    assert l.ttsmi_comm_init_rank(None, 1, idbuf, 0) == -1

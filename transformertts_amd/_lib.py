@@ -96,6 +96,10 @@ SIGNATURES = {
     'ttsmi_layernorm_bwd_xhat': (I, [P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, c_size_t, I, I, S]),
     'ttsmi_add_layernorm_bwd_nparts': (I, [I]),
     'ttsmi_layernorm_param_reduce_batched_nw': (I, [P, P, P, P, P, P, I, S]),
+    'ttsmi_comm_unique_id': (I, [P]),
+    'ttsmi_comm_init_rank': (I, [P, I, P, I]),
+    'ttsmi_comm_destroy': (I, [P]),
+    'ttsmi_allreduce_sum_f32': (I, [P, P, L, S]),
     'ttsmi_set_launch_observer': (I, [P]),
     'ttsmi_dense_block_fwd': (I, [P, P, P]),
     'ttsmi_dense_block_bwd': (I, [P, P, P, P]),

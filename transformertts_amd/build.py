@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(LIBDIR, 'libttsmi.so')
 SOURCES = ['api.cpp', 'gemm.hip', 'gemm_bf16.hip', 'attention.hip', 'attention_bf16.hip', 'layernorm.hip',
-           'elementwise.hip', 'lenreg.hip', 'stft_mel.hip', 'dense_block.hip', 'rowgemm.hip', 'gemm_k256.hip', 'griffinlim.hip']
+           'elementwise.hip', 'lenreg.hip', 'stft_mel.hip', 'dense_block.hip', 'rowgemm.hip', 'gemm_k256.hip', 'griffinlim.hip', 'collective.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 # measurement builds only, e.g. TTSMI_EXTRA_HIPCC_FLAGS=-DTTSMI_ABLATION_BUILD (stage-ablation knobs, csrc/common.h)
 FLAGS += os.environ.get('TTSMI_EXTRA_HIPCC_FLAGS', '').split()
@@ -70,7 +70,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     print(f'[ttsmi build] compiled {os.path.basename(done)}', file=sys.stderr)
     objs = [os.path.join(OBJDIR, s + '.o') for s in SOURCES]
     if jobs or force or not os.path.exists(LIB):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
