@@ -256,6 +256,17 @@ __device__ __forceinline__ f32x16 dot16(const uint16_t* S, int row, int g, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const uint16_t* src = S + row * (DH + 8) + 8 * g;
+    if constexpr (DH <= 64) {
+        // all fragment reads of the product in flight before its first multiply (written one at a time hipcc keeps a
+        // single read pair ahead: every second MFMA of the dependent chain then starts with an LDS round trip)
+        bf16x8 a[DH / 16];
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) a[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) acc = MFMA16(a[s], f[s], acc);
+        return acc;
+    }
 #pragma unroll
     for (int s = 0; s < DH / 16; ++s) {
         bf16x8 a = *reinterpret_cast<const bf16x8*>(src + 16 * s);
