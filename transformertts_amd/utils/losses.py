@@ -20,7 +20,9 @@ def weighted_sum_losses(targets, pred, loss_functions, coeffs, unit_seed=False, 
     a gradient); `unit_seed=True` is the train step's promise that it calls total.backward() with the default seed.
     `denominators` (not in the reference, which is single-device): per-term divisors that replace each mean's own element
     count - the GLOBAL padded-batch counts under batch data parallelism (transformertts_amd/dp.py), so that the sum over
-    ranks is the reference's mean over the whole batch.  Only the fused path takes them."""
+    ranks is the reference's mean over the whole batch.  Only the fused path takes them.
+    Note (differs from the reference's TF tensors): on the fused path the returned per-term `loss_vals` are detached
+    device scalars - only `total` carries a gradient, which is all the train step differentiates (models.py:478-480)."""
     if (1 <= len(loss_functions) <= 8 and all(f is masked_mean_absolute_error for f in loss_functions)
             and all(getattr(p, 'is_cuda', False) for p in pred)):
         flat = [t for i in range(len(loss_functions)) for t in (pred[i], targets[i])]
