@@ -1307,8 +1307,11 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
 static int hpick_splits(long rows, int tiles) {
     // ~1 workgroup per CU: wgrad overlaps the main stream, and fewer splits = less slab traffic.
     // Splits come in multiples of 8 so that the XCD-aware 1-D grid gives every XCD whole splits.
-    TTSMI_KNOB(target_env, "TTSMI_WGRAD_WGS", 128);
-    const int target = target_env < 8 ? 128 : target_env;
+    // (big weights - >= 64 output tiles, the conv blocks' [3 x 384, 1536] / [3 x 1536, 384] - are 100 GFLOP launches that
+    // make the second stream as long as the main one: there a full-GPU launch pays, 27.3 -> 26.2 ms per ref-default step;
+    // the dense blocks' 4-16-tile weights stay at 128: 5.42 ms per configs[1] step against 5.50 at 192 / 5.51 at 256)
+    TTSMI_KNOB(target_env, "TTSMI_WGRAD_WGS", 0);
+    const int target = target_env >= 8 ? target_env : (tiles >= 64 ? 256 : 128);
     int want = (target + tiles - 1) / tiles;
     if (want > 8) want = (want + 7) / 8 * 8;
     int maxs = (int)((rows + 511) / 512);
