@@ -406,6 +406,15 @@ int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64
                        const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
                        uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres,
                        void* part_ws, size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream);
+/* The same with a second K segment that has its own operands: dy = dy_part + a . bt^T + a2 . bt2^T (a [M,K1], bt [256,K1];
+ * a2 [M,K-K1], bt2 [256,K-K1]; K1 % 64 == 0).  The block backward uses it to complete the gradient of a block's input in
+ * one pass over it: dqkv . Wqkv^T and d_o . Wo[:d]^T (the `q_in` half of Dense(concat([q_in, ctx])), model/layers.py:148-149)
+ * arrive in the same accumulators instead of the second product being added to the fp32 tensor by a kernel of its own. */
+int ttsmi_hgemm_ln_bwd_dual(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
+                            int64_t ldb, const uint16_t* bt2, int64_t ldb2, const float* dy_part, const uint16_t* xhat_bf16,
+                            const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in, uint32_t site_in,
+                            uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres, void* part_ws,
+                            size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream);
 int ttsmi_layernorm_bwd_xhat_nparts(int M);
 int ttsmi_layernorm_bwd_xhat(const float* dy, const uint16_t* xhat_bf16, const float* rstd, const float* gamma,
                              const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,

@@ -168,6 +168,56 @@ def test_fused_dgrad_layernorm_backward_at_the_benchmark_rows(M, K):
     assert rel_err(dg, dg_ref) < 1e-4 and rel_err(db, db_ref) < 1e-4      # fp32 column sums over 28 800 rows
 
 
+@pytest.mark.parametrize('M,kernel', [(28800, 'rowgemm_dma_kernel<1, 128>'), (6400, 'rowgemm_dma_kernel<1, 64>'),
+                                      (1000, 'rowgemm_kernel<1>')])
+def test_fused_dgrad_layernorm_backward_with_two_k_segments(M, kernel):
+    """ttsmi_hgemm_ln_bwd_dual as the chained block backward launches it: dy = dy_part + dqkv.Wqkv^T + d_o.Wo[:d]^T with
+    each K segment reading its own activation AND its own weight matrix (K = 768 + 256), then res-norm 2's backward of
+    the block below (model/layers.py:116-118,148-149 backward into :100-102)."""
+    ops, _lib, l = _env()
+    from transformertts_amd.ops import _p, _stream, check
+    N, K1, K2, pdrop, seed, stepv, site = 256, 768, 256, 0.1, 5, 9, 3
+    a1 = g(M, K1, seed=1, scale=0.3).to(torch.bfloat16)
+    a2 = g(M, K2, seed=2, scale=0.3).to(torch.bfloat16)
+    w1 = g(N, K1, seed=3, scale=0.05)                     # Wqkv as stored [256][768]
+    w2 = g(2 * N, K2, seed=4, scale=0.05)                 # Wo as stored [512][256]: only its first 256 rows take part
+    part = g(M, N, seed=10)
+    xh = g(M, N, seed=11).to(torch.bfloat16)
+    rstd = (0.5 + torch.rand(M, generator=torch.Generator().manual_seed(12))).float()
+    gam = 1 + 0.1 * g(N, seed=4)
+    pad = (torch.arange(M) % 5 == 1).to(torch.uint8)
+    live = (pad == 0).double()[:, None]
+    keep = torch.from_numpy(dr.keep_mask(seed, stepv, site, np.arange(M), np.arange(N), pdrop))
+    dy = (part.double() + a1.double() @ bf(w1).T + a2.double() @ bf(w2)[:N].T) * live
+    t = dy * gam.double()
+    x = xh.double()
+    dz = rstd.double()[:, None] * (t - t.mean(-1, keepdim=True) - x * (t * x).mean(-1, keepdim=True))
+    dx_ref = dz * keep * (1.0 / (1.0 - float(np.float32(pdrop))))
+    dg_ref, db_ref = (dy * x).sum(0), dy.sum(0)
+    w1d, w2d = w1.to(DEV).to(torch.bfloat16), w2.to(DEV).to(torch.bfloat16)
+    step = torch.full((1,), stepv, dtype=torch.int64, device=DEV)
+    dxb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    dres = torch.empty(M, N, device=DEV)
+    nw = int(l.ttsmi_hgemm_ln_bwd_nparts(M))
+    ws = torch.empty(int(l.ttsmi_layernorm_partials_bytes(nw, N)), dtype=torch.uint8, device=DEV)
+    a1d, a2d, part_d, xh_d, rstd_d, gam_d, pad_d = (t.to(DEV) for t in (a1, a2, part, xh, rstd, gam, pad))
+    check(l.ttsmi_hgemm_ln_bwd_dual(_p(a1d), K1, _p(a2d), K2, K1, _p(w1d), K1, _p(w2d), K2, _p(part_d), _p(xh_d),
+                                    _p(rstd_d), _p(gam_d), _p(pad_d), pdrop, site, seed, _p(step), _p(dxb), _p(dres),
+                                    _p(ws), ws.numel(), M, N, K1 + K2, _stream()))
+    assert last_kernel(l) == kernel
+    dg, db = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    with ops.ln_param_batch():
+        ops._ln_defer(ws, dg, db, None, M, N, nw)
+    torch.cuda.synchronize()
+    assert rel_err(dres, dz) < 2e-5
+    assert rel_err(dxb.float(), dx_ref) < 4e-3
+    assert rel_err(dg, dg_ref) < 1e-4 and rel_err(db, db_ref) < 1e-4
+    # one of the two operands of the second segment alone is an argument error, not a silent single-segment run
+    assert l.ttsmi_hgemm_ln_bwd_dual(_p(a1d), K1, _p(a2d), K2, K1, _p(w1d), K1, None, 0, _p(part_d), _p(xh_d), _p(rstd_d),
+                                     _p(gam_d), _p(pad_d), pdrop, site, seed, _p(step), _p(dxb), _p(dres), _p(ws),
+                                     ws.numel(), M, N, K1 + K2, _stream()) != 0
+
+
 @pytest.mark.parametrize('K', [512, 768, 1024])
 @pytest.mark.parametrize('mode', ['plain', 'dual', 'accumulate', 'bf16out'])
 def test_persistent_dma_gemm_at_the_benchmark_rows(K, mode):

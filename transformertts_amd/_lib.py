@@ -92,6 +92,8 @@ SIGNATURES = {
     'ttsmi_layernorm_partials_bytes': (c_size_t, [I, I]),
     'ttsmi_hgemm_ln_bwd_nparts': (I, [I]),
     'ttsmi_hgemm_ln_bwd': (I, [P, L, P, L, P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, c_size_t, I, I, I, S]),
+    'ttsmi_hgemm_ln_bwd_dual': (I, [P, L, P, L, I, P, L, P, L, P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, c_size_t,
+                                    I, I, I, S]),
     'ttsmi_layernorm_bwd_xhat_nparts': (I, [I]),
     'ttsmi_layernorm_bwd_xhat': (I, [P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, c_size_t, I, I, S]),
     'ttsmi_add_layernorm_bwd_nparts': (I, [I]),

@@ -237,7 +237,17 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     // dh += do.Wo_top^T (fp32) and dctx = do.Wo_ctx^T (bf16): Wo as stored is [2d][d] = both weight halves back to back,
     // and both products read d_o - one weight-stationary launch when the shape suits it (d = 256, decoder-size M)
     TTSMI_KNOB(split_ok, "TTSMI_DENSE_SPLIT_DGRAD", 1);           // TTSMI_DENSE_SPLIT_DGRAD=0: two launches (A/B knob)
-    if (split_ok && d == 256 && ttsmi_hgemm_k256_eligible(M, 2 * d, d)) {
+    // Chained blocks: the q_in half (do.Wo_top^T) is a second K segment of the full-row kernel that completes dh below
+    // (ttsmi_hgemm_ln_bwd_dual, K = 3d + d) - no read-modify-write of the fp32 dh (59 MB at M = 28 800) and a
+    // 256-column product at that kernel's rate instead of a launch of its own; only dctx is computed here.
+    TTSMI_KNOB(fold_knob, "TTSMI_DENSE_FOLD_DHTO", 1);
+    const bool fold = fold_knob && D->fuse_ln && D->below != nullptr;
+    if (fold) {
+        OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 2, false), st);
+        if (pre_attn) arm(D, 2);
+        TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b + (long)d * d, d, nullptr, nullptr, 0, D->dctx, d, M, d, d,
+                           TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st));
+    } else if (split_ok && d == 256 && ttsmi_hgemm_k256_eligible(M, 2 * d, d)) {
         OBS("ttsmi_hgemm_tn", 2.0 * M * d * 2 * d, gemm_bytes(M, d, d, 4, true) + gemm_bytes(M, d, d, 2, false) - (double)M * d * 2, st);
         if (pre_attn) arm(D, 2);
         TRY(ttsmi_hgemm_k256_split(D->d_o, d, D->wo_b, d, D->dh, d, d, D->dctx, d, M, 2 * d, st));
@@ -278,13 +288,15 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         // dh + dqkv.Wqkv^T is the upstream gradient of the lower block's res-norm 2: its backward runs in this epilogue
         TTSMI_CHECK_ARG(L->fuse_ln && L->ln2_done && L->B == D->B && L->T == D->T && L->d == d,
                         "dense_block_bwd: `below` is not a chained block of the same shape");
-        OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * 3 * d, gemm_bytes(M, d, 3 * d, 4, true, (double)M * d * (2 + 2)), st);
+        OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * (fold ? 4 : 3) * d, gemm_bytes(M, d, (fold ? 4 : 3) * d, 4, true, (double)M * d * (2 + 2)), st);
         // this launch produces the lower block's df: its hand-off 0 rides on this kernel (recorded here either way, so
         // the lower block only waits)
         if (L->side_stream && kernel_events() && !lazy && !t_capturing) {
             arm(L, 0);
-            const int rc_ = ttsmi_hgemm_ln_bwd(D->dqkv, 3L * d, D->wqkv_b, 3L * d, D->dh, L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate,
-                                               L->site_ln2, L->seed, L->step_dev, L->df, L->da, L->lnp_ws2, L->lnp_ws2_bytes, M, d, 3 * d, st);
+            const int rc_ = ttsmi_hgemm_ln_bwd_dual(D->dqkv, 3L * d, fold ? D->d_o : nullptr, d, fold ? 3 * d : 0, D->wqkv_b, 3L * d,
+                                                    fold ? D->wo_b : nullptr, d, D->dh, L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate,
+                                                    L->site_ln2, L->seed, L->step_dev, L->df, L->da, L->lnp_ws2, L->lnp_ws2_bytes, M, d,
+                                                    fold ? 4 * d : 3 * d, st);
             hipEvent_t left = ttsmi_take_stop_event();
             t_armed = nullptr;
             if (rc_) return rc_;
@@ -295,8 +307,9 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
             t_prerecorded = (hipEvent_t)L->ev[0];
             return TTSMI_OK;
         }
-        TRY(ttsmi_hgemm_ln_bwd(D->dqkv, 3L * d, D->wqkv_b, 3L * d, D->dh, L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate,
-                               L->site_ln2, L->seed, L->step_dev, L->df, L->da, L->lnp_ws2, L->lnp_ws2_bytes, M, d, 3 * d, st));
+        TRY(ttsmi_hgemm_ln_bwd_dual(D->dqkv, 3L * d, fold ? D->d_o : nullptr, d, fold ? 3 * d : 0, D->wqkv_b, 3L * d,
+                                    fold ? D->wo_b : nullptr, d, D->dh, L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate, L->site_ln2,
+                                    L->seed, L->step_dev, L->df, L->da, L->lnp_ws2, L->lnp_ws2_bytes, M, d, fold ? 4 * d : 3 * d, st));
         return TTSMI_OK;
     }
     OBS("ttsmi_hgemm_tn", 2.0 * M * d * 3 * d, gemm_bytes(M, d, 3 * d, 4, true), st);

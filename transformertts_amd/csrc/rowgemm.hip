@@ -31,6 +31,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 struct RowGemmP {
     const uint16_t* A; long lda; const uint16_t* A2; long lda2; int K1;     // bf16 rows, optional second K segment
     const uint16_t* Bt; long ldb;                                           // bf16 [256][K] (W^T forward, W rows backward)
+    const uint16_t* Bt2; long ldb2;                                         // optional: the second K segment has its own [256][K - K1] matrix
     int M, K;
     const float* bias;                 // [256] or NULL
     const float* res;                  // fwd: residual [M,256];  bwd: the partial gradient the GEMM result is added to
@@ -273,7 +274,8 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(RowGemmP p) {
         const int kk_ = (k0_);                                                                          \
         const bool second_ = p.A2 != nullptr && kk_ >= p.K1;                                            \
         rg_fetch<RG_BM>(second_ ? p.A2 : p.A, second_ ? p.lda2 : p.lda, p.M, m0, second_ ? kk_ - p.K1 : kk_, tid, ra); \
-        rg_fetch<RG_N>(p.Bt, p.ldb, RG_N, 0, kk_, tid, rb);                                             \
+        if (second_ && p.Bt2 != nullptr) rg_fetch<RG_N>(p.Bt2, p.ldb2, RG_N, 0, kk_ - p.K1, tid, rb);   \
+        else rg_fetch<RG_N>(p.Bt, p.ldb, RG_N, 0, kk_, tid, rb);                                        \
     } while (0)
     RG_FETCH(0);
     rg_stash<RG_BM>(As, tid, ra);
@@ -367,12 +369,15 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
             const int gm = min(m0 + row, p.M - 1);                   // rows past M: clamped on load, dropped on store
             rd_dma16(Ab + (long)gm * lda + k0 + c * 8, rd_lds_offset(As + (wave * (8 * DMA_A) + i * 8) * 128));
         }
-        const int kb = ks * RG_BK;
+        int kb = ks * RG_BK;
+        const uint16_t* Bb = p.Bt;
+        long ldb = p.ldb;
+        if (p.Bt2 != nullptr && kb >= p.K1) { Bb = p.Bt2; ldb = p.ldb2; kb -= p.K1; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave * 32 + i * 8 + drow;
             const int c = dpos ^ ((row >> 1) & 7);
-            rd_dma16(p.Bt + (long)row * p.ldb + kb + c * 8, rd_lds_offset(Bs + (wave * 32 + i * 8) * 128));
+            rd_dma16(Bb + (long)row * ldb + kb + c * 8, rd_lds_offset(Bs + (wave * 32 + i * 8) * 128));
         }
     };
     const bool dma_on = !(TTSMI_ABLATE_BITS(p.ablate) & 2);
@@ -561,9 +566,21 @@ int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64
                        const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
                        uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres,
                        void* part_ws, size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream) {
+    return ttsmi_hgemm_ln_bwd_dual(a, lda, nullptr, 0, 0, bt, ldb, nullptr, 0, dy_part, xhat_bf16, rstd, gamma, row_pad, p_in,
+                                   site_in, seed, step_dev, dx_bf16, dres, part_ws, part_ws_bytes, M, N, K, stream);
+}
+
+int ttsmi_hgemm_ln_bwd_dual(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
+                            int64_t ldb, const uint16_t* bt2, int64_t ldb2, const float* dy_part, const uint16_t* xhat_bf16,
+                            const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in, uint32_t site_in,
+                            uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres, void* part_ws,
+                            size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream) {
     RowGemmP p;
-    int rc = rg_common(p, a, lda, nullptr, 0, 0, bt, ldb, M, N, K, "hgemm_ln_bwd");
+    int rc = rg_common(p, a, lda, a2, lda2, K1, bt, ldb, M, N, K, "hgemm_ln_bwd");
     if (rc) return rc;
+    TTSMI_CHECK_ARG((a2 != nullptr) == (bt2 != nullptr), "hgemm_ln_bwd: the second K segment needs both of its operands");
+    if (bt2) TTSMI_CHECK_ARG(ldb2 % 8 == 0 && rg_al16(bt2), "hgemm_ln_bwd: bad second weight matrix");
+    p.Bt2 = bt2; p.ldb2 = ldb2;
     TTSMI_CHECK_ARG(dy_part && xhat_bf16 && rstd && gamma && dx_bf16 && dres && part_ws, "hgemm_ln_bwd: null pointer");
     p.nparts = ttsmi_hgemm_ln_bwd_nparts(M);
     TTSMI_CHECK_ARG(part_ws_bytes >= ttsmi_layernorm_partials_bytes(p.nparts, N), "hgemm_ln_bwd: partial-sum workspace too small");
