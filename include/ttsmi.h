@@ -406,6 +406,22 @@ int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64
                        const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
                        uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres,
                        void* part_ws, size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream);
+/* bf16-residual forms (see ttsmi_dense_block.res16).  _fwd_h: the residual is bf16 [M,256] and y (fp32) may be NULL.
+ * _bwd_dual_h: dy_part is bf16; dres is bf16 [M,256] when dres_is_bf16 != 0, else fp32.  _bwd_xhat_h: dres is bf16. */
+int ttsmi_hgemm_ln_fwd_h(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
+                         int64_t ldb, const float* bias, const uint16_t* res_bf16, const float* gamma, const float* beta,
+                         const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
+                         float eps, float* y, uint16_t* y_bf16, uint16_t* xhat_bf16, float* rstd, int M, int N, int K,
+                         ttsmi_stream_t stream);
+int ttsmi_hgemm_ln_bwd_dual_h(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
+                              int64_t ldb, const uint16_t* bt2, int64_t ldb2, const uint16_t* dy_part_bf16,
+                              const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
+                              uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, void* dres,
+                              int dres_is_bf16, void* part_ws, size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream);
+int ttsmi_layernorm_bwd_xhat_h(const float* dy, const uint16_t* xhat_bf16, const float* rstd, const float* gamma,
+                               const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
+                               uint16_t* dx_bf16, uint16_t* dres_bf16, void* part_ws, size_t part_ws_bytes, int M, int C,
+                               ttsmi_stream_t stream);
 /* The same with a second K segment that has its own operands: dy = dy_part + a . bt^T + a2 . bt2^T (a [M,K1], bt [256,K1];
  * a2 [M,K-K1], bt2 [256,K-K1]; K1 % 64 == 0).  The block backward uses it to complete the gradient of a block's input in
  * one pass over it: dqkv . Wqkv^T and d_o . Wo[:d]^T (the `q_in` half of Dense(concat([q_in, ctx])), model/layers.py:148-149)
@@ -482,7 +498,14 @@ typedef struct ttsmi_dense_block {
      * ln2_done != 0: its `dout` argument is ignored.  Only valid when this block is the sole consumer of the lower
      * block's output. */
     const struct ttsmi_dense_block* below;
-    int32_t ln2_done, _pad1;
+    int32_t ln2_done;
+    /* res16 != 0 (fuse_ln only): the residual stream between the fused kernels is bf16.  Forward: the residual adds read
+     * h_bf / a_bf (the tensors the GEMMs read anyway), `a` is not written and `out` only with bit 1 set (a block whose fp32
+     * output somebody reads: the last of a stack); `h` may be NULL.  Backward: `da` holds bf16 [M,d]; `dh` is bf16 when the
+     * block is chained to a lower one (`below`, which then must be res16 too) and the fp32 result of the call otherwise.
+     * bf16 rounding of a LayerNorm output / of its gradient once per kernel boundary: depth-12 parity as measured in
+     * tests/test_config1_parity_gpu.py. */
+    int32_t res16;
 } ttsmi_dense_block;
 /* ---------------------------------------------------------------------------------------------
  * Batch data parallelism for a binding WITHOUT a collective library of its own (one all-reduce of the

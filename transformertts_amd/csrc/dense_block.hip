@@ -67,7 +67,7 @@ extern "C" {
 
 int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf) {
     TRY(check_desc(D, "dense_block_fwd"));
-    TTSMI_CHECK_ARG(h && h_bf, "dense_block_fwd: null input");
+    TTSMI_CHECK_ARG(h_bf && (h || (D->fuse_ln && D->res16)), "dense_block_fwd: null input");
     const int M = D->B * D->T, d = D->d, F = D->F, dh = d / D->H;
     ttsmi_stream_t st = D->main_stream;
     // qkv = h.Wqkv + b                                                     (layers.py:116-118, fused)
@@ -88,17 +88,29 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
                                     D->step_dev, D->site_attn, TTSMI_BF16_IO, st));
     }
     if (D->fuse_ln) {
+        // res16: the residual stream between the fused kernels is the bf16 tensor the next GEMM reads anyway (h_bf, a_bf,
+        // out_bf) - the fp32 copies are neither read nor, except for a requested block output (bit 1), written
+        const bool r16 = D->res16 != 0;
+        float* out32 = (!r16 || (D->res16 & 2)) ? D->out : nullptr;
         // a = LN(drop([h | ctx].Wo + b) + h) * mask in ONE launch            (layers.py:148-150,211,229)
-        { OBS("ttsmi_hgemm_ln_fwd", 2.0 * M * d * 2 * d, gemm_bytes(M, d, 2 * d, 4, false, (double)M * d * (4 + 2 + 2)), st);
-          TRY(ttsmi_hgemm_ln_fwd(h_bf, d, D->cx, d, d, D->wo_t, 2L * d, D->bo, h, D->ln1_g, D->ln1_b, D->pad, D->rate,
-                                 D->site_ln1, D->seed, D->step_dev, kLnEps, D->a, D->a_bf, D->xhat1, D->rstd1, M, d, 2 * d, st)); }
+        { OBS("ttsmi_hgemm_ln_fwd", 2.0 * M * d * 2 * d, gemm_bytes(M, d, 2 * d, r16 ? 0 : 4, false, (double)M * d * ((r16 ? 2 : 4) + 2 + 2)), st);
+          if (r16)
+              TRY(ttsmi_hgemm_ln_fwd_h(h_bf, d, D->cx, d, d, D->wo_t, 2L * d, D->bo, h_bf, D->ln1_g, D->ln1_b, D->pad, D->rate,
+                                       D->site_ln1, D->seed, D->step_dev, kLnEps, nullptr, D->a_bf, D->xhat1, D->rstd1, M, d, 2 * d, st));
+          else
+              TRY(ttsmi_hgemm_ln_fwd(h_bf, d, D->cx, d, d, D->wo_t, 2L * d, D->bo, h, D->ln1_g, D->ln1_b, D->pad, D->rate,
+                                     D->site_ln1, D->seed, D->step_dev, kLnEps, D->a, D->a_bf, D->xhat1, D->rstd1, M, d, 2 * d, st)); }
         { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false), st);
           TRY(ttsmi_hgemm_tn(D->a_bf, 0, d, nullptr, 0, 0, D->w1_t, d, D->b1, nullptr, 0, D->h1, F, M, F, d,
                              TTSMI_GEMM_RELU | TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
-        OBS("ttsmi_hgemm_ln_fwd", 2.0 * M * d * F, gemm_bytes(M, d, F, 4, false, (double)M * d * (4 + 2 + 2)), st);
+        OBS("ttsmi_hgemm_ln_fwd", 2.0 * M * d * F, gemm_bytes(M, d, F, out32 ? 4 : 0, false, (double)M * d * ((r16 ? 2 : 4) + 2 + 2)), st);
         // out = LN(drop(h1.W2 + b2) + a) * mask in ONE launch                (layers.py:100-102,230)
-        TRY(ttsmi_hgemm_ln_fwd(D->h1, F, nullptr, 0, 0, D->w2_t, F, D->b2, D->a, D->ln2_g, D->ln2_b, D->pad, D->rate,
-                               D->site_ln2, D->seed, D->step_dev, kLnEps, D->out, D->out_bf, D->xhat2, D->rstd2, M, d, F, st));
+        if (r16)
+            TRY(ttsmi_hgemm_ln_fwd_h(D->h1, F, nullptr, 0, 0, D->w2_t, F, D->b2, D->a_bf, D->ln2_g, D->ln2_b, D->pad, D->rate,
+                                     D->site_ln2, D->seed, D->step_dev, kLnEps, out32, D->out_bf, D->xhat2, D->rstd2, M, d, F, st));
+        else
+            TRY(ttsmi_hgemm_ln_fwd(D->h1, F, nullptr, 0, 0, D->w2_t, F, D->b2, D->a, D->ln2_g, D->ln2_b, D->pad, D->rate,
+                                   D->site_ln2, D->seed, D->step_dev, kLnEps, D->out, D->out_bf, D->xhat2, D->rstd2, M, d, F, st));
         return TTSMI_OK;
     }
     // o = [h | ctx].Wo + b                                                 (layers.py:148-149)
@@ -114,6 +126,23 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
     TRY(ttsmi_add_layernorm_fwd(D->f, D->a, D->ln2_g, D->ln2_b, nullptr, nullptr, 0, D->pad, D->rate, D->site_ln2, 0.f, 0,
                                 D->seed, D->step_dev, kLnEps, D->out, D->mean2, D->rstd2, M, d, D->out_bf, st));
     return TTSMI_OK;
+}
+
+// The last launch of a chained block: dy = dh + dqkv.Wqkv^T (+ d_o.Wo[:d]^T when folded) is the upstream gradient of the
+// lower block's res-norm 2, whose backward runs in the epilogue -> L->df (bf16), L->da (fp32, or bf16 with res16)
+static int chained_ln2(const ttsmi_dense_block* D, const ttsmi_dense_block* L, bool fold, bool dh16, int M, int d, ttsmi_stream_t st) {
+    if (dh16 || L->res16) {
+        if (!dh16) {
+            ttsmi_set_error("dense_block_bwd: a res16 chain needs the folded output-projection dgrad (TTSMI_DENSE_FOLD_DHTO)");
+            return TTSMI_ERR_INVALID_ARG;
+        }
+        return ttsmi_hgemm_ln_bwd_dual_h(D->dqkv, 3L * d, D->d_o, d, 3 * d, D->wqkv_b, 3L * d, D->wo_b, d, (const uint16_t*)D->dh,
+                                         L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate, L->site_ln2, L->seed, L->step_dev, L->df,
+                                         L->da, 1, L->lnp_ws2, L->lnp_ws2_bytes, M, d, 4 * d, st);
+    }
+    return ttsmi_hgemm_ln_bwd_dual(D->dqkv, 3L * d, fold ? D->d_o : nullptr, d, fold ? 3 * d : 0, D->wqkv_b, 3L * d,
+                                   fold ? D->wo_b : nullptr, d, D->dh, L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate, L->site_ln2,
+                                   L->seed, L->step_dev, L->df, L->da, L->lnp_ws2, L->lnp_ws2_bytes, M, d, fold ? 4 * d : 3 * d, st);
 }
 
 // The block's weight gradients leave their slab reductions to ONE batched launch at the end of the block's backward
@@ -180,7 +209,13 @@ static int wgrad_side(const ttsmi_dense_block* D, WgradBatch* wb, int ev, bool r
 
 int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf, const float* dout) {
     TRY(check_desc(D, "dense_block_bwd"));
-    TTSMI_CHECK_ARG(h && h_bf && (dout || (D->fuse_ln && D->ln2_done)), "dense_block_bwd: null input");
+    TTSMI_CHECK_ARG(h_bf && (h || D->fuse_ln) && (dout || (D->fuse_ln && D->ln2_done)), "dense_block_bwd: null input");
+    // res16: the gradient of the residual stream travels as bf16 between the fused kernels - `da` always, `dh` when this
+    // block's last launch is the chained full-row kernel that consumes it (otherwise dh is the fp32 result of the call)
+    const bool r16 = D->fuse_ln && D->res16 != 0;
+    TTSMI_KNOB(fold_knob, "TTSMI_DENSE_FOLD_DHTO", 1);
+    const bool fold = fold_knob && D->fuse_ln && D->below != nullptr;
+    const bool dh16 = r16 && fold;
     const int M = D->B * D->T, d = D->d, F = D->F, dh = d / D->H;
     ttsmi_stream_t st = D->main_stream;
     const bool dropout = D->rate > 0.f;
@@ -202,8 +237,12 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
             TTSMI_CHECK_ARG(dout, "dense_block_bwd: null dout");
             OBS("ttsmi_layernorm_bwd_xhat", 0.0, (double)M * d * (4 + 2 + 2 + 4), st);
             if (!lazy) arm(D, 0);
-            TRY(ttsmi_layernorm_bwd_xhat(dout, D->xhat2, D->rstd2, D->ln2_g, D->pad, D->rate, D->site_ln2, D->seed, D->step_dev,
-                                         D->df, D->da, D->lnp_ws2, D->lnp_ws2_bytes, M, d, st));
+            if (r16)
+                TRY(ttsmi_layernorm_bwd_xhat_h(dout, D->xhat2, D->rstd2, D->ln2_g, D->pad, D->rate, D->site_ln2, D->seed, D->step_dev,
+                                               D->df, (uint16_t*)D->da, D->lnp_ws2, D->lnp_ws2_bytes, M, d, st));
+            else
+                TRY(ttsmi_layernorm_bwd_xhat(dout, D->xhat2, D->rstd2, D->ln2_g, D->pad, D->rate, D->site_ln2, D->seed, D->step_dev,
+                                             D->df, D->da, D->lnp_ws2, D->lnp_ws2_bytes, M, d, st));
         }
     } else
         TRY(ttsmi_add_layernorm_bwd(dout, D->f, D->a, D->ln2_g, D->mean2, D->rstd2, nullptr, nullptr, 0, D->pad, D->rate,
@@ -220,8 +259,13 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         // (da + dh1.W1^T) never reaches HBM: res-norm 1's backward runs in the dgrad's epilogue -> d_o (bf16), dh (fp32)
         OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * F, gemm_bytes(M, d, F, 4, true, (double)M * d * (2 + 2)), st);
         if (!lazy) arm(D, 2);
-        TRY(ttsmi_hgemm_ln_bwd(D->dh1, F, D->w1_b, F, D->da, D->xhat1, D->rstd1, D->ln1_g, D->pad, D->rate, D->site_ln1,
-                               D->seed, D->step_dev, D->d_o, D->dh, D->lnp_ws1, D->lnp_ws1_bytes, M, d, F, st));
+        if (r16)
+            TRY(ttsmi_hgemm_ln_bwd_dual_h(D->dh1, F, nullptr, 0, 0, D->w1_b, F, nullptr, 0, (const uint16_t*)D->da, D->xhat1, D->rstd1,
+                                          D->ln1_g, D->pad, D->rate, D->site_ln1, D->seed, D->step_dev, D->d_o, D->dh, dh16 ? 1 : 0,
+                                          D->lnp_ws1, D->lnp_ws1_bytes, M, d, F, st));
+        else
+            TRY(ttsmi_hgemm_ln_bwd(D->dh1, F, D->w1_b, F, D->da, D->xhat1, D->rstd1, D->ln1_g, D->pad, D->rate, D->site_ln1,
+                                   D->seed, D->step_dev, D->d_o, D->dh, D->lnp_ws1, D->lnp_ws1_bytes, M, d, F, st));
     } else {
         TRY(ttsmi_hgemm_tn(D->dh1, 0, F, nullptr, 0, 0, D->w1_b, F, nullptr, nullptr, 0, D->da, d, M, d, F,
                            TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                   // da += dh1.W1^T
@@ -240,8 +284,6 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     // Chained blocks: the q_in half (do.Wo_top^T) is a second K segment of the full-row kernel that completes dh below
     // (ttsmi_hgemm_ln_bwd_dual, K = 3d + d) - no read-modify-write of the fp32 dh (59 MB at M = 28 800) and a
     // 256-column product at that kernel's rate instead of a launch of its own; only dctx is computed here.
-    TTSMI_KNOB(fold_knob, "TTSMI_DENSE_FOLD_DHTO", 1);
-    const bool fold = fold_knob && D->fuse_ln && D->below != nullptr;
     if (fold) {
         OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 2, false), st);
         if (pre_attn) arm(D, 2);
@@ -286,17 +328,14 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     const ttsmi_dense_block* L = D->below;
     if (D->fuse_ln && L != nullptr) {
         // dh + dqkv.Wqkv^T is the upstream gradient of the lower block's res-norm 2: its backward runs in this epilogue
-        TTSMI_CHECK_ARG(L->fuse_ln && L->ln2_done && L->B == D->B && L->T == D->T && L->d == d,
-                        "dense_block_bwd: `below` is not a chained block of the same shape");
+        TTSMI_CHECK_ARG(L->fuse_ln && L->ln2_done && L->B == D->B && L->T == D->T && L->d == d && (L->res16 != 0) == (D->res16 != 0),
+                        "dense_block_bwd: `below` is not a chained block of the same shape and residual type");
         OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * (fold ? 4 : 3) * d, gemm_bytes(M, d, (fold ? 4 : 3) * d, 4, true, (double)M * d * (2 + 2)), st);
         // this launch produces the lower block's df: its hand-off 0 rides on this kernel (recorded here either way, so
         // the lower block only waits)
         if (L->side_stream && kernel_events() && !lazy && !t_capturing) {
             arm(L, 0);
-            const int rc_ = ttsmi_hgemm_ln_bwd_dual(D->dqkv, 3L * d, fold ? D->d_o : nullptr, d, fold ? 3 * d : 0, D->wqkv_b, 3L * d,
-                                                    fold ? D->wo_b : nullptr, d, D->dh, L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate,
-                                                    L->site_ln2, L->seed, L->step_dev, L->df, L->da, L->lnp_ws2, L->lnp_ws2_bytes, M, d,
-                                                    fold ? 4 * d : 3 * d, st);
+            const int rc_ = chained_ln2(D, L, fold, dh16, M, d, st);
             hipEvent_t left = ttsmi_take_stop_event();
             t_armed = nullptr;
             if (rc_) return rc_;
@@ -307,9 +346,7 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
             t_prerecorded = (hipEvent_t)L->ev[0];
             return TTSMI_OK;
         }
-        TRY(ttsmi_hgemm_ln_bwd_dual(D->dqkv, 3L * d, fold ? D->d_o : nullptr, d, fold ? 3 * d : 0, D->wqkv_b, 3L * d,
-                                    fold ? D->wo_b : nullptr, d, D->dh, L->xhat2, L->rstd2, L->ln2_g, L->pad, L->rate, L->site_ln2,
-                                    L->seed, L->step_dev, L->df, L->da, L->lnp_ws2, L->lnp_ws2_bytes, M, d, fold ? 4 * d : 3 * d, st));
+        TRY(chained_ln2(D, L, fold, dh16, M, d, st));
         return TTSMI_OK;
     }
     OBS("ttsmi_hgemm_tn", 2.0 * M * d * 3 * d, gemm_bytes(M, d, 3 * d, 4, true), st);

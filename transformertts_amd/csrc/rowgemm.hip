@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -96,22 +97,27 @@ __device__ __forceinline__ void rg_stash(uint16_t (*S)[RG_LD], int tid, const ui
 // rstd for the backward) are one load by lanes 0..RPW-1 each, read back per row with a lane broadcast: no global load is
 // left inside the row loop - a load there meant an `s_waitcnt vmcnt(0)` per row, which also waited for the previous
 // row's STORES (vmcnt counts both) and serialised the store latency of all 16 rows.
-template <int EPI, int RPW>
+// RT: the types of the residual stream.  bit 0: the residual INPUT (fwd: res, bwd: dy_part) is bf16 instead of fp32;
+// bit 1 (bwd): the residual OUTPUT dres is written as bf16.  (fwd: the fp32 y is simply not stored when p.y is NULL.)
+template <int EPI, int RPW, int RT>
 struct RgPre {
-    float4 rs[RPW];
+    typename std::conditional<(RT & 1) != 0, uint2, float4>::type rs[RPW];
     uint2 xs[EPI == 1 ? RPW : 1];
     float rstd_l;            // lane i < RPW: rstd of row i (EPI 1)
     int pad_l;               // lane i < RPW: padding flag of row i
 };
+__device__ __forceinline__ void rg_res4(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void rg_res4(const uint2& v, float (&o)[4]) { rg_unpack4(v, o); }
 #define RG_NPRE(EPI, RPW) ((RPW) * ((EPI) == 1 ? 2 : 1) + ((EPI) == 1 ? 2 : 1))      // vector-memory instructions of rg_prefetch
-template <int EPI, int NW, int BM>
-__device__ __forceinline__ void rg_prefetch(const RowGemmP& p, int m0, int wave, int lane, RgPre<EPI, BM / NW>& pre) {
+template <int EPI, int NW, int BM, int RT>
+__device__ __forceinline__ void rg_prefetch(const RowGemmP& p, int m0, int wave, int lane, RgPre<EPI, BM / NW, RT>& pre) {
     constexpr int RPW = BM / NW;
     const int c4 = lane * 4;
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {                    // every row of this wave in flight at once
         const int row = min(m0 + wave * RPW + i, p.M - 1);
-        pre.rs[i] = *reinterpret_cast<const float4*>(p.res + (long)row * RG_N + c4);
+        if constexpr ((RT & 1) != 0) pre.rs[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.res) + (long)row * RG_N + c4);
+        else pre.rs[i] = *reinterpret_cast<const float4*>(p.res + (long)row * RG_N + c4);
         if constexpr (EPI == 1) pre.xs[i] = *reinterpret_cast<const uint2*>(p.xhat_in + (long)row * RG_N + c4);
     }
     // (always the same number of instructions - the LDS-DMA kernel counts them on vmcnt: without a padding mask the
@@ -125,9 +131,9 @@ __device__ __forceinline__ void rg_prefetch(const RowGemmP& p, int m0, int wave,
 }
 
 // NJ = 32-column blocks of a wave's accumulator tile (4: waves 2-wide over the 256 columns; 2: 4-wide)
-template <int EPI, int NW, int BM, int NJ = 4>
+template <int EPI, int NW, int BM, int RT, int NJ = 4>
 __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ], int m0, float* Z, int wave, int wm, int wc,
-                                            int lane, const RgPre<EPI, BM / NW>& pre) {
+                                            int lane, const RgPre<EPI, BM / NW, RT>& pre) {
     const int l31 = lane & 31, hh = lane >> 5;
     // ---- accumulators -> Z (all waves finished reading the operand stages: the caller synchronised)
     {
@@ -148,11 +154,12 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
         const float4 bs = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c4);
         const float4 bt = *reinterpret_cast<const float4*>(p.beta + c4);
-        const float4 (&rs)[RPW] = pre.rs;
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int rl = wave * RPW + i, row = m0 + rl;
             if (row >= p.M) break;                                     // wave-uniform
+            float rs4[4];
+            rg_res4(pre.rs[i], rs4);
             const float4 a = *reinterpret_cast<const float4*>(Z + rl * RG_ZLD + c4);
             float v[4] = {a.x + bs.x, a.y + bs.y, a.z + bs.z, a.w + bs.w};
             if (p.thr_in) {
@@ -163,7 +170,7 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
                 v[2] *= ((h1 & 0xFFFFu) >= p.thr_in) ? p.inv_in : 0.f;
                 v[3] *= ((h1 >> 16) >= p.thr_in) ? p.inv_in : 0.f;
             }
-            v[0] += rs[i].x; v[1] += rs[i].y; v[2] += rs[i].z; v[3] += rs[i].w;
+            v[0] += rs4[0]; v[1] += rs4[1]; v[2] += rs4[2]; v[3] += rs4[3];
             const float mean = wave_sum_dpp(v[0] + v[1] + v[2] + v[3]) * invC;
             float q = 0.f;
 #pragma unroll
@@ -180,7 +187,7 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
             if (padded) { yv[0] = 0.f; yv[1] = 0.f; yv[2] = 0.f; yv[3] = 0.f; }
             const long o = (long)row * RG_N + c4;
             if (TTSMI_ABLATE_BITS(p.ablate) & 8) continue;                     // (measurement: the epilogue without its global stores)
-            *reinterpret_cast<float4*>(p.y + o) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+            if (p.y != nullptr) *reinterpret_cast<float4*>(p.y + o) = make_float4(yv[0], yv[1], yv[2], yv[3]);   // (wave-uniform)
             *reinterpret_cast<uint2*>(p.y_bf + o) = rg_pack4(yv[0], yv[1], yv[2], yv[3]);
             *reinterpret_cast<uint2*>(p.xhat + o) = rg_pack4(xh[0], xh[1], xh[2], xh[3]);
         }
@@ -189,7 +196,6 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
         // d_o = keep(dz) (bf16), dres = dz (fp32); dgamma += g x^, dbeta += g summed over the tile's rows
         const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c4);
         float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
-        const float4 (&rs)[RPW] = pre.rs;
         const uint2 (&xs)[RPW] = pre.xs;
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
@@ -198,7 +204,9 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
             const float4 a = *reinterpret_cast<const float4*>(Z + rl * RG_ZLD + c4);
             const bool padded = __builtin_amdgcn_readlane(pre.pad_l, i) != 0;
             const float rstd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.rstd_l), i));
-            float gv[4] = {a.x + rs[i].x, a.y + rs[i].y, a.z + rs[i].z, a.w + rs[i].w};
+            float rs4[4];
+            rg_res4(pre.rs[i], rs4);
+            float gv[4] = {a.x + rs4[0], a.y + rs4[1], a.z + rs4[2], a.w + rs4[3]};
             if (padded) { gv[0] = 0.f; gv[1] = 0.f; gv[2] = 0.f; gv[3] = 0.f; }
             float xh[4];
             rg_unpack4(xs[i], xh);
@@ -222,7 +230,8 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dx[e] = dz[e];
             }
-            *reinterpret_cast<float4*>(p.dres + o) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+            if constexpr ((RT & 2) != 0) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.dres) + o) = rg_pack4(dz[0], dz[1], dz[2], dz[3]);
+            else *reinterpret_cast<float4*>(p.dres + o) = make_float4(dz[0], dz[1], dz[2], dz[3]);
             *reinterpret_cast<uint2*>(p.dx_bf + o) = rg_pack4(dx[0], dx[1], dx[2], dx[3]);
         }
         // parameter-gradient partials of the tile: waves summed through LDS in wave order (deterministic), one partial
@@ -250,7 +259,7 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
 }
 
 // EPI: 0 = LayerNorm forward, 1 = LayerNorm backward
-template <int EPI>
+template <int EPI, int RT = 0>
 __global__ __launch_bounds__(256, 2) void rowgemm_kernel(RowGemmP p) {
     constexpr int TILE_BYTES = (RG_BM + RG_N) * RG_LD * 2, Z_BYTES = RG_BM * RG_ZLD * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > Z_BYTES ? TILE_BYTES : Z_BYTES];
@@ -302,9 +311,9 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(RowGemmP p) {
         __syncthreads();
     }
 
-    RgPre<EPI, RG_BM / 4> pre;
-    rg_prefetch<EPI, 4, RG_BM>(p, m0, wave, lane, pre);
-    rg_epilogue<EPI, 4, RG_BM>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
+    RgPre<EPI, RG_BM / 4, RT> pre;
+    rg_prefetch<EPI, 4, RG_BM, RT>(p, m0, wave, lane, pre);
+    rg_epilogue<EPI, 4, RG_BM, RT>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
 }
 
 // =================================================================================================
@@ -332,7 +341,7 @@ __device__ __forceinline__ unsigned rd_lds_offset(const void* p) {
 // BM = 128: waves 4 (rows) x 2 (columns), wave tile 32 x 128.  BM = 64: waves 2 x 4, wave tile 32 x 64 - for launches whose
 // 128-row tiles would occupy fewer than half the CUs (the encoder side, M = 6 400: 50 workgroups): twice the workgroups,
 // each with a shorter fill per k-step (40 KB) and half the epilogue.
-template <int EPI, int BM>
+template <int EPI, int BM, int RT = 0>
 __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
     constexpr int NJ = BM == 128 ? 4 : 2;                  // 32-column blocks per wave
     constexpr int STAGE = (BM + RG_N) * RG_BK * 2;
@@ -389,8 +398,8 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
     // 0 and 1 and older than every later one
     constexpr int NPRE = RG_NPRE(EPI, BM / 8), NDMA = 4 + DMA_A;
     static_assert(NDMA + NPRE <= 63, "vmcnt is a 6-bit counter");
-    RgPre<EPI, BM / 8> pre;
-    rg_prefetch<EPI, 8, BM>(p, m0, wave, lane, pre);
+    RgPre<EPI, BM / 8, RT> pre;
+    rg_prefetch<EPI, 8, BM, RT>(p, m0, wave, lane, pre);
     for (int ks = 0; ks < nk; ++ks) {
         // step ks has landed once at most the newest step's 6 DMA instructions (and, for the first two steps, the
         // prefetch behind them) are outstanding
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
     }
     __syncthreads();
     if (TTSMI_ABLATE_BITS(p.ablate) & 4) return;
-    rg_epilogue<EPI, 8, BM, NJ>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
+    rg_epilogue<EPI, 8, BM, RT, NJ>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
 }
 
 // ---- standalone backward of a LayerNorm whose forward kept x^ (bf16) and rstd: the fused forward's counterpart for the
@@ -437,6 +446,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
 #define LNX_MAX_BLOCKS 1024
 static int lnx_blocks(int M) { int b = ttsmi_cdiv(M, 4); return b > LNX_MAX_BLOCKS ? LNX_MAX_BLOCKS : (b < 1 ? 1 : b); }
 
+template <bool OUT_H>
 __global__ __launch_bounds__(256) void ln_bwd_xhat_kernel(RowGemmP p, const float* __restrict__ dy) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwaves = gridDim.x * 4;
@@ -472,7 +482,8 @@ __global__ __launch_bounds__(256) void ln_bwd_xhat_kernel(RowGemmP p, const floa
 #pragma unroll
             for (int e = 0; e < 4; ++e) dx[e] = dz[e];
         }
-        *reinterpret_cast<float4*>(p.dres + base) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        if constexpr (OUT_H) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.dres) + base) = rg_pack4(dz[0], dz[1], dz[2], dz[3]);
+        else *reinterpret_cast<float4*>(p.dres + base) = make_float4(dz[0], dz[1], dz[2], dz[3]);
         *reinterpret_cast<uint2*>(p.dx_bf + base) = rg_pack4(dx[0], dx[1], dx[2], dx[3]);
     }
     __shared__ float red[3][2][RG_N];
@@ -533,6 +544,90 @@ static void rg_drop(RowGemmP& p, float p_in, uint32_t site_in, uint64_t seed, co
     p.seed = seed; p.step_dev = step_dev; p.site_in = site_in;
 }
 
+// launch by (rows, residual types): the kernel names reported through ttsmi_last_kernel keep their round-2 spelling for RT = 0
+template <int EPI, int RT>
+static void rg_launch(const RowGemmP& p, int M, ttsmi_stream_t stream) {
+    static const char* const names[3] = {
+        EPI == 0 ? (RT ? "rowgemm_dma_kernel<0, 64, 1>" : "rowgemm_dma_kernel<0, 64>")
+                 : (RT == 3 ? "rowgemm_dma_kernel<1, 64, 3>" : RT == 1 ? "rowgemm_dma_kernel<1, 64, 1>" : "rowgemm_dma_kernel<1, 64>"),
+        EPI == 0 ? (RT ? "rowgemm_dma_kernel<0, 128, 1>" : "rowgemm_dma_kernel<0, 128>")
+                 : (RT == 3 ? "rowgemm_dma_kernel<1, 128, 3>" : RT == 1 ? "rowgemm_dma_kernel<1, 128, 1>" : "rowgemm_dma_kernel<1, 128>"),
+        EPI == 0 ? (RT ? "rowgemm_kernel<0, 1>" : "rowgemm_kernel<0>")
+                 : (RT == 3 ? "rowgemm_kernel<1, 3>" : RT == 1 ? "rowgemm_kernel<1, 1>" : "rowgemm_kernel<1>")};
+    if (rg_use_dma(M)) {
+        if (rg_dma_bm(M) == 64) {
+            ttsmi_note_kernel(names[0]);
+            TTSMI_LAUNCH_EV((rowgemm_dma_kernel<EPI, 64, RT>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
+        } else {
+            ttsmi_note_kernel(names[1]);
+            TTSMI_LAUNCH_EV((rowgemm_dma_kernel<EPI, RD_BM, RT>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
+        }
+    } else {
+        ttsmi_note_kernel(names[2]);
+        TTSMI_LAUNCH_EV((rowgemm_kernel<EPI, RT>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p);
+    }
+}
+
+static int rg_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt, int64_t ldb,
+                  const float* bias, const void* res, bool res_h, const float* gamma, const float* beta, const uint8_t* row_pad,
+                  float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev, float eps, float* y, uint16_t* y_bf16,
+                  uint16_t* xhat_bf16, float* rstd, int M, int N, int K, ttsmi_stream_t stream) {
+    RowGemmP p;
+    int rc = rg_common(p, a, lda, a2, lda2, K1, bt, ldb, M, N, K, "hgemm_ln_fwd");
+    if (rc) return rc;
+    TTSMI_CHECK_ARG(res && gamma && beta && (y || res_h) && y_bf16 && xhat_bf16 && rstd, "hgemm_ln_fwd: null pointer");
+    TTSMI_CHECK_ARG(p_in >= 0.f && p_in < 1.f, "hgemm_ln_fwd: dropout rate out of [0,1)");
+    p.bias = bias; p.res = (const float*)res; p.gamma = gamma; p.beta = beta; p.row_pad = row_pad; p.eps = eps;
+    p.y = y; p.y_bf = y_bf16; p.xhat = xhat_bf16; p.rstd = rstd;
+    rg_drop(p, p_in, site_in, seed, step_dev);
+    if (res_h) rg_launch<0, 1>(p, M, stream); else rg_launch<0, 0>(p, M, stream);
+    TTSMI_CHECK_LAUNCH("hgemm_ln_fwd");
+    return TTSMI_OK;
+}
+
+static int rg_bwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt, int64_t ldb,
+                  const uint16_t* bt2, int64_t ldb2, const void* dy_part, bool part_h, const uint16_t* xhat_bf16, const float* rstd,
+                  const float* gamma, const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
+                  uint16_t* dx_bf16, void* dres, bool dres_h, void* part_ws, size_t part_ws_bytes, int M, int N, int K,
+                  ttsmi_stream_t stream) {
+    RowGemmP p;
+    int rc = rg_common(p, a, lda, a2, lda2, K1, bt, ldb, M, N, K, "hgemm_ln_bwd");
+    if (rc) return rc;
+    TTSMI_CHECK_ARG((a2 != nullptr) == (bt2 != nullptr), "hgemm_ln_bwd: the second K segment needs both of its operands");
+    if (bt2) TTSMI_CHECK_ARG(ldb2 % 8 == 0 && rg_al16(bt2), "hgemm_ln_bwd: bad second weight matrix");
+    TTSMI_CHECK_ARG(part_h || !dres_h, "hgemm_ln_bwd: a bf16 dres needs a bf16 dy_part (residual types: fp32/fp32, bf16/fp32, bf16/bf16)");
+    p.Bt2 = bt2; p.ldb2 = ldb2;
+    TTSMI_CHECK_ARG(dy_part && xhat_bf16 && rstd && gamma && dx_bf16 && dres && part_ws, "hgemm_ln_bwd: null pointer");
+    p.nparts = ttsmi_hgemm_ln_bwd_nparts(M);
+    TTSMI_CHECK_ARG(part_ws_bytes >= ttsmi_layernorm_partials_bytes(p.nparts, N), "hgemm_ln_bwd: partial-sum workspace too small");
+    p.res = (const float*)dy_part; p.xhat_in = xhat_bf16; p.rstd_in = rstd; p.gamma = gamma; p.row_pad = row_pad;
+    p.dx_bf = dx_bf16; p.dres = (float*)dres; p.part = (float*)part_ws;
+    rg_drop(p, p_in, site_in, seed, step_dev);
+    if (part_h && dres_h) rg_launch<1, 3>(p, M, stream);
+    else if (part_h) rg_launch<1, 1>(p, M, stream);
+    else rg_launch<1, 0>(p, M, stream);
+    TTSMI_CHECK_LAUNCH("hgemm_ln_bwd");
+    return TTSMI_OK;
+}
+
+static int rg_lnx(const float* dy, const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad,
+                  float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, void* dres, bool dres_h,
+                  void* part_ws, size_t part_ws_bytes, int M, int C, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(dy && xhat_bf16 && rstd && gamma && dx_bf16 && dres && part_ws && M > 0, "layernorm_bwd_xhat: null pointer");
+    TTSMI_CHECK_ARG(C == RG_N, "layernorm_bwd_xhat: built for C = %d (got %d)", RG_N, C);
+    RowGemmP p;
+    memset(&p, 0, sizeof(p));
+    p.nparts = lnx_blocks(M);
+    TTSMI_CHECK_ARG(part_ws_bytes >= ttsmi_layernorm_partials_bytes(p.nparts, C), "layernorm_bwd_xhat: partial-sum workspace too small");
+    p.M = M; p.xhat_in = xhat_bf16; p.rstd_in = rstd; p.gamma = gamma; p.row_pad = row_pad;
+    p.dx_bf = dx_bf16; p.dres = (float*)dres; p.part = (float*)part_ws;
+    rg_drop(p, p_in, site_in, seed, step_dev);
+    if (dres_h) TTSMI_LAUNCH_EV(ln_bwd_xhat_kernel<true>, dim3(p.nparts), dim3(256), 0, (hipStream_t)stream, p, dy);
+    else TTSMI_LAUNCH_EV(ln_bwd_xhat_kernel<false>, dim3(p.nparts), dim3(256), 0, (hipStream_t)stream, p, dy);
+    TTSMI_CHECK_LAUNCH("layernorm_bwd_xhat");
+    return TTSMI_OK;
+}
+
 extern "C" {
 
 int ttsmi_hgemm_ln_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
@@ -540,22 +635,16 @@ int ttsmi_hgemm_ln_fwd(const uint16_t* a, int64_t lda, const uint16_t* a2, int64
                        const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
                        float eps, float* y, uint16_t* y_bf16, uint16_t* xhat_bf16, float* rstd, int M, int N, int K,
                        ttsmi_stream_t stream) {
-    RowGemmP p;
-    int rc = rg_common(p, a, lda, a2, lda2, K1, bt, ldb, M, N, K, "hgemm_ln_fwd");
-    if (rc) return rc;
-    TTSMI_CHECK_ARG(res && gamma && beta && y && y_bf16 && xhat_bf16 && rstd, "hgemm_ln_fwd: null pointer");
-    TTSMI_CHECK_ARG(p_in >= 0.f && p_in < 1.f, "hgemm_ln_fwd: dropout rate out of [0,1)");
-    p.bias = bias; p.res = res; p.gamma = gamma; p.beta = beta; p.row_pad = row_pad; p.eps = eps;
-    p.y = y; p.y_bf = y_bf16; p.xhat = xhat_bf16; p.rstd = rstd;
-    rg_drop(p, p_in, site_in, seed, step_dev);
-    if (rg_use_dma(M)) {
-        ttsmi_note_kernel(rg_dma_bm(M) == 64 ? "rowgemm_dma_kernel<0, 64>" : "rowgemm_dma_kernel<0, 128>");
-        if (rg_dma_bm(M) == 64) TTSMI_LAUNCH_EV((rowgemm_dma_kernel<0, 64>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
-        else TTSMI_LAUNCH_EV((rowgemm_dma_kernel<0, RD_BM>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
-    }
-    else { ttsmi_note_kernel("rowgemm_kernel<0>"); TTSMI_LAUNCH_EV((rowgemm_kernel<0>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p); }
-    TTSMI_CHECK_LAUNCH("hgemm_ln_fwd");
-    return TTSMI_OK;
+    return rg_fwd(a, lda, a2, lda2, K1, bt, ldb, bias, res, false, gamma, beta, row_pad, p_in, site_in, seed, step_dev, eps, y,
+                  y_bf16, xhat_bf16, rstd, M, N, K, stream);
+}
+int ttsmi_hgemm_ln_fwd_h(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
+                         int64_t ldb, const float* bias, const uint16_t* res_bf16, const float* gamma, const float* beta,
+                         const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
+                         float eps, float* y, uint16_t* y_bf16, uint16_t* xhat_bf16, float* rstd, int M, int N, int K,
+                         ttsmi_stream_t stream) {
+    return rg_fwd(a, lda, a2, lda2, K1, bt, ldb, bias, res_bf16, true, gamma, beta, row_pad, p_in, site_in, seed, step_dev, eps, y,
+                  y_bf16, xhat_bf16, rstd, M, N, K, stream);
 }
 
 size_t ttsmi_layernorm_partials_bytes(int nparts, int C) { return (2 * (size_t)nparts * C + nparts) * sizeof(float) + 256; }
@@ -566,8 +655,8 @@ int ttsmi_hgemm_ln_bwd(const uint16_t* a, int64_t lda, const uint16_t* bt, int64
                        const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
                        uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres,
                        void* part_ws, size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream) {
-    return ttsmi_hgemm_ln_bwd_dual(a, lda, nullptr, 0, 0, bt, ldb, nullptr, 0, dy_part, xhat_bf16, rstd, gamma, row_pad, p_in,
-                                   site_in, seed, step_dev, dx_bf16, dres, part_ws, part_ws_bytes, M, N, K, stream);
+    return rg_bwd(a, lda, nullptr, 0, 0, bt, ldb, nullptr, 0, dy_part, false, xhat_bf16, rstd, gamma, row_pad, p_in, site_in, seed,
+                  step_dev, dx_bf16, dres, false, part_ws, part_ws_bytes, M, N, K, stream);
 }
 
 int ttsmi_hgemm_ln_bwd_dual(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
@@ -575,26 +664,17 @@ int ttsmi_hgemm_ln_bwd_dual(const uint16_t* a, int64_t lda, const uint16_t* a2, 
                             const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in, uint32_t site_in,
                             uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, float* dres, void* part_ws,
                             size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream) {
-    RowGemmP p;
-    int rc = rg_common(p, a, lda, a2, lda2, K1, bt, ldb, M, N, K, "hgemm_ln_bwd");
-    if (rc) return rc;
-    TTSMI_CHECK_ARG((a2 != nullptr) == (bt2 != nullptr), "hgemm_ln_bwd: the second K segment needs both of its operands");
-    if (bt2) TTSMI_CHECK_ARG(ldb2 % 8 == 0 && rg_al16(bt2), "hgemm_ln_bwd: bad second weight matrix");
-    p.Bt2 = bt2; p.ldb2 = ldb2;
-    TTSMI_CHECK_ARG(dy_part && xhat_bf16 && rstd && gamma && dx_bf16 && dres && part_ws, "hgemm_ln_bwd: null pointer");
-    p.nparts = ttsmi_hgemm_ln_bwd_nparts(M);
-    TTSMI_CHECK_ARG(part_ws_bytes >= ttsmi_layernorm_partials_bytes(p.nparts, N), "hgemm_ln_bwd: partial-sum workspace too small");
-    p.res = dy_part; p.xhat_in = xhat_bf16; p.rstd_in = rstd; p.gamma = gamma; p.row_pad = row_pad;
-    p.dx_bf = dx_bf16; p.dres = dres; p.part = (float*)part_ws;
-    rg_drop(p, p_in, site_in, seed, step_dev);
-    if (rg_use_dma(M)) {
-        ttsmi_note_kernel(rg_dma_bm(M) == 64 ? "rowgemm_dma_kernel<1, 64>" : "rowgemm_dma_kernel<1, 128>");
-        if (rg_dma_bm(M) == 64) TTSMI_LAUNCH_EV((rowgemm_dma_kernel<1, 64>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
-        else TTSMI_LAUNCH_EV((rowgemm_dma_kernel<1, RD_BM>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
-    }
-    else { ttsmi_note_kernel("rowgemm_kernel<1>"); TTSMI_LAUNCH_EV((rowgemm_kernel<1>), dim3(ttsmi_cdiv(M, RG_BM)), dim3(256), 0, (hipStream_t)stream, p); }
-    TTSMI_CHECK_LAUNCH("hgemm_ln_bwd");
-    return TTSMI_OK;
+    return rg_bwd(a, lda, a2, lda2, K1, bt, ldb, bt2, ldb2, dy_part, false, xhat_bf16, rstd, gamma, row_pad, p_in, site_in, seed,
+                  step_dev, dx_bf16, dres, false, part_ws, part_ws_bytes, M, N, K, stream);
+}
+
+int ttsmi_hgemm_ln_bwd_dual_h(const uint16_t* a, int64_t lda, const uint16_t* a2, int64_t lda2, int K1, const uint16_t* bt,
+                              int64_t ldb, const uint16_t* bt2, int64_t ldb2, const uint16_t* dy_part_bf16,
+                              const uint16_t* xhat_bf16, const float* rstd, const float* gamma, const uint8_t* row_pad, float p_in,
+                              uint32_t site_in, uint64_t seed, const int64_t* step_dev, uint16_t* dx_bf16, void* dres,
+                              int dres_is_bf16, void* part_ws, size_t part_ws_bytes, int M, int N, int K, ttsmi_stream_t stream) {
+    return rg_bwd(a, lda, a2, lda2, K1, bt, ldb, bt2, ldb2, dy_part_bf16, true, xhat_bf16, rstd, gamma, row_pad, p_in, site_in, seed,
+                  step_dev, dx_bf16, dres, dres_is_bf16 != 0, part_ws, part_ws_bytes, M, N, K, stream);
 }
 
 int ttsmi_layernorm_bwd_xhat_nparts(int M) { return lnx_blocks(M); }
@@ -603,18 +683,15 @@ int ttsmi_layernorm_bwd_xhat(const float* dy, const uint16_t* xhat_bf16, const f
                              const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
                              uint16_t* dx_bf16, float* dres, void* part_ws, size_t part_ws_bytes, int M, int C,
                              ttsmi_stream_t stream) {
-    TTSMI_CHECK_ARG(dy && xhat_bf16 && rstd && gamma && dx_bf16 && dres && part_ws && M > 0, "layernorm_bwd_xhat: null pointer");
-    TTSMI_CHECK_ARG(C == RG_N, "layernorm_bwd_xhat: built for C = %d (got %d)", RG_N, C);
-    RowGemmP p;
-    memset(&p, 0, sizeof(p));
-    p.nparts = lnx_blocks(M);
-    TTSMI_CHECK_ARG(part_ws_bytes >= ttsmi_layernorm_partials_bytes(p.nparts, C), "layernorm_bwd_xhat: partial-sum workspace too small");
-    p.M = M; p.xhat_in = xhat_bf16; p.rstd_in = rstd; p.gamma = gamma; p.row_pad = row_pad;
-    p.dx_bf = dx_bf16; p.dres = dres; p.part = (float*)part_ws;
-    rg_drop(p, p_in, site_in, seed, step_dev);
-    TTSMI_LAUNCH_EV(ln_bwd_xhat_kernel, dim3(p.nparts), dim3(256), 0, (hipStream_t)stream, p, dy);
-    TTSMI_CHECK_LAUNCH("layernorm_bwd_xhat");
-    return TTSMI_OK;
+    return rg_lnx(dy, xhat_bf16, rstd, gamma, row_pad, p_in, site_in, seed, step_dev, dx_bf16, dres, false, part_ws, part_ws_bytes,
+                  M, C, stream);
+}
+int ttsmi_layernorm_bwd_xhat_h(const float* dy, const uint16_t* xhat_bf16, const float* rstd, const float* gamma,
+                               const uint8_t* row_pad, float p_in, uint32_t site_in, uint64_t seed, const int64_t* step_dev,
+                               uint16_t* dx_bf16, uint16_t* dres_bf16, void* part_ws, size_t part_ws_bytes, int M, int C,
+                               ttsmi_stream_t stream) {
+    return rg_lnx(dy, xhat_bf16, rstd, gamma, row_pad, p_in, site_in, seed, step_dev, dx_bf16, dres_bf16, true, part_ws,
+                  part_ws_bytes, M, C, stream);
 }
 
 }  // extern "C"

@@ -218,6 +218,9 @@ class ForwardTransformer:
         self.fuse_ln = bool(kwargs.get('fuse_ln', True))               # res-norms in the GEMM epilogues (d_model 256)
         # consecutive planned blocks: the upper block's last dgrad runs the lower block's res-norm-2 backward in its epilogue
         self.chain_ln = bool(kwargs.get('chain_ln', True)) and os.environ.get('TTSMI_LN_CHAIN', '1') != '0'
+        # bf16 residual stream inside the planned dense blocks (ttsmi_dense_block.res16): the residual adds of the fused
+        # GEMM + LayerNorm kernels read the bf16 tensors the GEMMs read anyway, fp32 copies exist only at the stack ends
+        self.residual_bf16 = bool(kwargs.get('residual_bf16', True)) and os.environ.get('TTSMI_RES16', '1') != '0'
         self._use_plans, self._plans, self._plan_shared, self._plans_grown = False, {}, {}, {}
         self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}
@@ -380,7 +383,10 @@ class ForwardTransformer:
                         torch.cuda.current_stream().wait_event(ev)
                 if h_bf is None:
                     h_bf = ops.to_bf16(h)
-                plan.bind(pad, klen, rate, drop, sites, dmask)
+                nxt = i + 1
+                last = not (nxt < len(heads) and nxt < dense_blocks and self._plan_ok(f'{prefix}.blk{nxt}', heads[nxt], d))
+                plan.bind(pad, klen, rate, drop, sites, dmask, res16=self.residual_bf16,
+                          out32=last or self._taps is not None)
                 h, h_bf = ops.PlannedDenseBlockFn.apply(h, h_bf, plan)
                 if want_attn:
                     attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(

@@ -1561,9 +1561,13 @@ class DenseBlockPlan:
             above.desc.below = ctypes.addressof(self.desc)
         return ok
 
-    def bind(self, pad, klen, rate, drop, sites, dmask):
-        """Per-step inputs of the descriptor (masks are new tensors every step; the rest rarely changes)."""
+    def bind(self, pad, klen, rate, drop, sites, dmask, res16=False, out32=True):
+        """Per-step inputs of the descriptor (masks are new tensors every step; the rest rarely changes).
+        res16: bf16 residual stream between the fused kernels (ttsmi_dense_block.res16; ignored without fused LayerNorms);
+        out32: the fp32 block output is read by somebody (the last block of a stack, activation taps)."""
         D = self.desc
+        self.res16 = bool(res16) and self.fuse_ln
+        D.res16 = (1 | (2 if out32 else 0)) if self.res16 else 0
         D.pad, D.klen = pad.data_ptr(), klen.data_ptr()
         D.rate, D.seed, D.step_dev = float(rate), drop.seed, _p(drop.step_dev)
         D.site_attn, D.site_ln1, D.site_ln2 = sites
