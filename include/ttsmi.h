@@ -443,6 +443,18 @@ int ttsmi_layernorm_param_reduce_batched_nw(const void* const* ws, float* const*
                                             float* const* dpe_scale, const int* nparts, const int* C, int n,
                                             ttsmi_stream_t stream);
 
+/* The FFN's ReLU (model/layers.py:99) as a bit matrix for the backward, K = 256 GEMMs only (TTSMI_ERR_UNSUPPORTED when
+ * ttsmi_hgemm_k256_eligible(M, N, 256) is 0).  bits: ttsmi_relu_bits_bytes(M, N) bytes (8-byte aligned), one bit per
+ * element in the order the storing threads of the kernel hold a tile - an opaque hand-over between these two calls at the
+ * SAME (M, N), not a row-major matrix.
+ *   _relu_bits:   c = relu(a . bt^T + bias) as bf16, and bits = (c > 0)      (a [M,256], bt [N,256] bf16)
+ *   _masked_bits: c = (a . bt^T) where the bit is set, 0 elsewhere, as bf16 (the ReLU' of the FFN2 dgrad) */
+size_t ttsmi_relu_bits_bytes(int M, int N);
+int ttsmi_hgemm_k256_relu_bits(const uint16_t* a, int64_t lda, const uint16_t* bt, int64_t ldb, const float* bias,
+                               uint16_t* c, int64_t ldc, uint8_t* bits, int M, int N, ttsmi_stream_t stream);
+int ttsmi_hgemm_k256_masked_bits(const uint16_t* a, int64_t lda, const uint16_t* bt, int64_t ldb, const uint8_t* bits,
+                                 uint16_t* c, int64_t ldc, int M, int N, ttsmi_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * One SelfAttentionDenseBlock (model/layers.py:214-230: MultiHeadAttention + two res-norms + FFN) per call,
  * TTSMI_BF16 path: the forward enqueues its 8 launches, the backward its 9 main-stream launches and 5 weight
@@ -506,6 +518,10 @@ typedef struct ttsmi_dense_block {
      * bf16 rounding of a LayerNorm output / of its gradient once per kernel boundary: depth-12 parity as measured in
      * tests/test_config1_parity_gpu.py. */
     int32_t res16;
+    /* optional (NULL = not used): ttsmi_relu_bits_bytes(B*T, F) bytes.  When set and both FFN GEMMs are launches of the
+     * K = 256 weight-stationary kernel (fuse_ln, d == 256, ttsmi_hgemm_k256_eligible), the forward also leaves
+     * (h1 > 0) as one bit per element here and the backward masks the FFN2 dgrad with it instead of re-reading h1. */
+    void* relu_bits;
 } ttsmi_dense_block;
 /* ---------------------------------------------------------------------------------------------
  * Batch data parallelism for a binding WITHOUT a collective library of its own (one all-reduce of the

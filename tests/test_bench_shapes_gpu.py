@@ -253,6 +253,41 @@ def test_persistent_dma_gemm_at_the_benchmark_rows(K, mode):
     assert rel_err(y.float(), want) < (4e-3 if mode == 'bf16out' else 3e-6)
 
 
+@pytest.mark.parametrize('M,fwd_kernel,bwd_kernel', [(28800, 'gemm_k256_wide_kernel<1>', 'gemm_k256_wide_kernel<4>'),
+                                                      (6400, 'gemm_k256_kernel<1>', 'gemm_k256_kernel<4>'),
+                                                      (4096 + 37, 'gemm_k256_kernel<1>', 'gemm_k256_kernel<4>')])
+def test_relu_bit_matrix_of_the_ffn(M, fwd_kernel, bwd_kernel):
+    """ttsmi_hgemm_k256_relu_bits / _masked_bits (the FFN's ReLU handed to the backward as one bit per element,
+    model/layers.py:99): h1 and the masked FFN2 dgrad must be BIT-IDENTICAL to the launches that store / re-read the bf16
+    activation (ttsmi_hgemm_tn RELU / MASK_BF16, themselves checked against fp64 in test_ops_gpu)."""
+    ops, _lib, l = _env()
+    from transformertts_amd.ops import _p, _stream, check
+    d, F = 256, 1024
+    a = g(M, d, seed=1).to(torch.bfloat16).to(DEV)
+    w1 = ops.make_shadow(g(d, F, seed=2, scale=0.05).to(DEV))            # .wt = W1^T [F][d]
+    b1 = g(F, seed=3).to(DEV)
+    df = g(M, d, seed=4).to(torch.bfloat16).to(DEV)
+    w2 = ops.make_shadow(g(F, d, seed=5, scale=0.05).to(DEV))            # .wb = W2 as stored [F][d]: the dgrad operand
+    h1_ref = ops.hgemm_tn(a, w1.wt, b1, relu=True, out_bf16=True)
+    dh1_ref = ops.hgemm_tn(df, w2.wb, None, relu_src=h1_ref, out_bf16=True)
+    nbytes = int(l.ttsmi_relu_bits_bytes(M, F))
+    assert nbytes >= M * F // 8
+    bits = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    h1 = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
+    check(l.ttsmi_hgemm_k256_relu_bits(_p(a), d, _p(w1.wt), d, _p(b1), _p(h1), F, _p(bits), M, F, _stream()))
+    assert last_kernel(l) == fwd_kernel
+    dh1 = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
+    check(l.ttsmi_hgemm_k256_masked_bits(_p(df), d, _p(w2.wb), d, _p(bits), _p(dh1), F, M, F, _stream()))
+    assert last_kernel(l) == bwd_kernel
+    torch.cuda.synchronize()
+    assert torch.equal(h1.view(torch.int16), h1_ref.view(torch.int16))
+    # (the bit order is the kernels' own: what is checked is that the backward reads exactly the mask the forward meant)
+    assert 0.2 < float((h1_ref.float() > 0).float().mean()) < 0.8          # (a mask that is all ones or all zeros proves nothing)
+    assert torch.equal(dh1.view(torch.int16), dh1_ref.view(torch.int16))
+    # a shape the K = 256 kernel does not take is refused, not routed elsewhere
+    assert l.ttsmi_hgemm_k256_relu_bits(_p(a), d, _p(w1.wt), d, _p(b1), _p(h1), F, _p(bits), 64, F, _stream()) == -3     # TTSMI_ERR_UNSUPPORTED
+
+
 # the dense block's weight gradients (dense_block.hip): FFN2 [1024 -> 256], FFN1 [256 -> 1024], the two halves of Wo
 # [256 -> 256] (the second without a bias gradient), Wqkv [256 -> 768]; all operands bf16.  Last case: an fp32 x takes
 # the register-staged kernel (the route assertion must be able to fail).

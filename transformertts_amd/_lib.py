@@ -92,6 +92,9 @@ SIGNATURES = {
     'ttsmi_layernorm_partials_bytes': (c_size_t, [I, I]),
     'ttsmi_hgemm_ln_bwd_nparts': (I, [I]),
     'ttsmi_hgemm_ln_bwd': (I, [P, L, P, L, P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, P, c_size_t, I, I, I, S]),
+    'ttsmi_relu_bits_bytes': (c_size_t, [I, I]),
+    'ttsmi_hgemm_k256_relu_bits': (I, [P, L, P, L, P, P, L, P, I, I, S]),
+    'ttsmi_hgemm_k256_masked_bits': (I, [P, L, P, L, P, P, L, I, I, S]),
     'ttsmi_hgemm_ln_fwd_h': (I, [P, L, P, L, I, P, L, P, P, P, P, P, F, c_uint32, c_uint64, P, F, P, P, P, P, I, I, I, S]),
     'ttsmi_hgemm_ln_bwd_dual_h': (I, [P, L, P, L, I, P, L, P, L, P, P, P, P, P, F, c_uint32, c_uint64, P, P, P, I, P, c_size_t,
                                       I, I, I, S]),
@@ -125,7 +128,7 @@ def _dense_block_fields():
             [(n, p) for n in ptrs] + [('fuse_ln', i32), ('attn_split', i32)] +
             [(n, p) for n in ('xhat1', 'xhat2', 'lnp_ws1', 'lnp_ws2')] + [('lnp_ws1_bytes', u64), ('lnp_ws2_bytes', u64)] +
             [(n, p) for n in ptrs2] + [(n, u64) for n in ('attn_ws_bytes', 'ln_ws_bytes', 'wgrad_ws_bytes')] +
-            [('main_stream', p), ('side_stream', p), ('ev', p * 4), ('below', p), ('ln2_done', i32), ('res16', i32)])
+            [('main_stream', p), ('side_stream', p), ('ev', p * 4), ('below', p), ('ln2_done', i32), ('res16', i32), ('relu_bits', p)])
 
 
 class DenseBlockDesc(ctypes.Structure):

@@ -30,6 +30,12 @@ static double gemm_bytes(double M, double N, double K, int out_bytes, bool acc, 
 }
 #define OBS(name, flops, bytes, st) Obs obs__(name, flops, bytes, st)
 
+// the FFN's ReLU travels to the backward as a bit matrix when the caller provides one and both FFN GEMMs of the block are
+// launches of the K = 256 weight-stationary kernel (the only kernels that write / read it)
+static bool relu_bits(const ttsmi_dense_block* D) {
+    return D->relu_bits != nullptr && D->fuse_ln && D->d == 256 && ttsmi_hgemm_k256_eligible(D->B * D->T, D->F, D->d);
+}
+
 static int check_desc(const ttsmi_dense_block* D, const char* who) {
     TTSMI_CHECK_ARG(D, "%s: null descriptor", who);
     TTSMI_CHECK_ARG(D->B > 0 && D->H > 0 && D->T > 0 && D->d > 0 && D->F > 0 && D->d % D->H == 0,
@@ -100,9 +106,12 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
           else
               TRY(ttsmi_hgemm_ln_fwd(h_bf, d, D->cx, d, d, D->wo_t, 2L * d, D->bo, h, D->ln1_g, D->ln1_b, D->pad, D->rate,
                                      D->site_ln1, D->seed, D->step_dev, kLnEps, D->a, D->a_bf, D->xhat1, D->rstd1, M, d, 2 * d, st)); }
-        { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false), st);
-          TRY(ttsmi_hgemm_tn(D->a_bf, 0, d, nullptr, 0, 0, D->w1_t, d, D->b1, nullptr, 0, D->h1, F, M, F, d,
-                             TTSMI_GEMM_RELU | TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
+        { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false, relu_bits(D) ? (double)M * F / 8 : 0.0), st);
+          if (relu_bits(D))        // h1 and, for the backward, the sign of every element as one bit (layers.py:99 ReLU)
+              TRY(ttsmi_hgemm_k256_relu_bits(D->a_bf, d, D->w1_t, d, D->b1, D->h1, F, (uint8_t*)D->relu_bits, M, F, st));
+          else
+              TRY(ttsmi_hgemm_tn(D->a_bf, 0, d, nullptr, 0, 0, D->w1_t, d, D->b1, nullptr, 0, D->h1, F, M, F, d,
+                                 TTSMI_GEMM_RELU | TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
         OBS("ttsmi_hgemm_ln_fwd", 2.0 * M * d * F, gemm_bytes(M, d, F, out32 ? 4 : 0, false, (double)M * d * ((r16 ? 2 : 4) + 2 + 2)), st);
         // out = LN(drop(h1.W2 + b2) + a) * mask in ONE launch                (layers.py:100-102,230)
         if (r16)
@@ -235,7 +244,7 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     if (D->fuse_ln) {
         if (!D->ln2_done) {         // (chained: the block above already left df / da / the parameter partials)
             TTSMI_CHECK_ARG(dout, "dense_block_bwd: null dout");
-            OBS("ttsmi_layernorm_bwd_xhat", 0.0, (double)M * d * (4 + 2 + 2 + 4), st);
+            OBS("ttsmi_layernorm_bwd_xhat", 0.0, (double)M * d * (4 + 2 + 2 + (r16 ? 2 : 4)), st);
             if (!lazy) arm(D, 0);
             if (r16)
                 TRY(ttsmi_layernorm_bwd_xhat_h(dout, D->xhat2, D->rstd2, D->ln2_g, D->pad, D->rate, D->site_ln2, D->seed, D->step_dev,
@@ -249,15 +258,19 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
                                     D->site_ln2, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->da, D->da, nullptr,
                                     nullptr, nullptr, M, d, D->ln_ws2, D->ln_ws_bytes, D->df, st));
     if (!lazy) TRY(wgrad_side(D, &wb, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
-    { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false, (double)M * F * 2), st);
+    { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false, relu_bits(D) ? (double)M * F / 8 : (double)M * F * 2), st);
       if (!pre_attn) arm(D, 1);
-      TRY(ttsmi_hgemm_tn(D->df, 0, d, nullptr, 0, 0, D->w2_b, d, nullptr, (const float*)D->h1, F, D->dh1, F, M, F, d,
-                         TTSMI_GEMM_OUT_BF16 | TTSMI_GEMM_MASK_BF16, 1, 0, 0, 0, st)); }               // relu' fused
+      if (relu_bits(D))           // relu' from the bit matrix the forward left: 1 / 16 of the bytes of re-reading h1
+          TRY(ttsmi_hgemm_k256_masked_bits(D->df, d, D->w2_b, d, (const uint8_t*)D->relu_bits, D->dh1, F, M, F, st));
+      else
+          TRY(ttsmi_hgemm_tn(D->df, 0, d, nullptr, 0, 0, D->w2_b, d, nullptr, (const float*)D->h1, F, D->dh1, F, M, F, d,
+                             TTSMI_GEMM_OUT_BF16 | TTSMI_GEMM_MASK_BF16, 1, 0, 0, 0, st)); }           // relu' fused
     if (lazy && !pre_attn) TRY(wgrad_side(D, &wb, 1, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
     if (!pre_attn) TRY(wgrad_side(D, &wb, 1, !lazy, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
     if (D->fuse_ln) {
         // (da + dh1.W1^T) never reaches HBM: res-norm 1's backward runs in the dgrad's epilogue -> d_o (bf16), dh (fp32)
-        OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * F, gemm_bytes(M, d, F, 4, true, (double)M * d * (2 + 2)), st);
+        // (bytes: dh1 + W1 + the residual gradient in (da) and out (dh) at their stored widths + x^ + d_o)
+        OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * F, gemm_bytes(M, d, F, 0, false, (double)M * d * ((r16 ? 2 : 4) + (dh16 ? 2 : 4) + 2 + 2)), st);
         if (!lazy) arm(D, 2);
         if (r16)
             TRY(ttsmi_hgemm_ln_bwd_dual_h(D->dh1, F, nullptr, 0, 0, D->w1_b, F, nullptr, 0, (const uint16_t*)D->da, D->xhat1, D->rstd1,
@@ -330,7 +343,8 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
         // dh + dqkv.Wqkv^T is the upstream gradient of the lower block's res-norm 2: its backward runs in this epilogue
         TTSMI_CHECK_ARG(L->fuse_ln && L->ln2_done && L->B == D->B && L->T == D->T && L->d == d && (L->res16 != 0) == (D->res16 != 0),
                         "dense_block_bwd: `below` is not a chained block of the same shape and residual type");
-        OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * (fold ? 4 : 3) * d, gemm_bytes(M, d, (fold ? 4 : 3) * d, 4, true, (double)M * d * (2 + 2)), st);
+        OBS("ttsmi_hgemm_ln_bwd", 2.0 * M * d * (fold ? 4 : 3) * d,
+            gemm_bytes(M, d, (fold ? 4 : 3) * d, 0, false, (double)M * d * ((dh16 ? 2 : 4) + (L->res16 ? 2 : 4) + 2 + 2)), st);
         // this launch produces the lower block's df: its hand-off 0 rides on this kernel (recorded here either way, so
         // the lower block only waits)
         if (L->side_stream && kernel_events() && !lazy && !t_capturing) {

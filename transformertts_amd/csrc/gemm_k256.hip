@@ -41,6 +41,11 @@ struct K256P {
     int M, N;
     int nchunks, ngroups, ntiles;
     const uint16_t* mask; long ldmask;      // MODE 2: bf16 [M, N], output kept where mask > 0 (ReLU' of the saved activation)
+    // (output > 0) as one bit per element, in the order the STORING threads of the kernel hold the tile: block (row tile,
+    // column chunk) = 256 threads x one word (4 groups of 8 columns; wide kernel: two words, 8 groups) - written by MODE 1
+    // (optional) and read back by MODE 4 of the same kernel variant with one coalesced load per thread and tile
+    uint32_t* bits_out;
+    const uint32_t* bits_in;                // MODE 4: the mask (59 MB of bf16 activation -> 3.7 MB at M = 28 800, N = 1 024)
     int ablate;                             // measurement only (TTSMI_K256_ABLATE, wide kernel): 1 no stores, 2 no MFMA, 4 no DMA
     void* C2; long ldc2; int n_acc;         // MODE 3: columns < n_acc (a multiple of 128) are ADDED to the fp32 C, the
                                             // rest leave as bf16 into C2 (column n -> C2[., n - n_acc])
@@ -53,6 +58,15 @@ __device__ __forceinline__ void kw_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ unsigned kw_lds_offset(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
+// bit e of the result = bf16 element e of the 8-element group is > 0 (a half moved to the top of an int32 is > 0)
+__device__ __forceinline__ uint32_t kw_pos_bits(const uint4& v) {
+    auto two = [](uint32_t w) { return (((int32_t)(w << 16) > 0) ? 1u : 0u) | (((int32_t)(w & 0xFFFF0000u) > 0) ? 2u : 0u); };
+    return two(v.x) | (two(v.y) << 2) | (two(v.z) << 4) | (two(v.w) << 6);
+}
+__device__ __forceinline__ void kw_and_bits(uint4& v, uint32_t b) {
+    auto sel = [](uint32_t b2) { return ((b2 & 1u) ? 0x0000FFFFu : 0u) | ((b2 & 2u) ? 0xFFFF0000u : 0u); };
+    v.x &= sel(b); v.y &= sel(b >> 2); v.z &= sel(b >> 4); v.w &= sel(b >> 6);
+}
 __device__ __forceinline__ uint2 kw_pack4(float a, float b, float c, float d) {
     bf16x4 h;
     h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
@@ -63,7 +77,7 @@ __device__ __forceinline__ uint2 kw_pack4(float a, float b, float c, float d) {
 // n_acc columns, bf16 C2 for the rest (one launch for the two halves of the output-projection dgrad: d(h) += and d(ctx))
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
-    constexpr bool OUT_H = MODE == 1 || MODE == 2;
+    constexpr bool OUT_H = MODE == 1 || MODE == 2 || MODE == 4;
     constexpr int SLD_H = KW_BN + 8, SLD_F = KW_BN + 4;                    // staging row strides (elements)
     constexpr int SLD = OUT_H ? SLD_H : SLD_F;
     constexpr int STAGING = KW_BM * (OUT_H ? SLD_H * 2 : SLD_F * 4);        // MODE 3 stages either type in the fp32-sized tile
@@ -134,6 +148,7 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
         // epilogue operands from global memory (the mask / the accumulate target) are requested by the storing waves NOW,
         // a whole multiply ahead of their use; everything older on their vmcnt is the previous tile's stores
         uint4 pre_m[4];
+        uint32_t pre_b = 0u, out_b = 0u;
         float4 pre_c[8];
         const bool acc_chunk = MODE == 3 && chunk * KW_BN < p.n_acc;       // workgroup-uniform
         if (MODE >= 2 && !loader) {
@@ -147,6 +162,8 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
                                    ? *reinterpret_cast<const uint4*>(p.mask + (long)(m0 + row) * p.ldmask + ncol0 + c8)
                                    : make_uint4(0u, 0u, 0u, 0u);
                 }
+            } else if (MODE == 4) {
+                pre_b = p.bits_in[((long)(group + it * p.ngroups) * p.nchunks + chunk) * 256 + st_tid];
             } else if (acc_chunk) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -206,9 +223,13 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
                         };
                         v.x &= sel(pre_m[j].x); v.y &= sel(pre_m[j].y); v.z &= sel(pre_m[j].z); v.w &= sel(pre_m[j].w);
                     }
+                    if (MODE == 4) kw_and_bits(v, pre_b >> (8 * j));
+                    if (MODE == 1) out_b |= kw_pos_bits(v) << (8 * j);
                     *reinterpret_cast<uint4*>(dstb + (long)(m0 + row) * ldd + cd0 + c8) = v;
                 }
             }
+            if (MODE == 1 && p.bits_out != nullptr)
+                p.bits_out[((long)(group + it * p.ngroups) * p.nchunks + chunk) * 256 + st_tid] = out_b;
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
 #define KWW_BN 256
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_k256_wide_kernel(K256P p) {
-    static_assert(MODE == 1 || MODE == 2, "bf16 output only");
+    static_assert(MODE == 1 || MODE == 2 || MODE == 4, "bf16 output only");
     constexpr int SLD = KWW_BN + 8;                                        // staging row stride (bf16 elements)
     __shared__ __attribute__((aligned(16))) unsigned char smem[KW_STAGES * KW_STAGE + KW_BM * SLD * 2];
     __shared__ float biasS[KWW_BN];
@@ -356,8 +377,13 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_wide_kernel(K256P p) {
     const int st_tid = tid - 256;
     const int srow = st_tid >> 5, sc8 = (st_tid & 31) * 8;
     uint4 outv[8], pre_m[8];
+    uint2 pre_b = make_uint2(0u, 0u);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { outv[j] = make_uint4(0u, 0u, 0u, 0u); pre_m[j] = make_uint4(0u, 0u, 0u, 0u); }
+    auto bits_of = [&](int it) -> uint2 {          // the thread's 8 x 8 bits of tile `it` (clamped: the last request is one tile past the end)
+        const long tile = min(group + it * p.ngroups, p.ntiles - 1);
+        return *reinterpret_cast<const uint2*>(p.bits_in + ((tile * p.nchunks + chunk) * 256 + st_tid) * 2);
+    };
     auto mask_of = [&](int it, int j) {
         const int row = min((group + it * p.ngroups) * KW_BM + srow + 8 * j, p.M - 1), col = min(ncol0 + sc8, p.N - 8);
         return *reinterpret_cast<const uint4*>(p.mask + (long)row * p.ldmask + col);
@@ -384,6 +410,22 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_wide_kernel(K256P p) {
                     pre_m[j] = nxt[j];
                 }
             }
+            if (MODE == 4) {                 // the same schedule on the bit form of the mask: one 8-byte load per thread and tile
+                const uint2 nxt = bits_of(it);
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kw_and_bits(outv[j], (j < 4 ? pre_b.x : pre_b.y) >> (8 * (j & 3)));
+                pre_b = nxt;
+            }
+            if (MODE == 1 && p.bits_out != nullptr) {
+                uint2 ob = make_uint2(0u, 0u);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t b = kw_pos_bits(outv[j]) << (8 * (j & 3));
+                    if (j < 4) ob.x |= b; else ob.y |= b;
+                }
+                *reinterpret_cast<uint2*>(p.bits_out + (((long)(m0 / KW_BM) * p.nchunks + chunk) * 256 + st_tid) * 2) = ob;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int row = srow + 8 * j;
@@ -393,6 +435,8 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_wide_kernel(K256P p) {
         } else if (MODE == 2 && it == 0 && my_tiles > 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) pre_m[j] = mask_of(0, j);          // the first tile's mask
+        } else if (MODE == 4 && it == 0 && my_tiles > 0) {
+            pre_b = bits_of(0);
         }
         kw_barrier();                    // Y: staging(it) published
         if (it < my_tiles) {
@@ -426,12 +470,20 @@ static void kw_plan(K256P& p) {
 }
 
 // mask != nullptr: bf16 output (out_bf16 must be set) kept where the bf16 mask[M, N] is > 0
+static int kw_launch(const uint16_t* a, long lda, const uint16_t* bt, long ldb, const float* bias, void* c, long ldc,
+                     int M, int N, int relu, int out_bf16, const uint16_t* mask, long ldmask, uint32_t* bits_out,
+                     const uint32_t* bits_in, hipStream_t st);
 int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, long ldb, const float* bias, void* c, long ldc,
                             int M, int N, int relu, int out_bf16, const uint16_t* mask, long ldmask, hipStream_t st) {
+    return kw_launch(a, lda, bt, ldb, bias, c, ldc, M, N, relu, out_bf16, mask, ldmask, nullptr, nullptr, st);
+}
+static int kw_launch(const uint16_t* a, long lda, const uint16_t* bt, long ldb, const float* bias, void* c, long ldc,
+                     int M, int N, int relu, int out_bf16, const uint16_t* mask, long ldmask, uint32_t* bits_out,
+                     const uint32_t* bits_in, hipStream_t st) {
     K256P p;
     memset(&p, 0, sizeof(p));
     p.A = a; p.lda = lda; p.Bt = bt; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.relu = relu; p.M = M; p.N = N;
-    p.mask = mask; p.ldmask = ldmask;
+    p.mask = mask; p.ldmask = ldmask; p.bits_out = bits_out; p.bits_in = bits_in;
     // bf16 output, whole 256-column chunks, enough row tiles per workgroup to amortise its 128 KB of weights: wide variant
     TTSMI_KNOB(wide, "TTSMI_HGEMM_K256_WIDE", 1);               // TTSMI_HGEMM_K256_WIDE=0: always the 128-column kernel (A/B knob)
     if (wide && out_bf16 && N % KWW_BN == 0 && (M >= 16384 || wide > 1)) {
@@ -445,18 +497,53 @@ int ttsmi_hgemm_k256_launch(const uint16_t* a, long lda, const uint16_t* bt, lon
         TTSMI_ABLATE_KNOB(ablate, "TTSMI_K256_ABLATE");
         p.ablate = ablate;
         dim3 gridw(p.nchunks * p.ngroups);
-        ttsmi_note_kernel(mask ? "gemm_k256_wide_kernel<2>" : "gemm_k256_wide_kernel<1>");
-        if (mask) TTSMI_LAUNCH_EV((gemm_k256_wide_kernel<2>), gridw, dim3(512), 0, st, p);
+        ttsmi_note_kernel(bits_in ? "gemm_k256_wide_kernel<4>" : mask ? "gemm_k256_wide_kernel<2>" : "gemm_k256_wide_kernel<1>");
+        if (bits_in) TTSMI_LAUNCH_EV((gemm_k256_wide_kernel<4>), gridw, dim3(512), 0, st, p);
+        else if (mask) TTSMI_LAUNCH_EV((gemm_k256_wide_kernel<2>), gridw, dim3(512), 0, st, p);
         else TTSMI_LAUNCH_EV((gemm_k256_wide_kernel<1>), gridw, dim3(512), 0, st, p);
         return 0;
     }
     kw_plan(p);
     dim3 grid(p.nchunks * p.ngroups);
-    ttsmi_note_kernel(mask ? "gemm_k256_kernel<2>" : out_bf16 ? "gemm_k256_kernel<1>" : "gemm_k256_kernel<0>");
-    if (mask) TTSMI_LAUNCH_EV((gemm_k256_kernel<2>), grid, dim3(512), 0, st, p);
+    ttsmi_note_kernel(bits_in ? "gemm_k256_kernel<4>" : mask ? "gemm_k256_kernel<2>" : out_bf16 ? "gemm_k256_kernel<1>" : "gemm_k256_kernel<0>");
+    if (bits_in) TTSMI_LAUNCH_EV((gemm_k256_kernel<4>), grid, dim3(512), 0, st, p);
+    else if (mask) TTSMI_LAUNCH_EV((gemm_k256_kernel<2>), grid, dim3(512), 0, st, p);
     else if (out_bf16) TTSMI_LAUNCH_EV((gemm_k256_kernel<1>), grid, dim3(512), 0, st, p);
     else TTSMI_LAUNCH_EV((gemm_k256_kernel<0>), grid, dim3(512), 0, st, p);
     return 0;
+}
+
+static int kw_check(const void* a, int64_t lda, const void* bt, int64_t ldb, const void* c, int64_t ldc, const void* bits, int M, int N,
+                    const char* who) {
+    TTSMI_CHECK_ARG(a && bt && c && bits && (((uintptr_t)bits) & 7) == 0, "%s: null pointer / bit matrix not 8-byte aligned", who);
+    TTSMI_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "%s: bad shape M=%d N=%d", who, M, N);
+    TTSMI_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)bt) | ((uintptr_t)c)) & 15) == 0,
+                    "%s: operands must be 16-byte aligned with 16-byte row pitches", who);
+    if (!ttsmi_hgemm_k256_eligible(M, N, KW_K)) {
+        ttsmi_set_error("%s: M=%d N=%d is not a launch of the K = 256 weight-stationary kernel (ttsmi_hgemm_k256_eligible)", who, M, N);
+        return TTSMI_ERR_UNSUPPORTED;
+    }
+    return TTSMI_OK;
+}
+// one 1 KB block per (64-row tile, 128-column chunk) - the wide kernel's 2 KB blocks per 256 columns are the same total
+extern "C" size_t ttsmi_relu_bits_bytes(int M, int N) {
+    return M > 0 && N > 0 ? (size_t)ttsmi_cdiv(M, KW_BM) * (size_t)ttsmi_cdiv(N, KW_BN) * 1024 : 0;
+}
+extern "C" int ttsmi_hgemm_k256_relu_bits(const uint16_t* a, int64_t lda, const uint16_t* bt, int64_t ldb, const float* bias,
+                                          uint16_t* c, int64_t ldc, uint8_t* bits, int M, int N, ttsmi_stream_t stream) {
+    const int rc = kw_check(a, lda, bt, ldb, c, ldc, bits, M, N, "hgemm_k256_relu_bits");
+    if (rc) return rc;
+    kw_launch(a, (long)lda, bt, (long)ldb, bias, c, (long)ldc, M, N, 1, 1, nullptr, 0, (uint32_t*)bits, nullptr, (hipStream_t)stream);
+    TTSMI_CHECK_LAUNCH("hgemm_k256_relu_bits");
+    return TTSMI_OK;
+}
+extern "C" int ttsmi_hgemm_k256_masked_bits(const uint16_t* a, int64_t lda, const uint16_t* bt, int64_t ldb, const uint8_t* bits,
+                                            uint16_t* c, int64_t ldc, int M, int N, ttsmi_stream_t stream) {
+    const int rc = kw_check(a, lda, bt, ldb, c, ldc, bits, M, N, "hgemm_k256_masked_bits");
+    if (rc) return rc;
+    kw_launch(a, (long)lda, bt, (long)ldb, nullptr, c, (long)ldc, M, N, 0, 1, nullptr, 0, nullptr, (const uint32_t*)bits, (hipStream_t)stream);
+    TTSMI_CHECK_LAUNCH("hgemm_k256_masked_bits");
+    return TTSMI_OK;
 }
 
 extern "C" int ttsmi_hgemm_k256_split(const void* a, int64_t lda, const uint16_t* bt, int64_t ldb, float* c_acc, int64_t ldc_acc,

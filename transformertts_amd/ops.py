@@ -1461,6 +1461,9 @@ class DenseBlockPlan:
             unused = (not backward and name in ('df', 'dh1', 'd_o', 'dqkv', 'dh')) or (self.want_fuse and backward and
                                                                                         name in ('o', 'f'))
             t[name] = e((8,) if unused else shape, dt)
+        # the FFN's ReLU as one bit per element for the backward (ttsmi_dense_block.relu_bits); TTSMI_RELU_BITS=0: re-read h1
+        self.relu_bits = backward and self.want_fuse and os.environ.get('TTSMI_RELU_BITS', '1') != '0'
+        t['relu_bits'] = e((max(int(l.ttsmi_relu_bits_bytes(cap, F)), 8) if self.relu_bits else 8,), torch.uint8)
         # workspaces at their largest over every row count <= cap (tile heights switch with the row count)
         parts_cap = max((cap + 63) // 64 + 8, int(l.ttsmi_layernorm_bwd_xhat_nparts(cap)), int(l.ttsmi_hgemm_ln_bwd_nparts(cap)),
                         int(l.ttsmi_add_layernorm_bwd_nparts(cap)))
@@ -1506,6 +1509,7 @@ class DenseBlockPlan:
             for k in ('xhat1', 'xhat2', 'lnp_ws1', 'lnp_ws2'):
                 setattr(D, k, t[k].data_ptr())
         D.da, D.dctx = sh['da'].data_ptr(), sh['dctx'].data_ptr()
+        D.relu_bits = t['relu_bits'].data_ptr() if self.relu_bits else None
         D.ln_ws_bytes = ln_ws
         for i, ev in enumerate(self.events):
             D.ev[i] = ev.cuda_event
