@@ -356,13 +356,16 @@ class ForwardTransformer:
             # the kernel indexes pe[(row % T) * d]; the reference fails on pos_encoding[:, :seq_len] (layers.py:300)
             raise ValueError(f'{name}: sequence length {T} exceeds the positional-encoding table '
                              f'({pe.shape[0]} positions; {prefix}oder_max_position_encoding)')
+        # (planned dense blocks read the bf16 copy of their input: the stack's first LayerNorm writes it as well)
+        first_planned = bool(heads) and dense_blocks > 0 and self.fused_blocks and self._use_plans and \
+            self._plan_ok(f'{prefix}.blk0', heads[0], d)
         h = ops.add_layernorm(x.reshape(M, d), None, W[f'{prefix}.ln.gamma'], W[f'{prefix}.ln.beta'],
                               G[f'{prefix}.ln.gamma'], G[f'{prefix}.ln.beta'], pe=pe,
                               pe_scale=W[f'{prefix}.pos_scalar'], gpe_scale=G[f'{prefix}.pos_scalar'], T=T,
-                              p_out=rate, site_out=drop.site(), drop=drop)
+                              p_out=rate, site_out=drop.site(), drop=drop, want_h=first_planned)
+        h, h_bf = h if first_planned else (h, None)     # bf16 copy of h: later written by the previous block's LayerNorm
         attn = OrderedDict()
         dtype = ops._lib.TTSMI_BF16 if self.precision == 'bf16' else ops.TTSMI_F32
-        h_bf = None                      # bf16 copy of h written by the previous block's LayerNorm (TTSMI_BF16)
         below = None                     # the planned block whose output feeds the current one (backward chaining)
         for i, H in enumerate(heads):
             p = f'{prefix}.blk{i}'

@@ -774,7 +774,7 @@ class AddLayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta, ggamma, gbeta, pe, pe_scale, gpe_scale, T, row_pad,
-                p_in, site_in, p_out, site_out, drop, relu_in):
+                p_in, site_in, p_out, site_out, drop, relu_in, want_h=False):
         ctx.stream_h = _stream()         # backward launches on the stream forward ran on (predictor side stream)
         x = _c(x)
         res = None if res is None else _c(res)
@@ -782,6 +782,7 @@ class AddLayerNormFn(torch.autograd.Function):
         C = shp[-1]
         M = x.numel() // C
         y = torch.empty_like(x)
+        y_h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_h else None
         mean = torch.empty((M,), dtype=torch.float32, device=x.device)
         rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
         seed = drop.seed if drop is not None else 0
@@ -789,16 +790,19 @@ class AddLayerNormFn(torch.autograd.Function):
         check(_lib.lib().ttsmi_add_layernorm_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(pe), _p(pe_scale),
                                                  int(T), _p(row_pad), float(p_in), int(site_in), float(p_out),
                                                  int(site_out), seed, _p(step_dev), LN_EPS, _p(y), _p(mean),
-                                                 _p(rstd), M, C, None, _stream()), 'add_layernorm_fwd')
+                                                 _p(rstd), M, C, _p(y_h), _stream()), 'add_layernorm_fwd')
         ctx.save_for_backward(x, res, gamma, mean, rstd, pe, pe_scale, row_pad, step_dev)
         ctx.cfg = (int(T), float(p_in), int(site_in), float(p_out), int(site_out), seed, bool(relu_in), M, C)
         ctx.sinks = (ggamma, gbeta, gpe_scale)
+        if want_h:                      # the bf16 copy the first GEMM reads, written by the same kernel
+            ctx.mark_non_differentiable(y_h)
+            return y, y_h
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dy_h=None):
         with pin_stream(ctx.stream_h):
-            return AddLayerNormFn._backward(ctx, dy)
+            return AddLayerNormFn._backward(ctx, dy) + (None,)
 
     @staticmethod
     def _backward(ctx, dy):
@@ -839,9 +843,10 @@ class AddLayerNormFn(torch.autograd.Function):
 
 
 def add_layernorm(x, res, gamma, beta, ggamma=None, gbeta=None, pe=None, pe_scale=None, gpe_scale=None,
-                  T=0, row_pad=None, p_in=0.0, site_in=0, p_out=0.0, site_out=0, drop=None, relu_in=False):
+                  T=0, row_pad=None, p_in=0.0, site_in=0, p_out=0.0, site_out=0, drop=None, relu_in=False, want_h=False):
+    """want_h: returns (y, y as bf16) - the copy costs no launch of its own."""
     return AddLayerNormFn.apply(x, res, gamma, beta, ggamma, gbeta, pe, pe_scale, gpe_scale, T, row_pad,
-                                p_in, site_in, p_out, site_out, drop, relu_in)
+                                p_in, site_in, p_out, site_out, drop, relu_in, want_h)
 
 
 class AttentionFn(torch.autograd.Function):
