@@ -103,16 +103,20 @@ def bench_attn():
     from transformertts_amd.ops import _p, _stream, check
     dev, out = 'cuda:0', []
     l = _lib.lib()
-    for (B, H, T, dh, pdrop) in [(32, 4, 900, 64, 0.1), (32, 4, 900, 64, 0.0), (32, 4, 200, 64, 0.1)]:
+    # (.., io): 'h' = bf16 tensors (TTSMI_BF16_IO, the dense blocks), 'f' = fp32 tensors, bf16 MFMA (TTSMI_BF16, the conv blocks)
+    for (B, H, T, dh, pdrop, io) in [(32, 4, 900, 64, 0.1, 'h'), (32, 4, 900, 64, 0.0, 'h'), (32, 4, 200, 64, 0.1, 'h'),
+                                     (32, 2, 900, 192, 0.1, 'f'), (32, 2, 900, 192, 0.1, 'h')]:
         d = H * dh
         R = 3
-        qkvs = [(torch.randn(B * T, 3 * d, device=dev) * 0.5).bfloat16() for _ in range(R)]
-        dctx = [(torch.randn(B * T, d, device=dev) * 0.1).bfloat16() for _ in range(R)]
+        tdt = torch.bfloat16 if io == 'h' else torch.float32
+        IO = _lib.TTSMI_BF16_IO if io == 'h' else _lib.TTSMI_BF16
+        qkvs = [(torch.randn(B * T, 3 * d, device=dev) * 0.5).to(tdt) for _ in range(R)]
+        dctx = [(torch.randn(B * T, d, device=dev) * 0.1).to(tdt) for _ in range(R)]
         pad = torch.zeros(B, T, dtype=torch.uint8, device=dev)
         klen = torch.full((B,), T, dtype=torch.int32, device=dev)
-        ctx = torch.empty(B * T, d, device=dev, dtype=torch.bfloat16)
+        ctx = torch.empty(B * T, d, device=dev, dtype=tdt)
         lse = torch.empty(B, H, T, device=dev)
-        dqkv = torch.empty(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
+        dqkv = torch.empty(B * T, 3 * d, device=dev, dtype=tdt)
         step = torch.zeros(1, dtype=torch.int64, device=dev)
         ws = torch.empty(int(l.ttsmi_attention_bwd_ws_bytes(B, H, T, dh)), dtype=torch.uint8, device=dev)
         i = [0]
@@ -121,13 +125,13 @@ def bench_attn():
             j = i[0] % R
             i[0] += 1
             check(l.ttsmi_attention_fwd(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(lse), B, H, T, dh, pdrop, 7,
-                                        _p(step), 3, _lib.TTSMI_BF16_IO, _stream()), 'attention_fwd')
+                                        _p(step), 3, IO, _stream()), 'attention_fwd')
 
         def bwd():
             j = i[0] % R
             i[0] += 1
             check(l.ttsmi_attention_bwd(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(dctx[j]), _p(lse), _p(dqkv), B, H, T,
-                                        dh, pdrop, 7, _p(step), 3, _p(ws), ws.numel(), _lib.TTSMI_BF16_IO, _stream()),
+                                        dh, pdrop, 7, _p(step), 3, _p(ws), ws.numel(), IO, _stream()),
                   'attention_bwd')
         if pdrop > 0:
             drop = ops.DropCtx(7, step)
@@ -140,23 +144,23 @@ def bench_attn():
                 j = i[0] % R
                 i[0] += 1
                 check(l.ttsmi_attention_fwd_masked(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(lse), B, H, T, dh, pdrop,
-                                                   _p(dm), _lib.TTSMI_BF16_IO, _stream()), 'attention_fwd_masked')
+                                                   _p(dm), IO, _stream()), 'attention_fwd_masked')
 
             def bwd_m():
                 j = i[0] % R
                 i[0] += 1
                 check(l.ttsmi_attention_bwd_masked(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(dctx[j]), _p(lse), _p(dqkv),
-                                                   B, H, T, dh, pdrop, _p(dm), _p(ws), ws.numel(), _lib.TTSMI_BF16_IO,
+                                                   B, H, T, dh, pdrop, _p(dm), _p(ws), ws.numel(), IO,
                                                    _stream()), 'attention_bwd_masked')
             fl = 4.0 * B * H * T * T * dh
             for nm, fn, mult in (('gen bits', gen, 0), ('fwd bits', fwd_m, 1), ('bwd bits', bwd_m, 2)):
                 t = timeit(fn, n=20)
-                out.append(dict(kind='attn', name=f'{nm} p={pdrop}', M=B * T, K=T, N=dh, us=t, tflops=mult * fl / t / 1e6 + 1e-9, tbs=0.0))
+                out.append(dict(kind='attn', name=f'{nm} p={pdrop}' + ('' if io == 'h' else ' f32io'), M=B * T, K=T, N=dh, us=t, tflops=mult * fl / t / 1e6 + 1e-9, tbs=0.0))
         tf_ = timeit(fwd, n=20)
         tb_ = timeit(bwd, n=20)
         fl = 4.0 * B * H * T * T * dh
-        out.append(dict(kind='attn', name=f'fwd p={pdrop}', M=B * T, K=T, N=dh, us=tf_, tflops=fl / tf_ / 1e6, tbs=0.0))
-        out.append(dict(kind='attn', name=f'bwd p={pdrop}', M=B * T, K=T, N=dh, us=tb_, tflops=2 * fl / tb_ / 1e6, tbs=0.0))
+        out.append(dict(kind='attn', name=f'fwd p={pdrop}' + ('' if io == 'h' else ' f32io'), M=B * T, K=T, N=dh, us=tf_, tflops=fl / tf_ / 1e6, tbs=0.0))
+        out.append(dict(kind='attn', name=f'bwd p={pdrop}' + ('' if io == 'h' else ' f32io'), M=B * T, K=T, N=dh, us=tb_, tflops=2 * fl / tb_ / 1e6, tbs=0.0))
     return out
 
 

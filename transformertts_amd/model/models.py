@@ -221,6 +221,8 @@ class ForwardTransformer:
         # bf16 residual stream inside the planned dense blocks (ttsmi_dense_block.res16): the residual adds of the fused
         # GEMM + LayerNorm kernels read the bf16 tensors the GEMMs read anyway, fp32 copies exist only at the stack ends
         self.residual_bf16 = bool(kwargs.get('residual_bf16', True)) and os.environ.get('TTSMI_RES16', '1') != '0'
+        # bf16 precision, blocks outside the planned path: bf16 qkv / context tensors around the attention kernels
+        self._attn_io_bf16 = os.environ.get('TTSMI_ATTN_IO_BF16', '1') != '0'
         self._use_plans, self._plans, self._plan_shared, self._plans_grown = False, {}, {}, {}
         self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}
@@ -422,9 +424,15 @@ class ForwardTransformer:
                 if self._taps is not None:
                     self._taps.append((p, h.detach().reshape(B, T, d)))
                 continue
-            h_bf = None
+            # bf16 precision, per-layer path (the conv blocks of the reference-default architecture): qkv / ctx / their
+            # gradients are bf16 tensors as in the planned dense blocks - the attention kernels on fp32 tensors (dh 192:
+            # 99 KB of LDS, scratch) run the backward in 1.43 ms per decoder layer against 0.52 ms on bf16 tensors
+            io_h = (self.precision == 'bf16' and self._attn_io_bf16 and (d // H) in (32, 64, 192) and d % 8 == 0
+                    and S(f'{p}.wqkv') is not None and S(f'{p}.wo') is not None)
+            if io_h and h_bf is None:
+                h_bf = ops.to_bf16(h)
             qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'],
-                                     S(f'{p}.wqkv'))
+                                     S(f'{p}.wqkv'), io_h, h_bf if io_h else None)
             site = drop.site()
             dmask = None
             pre = self._dropmask_plan.get(p) if self._dropmask_plan else None
@@ -438,8 +446,11 @@ class ForwardTransformer:
             if want_attn:
                 key = (f'{name}_DenseBlock{i + 1}_SelfAttention' if dense
                        else f'{name}_ConvBlock{i - dense_blocks + 1}_SelfAttention')
-                attn[key] = ops.attention_weights(qkv.detach(), pad, lse, B, H, T, d // H, rate, drop, site)
-            o = ops.LinearFn.apply(h, ctx, W[f'{p}.wo'], W[f'{p}.bo'], G[f'{p}.wo'], G[f'{p}.bo'], S(f'{p}.wo'))
+                attn[key] = ops.attention_weights(qkv.detach(), pad, lse, B, H, T, d // H, rate, drop, site,
+                                                  ops._lib.TTSMI_BF16_IO if io_h else ops.TTSMI_F32)
+            o = ops.LinearFn.apply(h, ctx, W[f'{p}.wo'], W[f'{p}.bo'], G[f'{p}.wo'], G[f'{p}.bo'], S(f'{p}.wo'),
+                                   False, h_bf if io_h else None)
+            h_bf = None
             a = ops.add_layernorm(o, h, W[f'{p}.ln1.gamma'], W[f'{p}.ln1.beta'], G[f'{p}.ln1.gamma'],
                                   G[f'{p}.ln1.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop)
             if dense:
@@ -457,7 +468,9 @@ class ForwardTransformer:
                 shs = tuple(S(f'{p}.conv{j}.w') for j in range(n))
                 f = ops.ConvStackFn.apply(a.reshape(B, T, d), n, shs, *ps, *gs).reshape(M, d)
             h = ops.add_layernorm(f, a, W[f'{p}.ln2.gamma'], W[f'{p}.ln2.beta'], G[f'{p}.ln2.gamma'],
-                                  G[f'{p}.ln2.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop)
+                                  G[f'{p}.ln2.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop, want_h=io_h)
+            if io_h:
+                h, h_bf = h             # the next block's bf16 GEMM operand, written by the same LayerNorm launch
             if self._taps is not None:
                 self._taps.append((p, h.detach().reshape(B, T, d)))
         if below is not None:

@@ -639,14 +639,23 @@ def _sink(g, like):
 # autograd Functions (one per fused layer)
 # =================================================================================================
 class LinearFn(torch.autograd.Function):
-    """y = [x | x2] . w + b.   Dense at model/layers.py:116-120,148-149; model/models.py:422."""
+    """y = [x | x2] . w + b.   Dense at model/layers.py:116-120,148-149; model/models.py:422.
+    bf16 plumbing of the per-layer path (conv blocks): out_bf16 stores y as bf16 (the attention kernels' operand);
+    x_h is a bf16 copy of x used as the GEMM operand (x itself stays the differentiable input); a bf16 x2 (the attention
+    context) receives its gradient as bf16."""
 
     @staticmethod
-    def forward(ctx, x, x2, w, b, gw, gb, sh=None):
+    def forward(ctx, x, x2, w, b, gw, gb, sh=None, out_bf16=False, x_h=None):
         x = _c(x)
         x2 = None if x2 is None else _c(x2)
-        y = dense_fwd(x, w, b, False, x2, sh)
-        ctx.save_for_backward(x, x2, w)
+        xa = x if x_h is None else _c(x_h)
+        h_ok = sh is not None and w.shape[0] % 8 == 0 and _al(xa, 4)
+        if (out_bf16 or xa.dtype == torch.bfloat16 or (x2 is not None and x2.dtype == torch.bfloat16)):
+            assert h_ok and (x2 is None or x2.dtype == xa.dtype), 'bf16 operands need the bf16 MFMA route and one operand type'
+            y = hgemm_tn(xa, sh.wt, b, False, x2, out_bf16=out_bf16)
+        else:
+            y = dense_fwd(xa, w, b, False, x2, sh)
+        ctx.save_for_backward(xa, x2, w)
         ctx.sinks = (gw, gb)
         ctx.has_b = b is not None
         ctx.sh = sh
@@ -659,16 +668,20 @@ class LinearFn(torch.autograd.Function):
         dy = _c(dy)
         K1 = x.shape[1]
         dw = _sink(gw, w)
-        db = _sink(gb, dy[0]) if ctx.has_b else None
+        db = _sink(gb, w[0]) if ctx.has_b else None
         sh, K = ctx.sh, w.shape[0]
         dx = dense_dgrad(dy, w, sh, 0, K1) if ctx.needs_input_grad[0] else None
         dyT = dense_wgrad(x, dy, dw[:K1], db, sh)
         dx2 = None
         if x2 is not None:
-            dx2 = dense_dgrad(dy, w, sh, K1, K) if ctx.needs_input_grad[1] else None
+            if ctx.needs_input_grad[1]:
+                if x2.dtype == torch.bfloat16:
+                    dx2 = hgemm_tn(dy, sh.wb[K1:K], None, False, None, None, out_bf16=True)
+                else:
+                    dx2 = dense_dgrad(dy, w, sh, K1, K)
             dense_wgrad(x2, dy, dw[K1:], None, sh, dyT)
         return (dx, dx2, (None if gw is not None else dw), (None if (gb is not None or db is None) else db),
-                None, None, None)
+                None, None, None, None, None)
 
 
 class FFNFn(torch.autograd.Function):
@@ -859,11 +872,14 @@ class AttentionFn(torch.autograd.Function):
         same decisions as the in-kernel hash, read as bits by the forward and both backward kernels."""
         qkv = _c(qkv)
         d = H * dh
-        if dtype != TTSMI_F32 and dh not in (32, 64, 192):
+        if qkv.dtype == torch.bfloat16:        # bf16 tensors in and out (the same kernels the planned dense blocks launch)
+            assert dh in (32, 64, 192), 'bf16 attention kernels are built for head dims 32 / 64 / 192'
+            dtype = _lib.TTSMI_BF16_IO
+        elif dtype != TTSMI_F32 and dh not in (32, 64, 192):
             dtype = TTSMI_F32                  # bf16 kernels are built for head dims 32 / 64 / 192
-        if dtype != _lib.TTSMI_BF16 or not p_drop > 0:
+        if dtype not in (_lib.TTSMI_BF16, _lib.TTSMI_BF16_IO) or not p_drop > 0:
             dmask = None
-        out = torch.empty((B * T, d), dtype=torch.float32, device=qkv.device)
+        out = torch.empty((B * T, d), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
         seed = drop.seed if drop is not None else 0
         step_dev = drop.step_dev if drop is not None else None
