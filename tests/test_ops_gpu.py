@@ -144,6 +144,42 @@ def test_ffn_and_convstack_autograd():
         assert rel_err(a.grad, b.grad) < 5e-6
 
 
+@pytest.mark.parametrize('k', [3, 5])
+def test_bf16_conv_stack_autograd(monkeypatch, k):
+    """ConvStackFn with bf16 shadows (the conv blocks of the reference-default architecture, model/layers.py:30-38) on both
+    routes - 'plain': a GEMM with overlapping A rows over a zero-margin bf16 layout (lda = C, K = k C), weight gradients
+    per tap on shifted views; 'window': the implicit-GEMM kernel on fp32 activations - against the fp64 conv of the
+    bf16-rounded operands.  Three sequences, so two interior sequence boundaries: a row computed across one of them
+    must contribute nothing, forward or backward.  The hidden bias is +-8 per channel, so that no pre-activation sits
+    near ReLU's zero (with 135 rows a single bf16-induced flip moves a bias gradient by several per cent)."""
+    ops = _ops()
+    B, T, C, Fh = 3, 45, 64, 128
+    x, w0, w1, b1 = g(B, T, C, seed=1), g(k, C, Fh, seed=2, scale=0.1), g(k, Fh, C, seed=4, scale=0.1), g(C, seed=5)
+    b0 = 8.0 * (1 - 2 * (torch.arange(Fh) % 2).float())
+    dy = g(B, T, C, seed=6)
+    r = lambda t: t.to(torch.bfloat16).double()
+    td = [r(x).requires_grad_(), r(w0).requires_grad_(), b0.double().requires_grad_(), r(w1).requires_grad_(),
+          b1.double().requires_grad_()]
+    yd = fo.conv1d_same(fo.conv1d_same(td[0], td[1], td[2]).relu(), td[3], td[4])
+    yd.backward(dy.double())
+    runs = {}
+    for plain in (True, False):
+        monkeypatch.setattr(ops, '_CONV_PLAIN', plain)
+        ts = [t.to(DEV).requires_grad_() for t in (x, w0, b0, w1, b1)]
+        shs = (ops.make_shadow(ts[1]), ops.make_shadow(ts[3]))
+        y = ops.ConvStackFn.apply(ts[0], 2, shs, *ts[1:])
+        y.backward(dy.to(DEV))
+        ops.wgrad_join()
+        torch.cuda.synchronize()
+        # bf16 hidden activation and bf16 gradient operands: 2^-9 relative per element
+        assert rel_err(y.detach(), yd.detach()) < 6e-3, plain
+        for a, b in zip(ts, td):
+            assert rel_err(a.grad, b.grad) < 8e-3, plain
+        runs[plain] = [y.detach()] + [t.grad for t in ts]
+    for a, b in zip(runs[True], runs[False]):        # same operand rounding on both routes: fp32 summation order apart
+        assert rel_err(a, b) < 2e-3
+
+
 # ------------------------------------------------------------------------------------ layernorm
 @pytest.mark.parametrize('M,C', [(37, 64), (100, 256), (9, 226), (50, 384), (20, 1024), (5, 30), (3, 1536)])
 @pytest.mark.parametrize('mode', ['plain', 'res_mask', 'pe', 'relu_in'])

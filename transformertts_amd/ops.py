@@ -274,6 +274,7 @@ def attention_weights(qkv, key_pad, lse, B, H, T, dh, p_drop=0.0, drop: Optional
     return w
 
 
+_CONV_PLAIN = os.environ.get('TTSMI_CONV_PLAIN', '1') != '0'        # bf16 conv stacks as plain GEMMs over a zero-margin layout (ConvStackFn)
 _ATTN_DROPBITS = os.environ.get('TTSMI_ATTN_DROPBITS', '1') != '0'    # measurement knob: 0 = hash in the inner loops
 
 
@@ -720,10 +721,117 @@ class ConvStackFn(torch.autograd.Function):
     (forward: window over x with W^T; dgrad: window over dy with the flipped-tap layout `wd`, ReLU' of
     the producing layer fused; wgrad: wgrad_rows with the conv window) - fp32 activations throughout."""
 
+    # ---- bf16 "plain GEMM" route ---------------------------------------------------------------------------------
+    # Channels-last makes the window of frame t the contiguous run x[t-p : t+p+1, :], so a 'same' Conv1D over a layout
+    # with p zero rows around every sequence ([B, T + 2p, C], bf16) is an ordinary GEMM whose A rows OVERLAP: lda = C,
+    # K = k C, row j starts at buffer row j and its result is the output at buffer row j + p.  The rows computed across a
+    # sequence boundary land exactly on the margin rows of the output buffer and are zeroed (forward) or killed by the
+    # ReLU' mask, whose margins are zero (backward).  That puts these 100-GFLOP launches on the persistent LDS-DMA GEMM
+    # (gemm_bf16_dma_kernel: 691 / 781 TF at the reference-default shapes against 361 / 423 TF for the 64 x 128-tile
+    # window kernel on fp32 activations; the fp32 results are bit-identical) and the weight gradients - one bf16 row-major
+    # wgrad per tap, on shifted views - on wgrad_dma_kernel.  Every buffer carries 2p spare zero rows at its end so that
+    # the shifted views of the last tap stay inside it.
+    @staticmethod
+    def _plain_ok(x, n_layers, shadows, params):
+        if not _CONV_PLAIN or not shadows or x.dtype != torch.float32:
+            return False
+        k0 = params[0].shape[0]
+        for j in range(n_layers):
+            k, cin, cout = params[2 * j].shape
+            if shadows[j] is None or k != k0 or k % 2 == 0 or k < 3 or cin % 8 or cout % 8:
+                return False
+        return True
+
+    @staticmethod
+    def _padded(B, T, p, C, dtype, device):
+        """[B (T + 2p) + 2p, C] with zero margins / tail; returns (flat, interior view [B, T, C])."""
+        rows = B * (T + 2 * p)
+        flat = torch.empty((rows + 2 * p, C), dtype=dtype, device=device)
+        v = flat[:rows].view(B, T + 2 * p, C)
+        v[:, :p].zero_()
+        v[:, T + p:].zero_()
+        flat[rows:].zero_()
+        return flat, v[:, p:p + T]
+
+    @staticmethod
+    def _zero_margins(flat, B, T, p):
+        v = flat[:B * (T + 2 * p)].view(B, T + 2 * p, flat.shape[1])
+        v[:, :p].zero_()
+        v[:, T + p:].zero_()
+
+    @staticmethod
+    def _forward_plain(ctx, x, n_layers, shadows, params, sinks):
+        B, T, _ = x.shape
+        k = params[0].shape[0]
+        p = (k - 1) // 2
+        Mp = B * (T + 2 * p) - 2 * p                     # GEMM rows: every buffer row that has k rows below it
+        cur, inner = ConvStackFn._padded(B, T, p, x.shape[2], torch.bfloat16, x.device)
+        inner.copy_(x)                                   # fp32 -> bf16 into the padded layout, one launch
+        saved = [cur]
+        for j in range(n_layers):
+            w, b = params[2 * j], params[2 * j + 1]
+            _, cin, cout = w.shape
+            last = j == n_layers - 1
+            a_view = torch.as_strided(cur, (Mp, k * cin), (cin, 1))
+            out = torch.empty((cur.shape[0], cout), dtype=torch.float32 if last else torch.bfloat16, device=x.device)
+            hgemm_tn(a_view, shadows[j].wt, b, relu=not last, out=out[p:p + Mp])
+            if last:
+                y = out[:B * (T + 2 * p)].view(B, T + 2 * p, cout)[:, p:p + T].contiguous()
+            else:
+                ConvStackFn._zero_margins(out, B, T, p)
+                out[B * (T + 2 * p):].zero_()
+                saved.append(out)
+                cur = out
+        ctx.n = n_layers
+        ctx.plain = (B, T, k, p, Mp)
+        ctx.save_for_backward(*saved, *params[0::2])
+        ctx.sinks = sinks
+        ctx.shadows = shadows
+        return y
+
+    @staticmethod
+    def _backward_plain(ctx, dy):
+        n = ctx.n
+        B, T, k, p, Mp = ctx.plain
+        acts, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        sinks = ctx.sinks
+        rows = B * (T + 2 * p)
+        cout_last = ws[n - 1].shape[2]
+        g, g_inner = ConvStackFn._padded(B, T, p, cout_last, torch.bfloat16, dy.device)
+        g_inner.copy_(_c(dy))
+        outs = [None] * (2 * n)
+        dx = None
+        for j in reversed(range(n)):
+            gw, gb = (sinks[2 * j], sinks[2 * j + 1]) if sinks else (None, None)
+            w = ws[j]
+            _, cin, cout = w.shape
+            dw, db = _sink(gw, w), _sink(gb, w[0, 0])
+            xp = acts[j]
+            # dW[tap] = x[. + tap]^T . g[. + p] over all buffer rows (the margins of g are zero, so are those of x)
+            gv = g[p:p + rows]
+            for tap in range(k):
+                wgrad_rows_async(xp[tap:tap + rows], gv, dw[tap], db if tap == 0 else None)
+            if j > 0 or ctx.needs_input_grad[0]:
+                a_view = torch.as_strided(g, (Mp, k * cout), (cout, 1))
+                nxt = torch.empty((rows + 2 * p, cin), dtype=torch.bfloat16 if j > 0 else torch.float32, device=dy.device)
+                hgemm_tn(a_view, ctx.shadows[j].wd, None, relu_src=xp[p:p + Mp] if j > 0 else None, out=nxt[p:p + Mp])
+                if j > 0:
+                    nxt[:p].zero_()                       # rows no GEMM row writes; the mask zeroes the other margins
+                    nxt[p + Mp:].zero_()
+                    g = nxt
+                else:
+                    dx = nxt[:rows].view(B, T + 2 * p, cin)[:, p:p + T].contiguous()
+            outs[2 * j] = None if gw is not None else dw
+            outs[2 * j + 1] = None if gb is not None else db
+        return (dx, None, None, *outs, *([None] * len(sinks)))
+
     @staticmethod
     def forward(ctx, x, n_layers, shadows, *args):
         x = _c(x)
         params, sinks = args[:2 * n_layers], args[2 * n_layers:]
+        ctx.plain = None
+        if ConvStackFn._plain_ok(x, n_layers, shadows, params):
+            return ConvStackFn._forward_plain(ctx, x, n_layers, shadows, params, sinks)
         B, T, _ = x.shape
         acts = [x]
         h = x
@@ -749,6 +857,8 @@ class ConvStackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.plain is not None:
+            return ConvStackFn._backward_plain(ctx, dy)
         n = ctx.n
         acts, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
         sinks = ctx.sinks
