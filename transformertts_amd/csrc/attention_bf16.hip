@@ -731,15 +731,19 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
     // keys that took no part in the forward (>= klen) get probability 0 through a -inf logit
     const float padterm = !kact ? -INFINITY : ((p.key_pad[(long)b * p.T + key]) ? -1e9f * LOG2E : 0.f);
 
-    // head dims above 64: one pass (blockIdx.y) per 64 output columns of dK / dV - the score tiles are recomputed in
-    // every pass, the 2 x 6 accumulator tiles of dh = 192 at once would not leave registers for the operands
-    constexpr int NCB = DH > 64 ? 2 : DH / 32;
-    const int cb0 = blockIdx.y * NCB;
-    f32x16 dk[NCB], dv[NCB];
+    // head dims above 64 (SPLIT): the 2 x DH / 32 accumulator tiles of dK and dV together would not leave registers for
+    // the operands, so the launch has two passes (blockIdx.y) and each owns ONE of the outputs over all of its columns:
+    // pass 0 = dV needs only P (scores + exp: no dO.V^T, no delta), pass 1 = dK needs dS.  10 T^2 dh of products and two
+    // softmax recomputations - round 2 ran three passes of 64 columns of both (16 T^2 dh, three recomputations).
+    constexpr bool SPLIT = DH > 64;
+    constexpr int NCB = DH / 32;
+    constexpr int cb0 = 0;
+    const bool do_dv = !SPLIT || blockIdx.y == 0, do_dk = !SPLIT || blockIdx.y == 1;       // workgroup-uniform
+    f32x16 dk[NCB], dv[SPLIT ? 1 : NCB];          // SPLIT: `dk` is the pass's one accumulator set (dV in pass 0)
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[cb][r] = 0.f; dv[cb][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { dk[cb][r] = 0.f; if (!SPLIT) dv[cb][r] = 0.f; }
     const float inv_sqrt = 1.0f / p.sqrt_dk;
     const float c1 = LOG2E * inv_sqrt;
     const long stat0 = ((long)b * p.H + h) * p.T;
@@ -809,7 +813,12 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
             for (int qt = 0; qt < HKT / 32; ++qt) {
                 if (q0 + qt * 32 >= p.T || !wave_live) break;
                 f32x16 s = dot16<DH>(Qs, qt * 32 + l31, hh, kf);             // S[q][key]
-                f32x16 dp = dot16<DH>(Os, qt * 32 + l31, hh, vf);            // dP = dO.V^T
+                f32x16 dp;
+                if (do_dk) dp = dot16<DH>(Os, qt * 32 + l31, hh, vf);        // dP = dO.V^T
+                else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+                }
                 f32x16 pt;
                 const float ik2 = (DROP ? p.inv_keep : 1.0f) * inv_sqrt;
 #pragma unroll
@@ -833,10 +842,20 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
                     s[r] = pr * fmaf(dpr, ik2, -delS[ql]);                                     // dS
                 }
                 bf16x8 pb[2], sb[2];
-                to_frags(pt, pb);
-                to_frags(s, sb);
-                accumTR<DH, NCB>(Os, qt * 32, lane, pb, dv, cb0);             // dV^T += dO^T.P
-                accumTR<DH, NCB>(Qs, qt * 32, lane, sb, dk, cb0);             // dK^T += Q^T.dS
+                if constexpr (SPLIT) {
+                    if (do_dv) {
+                        to_frags(pt, pb);
+                        accumTR<DH, NCB>(Os, qt * 32, lane, pb, dk, cb0);     // pass 0: dV^T += dO^T.P
+                    } else {
+                        to_frags(s, sb);
+                        accumTR<DH, NCB>(Qs, qt * 32, lane, sb, dk, cb0);     // pass 1: dK^T += Q^T.dS
+                    }
+                } else {
+                    to_frags(pt, pb);
+                    to_frags(s, sb);
+                    accumTR<DH, NCB>(Os, qt * 32, lane, pb, dv, cb0);         // dV^T += dO^T.P
+                    accumTR<DH, NCB>(Qs, qt * 32, lane, sb, dk, cb0);         // dK^T += Q^T.dS
+                }
             }
         }
     }
@@ -845,8 +864,13 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
     int row0 = bx * 128 + wave * 32;
     int nvalid = min(32, p.T - row0);
     const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH + cb0 * 32);
-    storeT16<NCB * 32, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
-    storeT16<NCB * 32, QH>(patch, dv, DROP ? p.inv_keep : 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
+    if constexpr (SPLIT) {
+        if (do_dv) storeT16<NCB * 32, QH>(patch, dk, DROP ? p.inv_keep : 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
+        else storeT16<NCB * 32, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
+    } else {
+        storeT16<NCB * 32, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
+        storeT16<NCB * 32, QH>(patch, dv, DROP ? p.inv_keep : 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
+    }
 }
 
 // =================================================================================================
@@ -1165,7 +1189,7 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     hipEvent_t armed = ttsmi_take_stop_event();          // a hand-off event belongs to the LAST kernel of this entry point
     HDISPATCH_LDS(dh, hattn_bwd_dq_kernel, grid, dq_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dq(bf16)");
-    dim3 grid_kv(grid.x, dh > 64 ? dh / 64 : 1);
+    dim3 grid_kv(grid.x, dh > 64 ? 2 : 1);              // dh > 64: pass 0 = dV, pass 1 = dK (hattn_bwd_dkv_kernel)
     TTSMI_KNOB(dkv_pad, "TTSMI_ATTN_DKV_LDS", 0);
     ttsmi_arm_stop_event(armed);
     HDISPATCH_LDS(dh, hattn_bwd_dkv_kernel, grid_kv, dkv_pad, st, p);

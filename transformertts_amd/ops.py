@@ -742,22 +742,35 @@ class ConvStackFn(torch.autograd.Function):
                 return False
         return True
 
+    _MARGIN_IDX = {}
+
+    @staticmethod
+    def _margin_rows(B, T, p, device, mode):
+        """Row indices to zero in a [B (T + 2p) + 2p, C] buffer: 'all' = every margin row and the spare tail;
+        'ends' = the rows no GEMM row writes (the first p and everything from B (T + 2p) - p on).  Cached per shape:
+        zeroing is then ONE index_fill launch instead of three slice fills."""
+        key = (B, T, p, str(device), mode)
+        idx = ConvStackFn._MARGIN_IDX.get(key)
+        if idx is None:
+            rows = B * (T + 2 * p)
+            if mode == 'all':
+                r = torch.arange(rows + 2 * p)
+                t = r % (T + 2 * p)
+                idx = r[(t < p) | (t >= T + p) | (r >= rows)]
+            else:
+                idx = torch.cat([torch.arange(p), torch.arange(rows - p, rows + 2 * p)])
+            if len(ConvStackFn._MARGIN_IDX) > 64:
+                ConvStackFn._MARGIN_IDX.clear()
+            idx = ConvStackFn._MARGIN_IDX[key] = idx.to(device)
+        return idx
+
     @staticmethod
     def _padded(B, T, p, C, dtype, device):
         """[B (T + 2p) + 2p, C] with zero margins / tail; returns (flat, interior view [B, T, C])."""
         rows = B * (T + 2 * p)
         flat = torch.empty((rows + 2 * p, C), dtype=dtype, device=device)
-        v = flat[:rows].view(B, T + 2 * p, C)
-        v[:, :p].zero_()
-        v[:, T + p:].zero_()
-        flat[rows:].zero_()
-        return flat, v[:, p:p + T]
-
-    @staticmethod
-    def _zero_margins(flat, B, T, p):
-        v = flat[:B * (T + 2 * p)].view(B, T + 2 * p, flat.shape[1])
-        v[:, :p].zero_()
-        v[:, T + p:].zero_()
+        flat.index_fill_(0, ConvStackFn._margin_rows(B, T, p, device, 'all'), 0)
+        return flat, flat[:rows].view(B, T + 2 * p, C)[:, p:p + T]
 
     @staticmethod
     def _forward_plain(ctx, x, n_layers, shadows, params, sinks):
@@ -778,8 +791,7 @@ class ConvStackFn(torch.autograd.Function):
             if last:
                 y = out[:B * (T + 2 * p)].view(B, T + 2 * p, cout)[:, p:p + T].contiguous()
             else:
-                ConvStackFn._zero_margins(out, B, T, p)
-                out[B * (T + 2 * p):].zero_()
+                out.index_fill_(0, ConvStackFn._margin_rows(B, T, p, x.device, 'all'), 0)
                 saved.append(out)
                 cur = out
         ctx.n = n_layers
@@ -815,9 +827,8 @@ class ConvStackFn(torch.autograd.Function):
                 a_view = torch.as_strided(g, (Mp, k * cout), (cout, 1))
                 nxt = torch.empty((rows + 2 * p, cin), dtype=torch.bfloat16 if j > 0 else torch.float32, device=dy.device)
                 hgemm_tn(a_view, ctx.shadows[j].wd, None, relu_src=xp[p:p + Mp] if j > 0 else None, out=nxt[p:p + Mp])
-                if j > 0:
-                    nxt[:p].zero_()                       # rows no GEMM row writes; the mask zeroes the other margins
-                    nxt[p + Mp:].zero_()
+                if j > 0:                                 # rows no GEMM row writes; the mask zeroes the other margins
+                    nxt.index_fill_(0, ConvStackFn._margin_rows(B, T, p, dy.device, 'ends'), 0)
                     g = nxt
                 else:
                     dx = nxt[:rows].view(B, T + 2 * p, cin)[:, p:p + T].contiguous()
