@@ -150,6 +150,10 @@ int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float
                             float* weights, int B, int H, int T, int dh, float p_drop,
                             uint64_t seed, const int64_t* step_dev, uint32_t site, int dtype,
                             ttsmi_stream_t stream);
+/* The same with the dropout decisions read from the layer's keep-bit table (ttsmi_attention_dropmask; dtype must be
+ * TTSMI_BF16_IO): the hash costs ~23 vector instructions per weight, which makes the kernel compute-bound with dropout on. */
+int ttsmi_attention_weights_masked(const void* qkv, const uint8_t* key_pad, const float* lse, float* weights, int B, int H,
+                                   int T, int dh, float p_drop, const void* dropmask, int dtype, ttsmi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused [dropout ->] residual add -> LayerNormalization(eps) [-> + s*PE] [-> dropout] [-> row mask]

@@ -956,6 +956,12 @@ def test_bf16_attention_maps_equal_the_fp32_recomputation(B, H, T, dh, pdrop):
     assert w16.shape == (B, H, T, T) and torch.isfinite(w16).all()
     assert torch.equal(w16 == 0, w32 == 0)                                  # identical keep decisions / padded keys
     assert rel_err(w16, w32) < 2e-5                                          # same products, different summation order
+    if pdrop > 0:
+        # the keep decisions read from the layer's bit table (what a training step with maps uses): the same numbers
+        table = ops.attention_dropmask(B, H, T, pdrop, drop, 7, DEV)
+        wbits = ops.attention_weights(qkv, pad, lse, B, H, T, dh, pdrop, drop, 7, _lib.TTSMI_BF16_IO, table)
+        torch.cuda.synchronize()
+        assert torch.equal(wbits, w16)
     if pdrop == 0.0:
         rows = w16.sum(-1)
         assert float((rows - 1).abs().max()) < 2e-2                          # lse comes from the bf16 forward

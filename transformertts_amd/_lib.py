@@ -43,6 +43,7 @@ SIGNATURES = {
     'ttsmi_attention_bwd': (I, [P, P, P, P, P, P, P, I, I, I, I, F, c_uint64, P, c_uint32, P,
                                 c_size_t, I, S]),
     'ttsmi_attention_weights': (I, [P, P, P, P, I, I, I, I, F, c_uint64, P, c_uint32, I, S]),
+    'ttsmi_attention_weights_masked': (I, [P, P, P, P, I, I, I, I, F, P, I, S]),
     'ttsmi_attention_dropmask_bytes': (c_size_t, [I, I, I]),
     'ttsmi_attention_dropmask': (I, [P, I, I, I, F, c_uint64, P, c_uint32, S]),
     'ttsmi_attention_fwd_masked': (I, [P, P, P, P, P, I, I, I, I, F, P, I, S]),

@@ -589,6 +589,12 @@ int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const in
                                 dtype == TTSMI_BF16_IO, dropmask, (hipStream_t)stream);
 }
 
+int ttsmi_attention_weights_masked(const void* qkv, const uint8_t* key_pad, const float* lse, float* weights, int B, int H,
+                                   int T, int dh, float p_drop, const void* dropmask, int dtype, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(dtype == TTSMI_BF16_IO && dropmask, "attention_weights_masked: bf16 tensors and a keep-bit table required");
+    return ttsmi_hattention_weights(qkv, key_pad, lse, weights, B, H, T, dh, p_drop, 0, nullptr, 0, dropmask, (hipStream_t)stream);
+}
+
 int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float* lse,
                             float* weights, int B, int H, int T, int dh, float p_drop,
                             uint64_t seed, const int64_t* step_dev, uint32_t site, int dtype,
@@ -597,7 +603,7 @@ int ttsmi_attention_weights(const void* qkv, const uint8_t* key_pad, const float
     // TTSMI_BF16 (fp32 qkv, bf16 forward): recomputed from the fp32 q/k with the exact-fp32 MFMA (the maps are a logging
     // output; rows sum to 1 up to the bf16 rounding of the forward's log-sum-exp)
     if (dtype == TTSMI_BF16_IO)
-        return ttsmi_hattention_weights(qkv, key_pad, lse, weights, B, H, T, dh, p_drop, seed, step_dev, site,
+        return ttsmi_hattention_weights(qkv, key_pad, lse, weights, B, H, T, dh, p_drop, seed, step_dev, site, nullptr,
                                         (hipStream_t)stream);
     AttnP p;
     int rc = fill(p, qkv, key_pad, nullptr, B, H, T, dh, p_drop, seed, step_dev, site, TTSMI_F32, "attention_weights");

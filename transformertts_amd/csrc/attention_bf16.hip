@@ -952,7 +952,11 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
 // accumulator layout (lane = key, register = query) stores 128-byte row segments without a transpose.  The kernel is
 // bound by its 4 T^2 bytes of output per (b, h): 415 MB per decoder layer at the benchmark shape.  (The fp32 kernel of
 // attention.hip - 32 fp32 MFMAs per tile on a widened copy of qkv - took 2.4 x the write time.)
-template <int DH>
+// BITS: the dropout decisions come from the layer's keep-bit table (hattn_dropmask_kernel) instead of the hash - the
+// hash is ~23 vector instructions per weight, which made this write-bound kernel compute-bound with dropout on.  The lane
+// geometry is the dK/dV kernel's (lane = key, registers = queries): one dword per lane and 32-key block holds the bits of
+// the workgroup's 32 queries.
+template <int DH, bool BITS>
 __global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __restrict__ weights) {
     // A workgroup owns 32 queries of one (b, h) - their fragments stay in registers - and walks along the keys, 128 per
     // pass (32 per wave): its output is ONE contiguous block of 32 rows x T floats, written left to right.  (First
@@ -979,10 +983,25 @@ __global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __r
     // (small launches - batch-1 inference - split the key range over blockIdx.z so that the GPU still fills)
     const int kbeg = blockIdx.z * p.split_keys, kend = min(p.T, kbeg + p.split_keys);
     if (kbeg > 0) frags_of<DH, true>(Kb, p.ld, kbeg + wave * 32 + l31, kbeg + wave * 32 + l31 < p.T, hh, kf);
+    // BITS: word [bh][qt][kb][r'] of the table, 32-bit half hh', for this lane's key = 32 kb + rowmap16(r', hh')
+    const int ntile32 = (p.T + 31) >> 5;
+    const uint32_t* mlane = nullptr;
+    uint32_t mcur = 0u, mnext = 0u;
+    if (BITS) {
+        const int rp = (l31 & 3) + 4 * (l31 >> 3), hp = (l31 >> 2) & 1;
+        mlane = reinterpret_cast<const uint32_t*>(p.dmask) + ((((long)bh * ntile32 + blockIdx.x) * ntile32) * 16 + rp) * 2 + hp;
+        const int kb = (kbeg >> 5) + wave;
+        mnext = kb < ntile32 ? mlane[(long)kb * 32] : 0u;
+    }
     for (int k0 = kbeg; k0 < kend; k0 += 128) {
         const int key = k0 + wave * 32 + l31;
         const bool more = k0 + 128 < kend;
         if (more) frags_of<DH, true>(Kb, p.ld, key + 128, key + 128 < p.T, hh, kn);           // next pass's rows, a pass ahead
+        if (BITS) {
+            mcur = mnext >> (4 * hh);                                 // bit (r & 3) + 8 (r >> 2) = query rowmap16(r, hh)
+            const int kb = ((k0 + 128) >> 5) + wave;
+            if (more) mnext = kb < ntile32 ? mlane[(long)kb * 32] : 0u;
+        }
         if (k0 + wave * 32 < p.T) {                          // wave-uniform
             f32x16 s;
 #pragma unroll
@@ -996,7 +1015,8 @@ __global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __r
                 float pr = 0.f;
                 if (q < p.T && key < p.T) {
                     pr = __expf(s[r] * inv_sqrt + padterm - lse_r[r]);
-                    if (p.thr) pr *= ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q), (uint32_t)key, p.thr, p.inv_keep);
+                    if (BITS) pr = ((mcur >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pr * p.inv_keep : 0.f;
+                    else if (p.thr) pr *= ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q), (uint32_t)key, p.thr, p.inv_keep);
                     if (!vec) weights[(stat0 + q) * (long)p.T + key] = pr;
                 }
                 if (vec) tile[rowmap16(r, hh)][wave * 32 + l31] = pr;
@@ -1023,7 +1043,8 @@ __global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __r
 }
 
 int ttsmi_hattention_weights(const void* qkv, const uint8_t* key_pad, const float* lse, float* weights, int B, int H, int T,
-                             int dh, float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, hipStream_t st) {
+                             int dh, float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, const void* dropmask,
+                             hipStream_t st) {
     HAttnP p;
     static const int32_t* no_klen = reinterpret_cast<const int32_t*>(1);          // (not read by this kernel)
     int rc = hfill(p, qkv, key_pad, no_klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_weights(bf16)");
@@ -1037,10 +1058,17 @@ int ttsmi_hattention_weights(const void* qkv, const uint8_t* key_pad, const floa
     if (nz < 1) nz = 1;
     p.split_keys = ttsmi_cdiv(passes, nz) * 128;
     grid.z = ttsmi_cdiv(passes * 128, p.split_keys);
+    const bool bits = dropmask != nullptr && p.thr != 0;
+    p.dmask = (const uint64_t*)dropmask;
+#define HW_LAUNCH(DHV)                                                                                         \
+    do {                                                                                                       \
+        if (bits) hipLaunchKernelGGL((hattn_weights_kernel<DHV, true>), grid, dim3(256), 0, st, p, weights);   \
+        else hipLaunchKernelGGL((hattn_weights_kernel<DHV, false>), grid, dim3(256), 0, st, p, weights);       \
+    } while (0)
     switch (dh) {
-        case 32: hipLaunchKernelGGL((hattn_weights_kernel<32>), grid, dim3(256), 0, st, p, weights); break;
-        case 64: hipLaunchKernelGGL((hattn_weights_kernel<64>), grid, dim3(256), 0, st, p, weights); break;
-        case 192: hipLaunchKernelGGL((hattn_weights_kernel<192>), grid, dim3(256), 0, st, p, weights); break;
+        case 32: HW_LAUNCH(32); break;
+        case 64: HW_LAUNCH(64); break;
+        case 192: HW_LAUNCH(192); break;
         default:
             ttsmi_set_error("bf16 attention: head dim %d not built (32/64/192)", dh);
             return TTSMI_ERR_UNSUPPORTED;

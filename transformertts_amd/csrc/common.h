@@ -104,7 +104,8 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
                          float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, void* ws,
                          int qkv_is_bf16, const void* dropmask, hipStream_t st);
 int ttsmi_hattention_weights(const void* qkv, const uint8_t* key_pad, const float* lse, float* weights, int B, int H, int T,
-                             int dh, float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, hipStream_t st);
+                             int dh, float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, const void* dropmask,
+                             hipStream_t st);
 size_t ttsmi_hattention_fwd_split_ws_bytes(int B, int H, int T, int dh);
 int ttsmi_hattention_fwd_split(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx, float* lse,
                                int B, int H, int T, int dh, void* ws, size_t ws_bytes, hipStream_t st);

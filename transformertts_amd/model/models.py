@@ -395,7 +395,8 @@ class ForwardTransformer:
                 h, h_bf = ops.PlannedDenseBlockFn.apply(h, h_bf, plan)
                 if want_attn:
                     attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
-                        plan.t['qkv'], pad, plan.t['lse'], B, H, T, d // H, rate, drop, sites[0], ops._lib.TTSMI_BF16_IO)
+                        plan.t['qkv'], pad, plan.t['lse'], B, H, T, d // H, rate, drop, sites[0], ops._lib.TTSMI_BF16_IO,
+                        dmask)
                 if self._taps is not None:
                     self._taps.append((p, h.detach().reshape(B, T, d)))
                 continue
@@ -447,7 +448,7 @@ class ForwardTransformer:
                 key = (f'{name}_DenseBlock{i + 1}_SelfAttention' if dense
                        else f'{name}_ConvBlock{i - dense_blocks + 1}_SelfAttention')
                 attn[key] = ops.attention_weights(qkv.detach(), pad, lse, B, H, T, d // H, rate, drop, site,
-                                                  ops._lib.TTSMI_BF16_IO if io_h else ops.TTSMI_F32)
+                                                  ops._lib.TTSMI_BF16_IO if io_h else ops.TTSMI_F32, dmask if io_h else None)
             o = ops.LinearFn.apply(h, ctx, W[f'{p}.wo'], W[f'{p}.bo'], G[f'{p}.wo'], G[f'{p}.bo'], S(f'{p}.wo'),
                                    False, h_bf if io_h else None)
             h_bf = None

@@ -265,8 +265,13 @@ def lenreg_index(dur, cap):
 
 
 def attention_weights(qkv, key_pad, lse, B, H, T, dh, p_drop=0.0, drop: Optional[DropCtx] = None,
-                      site=0, dtype=TTSMI_F32):
+                      site=0, dtype=TTSMI_F32, dmask=None):
+    """dmask: the layer's keep-bit table (bf16 tensors only) - the same decisions as the hash, one bit test per weight."""
     w = torch.empty((B, H, T, T), dtype=torch.float32, device=qkv.device)
+    if dmask is not None and p_drop > 0 and dtype == _lib.TTSMI_BF16_IO:
+        check(_lib.lib().ttsmi_attention_weights_masked(_p(qkv), _p(key_pad), _p(lse), _p(w), B, H, T, dh, float(p_drop),
+                                                        _p(dmask), dtype, _stream()), 'attention_weights_masked')
+        return w
     check(_lib.lib().ttsmi_attention_weights(_p(qkv), _p(key_pad), _p(lse), _p(w), B, H, T, dh,
                                              float(p_drop), drop.seed if drop else 0,
                                              _p(drop.step_dev) if drop else None, site, dtype,
