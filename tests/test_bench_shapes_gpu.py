@@ -121,6 +121,125 @@ def test_fused_gemm_layernorm_forward_at_the_benchmark_rows(M, K, dual):
     assert float(y[(~live).to(DEV)].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('M,kernel', [(28800, 'rowgemm_dma_kernel<0, 128, 1>'), (6400, 'rowgemm_dma_kernel<0, 64, 1>')])
+@pytest.mark.parametrize('K,dual,want_y', [(512, True, False), (1024, False, True)])
+def test_fused_gemm_layernorm_forward_with_a_bf16_residual(M, kernel, K, dual, want_y):
+    """ttsmi_hgemm_ln_fwd_h, the form the planned dense blocks launch since the residual stream inside a stack is bf16
+    (ttsmi_dense_block.res16): the residual is the bf16 tensor the GEMM reads as well (K 512: [h | ctx].Wo + h with the
+    residual = the first A segment), the fp32 y is written only on request (K 1024: the last block of a stack)."""
+    ops, _lib, l = _env()
+    from transformertts_amd.ops import _p, _stream, check
+    N, pdrop, seed, stepv, site = 256, 0.1, 77, 2, 9
+    a = g(M, K, seed=1).to(torch.bfloat16)
+    w = g(K, N, seed=2, scale=0.05)
+    bias, gam, bet = g(N, seed=3), 1 + 0.1 * g(N, seed=4), 0.1 * g(N, seed=5)
+    res = a[:, :N].contiguous() if dual else g(M, N, seed=6).to(torch.bfloat16)
+    pad = (torch.arange(M) % 7 == 3).to(torch.uint8)
+    keep = torch.from_numpy(dr.keep_mask(seed, stepv, site, np.arange(M), np.arange(N), pdrop))
+    z = (a.double() @ bf(w) + bias.double()) * keep * (1.0 / (1.0 - float(np.float32(pdrop)))) + res.double()
+    y_ref, xh_ref, rstd_ref = _ln_ref(z, gam.double(), bet.double())
+    live = pad == 0
+    y_ref = y_ref * live[:, None]
+    ad, wd = a.to(DEV), w.to(DEV)
+    sh = ops.make_shadow(wd)
+    a1, a2 = (ad[:, :K // 2].contiguous(), ad[:, K // 2:].contiguous()) if dual else (ad, None)
+    step = torch.full((1,), stepv, dtype=torch.int64, device=DEV)
+    y = torch.full((M, N), 7.0, device=DEV)
+    yh = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    xh = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    rstd = torch.empty(M, device=DEV)
+    bias_d, gam_d, bet_d, pad_d = (t.to(DEV) for t in (bias, gam, bet, pad))
+    res_d = a1 if dual else res.to(DEV)
+    check(l.ttsmi_hgemm_ln_fwd_h(_p(a1), a1.stride(0), _p(a2), 0 if a2 is None else a2.stride(0), a1.shape[1] if dual else 0,
+                                 _p(sh.wt), sh.wt.stride(0), _p(bias_d), _p(res_d), _p(gam_d), _p(bet_d), _p(pad_d), pdrop, site,
+                                 seed, _p(step), EPS, _p(y) if want_y else None, _p(yh), _p(xh), _p(rstd), M, N, K, _stream()))
+    torch.cuda.synchronize()
+    assert last_kernel(l) == kernel
+    assert rel_err(rstd, rstd_ref) < 2e-5
+    assert rel_err(yh.float(), y_ref) < 4e-3
+    assert rel_err(xh.float()[live.to(DEV)], xh_ref[live]) < 4e-3
+    if want_y:
+        assert rel_err(y, y_ref) < 2e-5
+        assert float(y[(~live).to(DEV)].abs().max()) == 0.0
+    else:
+        assert float((y - 7.0).abs().max()) == 0.0                    # nothing written through the NULL fp32 output
+
+
+@pytest.mark.parametrize('M,tag', [(28800, '128'), (6400, '64')])
+@pytest.mark.parametrize('dres16', [True, False])
+def test_fused_dgrad_layernorm_backward_with_bf16_residual_gradients(M, tag, dres16):
+    """ttsmi_hgemm_ln_bwd_dual_h: the upstream partial gradient arrives as bf16 and the residual gradient leaves as bf16
+    (chained blocks) or fp32 (the bottom block of a stack); two K segments as the chained launch has them."""
+    ops, _lib, l = _env()
+    from transformertts_amd.ops import _p, _stream, check
+    N, K1, K2, pdrop, seed, stepv, site = 256, 768, 256, 0.1, 5, 9, 3
+    a1 = g(M, K1, seed=1, scale=0.3).to(torch.bfloat16)
+    a2 = g(M, K2, seed=2, scale=0.3).to(torch.bfloat16)
+    w1, w2 = g(N, K1, seed=3, scale=0.05), g(2 * N, K2, seed=4, scale=0.05)
+    part = g(M, N, seed=10).to(torch.bfloat16)
+    xh = g(M, N, seed=11).to(torch.bfloat16)
+    rstd = (0.5 + torch.rand(M, generator=torch.Generator().manual_seed(12))).float()
+    gam = 1 + 0.1 * g(N, seed=4)
+    pad = (torch.arange(M) % 5 == 1).to(torch.uint8)
+    live = (pad == 0).double()[:, None]
+    keep = torch.from_numpy(dr.keep_mask(seed, stepv, site, np.arange(M), np.arange(N), pdrop))
+    dy = (part.double() + a1.double() @ bf(w1).T + a2.double() @ bf(w2)[:N].T) * live
+    t = dy * gam.double()
+    x = xh.double()
+    dz = rstd.double()[:, None] * (t - t.mean(-1, keepdim=True) - x * (t * x).mean(-1, keepdim=True))
+    dx_ref = dz * keep * (1.0 / (1.0 - float(np.float32(pdrop))))
+    dg_ref, db_ref = (dy * x).sum(0), dy.sum(0)
+    w1d, w2d = w1.to(DEV).to(torch.bfloat16), w2.to(DEV).to(torch.bfloat16)
+    step = torch.full((1,), stepv, dtype=torch.int64, device=DEV)
+    dxb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    dres = torch.empty(M, N, device=DEV, dtype=torch.bfloat16 if dres16 else torch.float32)
+    nw = int(l.ttsmi_hgemm_ln_bwd_nparts(M))
+    ws = torch.empty(int(l.ttsmi_layernorm_partials_bytes(nw, N)), dtype=torch.uint8, device=DEV)
+    a1d, a2d, part_d, xh_d, rstd_d, gam_d, pad_d = (t.to(DEV) for t in (a1, a2, part, xh, rstd, gam, pad))
+    check(l.ttsmi_hgemm_ln_bwd_dual_h(_p(a1d), K1, _p(a2d), K2, K1, _p(w1d), K1, _p(w2d), K2, _p(part_d), _p(xh_d), _p(rstd_d),
+                                      _p(gam_d), _p(pad_d), pdrop, site, seed, _p(step), _p(dxb), _p(dres), int(dres16), _p(ws),
+                                      ws.numel(), M, N, K1 + K2, _stream()))
+    assert last_kernel(l) == f'rowgemm_dma_kernel<1, {tag}, {3 if dres16 else 1}>'
+    dg, db = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    with ops.ln_param_batch():
+        ops._ln_defer(ws, dg, db, None, M, N, nw)
+    torch.cuda.synchronize()
+    assert rel_err(dres.float(), dz) < (4e-3 if dres16 else 2e-5)
+    assert rel_err(dxb.float(), dx_ref) < 4e-3
+    assert rel_err(dg, dg_ref) < 1e-4 and rel_err(db, db_ref) < 1e-4
+    # argument errors stay errors in the bf16 forms: a null upstream gradient
+    assert l.ttsmi_hgemm_ln_bwd_dual_h(_p(a1d), K1, _p(a2d), K2, K1, _p(w1d), K1, _p(w2d), K2, None, _p(xh_d), _p(rstd_d),
+                                       _p(gam_d), _p(pad_d), pdrop, site, seed, _p(step), _p(dxb), _p(dres), int(dres16), _p(ws),
+                                       ws.numel(), M, N, K1 + K2, _stream()) != 0
+
+
+def test_layernorm_backward_xhat_with_a_bf16_residual_gradient():
+    """ttsmi_layernorm_bwd_xhat_h (the top block of a res16 stack): the same backward with dres stored as bf16."""
+    ops, _lib, l = _env()
+    from transformertts_amd.ops import _p, _stream, check
+    M, N, pdrop, seed, stepv, site = 28800, 256, 0.1, 5, 9, 3
+    dy = g(M, N, seed=10)
+    xh = g(M, N, seed=11).to(torch.bfloat16)
+    rstd = (0.5 + torch.rand(M, generator=torch.Generator().manual_seed(12))).float()
+    gam = 1 + 0.1 * g(N, seed=4)
+    pad = (torch.arange(M) % 5 == 1).to(torch.uint8)
+    step = torch.full((1,), stepv, dtype=torch.int64, device=DEV)
+    nw = int(l.ttsmi_layernorm_bwd_xhat_nparts(M))
+    ws = torch.empty(int(l.ttsmi_layernorm_partials_bytes(nw, N)), dtype=torch.uint8, device=DEV)
+    dy_d, xh_d, rstd_d, gam_d, pad_d = (t.to(DEV) for t in (dy, xh, rstd, gam, pad))
+    outs = {}
+    for h in (False, True):
+        dxb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        dres = torch.empty(M, N, device=DEV, dtype=torch.bfloat16 if h else torch.float32)
+        fn = l.ttsmi_layernorm_bwd_xhat_h if h else l.ttsmi_layernorm_bwd_xhat
+        check(fn(_p(dy_d), _p(xh_d), _p(rstd_d), _p(gam_d), _p(pad_d), pdrop, site, seed, _p(step), _p(dxb), _p(dres), _p(ws),
+                 ws.numel(), M, N, _stream()))
+        torch.cuda.synchronize()
+        outs[h] = (dxb, dres)
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][1], outs[False][1].to(torch.bfloat16))      # the fp32 result, rounded once
+
+
 # K 1024 = FFN1 dgrad + res-norm 1; K 768 = the qkv dgrad of the block above chained into res-norm 2
 @pytest.mark.parametrize('M,K', [(28800, 1024), (28800, 768), (16384 + 77, 1024)])
 def test_fused_dgrad_layernorm_backward_at_the_benchmark_rows(M, K):
