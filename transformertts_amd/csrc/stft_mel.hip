@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     constexpr int MELW_MAX = NFFT == 1024 ? 1536 : 2304;  // LDS copy of the sparse weights (<= 2 per bin)
     __shared__ float2 tw[NFFT];                       // exp(-2 pi i k / NFFT)
     __shared__ float2 buf[FR_PER_WG][NSUB][ZBUF];     // padded: physical index = i + (i >> 3)
-    __shared__ float mag[FR_PER_WG][NC + 8 + MEL_IT];      // bins NC+1.. stay 0 (mel items may read past NC)
+    __shared__ __attribute__((aligned(16))) float mag[FR_PER_WG][NC + 8 + MEL_IT];      // bins NC+1.. stay 0 (mel items may read past NC)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int k = tid; k < NFFT; k += 256) {
@@ -81,10 +81,12 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     __shared__ float partS[FR_PER_WG][MEL_ITEMS];
     if (mel_in_lds) {
         if (tid == 0) {
+            // an item starts at a multiple of 4 bins (the filter's first bin rounded down, zero weights in front): its
+            // magnitudes are read as three aligned float4 instead of twelve scalars
             int acc = 0;
             for (int m = 0; m < p.n_mels; ++m) {
                 itFirst[m] = acc;
-                acc += (melcntS[m] + MEL_IT - 1) / MEL_IT;
+                acc += ((melloS[m] & 3) + melcntS[m] + MEL_IT - 1) / MEL_IT;
             }
             itFirst[p.n_mels] = acc;
         }
@@ -92,11 +94,13 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         if (itFirst[p.n_mels] <= MEL_ITEMS) {
             for (int m = tid; m < p.n_mels; m += 256) {
                 const int first = itFirst[m], n = itFirst[m + 1] - first;
+                const int lead = melloS[m] & 3, lo4 = melloS[m] - lead;
                 for (int j = 0; j < n; ++j) {
-                    itLo[first + j] = melloS[m] + j * MEL_IT;
-                    const int cnt = min(MEL_IT, melcntS[m] - j * MEL_IT);
-                    for (int i = 0; i < MEL_IT; ++i)
-                        itWt[first + j][i] = i < cnt ? melwS[melptrS[m] + j * MEL_IT + i] : 0.f;
+                    itLo[first + j] = lo4 + j * MEL_IT;
+                    for (int i = 0; i < MEL_IT; ++i) {
+                        const int wi = j * MEL_IT + i - lead;                   // index into the filter's weights
+                        itWt[first + j][i] = (wi >= 0 && wi < melcntS[m]) ? melwS[melptrS[m] + wi] : 0.f;
+                    }
                 }
             }
         }
@@ -242,17 +246,17 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
             float* part = partS[wave];
             for (int it = lane; it < n_items; it += 64) {
                 const float4* w4 = reinterpret_cast<const float4*>(itWt[it]);
-                const float* x = mg + itLo[it];         // may run up to MEL_IT - 1 bins past the filter: zero weights
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+                const float4* x4 = reinterpret_cast<const float4*>(mg + itLo[it]);   // 16-byte aligned; may run past the filter: zero weights
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
                 for (int i = 0; i < MEL_IT / 4; ++i) {
-                    const float4 w = w4[i];
-                    s0 += w.x * x[4 * i];
-                    s1 += w.y * x[4 * i + 1];
-                    s2 += w.z * x[4 * i + 2];
-                    s0 += w.w * x[4 * i + 3];
+                    const float4 w = w4[i], x = x4[i];
+                    s0 += w.x * x.x;
+                    s1 += w.y * x.y;
+                    s2 += w.z * x.z;
+                    s3 += w.w * x.w;
                 }
-                part[it] = (s0 + s1) + s2;
+                part[it] = (s0 + s1) + (s2 + s3);
             }
             WAVE_SYNC();
         }
