@@ -956,8 +956,11 @@ static int hfill(HAttnP& p, const void* qkv, const uint8_t* key_pad, const int32
 // hash is ~23 vector instructions per weight, which made this write-bound kernel compute-bound with dropout on.  The lane
 // geometry is the dK/dV kernel's (lane = key, registers = queries): one dword per lane and 32-key block holds the bits of
 // the workgroup's 32 queries.
-template <int DH, bool BITS>
-__global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __restrict__ weights) {
+// DROP: 0 none, 1 hashed, 2 bit table.  Without the hash the kernel fits 128 registers = four workgroups per CU
+// (195 -> 173 us per decoder layer without dropout, 204 -> 183 us with the bit table); the hashed form spills there.
+template <int DH, int DROP>
+__global__ __launch_bounds__(256, (DH <= 64 && DROP != 1) ? 4 : 1) void hattn_weights_kernel(HAttnP p, float* __restrict__ weights) {
+    constexpr bool BITS = DROP == 2;
     // A workgroup owns 32 queries of one (b, h) - their fragments stay in registers - and walks along the keys, 128 per
     // pass (32 per wave): its output is ONE contiguous block of 32 rows x T floats, written left to right.  (First
     // version: one workgroup per 32 x 128 tile, 29 700 workgroups per decoder layer, 227 us; keys resident and a walk down
@@ -973,7 +976,7 @@ __global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __r
     frags_of<DH, true>(Qb, p.ld, q0 + l31, q0 + l31 < p.T, hh, qf);
     frags_of<DH, true>(Kb, p.ld, wave * 32 + l31, wave * 32 + l31 < p.T, hh, kf);
     const long stat0 = (long)bh * p.T;
-    const uint64_t dkey = p.thr ? ttsmi_drop_key(p.seed, p.step_dev, p.site) : 0;
+    const uint64_t dkey = DROP == 1 ? ttsmi_drop_key(p.seed, p.step_dev, p.site) : 0;
     const float inv_sqrt = 1.0f / p.sqrt_dk;
     __shared__ __attribute__((aligned(16))) float tile[32][132];
     const bool vec = (p.T & 3) == 0 && (((uintptr_t)weights) & 15) == 0;      // rows are 16-byte aligned
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(256) void hattn_weights_kernel(HAttnP p, float* __r
                 if (q < p.T && key < p.T) {
                     pr = __expf(s[r] * inv_sqrt + padterm - lse_r[r]);
                     if (BITS) pr = ((mcur >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pr * p.inv_keep : 0.f;
-                    else if (p.thr) pr *= ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q), (uint32_t)key, p.thr, p.inv_keep);
+                    else if (DROP == 1) pr *= ttsmi_keep_scale(dkey, (uint32_t)(stat0 + q), (uint32_t)key, p.thr, p.inv_keep);
                     if (!vec) weights[(stat0 + q) * (long)p.T + key] = pr;
                 }
                 if (vec) tile[rowmap16(r, hh)][wave * 32 + l31] = pr;
@@ -1062,8 +1065,9 @@ int ttsmi_hattention_weights(const void* qkv, const uint8_t* key_pad, const floa
     p.dmask = (const uint64_t*)dropmask;
 #define HW_LAUNCH(DHV)                                                                                         \
     do {                                                                                                       \
-        if (bits) hipLaunchKernelGGL((hattn_weights_kernel<DHV, true>), grid, dim3(256), 0, st, p, weights);   \
-        else hipLaunchKernelGGL((hattn_weights_kernel<DHV, false>), grid, dim3(256), 0, st, p, weights);       \
+        if (bits) hipLaunchKernelGGL((hattn_weights_kernel<DHV, 2>), grid, dim3(256), 0, st, p, weights);      \
+        else if (p.thr) hipLaunchKernelGGL((hattn_weights_kernel<DHV, 1>), grid, dim3(256), 0, st, p, weights); \
+        else hipLaunchKernelGGL((hattn_weights_kernel<DHV, 0>), grid, dim3(256), 0, st, p, weights);           \
     } while (0)
     switch (dh) {
         case 32: HW_LAUNCH(32); break;
