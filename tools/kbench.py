@@ -227,7 +227,13 @@ def bench_rowgemm():
                 j = i[0] % R; i[0] += 1
                 ops.hgemm_tn(As[j], wt, bias, out=o)
                 ops._ln_fwd(o, res[j], gam, bet, pad, PD, 5, drop, True)
-            for nm, fn in ((name + ' fused', fused), (name + ' gemm+ln', unfused)):
+            resh = [r.bfloat16() for r in res]
+
+            def fused_h():               # the form the planned blocks launch: bf16 residual, no fp32 output
+                j = i[0] % R; i[0] += 1
+                check(l.ttsmi_hgemm_ln_fwd_h(_p(As[j]), K, None, 0, 0, _p(wt), K, _p(bias), _p(resh[j]), _p(gam), _p(bet), _p(pad),
+                                             PD, 5, 7, _p(step), 1e-6, None, _p(yh), _p(xh), _p(rstd), M, N, K, _stream()))
+            for nm, fn in ((name + ' fused', fused), (name + ' fused res16', fused_h), (name + ' gemm+ln', unfused)):
                 t = timeit(fn)
                 out.append(dict(kind='rowg', name=nm, M=M, K=K, N=N, us=t, tflops=2.0 * M * N * K / t / 1e6, tbs=0.0))
         K = 1024
@@ -256,7 +262,16 @@ def bench_rowgemm():
             j = i[0] % R; i[0] += 1
             check(l.ttsmi_layernorm_bwd_xhat(_p(part[j]), _p(xh), _p(rstd), _p(gam), _p(pad), PD, 5, 7, _p(step), _p(dxb),
                                              _p(dres), _p(ws2), ws2.numel(), M, N, _stream()))
-        for nm, fn in (('da+LN1 bwd fused', fusedb), ('da+LN1 bwd gemm+ln', unfusedb), ('LN bwd xhat', xhatb)):
+        parth = [q.bfloat16() for q in part]
+        dresh = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+
+        def fusedb_h():                  # bf16 residual gradients in and out (chained blocks)
+            j = i[0] % R; i[0] += 1
+            check(l.ttsmi_hgemm_ln_bwd_dual_h(_p(As[j]), K, None, 0, 0, _p(wb), K, None, 0, _p(parth[j]), _p(xh), _p(rstd), _p(gam),
+                                              _p(pad), PD, 5, 7, _p(step), _p(dxb), _p(dresh), 1, _p(ws1), ws1.numel(), M, N, K,
+                                              _stream()))
+        for nm, fn in (('da+LN1 bwd fused', fusedb), ('da+LN1 bwd fused res16', fusedb_h), ('da+LN1 bwd gemm+ln', unfusedb),
+                       ('LN bwd xhat', xhatb)):
             t = timeit(fn)
             out.append(dict(kind='rowg', name=nm, M=M, K=K, N=N, us=t, tflops=2.0 * M * N * K / t / 1e6, tbs=0.0))
     return out
