@@ -377,12 +377,64 @@ def predict_bench(args):
                               'mel_frames_per_s': frames / p50})
         del model
     head = next(c for c in cases if c['batch'] == 1 and c['hipgraph'] and not c['attention_maps'])
-    print(json.dumps({'metric': 'predict p50 latency, batch 1, 400 phonemes, hipGraph-captured', 'value': head['p50_ms'],
-                      'unit': 'ms', 'n_gpus': 1, 'steps': len(lat), 'warmup': 4, 'higher_is_better': False,
-                      'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
-                      'config': {'workload': 'BASELINE.json configs[4]: ForwardTransformer.predict, d_model=256 6+6 dense '
-                                             'blocks, 400 phonemes, forced durations (mean 5.7 frames)'},
-                      'rtf_p50': head['rtf_p50'], 'cases': cases}))
+    big = next(c for c in cases if c['batch'] == 64 and c['hipgraph'] and not c['attention_maps'])
+    # what bounds it.  Batch 1 is a chain of ~100 graph nodes over 2 280 rows: its algorithmic bytes (every bf16 weight
+    # once + the activations of the path at their stored widths) against the HBM roof say how far from memory-bound a
+    # single utterance is (latency-bound); batch 64 is the same graph on 146 k rows, priced against the bf16 MFMA roof.
+    d, F, L = cfg['decoder_model_dimension'], cfg['decoder_feed_forward_dimension'], len(cfg['decoder_num_heads'])
+
+    def fwd_flops(rows_enc, rows_dec, B, Tm):
+        per_row = 2.0 * (3 * d * d + 2 * d * d + 2 * d * F)                       # qkv, [h | ctx] Wo, the two FFN layers
+        attn = lambda rows, T: 4.0 * rows * T * d                                  # QK^T and PV over all heads
+        return L * (per_row * (rows_enc + rows_dec) + attn(rows_enc, Tp) + attn(rows_dec, Tm)) + 2.0 * rows_dec * d * 80
+    n_par = sum(int(np.prod(v.shape)) for v in fo_weights(cfg).values())
+    rows_dec1 = head['frames']
+    act_bytes = lambda rows: L * rows * (3 * d + d + d + F + d + d + d) * 2.0 + rows * d * 4.0      # bf16 block tensors + fp32 ends
+    by1 = 2.0 * n_par + act_bytes(Tp) + act_bytes(rows_dec1) + rows_dec1 * 80 * 4.0
+    gbs1 = by1 / (head['p50_ms'] * 1e-3) / 1e9
+    fl64 = fwd_flops(64 * Tp, big['frames'], 64, big['frames'] // 64)
+    roof = {'bound': 'hbm', 'kernel': 'the whole batch-1 predict graph (two hipGraph replays, ~100 kernel nodes)',
+            'achieved': gbs1, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs1 / 8000.0, 'traffic': None,
+            'algorithmic_mb': by1 / 1e6,
+            'note': 'latency-bound: ~9 us per graph node at 2 280 rows; batch 64 amortises it',
+            'batch64': {'bound': 'mfma', 'achieved': fl64 / (big['p50_ms'] * 1e-3) / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                        'frac': fl64 / (big['p50_ms'] * 1e-3) / 1e12 / 2500.0, 'algorithmic_gflop': fl64 / 1e9}}
+    result = {'metric': 'predict p50 latency, batch 1, 400 phonemes, hipGraph-captured', 'value': head['p50_ms'],
+              'unit': 'ms', 'n_gpus': 1, 'steps': len(lat), 'warmup': 4, 'higher_is_better': False,
+              'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+              'config': {'workload': 'BASELINE.json configs[4]: ForwardTransformer.predict, d_model=256 6+6 dense '
+                                     'blocks, 400 phonemes, forced durations (mean 5.7 frames)'},
+              'rtf_p50': head['rtf_p50'], 'roofline': roof, 'cases': cases}
+    if not args.no_cpu_baseline:
+        result['cpu_baseline'] = predict_cpu_baseline(cfg, Tp, usable_cpus())
+    print(json.dumps(result))
+
+
+def fo_weights(cfg):
+    from oracle import ft_oracle as fo
+    return fo.init_weights({k: v for k, v in cfg.items() if k not in ('device', 'seed', 'precision', 'use_graph')}, seed=0)
+
+
+def predict_cpu_baseline(cfg, Tp, threads):
+    """The same batch-1 predict on the host: oracle/ft_oracle.py (torch-CPU fp32 restatement of model/models.py:518-550 with
+    forced durations), a bounded sample of calls."""
+    from oracle import ft_oracle as fo
+    torch.set_num_threads(threads)
+    ocfg = {k: v for k, v in cfg.items() if k not in ('device', 'seed', 'precision', 'use_graph')}
+    m = fo.ForwardTransformerOracle(ocfg, fo.init_weights(ocfg, seed=0), torch.float32)
+    rng = np.random.default_rng(1234)
+    tok = rng.integers(1, 127, size=(1, Tp)).astype(np.int32)
+    dur = rng.multinomial(int(5.7 * Tp), np.ones(Tp) / Tp, size=1).astype(np.int32)[..., None]
+    with torch.no_grad():
+        m.call(tok, target_durations=dur, training=False)                       # warm-up
+        n, t0 = 0, time.perf_counter()
+        while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 40):
+            m.call(tok, target_durations=dur, training=False)
+            n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {'value': dt * 1e3, 'unit': 'ms', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} batch-1 predict calls ({Tp} phonemes -> {int(dur.sum())} frames, forced durations, attention maps '
+                      f'materialised as the reference returns them), torch-CPU fp32 restatement, {threads} threads'}
 
 
 MEL_PMC_FILE = 'r03_pmc_hbm_traffic_mel.json'
