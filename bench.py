@@ -375,6 +375,7 @@ def predict_bench(args):
                 cases.append({'batch': B, 'hipgraph': graph, 'attention_maps': maps, 'frames': frames,
                               'audio_seconds': audio_s, 'p50_ms': p50 * 1e3, 'p90_ms': p90 * 1e3, 'rtf_p50': p50 / audio_s,
                               'mel_frames_per_s': frames / p50})
+        n_par = int(model.params.n_params)
         del model
     head = next(c for c in cases if c['batch'] == 1 and c['hipgraph'] and not c['attention_maps'])
     big = next(c for c in cases if c['batch'] == 64 and c['hipgraph'] and not c['attention_maps'])
@@ -387,7 +388,6 @@ def predict_bench(args):
         per_row = 2.0 * (3 * d * d + 2 * d * d + 2 * d * F)                       # qkv, [h | ctx] Wo, the two FFN layers
         attn = lambda rows, T: 4.0 * rows * T * d                                  # QK^T and PV over all heads
         return L * (per_row * (rows_enc + rows_dec) + attn(rows_enc, Tp) + attn(rows_dec, Tm)) + 2.0 * rows_dec * d * 80
-    n_par = sum(int(np.prod(v.shape)) for v in fo_weights(cfg).values())
     rows_dec1 = head['frames']
     act_bytes = lambda rows: L * rows * (3 * d + d + d + F + d + d + d) * 2.0 + rows * d * 4.0      # bf16 block tensors + fp32 ends
     by1 = 2.0 * n_par + act_bytes(Tp) + act_bytes(rows_dec1) + rows_dec1 * 80 * 4.0
@@ -408,11 +408,6 @@ def predict_bench(args):
     if not args.no_cpu_baseline:
         result['cpu_baseline'] = predict_cpu_baseline(cfg, Tp, usable_cpus())
     print(json.dumps(result))
-
-
-def fo_weights(cfg):
-    from oracle import ft_oracle as fo
-    return fo.init_weights({k: v for k, v in cfg.items() if k not in ('device', 'seed', 'precision', 'use_graph')}, seed=0)
 
 
 def predict_cpu_baseline(cfg, Tp, threads):
