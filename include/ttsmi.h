@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define TTSMI_VERSION 100
+/* Bumped whenever an entry point's argument list or the ttsmi_dense_block layout changes (101: round 3's `denom` argument of
+ * ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102: round 4).  Bindings check it at load
+ * time (transformertts_amd/_lib.py) so that a stale build is refused instead of being called with shifted arguments. */
+#define TTSMI_VERSION 102
 
 enum {
     TTSMI_OK = 0,

@@ -45,7 +45,7 @@ def test_library_exports_and_binds_every_declared_symbol(built):
     for name, nparams in d.items():
         assert hasattr(l, name), f'{name} not exported'
         assert len(built.SIGNATURES[name][1]) == nparams, name
-    assert l.ttsmi_version() == 100
+    assert l.ttsmi_version() == built.EXPECTED_VERSION == 102         # include/ttsmi.h TTSMI_VERSION, checked at load time
 
 
 def test_invalid_arguments_return_error_codes_not_crashes(built):
@@ -98,3 +98,28 @@ def test_dense_block_descriptor_layout_matches_the_header(tmp_path):
     out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert out[0] == ctypes.sizeof(DenseBlockDesc)
     assert out[1:] == [getattr(DenseBlockDesc, n).offset for n in names]
+
+
+def test_a_stale_library_is_refused_and_the_override_needs_an_opt_in(tmp_path):
+    """A build with another ABI version must not be called (its argument lists differ): _lib.lib() raises.  TTSMI_LIB is a
+    measurement knob: ignored unless TTSMI_ALLOW_LIB_OVERRIDE=1 is set with it (advisor finding, round 3)."""
+    import subprocess
+    import sys
+    src = tmp_path / 'stale.c'
+    src.write_text('int ttsmi_version(void) { return 100; }\n')
+    so = tmp_path / 'libttsmi_stale.so'
+    subprocess.run(['gcc', '-shared', '-fPIC', str(src), '-o', str(so)], check=True)
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'from transformertts_amd import _lib\n'
+            'print(_lib.LIB_PATH)\n'
+            'try:\n'
+            '    _lib.lib(); print("LOADED")\n'
+            'except _lib.TtsmiError as e:\n'
+            '    print("REFUSED", "ABI version 100" in str(e))\n') % ROOT
+    env = dict(os.environ, TTSMI_LIB=str(so))
+    env.pop('TTSMI_ALLOW_LIB_OVERRIDE', None)
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.split('\n')
+    assert out[0].endswith(os.path.join('transformertts_amd', 'lib', 'libttsmi.so')) and out[1] == 'LOADED', out
+    env['TTSMI_ALLOW_LIB_OVERRIDE'] = '1'
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.split('\n')
+    assert out[0] == str(so) and out[1] == 'REFUSED True', out

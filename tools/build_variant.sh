@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B library: tools/build_variant.sh NAME "EXTRA HIPCC FLAGS" file1.hip [file2.hip ...]
 # Recompiles only the named csrc files with the extra flags, links them with the objects of the regular build into
-# transformertts_amd/lib/libttsmi_NAME.so; select it with TTSMI_LIB=... (tools/kbench.py --variants, tools/ab_env.sh).
+# transformertts_amd/lib/libttsmi_NAME.so; select it with TTSMI_ALLOW_LIB_OVERRIDE=1 TTSMI_LIB=... (tools/kbench.py --variants, tools/ab_env.sh).
 set -e
 name=$1; extra=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)

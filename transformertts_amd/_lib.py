@@ -16,8 +16,12 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TTSMI_LIB (measurement only): another build of the same library, for same-box A/Bs of a source change
-# (tools/kbench.py --variants base TTSMI_LIB=<path>); the product and the tests always load the in-tree build
-LIB_PATH = os.environ.get('TTSMI_LIB') or os.path.join(_HERE, 'lib', 'libttsmi.so')
+# (tools/kbench.py --variants base TTSMI_LIB=<path>).  Honoured only together with TTSMI_ALLOW_LIB_OVERRIDE=1 - the
+# product and the tests always load the in-tree build - and any library, in-tree or not, must report the ABI
+# version this binding was written for (EXPECTED_VERSION, checked in lib()).
+_override = os.environ.get('TTSMI_LIB') if os.environ.get('TTSMI_ALLOW_LIB_OVERRIDE') == '1' else None
+LIB_PATH = _override or os.path.join(_HERE, 'lib', 'libttsmi.so')
+EXPECTED_VERSION = 102            # include/ttsmi.h: TTSMI_VERSION
 
 P = c_void_p          # every device pointer
 I = c_int
@@ -156,6 +160,14 @@ def lib() -> ctypes.CDLL:
         raise TtsmiError(f'{LIB_PATH} is missing - run `python -c "import __graft_entry__ as g; '
                          f'g.build()"` (hipcc --offload-arch=gfx950).  There is no CPU fallback.')
     l = ctypes.CDLL(LIB_PATH)
+    try:
+        l.ttsmi_version.restype = I
+        got = int(l.ttsmi_version())
+    except AttributeError as e:
+        raise TtsmiError(f'{LIB_PATH} does not export ttsmi_version; rebuild it') from e
+    if got != EXPECTED_VERSION:
+        raise TtsmiError(f'{LIB_PATH} reports ABI version {got}, this binding needs {EXPECTED_VERSION}: a stale or variant '
+                         f'build would be called with shifted arguments - rebuild it (python -m transformertts_amd.build)')
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(l, name)

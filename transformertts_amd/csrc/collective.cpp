@@ -28,13 +28,20 @@ struct Rccl {
     all_reduce_fn all_reduce = nullptr;
     error_string_fn error_string = nullptr;
     bool ok = false;
+    char why[256] = "symbols missing";                   // dlerror() captured ONCE, at the failing dlopen (a second call returns NULL)
     Rccl() {
         const char* names[] = {"librccl.so.1", "librccl.so"};
         for (const char* n : names) {                    // already in the process (torch's copy)?
             handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
             if (handle) break;
         }
-        for (int i = 0; !handle && i < 2; ++i) handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        for (int i = 0; !handle && i < 2; ++i) {
+            handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+            if (!handle) {
+                const char* e = dlerror();
+                if (e) { strncpy(why, e, sizeof(why) - 1); why[sizeof(why) - 1] = 0; }
+            }
+        }
         if (!handle) return;
         get_unique_id = (get_unique_id_fn)dlsym(handle, "ncclGetUniqueId");
         comm_init_rank = (comm_init_rank_fn)dlsym(handle, "ncclCommInitRank");
@@ -55,7 +62,7 @@ int fail(const char* who, int rc) {
 }
 int need(const char* who) {
     if (rccl().ok) return TTSMI_OK;
-    ttsmi_set_error("%s: librccl.so.1 could not be loaded (%s)", who, dlerror() ? dlerror() : "symbols missing");
+    ttsmi_set_error("%s: librccl.so.1 could not be loaded (%s)", who, rccl().why);
     return TTSMI_ERR_UNSUPPORTED;
 }
 }  // namespace

@@ -216,8 +216,25 @@ static int wgrad_side(const ttsmi_dense_block* D, WgradBatch* wb, int ev, bool r
     return TTSMI_OK;
 }
 
+static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf, const float* dout);
+
+// The armed / pre-recorded hand-off events are thread-local state that must not outlive the call that set them: an error
+// return between arm() and the producing launch would otherwise leave an event armed for the next, unrelated
+// TTSMI_LAUNCH_EV launch of this thread (advisor finding, round 3).  Every exit path goes through here: nothing stays
+// armed; `t_prerecorded` survives a SUCCESSFUL chained call only (the lower block's call consumes it).
 int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf, const float* dout) {
+    const int rc = dense_block_bwd_impl(D, h, h_bf, dout);
+    (void)ttsmi_take_stop_event();
+    t_armed = nullptr;
+    if (rc != TTSMI_OK) t_prerecorded = nullptr;
+    return rc;
+}
+
+}  // extern "C"
+
+static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf, const float* dout) {
     TRY(check_desc(D, "dense_block_bwd"));
+    if (t_prerecorded != nullptr && t_prerecorded != (hipEvent_t)D->ev[0]) t_prerecorded = nullptr;   // left by an aborted chain
     TTSMI_CHECK_ARG(h_bf && (h || D->fuse_ln) && (dout || (D->fuse_ln && D->ln2_done)), "dense_block_bwd: null input");
     // res16: the gradient of the residual stream travels as bf16 between the fused kernels - `da` always, `dh` when this
     // block's last launch is the chained full-row kernel that consumes it (otherwise dh is the fp32 result of the call)
@@ -368,5 +385,3 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
                        TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                       // dh += dqkv.Wqkv^T
     return TTSMI_OK;
 }
-
-}  // extern "C"

@@ -497,12 +497,22 @@ class ForwardTransformer:
                 del self._plans[k]
             self._plan_shared.get((prefix, key[1]), {}).clear()
             plan = None
+            # graphs that baked the dropped plans' buffers in are dropped with them and re-captured on their next use
+            # (they used to pin a complete copy of the stack's buffers per growth event: HBM grew with the number of
+            # growth events under graph mode - advisor finding, round 3)
+            if key[1] != 'fwd':
+                self._graphs.clear()
+            elif prefix == 'enc':
+                self._infer_graphs.clear()               # graph A of every input shape holds the encoder plans
+            else:
+                for A in self._infer_graphs.values():    # graphs B (one per decoder-length bucket) hold the decoder plans
+                    A['B'].clear()
         if plan is None:
             Pb, Gb, Sb = self._block_views(p)
             # every block of a stack gets the same capacity (the first one to be built decides; a little headroom so
             # that a slowly growing maximum does not rebuild the stack every few steps)
             cap = max([pl.cap for k, pl in self._plans.items() if k[0].startswith(prefix + '.') and k[1] == key[1]] +
-                      [M if not self._plans_grown.get((prefix, key[1])) else (M * 9 + 7) // 8])
+                      [M if not self._plans_grown.get((prefix, key[1])) else (M * 3 + 1) // 2])     # geometric growth: few rebuilds
             self._plans_grown[(prefix, key[1])] = True
             plan = self._plans[key] = ops.DenseBlockPlan(Pb, Gb, Sb, B, H, T, self.device,
                                                          self._plan_shared.setdefault((prefix, key[1]), {}), self.fuse_ln,

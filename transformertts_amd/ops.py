@@ -1691,7 +1691,13 @@ class DenseBlockPlan:
         else:
             need = max(256, int(l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, d // H)))
             if sh['attn_ws'] is None or sh['attn_ws'].numel() < need:
-                sh['attn_ws'] = _ws(need, self.t['qkv'].device)       # (inference: the old scratch stays alive in captured graphs' plans)
+                # Every scratch ever bound stays alive on the stack-wide entry: inference graphs captured earlier hold the
+                # old tensor's RAW pointer (their plans are shared objects whose `_attn_ws` moves on with this rebind), so
+                # freeing it would let a later replay write attention partials into memory the allocator has handed to
+                # somebody else (advisor finding, round 3).  The need is monotone per stack, so the list stays short.
+                if sh['attn_ws'] is not None:
+                    sh.setdefault('attn_ws_retired', []).append(sh['attn_ws'])
+                sh['attn_ws'] = _ws(need, self.t['qkv'].device)
             self._attn_ws = sh['attn_ws']
         D.attn_ws, D.attn_ws_bytes = sh['attn_ws'].data_ptr(), sh['attn_ws'].numel()
         D.attn_split = int(not self.backward and os.environ.get('TTSMI_ATTN_SPLIT', '1') != '0' and
