@@ -173,7 +173,7 @@ def kernel_family(name, args):
     return KERNEL_OF.get(name, RIDERS)
 
 
-PMC_FILE = 'r03_pmc_hbm_traffic_bf16.json'
+PMC_FILE = 'r04_pmc_hbm_traffic_bf16.json'
 PMC_KERNELS = {       # kernel family -> (rocprof names of its kernels, names of helper kernels of the same entry point)
     KERNEL_OF['ttsmi_hgemm_tn']: (['gemm_bf16_kernel', 'gemm_bf16_dma_kernel', 'gemm_bf16_deep_kernel', 'gemm_k256_kernel'], []),
     ROWGEMM: (['rowgemm_dma_kernel', 'rowgemm_kernel'], []),
@@ -265,15 +265,37 @@ def group_records(recs):
     return groups
 
 
+def _pmc_file(name):
+    """A committed PMC summary, or None when it is absent or was NOT collected on the build in this tree: the file is
+    stamped with transformertts_amd.build.library_digest() by tools/rocpd_pmc_traffic.py, and a kernel change without a
+    PMC refresh must not report stale bytes (round-3 review)."""
+    path = os.path.join(ROOT, 'profiles', name)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        from transformertts_amd.build import library_digest
+        return d if d.get('lib_digest') == library_digest() else None
+    except (OSError, ValueError):
+        return None
+
+
+def stamped_pmc(name, prefixes):
+    d = _pmc_file(name)
+    if d is None:
+        return None
+    hit = [v for k, v in d.get('kernels', {}).items() if any(k.startswith(p) for p in prefixes)]
+    return hit[0]['hbm_bytes_per_launch'] if hit else None
+
+
 def pmc_traffic(kernel_family: str):
     """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/, collected by
     tools/gpu_profile.sh with separate FETCH_SIZE / WRITE_SIZE runs and the guide's gfx950 correction)."""
-    path = os.path.join(ROOT, 'profiles', PMC_FILE)
     entry = PMC_KERNELS.get(kernel_family.replace(SIDE, ''))
-    if not entry or not os.path.exists(path):
+    d = _pmc_file(PMC_FILE)
+    if not entry or d is None:
         return None
     mains, helpers = entry
-    ks = json.load(open(path))['kernels']
+    ks = d['kernels']
     n = b = 0.0
     for k, v in ks.items():
         if any(k.startswith(p) for p in mains):
@@ -285,16 +307,14 @@ def pmc_traffic(kernel_family: str):
 
 
 def pmc_step_totals():
-    """Whole-step HBM bytes and kernel launches from the same committed PMC passes (None when absent)."""
-    path = os.path.join(ROOT, 'profiles', PMC_FILE)
-    if not os.path.exists(path):
-        return None
-    d = json.load(open(path))
-    if 'hbm_bytes_per_step' not in d:
+    """Whole-step HBM bytes and kernel launches from the same committed PMC passes (None when absent / stale)."""
+    d = _pmc_file(PMC_FILE)
+    if d is None or 'hbm_bytes_per_step' not in d:
         return None
     return {'hbm_gb_per_step': d['hbm_bytes_per_step'] / 1e9, 'kernel_launches_per_step': d['launches_per_step'],
-            'source': 'profiles/' + PMC_FILE + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at the '
-                      'commit the file was collected on, all kernels of a step, both streams)'}
+            'lib_digest': d.get('lib_digest'),
+            'source': 'profiles/' + PMC_FILE + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench on the '
+                      'build with this digest, all kernels of a step, both streams)'}
 
 
 def usable_cpus() -> int:
@@ -335,12 +355,9 @@ def cpu_baseline(cfg, shape, threads):
                       f'with ms_per_step_with_attention_maps)'}
 
 
-def predict_bench(args):
-    """BASELINE.json configs[4]: inference-only ForwardTransformer.predict, batch 1 and batch 64, long sentences (400
-    phonemes), hipGraph-captured (model.graph_inference), 1 GPU: p50 / p90 latency and RTF = latency / seconds of audio
-    (hop 256 @ 22.05 kHz).  Durations are forced (synthetic, mean 5.7 frames per phoneme -> ~2 280 frames) so that the
-    decoder length is realistic with random-init weights.  Two lines per batch size: without the attention maps and -
-    as the reference's predict returns them - with all 12 maps materialised."""
+def predict_cases(precision, reps, graphs=(True, False), with_maps=True):
+    """Latency cases of ForwardTransformer.predict at 400 phonemes with forced durations (mean 5.7 frames per phoneme):
+    batch 1 and batch 64, hipGraph-captured and/or eager, optionally with the 12 attention maps at batch 1."""
     from transformertts_amd.model.models import ForwardTransformer
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
@@ -348,14 +365,15 @@ def predict_bench(args):
     rng = np.random.default_rng(1234)
     Tp = 400
     cases = []
-    for graph in (True, False):
-        model = ForwardTransformer.from_config(dict(cfg, device=str(dev), seed=0, precision=args.precision,
+    n_par = 0
+    for graph in graphs:
+        model = ForwardTransformer.from_config(dict(cfg, device=str(dev), seed=0, precision=precision,
                                                     graph_inference=graph))
         for B in (1, 64):
             tok = torch.from_numpy(rng.integers(1, 127, size=(B, Tp)).astype(np.int32)).to(dev)
             dur = torch.from_numpy(rng.multinomial(int(5.7 * Tp), np.ones(Tp) / Tp, size=B).astype(np.int32)).to(dev)
             for maps in (False, True):
-                if maps and (B > 1 or not graph):
+                if maps and (B > 1 or not graph or not with_maps):
                     continue              # 12 maps of [64, 4, 2280, 2280] fp32 are 63 GB: batch 1 only
                 model.return_attention = maps
                 fn = lambda: model.predict(tok, encode=False, phoneme_durations=dur)   # noqa: E731
@@ -363,7 +381,7 @@ def predict_bench(args):
                     o = fn()
                 torch.cuda.synchronize()
                 lat = []
-                for _ in range(max(20, args.steps * 3)):
+                for _ in range(reps):
                     t0 = time.perf_counter()
                     o = fn()
                     torch.cuda.synchronize()
@@ -377,11 +395,13 @@ def predict_bench(args):
                               'mel_frames_per_s': frames / p50})
         n_par = int(model.params.n_params)
         del model
-    head = next(c for c in cases if c['batch'] == 1 and c['hipgraph'] and not c['attention_maps'])
-    big = next(c for c in cases if c['batch'] == 64 and c['hipgraph'] and not c['attention_maps'])
-    # what bounds it.  Batch 1 is a chain of ~100 graph nodes over 2 280 rows: its algorithmic bytes (every bf16 weight
-    # once + the activations of the path at their stored widths) against the HBM roof say how far from memory-bound a
-    # single utterance is (latency-bound); batch 64 is the same graph on 146 k rows, priced against the bf16 MFMA roof.
+    return cfg, Tp, cases, n_par
+
+
+def predict_roofline(cfg, Tp, head, big, n_par):
+    """What bounds predict.  Batch 1 is a chain of ~100 graph nodes over 2 280 rows: its algorithmic bytes (every bf16
+    weight once + the activations of the path at their stored widths) against the HBM roof say how far from memory-bound
+    a single utterance is (latency-bound); batch 64 is the same graph on 146 k rows, priced against the bf16 MFMA roof."""
     d, F, L = cfg['decoder_model_dimension'], cfg['decoder_feed_forward_dimension'], len(cfg['decoder_num_heads'])
 
     def fwd_flops(rows_enc, rows_dec, B, Tm):
@@ -393,14 +413,27 @@ def predict_bench(args):
     by1 = 2.0 * n_par + act_bytes(Tp) + act_bytes(rows_dec1) + rows_dec1 * 80 * 4.0
     gbs1 = by1 / (head['p50_ms'] * 1e-3) / 1e9
     fl64 = fwd_flops(64 * Tp, big['frames'], 64, big['frames'] // 64)
-    roof = {'bound': 'hbm', 'kernel': 'the whole batch-1 predict graph (two hipGraph replays, ~100 kernel nodes)',
+    return {'bound': 'hbm', 'kernel': 'the whole batch-1 predict graph (two hipGraph replays, ~100 kernel nodes)',
             'achieved': gbs1, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs1 / 8000.0, 'traffic': None,
             'algorithmic_mb': by1 / 1e6,
             'note': 'latency-bound: ~9 us per graph node at 2 280 rows; batch 64 amortises it',
             'batch64': {'bound': 'mfma', 'achieved': fl64 / (big['p50_ms'] * 1e-3) / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
                         'frac': fl64 / (big['p50_ms'] * 1e-3) / 1e12 / 2500.0, 'algorithmic_gflop': fl64 / 1e9}}
+
+
+def predict_bench(args):
+    """BASELINE.json configs[4]: inference-only ForwardTransformer.predict, batch 1 and batch 64, long sentences (400
+    phonemes), hipGraph-captured (model.graph_inference), 1 GPU: p50 / p90 latency and RTF = latency / seconds of audio
+    (hop 256 @ 22.05 kHz).  Durations are forced (synthetic, mean 5.7 frames per phoneme -> ~2 280 frames) so that the
+    decoder length is realistic with random-init weights.  Two lines per batch size: without the attention maps and -
+    as the reference's predict returns them - with all 12 maps materialised."""
+    reps = max(20, args.steps * 3)
+    cfg, Tp, cases, n_par = predict_cases(args.precision, reps)
+    head = next(c for c in cases if c['batch'] == 1 and c['hipgraph'] and not c['attention_maps'])
+    big = next(c for c in cases if c['batch'] == 64 and c['hipgraph'] and not c['attention_maps'])
+    roof = predict_roofline(cfg, Tp, head, big, n_par)
     result = {'metric': 'predict p50 latency, batch 1, 400 phonemes, hipGraph-captured', 'value': head['p50_ms'],
-              'unit': 'ms', 'n_gpus': 1, 'steps': len(lat), 'warmup': 4, 'higher_is_better': False,
+              'unit': 'ms', 'n_gpus': 1, 'steps': reps, 'warmup': 4, 'higher_is_better': False,
               'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
               'config': {'workload': 'BASELINE.json configs[4]: ForwardTransformer.predict, d_model=256 6+6 dense '
                                      'blocks, 400 phonemes, forced durations (mean 5.7 frames)'},
@@ -410,7 +443,7 @@ def predict_bench(args):
     print(json.dumps(result))
 
 
-def predict_cpu_baseline(cfg, Tp, threads):
+def predict_cpu_baseline(cfg, Tp, threads, seconds=10.0):
     """The same batch-1 predict on the host: oracle/ft_oracle.py (torch-CPU fp32 restatement of model/models.py:518-550 with
     forced durations), a bounded sample of calls."""
     from oracle import ft_oracle as fo
@@ -423,7 +456,7 @@ def predict_cpu_baseline(cfg, Tp, threads):
     with torch.no_grad():
         m.call(tok, target_durations=dur, training=False)                       # warm-up
         n, t0 = 0, time.perf_counter()
-        while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 40):
+        while n < 3 or (time.perf_counter() - t0 < seconds and n < 40):
             m.call(tok, target_durations=dur, training=False)
             n += 1
     dt = (time.perf_counter() - t0) / n
@@ -432,7 +465,7 @@ def predict_cpu_baseline(cfg, Tp, threads):
                       f'materialised as the reference returns them), torch-CPU fp32 restatement, {threads} threads'}
 
 
-MEL_PMC_FILE = 'r03_pmc_hbm_traffic_mel.json'
+MEL_PMC_FILE = 'r04_pmc_hbm_traffic_mel.json'
 
 
 def _mel_cpu_clip(args):
@@ -442,7 +475,7 @@ def _mel_cpu_clip(args):
     return mo.mel_spectrogram(args).shape[0]
 
 
-def mel_cpu_baseline(clips, bytes_per_clip, cores):
+def mel_cpu_baseline(clips, bytes_per_clip, cores, single_seconds=3.0, pool_seconds=10.0):
     """NumPy restatement (oracle/mel_oracle.py: rfft + dense mel matmul, what librosa does) timed on the host: one core,
     and a pool of `cores` single-threaded processes (the reference extracts features with a process pool).  Bounded
     sample: the pool works for ~10 s."""
@@ -452,7 +485,7 @@ def mel_cpu_baseline(clips, bytes_per_clip, cores):
     with threadpool_limits(1):                             # ONE core: no BLAS threads behind the mel matmul
         mo.mel_spectrogram(clips[0])                       # filterbank construction / FFT plan warm-up
         n1, t0 = 0, time.perf_counter()
-        while n1 < 4 or time.perf_counter() - t0 < 3.0:
+        while n1 < 4 or time.perf_counter() - t0 < single_seconds:
             mo.mel_spectrogram(clips[n1 % len(clips)])
             n1 += 1
         dt1 = time.perf_counter() - t0
@@ -461,7 +494,7 @@ def mel_cpu_baseline(clips, bytes_per_clip, cores):
             t0 = time.perf_counter()
             pool.map(_mel_cpu_clip, clips, chunksize=1)    # workers warm + a timing of one pass
             one_pass = time.perf_counter() - t0
-            reps = max(1, min(512, int(10.0 / max(one_pass, 1e-3))))
+            reps = max(1, min(512, int(pool_seconds / max(one_pass, 1e-3))))
             work = clips * reps
             t0 = time.perf_counter()
             pool.map(_mel_cpu_clip, work, chunksize=1)
@@ -482,15 +515,26 @@ def mel_bench(args):
     A step = one pass over the rank's 10 000 clips.  value = algorithmic GB/s (4 N bytes of samples in + 320 bytes per
     frame out) summed over ranks / max-over-ranks time, against the 8 TB/s HBM roof.  Replicas only:
     every rank extracts its own clips, no collective on the data path."""
-    from transformertts_amd import dp, ops
-    from transformertts_amd.data.audio import Audio
+    from transformertts_amd import dp
     rank, local, world = dp.init_process_group()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    n_clips = args.clips
+    result = mel_run(torch.device('cuda', local), rank, world, args.clips, args.steps, args.warmup,
+                     roofline=not args.no_roofline, cpu=not args.no_cpu_baseline)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        torch.distributed.destroy_process_group()
+
+
+def mel_run(dev, rank, world, n_clips, steps, warmup, roofline=True, cpu=True, cpu_single_s=3.0, cpu_pool_s=10.0):
+    """The mel workload on one rank (see mel_bench); returns the driver-format result dict (complete on rank 0)."""
+    from transformertts_amd import ops
+    from transformertts_amd.data.audio import Audio
     audio = Audio(22050, 1024, 80, 256, 1024, 0, 8000, 'MelGAN', device=str(dev))
     rng = np.random.default_rng(1234 + rank)
     lens = np.clip(rng.normal(145000, 48000, n_clips), 24000, 222000).astype(np.int64)      # SURVEY.md 8d
@@ -517,28 +561,28 @@ def mel_bench(args):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                       # (the launch goes to torch's current stream: these events bracket the kernels)
-    for _ in range(args.steps):
+    for _ in range(steps):
         mel = step()
     ev1.record()
     sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    kernel_ms = ev0.elapsed_time(ev1) / steps
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert bool(torch.isfinite(mel[:4096]).all())
     byt = 4.0 * total + 4.0 * 80 * frames              # algorithmic bytes of one pass of one rank
-    sec = elapsed / args.steps
+    sec = elapsed / steps
     result = {
         'metric': 'mel feature extraction, algorithmic GB/s (wav -> 1024-pt STFT -> 80-bin log-mel)',
-        'value': byt * world / sec / 1e9, 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'value': byt * world / sec / 1e9, 'unit': 'GB/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
         'ms_per_step': 1e3 * sec, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic',
         'config': {'workload': f'BASELINE.json configs[3]: mel microbench, {n_clips} LJSpeech-length clips per GPU '
@@ -549,32 +593,233 @@ def mel_bench(args):
                    'algorithmic_bytes_per_step': byt * world, 'parallelism': f'replicas x{world}'},
         'clips_per_s': n_clips * world / sec, 'frames_per_s': frames * world / sec,
     }
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and roofline:
         gbs = byt / kernel_ms / 1e6
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', MEL_PMC_FILE)) as f:
-                ks = json.load(f).get('kernels', {})
-            hit = [v for k, v in ks.items() if k.startswith('stft_logmel_kernel')]
-            traffic = hit[0]['hbm_bytes_per_launch'] if hit else None
-        except (OSError, ValueError):
-            pass
+        traffic = stamped_pmc(MEL_PMC_FILE, ['stft_logmel_kernel'])
+        gflop = frames * 28.6e3 / 1e9
         result['roofline'] = {
             'bound': 'hbm', 'kernel': 'stft_logmel_kernel<1024>', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
             'frac': gbs / PEAK_HBM_GBS, 'traffic': traffic,
-            'traffic_note': (f'HBM bytes per launch from the committed PMC passes (profiles/{MEL_PMC_FILE})' if traffic else None),
+            'traffic_note': (f'HBM bytes per launch from the committed PMC passes (profiles/{MEL_PMC_FILE})' if traffic else
+                             'null: no PMC file collected on this build of the library (digest mismatch or file absent)'),
             'avg_launch_ms': kernel_ms, 'algorithmic_mb_per_launch': byt / 1e6,
-            'algorithmic_gflop_per_launch': frames * 28.6e3 / 1e9,
-            'flop_per_byte': frames * 28.6e3 / byt,
+            'algorithmic_gflop_per_launch': gflop, 'flop_per_byte': frames * 28.6e3 / byt,
+            # the kernel's FLOP/byte (~21) sits at the fp32 vector ridge (157.3 T / 8 T): the other roof, stated
+            'other_roof_frac': gflop / kernel_ms / PEAK_F32_MFMA_TFLOPS,
+            'other_roof': f'fp32 vector / MFMA-f32 peak {PEAK_F32_MFMA_TFLOPS} TFLOP/s',
             'note': 'HIP events on the launch stream around the timed launches; algorithmic FLOPs = 25.6 k (1024-pt rFFT) + '
-                    '3 k (sparse mel) per frame (SURVEY.md 8d): ~21 FLOP/B, at the fp32 vector ridge - the kernel is '
-                    'bound by VALU issue, the HBM fraction is what BASELINE.json asks to be reported',
+                    '3 k (sparse mel) per frame (SURVEY.md 8d): ~21 FLOP/B, at the fp32 vector ridge',
         }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and cpu:
         n_cpu = 32
         clips = [wav[int(clip_off[i]):int(clip_off[i + 1])].cpu().numpy() for i in range(n_cpu)]
         bpc = [4.0 * int(lens[i]) + 320.0 * (1 + int(lens[i]) // 256) for i in range(n_cpu)]
-        result['cpu_baseline'] = mel_cpu_baseline(clips, bpc, usable_cpus())
+        result['cpu_baseline'] = mel_cpu_baseline(clips, bpc, usable_cpus(), cpu_single_s, cpu_pool_s)
+    del wav, out
+    return result
+
+
+def f32_train_leg(dev, cfg, shape, dropout, step_flops, steps=5, warmup=2):
+    """The same train step on the exact-fp32 path (precision='f32': v_mfma_f32_32x32x2_f32 everywhere - the path that
+    meets north_star's 1e-4 against the fp64 oracle, tests/test_config1_parity_gpu.py) - a short timed leg."""
+    from transformertts_amd.model.models import ForwardTransformer
+    from transformertts_amd.utils.synthetic import synthetic_batch
+    model = ForwardTransformer.from_config(dict(cfg, dropout_rate=dropout, predictors_dropout=dropout, device=str(dev),
+                                                seed=0, precision='f32', use_graph=False))
+    model._compile(learning_rate=1e-4)
+    batch = [torch.from_numpy(a).to(dev) for a in synthetic_batch(shape['B'], shape['Tp'], shape['Tm'], seed=1234)]
+    for _ in range(warmup):
+        out = model.train_step(*batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model.train_step(*batch)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    loss = float(out['loss'])
+    assert np.isfinite(loss)
+    del model, batch, out
+    torch.cuda.empty_cache()
+    tfs = step_flops / ms / 1e9 if step_flops else None
+    return {'metric': 'mel-frames/sec (train step)', 'dtype': 'f32', 'value': shape['B'] * shape['Tm'] / (ms * 1e-3),
+            'unit': 'mel-frames/s', 'ms_per_step': ms, 'steps': steps, 'warmup': warmup, 'loss_after': loss,
+            'step_tflops': tfs, 'step_mfma_frac': (tfs / PEAK_F32_MFMA_TFLOPS if tfs else None),
+            'roof': f'exact-fp32 MFMA peak {PEAK_F32_MFMA_TFLOPS} TFLOP/s',
+            'note': 'same workload, batch and dropout as the headline; the path inside the 1e-4 parity contract '
+                    '(loss < 1e-6, mel 1.2e-6 against the fp64 oracle at this batch)'}
+
+
+def also_legs(dev, cfg, shape, dropout, step_flops):
+    """Short extra legs of the default run, after its timed region, so that the driver's record carries them: the
+    exact-fp32 train step, the mel workload (BASELINE configs[3]) and predict (configs[4]).  Each leg is bounded (the
+    whole set ~40 s) and isolated: a failing leg reports its error and leaves the headline line intact."""
+    legs = {}
+
+    def run(name, fn):
+        t0 = time.perf_counter()
+        try:
+            legs[name] = fn()
+        except Exception as e:                                 # noqa: BLE001 - the headline must still be printed
+            legs[name] = {'error': f'{type(e).__name__}: {e}'}
+        legs[name]['leg_seconds'] = time.perf_counter() - t0
+        torch.cuda.empty_cache()
+
+    run('train_step_f32', lambda: f32_train_leg(dev, cfg, shape, dropout, step_flops))
+
+    def mel():
+        r = mel_run(dev, 0, 1, 10000, steps=3, warmup=1, roofline=True, cpu=True, cpu_single_s=1.5, cpu_pool_s=5.0)
+        keep = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'clips_per_s', 'frames_per_s')
+        out = {k: r[k] for k in keep}
+        out['workload'] = 'BASELINE.json configs[3]: 10 000 LJSpeech-length clips generated on the device, one batched launch per step'
+        rf = r['roofline']
+        out['roofline'] = {k: rf[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms',
+                                              'algorithmic_mb_per_launch', 'other_roof_frac', 'other_roof')}
+        cb = r['cpu_baseline']
+        out['cpu_baseline'] = {k: cb[k] for k in ('value', 'unit', 'cores', 'kind', 'clips_per_s', 'single_core', 'sample')}
+        return out
+    run('mel', mel)
+
+    def predict():
+        cfg_p, Tp, cases, n_par = predict_cases('bf16', 20, graphs=(True,), with_maps=False)
+        head = next(c for c in cases if c['batch'] == 1)
+        big = next(c for c in cases if c['batch'] == 64)
+        rf = predict_roofline(cfg_p, Tp, head, big, n_par)
+        return {'metric': 'predict p50 latency, 400 phonemes -> ~2 280 frames, hipGraph-captured', 'unit': 'ms',
+                'workload': 'BASELINE.json configs[4]', 'dtype': 'bf16',
+                'batch1': {k: head[k] for k in ('p50_ms', 'p90_ms', 'rtf_p50', 'frames', 'mel_frames_per_s')},
+                'batch64': {k: big[k] for k in ('p50_ms', 'p90_ms', 'rtf_p50', 'frames', 'mel_frames_per_s')},
+                'roofline': {'batch1_hbm_frac': rf['frac'], 'batch1_gbs': rf['achieved'],
+                             'batch64_mfma_frac': rf['batch64']['frac'], 'batch64_tflops': rf['batch64']['achieved']},
+                'cpu_baseline': predict_cpu_baseline(cfg_p, Tp, usable_cpus(), seconds=4.0)}
+    run('predict', predict)
+    return legs
+
+
+# reference config/training_config.yaml:22-23 (mel-length buckets and their batch sizes)
+LJ_BUCKET_BOUNDARIES = [200, 300, 400, 500, 600, 700, 800, 900, 1000, 1200]
+LJ_BUCKET_BATCH_SIZES = [64, 42, 32, 25, 21, 18, 16, 14, 12, 6, 1]
+
+
+def lj_dist_samples(n, seed, content_seed, mel_channels=80):
+    """SURVEY.md 8d 'LJ-dist' set: Tp_b ~ U{60..200}, Tm_b = sum(dur_b) with mean duration 4.5 frames per phoneme
+    (jittered +-25 %), capped at 900; sample 0 at both maxima.  Lengths come from `seed` (shared by all ranks: equal
+    shapes per step), contents from `content_seed`.  Returned in the trainer's component order (data/datasets.py:153-169:
+    mel, phonemes, durations, pitch, name); the name carries the frame count for the host-side tally."""
+    rl, rc = np.random.default_rng(seed), np.random.default_rng(content_seed)
+    out = []
+    for i in range(n):
+        tp = 200 if i == 0 else int(rl.integers(60, 201))
+        tm = 900 if i == 0 else int(min(900, max(tp, round(4.5 * tp * float(rl.uniform(0.75, 1.25))))))
+        dur = rc.multinomial(tm, np.full(tp, 1.0 / tp)).astype(np.int32)
+        pit = rc.standard_normal(tp).astype(np.float32)
+        pit[rc.random(tp) < 0.3] = 0.0
+        mel = np.clip(rc.normal(-5.0, 2.0, size=(tm, mel_channels)), -11.5129, 2.0).astype(np.float32)
+        tok = rc.integers(1, 127, size=tp).astype(np.int32)
+        out.append((mel, tok, dur, pit, str(tm)))
+    return out
+
+
+def lj_dist_bench(args):
+    """`--workload lj-dist`: the ragged set of SURVEY.md 8d fed through the bucketed batch producer
+    (transformertts_amd/data/datasets.py = reference data/datasets.py:238-284 with the bucket table of
+    config/training_config.yaml:22-23): every step is a NEW (B, Tp_max, Tm_max) - plans re-bind, keep-bit tables are
+    re-sized, the producer thread pads / pins / copies ahead.  value = REAL (unpadded) mel frames per second; beside it
+    the padded rate, the host's stall in next_batch(), allocator growth, and the max-shape step of the same process for
+    the ms-per-padded-frame comparison."""
+    from transformertts_amd import dp
+    from transformertts_amd.data.datasets import Dataset
+    from transformertts_amd.model.models import ForwardTransformer
+    from transformertts_amd.utils.synthetic import synthetic_batch
+    rank, local, world = dp.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    cfg, shape = workload_config('configs[1]')
+    cfg = dict(cfg, dropout_rate=args.dropout, predictors_dropout=args.dropout, device=str(dev), seed=0,
+               precision=args.precision, use_graph=False)
+    model = ForwardTransformer.from_config(cfg)
+    model._compile(learning_rate=1e-4)
+    wrapped = dp.DataParallel(model)
+    samples = lj_dist_samples(args.lj_samples, 1234, 4321 + rank)
+    ds = Dataset(samples=list(range(len(samples))), preprocessor=lambda i: samples[i],
+                 len_function=lambda mel, *_: int(mel.shape[0]), bucket_boundaries=LJ_BUCKET_BOUNDARIES,
+                 bucket_batch_sizes=LJ_BUCKET_BATCH_SIZES, shuffle=True, drop_remainder=True, seed=42, device=dev, prefetch=4)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    shapes, real, padded, stall = set(), 0, 0, 0.0
+
+    def one(count):
+        nonlocal real, padded, stall
+        t0 = time.perf_counter()
+        mel, tok, dur, pit, names = ds.next_batch()
+        t1 = time.perf_counter()
+        B, Tm, Tp = int(mel.shape[0]), int(mel.shape[1]), int(tok.shape[1])
+        out = wrapped.train_step(tok, mel, dur, pit, global_shape=(B * world, Tp, Tm), reduce_losses=False)
+        if count:
+            stall += t1 - t0
+            shapes.add((B, Tp, Tm))
+            real += sum(int(n) for n in names)
+            padded += B * Tm
+        return out
+
+    for _ in range(args.warmup):
+        one(False)
+    sync()
+    reserved0 = torch.cuda.memory_reserved(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one(True)
+    host = time.perf_counter() - t0
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    reserved1 = torch.cuda.memory_reserved(dev)
+    loss = float(out['loss']) * world
+    assert np.isfinite(loss), 'non-finite loss'
+    ds.close()
+    # the max-shape step of the SAME process (plans already at capacity): ms per padded frame to compare with
+    batch = [torch.from_numpy(a).to(dev) for a in synthetic_batch(shape['B'], shape['Tp'], shape['Tm'], seed=1234 + rank)]
+    gshape = (shape['B'] * world, shape['Tp'], shape['Tm'])
+    for _ in range(3):
+        wrapped.train_step(*batch, global_shape=gshape, reduce_losses=False)
+    sync()
+    t1 = time.perf_counter()
+    n_max = 20
+    for _ in range(n_max):
+        wrapped.train_step(*batch, global_shape=gshape, reduce_losses=False)
+    sync()
+    ms_max = 1e3 * (time.perf_counter() - t1) / n_max
+    us_per_padded = 1e6 * elapsed / padded
+    us_per_padded_max = 1e3 * ms_max / (shape['B'] * shape['Tm'])
+    result = {
+        'metric': 'mel-frames/sec (train step), real unpadded frames, bucketed ragged batches', 'value': real * world / elapsed,
+        'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': f'SURVEY.md 8d LJ-dist set: {len(samples)} samples per GPU, Tp ~ U{{60..200}}, mean duration 4.5 '
+                               f'frames, mel length <= 900, through the bucketed batch producer (boundaries '
+                               f'{LJ_BUCKET_BOUNDARIES}, batch sizes {LJ_BUCKET_BATCH_SIZES}: reference '
+                               f'config/training_config.yaml:22-23), ForwardTransformer configs[1] architecture, dropout '
+                               f'{args.dropout}', 'parallelism': f'dp{world}', 'loss_after': loss},
+        'distinct_batch_shapes': len(shapes), 'real_frames': real * world, 'padded_frames': padded * world,
+        'padding_fraction': 1.0 - real / padded,
+        'padded_mel_frames_per_s': padded * world / elapsed,
+        'host_stall_ms_per_step': 1e3 * stall / args.steps,
+        'host_issue_ms_per_step': 1e3 * host / args.steps,
+        'allocator_growth_mb': (reserved1 - reserved0) / 1e6, 'allocator_reserved_mb': reserved1 / 1e6,
+        'us_per_padded_frame': us_per_padded,
+        'max_shape': {'ms_per_step': ms_max, 'us_per_padded_frame': us_per_padded_max, 'steps': n_max},
+        'ragged_over_max_shape_per_padded_frame': us_per_padded / us_per_padded_max,
+    }
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -605,6 +850,8 @@ def main():
                     help='skip the extra timed leg that also materialises the 12 attention maps')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--clips', type=int, default=10000, help='--workload mel: clips per GPU (BASELINE configs[3]: 10 000)')
+    ap.add_argument('--no-also', action='store_true', help='skip the extra legs of the default run (f32 step, mel, predict)')
+    ap.add_argument('--lj-samples', type=int, default=4096, help='--workload lj-dist: synthetic samples per GPU')
     args = ap.parse_args()
 
     if args.workload == 'predict':
@@ -624,6 +871,10 @@ def main():
 
     if args.workload == 'mel':
         return mel_bench(args)
+    if args.workload == 'lj-dist':
+        if args.steps == 40 and args.warmup == 5:            # this workload's defaults: >= 200 steps over many shapes
+            args.steps, args.warmup = 200, 20
+        return lj_dist_bench(args)
 
     from transformertts_amd import dp
     rank, local, world = dp.init_process_group()
@@ -747,7 +998,7 @@ def main():
             'traffic': traffic,
             'traffic_note': ('HBM bytes per launch from the committed PMC passes (profiles/' + PMC_FILE +
                              ', FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 correction applied)')
-                            if traffic else None,
+                            if traffic else 'null: no PMC file collected on this build of the library (digest mismatch or file absent)',
             'avg_launch_ms': gms / n, 'algorithmic_mb_per_launch': by / n / 1e6,
             'algorithmic_gflop_per_launch': fl / n / 1e9, 'flop_per_byte': fl / by, 'ridge_flop_per_byte': ridge,
             'other_roof_frac': tfs / peak_fl if hbm_bound else gbs / PEAK_HBM_GBS,
@@ -786,6 +1037,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline({k: v for k, v in cfg.items() if k not in ('device', 'seed', 'precision', 'use_graph')},
                                               shape, usable_cpus())
+    # the other measurements the contract names, as short legs AFTER the timed region (driver-visible: same JSON line)
+    if (rank == 0 and world == 1 and not args.no_also and not args.no_roofline and args.workload == 'configs[1]'
+            and args.precision == 'bf16' and not args.batch):
+        step_flops = result.get('roofline', {}).get('step_gflop', 0.0) * 1e9
+        del model, wrapped, batch, out
+        torch.cuda.empty_cache()
+        base_cfg, _ = workload_config(args.workload)
+        result['also'] = also_legs(dev, base_cfg, shape, args.dropout, step_flops)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

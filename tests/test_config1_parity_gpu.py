@@ -44,6 +44,12 @@ BOUNDS = {
     # other matrix stays below 3 %.
     'bf16': dict(fwd=3e-2, loss=4e-3, grad=6e-2, grad_embedding=1.3e-1, grad_vec=1e-1, gnorm=1e-1, tap=1.5e-2),
 }
+# The bf16 path AT THE BENCHMARKED BATCH (B = 32) is held to at most twice what it measures there (round-3 final build,
+# gpurun_out/config1_parity.jsonl, maxshape / ragged): outputs 1.0 / 1.0 % (mel), 2.1 / 1.6 % (duration), 1.5 / 1.6 %
+# (pitch); total loss 5.6e-4, pitch-loss term 2.2e-3; block outputs <= 0.67 / 0.70 %; worst weight matrix 0.93 / 1.2 %
+# (enc.blk0.wq), embedding 2.2 / 2.9 %, worst vector 2.5 / 2.9 % (enc.ln.gamma), worst L2 norm 1.4 / 0.5 %.  Gradients
+# at B = 32 average 8 x more rows than the B = 4 cases above, whose wider bounds (3.8 % / 6.9 % / 7.2 % measured) stay.
+BOUNDS_BF16_B32 = dict(fwd=3e-2, loss=4e-3, grad=2.4e-2, grad_embedding=5.8e-2, grad_vec=5.7e-2, gnorm=2.9e-2, tap=1.4e-2)
 
 
 @pytest.fixture(scope='module')
@@ -213,9 +219,9 @@ def test_bf16_path_at_the_benchmarked_batch_of_32(gold32, setup, tag):
     from transformertts_amd import _lib
     cfg, W = setup
     m, out = _run32(cfg, W, tag, 'bf16')
-    report = _compare32(gold32, tag, m, out, BOUNDS['bf16'])
+    report = _compare32(gold32, tag, m, out, BOUNDS_BF16_B32)
     _dump(tag + '_b32', 'bf16', report)
-    _check(report, BOUNDS['bf16'])
+    _check(report, BOUNDS_BF16_B32)
     dec = [report['taps'][f'dec.blk{i}'] for i in range(6)]
     assert dec[-1] < 20 * max(dec[0], 1e-3), dec
     # the routers are deterministic in the shapes: the decoder-size entry points select the benchmark's variants

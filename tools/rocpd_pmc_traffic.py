@@ -12,9 +12,12 @@ per launch per kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM 
 
 Usage: python tools/rocpd_pmc_traffic.py <fetch.db> <write.db> <out.json>"""
 import json
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(name: str) -> str:
@@ -54,7 +57,9 @@ def with_totals(out):
     step_k = {k: v for k, v in out.items() if not k.startswith('__amd_rocclr')}
     total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in step_k.values())
     launches = sum(v['launches'] for v in step_k.values())
-    return {'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950, 16 B/lane loads; '
+    from transformertts_amd.build import library_digest
+    return {'lib_digest': library_digest(),       # the build these bytes were measured on (bench.py: null on mismatch)
+            'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950, 16 B/lane loads; '
                           'calibrated on adam_tf_kernel and cast_bf16_kernel in this trace)',
             'steps_in_trace': steps, 'hbm_bytes_per_step': total / steps, 'launches_per_step': launches / steps,
             'runtime_copy_launches_in_trace': sum(v['launches'] for k, v in out.items() if k.startswith('__amd_rocclr')),
