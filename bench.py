@@ -157,7 +157,7 @@ KERNEL_OF = {
 RIDERS = 'hbm-bound riders (LN, lenreg, loss, Adam, ...)'
 SIDE = ' [side stream]'
 HATTN_FWD = 'hattn_fwd_kernel (bf16 MFMA flash attention forward)'
-HATTN_BWD = 'hattn_bwd_dq_kernel + hattn_bwd_dkv_kernel (bf16 MFMA flash attention backward)'
+HATTN_BWD = 'hattn_bwd_fused_kernel | hattn_bwd_dq_kernel + hattn_bwd_dkv_kernel (bf16 MFMA flash attention backward)'
 ROWGEMM = 'rowgemm_dma_kernel / rowgemm_kernel (full-row GEMM + fused LayerNorm forward / backward, bf16 MFMA)'
 # launch groups announced by the C++ block launcher (ttsmi_set_launch_observer) -> kernel family
 OBSERVED = {'ttsmi_hgemm_tn': KERNEL_OF['ttsmi_hgemm_tn'], 'ttsmi_hgemm_ln_fwd': ROWGEMM, 'ttsmi_hgemm_ln_bwd': ROWGEMM,
@@ -179,7 +179,7 @@ PMC_KERNELS = {       # kernel family -> (rocprof names of its kernels, names of
     ROWGEMM: (['rowgemm_dma_kernel', 'rowgemm_kernel'], []),
     KERNEL_OF['ttsmi_hgemm_wgrad_rows']: (['wgrad_rows_kernel', 'wgrad_dma_kernel'], ['hsplit_reduce']),
     HATTN_FWD: (['hattn_fwd_kernel'], []),
-    HATTN_BWD: (['hattn_bwd_dq_kernel'], ['hattn_bwd_dkv_kernel']),
+    HATTN_BWD: (['hattn_bwd_dq_kernel', 'hattn_bwd_fused_kernel'], ['hattn_bwd_dkv_kernel']),
 }
 
 

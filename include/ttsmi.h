@@ -139,6 +139,28 @@ int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const in
                                const void* ctx, const void* dctx, const float* lse, void* dqkv, int B,
                                int H, int T, int dh, float p_drop, const void* dropmask, void* ws, size_t ws_bytes,
                                int dtype, ttsmi_stream_t stream);
+/* ONE-PASS backward for TTSMI_BF16_IO tensors at head dim 64 (model/layers.py:176-195 differentiated once): dK, dV and dQ
+ * from a single recomputation of S = q.k^T and dP = d(ctx).v^T - 10 T^2 dh of products and one softmax pass where
+ * ttsmi_attention_bwd runs two kernels, 14 T^2 dh and two softmax passes.  Key-stationary workgroups; dQ is summed over
+ * the key tiles of a head in a FIXED order through fp32 tiles in `ws` (hand-off flags in L2, no float atomics: results are
+ * bit-reproducible).  Same results as ttsmi_attention_bwd / _bwd_masked up to fp32 summation order (dQ is rounded to bf16
+ * once, after the whole sum).  dropmask: the keep-bit table of ttsmi_attention_dropmask, or NULL (then seed / step_dev /
+ * site drive the hashed dropout as in ttsmi_attention_bwd; p_drop == 0: no dropout).
+ *   ws: 256-byte aligned, at least ttsmi_attention_bwd_fused_ws_bytes(rows, H) bytes for every batch of B*T <= rows rows
+ *       (T >= 32), initialised ONCE after allocation with ttsmi_attention_bwd_fused_ws_init (zeroes the flags: they reset
+ *       themselves at the end of every launch); the first 8 bytes are two int32 diagnostic counters that stay 0 in a
+ *       healthy run ([0] hand-offs that timed out - the kernel then finishes with a wrong dQ instead of hanging -,
+ *       [1] hand-offs between workgroups on different XCC ids);
+ *   _supported: non-zero when (B, H, T, dh) can run on a workspace of ws_bytes (dh == 64, flags + tiles fit); the
+ *       entry point returns TTSMI_ERR_UNSUPPORTED otherwise and the caller uses ttsmi_attention_bwd.
+ * TTSMI_ATTN_FUSED_BWD=0 (A/B knob) makes _supported return 0. */
+size_t ttsmi_attention_bwd_fused_ws_bytes(int rows, int H);
+int ttsmi_attention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes);
+int ttsmi_attention_bwd_fused_ws_init(void* ws, size_t ws_bytes, ttsmi_stream_t stream);
+int ttsmi_attention_bwd_fused(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
+                              const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
+                              float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, const void* dropmask,
+                              void* ws, size_t ws_bytes, ttsmi_stream_t stream);
 /* Inference forward (no dropout, TTSMI_BF16_IO tensors) for launches too small to fill the GPU - batch 1, a few heads:
  * the keys are split over extra workgroups, each split writes a normalised partial context + log-sum-exp into `ws`, and a
  * combine pass forms the result (model/layers.py:176-195 with training=False).  _ws_bytes returns 0 when B*H*T already
@@ -529,6 +551,12 @@ typedef struct ttsmi_dense_block {
      * K = 256 weight-stationary kernel (fuse_ln, d == 256, ttsmi_hgemm_k256_eligible), the forward also leaves
      * (h1 > 0) as one bit per element here and the backward masks the FFN2 dgrad with it instead of re-reading h1. */
     void* relu_bits;
+    /* optional (NULL = not used): a workspace of the one-pass attention backward, sized by
+     * ttsmi_attention_bwd_fused_ws_bytes and initialised by ttsmi_attention_bwd_fused_ws_init - the backward then runs
+     * ttsmi_attention_bwd_fused whenever ttsmi_attention_bwd_fused_supported says so (attn_ws stays the scratch of the
+     * two-kernel form). */
+    void* attn_fused_ws;
+    uint64_t attn_fused_ws_bytes;
 } ttsmi_dense_block;
 /* ---------------------------------------------------------------------------------------------
  * Batch data parallelism for a binding WITHOUT a collective library of its own (one all-reduce of the

@@ -6,7 +6,9 @@ rounding of the bf16 path changes where training goes.  Here both precisions sta
 300 Adam steps on one fixed ragged batch of the benchmarked architecture (BASELINE.json configs[1]: d_model 256, 6+6
 dense blocks, 4 heads, FFN 1024), dropout 0 so that the two runs see the same function: the bf16 loss must stay within
 2 % of the fp32 loss at every 50th step and at the end, and both must have learned the batch (final loss below 0.6 x the
-initial one - with random-init weights the three L1 terms start near 11 and overfit to ~1)."""
+initial one).  The batch is `learnable_batch`: durations, pitch and mel frames are functions of the token ids - the
+noise targets of the throughput benchmark cannot be fitted (a first version of this test on them plateaued at 0.62 x
+the initial loss in both precisions, at the noise's mean absolute deviation)."""
 import json
 import os
 
@@ -19,7 +21,8 @@ from oracle import ft_oracle as fo
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-STEPS, EVERY, LR = 300, 50, 1e-3
+STEPS, EVERY = 300, 50
+LR = float(os.environ.get('TTSMI_CURVE_LR', '1e-3'))          # (measurement knob: the curve at another learning rate)
 
 
 def _curve(precision, cfg, W, batch):
@@ -42,7 +45,8 @@ def _curve(precision, cfg, W, batch):
 def test_bf16_training_curve_tracks_fp32_over_300_steps():
     cfg = dict(fo.make_config(), dropout_rate=0.0, predictors_dropout=0.0)
     W = fo.init_weights(cfg, seed=5)
-    batch = fo.synthetic_batch(8, 200, 900, seed=77, ragged=True)
+    from transformertts_amd.utils.synthetic import learnable_batch
+    batch = learnable_batch(8, 200, 900, seed=77)
     f32 = _curve('f32', cfg, W, batch)
     bf16 = _curve('bf16', cfg, W, batch)
     rel = [abs(a - b) / b for a, b in zip(bf16, f32)]

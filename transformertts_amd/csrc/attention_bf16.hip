@@ -43,6 +43,10 @@ struct HAttnP {
     // forward only, split_keys != 0: blockIdx.y = key split s owns keys [s*split_keys, (s+1)*split_keys) and writes its
     // own softmax-normalised partial context / log-sum-exp at ctx + s*ctx_split (elements) / lse + s*lse_split
     int split_keys; long ctx_split, lse_split;
+    // one-pass backward only (hattn_bwd_fused_kernel): the fp32 dQ tiles in flight between the key tiles of a head (one
+    // 16 KB register image per (b, h, 64-query tile)), their hand-off flags, and two diagnostic counters
+    float* dq_acc; int* sem; int* diag;
+    int acc_sc1;                    // 1: the dQ tiles are stored with agent-scope (sc1) stores instead of plain ones (A/B knob)
 };
 
 // DROP template values: 0 = no dropout, 1 = keep decisions hashed in the inner loop (ttsmi_pair_hash), 2 = keep
@@ -874,6 +878,298 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
 }
 
 // =================================================================================================
+// backward, ONE pass: dK, dV AND dQ from a single recomputation of S / dP   (model/layers.py:176-195 differentiated once)
+// =================================================================================================
+// The two-kernel backward above recomputes S = Q.K^T, dP = dO.V^T and the softmax twice (14 T^2 dh of products for 8
+// algorithmic, two passes of ~8 vector instructions per score).  Here a key-stationary workgroup (128 keys, as in the dK/dV
+// kernel) also produces dQ: every wave writes its 32 x 32 dS tile (bf16) into an LDS image dS[128 keys][64 queries], and
+// after the two query sub-tiles of a staged tile the four waves multiply dQ^T[c][q] = sum_key K^T[c][key] dS^T[key][q] over
+// all 128 keys of the workgroup - one 32 x 32 block per wave, both operands through the transposing LDS read - 10 T^2 dh
+// of products and ONE softmax recomputation.
+//
+// dQ is reduced over the key tiles of a head ACROSS workgroups, in a fixed order (reproducible bits, no float atomics):
+// the partial tile travels j = 0 -> 1 -> ... through an fp32 scratch image in HBM/L2; workgroup j waits for flag == j, adds
+// the image to its own product, stores it and posts j + 1; the last active key tile converts to bf16 and writes dqkv.
+// What makes this cheap: all key tiles of a (b, h) are dispatched to ONE XCD (block id = 8 * slot + xcd; group =
+// xcd + 8 * (slot / nkt), key tile = slot % nkt), so the hand-off lives in that XCD's L2 - plain write-through stores, an
+// `s_waitcnt vmcnt(0)` + barrier before the flag, agent-scope (L1-bypassing) loads on the reading side; no L2 write-back
+// / invalidate (what an agent-scope release / acquire fence costs on a multi-XCD part).  A workgroup only ever waits for
+// a LOWER block id of its own XCD, which the in-order dispatcher started earlier (tools/probes/xcd_sem_probe.hip measures
+// placement, start order, and the protocol itself).  Spins are bounded: a wait that never ends raises diag[0] and the
+// kernel finishes (with wrong dQ) instead of hanging; diag[1] counts hand-offs between different XCC ids.  Flags reset
+// themselves (the last workgroup of a chain posts 0), so the flag region only has to be zero once, at allocation
+// (ttsmi_attention_bwd_fused_ws_init).
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* img, int k0, int t, int colblock, int lane) {
+    // MFMA 32x32x16 operand (A or B alike) whose 8 reduction elements are rows k0 + 16 t + 4 hh + {0..3, 8..11} of the
+    // row-major image img[row][72] at column colblock * 32 + (lane & 31): the addressing of accumTR
+    typedef __attribute__((address_space(3))) as16x4* lds_ptr;
+    constexpr int LD = 72;
+    const uint16_t* a = img + (k0 + 16 * t + 4 * (lane >> 5) + ((lane & 15) >> 2)) * LD + ((lane >> 4) & 1) * 16 + 4 * (lane & 3) +
+                        colblock * 32;
+    as16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
+    as16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 8 * LD));
+    as16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ float row16_sum(float v) {          // sum over the 16 lanes of a DPP row, in every lane of it
+    v += ttsmi_dpp<TTSMI_DPP_QUAD_1032, 0xF>(v, 0.f);
+    v += ttsmi_dpp<TTSMI_DPP_QUAD_2301, 0xF>(v, 0.f);
+    v += ttsmi_dpp<TTSMI_DPP_ROW_HALF_MIRROR, 0xF>(v, 0.f);
+    v += ttsmi_dpp<TTSMI_DPP_ROW_MIRROR, 0xF>(v, 0.f);
+    return v;
+}
+#define HFUSED_SPIN_LIMIT (1 << 18)
+
+template <int DH, int DROP>
+__global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
+    static_assert(DH == 64, "the one-pass backward is built for head dim 64 (one 32 x 32 dQ block per wave)");
+    constexpr bool QH = true;                        // bf16 tensors only
+    constexpr int LD = DH + 8;                       // row stride of every LDS image (bf16 elements); HKT + 8 as well
+    constexpr int IMG = HKT * LD;
+    __shared__ __attribute__((aligned(16))) uint16_t smem_h[2 * IMG + 2 * 128 * LD];
+    __shared__ float statS[3 * HKT];
+    uint16_t* Qs = smem_h;                           // [64 queries][72]
+    uint16_t* Os = Qs + IMG;                         // dO tile
+    uint16_t* Ks = Os + IMG;                         // [128 keys][72]: this workgroup's K rows, stationary (dQ's A operand)
+    uint16_t* dSs = Ks + 128 * LD;                   // [128 keys][64 queries + 8]
+    float* lseS = statS;
+    float* delS = lseS + HKT;
+    uint32_t* rbS = reinterpret_cast<uint32_t*>(delS + HKT);
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nkt = (p.T + 127) >> 7, nqt = (p.T + HKT - 1) / HKT;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = xcd + 8 * (slot / nkt), bx = slot % nkt;       // grp = b * H + h; bx = key tile = position in the chain
+    if (grp >= p.B * p.H) return;
+    const int h = grp % p.H, b = grp / p.H;
+    const int d = p.H * DH;
+    const int key = bx * 128 + wave * 32 + l31;
+    const int klen = p.klen[b];
+    const int nact = max(1, (klen + 127) >> 7);      // key tiles that take part in the chain (tile 0 always does)
+    const bool kok = key < p.T;
+    const bool kact = key < klen;
+    const bool wave_live = (bx * 128 + wave * 32) < klen;
+    const bool wg_active = bx < nact;
+    const bool chain_last = bx == nact - 1;
+    const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
+    const float* Kb = eptr<QH>(Qb, d);
+    const float* Vb = eptr<QH>(Qb, 2 * d);
+    const float* dOb = eptr<QH>(p.dctx, (long)b * p.T * d + h * DH);
+    const float* Ob = eptr<QH>(p.octx, (long)b * p.T * d + h * DH);
+
+    f32x16 dk[DH / 32], dv[DH / 32];
+#pragma unroll
+    for (int cb = 0; cb < DH / 32; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[cb][r] = 0.f; dv[cb][r] = 0.f; }
+
+    if (wg_active) {
+        bf16x8 kf[DH / 16], vf[DH / 16];
+        frags_of<DH, QH>(Kb, p.ld, key, kok, hh, kf);
+        frags_of<DH, QH>(Vb, p.ld, key, kok, hh, vf);
+        const float padterm = !kact ? -INFINITY : ((p.key_pad[(long)b * p.T + key]) ? -1e9f * LOG2E : 0.f);
+        const float inv_sqrt = 1.0f / p.sqrt_dk;
+        const float c1 = LOG2E * inv_sqrt;
+        const long stat0 = (long)grp * p.T;
+        uint64_t dkey = 0;
+        if (DROP == 1) dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
+        const int ntile32 = (p.T + 31) >> 5;
+        const uint32_t* mlane = nullptr;
+        uint32_t mnext[HKT / 32] = {0u, 0u};
+        if (DROP == 2) {
+            const int rp = (l31 & 3) + 4 * (l31 >> 3), hp = (l31 >> 2) & 1;
+            mlane = reinterpret_cast<const uint32_t*>(p.dmask) +
+                    (((long)grp * ntile32 * ntile32 + (bx * 4 + wave)) * 16 + rp) * 2 + hp;
+        }
+        auto mask_fetch = [&](int q0) {
+            if (DROP == 2 && kok) {
+#pragma unroll
+                for (int u = 0; u < HKT / 32; ++u) {
+                    const int qt = (q0 >> 5) + u;
+                    mnext[u] = qt < ntile32 ? mlane[(long)qt * ntile32 * 32] : 0u;
+                }
+            }
+        };
+        // ---- the stationary K image (dQ's A operand) and a zeroed dS image (dead waves never write theirs)
+        {
+            Tile<DH, QH> t0, t1;
+            t0.fetch(Kb, p.ld, bx * 128, max(0, min(HKT, p.T - bx * 128)), tid);
+            t1.fetch(Kb, p.ld, bx * 128 + HKT, max(0, min(HKT, p.T - bx * 128 - HKT)), tid);
+            t0.stash(Ks, tid);
+            t1.stash(Ks + IMG, tid);
+            for (int i = tid; i < 128 * LD / 8; i += 256) reinterpret_cast<uint4*>(dSs)[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        int* const sem = p.sem + (long)grp * nqt;
+        float* const acc0 = p.dq_acc + (long)grp * nqt * 4096 + (wave * 16 * 64 + lane);      // + r * 64 + tile * 4096
+        unsigned xid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
+        xid &= 15;
+        const int cbq = wave & 1, qbq = wave >> 1;       // this wave's 32 x 32 block of the dQ^T tile: columns / queries
+        bool dead = false;                               // (thread 0) a hand-off timed out: stop waiting, finish the kernel
+        int post = -1;                                   // (thread 0) flag value to post for the previous tile, after its stores
+
+        Tile<DH, QH> rq, ro, rc;
+        float rl = 0.f;
+        int rnv = 0;
+        {
+            int nv = min(HKT, p.T);
+            rq.fetch(Qb, p.ld, 0, nv, tid);
+            ro.fetch(dOb, d, 0, nv, tid);
+            rc.fetch(Ob, d, 0, nv, tid);
+            mask_fetch(0);
+            rnv = nv;
+            if (tid < HKT) rl = p.lse[stat0 + min(tid, p.T - 1)];
+        }
+        for (int q0 = 0, it = 0; q0 < p.T; q0 += HKT, ++it) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the previous tile's dQ stores have reached L2
+            __syncthreads();
+            if (tid == 0 && post >= 0) {
+                __hip_atomic_store(sem + it - 1, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                post = -1;
+            }
+            rq.stash(Qs, tid);
+            ro.stash(Os, tid);
+            {
+                // delta = rowsum(dO * O) of the staged rows: a thread holds 4 columns of rows tid / 16 + 16 i, the 16 lanes
+                // of a DPP row share a row.  dS = P (keep dP / (1 - p) - delta) / sqrt(dh): the scale is folded in.
+#pragma unroll
+                for (int i = 0; i < DH / 16; ++i) {
+                    const bf16x4 x = __builtin_bit_cast(bf16x4, ro.h[i]), y = __builtin_bit_cast(bf16x4, rc.h[i]);
+                    float sdl = (float)x[0] * (float)y[0] + (float)x[1] * (float)y[1] + (float)x[2] * (float)y[2] + (float)x[3] * (float)y[3];
+                    sdl = row16_sum(sdl);
+                    if ((tid & 15) == 0) delS[(tid >> 4) + 16 * i] = sdl * inv_sqrt;
+                }
+            }
+            if (tid < HKT) {
+                lseS[tid] = tid < rnv ? rl * LOG2E : INFINITY;
+                if (DROP == 1) rbS[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0 + tid));
+            }
+            uint32_t mcur[HKT / 32];
+#pragma unroll
+            for (int u = 0; u < HKT / 32; ++u) mcur[u] = mnext[u] >> (4 * hh);
+            __syncthreads();
+            if (q0 + HKT < p.T) {
+                int nv = min(HKT, p.T - (q0 + HKT));
+                rq.fetch(Qb, p.ld, q0 + HKT, nv, tid);
+                ro.fetch(dOb, d, q0 + HKT, nv, tid);
+                rc.fetch(Ob, d, q0 + HKT, nv, tid);
+                mask_fetch(q0 + HKT);
+                rnv = nv;
+                if (tid < HKT) rl = p.lse[stat0 + min(q0 + HKT + tid, p.T - 1)];
+            }
+#pragma unroll
+            for (int qt = 0; qt < HKT / 32; ++qt) {
+                if (!wave_live) break;                         // (its dS rows stay zero)
+                f32x16 s = dot16<DH>(Qs, qt * 32 + l31, hh, kf);             // S[q][key]
+                f32x16 dp = dot16<DH>(Os, qt * 32 + l31, hh, vf);            // dP = dO.V^T
+                f32x16 pt;
+                const float ik2 = (DROP ? p.inv_keep : 1.0f) * inv_sqrt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = qt * 32 + rowmap16(r, hh);
+                    float pr = EXP2(s[r] * c1 + padterm - lseS[ql]);        // lse = +inf for q >= T
+                    float dpr = dp[r];
+                    if (DROP == 1) {
+                        const uint32_t hsh = ttsmi_pair_hash(rbS[ql], (uint32_t)key);
+                        const bool keep = ttsmi_keep_of(hsh, (uint32_t)key, p.thr, 1.0f) != 0.f;
+                        dpr = keep ? dpr : 0.f;
+                        pt[r] = keep ? pr : 0.f;
+                    } else if (DROP == 2) {
+                        const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe(mcur[qt], (r & 3) + 8 * (r >> 2), 1);   // 0 / ~0
+                        dpr = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, dpr) & km);
+                        pt[r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, pr) & km);
+                    } else {
+                        pt[r] = pr;
+                    }
+                    s[r] = pr * fmaf(dpr, ik2, -delS[ql]);                                     // dS
+                }
+                bf16x8 pb[2], sb[2];
+                to_frags(pt, pb);
+                to_frags(s, sb);
+                accumTR<DH, DH / 32>(Os, qt * 32, lane, pb, dv, 0);           // dV^T += dO^T.P
+                accumTR<DH, DH / 32>(Qs, qt * 32, lane, sb, dk, 0);           // dK^T += Q^T.dS
+                // dS[key = this lane][q = qt * 32 + 8 g + 4 hh + 0..3] = registers 4 g .. 4 g + 3 = sb[g >> 1][4 (g & 1) ..]
+                uint16_t* row = dSs + (wave * 32 + l31) * LD + qt * 32 + 4 * hh;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const as16x8 v = __builtin_bit_cast(as16x8, sb[g4 >> 1]);
+                    as16x4 w;
+                    w[0] = v[4 * (g4 & 1)]; w[1] = v[4 * (g4 & 1) + 1]; w[2] = v[4 * (g4 & 1) + 2]; w[3] = v[4 * (g4 & 1) + 3];
+                    *reinterpret_cast<as16x4*>(row + 8 * g4) = w;
+                }
+            }
+            // ---- the chain: wait until key tile bx - 1 has stored its sum for this query tile
+            if (bx > 0 && tid == 0 && !dead) {
+                int spins = 0, f;
+                while (((f = __hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFF) != bx) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > HFUSED_SPIN_LIMIT ||
+                        ((spins & 1023) == 0 && __hip_atomic_load(p.diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        atomicAdd(p.diag, 1);
+                        dead = true;
+                        break;
+                    }
+                }
+                if (!dead && (unsigned)(f >> 8) != xid) atomicAdd(p.diag + 1, 1);
+            }
+            __syncthreads();                                   // the dS image is complete, the incoming sum is in L2
+            float* const acc = acc0 + (long)it * 4096;
+            float in[16];
+            if (bx > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) in[r] = __hip_atomic_load(acc + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            f32x16 dqt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqt[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    dqt = MFMA16(tr_frag(Ks, kk * 32, t, cbq, lane), tr_frag(dSs, kk * 32, t, qbq, lane), dqt);   // dQ^T += K^T.dS^T
+            if (bx > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dqt[r] += in[r];
+            }
+            if (chain_last) {
+                const int q = q0 + qbq * 32 + l31;
+                if (q < p.T) {
+                    uint16_t* dst = reinterpret_cast<uint16_t*>(p.dqkv) + ((long)b * p.T + q) * p.ld + h * DH + cbq * 32 + 4 * hh;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        bf16x4 o4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = (__bf16)dqt[4 * g4 + e];
+                        *reinterpret_cast<uint2*>(dst + 8 * g4) = __builtin_bit_cast(uint2, o4);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // plain stores are written through the CU's L1 into the XCD's L2, where the next key tile's L1-bypassing
+                    // loads find them; the sc1 form (agent scope) is the A/B alternative (TTSMI_ATTN_FUSED_SC1=1)
+                    if (p.acc_sc1) __hip_atomic_store(acc + r * 64, dqt[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else acc[r * 64] = dqt[r];
+                }
+            }
+            if (tid == 0) post = chain_last ? 0 : ((bx + 1) | ((int)xid << 8));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && post >= 0) __hip_atomic_store(sem + nqt - 1, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // dK / dV of this workgroup's 128 keys (zeros for a key tile past the last unpadded key)
+    float* patch = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(smem_h) + wave * (32 * (DH + 8) * 2));
+    const int row0 = bx * 128 + wave * 32;
+    const int nvalid = min(32, p.T - row0);
+    const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH);
+    storeT16<DH, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
+    storeT16<DH, QH>(patch, dv, DROP ? p.inv_keep : 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
+}
+
+// =================================================================================================
 // keep-bit generator for DROP == 2 (layout: see the top of the file).  One wave per 32-query tile walks the key
 // blocks; the decisions are the SAME hash the DROP == 1 kernels, the exact-fp32 kernels and attention_weights
 // evaluate, so every consumer sees one mask.
@@ -1226,5 +1522,68 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     ttsmi_arm_stop_event(armed);
     HDISPATCH_LDS(dh, hattn_bwd_dkv_kernel, grid_kv, dkv_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_bwd_dkv(bf16)");
+    return TTSMI_OK;
+}
+
+// ---- one-pass backward (hattn_bwd_fused_kernel) ------------------------------------------------------------------------
+// Workspace layout (bytes): [0, 16) four int32 diagnostic counters (0: hand-offs that timed out, 1: hand-offs between
+// different XCC ids; both stay 0 in a healthy run), [16, 16 + S) the hand-off flags (S from the workspace size alone, so
+// the region does not move with the batch shape and stays all-zero between launches), then the fp32 dQ tiles.
+static size_t hfused_flag_bytes(size_t ws_bytes) { return ((ws_bytes / 4096 + 255) / 256) * 256; }
+size_t ttsmi_hattention_bwd_fused_ws_bytes(int rows, int H) {
+    // an upper bound over every (B, T) with B * T <= rows and T >= 32: tiles <= H * (rows / 64 + B) <= H * 3 * rows / 64
+    const size_t tiles = (size_t)H * (3 * ((size_t)rows / 64 + 1) + 8);
+    size_t acc = tiles * 16384;
+    return 16 + hfused_flag_bytes(acc + acc / 2048) + 512 + acc;
+}
+int ttsmi_hattention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes) {
+    TTSMI_KNOB(on, "TTSMI_ATTN_FUSED_BWD", 1);
+    if (!on || dh != 64 || B <= 0 || H <= 0 || T <= 0) return 0;
+    const size_t flags = hfused_flag_bytes(ws_bytes);
+    const size_t tiles = (size_t)B * H * ttsmi_cdiv(T, HKT);
+    return tiles * 4 <= flags && 16 + flags + 256 + tiles * 16384 <= ws_bytes;
+}
+int ttsmi_hattention_bwd_fused_ws_init(void* ws, size_t ws_bytes, hipStream_t st) {
+    TTSMI_CHECK_ARG(ws && ws_bytes >= 4096 && (((uintptr_t)ws) & 255) == 0, "attention_bwd_fused_ws_init: workspace missing, < 4096 bytes or not 256-byte aligned");
+    if (hipMemsetAsync(ws, 0, 16 + hfused_flag_bytes(ws_bytes), st) != hipSuccess) {
+        ttsmi_set_error("attention_bwd_fused_ws_init: memset failed");
+        return TTSMI_ERR_LAUNCH;
+    }
+    return TTSMI_OK;
+}
+int ttsmi_hattention_bwd_fused(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
+                               const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
+                               float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, const void* dropmask,
+                               void* ws, size_t ws_bytes, hipStream_t st) {
+    HAttnP p;
+    int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_bwd_fused");
+    if (rc) return rc;
+    TTSMI_CHECK_ARG(ctx && dctx && lse && dqkv && ws, "attention_bwd_fused: null pointer");
+    TTSMI_CHECK_ARG((((uintptr_t)ws) & 255) == 0, "attention_bwd_fused: workspace must be 256-byte aligned");
+    if (!ttsmi_hattention_bwd_fused_supported(B, H, T, dh, ws_bytes)) {
+        ttsmi_set_error("attention_bwd_fused: head dim %d / workspace of %zu bytes not supported for B=%d H=%d T=%d "
+                        "(ttsmi_attention_bwd_fused_supported)", dh, ws_bytes, B, H, T);
+        return TTSMI_ERR_UNSUPPORTED;
+    }
+    p.dmask = (const uint64_t*)dropmask;
+    p.octx = (const float*)ctx; p.dctx = (const float*)dctx; p.lse = (float*)lse; p.dqkv = (float*)dqkv;
+    p.diag = (int*)ws;
+    p.sem = (int*)((char*)ws + 16);
+    p.dq_acc = (float*)((char*)ws + 16 + hfused_flag_bytes(ws_bytes) + 240);        // 256-byte aligned
+    TTSMI_KNOB(sc1, "TTSMI_ATTN_FUSED_SC1", 0);
+    p.acc_sc1 = sc1;
+    const int nkt = ttsmi_cdiv(T, 128), groups = B * H;
+    dim3 grid(8 * ttsmi_cdiv(groups, 8) * nkt);
+    if (p.thr && p.dmask) {
+        ttsmi_note_kernel("hattn_bwd_fused_kernel<64, 2>");
+        TTSMI_LAUNCH_EV((hattn_bwd_fused_kernel<64, 2>), grid, dim3(256), 0, st, p);
+    } else if (p.thr) {
+        ttsmi_note_kernel("hattn_bwd_fused_kernel<64, 1>");
+        TTSMI_LAUNCH_EV((hattn_bwd_fused_kernel<64, 1>), grid, dim3(256), 0, st, p);
+    } else {
+        ttsmi_note_kernel("hattn_bwd_fused_kernel<64, 0>");
+        TTSMI_LAUNCH_EV((hattn_bwd_fused_kernel<64, 0>), grid, dim3(256), 0, st, p);
+    }
+    TTSMI_CHECK_LAUNCH("attention_bwd_fused");
     return TTSMI_OK;
 }

@@ -54,3 +54,32 @@ def synthetic_batch(B: int, Tp: int, Tm: int, mel_channels: int = 80, seed: int 
         pitch[b, :tp] = p
         mel[b, :tm] = np.clip(rng.normal(-5.0, 2.0, size=(tm, mel_channels)), -11.5129, 2.0)
     return tokens, mel, durs, pitch
+
+
+def learnable_batch(B: int, Tp: int, Tm: int, mel_channels: int = 80, seed: int = 1234, vocab_size: int = 127):
+    """A ragged batch whose TARGETS ARE FUNCTIONS OF ITS INPUTS, so that a few hundred optimiser steps can fit it (the
+    noise targets of `synthetic_batch` cannot be: their loss plateaus at the noise's mean absolute deviation): the duration
+    of a phoneme is 1 + token % 7, its pitch a fixed per-token value, and every mel frame the fixed 80-bin row of the token
+    it expands from.  Sample 0 has Tp phonemes and exactly Tm frames (durations rescaled), the others are shorter;
+    sum(dur_b) == mel_len_b.  Returns (tokens i32 [B,Tp], mel f32 [B,Tm,C], durations i32 [B,Tp], pitch f32 [B,Tp])."""
+    rng = np.random.default_rng(seed)
+    table = np.clip(rng.normal(-5.0, 2.0, size=(vocab_size, mel_channels)), -11.5129, 2.0).astype(np.float32)
+    ptab = rng.standard_normal(vocab_size).astype(np.float32)
+    tok = np.zeros((B, Tp), np.int32)
+    dur = np.zeros((B, Tp), np.int32)
+    pit = np.zeros((B, Tp), np.float32)
+    mel = np.zeros((B, Tm, mel_channels), np.float32)
+    for b in range(B):
+        tp = Tp if b == 0 else int(rng.integers(max(1, Tp // 2), Tp + 1))
+        t = rng.integers(1, vocab_size, size=tp)
+        d = 1 + (t % 7)
+        if b == 0:                                     # stretch to exactly Tm frames
+            d = np.maximum(1, np.floor(d * (Tm / d.sum()))).astype(np.int64)
+            d[np.argmax(d)] += Tm - d.sum()
+            assert d.min() >= 1 and d.sum() == Tm
+        while d.sum() > Tm:                            # shorter samples: drop phonemes until the frames fit
+            tp -= 1
+            t, d = t[:tp], d[:tp]
+        tok[b, :tp], dur[b, :tp], pit[b, :tp] = t, d, ptab[t]
+        mel[b, :int(d.sum())] = np.repeat(table[t], d, axis=0)
+    return tok, mel, dur, pit
