@@ -141,20 +141,20 @@ int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const in
                                int dtype, ttsmi_stream_t stream);
 /* ONE-PASS backward for TTSMI_BF16_IO tensors at head dim 64 (model/layers.py:176-195 differentiated once): dK, dV and dQ
  * from a single recomputation of S = q.k^T and dP = d(ctx).v^T - 10 T^2 dh of products and one softmax pass where
- * ttsmi_attention_bwd runs two kernels, 14 T^2 dh and two softmax passes.  Key-stationary workgroups; dQ is summed over
- * the key tiles of a head in a FIXED order through fp32 tiles in `ws` (hand-off flags in L2, no float atomics: results are
- * bit-reproducible).  Same results as ttsmi_attention_bwd / _bwd_masked up to fp32 summation order (dQ is rounded to bf16
- * once, after the whole sum).  dropmask: the keep-bit table of ttsmi_attention_dropmask, or NULL (then seed / step_dev /
- * site drive the hashed dropout as in ttsmi_attention_bwd; p_drop == 0: no dropout).
- *   ws: 256-byte aligned, at least ttsmi_attention_bwd_fused_ws_bytes(rows, H) bytes for every batch of B*T <= rows rows
- *       (T >= 32), initialised ONCE after allocation with ttsmi_attention_bwd_fused_ws_init (zeroes the flags: they reset
- *       themselves at the end of every launch); the first 8 bytes are two int32 diagnostic counters that stay 0 in a
- *       healthy run ([0] hand-offs that timed out - the kernel then finishes with a wrong dQ instead of hanging -,
- *       [1] hand-offs between workgroups on different XCC ids);
- *   _supported: non-zero when (B, H, T, dh) can run on a workspace of ws_bytes (dh == 64, flags + tiles fit); the
+ * ttsmi_attention_bwd runs two kernels, 14 T^2 dh and two softmax passes.  Key-stationary workgroups; every key tile of a
+ * head stores its fp32 partial of a dQ tile in `ws` and draws a ticket, and the workgroup that draws the last ticket adds
+ * the partials in a FIXED order (no float atomics, nobody waits for anybody: results are bit-reproducible).  Same results
+ * as ttsmi_attention_bwd / _bwd_masked up to fp32 summation order (dQ is rounded to bf16 once, after the whole sum).
+ * dropmask: the keep-bit table of ttsmi_attention_dropmask, or NULL (then seed / step_dev / site drive the hashed dropout
+ * as in ttsmi_attention_bwd; p_drop == 0: no dropout).
+ *   ws: 256-byte aligned, at least ttsmi_attention_bwd_fused_ws_bytes(B, H, T) bytes, initialised ONCE after allocation
+ *       with ttsmi_attention_bwd_fused_ws_init (zeroes the ticket counters: they reset themselves at the end of every
+ *       launch, whatever its shape); bytes [4, 8) are an int32 diagnostic counter that stays 0 in a healthy run
+ *       (workgroups that ran on another XCC than block id % 8 - the placement that keeps the partials in one L2);
+ *   _supported: non-zero when (B, H, T, dh) can run on a workspace of ws_bytes (dh == 64, counters + tiles fit); the
  *       entry point returns TTSMI_ERR_UNSUPPORTED otherwise and the caller uses ttsmi_attention_bwd.
  * TTSMI_ATTN_FUSED_BWD=0 (A/B knob) makes _supported return 0. */
-size_t ttsmi_attention_bwd_fused_ws_bytes(int rows, int H);
+size_t ttsmi_attention_bwd_fused_ws_bytes(int B, int H, int T);
 int ttsmi_attention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes);
 int ttsmi_attention_bwd_fused_ws_init(void* ws, size_t ws_bytes, ttsmi_stream_t stream);
 int ttsmi_attention_bwd_fused(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,

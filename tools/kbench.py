@@ -155,7 +155,7 @@ def bench_attn():
             fl = 4.0 * B * H * T * T * dh
             cases = [('gen bits', gen, 0), ('fwd bits', fwd_m, 1), ('bwd bits', bwd_m, 2)]
             if io == 'h' and dh == 64:                  # the one-pass backward (ttsmi_attention_bwd_fused), keep-bit dropout
-                fws = torch.empty(int(l.ttsmi_attention_bwd_fused_ws_bytes(B * T, H)), dtype=torch.uint8, device=dev)
+                fws = torch.empty(int(l.ttsmi_attention_bwd_fused_ws_bytes(B, H, T)), dtype=torch.uint8, device=dev)
                 check(l.ttsmi_attention_bwd_fused_ws_init(_p(fws), fws.numel(), _stream()))
 
                 def bwd_f():
@@ -172,7 +172,7 @@ def bench_attn():
         tb_ = timeit(bwd, n=20)
         fl = 4.0 * B * H * T * T * dh
         if io == 'h' and dh == 64 and pdrop == 0:
-            fws0 = torch.empty(int(l.ttsmi_attention_bwd_fused_ws_bytes(B * T, H)), dtype=torch.uint8, device=dev)
+            fws0 = torch.empty(int(l.ttsmi_attention_bwd_fused_ws_bytes(B, H, T)), dtype=torch.uint8, device=dev)
             check(l.ttsmi_attention_bwd_fused_ws_init(_p(fws0), fws0.numel(), _stream()))
 
             def bwd_f0():
@@ -184,7 +184,7 @@ def bench_attn():
             t1 = timeit(bwd_f0, n=20)
             out.append(dict(kind='attn', name='bwd 1pass p=0.0', M=B * T, K=T, N=dh, us=t1, tflops=2 * fl / t1 / 1e6, tbs=0.0))
             dg = fws0[:8].view(torch.int32).cpu().tolist()
-            assert dg == [0, 0], f'one-pass backward hand-off diagnostics {dg}'
+            assert dg == [0, 0], f'one-pass backward diagnostics {dg}'
         out.append(dict(kind='attn', name=f'fwd p={pdrop}' + ('' if io == 'h' else ' f32io'), M=B * T, K=T, N=dh, us=tf_, tflops=fl / tf_ / 1e6, tbs=0.0))
         out.append(dict(kind='attn', name=f'bwd p={pdrop}' + ('' if io == 'h' else ' f32io'), M=B * T, K=T, N=dh, us=tb_, tflops=2 * fl / tb_ / 1e6, tbs=0.0))
     return out

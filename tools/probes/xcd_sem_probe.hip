@@ -1,3 +1,7 @@
+// (Round 4: the measurement that made the one-pass attention backward a TICKET scheme instead of this chain - every
+// hand-off here costs a poll round trip, a tile round trip and a store acknowledgement, and start order inside an XCD is
+// not block-id order; what the kernel kept from it: XCC_ID == blockIdx % 8, and plain stores + L1-bypassing loads are
+// coherent inside one XCD's L2 while the same protocol across XCDs reads stale data.)
 // Can workgroups of ONE kernel hand a tile to each other through L2 in a FIXED order, cheaply?  (The one-pass attention
 // backward needs it: key-stationary workgroups each hold a partial dQ tile that has to be summed over the key tiles of a
 // head in a reproducible order - csrc/attention_bf16.hip, hattn_bwd_fused_kernel.)

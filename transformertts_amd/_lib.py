@@ -54,7 +54,7 @@ SIGNATURES = {
     'ttsmi_attention_fwd_splitkeys_ws_bytes': (c_size_t, [I, I, I, I]),
     'ttsmi_attention_fwd_splitkeys': (I, [P, P, P, P, P, I, I, I, I, P, c_size_t, S]),
     'ttsmi_attention_bwd_masked': (I, [P, P, P, P, P, P, P, I, I, I, I, F, P, P, c_size_t, I, S]),
-    'ttsmi_attention_bwd_fused_ws_bytes': (c_size_t, [I, I]),
+    'ttsmi_attention_bwd_fused_ws_bytes': (c_size_t, [I, I, I]),
     'ttsmi_attention_bwd_fused_supported': (I, [I, I, I, I, c_size_t]),
     'ttsmi_attention_bwd_fused_ws_init': (I, [P, c_size_t, S]),
     'ttsmi_attention_bwd_fused': (I, [P, P, P, P, P, P, P, I, I, I, I, F, c_uint64, P, c_uint32, P, P, c_size_t, S]),

@@ -553,7 +553,7 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
     return TTSMI_OK;
 }
 
-size_t ttsmi_attention_bwd_fused_ws_bytes(int rows, int H) { return ttsmi_hattention_bwd_fused_ws_bytes(rows, H); }
+size_t ttsmi_attention_bwd_fused_ws_bytes(int B, int H, int T) { return ttsmi_hattention_bwd_fused_ws_bytes(B, H, T); }
 int ttsmi_attention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes) {
     return ttsmi_hattention_bwd_fused_supported(B, H, T, dh, ws_bytes);
 }

@@ -43,10 +43,9 @@ struct HAttnP {
     // forward only, split_keys != 0: blockIdx.y = key split s owns keys [s*split_keys, (s+1)*split_keys) and writes its
     // own softmax-normalised partial context / log-sum-exp at ctx + s*ctx_split (elements) / lse + s*lse_split
     int split_keys; long ctx_split, lse_split;
-    // one-pass backward only (hattn_bwd_fused_kernel): the fp32 dQ tiles in flight between the key tiles of a head (one
-    // 16 KB register image per (b, h, 64-query tile)), their hand-off flags, and two diagnostic counters
+    // one-pass backward only (hattn_bwd_fused_kernel): the fp32 partial dQ tiles of the key tiles of a head (a 16 KB register
+    // image per (b, h, 64-query tile, key tile)), the ticket counters (`sem`), and the diagnostic counters
     float* dq_acc; int* sem; int* diag;
-    int acc_sc1;                    // 1: the dQ tiles are stored with agent-scope (sc1) stores instead of plain ones (A/B knob)
 };
 
 // DROP template values: 0 = no dropout, 1 = keep decisions hashed in the inner loop (ttsmi_pair_hash), 2 = keep
@@ -887,18 +886,21 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
 // all 128 keys of the workgroup - one 32 x 32 block per wave, both operands through the transposing LDS read - 10 T^2 dh
 // of products and ONE softmax recomputation.
 //
-// dQ is reduced over the key tiles of a head ACROSS workgroups, in a fixed order (reproducible bits, no float atomics):
-// the partial tile travels j = 0 -> 1 -> ... through an fp32 scratch image in HBM/L2; workgroup j waits for flag == j, adds
-// the image to its own product, stores it and posts j + 1; the last active key tile converts to bf16 and writes dqkv.
-// What makes this cheap: all key tiles of a (b, h) are dispatched to ONE XCD (block id = 8 * slot + xcd; group =
-// xcd + 8 * (slot / nkt), key tile = slot % nkt), so the hand-off lives in that XCD's L2 - plain write-through stores, an
-// `s_waitcnt vmcnt(0)` + barrier before the flag, agent-scope (L1-bypassing) loads on the reading side; no L2 write-back
-// / invalidate (what an agent-scope release / acquire fence costs on a multi-XCD part).  A workgroup only ever waits for
-// a LOWER block id of its own XCD, which the in-order dispatcher started earlier (tools/probes/xcd_sem_probe.hip measures
-// placement, start order, and the protocol itself).  Spins are bounded: a wait that never ends raises diag[0] and the
-// kernel finishes (with wrong dQ) instead of hanging; diag[1] counts hand-offs between different XCC ids.  Flags reset
-// themselves (the last workgroup of a chain posts 0), so the flag region only has to be zero once, at allocation
-// (ttsmi_attention_bwd_fused_ws_init).
+// dQ still has to be summed over the key tiles of a head, i.e. ACROSS workgroups - reproducibly, so no float atomics, and
+// without one workgroup ever waiting for another (round 4's first version handed the running sum down a chain j = 0 -> 1
+// -> .. of flags: correct, but every hand-off exposed an L2 round trip for the poll, one for the tile and one for the store
+// acknowledgement - +2.6 us on a 2.9 us step - and a waiting workgroup depends on the dispatcher having started its
+// predecessor, which tools/probes/xcd_sem_probe.hip shows is NOT strictly in block-id order).  So: every workgroup stores
+// its own fp32 partial tile (a 16 KB register image) to scratch and, once the stores are acknowledged, takes a ticket
+// from a counter of that (head, query tile).  The workgroup that draws the LAST ticket - whichever it is - adds all the
+// partials in the fixed order j = 0, 1, .. and writes the bf16 result: the bits do not depend on who arrived when.
+// Nobody spins.  All key tiles of a head are dispatched to one XCD (block id = 8 * slot + xcd; head = xcd + 8 * (slot /
+// nkt), key tile = slot % nkt - XCC_ID == block id % 8 on this part, measured by the probe and re-checked here: diag[1]),
+// so the partials meet in that XCD's L2: plain write-through stores, `s_waitcnt vmcnt(0)` + a barrier before the ticket,
+// L1-bypassing (agent-scope) loads in the reducer; no L2 write-back / invalidate.  The ticket of tile i is drawn one step
+// later (when its stores have long been acknowledged) and its value is looked at another half step later, so neither
+// round trip is waited for.  Counters reset themselves (the reducer stores 0), so their region only has to be zero once,
+// at allocation (ttsmi_attention_bwd_fused_ws_init).
 __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* img, int k0, int t, int colblock, int lane) {
     // MFMA 32x32x16 operand (A or B alike) whose 8 reduction elements are rows k0 + 16 t + 4 hh + {0..3, 8..11} of the
     // row-major image img[row][72] at column colblock * 32 + (lane & 31): the addressing of accumTR
@@ -918,7 +920,6 @@ __device__ __forceinline__ float row16_sum(float v) {          // sum over the 1
     v += ttsmi_dpp<TTSMI_DPP_ROW_MIRROR, 0xF>(v, 0.f);
     return v;
 }
-#define HFUSED_SPIN_LIMIT (1 << 18)
 
 template <int DH, int DROP>
 __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
@@ -928,6 +929,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
     constexpr int IMG = HKT * LD;
     __shared__ __attribute__((aligned(16))) uint16_t smem_h[2 * IMG + 2 * 128 * LD];
     __shared__ float statS[3 * HKT];
+    __shared__ int lastS;                            // 1: this workgroup drew the last ticket of the previous query tile
     uint16_t* Qs = smem_h;                           // [64 queries][72]
     uint16_t* Os = Qs + IMG;                         // dO tile
     uint16_t* Ks = Os + IMG;                         // [128 keys][72]: this workgroup's K rows, stationary (dQ's A operand)
@@ -940,18 +942,17 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkt = (p.T + 127) >> 7, nqt = (p.T + HKT - 1) / HKT;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int grp = xcd + 8 * (slot / nkt), bx = slot % nkt;       // grp = b * H + h; bx = key tile = position in the chain
+    const int grp = xcd + 8 * (slot / nkt), bx = slot % nkt;       // grp = b * H + h; bx = key tile
     if (grp >= p.B * p.H) return;
     const int h = grp % p.H, b = grp / p.H;
     const int d = p.H * DH;
     const int key = bx * 128 + wave * 32 + l31;
     const int klen = p.klen[b];
-    const int nact = max(1, (klen + 127) >> 7);      // key tiles that take part in the chain (tile 0 always does)
+    const int nact = max(1, (klen + 127) >> 7);      // key tiles that hold unpadded keys (tile 0 always counts): the partials of a sum
     const bool kok = key < p.T;
     const bool kact = key < klen;
     const bool wave_live = (bx * 128 + wave * 32) < klen;
     const bool wg_active = bx < nact;
-    const bool chain_last = bx == nact - 1;
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
     const float* Vb = eptr<QH>(Qb, 2 * d);
@@ -965,6 +966,11 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
         for (int r = 0; r < 16; ++r) { dk[cb][r] = 0.f; dv[cb][r] = 0.f; }
 
     if (wg_active) {
+        if (tid == 0) {
+            unsigned xid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
+            if ((int)(xid & 15) != xcd) atomicAdd(p.diag + 1, 1);          // the placement this kernel relies on does not hold
+        }
         bf16x8 kf[DH / 16], vf[DH / 16];
         frags_of<DH, QH>(Kb, p.ld, key, kok, hh, kf);
         frags_of<DH, QH>(Vb, p.ld, key, kok, hh, vf);
@@ -999,15 +1005,40 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             t0.stash(Ks, tid);
             t1.stash(Ks + IMG, tid);
             for (int i = tid; i < 128 * LD / 8; i += 256) reinterpret_cast<uint4*>(dSs)[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid == 0) lastS = 0;
         }
-        int* const sem = p.sem + (long)grp * nqt;
-        float* const acc0 = p.dq_acc + (long)grp * nqt * 4096 + (wave * 16 * 64 + lane);      // + r * 64 + tile * 4096
-        unsigned xid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
-        xid &= 15;
+        int* const cnt = p.sem + (long)grp * nqt;                              // one ticket counter per query tile of this head
+        float* const part0 = p.dq_acc + (long)grp * nqt * nkt * 4096;          // [query tile][key tile][4096]: the partials
+        const int img_off = wave * 16 * 64 + lane;                             // register image: + r * 64
         const int cbq = wave & 1, qbq = wave >> 1;       // this wave's 32 x 32 block of the dQ^T tile: columns / queries
-        bool dead = false;                               // (thread 0) a hand-off timed out: stop waiting, finish the kernel
-        int post = -1;                                   // (thread 0) flag value to post for the previous tile, after its stores
+        int ticket = -1;                                 // (thread 0) ticket drawn for the previous query tile
+
+        // dQ of query tile `qt_i` = the partials of all key tiles in the fixed order 0, 1, ..: run by the last arrival
+        auto reduce_tile = [&](int qt_i) {
+            const float* src = part0 + (long)qt_i * nkt * 4096 + img_off;
+            float acc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int j = 0; j < nact; ++j) {
+                float in[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) in[r] = __hip_atomic_load(src + (long)j * 4096 + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += in[r];
+            }
+            const int q = qt_i * HKT + qbq * 32 + l31;
+            if (q < p.T) {
+                uint16_t* dst = reinterpret_cast<uint16_t*>(p.dqkv) + ((long)b * p.T + q) * p.ld + h * DH + cbq * 32 + 4 * hh;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    bf16x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (__bf16)acc[4 * g4 + e];
+                    *reinterpret_cast<uint2*>(dst + 8 * g4) = __builtin_bit_cast(uint2, o4);
+                }
+            }
+            if (tid == 0) __hip_atomic_store(cnt + qt_i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+        };
 
         Tile<DH, QH> rq, ro, rc;
         float rl = 0.f;
@@ -1022,12 +1053,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             if (tid < HKT) rl = p.lse[stat0 + min(tid, p.T - 1)];
         }
         for (int q0 = 0, it = 0; q0 < p.T; q0 += HKT, ++it) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the previous tile's dQ stores have reached L2
             __syncthreads();
-            if (tid == 0 && post >= 0) {
-                __hip_atomic_store(sem + it - 1, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                post = -1;
-            }
             rq.stash(Qs, tid);
             ro.stash(Os, tid);
             {
@@ -1048,7 +1074,12 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             uint32_t mcur[HKT / 32];
 #pragma unroll
             for (int u = 0; u < HKT / 32; ++u) mcur[u] = mnext[u] >> (4 * hh);
+            // the previous tile's partial (and whatever a reduction stored) has reached L2 by now: nothing younger is in
+            // flight - this step's prefetches are issued below - so the wait is for stores issued a barrier and a stash ago
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (tid == 0 && it > 0)                       // (the returned ticket is only looked at after the sub-tiles)
+                ticket = __hip_atomic_fetch_add(cnt + it - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (q0 + HKT < p.T) {
                 int nv = min(HKT, p.T - (q0 + HKT));
                 rq.fetch(Qb, p.ld, q0 + HKT, nv, tid);
@@ -1099,65 +1130,33 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
                     *reinterpret_cast<as16x4*>(row + 8 * g4) = w;
                 }
             }
-            // ---- the chain: wait until key tile bx - 1 has stored its sum for this query tile
-            if (bx > 0 && tid == 0 && !dead) {
-                int spins = 0, f;
-                while (((f = __hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFF) != bx) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > HFUSED_SPIN_LIMIT ||
-                        ((spins & 1023) == 0 && __hip_atomic_load(p.diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        atomicAdd(p.diag, 1);
-                        dead = true;
-                        break;
-                    }
+            if (tid == 0) lastS = (it > 0 && ticket == nact - 1) ? 1 : 0;
+            __syncthreads();                                   // the dS image is complete
+            f32x16 dqa, dqb;                                   // two independent accumulation chains
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dqa[r] = 0.f; dqb[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; kk += 2)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    dqa = MFMA16(tr_frag(Ks, kk * 32, t, cbq, lane), tr_frag(dSs, kk * 32, t, qbq, lane), dqa);   // dQ^T += K^T.dS^T
+                    dqb = MFMA16(tr_frag(Ks, kk * 32 + 32, t, cbq, lane), tr_frag(dSs, kk * 32 + 32, t, qbq, lane), dqb);
                 }
-                if (!dead && (unsigned)(f >> 8) != xid) atomicAdd(p.diag + 1, 1);
+            {
+                float* dstp = part0 + ((long)it * nkt + bx) * 4096 + img_off;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dstp[r * 64] = dqa[r] + dqb[r];       // plain stores: written through to the XCD's L2
             }
-            __syncthreads();                                   // the dS image is complete, the incoming sum is in L2
-            float* const acc = acc0 + (long)it * 4096;
-            float in[16];
-            if (bx > 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) in[r] = __hip_atomic_load(acc + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            f32x16 dqt;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dqt[r] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    dqt = MFMA16(tr_frag(Ks, kk * 32, t, cbq, lane), tr_frag(dSs, kk * 32, t, qbq, lane), dqt);   // dQ^T += K^T.dS^T
-            if (bx > 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dqt[r] += in[r];
-            }
-            if (chain_last) {
-                const int q = q0 + qbq * 32 + l31;
-                if (q < p.T) {
-                    uint16_t* dst = reinterpret_cast<uint16_t*>(p.dqkv) + ((long)b * p.T + q) * p.ld + h * DH + cbq * 32 + 4 * hh;
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        bf16x4 o4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = (__bf16)dqt[4 * g4 + e];
-                        *reinterpret_cast<uint2*>(dst + 8 * g4) = __builtin_bit_cast(uint2, o4);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // plain stores are written through the CU's L1 into the XCD's L2, where the next key tile's L1-bypassing
-                    // loads find them; the sc1 form (agent scope) is the A/B alternative (TTSMI_ATTN_FUSED_SC1=1)
-                    if (p.acc_sc1) __hip_atomic_store(acc + r * 64, dqt[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else acc[r * 64] = dqt[r];
-                }
-            }
-            if (tid == 0) post = chain_last ? 0 : ((bx + 1) | ((int)xid << 8));
+            if (lastS) reduce_tile(it - 1);                    // (workgroup-uniform; lastS is rewritten after two more barriers)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0 && post >= 0) __hip_atomic_store(sem + nqt - 1, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            ticket = __hip_atomic_fetch_add(cnt + nqt - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lastS = ticket == nact - 1 ? 1 : 0;
+        }
+        __syncthreads();
+        if (lastS) reduce_tile(nqt - 1);
     }
     __syncthreads();
     // dK / dV of this workgroup's 128 keys (zeros for a key tile past the last unpadded key)
@@ -1526,22 +1525,22 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
 }
 
 // ---- one-pass backward (hattn_bwd_fused_kernel) ------------------------------------------------------------------------
-// Workspace layout (bytes): [0, 16) four int32 diagnostic counters (0: hand-offs that timed out, 1: hand-offs between
-// different XCC ids; both stay 0 in a healthy run), [16, 16 + S) the hand-off flags (S from the workspace size alone, so
-// the region does not move with the batch shape and stays all-zero between launches), then the fp32 dQ tiles.
+// Workspace layout (bytes): [0, 16) four int32 diagnostic counters ([1]: workgroups that found themselves on another XCC
+// than block id % 8; stays 0), [16, 16 + S) the ticket counters, one per (head, 64-query tile) (S from the workspace size
+// alone, so the region does not move with the batch shape and stays all-zero between launches), then the fp32 partial dQ
+// tiles [head][query tile][key tile][4096].
 static size_t hfused_flag_bytes(size_t ws_bytes) { return ((ws_bytes / 4096 + 255) / 256) * 256; }
-size_t ttsmi_hattention_bwd_fused_ws_bytes(int rows, int H) {
-    // an upper bound over every (B, T) with B * T <= rows and T >= 32: tiles <= H * (rows / 64 + B) <= H * 3 * rows / 64
-    const size_t tiles = (size_t)H * (3 * ((size_t)rows / 64 + 1) + 8);
-    size_t acc = tiles * 16384;
-    return 16 + hfused_flag_bytes(acc + acc / 2048) + 512 + acc;
+size_t ttsmi_hattention_bwd_fused_ws_bytes(int B, int H, int T) {
+    const size_t tiles = (size_t)B * H * ttsmi_cdiv(T, HKT) * ttsmi_cdiv(T, 128);
+    const size_t acc = tiles * 16384;
+    return 16 + hfused_flag_bytes(acc + acc / 2048 + 8192) + 512 + acc;
 }
 int ttsmi_hattention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes) {
     TTSMI_KNOB(on, "TTSMI_ATTN_FUSED_BWD", 1);
     if (!on || dh != 64 || B <= 0 || H <= 0 || T <= 0) return 0;
     const size_t flags = hfused_flag_bytes(ws_bytes);
-    const size_t tiles = (size_t)B * H * ttsmi_cdiv(T, HKT);
-    return tiles * 4 <= flags && 16 + flags + 256 + tiles * 16384 <= ws_bytes;
+    const size_t qtiles = (size_t)B * H * ttsmi_cdiv(T, HKT);
+    return qtiles * 4 <= flags && 16 + flags + 256 + qtiles * ttsmi_cdiv(T, 128) * 16384 <= ws_bytes;
 }
 int ttsmi_hattention_bwd_fused_ws_init(void* ws, size_t ws_bytes, hipStream_t st) {
     TTSMI_CHECK_ARG(ws && ws_bytes >= 4096 && (((uintptr_t)ws) & 255) == 0, "attention_bwd_fused_ws_init: workspace missing, < 4096 bytes or not 256-byte aligned");
@@ -1570,8 +1569,6 @@ int ttsmi_hattention_bwd_fused(const void* qkv, const uint8_t* key_pad, const in
     p.diag = (int*)ws;
     p.sem = (int*)((char*)ws + 16);
     p.dq_acc = (float*)((char*)ws + 16 + hfused_flag_bytes(ws_bytes) + 240);        // 256-byte aligned
-    TTSMI_KNOB(sc1, "TTSMI_ATTN_FUSED_SC1", 0);
-    p.acc_sc1 = sc1;
     const int nkt = ttsmi_cdiv(T, 128), groups = B * H;
     dim3 grid(8 * ttsmi_cdiv(groups, 8) * nkt);
     if (p.thr && p.dmask) {

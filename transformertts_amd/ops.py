@@ -1628,7 +1628,7 @@ class DenseBlockPlan:
             # (the model drops a stack's plans together when one of them has to grow, so nobody holds the old entry)
             shared[key] = ({'cap': cap, 'da': e((cap, d), f32), 'dctx': e((cap, d), bf),
                             'attn_ws': _ws(4 * cap * H + 1024, device),
-                            'attn_fused_ws': self._attn_fused_ws(l, cap, H, d // H, device)} if backward else
+                            'attn_fused_ws': None} if backward else
                            {'cap': cap, 'da': e((8,), f32), 'dctx': e((8,), bf),  # forward only: scratch of the split-key attention
                             'attn_ws': None})
         sh = shared[key]
@@ -1668,14 +1668,21 @@ class DenseBlockPlan:
         self.rebind(B, T)
 
     @staticmethod
-    def _attn_fused_ws(l, cap, H, dh, device):
-        """Workspace of the one-pass attention backward (ttsmi_attention_bwd_fused: the fp32 dQ tiles in flight between the
-        key tiles of a head + their hand-off flags), shared by the blocks of a stack; the flag region is zeroed once here and
-        resets itself after every launch.  None: head dim other than 64, or TTSMI_ATTN_FUSED_BWD=0."""
+    def _attn_fused_ws(l, sh, B, H, T, dh, device):
+        """Workspace of the one-pass attention backward (ttsmi_attention_bwd_fused: the fp32 partial dQ tiles of a head's
+        key tiles + their ticket counters), shared by the blocks of a stack and grown when a batch shape needs more; the
+        counter region is zeroed once per allocation and resets itself after every launch.  None: head dim other than 64,
+        or TTSMI_ATTN_FUSED_BWD=0."""
         if dh != 64 or os.environ.get('TTSMI_ATTN_FUSED_BWD', '1') == '0':
             return None
-        ws = _ws(int(l.ttsmi_attention_bwd_fused_ws_bytes(cap, H)), device)
-        check(l.ttsmi_attention_bwd_fused_ws_init(_p(ws), ws.numel(), _stream()), 'attention_bwd_fused_ws_init')
+        ws = sh.get('attn_fused_ws')
+        if ws is None or not l.ttsmi_attention_bwd_fused_supported(B, H, T, dh, ws.numel()):
+            need = int(l.ttsmi_attention_bwd_fused_ws_bytes(B, H, T))
+            # (the old workspace stays alive: captured graphs hold its raw pointer; growth is monotone, so the list stays short)
+            if ws is not None:
+                sh.setdefault('attn_fused_ws_retired', []).append(ws)
+            ws = sh['attn_fused_ws'] = _ws(need + need // 8, device)
+            check(l.ttsmi_attention_bwd_fused_ws_init(_p(ws), ws.numel(), _stream()), 'attention_bwd_fused_ws_init')
         return ws
 
     def rebind(self, B, T):
@@ -1712,7 +1719,7 @@ class DenseBlockPlan:
                 sh['attn_ws'] = _ws(need, self.t['qkv'].device)
             self._attn_ws = sh['attn_ws']
         D.attn_ws, D.attn_ws_bytes = sh['attn_ws'].data_ptr(), sh['attn_ws'].numel()
-        fws = sh.get('attn_fused_ws') if self.backward else None
+        fws = self._attn_fused_ws(l, sh, B, H, T, d // H, self.t['qkv'].device) if self.backward else None
         D.attn_fused_ws, D.attn_fused_ws_bytes = (fws.data_ptr(), fws.numel()) if fws is not None else (None, 0)
         D.attn_split = int(not self.backward and os.environ.get('TTSMI_ATTN_SPLIT', '1') != '0' and
                            l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, d // H) > 0)
