@@ -753,11 +753,16 @@ def lj_dist_bench(args):
         torch.cuda.synchronize()
 
     shapes, real, padded, stall = set(), 0, 0, 0.0
+    preloaded = None
+    if args.lj_preload:          # diagnosis: the same batches, produced BEFORE the timed loop (no producer thread beside it)
+        preloaded = [ds.next_batch() for _ in range(args.steps + args.warmup)]
+        ds.close()
+        torch.cuda.synchronize()
 
     def one(count):
         nonlocal real, padded, stall
         t0 = time.perf_counter()
-        mel, tok, dur, pit, names = ds.next_batch()
+        mel, tok, dur, pit, names = preloaded.pop() if preloaded is not None else ds.next_batch()
         t1 = time.perf_counter()
         B, Tm, Tp = int(mel.shape[0]), int(mel.shape[1]), int(tok.shape[1])
         out = wrapped.train_step(tok, mel, dur, pit, global_shape=(B * world, Tp, Tm), reduce_losses=False)
@@ -816,6 +821,7 @@ def lj_dist_bench(args):
         'host_stall_ms_per_step': 1e3 * stall / args.steps,
         'host_issue_ms_per_step': 1e3 * host / args.steps,
         'allocator_growth_mb': (reserved1 - reserved0) / 1e6, 'allocator_reserved_mb': reserved1 / 1e6,
+        'batches_preloaded': bool(args.lj_preload),
         'us_per_padded_frame': us_per_padded,
         'max_shape': {'ms_per_step': ms_max, 'us_per_padded_frame': us_per_padded_max, 'steps': n_max},
         'ragged_over_max_shape_per_padded_frame': us_per_padded / us_per_padded_max,
@@ -852,6 +858,8 @@ def main():
     ap.add_argument('--clips', type=int, default=10000, help='--workload mel: clips per GPU (BASELINE configs[3]: 10 000)')
     ap.add_argument('--no-also', action='store_true', help='skip the extra legs of the default run (f32 step, mel, predict)')
     ap.add_argument('--lj-samples', type=int, default=4096, help='--workload lj-dist: synthetic samples per GPU')
+    ap.add_argument('--lj-preload', action='store_true', help='--workload lj-dist: produce every batch before the timed loop '
+                                                              '(diagnosis: the step without the producer thread beside it)')
     args = ap.parse_args()
 
     if args.workload == 'predict':

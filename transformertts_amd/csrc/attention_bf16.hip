@@ -886,21 +886,26 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
 // all 128 keys of the workgroup - one 32 x 32 block per wave, both operands through the transposing LDS read - 10 T^2 dh
 // of products and ONE softmax recomputation.
 //
-// dQ still has to be summed over the key tiles of a head, i.e. ACROSS workgroups - reproducibly, so no float atomics, and
-// without one workgroup ever waiting for another (round 4's first version handed the running sum down a chain j = 0 -> 1
-// -> .. of flags: correct, but every hand-off exposed an L2 round trip for the poll, one for the tile and one for the store
-// acknowledgement - +2.6 us on a 2.9 us step - and a waiting workgroup depends on the dispatcher having started its
-// predecessor, which tools/probes/xcd_sem_probe.hip shows is NOT strictly in block-id order).  So: every workgroup stores
-// its own fp32 partial tile (a 16 KB register image) to scratch and, once the stores are acknowledged, takes a ticket
-// from a counter of that (head, query tile).  The workgroup that draws the LAST ticket - whichever it is - adds all the
-// partials in the fixed order j = 0, 1, .. and writes the bf16 result: the bits do not depend on who arrived when.
-// Nobody spins.  All key tiles of a head are dispatched to one XCD (block id = 8 * slot + xcd; head = xcd + 8 * (slot /
-// nkt), key tile = slot % nkt - XCC_ID == block id % 8 on this part, measured by the probe and re-checked here: diag[1]),
-// so the partials meet in that XCD's L2: plain write-through stores, `s_waitcnt vmcnt(0)` + a barrier before the ticket,
-// L1-bypassing (agent-scope) loads in the reducer; no L2 write-back / invalidate.  The ticket of tile i is drawn one step
-// later (when its stores have long been acknowledged) and its value is looked at another half step later, so neither
-// round trip is waited for.  Counters reset themselves (the reducer stores 0), so their region only has to be zero once,
-// at allocation (ttsmi_attention_bwd_fused_ws_init).
+// dQ still has to be summed over the key tiles of a head, i.e. ACROSS workgroups - reproducibly, so no float atomics.
+// The running sum of a (head, 64-query tile) travels down the key tiles j = 0 -> 1 -> ... through ONE fp32 register image
+// (16 KB) in scratch: key tile j waits for flag == j, adds the image to its own product, stores it back and posts j + 1;
+// the last key tile with unpadded keys converts to bf16 and writes dqkv.  The order is fixed, so the bits are.  All key
+// tiles of a head are dispatched to one XCD (block id = 8 * slot + xcd; head = xcd + 8 * (slot / nkt), key tile = slot %
+// nkt; XCC_ID == block id % 8 on this part - tools/probes/xcd_sem_probe.hip - and re-checked here: diag[1]), so the
+// image (31 MB for a whole decoder layer, rewritten in place 8 times) lives in that XCD's L2: plain write-through stores,
+// `s_waitcnt vmcnt(0)` + a barrier before the flag, L1-bypassing (agent-scope) loads on the reading side; no L2 write-back
+// / invalidate (what an agent-scope release / acquire fence costs on a multi-XCD part; the probe shows the same protocol
+// reading stale data ACROSS XCDs and being exact inside one).
+// Three round trips per hand-off are kept off the critical path (the first version exposed them: +2.6 us on a 2.9 us
+// step): every wave issues its own flag load right after the barrier that starts a step and looks at the value after the
+// two query sub-tiles; the incoming image is requested as soon as the flag is seen, before the barrier that completes the
+// dS image, and added after the dQ product; the outgoing image's acknowledgement is waited for one step later (before the
+// next step's second barrier), where the flag is posted.  A key tile therefore runs about one step behind its
+// predecessor.  Waits are bounded: one that never ends raises diag[0] and the kernel finishes (with a wrong dQ) instead
+// of hanging; a workgroup only waits for a LOWER block id of its own XCD.  Flags reset themselves (the last key tile
+// posts 0), so their region only has to be zero once, at allocation (ttsmi_attention_bwd_fused_ws_init).
+// (Also measured: a ticket scheme without any waiting - every key tile stores its own partial image, the last arrival adds
+// them in fixed order - is 40 % SLOWER than the two kernels: 251 MB of partials per decoder layer do not stay in L2.)
 __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* img, int k0, int t, int colblock, int lane) {
     // MFMA 32x32x16 operand (A or B alike) whose 8 reduction elements are rows k0 + 16 t + 4 hh + {0..3, 8..11} of the
     // row-major image img[row][72] at column colblock * 32 + (lane & 31): the addressing of accumTR
@@ -920,6 +925,7 @@ __device__ __forceinline__ float row16_sum(float v) {          // sum over the 1
     v += ttsmi_dpp<TTSMI_DPP_ROW_MIRROR, 0xF>(v, 0.f);
     return v;
 }
+#define HFUSED_SPIN_LIMIT (1 << 18)
 
 template <int DH, int DROP>
 __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
@@ -929,7 +935,6 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
     constexpr int IMG = HKT * LD;
     __shared__ __attribute__((aligned(16))) uint16_t smem_h[2 * IMG + 2 * 128 * LD];
     __shared__ float statS[3 * HKT];
-    __shared__ int lastS;                            // 1: this workgroup drew the last ticket of the previous query tile
     uint16_t* Qs = smem_h;                           // [64 queries][72]
     uint16_t* Os = Qs + IMG;                         // dO tile
     uint16_t* Ks = Os + IMG;                         // [128 keys][72]: this workgroup's K rows, stationary (dQ's A operand)
@@ -942,17 +947,18 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkt = (p.T + 127) >> 7, nqt = (p.T + HKT - 1) / HKT;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int grp = xcd + 8 * (slot / nkt), bx = slot % nkt;       // grp = b * H + h; bx = key tile
+    const int grp = xcd + 8 * (slot / nkt), bx = slot % nkt;       // grp = b * H + h; bx = key tile = position in the chain
     if (grp >= p.B * p.H) return;
     const int h = grp % p.H, b = grp / p.H;
     const int d = p.H * DH;
     const int key = bx * 128 + wave * 32 + l31;
     const int klen = p.klen[b];
-    const int nact = max(1, (klen + 127) >> 7);      // key tiles that hold unpadded keys (tile 0 always counts): the partials of a sum
+    const int nact = max(1, (klen + 127) >> 7);      // key tiles that take part in the chain (tile 0 always does)
     const bool kok = key < p.T;
     const bool kact = key < klen;
     const bool wave_live = (bx * 128 + wave * 32) < klen;
     const bool wg_active = bx < nact;
+    const bool chain_last = bx == nact - 1;
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
     const float* Vb = eptr<QH>(Qb, 2 * d);
@@ -966,11 +972,10 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
         for (int r = 0; r < 16; ++r) { dk[cb][r] = 0.f; dv[cb][r] = 0.f; }
 
     if (wg_active) {
-        if (tid == 0) {
-            unsigned xid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
-            if ((int)(xid & 15) != xcd) atomicAdd(p.diag + 1, 1);          // the placement this kernel relies on does not hold
-        }
+        unsigned xid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
+        xid &= 15;
+        if (tid == 0 && (int)xid != xcd) atomicAdd(p.diag + 1, 1);            // the placement this kernel relies on does not hold
         bf16x8 kf[DH / 16], vf[DH / 16];
         frags_of<DH, QH>(Kb, p.ld, key, kok, hh, kf);
         frags_of<DH, QH>(Vb, p.ld, key, kok, hh, vf);
@@ -1005,40 +1010,12 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             t0.stash(Ks, tid);
             t1.stash(Ks + IMG, tid);
             for (int i = tid; i < 128 * LD / 8; i += 256) reinterpret_cast<uint4*>(dSs)[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (tid == 0) lastS = 0;
         }
-        int* const cnt = p.sem + (long)grp * nqt;                              // one ticket counter per query tile of this head
-        float* const part0 = p.dq_acc + (long)grp * nqt * nkt * 4096;          // [query tile][key tile][4096]: the partials
-        const int img_off = wave * 16 * 64 + lane;                             // register image: + r * 64
+        int* const sem = p.sem + (long)grp * nqt;                              // one hand-off flag per query tile of this head
+        float* const acc0 = p.dq_acc + (long)grp * nqt * 4096 + (wave * 16 * 64 + lane);      // register image: + r * 64, + tile * 4096
         const int cbq = wave & 1, qbq = wave >> 1;       // this wave's 32 x 32 block of the dQ^T tile: columns / queries
-        int ticket = -1;                                 // (thread 0) ticket drawn for the previous query tile
-
-        // dQ of query tile `qt_i` = the partials of all key tiles in the fixed order 0, 1, ..: run by the last arrival
-        auto reduce_tile = [&](int qt_i) {
-            const float* src = part0 + (long)qt_i * nkt * 4096 + img_off;
-            float acc[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int j = 0; j < nact; ++j) {
-                float in[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) in[r] = __hip_atomic_load(src + (long)j * 4096 + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] += in[r];
-            }
-            const int q = qt_i * HKT + qbq * 32 + l31;
-            if (q < p.T) {
-                uint16_t* dst = reinterpret_cast<uint16_t*>(p.dqkv) + ((long)b * p.T + q) * p.ld + h * DH + cbq * 32 + 4 * hh;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    bf16x4 o4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = (__bf16)acc[4 * g4 + e];
-                    *reinterpret_cast<uint2*>(dst + 8 * g4) = __builtin_bit_cast(uint2, o4);
-                }
-            }
-            if (tid == 0) __hip_atomic_store(cnt + qt_i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-        };
+        bool dead = false;                               // (wave-uniform) a hand-off timed out: stop waiting, finish the kernel
+        int post = -1;                                   // (thread 0) flag to post for the previous tile, once its stores are acknowledged
 
         Tile<DH, QH> rq, ro, rc;
         float rl = 0.f;
@@ -1074,12 +1051,17 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             uint32_t mcur[HKT / 32];
 #pragma unroll
             for (int u = 0; u < HKT / 32; ++u) mcur[u] = mnext[u] >> (4 * hh);
-            // the previous tile's partial (and whatever a reduction stored) has reached L2 by now: nothing younger is in
-            // flight - this step's prefetches are issued below - so the wait is for stores issued a barrier and a stash ago
+            // the previous tile's image has reached L2 by now: nothing younger is in flight - this step's prefetches are
+            // issued below - so the wait is for stores issued a barrier and a stash ago
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0 && it > 0)                       // (the returned ticket is only looked at after the sub-tiles)
-                ticket = __hip_atomic_fetch_add(cnt + it - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && post >= 0) {
+                __hip_atomic_store(sem + it - 1, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                post = -1;
+            }
+            // every wave reads this tile's flag for itself, now; the value is looked at after the sub-tiles
+            int flag = 0;
+            if (bx > 0 && !dead) flag = __hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (q0 + HKT < p.T) {
                 int nv = min(HKT, p.T - (q0 + HKT));
                 rq.fetch(Qb, p.ld, q0 + HKT, nv, tid);
@@ -1130,7 +1112,28 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
                     *reinterpret_cast<as16x4*>(row + 8 * g4) = w;
                 }
             }
-            if (tid == 0) lastS = (it > 0 && ticket == nact - 1) ? 1 : 0;
+            // ---- the chain: key tile bx - 1 must have stored its sum for this query tile (normally seen by the early load)
+            float* const acc = acc0 + (long)it * 4096;
+            float in[16];
+            if (bx > 0) {
+                if (!dead) {
+                    int spins = 0;
+                    flag = __builtin_amdgcn_readfirstlane(flag);
+                    while ((flag & 0xFF) != bx) {
+                        __builtin_amdgcn_s_sleep(1);
+                        flag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (++spins > HFUSED_SPIN_LIMIT ||
+                            ((spins & 1023) == 0 && __hip_atomic_load(p.diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            if (lane == 0) atomicAdd(p.diag, 1);
+                            dead = true;
+                            break;
+                        }
+                    }
+                    if (!dead && (unsigned)(flag >> 8) != xid && lane == 0) atomicAdd(p.diag + 1, 1);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) in[r] = __hip_atomic_load(acc + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __syncthreads();                                   // the dS image is complete
             f32x16 dqa, dqb;                                   // two independent accumulation chains
 #pragma unroll
@@ -1142,21 +1145,30 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
                     dqa = MFMA16(tr_frag(Ks, kk * 32, t, cbq, lane), tr_frag(dSs, kk * 32, t, qbq, lane), dqa);   // dQ^T += K^T.dS^T
                     dqb = MFMA16(tr_frag(Ks, kk * 32 + 32, t, cbq, lane), tr_frag(dSs, kk * 32 + 32, t, qbq, lane), dqb);
                 }
-            {
-                float* dstp = part0 + ((long)it * nkt + bx) * 4096 + img_off;
+            float dq[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dstp[r * 64] = dqa[r] + dqb[r];       // plain stores: written through to the XCD's L2
+            for (int r = 0; r < 16; ++r) dq[r] = bx > 0 ? in[r] + (dqa[r] + dqb[r]) : dqa[r] + dqb[r];
+            if (chain_last) {
+                const int q = q0 + qbq * 32 + l31;
+                if (q < p.T) {
+                    uint16_t* dst = reinterpret_cast<uint16_t*>(p.dqkv) + ((long)b * p.T + q) * p.ld + h * DH + cbq * 32 + 4 * hh;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        bf16x4 o4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = (__bf16)dq[4 * g4 + e];
+                        *reinterpret_cast<uint2*>(dst + 8 * g4) = __builtin_bit_cast(uint2, o4);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r * 64] = dq[r];       // plain stores: written through to the XCD's L2
             }
-            if (lastS) reduce_tile(it - 1);                    // (workgroup-uniform; lastS is rewritten after two more barriers)
+            if (tid == 0) post = chain_last ? 0 : ((bx + 1) | ((int)xid << 8));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            ticket = __hip_atomic_fetch_add(cnt + nqt - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lastS = ticket == nact - 1 ? 1 : 0;
-        }
-        __syncthreads();
-        if (lastS) reduce_tile(nqt - 1);
+        if (tid == 0 && post >= 0) __hip_atomic_store(sem + nqt - 1, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     // dK / dV of this workgroup's 128 keys (zeros for a key tile past the last unpadded key)
@@ -1525,13 +1537,13 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
 }
 
 // ---- one-pass backward (hattn_bwd_fused_kernel) ------------------------------------------------------------------------
-// Workspace layout (bytes): [0, 16) four int32 diagnostic counters ([1]: workgroups that found themselves on another XCC
-// than block id % 8; stays 0), [16, 16 + S) the ticket counters, one per (head, 64-query tile) (S from the workspace size
-// alone, so the region does not move with the batch shape and stays all-zero between launches), then the fp32 partial dQ
-// tiles [head][query tile][key tile][4096].
+// Workspace layout (bytes): [0, 16) four int32 diagnostic counters ([0]: hand-offs that timed out, [1]: hand-offs between
+// different XCC ids / workgroups off their XCD; both stay 0), [16, 16 + S) the hand-off flags, one per (head, 64-query
+// tile) (S from the workspace size alone, so the region does not move with the batch shape and stays all-zero between
+// launches), then the fp32 dQ images [head][query tile][4096].
 static size_t hfused_flag_bytes(size_t ws_bytes) { return ((ws_bytes / 4096 + 255) / 256) * 256; }
 size_t ttsmi_hattention_bwd_fused_ws_bytes(int B, int H, int T) {
-    const size_t tiles = (size_t)B * H * ttsmi_cdiv(T, HKT) * ttsmi_cdiv(T, 128);
+    const size_t tiles = (size_t)B * H * ttsmi_cdiv(T, HKT);
     const size_t acc = tiles * 16384;
     return 16 + hfused_flag_bytes(acc + acc / 2048 + 8192) + 512 + acc;
 }
@@ -1540,7 +1552,7 @@ int ttsmi_hattention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_
     if (!on || dh != 64 || B <= 0 || H <= 0 || T <= 0) return 0;
     const size_t flags = hfused_flag_bytes(ws_bytes);
     const size_t qtiles = (size_t)B * H * ttsmi_cdiv(T, HKT);
-    return qtiles * 4 <= flags && 16 + flags + 256 + qtiles * ttsmi_cdiv(T, 128) * 16384 <= ws_bytes;
+    return qtiles * 4 <= flags && 16 + flags + 256 + qtiles * 16384 <= ws_bytes;
 }
 int ttsmi_hattention_bwd_fused_ws_init(void* ws, size_t ws_bytes, hipStream_t st) {
     TTSMI_CHECK_ARG(ws && ws_bytes >= 4096 && (((uintptr_t)ws) & 255) == 0, "attention_bwd_fused_ws_init: workspace missing, < 4096 bytes or not 256-byte aligned");
