@@ -900,8 +900,9 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
 // step): every wave issues its own flag load right after the barrier that starts a step and looks at the value after the
 // two query sub-tiles; the incoming image is requested as soon as the flag is seen, before the barrier that completes the
 // dS image, and added after the dQ product; the outgoing image's acknowledgement is waited for one step later (before the
-// next step's second barrier), where the flag is posted.  A key tile therefore runs about one step behind its
-// predecessor.  Waits are bounded: one that never ends raises diag[0] and the kernel finishes (with a wrong dQ) instead
+// next step's second barrier), where the flag is posted; the barriers inside the loop order LDS only (hlds_barrier: a
+// __syncthreads() drains the vector-memory counter, i.e. waits for exactly those round trips - 203 vs 139 us measured).
+// A key tile therefore runs about one step behind its predecessor.  Waits are bounded: one that never ends raises diag[0] and the kernel finishes (with a wrong dQ) instead
 // of hanging; a workgroup only waits for a LOWER block id of its own XCD.  Flags reset themselves (the last key tile
 // posts 0), so their region only has to be zero once, at allocation (ttsmi_attention_bwd_fused_ws_init).
 // (Also measured: a ticket scheme without any waiting - every key tile stores its own partial image, the last arrival adds
@@ -926,6 +927,10 @@ __device__ __forceinline__ float row16_sum(float v) {          // sum over the 1
     return v;
 }
 #define HFUSED_SPIN_LIMIT (1 << 18)
+// A workgroup barrier that orders LDS accesses only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)): every barrier of a step would then wait for the dQ image stores to be acknowledged, for the
+// incoming image and for the next tile's prefetch - the round trips this kernel keeps in flight across its barriers.
+__device__ __forceinline__ void hlds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int DH, int DROP>
 __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
@@ -1030,7 +1035,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             if (tid < HKT) rl = p.lse[stat0 + min(tid, p.T - 1)];
         }
         for (int q0 = 0, it = 0; q0 < p.T; q0 += HKT, ++it) {
-            __syncthreads();
+            hlds_barrier();                                    // nobody still reads the previous step's Q / dO / dS images
             rq.stash(Qs, tid);
             ro.stash(Os, tid);
             {
@@ -1054,7 +1059,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             // the previous tile's image has reached L2 by now: nothing younger is in flight - this step's prefetches are
             // issued below - so the wait is for stores issued a barrier and a stash ago
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            hlds_barrier();
             if (tid == 0 && post >= 0) {
                 __hip_atomic_store(sem + it - 1, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 post = -1;
@@ -1134,7 +1139,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) in[r] = __hip_atomic_load(acc + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __syncthreads();                                   // the dS image is complete
+            hlds_barrier();                                    // the dS image is complete (the incoming image may still be in flight)
             f32x16 dqa, dqb;                                   // two independent accumulation chains
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dqa[r] = 0.f; dqb[r] = 0.f; }
@@ -1167,7 +1172,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             if (tid == 0) post = chain_last ? 0 : ((bx + 1) | ((int)xid << 8));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        hlds_barrier();
         if (tid == 0 && post >= 0) __hip_atomic_store(sem + nqt - 1, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
