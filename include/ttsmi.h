@@ -141,19 +141,22 @@ int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const in
                                int dtype, ttsmi_stream_t stream);
 /* ONE-PASS backward for TTSMI_BF16_IO tensors at head dim 64 (model/layers.py:176-195 differentiated once): dK, dV and dQ
  * from a single recomputation of S = q.k^T and dP = d(ctx).v^T - 10 T^2 dh of products and one softmax pass where
- * ttsmi_attention_bwd runs two kernels, 14 T^2 dh and two softmax passes.  Key-stationary workgroups; every key tile of a
- * head stores its fp32 partial of a dQ tile in `ws` and draws a ticket, and the workgroup that draws the last ticket adds
- * the partials in a FIXED order (no float atomics, nobody waits for anybody: results are bit-reproducible).  Same results
+ * ttsmi_attention_bwd runs two kernels, 14 T^2 dh and two softmax passes.  Key-stationary workgroups; the running sum of a
+ * dQ tile travels down the key tiles of a head through one fp32 image in `ws` (hand-off flags inside one XCD's L2, a FIXED
+ * order, no float atomics: results are bit-reproducible; waits are bounded).  Same results
  * as ttsmi_attention_bwd / _bwd_masked up to fp32 summation order (dQ is rounded to bf16 once, after the whole sum).
  * dropmask: the keep-bit table of ttsmi_attention_dropmask, or NULL (then seed / step_dev / site drive the hashed dropout
  * as in ttsmi_attention_bwd; p_drop == 0: no dropout).
  *   ws: 256-byte aligned, at least ttsmi_attention_bwd_fused_ws_bytes(B, H, T) bytes, initialised ONCE after allocation
- *       with ttsmi_attention_bwd_fused_ws_init (zeroes the ticket counters: they reset themselves at the end of every
- *       launch, whatever its shape); bytes [4, 8) are an int32 diagnostic counter that stays 0 in a healthy run
- *       (workgroups that ran on another XCC than block id % 8 - the placement that keeps the partials in one L2);
+ *       with ttsmi_attention_bwd_fused_ws_init (zeroes the hand-off flags: they reset themselves at the end of every
+ *       launch, whatever its shape); the first 8 bytes are two int32 diagnostic counters that stay 0 in a healthy run
+ *       ([0] hand-offs that timed out - the kernel then finishes with a wrong dQ instead of hanging -, [1] workgroups /
+ *       hand-offs off the XCC that block id % 8 names - the placement that keeps the image in one L2);
  *   _supported: non-zero when (B, H, T, dh) can run on a workspace of ws_bytes (dh == 64, counters + tiles fit); the
  *       entry point returns TTSMI_ERR_UNSUPPORTED otherwise and the caller uses ttsmi_attention_bwd.
- * TTSMI_ATTN_FUSED_BWD=0 (A/B knob) makes _supported return 0. */
+ * Round-4 status: correct and reproducible, but at the benchmark shape (32, 4, 900, 64) it runs in 222 us against 183 us
+ * for ttsmi_attention_bwd_masked (csrc/attention_bf16.hip has the timeline and the stage ablation), so the dense-block
+ * launcher only uses it with TTSMI_ATTN_FUSED_BWD=1. */
 size_t ttsmi_attention_bwd_fused_ws_bytes(int B, int H, int T);
 int ttsmi_attention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes);
 int ttsmi_attention_bwd_fused_ws_init(void* ws, size_t ws_bytes, ttsmi_stream_t stream);

@@ -46,6 +46,8 @@ struct HAttnP {
     // one-pass backward only (hattn_bwd_fused_kernel): the fp32 partial dQ tiles of the key tiles of a head (a 16 KB register
     // image per (b, h, 64-query tile, key tile)), the ticket counters (`sem`), and the diagnostic counters
     float* dq_acc; int* sem; int* diag;
+    int ablate;                     // measurement build only: 1 = no hand-off waits / incoming image, 2 = no image stores, 4 = no dQ product
+    unsigned long long* dbg;        // measurement build only (-DTTSMI_ABLATION_BUILD): per-workgroup time stamps of the one-pass backward
 };
 
 // DROP template values: 0 = no dropout, 1 = keep decisions hashed in the inner loop (ttsmi_pair_hash), 2 = keep
@@ -905,6 +907,14 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
 // A key tile therefore runs about one step behind its predecessor.  Waits are bounded: one that never ends raises diag[0] and the kernel finishes (with a wrong dQ) instead
 // of hanging; a workgroup only waits for a LOWER block id of its own XCD.  Flags reset themselves (the last key tile
 // posts 0), so their region only has to be zero once, at allocation (ttsmi_attention_bwd_fused_ws_init).
+// STATUS (round 4): correct, bit-reproducible, tested - and NOT faster than the two kernels at the benchmark shape, so it is
+// opt-in (TTSMI_ATTN_FUSED_BWD=1 for the planned dense blocks; the entry point is always available).  Decoder layer, (32, 4,
+// 900, 64), keep-bit dropout: two kernels 183 us, this kernel 222 us.  Its timeline (tools/debug/fused_bwd_timeline.py on
+// a measurement build): key tile 0, which never waits, lives 65 us = 4.2 us per step where the dK/dV kernel takes 2.9;
+// tile j waits 3.5-4 us per link of the chain in total (tile 7: 27 us of its 95).  Stage ablation of the same build
+// (TTSMI_ATTN_FUSED_ABLATE): no hand-offs 147 us, also no image stores 137, also no dQ product 130 - i.e. the best any
+// hand-off scheme could reach is 147 against 183, and the dK/dV core of THIS kernel (third staged tile, in-kernel delta,
+// dS image writes, a third barrier per step) is 124 us where the dedicated kernel is 87.
 // (Also measured: a ticket scheme without any waiting - every key tile stores its own partial image, the last arrival adds
 // them in fixed order - is 40 % SLOWER than the two kernels: 251 MB of partials per decoder layer do not stay in L2.)
 __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* img, int k0, int t, int colblock, int lane) {
@@ -954,6 +964,11 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int grp = xcd + 8 * (slot / nkt), bx = slot % nkt;       // grp = b * H + h; bx = key tile = position in the chain
     if (grp >= p.B * p.H) return;
+#ifdef TTSMI_ABLATION_BUILD
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+    unsigned long long dbg_spin = 0, dbg_first = 0;
+    int dbg_polls = 0;
+#endif
     const int h = grp % p.H, b = grp / p.H;
     const int d = p.H * DH;
     const int key = bx * 128 + wave * 32 + l31;
@@ -964,6 +979,8 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
     const bool wave_live = (bx * 128 + wave * 32) < klen;
     const bool wg_active = bx < nact;
     const bool chain_last = bx == nact - 1;
+    const int abl = TTSMI_ABLATE_BITS(p.ablate);
+    const bool chained = bx > 0 && !(abl & 1);
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
     const float* Vb = eptr<QH>(Qb, 2 * d);
@@ -1066,7 +1083,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             }
             // every wave reads this tile's flag for itself, now; the value is looked at after the sub-tiles
             int flag = 0;
-            if (bx > 0 && !dead) flag = __hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (chained && !dead) flag = __hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (q0 + HKT < p.T) {
                 int nv = min(HKT, p.T - (q0 + HKT));
                 rq.fetch(Qb, p.ld, q0 + HKT, nv, tid);
@@ -1120,10 +1137,13 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             // ---- the chain: key tile bx - 1 must have stored its sum for this query tile (normally seen by the early load)
             float* const acc = acc0 + (long)it * 4096;
             float in[16];
-            if (bx > 0) {
+            if (chained) {
                 if (!dead) {
                     int spins = 0;
                     flag = __builtin_amdgcn_readfirstlane(flag);
+#ifdef TTSMI_ABLATION_BUILD
+                    const unsigned long long dbg_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
                     while ((flag & 0xFF) != bx) {
                         __builtin_amdgcn_s_sleep(1);
                         flag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1135,6 +1155,14 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
                         }
                     }
                     if (!dead && (unsigned)(flag >> 8) != xid && lane == 0) atomicAdd(p.diag + 1, 1);
+#ifdef TTSMI_ABLATION_BUILD
+                    if (wave == 0) {
+                        const unsigned long long dbg_w1 = __builtin_amdgcn_s_memrealtime();
+                        dbg_spin += dbg_w1 - dbg_w0;
+                        dbg_polls += spins;
+                        if (it == 0) dbg_first = dbg_w1 - dbg_t0;
+                    }
+#endif
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) in[r] = __hip_atomic_load(acc + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1143,6 +1171,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             f32x16 dqa, dqb;                                   // two independent accumulation chains
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dqa[r] = 0.f; dqb[r] = 0.f; }
+            if (!(abl & 4))
 #pragma unroll
             for (int kk = 0; kk < 4; kk += 2)
 #pragma unroll
@@ -1152,7 +1181,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
                 }
             float dq[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dq[r] = bx > 0 ? in[r] + (dqa[r] + dqb[r]) : dqa[r] + dqb[r];
+            for (int r = 0; r < 16; ++r) dq[r] = chained ? in[r] + (dqa[r] + dqb[r]) : dqa[r] + dqb[r];
             if (chain_last) {
                 const int q = q0 + qbq * 32 + l31;
                 if (q < p.T) {
@@ -1165,7 +1194,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
                         *reinterpret_cast<uint2*>(dst + 8 * g4) = __builtin_bit_cast(uint2, o4);
                     }
                 }
-            } else {
+            } else if (!(abl & 2)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r * 64] = dq[r];       // plain stores: written through to the XCD's L2
             }
@@ -1183,6 +1212,13 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
     const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH);
     storeT16<DH, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
     storeT16<DH, QH>(patch, dv, DROP ? p.inv_keep : 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
+#ifdef TTSMI_ABLATION_BUILD
+    if (p.dbg && tid == 0) {                 // [block id][8]: start, end, time spent waiting, time to the first hand-off, polls, key tile, head, active
+        unsigned long long* o = p.dbg + (long)blockIdx.x * 8;
+        o[0] = dbg_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = dbg_spin; o[3] = dbg_first;
+        o[4] = (unsigned long long)dbg_polls; o[5] = (unsigned long long)bx; o[6] = (unsigned long long)grp; o[7] = wg_active ? 1 : 0;
+    }
+#endif
 }
 
 // =================================================================================================
@@ -1541,6 +1577,16 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     return TTSMI_OK;
 }
 
+#ifdef TTSMI_ABLATION_BUILD
+static unsigned long long* g_fused_dbg = nullptr;
+static int g_fused_dbg_n = 0;
+extern "C" int ttsmi_debug_fused_dump(unsigned long long* host, int max_blocks) {
+    if (!g_fused_dbg) return 0;
+    const int n = g_fused_dbg_n < max_blocks ? g_fused_dbg_n : max_blocks;
+    if (hipMemcpy(host, g_fused_dbg, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+#endif
 // ---- one-pass backward (hattn_bwd_fused_kernel) ------------------------------------------------------------------------
 // Workspace layout (bytes): [0, 16) four int32 diagnostic counters ([0]: hand-offs that timed out, [1]: hand-offs between
 // different XCC ids / workgroups off their XCD; both stay 0), [16, 16 + S) the hand-off flags, one per (head, 64-query
@@ -1553,8 +1599,7 @@ size_t ttsmi_hattention_bwd_fused_ws_bytes(int B, int H, int T) {
     return 16 + hfused_flag_bytes(acc + acc / 2048 + 8192) + 512 + acc;
 }
 int ttsmi_hattention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes) {
-    TTSMI_KNOB(on, "TTSMI_ATTN_FUSED_BWD", 1);
-    if (!on || dh != 64 || B <= 0 || H <= 0 || T <= 0) return 0;
+    if (dh != 64 || B <= 0 || H <= 0 || T <= 0) return 0;
     const size_t flags = hfused_flag_bytes(ws_bytes);
     const size_t qtiles = (size_t)B * H * ttsmi_cdiv(T, HKT);
     return qtiles * 4 <= flags && 16 + flags + 256 + qtiles * 16384 <= ws_bytes;
@@ -1588,6 +1633,17 @@ int ttsmi_hattention_bwd_fused(const void* qkv, const uint8_t* key_pad, const in
     p.dq_acc = (float*)((char*)ws + 16 + hfused_flag_bytes(ws_bytes) + 240);        // 256-byte aligned
     const int nkt = ttsmi_cdiv(T, 128), groups = B * H;
     dim3 grid(8 * ttsmi_cdiv(groups, 8) * nkt);
+    p.dbg = nullptr;
+    TTSMI_ABLATE_KNOB(fabl, "TTSMI_ATTN_FUSED_ABLATE");      // wrong results by construction: measurement build only
+    p.ablate = fabl;
+#ifdef TTSMI_ABLATION_BUILD
+    {   // measurement build: time stamps of the LAST launch, read back with ttsmi_debug_fused_dump (not in include/ttsmi.h)
+        static unsigned long long* dbuf = nullptr;
+        if (!dbuf && hipMalloc(&dbuf, 8192 * 8 * sizeof(unsigned long long)) != hipSuccess) dbuf = nullptr;
+        if (grid.x <= 8192) p.dbg = dbuf;
+        g_fused_dbg = dbuf; g_fused_dbg_n = (int)grid.x;
+    }
+#endif
     if (p.thr && p.dmask) {
         ttsmi_note_kernel("hattn_bwd_fused_kernel<64, 2>");
         TTSMI_LAUNCH_EV((hattn_bwd_fused_kernel<64, 2>), grid, dim3(256), 0, st, p);

@@ -1672,8 +1672,8 @@ class DenseBlockPlan:
         """Workspace of the one-pass attention backward (ttsmi_attention_bwd_fused: the fp32 partial dQ tiles of a head's
         key tiles + their ticket counters), shared by the blocks of a stack and grown when a batch shape needs more; the
         counter region is zeroed once per allocation and resets itself after every launch.  None: head dim other than 64,
-        or TTSMI_ATTN_FUSED_BWD=0."""
-        if dh != 64 or os.environ.get('TTSMI_ATTN_FUSED_BWD', '1') == '0':
+        or TTSMI_ATTN_FUSED_BWD is not 1 (the default: the two-kernel backward measured faster)."""
+        if dh != 64 or os.environ.get('TTSMI_ATTN_FUSED_BWD', '0') != '1':       # opt-in: not faster than two kernels (round 4)
             return None
         ws = sh.get('attn_fused_ws')
         if ws is None or not l.ttsmi_attention_bwd_fused_supported(B, H, T, dh, ws.numel()):
