@@ -5,19 +5,23 @@ loop (train_tts.py:149-160: set_constants(learning_rate) -> train_step -> ...), 
 rounding of the bf16 path changes where training goes.  Here both precisions start from the same seeded weights and take
 300 Adam steps at the reference's learning rate (1e-4, config/training_config.yaml:129-131) on one fixed ragged batch of
 the benchmarked architecture (BASELINE.json configs[1]: d_model 256, 6+6 dense blocks, 4 heads, FFN 1024), dropout 0 so
-that the two runs see the same function: the bf16 loss must stay within 2 % of the fp32 loss at every 50th step and at
-the end, and both must have learned the batch (final loss below 0.6 x the initial one).  The batch is `learnable_batch`:
-durations, pitch and mel frames are functions of the token ids - the noise targets of the throughput benchmark cannot be
-fitted (a first version of this test on them plateaued at 0.62 x the initial loss in both precisions, at the noise's mean
-absolute deviation; so did 1e-3 on this batch: a 12-block post-LayerNorm stack without warm-up only learns the biases at
-that rate.  The torch-CPU oracle at this architecture and rate goes 9.9 -> 0.85 in 300 steps).
-A single step's loss wiggles by a few per cent around the trend, and the curve has spikes (Adam at a constant rate on a
-post-LayerNorm stack without warm-up): two trajectories that differ by ONE rounding error separate and then wiggle and
-spike independently.  So (i) each checkpoint compares the MEAN over the 10 steps around it, and (ii) the test measures
-how far two exact-fp32 runs drift apart when the initial weights of one are perturbed by one part in 10^7 (the "chaos
-floor" of this batch and rate) and holds bf16 to max(2 %, twice that floor): measured on the first version of this test,
-bf16 and fp32 window means agreed to 0.3-1.6 % except around a loss spike near step 100 (20 %) that the two runs took at
-different steps.  The raw values are printed beside the window means."""
+that the runs see the same function.  The batch is `learnable_batch`: durations, pitch and mel frames are functions of the
+token ids - the noise targets of the throughput benchmark cannot be fitted (a first version of this test on them
+plateaued at 0.62 x the initial loss in both precisions, at the noise's mean absolute deviation; so did 1e-3 on this
+batch: a 12-block post-LayerNorm stack without warm-up only learns the biases at that rate).
+
+What can be asked of two such trajectories.  The loss falls 10.4 -> 1.0, with spikes (Adam at a constant rate, no
+warm-up): once two runs differ by ONE rounding error they take their spikes at different steps.  The test therefore
+measures that sensitivity itself - a THIRD run, exact fp32 again, from weights perturbed by one part in 10^7 - and
+compares means over blocks of 50 steps.  Measured (round 4): fp32 vs perturbed fp32 differ by 1.0 / 3.4 / 1.7 / 4.6 /
+3.1 % in the five blocks after the first, bf16 vs fp32 by 4.1 / 6.8 / 1.9 / 6.5 / 3.3 %; a pointwise "within 2 % at every
+50th step" holds for neither pair (10-step window means: fp32 pair up to 3.5 %, bf16 up to 20 % at a spike near step
+100), while the first block - before the runs have separated - agrees to 0.5 %, the mean over steps 50..300 to 1.4 %
+(fp32 pair 0.4 %) and the last 100 steps to 5.0 % (fp32 pair 4.0 %).  Asserted:
+  * every run ends below 0.6 x its initial loss (they end near 0.1 x);
+  * block 0 (steps 0..49) within 2 %;
+  * every later 50-step block within max(2 %, twice the worst fp32-vs-perturbed-fp32 block);
+  * the mean loss over steps 50..299 within 3 %."""
 import json
 import os
 
@@ -30,7 +34,7 @@ from oracle import ft_oracle as fo
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-STEPS, EVERY, WINDOW = 300, 50, 10
+STEPS, BLOCK = 300, 50
 LR = float(os.environ.get('TTSMI_CURVE_LR', '1e-4'))          # (measurement knob: the curve at another learning rate)
 
 
@@ -49,15 +53,6 @@ def _curve(precision, cfg, W, batch):
     return np.array([float(x) for x in losses])
 
 
-def _checkpoints(curve):
-    """(raw loss, mean over the WINDOW steps around it) at steps 0, EVERY, 2 EVERY, .. and the last one"""
-    out = []
-    for k in list(range(0, STEPS, EVERY)) + [STEPS - 1]:
-        lo = max(0, min(k - WINDOW // 2, STEPS - WINDOW))
-        out.append((float(curve[k]), float(curve[lo:lo + WINDOW].mean())))
-    return out
-
-
 def test_bf16_training_curve_tracks_fp32_over_300_steps():
     from transformertts_amd.utils.synthetic import learnable_batch
     cfg = dict(fo.make_config(), dropout_rate=0.0, predictors_dropout=0.0)
@@ -68,22 +63,26 @@ def test_bf16_training_curve_tracks_fp32_over_300_steps():
     rng = np.random.default_rng(1)
     Wp = {k: (np.asarray(v) * (1.0 + 1e-7 * rng.standard_normal(np.shape(v)))).astype(np.float32) for k, v in W.items()}
     f32p = _curve('f32', cfg, Wp, batch)                        # the same precision, weights off by one part in 10^7
-    cf, cb, cp = _checkpoints(f32), _checkpoints(bf16), _checkpoints(f32p)
-    rel_raw = [abs(a[0] - b[0]) / b[0] for a, b in zip(cb, cf)]
-    rel = [abs(a[1] - b[1]) / b[1] for a, b in zip(cb, cf)]
-    floor = [abs(a[1] - b[1]) / b[1] for a, b in zip(cp, cf)]
-    line = {'steps': STEPS, 'every': EVERY, 'window': WINDOW, 'lr': LR, 'f32': [c[0] for c in cf], 'bf16': [c[0] for c in cb],
-            'f32_window_mean': [c[1] for c in cf], 'bf16_window_mean': [c[1] for c in cb],
-            'f32_perturbed_window_mean': [c[1] for c in cp], 'rel_raw': rel_raw, 'rel': rel, 'chaos_floor': floor}
+    blocks = lambda c: c.reshape(STEPS // BLOCK, BLOCK).mean(axis=1)
+    bf, bb, bp = blocks(f32), blocks(bf16), blocks(f32p)
+    rel = np.abs(bb - bf) / bf
+    floor = np.abs(bp - bf) / bf
+    mean_rel = abs(bf16[BLOCK:].mean() - f32[BLOCK:].mean()) / f32[BLOCK:].mean()
+    mean_floor = abs(f32p[BLOCK:].mean() - f32[BLOCK:].mean()) / f32[BLOCK:].mean()
+    line = {'steps': STEPS, 'block': BLOCK, 'lr': LR, 'f32_block_means': bf.tolist(), 'bf16_block_means': bb.tolist(),
+            'f32_perturbed_block_means': bp.tolist(), 'bf16_vs_f32': rel.tolist(), 'f32_perturbed_vs_f32': floor.tolist(),
+            'mean_loss_steps_50_299': {'f32': float(f32[BLOCK:].mean()), 'bf16': float(bf16[BLOCK:].mean()),
+                                       'f32_perturbed': float(f32p[BLOCK:].mean()), 'bf16_vs_f32': mean_rel,
+                                       'f32_perturbed_vs_f32': mean_floor},
+            'every_50th_step': {'f32': f32[::BLOCK].tolist() + [float(f32[-1])], 'bf16': bf16[::BLOCK].tolist() + [float(bf16[-1])]}}
     print('\nbf16 vs f32 training curve', json.dumps(line))
     d = os.path.join(os.path.dirname(HERE), 'gpurun_out')
     if os.path.isdir(d):
         with open(os.path.join(d, 'bf16_vs_f32_curve.json'), 'w') as f:
             json.dump(dict(line, f32_curve=f32.tolist(), bf16_curve=bf16.tolist(), f32_perturbed_curve=f32p.tolist()), f)
-    assert np.isfinite(f32).all() and np.isfinite(bf16).all()
-    assert f32[-WINDOW:].mean() < 0.6 * f32[0] and bf16[-WINDOW:].mean() < 0.6 * bf16[0], (cf, cb)
-    bound = max(2e-2, 2.0 * max(floor))
-    assert max(rel) < bound, (rel, floor, rel_raw)
-    # and over the whole run: the mean loss of the last 100 steps (spikes average out) within 3 %
-    tail = abs(bf16[-100:].mean() - f32[-100:].mean()) / f32[-100:].mean()
-    assert tail < max(3e-2, 2.0 * abs(f32p[-100:].mean() - f32[-100:].mean()) / f32[-100:].mean()), tail
+    for c in (f32, bf16, f32p):
+        assert np.isfinite(c).all()
+        assert c[-BLOCK:].mean() < 0.6 * c[0], (c[0], c[-BLOCK:].mean())
+    assert rel[0] < 2e-2, rel
+    assert rel[1:].max() < max(2e-2, 2.0 * floor[1:].max()), (rel, floor)
+    assert mean_rel < 3e-2, (mean_rel, mean_floor)
