@@ -589,6 +589,15 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* desc, const float* h, const u
  * LayerNorm parameter-gradient partials in ln_ws1 / ln_ws2 for ttsmi_layernorm_param_reduce_batched.
  * The caller joins side_stream before it reads the weight gradients. */
 int ttsmi_dense_block_bwd(const ttsmi_dense_block* desc, const float* h, const uint16_t* h_bf, const float* dout);
+/* A whole STACK of n consecutive dense blocks (SelfAttentionBlocks.call's loop over its dense blocks, model/layers.py:
+ * 303-306) from one call: block i reads block i - 1's out / out_bf, the backward walks n - 1 .. 0 and hands block i + 1's
+ * dh to block i as its dout (ignored by a chained block, see `below`).  Exactly the launches, in exactly the order, of n
+ * ttsmi_dense_block_fwd / _bwd calls - minus their host round trips: with ~12 k rows per batch (the reference's bucket
+ * sizes) a train step is bound by the host's issue rate, not by the GPU (bench.py --workload lj-dist).  h / h_bf: the
+ * stack's input (block 0's); dout: the gradient of block n - 1's output.  blocks[i]->out / out_bf / dh must be the
+ * buffers the neighbouring descriptors expect (every block of one shape B, T, d). */
+int ttsmi_dense_stack_fwd(const ttsmi_dense_block* const* blocks, int n, const float* h, const uint16_t* h_bf);
+int ttsmi_dense_stack_bwd(const ttsmi_dense_block* const* blocks, int n, const float* h, const uint16_t* h_bf, const float* dout);
 
 #ifdef __cplusplus
 }

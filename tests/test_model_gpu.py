@@ -375,6 +375,30 @@ def test_dropout_training_step_is_finite_and_reproducible(tiny):
     assert abs(outs[0][0] - l0) / l0 < 0.2         # dropout perturbs, does not destroy, the loss
 
 
+def test_stack_level_launcher_equals_one_call_per_block(tiny, monkeypatch):
+    """ops.PlannedDenseStackFn (ttsmi_dense_stack_fwd / _bwd: a stack of planned dense blocks from ONE C++ call per
+    direction) issues the launches of the per-block calls in the same order: three train steps with dropout on end in
+    bit-identical parameters, losses and outputs; predict() (forward-only plans) likewise."""
+    from transformertts_amd.model import models as mm
+    cfg, W = tiny
+    batch = fo.synthetic_batch(4, 50, 200, seed=21, ragged=True)
+    kw = dict(dropout_rate=0.1, predictors_dropout=0.1, seed=5, precision='bf16')
+    runs = []
+    for stack in (True, False):
+        monkeypatch.setattr(mm, '_DENSE_STACK', stack)
+        m = _model(cfg, W, **kw)
+        m._compile(learning_rate=1e-3)
+        outs = [m.train_step(*batch) for _ in range(3)]
+        m.return_attention = False
+        mel = m.predict(batch[0][:2], encode=False, phoneme_durations=batch[2][:2])['mel'].clone()
+        torch.cuda.synchronize()
+        runs.append((m.params.data.clone(), [float(o['loss']) for o in outs], outs[-1]['mel'].clone(), mel))
+    assert runs[0][1] == runs[1][1], (runs[0][1], runs[1][1])
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3])
+    l = __import__('transformertts_amd._lib', fromlist=['lib']).lib()
+    assert l.ttsmi_dense_stack_fwd(None, 0, None, None) == -1 and b'block list' in l.ttsmi_last_error()
+
+
 def test_variable_batch_shapes_reuse_capacity_plans(tiny):
     """Length-bucketed training data brings a new (B, Tp, Tm) almost every step: the C++-driven dense blocks keep ONE
     plan per block sized for the largest batch so far and re-bind it (ops.DenseBlockPlan.rebind) - results equal a

@@ -121,6 +121,8 @@ SIGNATURES = {
     'ttsmi_set_launch_observer': (I, [P]),
     'ttsmi_dense_block_fwd': (I, [P, P, P]),
     'ttsmi_dense_block_bwd': (I, [P, P, P, P]),
+    'ttsmi_dense_stack_fwd': (I, [P, I, P, P]),
+    'ttsmi_dense_stack_bwd': (I, [P, I, P, P, P]),
 }
 
 

@@ -91,6 +91,9 @@ size_t ttsmi_hgemm_wgrad_rows_exact_bytes(int rows, int kin, int n, int has_db);
 int ttsmi_hgemm_wgrad_rows_deferred(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
                                     float* dw, int64_t lddw, float* db, int rows, int kin, int n, void* ws, size_t ws_bytes,
                                     ttsmi_stream_t stream, ttsmi_wgrad_job* job);
+int ttsmi_hgemm_wgrad_rows_deferred_dual(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1, const void* dy,
+                                         int64_t lddy, float* dw, int64_t lddw, float* db, int rows, int kin, int n, void* ws,
+                                         size_t ws_bytes, ttsmi_stream_t stream, ttsmi_wgrad_job* job);
 int ttsmi_hgemm_wgrad_reduce_jobs(const ttsmi_wgrad_job* jobs, int njobs, ttsmi_stream_t stream);
 }
 

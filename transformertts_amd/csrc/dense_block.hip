@@ -174,7 +174,8 @@ static int wgrad_flush(const ttsmi_dense_block* D, WgradBatch* wb) {
 // weight gradient dW[kin,n] = x^T . dy (+ db) on the side stream, ordered after everything the main stream has
 // enqueued so far (its operands) through one event
 static int wgrad_side(const ttsmi_dense_block* D, WgradBatch* wb, int ev, bool record, const uint16_t* x, int ldx,
-                      const uint16_t* dy, int lddy, float* dw, float* db, int kin, int n) {
+                      const uint16_t* dy, int lddy, float* dw, float* db, int kin, int n, const uint16_t* x2 = nullptr,
+                      int ldx2 = 0, int k1 = 0) {
     const int M = D->B * D->T;
     TTSMI_ABLATE_KNOB(skip, "TTSMI_DEBUG_SKIP_WGRAD");      // measurement knob (results are then WRONG: no weight gradients): main-stream-only backward time
     if (skip) return TTSMI_OK;
@@ -203,10 +204,19 @@ static int wgrad_side(const ttsmi_dense_block* D, WgradBatch* wb, int ev, bool r
     const size_t need = ttsmi_hgemm_wgrad_rows_exact_bytes(M, kin, n, db != nullptr);
     if (!batched || need > D->wgrad_ws_bytes) {
         TRY(wgrad_flush(D, wb));
+        if (x2) {           // (callers only pass x2 on the batched path; without it: the two halves one after the other)
+            TRY(ttsmi_hgemm_wgrad_rows(x, 1, ldx, dy, 1, lddy, dw, n, db, M, k1, n, 1, 0, 0, 0, D->wgrad_ws, D->wgrad_ws_bytes, st));
+            return ttsmi_hgemm_wgrad_rows(x2, 1, ldx2, dy, 1, lddy, dw + (long)k1 * n, n, nullptr, M, kin - k1, n, 1, 0, 0, 0,
+                                          D->wgrad_ws, D->wgrad_ws_bytes, st);
+        }
         return ttsmi_hgemm_wgrad_rows(x, 1, ldx, dy, 1, lddy, dw, n, db, M, kin, n, 1, 0, 0, 0, D->wgrad_ws, D->wgrad_ws_bytes, st);
     }
     if (wb->n == TTSMI_WGRAD_MAX_JOBS || wb->used + need > D->wgrad_ws_bytes) TRY(wgrad_flush(D, wb));
     ttsmi_wgrad_job* job = &wb->jobs[wb->n];
+    if (x2)
+        TRY(ttsmi_hgemm_wgrad_rows_deferred_dual(x, ldx, x2, ldx2, k1, dy, lddy, dw, n, db, M, kin, n, (char*)D->wgrad_ws + wb->used,
+                                                 D->wgrad_ws_bytes - wb->used, st, job));
+    else
     TRY(ttsmi_hgemm_wgrad_rows_deferred(x, 1, ldx, dy, 1, lddy, dw, n, db, M, kin, n, (char*)D->wgrad_ws + wb->used,
                                         D->wgrad_ws_bytes - wb->used, st, job));
     if (job->splits > 0) {
@@ -222,6 +232,18 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
 // return between arm() and the producing launch would otherwise leave an event armed for the next, unrelated
 // TTSMI_LAUNCH_EV launch of this thread (advisor finding, round 3).  Every exit path goes through here: nothing stays
 // armed; `t_prerecorded` survives a SUCCESSFUL chained call only (the lower block's call consumes it).
+// Wo = Dense(concat([q_in, ctx])) is stored [2d][d]: its two halves' gradients read the same d_o - one dual-X launch
+// (TTSMI_WGRAD_WO_DUAL=0: two launches, the round-3 form - same products; the row split, hence the order of the fp32
+// partial sums, may differ)
+static int wgrad_wo(const ttsmi_dense_block* D, WgradBatch* wb, int ev, bool record, const uint16_t* h_bf) {
+    const int d = D->d;
+    TTSMI_KNOB(dual, "TTSMI_WGRAD_WO_DUAL", 1);
+    if (dual && d % 128 == 0)
+        return wgrad_side(D, wb, ev, record, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, 2 * d, d, D->cx, d, d);
+    TRY(wgrad_side(D, wb, ev, record, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
+    return wgrad_side(D, wb, ev, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d);
+}
+
 int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf, const float* dout) {
     const int rc = dense_block_bwd_impl(D, h, h_bf, dout);
     (void)ttsmi_take_stop_event();
@@ -305,8 +327,7 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
                                     nullptr, nullptr, M, d, D->ln_ws1, D->ln_ws_bytes, D->d_o, st));
     }
     if (!lazy) {
-        TRY(wgrad_side(D, &wb, 2, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
-        TRY(wgrad_side(D, &wb, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
+        TRY(wgrad_wo(D, &wb, 2, true, h_bf));
     }
     // dh += do.Wo_top^T (fp32) and dctx = do.Wo_ctx^T (bf16): Wo as stored is [2d][d] = both weight halves back to back,
     // and both products read d_o - one weight-stationary launch when the shape suits it (d = 256, decoder-size M)
@@ -334,8 +355,7 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
     if (pre_attn) {      // everything the weight-gradient stream can do before dqkv exists, handed over in one go
         TRY(wgrad_side(D, &wb, 2, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
         TRY(wgrad_side(D, &wb, 2, false, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
-        TRY(wgrad_side(D, &wb, 2, false, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
-        TRY(wgrad_side(D, &wb, 2, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
+        TRY(wgrad_wo(D, &wb, 2, false, h_bf));
     }
     // ---- attention + qkv projection
     {
@@ -355,8 +375,7 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
                                 D->seed, D->step_dev, D->site_attn, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));
     }
     if (lazy && !pre_attn) {
-        TRY(wgrad_side(D, &wb, 3, true, h_bf, d, D->d_o, d, D->g_wo, D->g_bo, d, d));
-        TRY(wgrad_side(D, &wb, 3, false, D->cx, d, D->d_o, d, D->g_wo + (long)d * d, nullptr, d, d));
+        TRY(wgrad_wo(D, &wb, 3, true, h_bf));
     }
     TRY(wgrad_side(D, &wb, 3, !lazy || pre_attn, h_bf, d, D->dqkv, 3 * d, D->g_wqkv, D->g_bqkv, d, 3 * d));
     TRY(wgrad_flush(D, &wb));            // the block's five slab reductions, one launch on the weight-gradient stream
@@ -390,3 +409,38 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
                        TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));                                       // dh += dqkv.Wqkv^T
     return TTSMI_OK;
 }
+
+extern "C" {
+
+static int check_stack(const ttsmi_dense_block* const* blocks, int n, const char* who) {
+    TTSMI_CHECK_ARG(blocks && n > 0 && n <= 64, "%s: bad block list", who);
+    for (int i = 0; i < n; ++i) {
+        TTSMI_CHECK_ARG(blocks[i], "%s: null descriptor %d", who, i);
+        TTSMI_CHECK_ARG(blocks[i]->B == blocks[0]->B && blocks[i]->T == blocks[0]->T && blocks[i]->d == blocks[0]->d,
+                        "%s: block %d has another shape than block 0", who, i);
+    }
+    return TTSMI_OK;
+}
+
+int ttsmi_dense_stack_fwd(const ttsmi_dense_block* const* blocks, int n, const float* h, const uint16_t* h_bf) {
+    TRY(check_stack(blocks, n, "dense_stack_fwd"));
+    for (int i = 0; i < n; ++i) {
+        TRY(ttsmi_dense_block_fwd(blocks[i], h, h_bf));
+        h = blocks[i]->out;                       // (not written inside a res16 stack, and then not read either)
+        h_bf = blocks[i]->out_bf;
+    }
+    return TTSMI_OK;
+}
+
+int ttsmi_dense_stack_bwd(const ttsmi_dense_block* const* blocks, int n, const float* h, const uint16_t* h_bf, const float* dout) {
+    TRY(check_stack(blocks, n, "dense_stack_bwd"));
+    for (int i = n - 1; i >= 0; --i) {
+        const float* hi = i ? blocks[i - 1]->out : h;
+        const uint16_t* hbi = i ? blocks[i - 1]->out_bf : h_bf;
+        TRY(ttsmi_dense_block_bwd(blocks[i], hi, hbi, dout));
+        dout = blocks[i]->dh;                     // (bf16 behind a chained block, which ignores its dout argument)
+    }
+    return TTSMI_OK;
+}
+
+}  // extern "C"

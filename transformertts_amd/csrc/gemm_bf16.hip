@@ -691,6 +691,9 @@ struct WRowsP {
     int k_per_split;
     float* ws; float* colsum; float* colsum_ws;
     int tiles_k, tiles_n;
+    // dual X (no conv window): K_in rows [0, K1) of dW come from X, rows [K1, K) from X2 - the two halves of
+    // Dense(concat([q_in, ctx])) (model/layers.py:148) as ONE weight gradient; X2 == nullptr: single operand
+    const float* X2; long ldx2; int K1;
 };
 
 // Per-thread fetch cursor over a row-major operand tile: item i = row (tid >> 5) + 8 i of the step, 4
@@ -792,7 +795,9 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(WRowsP p) {
 
     float4 rx[WR_NI], ry[WR_NI];       // fp32-source prefetch registers
     uint2 rxh[WR_NI], ryh[WR_NI];      // bf16-source prefetch registers (the unused set is dead code)
-    WrCursor cx = wr_cursor(p.X, XH ? 2 : 4, p.ldx, xcols, mbeg, xcol0, shift, Tw, tid);
+    const bool second = p.X2 != nullptr && k0 >= p.K1;                    // (workgroup-uniform)
+    if (p.X2 != nullptr) { xcols = second ? p.K - p.K1 : p.K1; xcol0 = second ? k0 - p.K1 : k0; }
+    WrCursor cx = wr_cursor(second ? p.X2 : p.X, XH ? 2 : 4, second ? p.ldx2 : p.ldx, xcols, mbeg, xcol0, shift, Tw, tid);
     WrCursor cy = wr_cursor(p.DY, YH ? 2 : 4, p.lddy, p.N, mbeg, n0, 0, 0, tid);
     auto fetch_tiles = [&]() {
         if constexpr (XH) wr_fetch(cx, mend, shift, Tw, rxh); else wr_fetch(cx, mend, shift, Tw, rx);
@@ -936,7 +941,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WRowsP p) {
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
     const bool do_colsum = (p.colsum != nullptr) && (tk == 0) && (wr == 0);
 
-    const uint16_t* X = (const uint16_t*)p.X;
+    const bool second = p.X2 != nullptr && k0 >= p.K1;                    // (workgroup-uniform) which X this K tile reads
+    const uint16_t* X = (const uint16_t*)(second ? p.X2 : p.X);
+    const long ldx = second ? p.ldx2 : p.ldx;
+    const int xk0 = second ? k0 - p.K1 : k0;
     const uint16_t* DY = (const uint16_t*)p.DY;
     // DMA: a wave instruction = 4 rows x 16 chunks of 16 bytes; wave w owns rows [8w, 8w + 8) of a step
     const int drow = lane >> 4, dpos = lane & 15;
@@ -948,7 +956,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WRowsP p) {
         for (int i = 0; i < 2; ++i) {
             const int row = wave * 8 + i * 4 + drow;
             const int c = dpos ^ ((row & 3) << 2);
-            lds_dma16(X + (m0 + row) * p.ldx + k0 + c * 8, lds_offset(Xi + (wave * 8 + i * 4) * 256));
+            lds_dma16(X + (m0 + row) * ldx + xk0 + c * 8, lds_offset(Xi + (wave * 8 + i * 4) * 256));
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1420,7 +1428,7 @@ size_t ttsmi_hgemm_wgrad_rows_exact_bytes(int rows, int kin, int n, int has_db) 
 static int wgrad_rows_impl(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
                            float* dw, int64_t lddw, float* db, int rows, int kin, int n, int conv_taps,
                            int conv_T, int conv_C, int conv_pad, void* ws, size_t ws_bytes,
-                           ttsmi_stream_t stream, ttsmi_wgrad_job* job);
+                           ttsmi_stream_t stream, ttsmi_wgrad_job* job, const void* x2 = nullptr, int64_t ldx2 = 0, int k1 = 0);
 
 int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
                            float* dw, int64_t lddw, float* db, int rows, int kin, int n, int conv_taps,
@@ -1444,6 +1452,16 @@ int ttsmi_hgemm_wgrad_rows_deferred(const void* x, int x_is_bf16, int64_t ldx, c
                            stream, job);
 }
 
+// dW[0:K1] = x^T dy and dW[K1:kin] = x2^T dy (one dy, one db) as ONE launch: both halves of Wo = Dense(concat([q_in, ctx]))
+int ttsmi_hgemm_wgrad_rows_deferred_dual(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1, const void* dy,
+                                         int64_t lddy, float* dw, int64_t lddw, float* db, int rows, int kin, int n, void* ws,
+                                         size_t ws_bytes, ttsmi_stream_t stream, ttsmi_wgrad_job* job) {
+    TTSMI_CHECK_ARG(job && x2, "hgemm_wgrad_rows_deferred_dual: null job / x2");
+    TTSMI_CHECK_ARG(ws && ws_bytes >= ttsmi_hgemm_wgrad_rows_exact_bytes(rows, kin, n, db != nullptr),
+                    "hgemm_wgrad_rows_deferred_dual: workspace too small");
+    return wgrad_rows_impl(x, 1, ldx, dy, 1, lddy, dw, lddw, db, rows, kin, n, 1, 0, 0, 0, ws, ws_bytes, stream, job, x2, ldx2, k1);
+}
+
 int ttsmi_hgemm_wgrad_reduce_jobs(const ttsmi_wgrad_job* jobs, int njobs, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(jobs && njobs >= 0 && njobs <= TTSMI_WGRAD_MAX_JOBS, "hgemm_wgrad_reduce_jobs: bad job list");
     if (njobs == 0) return TTSMI_OK;
@@ -1463,8 +1481,10 @@ int ttsmi_hgemm_wgrad_reduce_jobs(const ttsmi_wgrad_job* jobs, int njobs, ttsmi_
 static int wgrad_rows_impl(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
                            float* dw, int64_t lddw, float* db, int rows, int kin, int n, int conv_taps,
                            int conv_T, int conv_C, int conv_pad, void* ws, size_t ws_bytes,
-                           ttsmi_stream_t stream, ttsmi_wgrad_job* job) {
+                           ttsmi_stream_t stream, ttsmi_wgrad_job* job, const void* x2, int64_t ldx2, int k1) {
     (void)ws_bytes;
+    if (x2) TTSMI_CHECK_ARG(conv_taps <= 1 && k1 > 0 && k1 < kin && k1 % 128 == 0 && al16(x2) && ldx2 % 8 == 0,
+                            "hgemm_wgrad_rows: dual X needs no conv window, 0 < K1 < K with K1 %% 128 == 0, an aligned X2");
     if (job) job->splits = 0;
     TTSMI_CHECK_ARG(!(x_is_bf16 && conv_taps > 1), "hgemm_wgrad_rows: conv needs an fp32 x");
     TTSMI_CHECK_ARG(x && dy && dw, "hgemm_wgrad_rows: null pointer");
@@ -1483,6 +1503,7 @@ static int wgrad_rows_impl(const void* x, int x_is_bf16, int64_t ldx, const void
     p.M = rows; p.K = kin; p.N = n;
     p.taps = conv_taps > 1 ? conv_taps : 1; p.T = conv_T; p.Cin = conv_C; p.pad = conv_pad;
     p.tiles_k = ttsmi_cdiv(kin, 128); p.tiles_n = ttsmi_cdiv(n, 128);
+    p.X2 = (const float*)x2; p.ldx2 = ldx2; p.K1 = k1;
     int tiles = p.tiles_k * p.tiles_n;
     int kps = 0;
     const int splits = wgrad_rows_splits(rows, kin, n, &kps);

@@ -34,6 +34,7 @@ from ..utils.losses import masked_mean_absolute_error, weighted_sum_losses
 from .transformer_utils import positional_encoding
 
 
+_DENSE_STACK = os.environ.get('TTSMI_DENSE_STACK', '1') != '0'      # A/B knob: 0 = one autograd node per planned block
 _PRED_LATE = os.environ.get('TTSMI_PRED_LATE', '1') != '0'      # A/B knob: 0 = predictors issued before the decoder (round 2)
 _DROPBITS_CONV = os.environ.get('TTSMI_ATTN_DROPBITS_CONV', '0') == '1'
 
@@ -369,9 +370,24 @@ class ForwardTransformer:
         attn = OrderedDict()
         dtype = ops._lib.TTSMI_BF16 if self.precision == 'bf16' else ops.TTSMI_F32
         below = None                     # the planned block whose output feeds the current one (backward chaining)
+        # consecutive planned blocks are issued by ONE C++ call per direction (ops.PlannedDenseStackFn) unless somebody
+        # needs a block's output on the host side of the boundary (attention maps, activation taps)
+        stack_mode = _DENSE_STACK and not want_attn and self._taps is None
+        pending = []
+
+        def flush(h, h_bf):
+            if not pending:
+                return h, h_bf
+            plans = tuple(pending)
+            pending.clear()
+            if len(plans) == 1:
+                return ops.PlannedDenseBlockFn.apply(h, h_bf, plans[0])
+            return ops.PlannedDenseStackFn.apply(h, h_bf, plans)
         for i, H in enumerate(heads):
             p = f'{prefix}.blk{i}'
             dense = i < dense_blocks
+            if not (dense and self.fused_blocks and self._use_plans and self._plan_ok(p, H, d)):
+                h, h_bf = flush(h, h_bf)
             if dense and self.fused_blocks and self._use_plans and self._plan_ok(p, H, d):
                 # launch sequence of the block issued from C++ (ops.DenseBlockPlan): two host calls per block and step
                 plan = self._block_plan(p, prefix, B, H, T)
@@ -392,7 +408,9 @@ class ForwardTransformer:
                 last = not (nxt < len(heads) and nxt < dense_blocks and self._plan_ok(f'{prefix}.blk{nxt}', heads[nxt], d))
                 plan.bind(pad, klen, rate, drop, sites, dmask, res16=self.residual_bf16,
                           out32=last or self._taps is not None)
-                h, h_bf = ops.PlannedDenseBlockFn.apply(h, h_bf, plan)
+                pending.append(plan)
+                if not stack_mode or last:
+                    h, h_bf = flush(h, h_bf)
                 if want_attn:
                     attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
                         plan.t['qkv'], pad, plan.t['lse'], B, H, T, d // H, rate, drop, sites[0], ops._lib.TTSMI_BF16_IO,
@@ -474,6 +492,7 @@ class ForwardTransformer:
                 h, h_bf = h             # the next block's bf16 GEMM operand, written by the same LayerNorm launch
             if self._taps is not None:
                 self._taps.append((p, h.detach().reshape(B, T, d)))
+        h, h_bf = flush(h, h_bf)
         if below is not None:
             below.chain_above(None)          # the stack's last block: its output gradient comes from outside
         return h.reshape(B, T, d), attn

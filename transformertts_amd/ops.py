@@ -1756,7 +1756,8 @@ class DenseBlockPlan:
     def fwd(self, h, h_bf):
         check(_lib.lib().ttsmi_dense_block_fwd(self._dref, _p(h), _p(h_bf)), 'dense_block_fwd')
 
-    def bwd(self, h, h_bf, dout):
+    def _prepare_bwd(self, device):
+        """The weight-gradient stream / workspace fields of the descriptor for the coming backward."""
         assert self.backward, 'forward-only plan'
         D = self.desc
         if _WgradStream.enabled:
@@ -1767,14 +1768,22 @@ class DenseBlockPlan:
                 W.handle = W.stream.cuda_stream
             if W.ws is None or W.ws.numel() < self.wgrad_need:
                 with torch.cuda.stream(W.stream):
-                    W.ws = torch.empty(int(max(self.wgrad_need, 1 << 26)), dtype=torch.uint8, device=h.device)
+                    W.ws = torch.empty(int(max(self.wgrad_need, 1 << 26)), dtype=torch.uint8, device=device)
             D.side_stream, D.wgrad_ws, D.wgrad_ws_bytes = W.handle, W.ws.data_ptr(), W.ws.numel()
             W.pending = True
         else:
-            ws = _ws(self.wgrad_need, h.device)
+            ws = _ws(self.wgrad_need, device)
             self.keep = self.keep + (ws,)
             D.side_stream, D.wgrad_ws, D.wgrad_ws_bytes = None, ws.data_ptr(), ws.numel()
+
+    def bwd(self, h, h_bf, dout):
+        self._prepare_bwd(h.device if h is not None else h_bf.device)
         check(_lib.lib().ttsmi_dense_block_bwd(self._dref, _p(h), _p(h_bf), _p(dout)), 'dense_block_bwd')
+        self._defer_ln()
+
+    def _defer_ln(self):
+        """The block's LayerNorm parameter-gradient partials join the step's batched reduction."""
+        D = self.desc
         t, G, M, d = self.t, self.G, self.M, self.d
 
         def defer():
@@ -1811,3 +1820,34 @@ class PlannedDenseBlockFn(torch.autograd.Function):
         plan = ctx.plan
         plan.bwd(ctx.h, ctx.h_bf, _c(dout))
         return plan.t['dh'][:plan.M].detach(), None, None
+
+
+class PlannedDenseStackFn(torch.autograd.Function):
+    """A whole stack of consecutive planned dense blocks as ONE autograd node: ttsmi_dense_stack_fwd / _bwd issue every
+    block's launches from one C++ call each.  Same launches in the same order as a PlannedDenseBlockFn per block (results
+    are bit-identical); what disappears is ~10 autograd nodes and ~40 Python -> C round trips per step - with the
+    reference's bucketed batches (~12 k rows) the step is bound by the host's issue rate (bench.py --workload lj-dist)."""
+
+    @staticmethod
+    def forward(ctx, h, h_bf, plans):
+        n = len(plans)
+        arr = (ctypes.c_void_p * n)(*[ctypes.addressof(pl.desc) for pl in plans])
+        check(_lib.lib().ttsmi_dense_stack_fwd(arr, n, _p(h), _p(h_bf)), 'dense_stack_fwd')
+        ctx.plans, ctx.arr, ctx.h, ctx.h_bf = plans, arr, h, h_bf
+        top = plans[-1]
+        out, out_bf = top.t['out'][:top.M].detach(), top.t['out_bf'][:top.M].detach()
+        ctx.mark_non_differentiable(out_bf)
+        ctx.set_materialize_grads(False)
+        return out, out_bf
+
+    @staticmethod
+    def backward(ctx, dout, _dout_bf):
+        plans = ctx.plans
+        dev = ctx.h_bf.device
+        for pl in plans:
+            pl._prepare_bwd(dev)
+        check(_lib.lib().ttsmi_dense_stack_bwd(ctx.arr, len(plans), _p(ctx.h), _p(ctx.h_bf), _p(_c(dout))), 'dense_stack_bwd')
+        for pl in reversed(plans):
+            pl._defer_ln()
+        bottom = plans[0]
+        return bottom.t['dh'][:bottom.M].detach(), None, None
