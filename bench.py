@@ -198,9 +198,11 @@ def instrumented_step(step_fn):
 
     def hook(name, args, fn):
         if (name.endswith('_bytes') or name.endswith('_nparts') or
-                name in ('ttsmi_last_error', 'ttsmi_version', 'ttsmi_dense_block_fwd', 'ttsmi_dense_block_bwd',
-                         'ttsmi_set_launch_observer')):
-            return fn(*args)          # queries; the block launchers announce their launches through the observer
+                name in ('ttsmi_last_error', 'ttsmi_version', 'ttsmi_last_kernel', 'ttsmi_dense_block_fwd', 'ttsmi_dense_block_bwd',
+                         'ttsmi_dense_stack_fwd', 'ttsmi_dense_stack_bwd', 'ttsmi_set_launch_observer') or
+                'comm' in name or name.endswith('_supported')):
+            return fn(*args)          # queries / entry points without a stream; the block and stack launchers announce
+            #                           their launches through the observer
         # the launch stream is the entry point's last argument (the weight gradients pass the side
         # stream's handle explicitly while torch's current stream stays the main one)
         h = args[-1] if isinstance(args[-1], int) else None

@@ -709,3 +709,18 @@ def test_optimizer_state_of_another_layout_is_refused_with_a_clear_message(tiny,
     from transformertts_amd.model.models import ForwardTransformer
     with pytest.raises(ValueError, match='Adam state'):
         ForwardTransformer.load_model(tmp_path / 'ckpt')
+
+
+def test_bench_instrumented_step_runs_on_the_planned_path(tiny):
+    """bench.py's roofline leg brackets every C-ABI call of one step with HIP events (and the C++ launchers' launches
+    through the observer): it must survive every entry point the step uses - the stack launchers crashed it once."""
+    import bench
+    cfg, W = tiny
+    m = _model(cfg, W, dropout_rate=0.1, predictors_dropout=0.1, seed=1, precision='bf16')
+    m._compile(learning_rate=1e-3)
+    batch = [torch.from_numpy(np.asarray(a)).cuda() for a in fo.synthetic_batch(4, 50, 200, seed=3, ragged=True)]
+    for _ in range(2):
+        m.train_step(*batch)
+    groups = bench.group_records(bench.instrumented_step(lambda: m.train_step(*batch)))
+    assert any('attention' in k for k in groups) and sum(v[0] for v in groups.values()) > 40
+    assert all(np.isfinite(v[3]) and v[3] >= 0 for v in groups.values())
