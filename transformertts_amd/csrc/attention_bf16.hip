@@ -735,6 +735,8 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
     frags_of<DH, QH>(Vb, p.ld, key, kok, hh, vf);
     // keys that took no part in the forward (>= klen) get probability 0 through a -inf logit
     const float padterm = !kact ? -INFINITY : ((p.key_pad[(long)b * p.T + key]) ? -1e9f * LOG2E : 0.f);
+    // (measured and rejected, round 4: a wave-uniform "no padded key in this wave" fast path that saves the add of `padterm`
+    // per score made hipcc duplicate the query loop with another register allocation: 179 -> 207 us for dQ + dK/dV)
 
     // head dims above 64 (SPLIT): the 2 x DH / 32 accumulator tiles of dK and dV together would not leave registers for
     // the operands, so the launch has two passes (blockIdx.y) and each owns ONE of the outputs over all of its columns:

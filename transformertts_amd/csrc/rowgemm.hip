@@ -131,12 +131,25 @@ __device__ __forceinline__ void rg_prefetch(const RowGemmP& p, int m0, int wave,
 }
 
 // NJ = 32-column blocks of a wave's accumulator tile (4: waves 2-wide over the 256 columns; 2: 4-wide)
-template <int EPI, int NW, int BM, int RT, int NJ = 4>
+// W64: the wave's tile is 64 rows x 64 columns = acc[mi * 2 + nj] (wm = row half, wc = column quarter) instead of 32 x NJ*32
+template <int EPI, int NW, int BM, int RT, int NJ = 4, bool W64 = false>
 __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ], int m0, float* Z, int wave, int wm, int wc,
                                             int lane, const RgPre<EPI, BM / NW, RT>& pre) {
     const int l31 = lane & 31, hh = lane >> 5;
     // ---- accumulators -> Z (all waves finished reading the operand stages: the caller synchronised)
-    {
+    if constexpr (W64) {
+        static_assert(NJ == 4, "64 x 64 wave tiles: four accumulators");
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                float* zr = Z + (wm * 64 + mi * 32 + l31) * RG_ZLD + wc * 64 + nj * 32 + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(zr + 8 * g) = make_float4(acc[mi * 2 + nj][4 * g + 0], acc[mi * 2 + nj][4 * g + 1],
+                                                                         acc[mi * 2 + nj][4 * g + 2], acc[mi * 2 + nj][4 * g + 3]);
+            }
+    } else {
         float* zr = Z + (wm * 32 + l31) * RG_ZLD + wc * (NJ * 32) + 4 * hh;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -341,8 +354,11 @@ __device__ __forceinline__ unsigned rd_lds_offset(const void* p) {
 // BM = 128: waves 4 (rows) x 2 (columns), wave tile 32 x 128.  BM = 64: waves 2 x 4, wave tile 32 x 64 - for launches whose
 // 128-row tiles would occupy fewer than half the CUs (the encoder side, M = 6 400: 50 workgroups): twice the workgroups,
 // each with a shorter fill per k-step (40 KB) and half the epilogue.
-template <int EPI, int BM, int RT = 0>
+// W64 (BM = 128 only): wave tiles of 64 x 64 (waves 2 x 4) - 8 fragment reads per 8 MFMAs instead of 10 (the k-loop is
+// paced by LDS traffic together with the fill: 160 KB of fragment reads + 48 KB of DMA writes per k-step and workgroup)
+template <int EPI, int BM, int RT = 0, bool W64 = false>
 __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
+    static_assert(!W64 || BM == 128, "64 x 64 wave tiles need the 128-row workgroup tile");
     constexpr int NJ = BM == 128 ? 4 : 2;                  // 32-column blocks per wave
     constexpr int STAGE = (BM + RG_N) * RG_BK * 2;
     constexpr int DMA_A = BM / 64;                         // A-image DMA instructions per wave and k-step (+ 4 for W)
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[RD_STAGES * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                      // 0..7
-    const int wm = BM == 128 ? wave >> 1 : wave >> 2, wc = BM == 128 ? wave & 1 : wave & 3;
+    const int wm = W64 ? wave >> 2 : (BM == 128 ? wave >> 1 : wave >> 2), wc = W64 ? wave & 3 : (BM == 128 ? wave & 1 : wave & 3);
     const int m0 = blockIdx.x * BM;
     const int nk = p.K / RG_BK;
 
@@ -414,6 +430,31 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
         // Fragments of TWO 16-wide k-slices (10 x 16 B per lane) are requested before the first of their 8 MFMAs issues:
         // written one fragment at a time, hipcc keeps a single ds_read ahead of each MFMA and the matrix pipe waits out an
         // LDS round trip per multiply (23 % busy in the k-loop: it, not the fill, was what bounded this kernel).
+        if constexpr (W64) {
+#pragma unroll
+            for (int k2 = 0; k2 < RG_BK / 32; ++k2) {
+                bf16x8 a[2][2], b[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = (k2 * 2 + u) * 2 + hh;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int arow = wm * 64 + t * 32 + l31, brow = wc * 64 + t * 32 + l31;
+                        a[u][t] = *reinterpret_cast<const bf16x8*>(As + arow * 128 + ((c ^ ((arow >> 1) & 7)) << 4));
+                        b[u][t] = *reinterpret_cast<const bf16x8*>(Bs + brow * 128 + ((c ^ ((brow >> 1) & 7)) << 4));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);        // all eight reads are in flight before the multiplies start
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int nj = 0; nj < 2; ++nj)
+                            acc[mi * 2 + nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[u][nj], a[u][mi], acc[mi * 2 + nj], 0, 0, 0);
+            }
+            continue;
+        }
 #pragma unroll
         for (int k2 = 0; k2 < RG_BK / 32; ++k2) {
             bf16x8 a[2], b[2][NJ];
@@ -437,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
     }
     __syncthreads();
     if (TTSMI_ABLATE_BITS(p.ablate) & 4) return;
-    rg_epilogue<EPI, 8, BM, RT, NJ>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
+    rg_epilogue<EPI, 8, BM, RT, NJ, W64>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
 }
 
 // ---- standalone backward of a LayerNorm whose forward kept x^ (bf16) and rstd: the fused forward's counterpart for the
@@ -560,6 +601,9 @@ static void rg_launch(const RowGemmP& p, int M, ttsmi_stream_t stream) {
             TTSMI_LAUNCH_EV((rowgemm_dma_kernel<EPI, 64, RT>), dim3(ttsmi_cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, p);
         } else {
             ttsmi_note_kernel(names[1]);
+            TTSMI_KNOB(w64, "TTSMI_ROWGEMM_W64", 1);        // A/B knob: 0 = wave tiles of 32 x 128 (rounds 2-3)
+            if (w64) TTSMI_LAUNCH_EV((rowgemm_dma_kernel<EPI, RD_BM, RT, true>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
+            else
             TTSMI_LAUNCH_EV((rowgemm_dma_kernel<EPI, RD_BM, RT>), dim3(ttsmi_cdiv(M, RD_BM)), dim3(512), 0, (hipStream_t)stream, p);
         }
     } else {

@@ -244,19 +244,24 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         // ---- sparse mel + normalisation ---------------------------------------------------------
         if (mel_items && !(TTSMI_ABLATE_BITS(p.ablate) & 2)) {
             float* part = partS[wave];
+            // The products are formed as PAIRS along the weight index (v_pk_fma_f32 on the two halves of each 16-byte read):
+            // written with four scalar accumulators, hipcc's SLP pass paired the SAME accumulator of two loop iterations
+            // instead and spent 36 v_mov_b32 per 12 packed FMAs shuffling the operands together (ISA reading, round 4).
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#pragma clang loop unroll(disable)
             for (int it = lane; it < n_items; it += 64) {
-                const float4* w4 = reinterpret_cast<const float4*>(itWt[it]);
-                const float4* x4 = reinterpret_cast<const float4*>(mg + itLo[it]);   // 16-byte aligned; may run past the filter: zero weights
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                const f32x4_t* w4 = reinterpret_cast<const f32x4_t*>(itWt[it]);
+                const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(mg + itLo[it]);   // 16-byte aligned; may run past the filter: zero weights
+                f32x2_t a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < MEL_IT / 4; ++i) {
-                    const float4 w = w4[i], x = x4[i];
-                    s0 += w.x * x.x;
-                    s1 += w.y * x.y;
-                    s2 += w.z * x.z;
-                    s3 += w.w * x.w;
+                    const f32x4_t w = w4[i], x = x4[i];
+                    a0 += w.xy * x.xy;
+                    a1 += w.zw * x.zw;
                 }
-                part[it] = (s0 + s1) + (s2 + s3);
+                a0 += a1;
+                part[it] = a0.x + a0.y;
             }
             WAVE_SYNC();
         }
