@@ -36,9 +36,9 @@ extern "C" {
 #endif
 
 /* Bumped whenever an entry point's argument list or the ttsmi_dense_block layout changes (101: round 3's `denom` argument of
- * ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102: round 4).  Bindings check it at load
+ * ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102: round 4; 103: ttsmi_mel_nnls added).  Bindings check it at load
  * time (transformertts_amd/_lib.py) so that a stale build is refused instead of being called with shifted arguments. */
-#define TTSMI_VERSION 102
+#define TTSMI_VERSION 103
 
 enum {
     TTSMI_OK = 0,
@@ -344,6 +344,24 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
 size_t ttsmi_griffinlim_ws_bytes(int T);
 int ttsmi_griffinlim(const float* mag, float* angles, const float* window, const float* wss, int T, int n_fft, int hop,
                      int n_iter, float momentum, float* wav, void* ws, size_t ws_bytes, ttsmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * mel -> linear magnitudes, the step in front of Griffin-Lim: librosa.feature.inverse.mel_to_stft (0.7.1 [3P]) as
+ * data/audio.py:94-110 (reconstruct_waveform) calls it - per frame, minimise 1/2 ||B x - m||^2 subject to x >= 0, from
+ * the clipped least-squares start point.  One wave64 per frame runs an accelerated projected gradient on chip
+ * (csrc/nnls.hip); librosa runs L-BFGS-B on the host.  The minimiser is unique in B x, not in x.
+ * mel       [T][n_mels] fp32 amplitudes (de-normalised), frame-major;
+ * pinv_t    [n_mels][n_bins] fp32: pinv(B) transposed;
+ * row_lo / row_cnt / row_ptr [n_mels], w [n_w]: the filterbank's rows as runs of non-zeros (the layout ttsmi_stft_logmel
+ *           takes);
+ * x         [T][n_bins] fp32, frame-major (what ttsmi_griffinlim takes as `mag`): the solution raised to inv_power
+ *           (1 / power of the mel: 1 for the reference's amplitude mels);
+ * inv_lipschitz = 1 / ||B||_2^2 (the step), n_iter projected-gradient steps (300 pass scipy's objective; 512 is the
+ *           host mirror's default).
+ * ------------------------------------------------------------------------------------------- */
+int ttsmi_mel_nnls(const float* mel, const float* pinv_t, const int* row_lo, const int* row_cnt, const int* row_ptr,
+                   const float* w, int n_w, float* x, int T, int n_mels, int n_bins, float inv_lipschitz, int n_iter,
+                   float inv_power, ttsmi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * TTSMI_BF16 GEMM path: bf16 operands (round to nearest even), fp32 accumulate on

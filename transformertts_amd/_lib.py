@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # version this binding was written for (EXPECTED_VERSION, checked in lib()).
 _override = os.environ.get('TTSMI_LIB') if os.environ.get('TTSMI_ALLOW_LIB_OVERRIDE') == '1' else None
 LIB_PATH = _override or os.path.join(_HERE, 'lib', 'libttsmi.so')
-EXPECTED_VERSION = 102            # include/ttsmi.h: TTSMI_VERSION
+EXPECTED_VERSION = 103            # include/ttsmi.h: TTSMI_VERSION
 
 P = c_void_p          # every device pointer
 I = c_int
@@ -85,6 +85,7 @@ SIGNATURES = {
     'ttsmi_adam_tf': (I, [P, P, P, P, L, P, P, F, F, F, P, S]),
     'ttsmi_step_increment': (I, [P, S]),
     'ttsmi_stft_logmel': (I, [P, P, P, I, L, I, I, P, I, P, P, P, P, I, F, P, S]),
+    'ttsmi_mel_nnls': (I, [P, P, P, P, P, P, I, P, I, I, I, F, I, F, S]),
     'ttsmi_griffinlim_ws_bytes': (c_size_t, [I]),
     'ttsmi_griffinlim': (I, [P, P, P, P, I, I, I, I, F, P, P, c_size_t, S]),
     'ttsmi_cast_f32_to_bf16': (I, [P, P, L, S]),

@@ -211,6 +211,7 @@ class Audio:
         self._mel = tuple(torch.from_numpy(a).to(dev) for a in (lo, cnt, ptr, w))
         self._window_host = hann_window_padded(win_length, n_fft)
         self._window = torch.from_numpy(self._window_host).to(dev)
+        self._nnls = None                         # (pinv(B)^T on the device, 1 / ||B||_2^2): built on first use
 
     @classmethod
     def from_config(cls, config: dict):
@@ -261,27 +262,55 @@ class Audio:
                                       'outside the hot path: trim the clips upstream and configure them off')
         return pad_for_frame_count(y, self.hop_length)
 
-    def reconstruct_waveform(self, mel, n_iter=32, random_state=None, momentum=0.99):
+    def mel_to_stft(self, amp_mel, n_iter=512, power=1.0):
+        """librosa.feature.inverse.mel_to_stft [3P] on the GPU (ttsmi_mel_nnls): amplitude mel [mel_channels, T] (numpy or
+        tensor) -> DEVICE tensor [T, 1 + n_fft // 2] of non-negative linear magnitudes, frame-major.  Same problem and
+        start point as the host function of this module (scipy L-BFGS-B, librosa's optimiser); the minimiser is unique
+        in its mel projection, not in x, and this one reaches a lower objective than scipy's stopping rule does."""
+        dev = self.device
+        if self._nnls is None:
+            B = mel_filterbank_dense(self.sampling_rate, self.n_fft, self.mel_channels, self.f_min, self.f_max,
+                                     dtype=np.float64)
+            pinv_t = np.ascontiguousarray(np.linalg.pinv(B).T, dtype=np.float32)          # [n_mels, n_bins]
+            self._nnls = (torch.from_numpy(pinv_t).to(dev), float(1.0 / np.linalg.norm(B, 2) ** 2))
+        pinv_t, inv_l = self._nnls
+        m = amp_mel if torch.is_tensor(amp_mel) else torch.from_numpy(np.asarray(amp_mel))
+        m = m.detach().to(dev, torch.float32).t().contiguous()                            # [T, n_mels]
+        lo, cnt, ptr, w = self._mel
+        with torch.cuda.device(dev):
+            return ops.mel_nnls(m, pinv_t, lo, cnt, ptr, w, inv_l, n_iter=n_iter, power=power)
+
+    def reconstruct_waveform(self, mel, n_iter=32, random_state=None, momentum=0.99, nnls='device', nnls_iter=512):
         """Reference Audio.reconstruct_waveform (data/audio.py:94-110): normalised mel [mel_channels, T] (callers pass
         `mel.T`, predict_tts.py:56) -> float32 wav [hop * (T - 1)].  `random_state` (int seed / RandomState / None)
         draws the start phases exactly as librosa.griffinlim does (None = NumPy's global generator: unseeded, like the
-        reference's call)."""
+        reference's call).  nnls: 'device' (ttsmi_mel_nnls, milliseconds) or 'lbfgs' (librosa's own optimiser on the
+        host, seconds to minutes: the trajectory the reference takes - the two agree in the mel projection of the
+        result, not bin by bin, see mel_to_stft)."""
         mel = np.asarray(mel.detach().cpu() if torch.is_tensor(mel) else mel)
         amp_mel = self._denormalize(mel)
-        S = mel_to_stft(amp_mel, self.sampling_rate, self.n_fft, self.f_min, self.f_max, power=1)
+        if nnls == 'device':
+            S = self.mel_to_stft(amp_mel, n_iter=nnls_iter)                                # [T, bins] on the device
+            shape = (int(S.shape[1]), int(S.shape[0]))
+        elif nnls == 'lbfgs':
+            S = mel_to_stft(amp_mel, self.sampling_rate, self.n_fft, self.f_min, self.f_max, power=1)
+            shape = S.shape
+        else:
+            raise ValueError(f"nnls must be 'device' or 'lbfgs', not {nnls!r}")
         rng = (np.random if random_state is None else random_state if isinstance(random_state, np.random.RandomState)
                else np.random.RandomState(seed=random_state))
-        angles = np.empty(S.shape, dtype=np.complex64)
-        angles[:] = np.exp(2j * np.pi * rng.rand(*S.shape))
+        angles = np.empty(shape, dtype=np.complex64)
+        angles[:] = np.exp(2j * np.pi * rng.rand(*shape))
         return self.griffinlim(S, angles, n_iter=n_iter, momentum=momentum)
 
     def griffinlim(self, S, angles, n_iter=32, momentum=0.99, return_angles=False):
-        """librosa.core.griffinlim [3P] on the GPU: S [1 + n_fft // 2, T] linear magnitudes, `angles` the complex
-        start phases of the same shape."""
-        T = int(S.shape[1])
+        """librosa.core.griffinlim [3P] on the GPU: S [1 + n_fft // 2, T] linear magnitudes (numpy), or a DEVICE tensor
+        [T, 1 + n_fft // 2] (frame-major, as mel_to_stft returns it); `angles` the complex start phases [bins, T]."""
         dev = self.device
+        T = int(S.shape[0] if torch.is_tensor(S) else S.shape[1])
         with torch.cuda.device(dev):
-            mag = torch.from_numpy(np.ascontiguousarray(S.T, dtype=np.float32)).to(dev)
+            mag = (S.to(dev, torch.float32).contiguous() if torch.is_tensor(S)
+                   else torch.from_numpy(np.ascontiguousarray(S.T, dtype=np.float32)).to(dev))
             a = np.ascontiguousarray(np.asarray(angles, dtype=np.complex64).T)
             ang = torch.from_numpy(a.view(np.float32).reshape(T, -1, 2).copy()).to(dev)
             wss = torch.from_numpy(window_sumsquare(self._window_host, T, self.hop_length)).to(dev)

@@ -313,6 +313,19 @@ def stft_logmel(wav, clip_off, frame_off, total_frames, n_fft, hop, window, n_me
     return out
 
 
+def mel_nnls(mel, pinv_t, mel_lo, mel_cnt, mel_ptr, mel_w, inv_lipschitz, n_iter=512, power=1.0):
+    """ttsmi_mel_nnls (include/ttsmi.h): amplitude mel [T, n_mels] fp32 -> non-negative linear magnitudes [T, n_bins] fp32
+    (frame-major, what `griffinlim` takes) whose mel projection is closest to it."""
+    T, n_mels = int(mel.shape[0]), int(mel.shape[1])
+    n_bins = int(pinv_t.shape[1])
+    assert mel.is_contiguous() and mel.dtype == torch.float32 and tuple(pinv_t.shape) == (n_mels, n_bins)
+    x = torch.empty((T, n_bins), dtype=torch.float32, device=mel.device)
+    check(_lib.lib().ttsmi_mel_nnls(_p(mel), _p(pinv_t), _p(mel_lo), _p(mel_cnt), _p(mel_ptr), _p(mel_w), mel_w.numel(),
+                                    _p(x), T, n_mels, n_bins, float(inv_lipschitz), int(n_iter), 1.0 / float(power),
+                                    _stream()), 'mel_nnls')
+    return x
+
+
 def griffinlim(mag, angles, window, wss, n_fft, hop, n_iter, momentum):
     """ttsmi_griffinlim (include/ttsmi.h): mag [T,513] fp32, angles [T,513,2] fp32 (updated in place), window [n_fft],
     wss [n_fft + hop (T - 1)] -> wav [hop (T - 1)] fp32 on the device."""
