@@ -1,140 +1,264 @@
-// Issue-rate probe for the VALU instructions that sit in the attention inner loop (gfx950): N dependent-free copies of
-// one instruction per loop iteration on 8 independent registers, one wave per SIMD vs 2 / 4 waves per SIMD.
-// Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_probe tools/probes/valu_rate_probe.hip ; run on the GPU box.
+// Issue rates of the VALU instructions the attention kernels are made of, on this part and at the clock it really runs
+// at under load: the softmax of a 32 x 32 score block is ~140 VALU instructions per wave against 8 MFMAs (dh = 64), so the
+// kernels are paced by the vector ALU - this table says what an instruction costs and what the diet is worth.
+// Every SIMD runs WAVES waves, each issuing REPS x 16 independent copies of one instruction (inline asm, 16 distinct
+// destination registers: no dependency stalls); cycles per instruction = time x clock / (REPS x 16 x WAVES).
+// The clock is taken from s_memtime (shader clock) against the 100 MHz s_memrealtime over the same interval.
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/valu_rate_probe.hip -o tools/probes/valu_rate_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include <stdint.h>
 
-#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-template <int OP>
-__global__ void probe(uint32_t* out, int iters, uint32_t seed) {
-    uint32_t r0 = seed + threadIdx.x, r1 = r0 * 3 + 1, r2 = r0 * 5 + 2, r3 = r0 * 7 + 3, r4 = r0 ^ 0x55, r5 = r0 ^ 0xaa, r6 = r0 + 77, r7 = r0 + 99;
-    uint32_t c = seed | 1;
-    for (int i = 0; i < iters; ++i) {
-#define ASM1(OPS, R) asm volatile(OPS : "+v"(R) : "v"(c));
-        if (OP == 0) { // v_mul_lo_u32
-#define X(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 1) { // v_xor_b32
-#define X(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 2) { // v_mul_u32_u24
-#define X(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 3) { // v_exp_f32
-#define X(i) asm volatile("v_exp_f32 %0, %0" : "+v"(r##i));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 4) { // v_mad_u32_u24
-#define X(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 5) { // v_cndmask
-#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 6) { // v_fma_f32
-#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 7) { // v_mul_hi_u32
-#define X(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 8) { // v_lshl_add_u32 / xad
-#define X(i) asm volatile("v_xad_u32 %0, %0, %1, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 9) { // v_alignbit (rotate)
-#define X(i) asm volatile("v_alignbit_b32 %0, %0, %0, 13" : "+v"(r##i));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 10) { // v_cmp + nothing
-#define X(i) asm volatile("v_cmp_le_u32 vcc, %0, %1" :: "v"(r##i), "v"(c) : "vcc");
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 11) { // v_pk_mul_f32
-            uint64_t q0 = r0, q1 = r1, q2 = r2, q3 = r3; uint64_t cc = c;
-#define Y(q) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(q) : "v"(cc));
-            Y(q0) Y(q1) Y(q2) Y(q3) Y(q0) Y(q1) Y(q2) Y(q3) Y(q0) Y(q1) Y(q2) Y(q3) Y(q0) Y(q1) Y(q2) Y(q3)
-            Y(q0) Y(q1) Y(q2) Y(q3) Y(q0) Y(q1) Y(q2) Y(q3) Y(q0) Y(q1) Y(q2) Y(q3) Y(q0) Y(q1) Y(q2) Y(q3)
-#undef Y
-            r0 ^= (uint32_t)q0; r1 ^= (uint32_t)q1; r2 ^= (uint32_t)q2; r3 ^= (uint32_t)q3;
-        } else if (OP == 12) { // v_bfe_u32
-#define X(i) asm volatile("v_bfe_u32 %0, %0, 3, 16" : "+v"(r##i));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 14) { // v_cndmask e64 with an SGPR pair mask
-            uint64_t m = 0x5555aaaa5555aaaaull ^ seed;
-#define X(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r##i) : "v"(c), "s"(m));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 15) { // v_cmp + v_cndmask pairs (the dropout select as compiled today)
-#define X(i) asm volatile("v_cmp_le_u32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(r##i) : "v"(c) : "vcc");
-            REP8(X) REP8(X)
-#undef X
-        } else if (OP == 16) { // v_cndmask with a destination that is not a source
-            uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
-#define X(i) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(t##i) : "v"(r##i), "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-            r0 ^= t0; r1 ^= t1; r2 ^= t2; r3 ^= t3; r4 ^= t4; r5 ^= t5; r6 ^= t6; r7 ^= t7;
-        } else if (OP == 17) { // v_and_b32
-#define X(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 18) { // v_bfe_i32 (1-bit sign-extended field -> 0 / -1 mask)
-#define X(i) asm volatile("v_bfe_i32 %0, %0, 5, 1" : "+v"(r##i));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 19) { // v_max3_f32
-#define X(i) asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 20) { // v_mul_f32 e32
-#define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 21) { // v_add_u32 e32
-#define X(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
-        } else if (OP == 13) { // v_cvt_pk_bf16_f32
-#define X(i) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(r##i) : "v"(c));
-            REP8(X) REP8(X) REP8(X) REP8(X)
-#undef X
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+#define REPS 2048
+
+template <int KIND>
+__global__ __launch_bounds__(256) void rate_kernel(float* out, unsigned long long* clk) {
+    float a = threadIdx.x * 0.001f, b = 1.0f, c = 0.5f + blockIdx.x * 1e-6f, d = 0.25f;
+    double c2 = 0.5 + blockIdx.x * 1e-6, d2 = 0.25;                    // 64-bit register pairs for the packed forms
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const unsigned long long r0 = wall_clock64();
+    asm volatile("s_mov_b64 s[20:21], 0x55555555" ::: "s20", "s21");
+    for (int it = 0; it < REPS; ++it) {
+        if (KIND == 0) {
+            asm volatile(
+                "v_fma_f32 v100, %2, %3, %2\n v_fma_f32 v102, %2, %3, %2\n v_fma_f32 v104, %2, %3, %2\n v_fma_f32 v106, %2, %3, %2\n"
+                "v_fma_f32 v108, %2, %3, %2\n v_fma_f32 v110, %2, %3, %2\n v_fma_f32 v112, %2, %3, %2\n v_fma_f32 v114, %2, %3, %2\n"
+                "v_fma_f32 v116, %2, %3, %2\n v_fma_f32 v118, %2, %3, %2\n v_fma_f32 v120, %2, %3, %2\n v_fma_f32 v122, %2, %3, %2\n"
+                "v_fma_f32 v124, %2, %3, %2\n v_fma_f32 v126, %2, %3, %2\n v_fma_f32 v128, %2, %3, %2\n v_fma_f32 v130, %2, %3, %2\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116",
+                  "v118", "v120", "v122", "v124", "v126", "v128", "v130");
+        } else if (KIND == 1) {
+            asm volatile(
+                "v_exp_f32 v100, %2\n v_exp_f32 v102, %2\n v_exp_f32 v104, %2\n v_exp_f32 v106, %2\n"
+                "v_exp_f32 v108, %2\n v_exp_f32 v110, %2\n v_exp_f32 v112, %2\n v_exp_f32 v114, %2\n"
+                "v_exp_f32 v116, %2\n v_exp_f32 v118, %2\n v_exp_f32 v120, %2\n v_exp_f32 v122, %2\n"
+                "v_exp_f32 v124, %2\n v_exp_f32 v126, %2\n v_exp_f32 v128, %2\n v_exp_f32 v130, %2\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116",
+                  "v118", "v120", "v122", "v124", "v126", "v128", "v130");
+        } else if (KIND == 2) {
+            asm volatile(
+                "v_pk_fma_f32 v[100:101], %2, %3, %2\n v_pk_fma_f32 v[102:103], %2, %3, %2\n v_pk_fma_f32 v[104:105], %2, %3, %2\n v_pk_fma_f32 v[106:107], %2, %3, %2\n"
+                "v_pk_fma_f32 v[108:109], %2, %3, %2\n v_pk_fma_f32 v[110:111], %2, %3, %2\n v_pk_fma_f32 v[112:113], %2, %3, %2\n v_pk_fma_f32 v[114:115], %2, %3, %2\n"
+                "v_pk_fma_f32 v[116:117], %2, %3, %2\n v_pk_fma_f32 v[118:119], %2, %3, %2\n v_pk_fma_f32 v[120:121], %2, %3, %2\n v_pk_fma_f32 v[122:123], %2, %3, %2\n"
+                "v_pk_fma_f32 v[124:125], %2, %3, %2\n v_pk_fma_f32 v[126:127], %2, %3, %2\n v_pk_fma_f32 v[128:129], %2, %3, %2\n v_pk_fma_f32 v[130:131], %2, %3, %2\n"
+                : "+v"(a), "+v"(b) : "v"(c2), "v"(d2) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+                  "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
+                  "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131");
+        } else if (KIND == 3) {
+            asm volatile(
+                "v_cndmask_b32 v100, %2, %3, vcc\n v_cndmask_b32 v102, %2, %3, vcc\n v_cndmask_b32 v104, %2, %3, vcc\n v_cndmask_b32 v106, %2, %3, vcc\n"
+                "v_cndmask_b32 v108, %2, %3, vcc\n v_cndmask_b32 v110, %2, %3, vcc\n v_cndmask_b32 v112, %2, %3, vcc\n v_cndmask_b32 v114, %2, %3, vcc\n"
+                "v_cndmask_b32 v116, %2, %3, vcc\n v_cndmask_b32 v118, %2, %3, vcc\n v_cndmask_b32 v120, %2, %3, vcc\n v_cndmask_b32 v122, %2, %3, vcc\n"
+                "v_cndmask_b32 v124, %2, %3, vcc\n v_cndmask_b32 v126, %2, %3, vcc\n v_cndmask_b32 v128, %2, %3, vcc\n v_cndmask_b32 v130, %2, %3, vcc\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116",
+                  "v118", "v120", "v122", "v124", "v126", "v128", "v130", "vcc");
+        } else if (KIND == 4) {
+            asm volatile(
+                "v_cvt_pk_bf16_f32 v100, %2, %3\n v_cvt_pk_bf16_f32 v102, %2, %3\n v_cvt_pk_bf16_f32 v104, %2, %3\n v_cvt_pk_bf16_f32 v106, %2, %3\n"
+                "v_cvt_pk_bf16_f32 v108, %2, %3\n v_cvt_pk_bf16_f32 v110, %2, %3\n v_cvt_pk_bf16_f32 v112, %2, %3\n v_cvt_pk_bf16_f32 v114, %2, %3\n"
+                "v_cvt_pk_bf16_f32 v116, %2, %3\n v_cvt_pk_bf16_f32 v118, %2, %3\n v_cvt_pk_bf16_f32 v120, %2, %3\n v_cvt_pk_bf16_f32 v122, %2, %3\n"
+                "v_cvt_pk_bf16_f32 v124, %2, %3\n v_cvt_pk_bf16_f32 v126, %2, %3\n v_cvt_pk_bf16_f32 v128, %2, %3\n v_cvt_pk_bf16_f32 v130, %2, %3\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116",
+                  "v118", "v120", "v122", "v124", "v126", "v128", "v130");
+        } else if (KIND == 5) {
+            asm volatile(
+                "v_max3_f32 v100, %2, %3, %2\n v_max3_f32 v102, %2, %3, %2\n v_max3_f32 v104, %2, %3, %2\n v_max3_f32 v106, %2, %3, %2\n"
+                "v_max3_f32 v108, %2, %3, %2\n v_max3_f32 v110, %2, %3, %2\n v_max3_f32 v112, %2, %3, %2\n v_max3_f32 v114, %2, %3, %2\n"
+                "v_max3_f32 v116, %2, %3, %2\n v_max3_f32 v118, %2, %3, %2\n v_max3_f32 v120, %2, %3, %2\n v_max3_f32 v122, %2, %3, %2\n"
+                "v_max3_f32 v124, %2, %3, %2\n v_max3_f32 v126, %2, %3, %2\n v_max3_f32 v128, %2, %3, %2\n v_max3_f32 v130, %2, %3, %2\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116",
+                  "v118", "v120", "v122", "v124", "v126", "v128", "v130");
+        } else if (KIND == 6) {
+            asm volatile(
+                "v_pk_mul_f32 v[100:101], %2, %3\n v_pk_mul_f32 v[102:103], %2, %3\n v_pk_mul_f32 v[104:105], %2, %3\n v_pk_mul_f32 v[106:107], %2, %3\n"
+                "v_pk_mul_f32 v[108:109], %2, %3\n v_pk_mul_f32 v[110:111], %2, %3\n v_pk_mul_f32 v[112:113], %2, %3\n v_pk_mul_f32 v[114:115], %2, %3\n"
+                "v_pk_mul_f32 v[116:117], %2, %3\n v_pk_mul_f32 v[118:119], %2, %3\n v_pk_mul_f32 v[120:121], %2, %3\n v_pk_mul_f32 v[122:123], %2, %3\n"
+                "v_pk_mul_f32 v[124:125], %2, %3\n v_pk_mul_f32 v[126:127], %2, %3\n v_pk_mul_f32 v[128:129], %2, %3\n v_pk_mul_f32 v[130:131], %2, %3\n"
+                : "+v"(a), "+v"(b) : "v"(c2), "v"(d2) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+                  "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
+                  "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131");
+        } else if (KIND == 7) {
+            asm volatile(
+                "v_mul_f32 v100, %2, %3\n v_mul_f32 v102, %2, %3\n v_mul_f32 v104, %2, %3\n v_mul_f32 v106, %2, %3\n"
+                "v_mul_f32 v108, %2, %3\n v_mul_f32 v110, %2, %3\n v_mul_f32 v112, %2, %3\n v_mul_f32 v114, %2, %3\n"
+                "v_mul_f32 v116, %2, %3\n v_mul_f32 v118, %2, %3\n v_mul_f32 v120, %2, %3\n v_mul_f32 v122, %2, %3\n"
+                "v_mul_f32 v124, %2, %3\n v_mul_f32 v126, %2, %3\n v_mul_f32 v128, %2, %3\n v_mul_f32 v130, %2, %3\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116",
+                  "v118", "v120", "v122", "v124", "v126", "v128", "v130");
+        } else if (KIND == 8) {
+            asm volatile(
+                "v_permlane32_swap_b32 v100, v102\n v_permlane32_swap_b32 v104, v106\n v_permlane32_swap_b32 v108, v110\n v_permlane32_swap_b32 v112, v114\n"
+                "v_permlane32_swap_b32 v116, v118\n v_permlane32_swap_b32 v120, v122\n v_permlane32_swap_b32 v124, v126\n v_permlane32_swap_b32 v128, v130\n"
+                "v_permlane32_swap_b32 v100, v102\n v_permlane32_swap_b32 v104, v106\n v_permlane32_swap_b32 v108, v110\n v_permlane32_swap_b32 v112, v114\n"
+                "v_permlane32_swap_b32 v116, v118\n v_permlane32_swap_b32 v120, v122\n v_permlane32_swap_b32 v124, v126\n v_permlane32_swap_b32 v128, v130\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116",
+                  "v118", "v120", "v122", "v124", "v126", "v128", "v130");
+        } else if (KIND == 9) {
+            asm volatile(
+                "v_mov_b32_dpp v100, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v102, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                "v_mov_b32_dpp v104, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v106, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                "v_mov_b32_dpp v108, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v110, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                "v_mov_b32_dpp v112, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v114, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                "v_mov_b32_dpp v116, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v118, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                "v_mov_b32_dpp v120, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v122, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                "v_mov_b32_dpp v124, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v126, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                "v_mov_b32_dpp v128, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v130, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116",
+                  "v118", "v120", "v122", "v124", "v126", "v128", "v130");
+        } else if (KIND == 10) {
+            asm volatile(
+                "v_pk_add_f32 v[100:101], %2, %3\n v_pk_add_f32 v[102:103], %2, %3\n v_pk_add_f32 v[104:105], %2, %3\n v_pk_add_f32 v[106:107], %2, %3\n"
+                "v_pk_add_f32 v[108:109], %2, %3\n v_pk_add_f32 v[110:111], %2, %3\n v_pk_add_f32 v[112:113], %2, %3\n v_pk_add_f32 v[114:115], %2, %3\n"
+                "v_pk_add_f32 v[116:117], %2, %3\n v_pk_add_f32 v[118:119], %2, %3\n v_pk_add_f32 v[120:121], %2, %3\n v_pk_add_f32 v[122:123], %2, %3\n"
+                "v_pk_add_f32 v[124:125], %2, %3\n v_pk_add_f32 v[126:127], %2, %3\n v_pk_add_f32 v[128:129], %2, %3\n v_pk_add_f32 v[130:131], %2, %3\n"
+                : "+v"(a), "+v"(b) : "v"(c2), "v"(d2) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+                  "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
+                  "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131");
+        } else if (KIND == 11) {
+            asm volatile(
+                "v_cndmask_b32_e64 v100, %2, %3, s[20:21]\n v_cndmask_b32_e64 v102, %2, %3, s[20:21]\n v_cndmask_b32_e64 v104, %2, %3, s[20:21]\n v_cndmask_b32_e64 v106, %2, %3, s[20:21]\n"
+                "v_cndmask_b32_e64 v108, %2, %3, s[20:21]\n v_cndmask_b32_e64 v110, %2, %3, s[20:21]\n v_cndmask_b32_e64 v112, %2, %3, s[20:21]\n v_cndmask_b32_e64 v114, %2, %3, s[20:21]\n"
+                "v_cndmask_b32_e64 v116, %2, %3, s[20:21]\n v_cndmask_b32_e64 v118, %2, %3, s[20:21]\n v_cndmask_b32_e64 v120, %2, %3, s[20:21]\n v_cndmask_b32_e64 v122, %2, %3, s[20:21]\n"
+                "v_cndmask_b32_e64 v124, %2, %3, s[20:21]\n v_cndmask_b32_e64 v126, %2, %3, s[20:21]\n v_cndmask_b32_e64 v128, %2, %3, s[20:21]\n v_cndmask_b32_e64 v130, %2, %3, s[20:21]\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116", "v118", "v120", "v122", "v124", "v126", "v128", "v130", "s20", "s21");
+        } else if (KIND == 12) {
+            asm volatile(
+                "v_and_b32 v100, %2, %3\n v_and_b32 v102, %2, %3\n v_and_b32 v104, %2, %3\n v_and_b32 v106, %2, %3\n"
+                "v_and_b32 v108, %2, %3\n v_and_b32 v110, %2, %3\n v_and_b32 v112, %2, %3\n v_and_b32 v114, %2, %3\n"
+                "v_and_b32 v116, %2, %3\n v_and_b32 v118, %2, %3\n v_and_b32 v120, %2, %3\n v_and_b32 v122, %2, %3\n"
+                "v_and_b32 v124, %2, %3\n v_and_b32 v126, %2, %3\n v_and_b32 v128, %2, %3\n v_and_b32 v130, %2, %3\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116", "v118", "v120", "v122", "v124", "v126", "v128", "v130");
+        } else if (KIND == 13) {
+            asm volatile(
+                "v_bfe_i32 v100, %2, 3, 1\n v_bfe_i32 v102, %2, 3, 1\n v_bfe_i32 v104, %2, 3, 1\n v_bfe_i32 v106, %2, 3, 1\n"
+                "v_bfe_i32 v108, %2, 3, 1\n v_bfe_i32 v110, %2, 3, 1\n v_bfe_i32 v112, %2, 3, 1\n v_bfe_i32 v114, %2, 3, 1\n"
+                "v_bfe_i32 v116, %2, 3, 1\n v_bfe_i32 v118, %2, 3, 1\n v_bfe_i32 v120, %2, 3, 1\n v_bfe_i32 v122, %2, 3, 1\n"
+                "v_bfe_i32 v124, %2, 3, 1\n v_bfe_i32 v126, %2, 3, 1\n v_bfe_i32 v128, %2, 3, 1\n v_bfe_i32 v130, %2, 3, 1\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116", "v118", "v120", "v122", "v124", "v126", "v128", "v130");
+        } else if (KIND == 15) {
+            asm volatile(
+                "v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n"
+                "v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n"
+                "v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n"
+                "v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %2, %3\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116", "v118", "v120", "v122", "v124", "v126", "v128", "v130", "vcc");
+        } else if (KIND == 16) {
+            asm volatile(
+                "v_cndmask_b32_e64 v100, 0, %3, s[20:21]\n v_cndmask_b32_e64 v102, 0, %3, s[20:21]\n v_cndmask_b32_e64 v104, 0, %3, s[20:21]\n v_cndmask_b32_e64 v106, 0, %3, s[20:21]\n"
+                "v_cndmask_b32_e64 v108, 0, %3, s[20:21]\n v_cndmask_b32_e64 v110, 0, %3, s[20:21]\n v_cndmask_b32_e64 v112, 0, %3, s[20:21]\n v_cndmask_b32_e64 v114, 0, %3, s[20:21]\n"
+                "v_cndmask_b32_e64 v116, 0, %3, s[20:21]\n v_cndmask_b32_e64 v118, 0, %3, s[20:21]\n v_cndmask_b32_e64 v120, 0, %3, s[20:21]\n v_cndmask_b32_e64 v122, 0, %3, s[20:21]\n"
+                "v_cndmask_b32_e64 v124, 0, %3, s[20:21]\n v_cndmask_b32_e64 v126, 0, %3, s[20:21]\n v_cndmask_b32_e64 v128, 0, %3, s[20:21]\n v_cndmask_b32_e64 v130, 0, %3, s[20:21]\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116", "v118", "v120", "v122", "v124", "v126", "v128", "v130", "s20", "s21");
+        } else if (KIND == 17) {
+            asm volatile(
+                "v_cndmask_b32_e64 v100, %2, %3, vcc\n v_cndmask_b32_e64 v102, %2, %3, vcc\n v_cndmask_b32_e64 v104, %2, %3, vcc\n v_cndmask_b32_e64 v106, %2, %3, vcc\n"
+                "v_cndmask_b32_e64 v108, %2, %3, vcc\n v_cndmask_b32_e64 v110, %2, %3, vcc\n v_cndmask_b32_e64 v112, %2, %3, vcc\n v_cndmask_b32_e64 v114, %2, %3, vcc\n"
+                "v_cndmask_b32_e64 v116, %2, %3, vcc\n v_cndmask_b32_e64 v118, %2, %3, vcc\n v_cndmask_b32_e64 v120, %2, %3, vcc\n v_cndmask_b32_e64 v122, %2, %3, vcc\n"
+                "v_cndmask_b32_e64 v124, %2, %3, vcc\n v_cndmask_b32_e64 v126, %2, %3, vcc\n v_cndmask_b32_e64 v128, %2, %3, vcc\n v_cndmask_b32_e64 v130, %2, %3, vcc\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116", "v118", "v120", "v122", "v124", "v126", "v128", "v130", "vcc");
+        } else if (KIND == 18) {
+            asm volatile(
+                "v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n"
+                "v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n"
+                "v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n"
+                "v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n v_cmp_gt_f32_e64 s[20:21], %2, %3\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116", "v118", "v120", "v122", "v124", "v126", "v128", "v130", "s20", "s21");
+        } else if (KIND == 19) {
+            asm volatile(
+                "v_mul_legacy_f32 v100, %2, %3\n v_mul_legacy_f32 v102, %2, %3\n v_mul_legacy_f32 v104, %2, %3\n v_mul_legacy_f32 v106, %2, %3\n"
+                "v_mul_legacy_f32 v108, %2, %3\n v_mul_legacy_f32 v110, %2, %3\n v_mul_legacy_f32 v112, %2, %3\n v_mul_legacy_f32 v114, %2, %3\n"
+                "v_mul_legacy_f32 v116, %2, %3\n v_mul_legacy_f32 v118, %2, %3\n v_mul_legacy_f32 v120, %2, %3\n v_mul_legacy_f32 v122, %2, %3\n"
+                "v_mul_legacy_f32 v124, %2, %3\n v_mul_legacy_f32 v126, %2, %3\n v_mul_legacy_f32 v128, %2, %3\n v_mul_legacy_f32 v130, %2, %3\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116", "v118", "v120", "v122", "v124", "v126", "v128", "v130");
+        } else if (KIND == 14) {
+            asm volatile(
+                "s_mov_b64 s[22:23], exec\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v100, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v102, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v104, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v106, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v108, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v110, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v112, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v114, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v116, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v118, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v120, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v122, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v124, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v126, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v128, 0\n"
+                "s_mov_b64 exec, s[20:21]\n v_mov_b32 v130, 0\n"
+                "s_mov_b64 exec, s[22:23]\n"
+                : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v102", "v104", "v106", "v108", "v110", "v112", "v114", "v116", "v118", "v120", "v122", "v124", "v126", "v128", "v130", "s20", "s21", "s22", "s23");
+        } else if (KIND == 20) {                                  // 4 independent MFMAs (each its own accumulator)
+            asm volatile("v_mfma_f32_32x32x16_bf16 v[132:147], v[100:103], v[104:107], v[132:147]\nv_mfma_f32_32x32x16_bf16 v[148:163], v[100:103], v[104:107], v[148:163]\nv_mfma_f32_32x32x16_bf16 v[164:179], v[100:103], v[104:107], v[164:179]\nv_mfma_f32_32x32x16_bf16 v[180:195], v[100:103], v[104:107], v[180:195]\n" : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195");
+        } else if (KIND == 21) {                                  // the same 4 MFMAs with 8 independent v_fma behind each
+            asm volatile("v_mfma_f32_32x32x16_bf16 v[132:147], v[100:103], v[104:107], v[132:147]\nv_fma_f32 v108, %2, %3, %2\nv_fma_f32 v110, %2, %3, %2\nv_fma_f32 v112, %2, %3, %2\nv_fma_f32 v114, %2, %3, %2\nv_fma_f32 v116, %2, %3, %2\nv_fma_f32 v118, %2, %3, %2\nv_fma_f32 v120, %2, %3, %2\nv_fma_f32 v122, %2, %3, %2\nv_mfma_f32_32x32x16_bf16 v[148:163], v[100:103], v[104:107], v[148:163]\nv_fma_f32 v108, %2, %3, %2\nv_fma_f32 v110, %2, %3, %2\nv_fma_f32 v112, %2, %3, %2\nv_fma_f32 v114, %2, %3, %2\nv_fma_f32 v116, %2, %3, %2\nv_fma_f32 v118, %2, %3, %2\nv_fma_f32 v120, %2, %3, %2\nv_fma_f32 v122, %2, %3, %2\nv_mfma_f32_32x32x16_bf16 v[164:179], v[100:103], v[104:107], v[164:179]\nv_fma_f32 v108, %2, %3, %2\nv_fma_f32 v110, %2, %3, %2\nv_fma_f32 v112, %2, %3, %2\nv_fma_f32 v114, %2, %3, %2\nv_fma_f32 v116, %2, %3, %2\nv_fma_f32 v118, %2, %3, %2\nv_fma_f32 v120, %2, %3, %2\nv_fma_f32 v122, %2, %3, %2\nv_mfma_f32_32x32x16_bf16 v[180:195], v[100:103], v[104:107], v[180:195]\nv_fma_f32 v108, %2, %3, %2\nv_fma_f32 v110, %2, %3, %2\nv_fma_f32 v112, %2, %3, %2\nv_fma_f32 v114, %2, %3, %2\nv_fma_f32 v116, %2, %3, %2\nv_fma_f32 v118, %2, %3, %2\nv_fma_f32 v120, %2, %3, %2\nv_fma_f32 v122, %2, %3, %2\n" : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195");
+        } else if (KIND == 22) {                                  // the 32 v_fma alone
+            asm volatile("v_fma_f32 v108, %2, %3, %2\nv_fma_f32 v110, %2, %3, %2\nv_fma_f32 v112, %2, %3, %2\nv_fma_f32 v114, %2, %3, %2\nv_fma_f32 v116, %2, %3, %2\nv_fma_f32 v118, %2, %3, %2\nv_fma_f32 v120, %2, %3, %2\nv_fma_f32 v122, %2, %3, %2\nv_fma_f32 v108, %2, %3, %2\nv_fma_f32 v110, %2, %3, %2\nv_fma_f32 v112, %2, %3, %2\nv_fma_f32 v114, %2, %3, %2\nv_fma_f32 v116, %2, %3, %2\nv_fma_f32 v118, %2, %3, %2\nv_fma_f32 v120, %2, %3, %2\nv_fma_f32 v122, %2, %3, %2\nv_fma_f32 v108, %2, %3, %2\nv_fma_f32 v110, %2, %3, %2\nv_fma_f32 v112, %2, %3, %2\nv_fma_f32 v114, %2, %3, %2\nv_fma_f32 v116, %2, %3, %2\nv_fma_f32 v118, %2, %3, %2\nv_fma_f32 v120, %2, %3, %2\nv_fma_f32 v122, %2, %3, %2\nv_fma_f32 v108, %2, %3, %2\nv_fma_f32 v110, %2, %3, %2\nv_fma_f32 v112, %2, %3, %2\nv_fma_f32 v114, %2, %3, %2\nv_fma_f32 v116, %2, %3, %2\nv_fma_f32 v118, %2, %3, %2\nv_fma_f32 v120, %2, %3, %2\nv_fma_f32 v122, %2, %3, %2\n" : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195");
+        } else if (KIND == 23) {                                  // 4 MFMAs with 8 v_exp behind each
+            asm volatile("v_mfma_f32_32x32x16_bf16 v[132:147], v[100:103], v[104:107], v[132:147]\nv_exp_f32 v108, %2\nv_exp_f32 v110, %2\nv_exp_f32 v112, %2\nv_exp_f32 v114, %2\nv_exp_f32 v116, %2\nv_exp_f32 v118, %2\nv_exp_f32 v120, %2\nv_exp_f32 v122, %2\nv_mfma_f32_32x32x16_bf16 v[148:163], v[100:103], v[104:107], v[148:163]\nv_exp_f32 v108, %2\nv_exp_f32 v110, %2\nv_exp_f32 v112, %2\nv_exp_f32 v114, %2\nv_exp_f32 v116, %2\nv_exp_f32 v118, %2\nv_exp_f32 v120, %2\nv_exp_f32 v122, %2\nv_mfma_f32_32x32x16_bf16 v[164:179], v[100:103], v[104:107], v[164:179]\nv_exp_f32 v108, %2\nv_exp_f32 v110, %2\nv_exp_f32 v112, %2\nv_exp_f32 v114, %2\nv_exp_f32 v116, %2\nv_exp_f32 v118, %2\nv_exp_f32 v120, %2\nv_exp_f32 v122, %2\nv_mfma_f32_32x32x16_bf16 v[180:195], v[100:103], v[104:107], v[180:195]\nv_exp_f32 v108, %2\nv_exp_f32 v110, %2\nv_exp_f32 v112, %2\nv_exp_f32 v114, %2\nv_exp_f32 v116, %2\nv_exp_f32 v118, %2\nv_exp_f32 v120, %2\nv_exp_f32 v122, %2\n" : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195");
         }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    const unsigned long long r1 = wall_clock64();
+    if (a == 12345.f) out[0] = a + b;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
-template <int OP>
-static void run(const char* name, uint32_t* d) {
-    const int iters = 2000;
-    for (int wps = 1; wps <= 4; wps *= 2) {          // waves per SIMD
-        dim3 grid(256), block(256 * wps);            // 1 block per CU: 4*wps waves per CU
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipLaunchKernelGGL(probe<OP>, grid, block, 0, 0, d, 10, 1u);
-        hipEventRecord(e0);
-        hipLaunchKernelGGL(probe<OP>, grid, block, 0, 0, d, iters, 1u);
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        // cycles per wave-instruction per SIMD at 2.4 GHz: each SIMD issued wps * iters * 32 instructions
-        double cyc = ms * 1e-3 * 2.4e9 / ((double)wps * iters * 32);
-        printf("%-18s waves/SIMD %d: %.2f cycles per wave-instruction (SIMD-level)\n", name, wps, cyc);
+template <int KIND>
+static int run(const char* name, int blocks_per_cu, float* out, unsigned long long* clk) {
+    hipEvent_t t0, t1;
+    CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+    float best = 1e9f;
+    unsigned long long h[2] = {0, 0};
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(t0, 0));
+        hipLaunchKernelGGL(rate_kernel<KIND>, dim3(256 * blocks_per_cu), dim3(256), 0, 0, out, clk);
+        CK(hipEventRecord(t1, 0));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, t0, t1));
+        if (ms < best) { best = ms; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost)); }
     }
+    // a SIMD hosts blocks_per_cu waves (one wave of each 4-wave workgroup); instructions per SIMD = waves x REPS x 16
+    const double insts = (double)blocks_per_cu * REPS * 16;
+    const double ghz = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0.0;                 // shader cycles per ns (100 MHz wall clock)
+    printf("%-22s %d waves/SIMD: %8.1f us   %6.2f ns per instruction per SIMD   shader clock %.2f GHz -> %5.2f cycles\n", name,
+           blocks_per_cu, best * 1e3, best * 1e6 / insts, ghz, best * 1e6 / insts * ghz);
+    return 0;
 }
 
 int main() {
-    uint32_t* d; hipMalloc(&d, 256 * 1024 * 4);
-    run<1>("v_xor_b32", d); run<0>("v_mul_lo_u32", d); run<7>("v_mul_hi_u32", d); run<2>("v_mul_u32_u24", d);
-    run<4>("v_mad_u32_u24", d); run<3>("v_exp_f32", d); run<5>("v_cndmask_b32", d); run<6>("v_fma_f32", d);
-    run<8>("v_xad_u32", d); run<9>("v_alignbit_b32", d); run<10>("v_cmp_le_u32", d); run<11>("v_pk_mul_f32", d);
-    run<12>("v_bfe_u32", d); run<13>("v_cvt_pk_bf16_f32", d);
-    run<14>("v_cndmask e64 sgpr", d); run<15>("v_cmp+v_cndmask (x16)", d); run<16>("v_cndmask dst!=src", d);
-    run<17>("v_and_b32", d); run<18>("v_bfe_i32", d); run<19>("v_max3_f32", d); run<20>("v_mul_f32", d); run<21>("v_add_u32", d);
+    float* out;
+    unsigned long long* clk;
+    CK(hipMalloc(&out, 64)); CK(hipMalloc(&clk, 64));
+    for (int w = 1; w <= 4; w *= 2) {
+        run<0>("v_fma_f32", w, out, clk);
+        run<7>("v_mul_f32", w, out, clk);
+        run<2>("v_pk_fma_f32", w, out, clk);
+        run<6>("v_pk_mul_f32", w, out, clk);
+        run<10>("v_pk_add_f32", w, out, clk);
+        run<1>("v_exp_f32", w, out, clk);
+        run<3>("v_cndmask_b32 (vcc)", w, out, clk);
+        run<4>("v_cvt_pk_bf16_f32", w, out, clk);
+        run<5>("v_max3_f32", w, out, clk);
+        run<8>("v_permlane32_swap_b32", w, out, clk);
+        run<9>("v_mov_b32 dpp row_shr", w, out, clk);
+        run<17>("v_cndmask_b32_e64 vcc", w, out, clk);
+        run<11>("v_cndmask_b32_e64 sgpr", w, out, clk);
+        run<16>("v_cndmask_e64 0,v,sgpr", w, out, clk);
+        run<12>("v_and_b32", w, out, clk);
+        run<13>("v_bfe_i32", w, out, clk);
+        run<14>("s_mov exec + v_mov", w, out, clk);
+        run<15>("v_cmp_gt_f32 vcc", w, out, clk);
+        run<18>("v_cmp_gt_f32 sgpr", w, out, clk);
+        run<19>("v_mul_legacy_f32", w, out, clk);
+        run<20>("4 mfma 32x32x16 (per 16)", w, out, clk);
+        run<21>("4 mfma + 32 v_fma (per 16)", w, out, clk);
+        run<22>("32 v_fma (per 16)", w, out, clk);
+        run<23>("4 mfma + 32 v_exp (per 16)", w, out, clk);
+    }
     return 0;
 }

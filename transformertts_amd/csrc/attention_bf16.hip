@@ -30,6 +30,24 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
+// Lanes l and l ^ 32 exchange a value through v_permlane32_swap_b32 (gfx950: one VALU instruction, ~8 cycles) instead of
+// ds_bpermute (an LDS round trip the caller then waits for: the row maximum sits on every score block's critical path).
+// Both halves get the SAME bits (max / + of the same two operands, commutative).
+__device__ __forceinline__ void xhalf_pair(float v, float& lo, float& hi) {
+    // Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc 7.2 folds the builtin's two results into one (max(r[0], r[1])
+    // became r[0], r[0] + r[1] became 2 r[0] - found as a 29 % error of the context rows), whatever its operands are.
+    // s_nop 1: the operands were just written by VALU instructions the hazard recogniser cannot see into the asm for.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));    // a = lanes 0-31's value, b = lanes 32-63's
+    lo = a;
+    hi = b;
+}
+__device__ __forceinline__ float xhalf_max(float v) {                       // (the max inside the asm: fmaxf on asm results
+    float a = v, b = v;                                                      //  would first canonicalise both operands)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+    return a;
+}
+__device__ __forceinline__ float xhalf_sum(float v) { float a, b; xhalf_pair(v, a, b); return a + b; }
 
 struct HAttnP {
     const float* qkv; long ld;
@@ -444,6 +462,9 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
         hmask_request(mw, mrow);
     }
 
+    // measurement build only (TTSMI_ATTN_FWD_ABLATE, results WRONG): 1 = no global fetch inside the loop (the first tile is
+    // stashed again and again), 2 = no exponentials, 4 = no keep-bit selects, 8 = no barriers and no stash at all, 16 / 32 = no K / V fragment reads
+    const int abl = TTSMI_ABLATE_BITS(p.ablate);
     Tile<DH, QH> rk, rv;
     // The padding byte of the NEXT tile is only LOADED in the fetch phase and turned into a float when the tile is
     // stashed (HPAD_*): any arithmetic on it right after the load put an `s_waitcnt vmcnt(0)` behind the K / V prefetch
@@ -460,13 +481,16 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
         HPAD_FETCH(kbeg, nv);
     }
     for (int k0 = kbeg; k0 < klen; k0 += HKT) {
-        __syncthreads();
-        rk.stash(Ks, tid);
-        rv.stash(Vs, tid);
-        HPAD_STASH();
-        __syncthreads();
-        const int anypad = HPAD_ANY();
-        if (k0 + HKT < klen) {
+        int anypad = 0;
+        if (!(abl & 8) || k0 == kbeg) {
+            __syncthreads();
+            rk.stash(Ks, tid);
+            rv.stash(Vs, tid);
+            HPAD_STASH();
+            __syncthreads();
+            anypad = HPAD_ANY();
+        }
+        if (k0 + HKT < klen && !(abl & 1)) {
             int nv = min(HKT, klen - (k0 + HKT));
             rk.fetch(Kb, p.ld, k0 + HKT, nv, tid);
             rv.fetch(Vb, p.ld, k0 + HKT, nv, tid);
@@ -476,7 +500,15 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
         for (int kt = 0; kt < HKT / 32; ++kt) {
             const int kbase = k0 + kt * 32;
             if (kbase >= klen || !wave_live) break;
-            f32x16 s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                 // S^T[key][q]
+            f32x16 s;
+            if (abl & 16) {                                                   // (measurement: no K fragment reads)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < DH / 16; ++t) s = MFMA16(qf[t], qf[t], s);
+            } else {
+                s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                     // S^T[key][q]
+            }
             // The 1 / sqrt(dh) scale (c1, log2 units) rides in the exponent's fma: p = 2^(s c1 - m).  Only a block with a
             // padded key or the ragged tail needs the logits themselves scaled first (wave-uniform branch, rare).
             float cs = c1;
@@ -497,11 +529,16 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * cs;              // cs > 0: max commutes with the scale
+            mx = xhalf_max(mx) * cs;                                  // cs > 0: max commutes with the scale
             const float mn = fmaxf(m, mx);
             const float alpha = EXP2(m - mn);
+            if (abl & 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = EXP2(fmaf(s[r], cs, -mn));
+                for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], cs, -mn);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = EXP2(fmaf(s[r], cs, -mn));
+            }
             f32x2 rs2 = {s[0], s[1]};                                 // pairwise: packed adds
 #pragma unroll
             for (int r = 2; r < 16; r += 2) rs2 += f32x2{s[r], s[r + 1]};
@@ -517,11 +554,11 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
             }
             if (DROP == 2) {
                 hmask_wait(mw);
-                hmask_apply_all(s, mw);
+                if (!(abl & 4)) hmask_apply_all(s, mw);
                 hmask_request(mw, mrow + min((kbase >> 5) + 1, ntile32 - 1) * 16);      // the next block's words
             }
-            rs += __shfl_xor(rs, 32, 64);
-            l = l * alpha + rs;
+            l = l * alpha + rs;                                       // this HALF's keys only: the halves share m, so their
+                                                                      // sums are added once, after the last tile
             m = mn;
             if (!__all(alpha == 1.0f)) {
 #pragma unroll
@@ -531,10 +568,18 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
             }
             bf16x8 pb[2];
             to_frags(s, pb);
-            accumTR<DH>(Vs, kt * 32, lane, pb, o);                            // O^T += V^T.P^T
+            if (abl & 32) {                                                   // (measurement: no V fragment reads)
+#pragma unroll
+                for (int cb = 0; cb < DH / 32; ++cb)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) o[cb] = MFMA16(pb[t], pb[t], o[cb]);
+            } else {
+                accumTR<DH>(Vs, kt * 32, lane, pb, o);                        // O^T += V^T.P^T
+            }
         }
     }
     __syncthreads();
+    l = xhalf_sum(l);
     // (an empty key range - a split past the last unpadded key - leaves l = 0: weight 0 in the combine)
     const long sp = p.split_keys ? blockIdx.y : 0;
     if (qok && hh == 0) p.lse[sp * p.lse_split + ((long)b * p.H + h) * p.T + q] = l > 0.f ? (m + log2f(l)) * LN2 : -INFINITY;
@@ -601,7 +646,7 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dq_kernel(HAtt
             }
         }
     }
-    delta += __shfl_xor(delta, 32, 64);
+    delta = xhalf_sum(delta);
     const long sidx = ((long)b * p.H + h) * p.T + q;
     if (qok && hh == 0) p.delta[sidx] = delta;
     const float lse2 = qok ? p.lse[sidx] * LOG2E : INFINITY;
@@ -891,32 +936,38 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
 // of products and ONE softmax recomputation.
 //
 // dQ still has to be summed over the key tiles of a head, i.e. ACROSS workgroups - reproducibly, so no float atomics.
-// The running sum of a (head, 64-query tile) travels down the key tiles j = 0 -> 1 -> ... through ONE fp32 register image
-// (16 KB) in scratch: key tile j waits for flag == j, adds the image to its own product, stores it back and posts j + 1;
-// the last key tile with unpadded keys converts to bf16 and writes dqkv.  The order is fixed, so the bits are.  All key
-// tiles of a head are dispatched to one XCD (block id = 8 * slot + xcd; head = xcd + 8 * (slot / nkt), key tile = slot %
-// nkt; XCC_ID == block id % 8 on this part - tools/probes/xcd_sem_probe.hip - and re-checked here: diag[1]), so the
-// image (31 MB for a whole decoder layer, rewritten in place 8 times) lives in that XCD's L2: plain write-through stores,
-// `s_waitcnt vmcnt(0)` + a barrier before the flag, L1-bypassing (agent-scope) loads on the reading side; no L2 write-back
-// / invalidate (what an agent-scope release / acquire fence costs on a multi-XCD part; the probe shows the same protocol
-// reading stale data ACROSS XCDs and being exact inside one).
+// The running sum of a (head, 64-query tile) travels from key tile to key tile through ONE fp32 register image (16 KB) in
+// scratch: the k-th contributor of a query tile waits for flag == k, adds the image to its own product, stores it back and
+// posts k + 1; the last one converts to bf16 and writes dqkv.  The order of the contributors of a query tile is fixed (see
+// the rotated visiting order in the kernel), so the bits are.  All key tiles of a head are dispatched to one XCD (block id =
+// 8 * slot + xcd; head = xcd + 8 * (slot / nkt), key tile = slot % nkt; XCC_ID == block id % 8 on this part -
+// tools/probes/xcd_sem_probe.hip - and re-checked here: diag[1]), so the image (31 MB for a whole decoder layer, rewritten
+// in place 8 times) lives in that XCD's L2: plain write-through stores, `s_waitcnt vmcnt(0)` + a barrier before the flag,
+// L1-bypassing (agent-scope) loads on the reading side; no L2 write-back / invalidate (what an agent-scope release / acquire
+// fence costs on a multi-XCD part; the probe shows the same protocol reading stale data ACROSS XCDs and being exact inside
+// one).
 // Three round trips per hand-off are kept off the critical path (the first version exposed them: +2.6 us on a 2.9 us
 // step): every wave issues its own flag load right after the barrier that starts a step and looks at the value after the
 // two query sub-tiles; the incoming image is requested as soon as the flag is seen, before the barrier that completes the
 // dS image, and added after the dQ product; the outgoing image's acknowledgement is waited for one step later (before the
 // next step's second barrier), where the flag is posted; the barriers inside the loop order LDS only (hlds_barrier: a
 // __syncthreads() drains the vector-memory counter, i.e. waits for exactly those round trips - 203 vs 139 us measured).
-// A key tile therefore runs about one step behind its predecessor.  Waits are bounded: one that never ends raises diag[0] and the kernel finishes (with a wrong dQ) instead
-// of hanging; a workgroup only waits for a LOWER block id of its own XCD.  Flags reset themselves (the last key tile
-// posts 0), so their region only has to be zero once, at allocation (ttsmi_attention_bwd_fused_ws_init).
-// STATUS (round 4): correct, bit-reproducible, tested - and NOT faster than the two kernels at the benchmark shape, so it is
-// opt-in (TTSMI_ATTN_FUSED_BWD=1 for the planned dense blocks; the entry point is always available).  Decoder layer, (32, 4,
-// 900, 64), keep-bit dropout: two kernels 183 us, this kernel 222 us.  Its timeline (tools/debug/fused_bwd_timeline.py on
-// a measurement build): key tile 0, which never waits, lives 65 us = 4.2 us per step where the dK/dV kernel takes 2.9;
-// tile j waits 3.5-4 us per link of the chain in total (tile 7: 27 us of its 95).  Stage ablation of the same build
-// (TTSMI_ATTN_FUSED_ABLATE): no hand-offs 147 us, also no image stores 137, also no dQ product 130 - i.e. the best any
-// hand-off scheme could reach is 147 against 183, and the dK/dV core of THIS kernel (third staged tile, in-kernel delta,
-// dS image writes, a third barrier per step) is 124 us where the dedicated kernel is 87.
+// Waits are bounded: one that never ends raises diag[0] and the kernel finishes (with a wrong dQ) instead of hanging.  A
+// workgroup waits for workgroups of its own head only; block ids are dispatched in order and a head's key tiles have
+// consecutive slots of one XCD, so at most the NEWEST head of an XCD is partly resident - every other resident workgroup
+// has its whole head beside it and finishes without anybody's help, which frees the slots the newest head is waiting for.
+// Flags reset themselves (the last contributor posts 0), so their region only has to be zero once, at allocation
+// (ttsmi_attention_bwd_fused_ws_init).
+// STATUS (round 4): correct, bit-reproducible, tested; opt-in (TTSMI_ATTN_FUSED_BWD=1 for the planned dense blocks; the
+// entry point is always available).  Decoder layer (32, 4, 900, 64), keep-bit dropout, ALONE: two kernels 181 us, this
+// kernel 166 us (with its delta launch); first version 222 us - every key tile walked the query tiles 0, 1, 2 ... and the
+// chain was a pipeline that fills (key tile 7 waited 27 of its 95 us; tools/debug/fused_bwd_timeline.py) - 182 us with the
+// rotated order, 166 us with delta taken out of the loop.  INSIDE the train step it still loses: 5.18 against 5.10 ms
+// per step (4.97 / 4.91 without the weight-gradient stream beside it): a launch that follows a draining kernel gets its
+// slots one at a time, heads stay partly resident for longer, and a workgroup that spins keeps a slot busy - the two
+// kernels have no workgroup that waits for another.  What is left per step of a key tile besides the dK/dV kernel's work:
+// the dS image (written and read back transposed), the dQ product, 16 KB of image in and 16 KB out through L2 (0.5 GB per
+// decoder layer), a third barrier.
 // (Also measured: a ticket scheme without any waiting - every key tile stores its own partial image, the last arrival adds
 // them in fixed order - is 40 % SLOWER than the two kernels: 251 MB of partials per decoder layer do not stay in L2.)
 __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* img, int k0, int t, int colblock, int lane) {
@@ -943,6 +994,31 @@ __device__ __forceinline__ float row16_sum(float v) {          // sum over the 1
 // (s_waitcnt vmcnt(0)): every barrier of a step would then wait for the dQ image stores to be acknowledged, for the
 // incoming image and for the next tile's prefetch - the round trips this kernel keeps in flight across its barriers.
 __device__ __forceinline__ void hlds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// delta[b, h, t] = sum_c dO[b, t, h, c] O[b, t, h, c] for the one-pass backward (bf16 tensors, head dim 64): 8 lanes share a
+// (row, head) pair, 16 bytes of each tensor per lane.  Every key tile of a head needs the value of every query BEFORE its
+// scores, so it cannot travel down the chain; computed inside the one-pass kernel it was a third staged tile and 16 DPP
+// sums per step in each of the 8 key tiles of a head (the two-kernel backward takes it from its dQ kernel).
+__global__ __launch_bounds__(256) void hattn_delta_kernel(const uint16_t* __restrict__ dO, const uint16_t* __restrict__ O,
+                                                          float* __restrict__ delta, int B, int H, int T) {
+    const int lane = threadIdx.x & 63;
+    const long pair = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);       // (row, head)
+    const long rows = (long)B * T;
+    const bool ok = pair < rows * H;
+    const long row = ok ? pair / H : 0;
+    const int h = ok ? (int)(pair - row * H) : 0;
+    const long off = row * (long)(H * 64) + h * 64 + (lane & 7) * 8;
+    const uint4 xa = *reinterpret_cast<const uint4*>(dO + off), ya = *reinterpret_cast<const uint4*>(O + off);
+    const bf16x8 x = __builtin_bit_cast(bf16x8, xa), y = __builtin_bit_cast(bf16x8, ya);
+    float v = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v += (float)x[e] * (float)y[e];
+    v += ttsmi_dpp<TTSMI_DPP_QUAD_1032, 0xF>(v, 0.f);
+    v += ttsmi_dpp<TTSMI_DPP_QUAD_2301, 0xF>(v, 0.f);
+    v += ttsmi_dpp<TTSMI_DPP_ROW_HALF_MIRROR, 0xF>(v, 0.f);                 // every lane: the sum of its group of 8
+    const long b = row / T, t = row - b * T;
+    if (ok && (lane & 7) == 0) delta[(b * H + h) * T + t] = v;
+}
 
 template <int DH, int DROP>
 __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
@@ -980,14 +1056,19 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
     const bool kact = key < klen;
     const bool wave_live = (bx * 128 + wave * 32) < klen;
     const bool wg_active = bx < nact;
-    const bool chain_last = bx == nact - 1;
     const int abl = TTSMI_ABLATE_BITS(p.ablate);
-    const bool chained = bx > 0 && !(abl & 1);
+    // ROTATED visiting order: key tile j walks the query tiles (s + j c) mod nqt, s = 0 .. nqt - 1.  With every key tile
+    // walking 0, 1, 2 ... the chain was a pipeline that FILLS: key tile j could not add anything before step j (tile 7 of
+    // the benchmark shape spent 27 of its 95 us waiting).  Rotated, the active key tiles start on nact DIFFERENT query
+    // tiles - each opens that tile's sum instead of waiting for it - and afterwards always find a tile whose previous
+    // contributor finished it at least one step earlier.  The order in which the key tiles add to ONE query tile is still
+    // fixed (by the steps at which they reach it), so the bits are; it differs from query tile to query tile.
+    const int rot_c = nact > 1 ? max(1, (nqt - 1) / (nact - 1)) : 1;         // offsets j c <= nqt - 1: all different
+    const int rot_off = bx * rot_c;
     const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
     const float* Kb = eptr<QH>(Qb, d);
     const float* Vb = eptr<QH>(Qb, 2 * d);
     const float* dOb = eptr<QH>(p.dctx, (long)b * p.T * d + h * DH);
-    const float* Ob = eptr<QH>(p.octx, (long)b * p.T * d + h * DH);
 
     f32x16 dk[DH / 32], dv[DH / 32];
 #pragma unroll
@@ -1041,34 +1122,39 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
         bool dead = false;                               // (wave-uniform) a hand-off timed out: stop waiting, finish the kernel
         int post = -1;                                   // (thread 0) flag to post for the previous tile, once its stores are acknowledged
 
-        Tile<DH, QH> rq, ro, rc;
-        float rl = 0.f;
+        Tile<DH, QH> rq, ro;
+        float rl = 0.f, rdl = 0.f;
         int rnv = 0;
         {
-            int nv = min(HKT, p.T);
-            rq.fetch(Qb, p.ld, 0, nv, tid);
-            ro.fetch(dOb, d, 0, nv, tid);
-            rc.fetch(Ob, d, 0, nv, tid);
-            mask_fetch(0);
+            const int qf = (rot_off % nqt) * HKT;
+            int nv = min(HKT, p.T - qf);
+            rq.fetch(Qb, p.ld, qf, nv, tid);
+            ro.fetch(dOb, d, qf, nv, tid);
+            mask_fetch(qf);
             rnv = nv;
-            if (tid < HKT) rl = p.lse[stat0 + min(tid, p.T - 1)];
+            if (tid < HKT) {
+                rl = p.lse[stat0 + min(qf + tid, p.T - 1)];
+                rdl = p.delta[stat0 + min(qf + tid, p.T - 1)];
+            }
         }
-        for (int q0 = 0, it = 0; q0 < p.T; q0 += HKT, ++it) {
+        int post_it = 0;                                 // the query tile `post` belongs to
+        for (int st = 0; st < nqt; ++st) {
+            const int it = (st + rot_off) % nqt, q0 = it * HKT;              // this step's query tile
+            // position of this key tile among the contributors of query tile `it`: the active key tiles ordered by the step
+            // at which they reach it (all different)
+            int pos = 0;
+            for (int j = 0; j < nact; ++j) {
+                int sj = it - j * rot_c;
+                sj += sj < 0 ? nqt : 0;
+                pos += sj < st ? 1 : 0;
+            }
+            const bool chained = pos > 0 && !(abl & 1);
+            const bool chain_last = pos == nact - 1;
             hlds_barrier();                                    // nobody still reads the previous step's Q / dO / dS images
             rq.stash(Qs, tid);
             ro.stash(Os, tid);
-            {
-                // delta = rowsum(dO * O) of the staged rows: a thread holds 4 columns of rows tid / 16 + 16 i, the 16 lanes
-                // of a DPP row share a row.  dS = P (keep dP / (1 - p) - delta) / sqrt(dh): the scale is folded in.
-#pragma unroll
-                for (int i = 0; i < DH / 16; ++i) {
-                    const bf16x4 x = __builtin_bit_cast(bf16x4, ro.h[i]), y = __builtin_bit_cast(bf16x4, rc.h[i]);
-                    float sdl = (float)x[0] * (float)y[0] + (float)x[1] * (float)y[1] + (float)x[2] * (float)y[2] + (float)x[3] * (float)y[3];
-                    sdl = row16_sum(sdl);
-                    if ((tid & 15) == 0) delS[(tid >> 4) + 16 * i] = sdl * inv_sqrt;
-                }
-            }
             if (tid < HKT) {
+                delS[tid] = rdl * inv_sqrt;      // dS = P (keep dP / (1 - p) - delta) / sqrt(dh): the scale is folded in
                 lseS[tid] = tid < rnv ? rl * LOG2E : INFINITY;
                 if (DROP == 1) rbS[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0 + tid));
             }
@@ -1080,20 +1166,23 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             hlds_barrier();
             if (tid == 0 && post >= 0) {
-                __hip_atomic_store(sem + it - 1, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sem + post_it, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 post = -1;
             }
             // every wave reads this tile's flag for itself, now; the value is looked at after the sub-tiles
             int flag = 0;
             if (chained && !dead) flag = __hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (q0 + HKT < p.T) {
-                int nv = min(HKT, p.T - (q0 + HKT));
-                rq.fetch(Qb, p.ld, q0 + HKT, nv, tid);
-                ro.fetch(dOb, d, q0 + HKT, nv, tid);
-                rc.fetch(Ob, d, q0 + HKT, nv, tid);
-                mask_fetch(q0 + HKT);
+            if (st + 1 < nqt) {
+                const int qn = ((st + 1 + rot_off) % nqt) * HKT;
+                int nv = min(HKT, p.T - qn);
+                rq.fetch(Qb, p.ld, qn, nv, tid);
+                ro.fetch(dOb, d, qn, nv, tid);
+                mask_fetch(qn);
                 rnv = nv;
-                if (tid < HKT) rl = p.lse[stat0 + min(q0 + HKT + tid, p.T - 1)];
+                if (tid < HKT) {
+                    rl = p.lse[stat0 + min(qn + tid, p.T - 1)];
+                    rdl = p.delta[stat0 + min(qn + tid, p.T - 1)];
+                }
             }
 #pragma unroll
             for (int qt = 0; qt < HKT / 32; ++qt) {
@@ -1146,7 +1235,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
 #ifdef TTSMI_ABLATION_BUILD
                     const unsigned long long dbg_w0 = __builtin_amdgcn_s_memrealtime();
 #endif
-                    while ((flag & 0xFF) != bx) {
+                    while ((flag & 0xFF) != pos) {
                         __builtin_amdgcn_s_sleep(1);
                         flag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                         if (++spins > HFUSED_SPIN_LIMIT ||
@@ -1162,7 +1251,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
                         const unsigned long long dbg_w1 = __builtin_amdgcn_s_memrealtime();
                         dbg_spin += dbg_w1 - dbg_w0;
                         dbg_polls += spins;
-                        if (it == 0) dbg_first = dbg_w1 - dbg_t0;
+                        if (st == 0) dbg_first = dbg_w1 - dbg_t0;
                     }
 #endif
                 }
@@ -1200,11 +1289,11 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r * 64] = dq[r];       // plain stores: written through to the XCD's L2
             }
-            if (tid == 0) post = chain_last ? 0 : ((bx + 1) | ((int)xid << 8));
+            if (tid == 0) { post = chain_last ? 0 : ((pos + 1) | ((int)xid << 8)); post_it = it; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         hlds_barrier();
-        if (tid == 0 && post >= 0) __hip_atomic_store(sem + nqt - 1, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && post >= 0) __hip_atomic_store(sem + post_it, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     // dK / dV of this workgroup's 128 keys (zeros for a key tile past the last unpadded key)
@@ -1547,6 +1636,8 @@ int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     p.ctx = (float*)ctx; p.lse = lse;
     dim3 grid(ttsmi_cdiv(T, 128) * H * B);
     TTSMI_KNOB(fwd_pad, "TTSMI_ATTN_FWD_LDS", 0);        // A/B knob: 24576 caps the forward at 3 workgroups per CU
+    TTSMI_ABLATE_KNOB(fwd_abl, "TTSMI_ATTN_FWD_ABLATE");  // measurement build only (see the kernel)
+    p.ablate = fwd_abl;
     HDISPATCH_LDS(dh, hattn_fwd_kernel, grid, fwd_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_fwd(bf16)");
     return TTSMI_OK;
@@ -1593,18 +1684,20 @@ extern "C" int ttsmi_debug_fused_dump(unsigned long long* host, int max_blocks) 
 // Workspace layout (bytes): [0, 16) four int32 diagnostic counters ([0]: hand-offs that timed out, [1]: hand-offs between
 // different XCC ids / workgroups off their XCD; both stay 0), [16, 16 + S) the hand-off flags, one per (head, 64-query
 // tile) (S from the workspace size alone, so the region does not move with the batch shape and stays all-zero between
-// launches), then the fp32 dQ images [head][query tile][4096].
+// launches), then the fp32 dQ images [head][query tile][4096], then delta [batch][head][T] (hattn_delta_kernel).
 static size_t hfused_flag_bytes(size_t ws_bytes) { return ((ws_bytes / 4096 + 255) / 256) * 256; }
+static size_t hfused_delta_bytes(int B, int H, int T) { return (((size_t)B * H * T * sizeof(float) + 255) / 256) * 256; }
 size_t ttsmi_hattention_bwd_fused_ws_bytes(int B, int H, int T) {
     const size_t tiles = (size_t)B * H * ttsmi_cdiv(T, HKT);
     const size_t acc = tiles * 16384;
-    return 16 + hfused_flag_bytes(acc + acc / 2048 + 8192) + 512 + acc;
+    const size_t dl = hfused_delta_bytes(B, H, T);
+    return 16 + hfused_flag_bytes(acc + dl + acc / 2048 + 8192) + 512 + acc + dl;
 }
 int ttsmi_hattention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes) {
     if (dh != 64 || B <= 0 || H <= 0 || T <= 0) return 0;
     const size_t flags = hfused_flag_bytes(ws_bytes);
     const size_t qtiles = (size_t)B * H * ttsmi_cdiv(T, HKT);
-    return qtiles * 4 <= flags && 16 + flags + 256 + qtiles * 16384 <= ws_bytes;
+    return qtiles * 4 <= flags && 16 + flags + 256 + qtiles * 16384 + hfused_delta_bytes(B, H, T) <= ws_bytes;
 }
 int ttsmi_hattention_bwd_fused_ws_init(void* ws, size_t ws_bytes, hipStream_t st) {
     TTSMI_CHECK_ARG(ws && ws_bytes >= 4096 && (((uintptr_t)ws) & 255) == 0, "attention_bwd_fused_ws_init: workspace missing, < 4096 bytes or not 256-byte aligned");
@@ -1633,6 +1726,9 @@ int ttsmi_hattention_bwd_fused(const void* qkv, const uint8_t* key_pad, const in
     p.diag = (int*)ws;
     p.sem = (int*)((char*)ws + 16);
     p.dq_acc = (float*)((char*)ws + 16 + hfused_flag_bytes(ws_bytes) + 240);        // 256-byte aligned
+    p.delta = p.dq_acc + (size_t)B * H * ttsmi_cdiv(T, HKT) * 4096;                  // [B][H][T], behind the images
+    hipLaunchKernelGGL(hattn_delta_kernel, dim3((unsigned)ttsmi_cdiv((long)B * T * H, 32)), dim3(256), 0, st,
+                       (const uint16_t*)dctx, (const uint16_t*)ctx, p.delta, B, H, T);
     const int nkt = ttsmi_cdiv(T, 128), groups = B * H;
     dim3 grid(8 * ttsmi_cdiv(groups, 8) * nkt);
     p.dbg = nullptr;
