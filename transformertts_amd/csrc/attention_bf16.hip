@@ -1040,8 +1040,16 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkt = (p.T + 127) >> 7, nqt = (p.T + HKT - 1) / HKT;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int grp = xcd + 8 * (slot / nkt), bx = slot % nkt;       // grp = b * H + h; bx = key tile = position in the chain
-    if (grp >= p.B * p.H) return;
+    const int bx = slot % nkt;                                     // this workgroup's key tile
+    // The grid holds hx heads per XCD and a workgroup walks heads gi, gi + hx, ...: by default hx = every head (one head per
+    // workgroup).  TTSMI_ATTN_FUSED_PERSIST=1 caps hx at what is resident at once (2 workgroups per CU) so that no second
+    // ROUND of workgroups starts one by one with its heads partly resident - measured SLOWER (decoder layer alone 179.6
+    // against 166 us, +0.16 instead of +0.09 ms per step): the prologue (fragments, the K image, the first tile's round
+    // trip) and the dK / dV stores of a team of 8 then run back to back instead of beside other workgroups' steps.
+    const int hx = (int)(gridDim.x >> 3) / nkt, ngi = (p.B * p.H + 7) >> 3;
+  for (int gi = slot / nkt; gi < ngi; gi += hx) {
+    const int grp = xcd + 8 * gi;                                  // grp = b * H + h
+    if (grp >= p.B * p.H) break;
 #ifdef TTSMI_ABLATION_BUILD
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
     unsigned long long dbg_spin = 0, dbg_first = 0;
@@ -1303,6 +1311,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
     const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH);
     storeT16<DH, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
     storeT16<DH, QH>(patch, dv, DROP ? p.inv_keep : 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
+    __syncthreads();                         // the patches alias the images the next head stages
 #ifdef TTSMI_ABLATION_BUILD
     if (p.dbg && tid == 0) {                 // [block id][8]: start, end, time spent waiting, time to the first hand-off, polls, key tile, head, active
         unsigned long long* o = p.dbg + (long)blockIdx.x * 8;
@@ -1310,6 +1319,7 @@ __global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
         o[4] = (unsigned long long)dbg_polls; o[5] = (unsigned long long)bx; o[6] = (unsigned long long)grp; o[7] = wg_active ? 1 : 0;
     }
 #endif
+  }
 }
 
 // =================================================================================================
@@ -1730,7 +1740,12 @@ int ttsmi_hattention_bwd_fused(const void* qkv, const uint8_t* key_pad, const in
     hipLaunchKernelGGL(hattn_delta_kernel, dim3((unsigned)ttsmi_cdiv((long)B * T * H, 32)), dim3(256), 0, st,
                        (const uint16_t*)dctx, (const uint16_t*)ctx, p.delta, B, H, T);
     const int nkt = ttsmi_cdiv(T, 128), groups = B * H;
-    dim3 grid(8 * ttsmi_cdiv(groups, 8) * nkt);
+    // heads per XCD in the grid: all of them, or (TTSMI_ATTN_FUSED_PERSIST=1) what fits the chip at once at 2 workgroups per CU
+    static const int cus = [] { hipDeviceProp_t pr; int dv = 0; return hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess ? pr.multiProcessorCount : 256; }();
+    TTSMI_KNOB(fused_persist, "TTSMI_ATTN_FUSED_PERSIST", 0);
+    int hx = ttsmi_cdiv(groups, 8);
+    if (fused_persist) { const int cap = (2 * cus / 8) / nkt; hx = hx < cap ? hx : (cap > 0 ? cap : 1); }
+    dim3 grid(8 * hx * nkt);
     p.dbg = nullptr;
     TTSMI_ABLATE_KNOB(fabl, "TTSMI_ATTN_FUSED_ABLATE");      // wrong results by construction: measurement build only
     p.ablate = fabl;

@@ -36,6 +36,7 @@ from .transformer_utils import positional_encoding
 
 _DENSE_STACK = os.environ.get('TTSMI_DENSE_STACK', '1') != '0'      # A/B knob: 0 = one autograd node per planned block
 _PRED_LATE = os.environ.get('TTSMI_PRED_LATE', '1') != '0'      # A/B knob: 0 = predictors issued before the decoder (round 2)
+_PRED_ONE_NODE = os.environ.get('TTSMI_PRED_ONE_NODE', '1') != '0'  # A/B knob: 0 = eight autograd nodes per StatPredictor
 _DROPBITS_CONV = os.environ.get('TTSMI_ATTN_DROPBITS_CONV', '0') == '1'
 
 
@@ -556,6 +557,13 @@ class ForwardTransformer:
     def _stat_predictor(self, prefix, x, pad, n_layers, relu_head, rate):
         """StatPredictor.call + CNNDropout.call (layers.py:481-485,510-524).  x [B,T,d]."""
         W, G, drop = self.params.w, self.params.g, self.drop
+        if _PRED_ONE_NODE:
+            convs = [(W[f'{prefix}.conv{j}.w'], W[f'{prefix}.conv{j}.b'], G[f'{prefix}.conv{j}.w'], G[f'{prefix}.conv{j}.b'],
+                      self.shadow.get(f'{prefix}.conv{j}.w')) for j in range(n_layers)]
+            lns = [(W[f'{prefix}.ln{j}.gamma'], W[f'{prefix}.ln{j}.beta'], G[f'{prefix}.ln{j}.gamma'], G[f'{prefix}.ln{j}.beta'],
+                    drop.site()) for j in range(n_layers)]
+            lin = (W[f'{prefix}.lin.w'], W[f'{prefix}.lin.b'], G[f'{prefix}.lin.w'], G[f'{prefix}.lin.b'])
+            return ops.StatPredictorFn.apply(x, pad, convs, lns, lin, relu_head, rate, drop)
         B, T, _ = x.shape
         h = ops.RowMaskFn.apply(x, pad)
         for j in range(n_layers):

@@ -1384,6 +1384,68 @@ class ConvReluPreMaskedFn(torch.autograd.Function):
 
 
 # =================================================================================================
+# One autograd node per StatPredictor (model/layers.py:481-485, 510-524)
+# =================================================================================================
+class _SubCtx:
+    """What our own Functions use of an autograd ctx, for a Function that runs INSIDE another Function's forward /
+    backward (torch.autograd.Function.apply costs ~20 us of host time per node and direction - tools/debug/launch_cost.py -
+    and a StatPredictor was eight nodes around ~25 launches; the activation gradient is the only one that travels
+    between them: every parameter gradient goes to its caller-owned sink)."""
+
+    def __init__(self, n_inputs):
+        self.needs_input_grad = (True,) + (False,) * (n_inputs - 1)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+class StatPredictorFn(torch.autograd.Function):
+    """RowMask -> [conv + relu -> LayerNorm (+ dropout)] x n -> row dot, as ONE autograd node: the member Functions' own
+    forward / _backward bodies run back to back (same launches, same order, same stream as the separate nodes).
+    convs: [(w, b, gw, gb, shadow)], lns: [(gamma, beta, ggamma, gbeta, site_out)], lin: (w, b, gw, gb)."""
+
+    @staticmethod
+    def forward(ctx, x, pad, convs, lns, lin, relu_head, rate, drop):
+        ctx.stream_h = _stream()         # backward launches on the stream forward ran on (predictor side stream)
+        subs = []
+        c = _SubCtx(2)
+        h = RowMaskFn.forward(c, x, pad)
+        subs.append((RowMaskFn, c, None))
+        for (w, b, gw, gb, sh), (gamma, beta, ggamma, gbeta, site) in zip(convs, lns):
+            c = _SubCtx(6)
+            h = ConvReluPreMaskedFn.forward(c, h, w, b, gw, gb, sh)
+            subs.append((ConvReluPreMaskedFn, c, tuple(h.shape)))
+            B, T, C = h.shape
+            c = _SubCtx(18)
+            h = AddLayerNormFn.forward(c, h.reshape(B * T, C), None, gamma, beta, ggamma, gbeta, None, None, None, 0, None,
+                                       0.0, 0, rate, site, drop, True, False).reshape(B, T, C)
+            subs.append((AddLayerNormFn, c, None))
+        c = _SubCtx(7)
+        y = RowDotFn.forward(c, h, lin[0], lin[1], lin[2], lin[3], pad, relu_head)
+        subs.append((RowDotFn, c, None))
+        ctx.subs = subs
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        with pin_stream(ctx.stream_h):
+            g = dy
+            for cls, c, shape in reversed(ctx.subs):
+                if shape is not None:
+                    g = g.reshape(shape)                 # the conv's output gradient [B, T, C] (its LayerNorm worked on rows)
+                g = cls._backward(c, g)[0]
+        ctx.subs = None
+        return g, None, None, None, None, None, None, None
+
+
+# =================================================================================================
 # One autograd node per SelfAttentionDenseBlock (model/layers.py:214-230)
 # =================================================================================================
 def to_bf16(t):
