@@ -37,6 +37,7 @@ from .transformer_utils import positional_encoding
 _DENSE_STACK = os.environ.get('TTSMI_DENSE_STACK', '1') != '0'      # A/B knob: 0 = one autograd node per planned block
 _PRED_LATE = os.environ.get('TTSMI_PRED_LATE', '1') != '0'      # A/B knob: 0 = predictors issued before the decoder (round 2)
 _PRED_ONE_NODE = os.environ.get('TTSMI_PRED_ONE_NODE', '1') != '0'  # A/B knob: 0 = eight autograd nodes per StatPredictor
+_BWD_SAME_THREAD = os.environ.get('TTSMI_BWD_SAME_THREAD', '1') != '0'  # A/B knob: 0 = backward on the autograd engine's thread
 _DROPBITS_CONV = os.environ.get('TTSMI_ATTN_DROPBITS_CONV', '0') == '1'
 
 
@@ -375,6 +376,7 @@ class ForwardTransformer:
         # needs a block's output on the host side of the boundary (attention maps, activation taps)
         stack_mode = _DENSE_STACK and not want_attn and self._taps is None
         pending = []
+        waited_ev = None                 # the keep-bit tables of a stack share ONE event: the main stream waits for it once
 
         def flush(h, h_bf):
             if not pending:
@@ -401,8 +403,9 @@ class ForwardTransformer:
                 if pre is not None:
                     dmask, site_planned, ev = pre
                     assert site_planned == sites[0], (p, site_planned, sites)
-                    if ev is not None:
+                    if ev is not None and ev is not waited_ev:
                         torch.cuda.current_stream().wait_event(ev)
+                        waited_ev = ev
                 if h_bf is None:
                     h_bf = ops.to_bf16(h)
                 nxt = i + 1
@@ -815,7 +818,10 @@ class ForwardTransformer:
             loss, loss_vals = self._losses(model_out, ts, td, tp, unit_seed=True)    # seeded by loss.backward() below
             ops.enable_wgrad_stream(self.overlap_wgrad)
             try:
-                with ops.ln_param_batch():
+                # the backward pass on THIS thread: handing the graph to the autograd engine's device thread and waiting for
+                # it costs ~0.1 ms of host time per step and buys nothing here (one graph, one device; the Functions
+                # pick their streams themselves)
+                with ops.ln_param_batch(), torch.autograd.set_multithreading_enabled(not _BWD_SAME_THREAD):
                     loss.backward()                                                  # :480
                     self._mark('bwd')
                     ops.ln_flush()               # LayerNorm parameter gradients: one reduce per producing stream, then
