@@ -372,6 +372,52 @@ def test_persistent_dma_gemm_at_the_benchmark_rows(K, mode):
     assert rel_err(y.float(), want) < (4e-3 if mode == 'bf16out' else 3e-6)
 
 
+@pytest.mark.parametrize('mode', ['conv-fwd', 'conv-dgrad', 'plain-f32', 'ragged'])
+def test_256_tile_dma_gemm_at_the_reference_default_conv_shapes(mode):
+    """ttsmi_hgemm_tn on the LARGE launches of the reference-default conv stacks = gemm_bf16_dma256_kernel (256 x 256
+    tiles): (28 864, K 1 152, N 1 536) as the first conv's forward (overlapping A rows: lda = C, K = 3 C; bias, ReLU, bf16
+    out) and the second conv's dgrad (bf16 ReLU' mask, bf16 out), a plain fp32-out product, and a shape whose M and N are
+    not multiples of the tile; against the fp64 product of the same bf16 operands on a sample of rows
+    (model/layers.py:19-26, 30-38 through ops.ConvStackFn's plain-GEMM route)."""
+    ops, _lib, l = _env()
+    C, k = 384, 3
+    K, N = k * C, 1536
+    M = 32 * 902 - 2 if mode != 'ragged' else 131 * 256 + 77
+    if mode == 'ragged':
+        N = 1536 - 64
+    rows_buf = M + 2
+    w = g(K, N, seed=2, scale=0.03)
+    b = g(N, seed=3)
+    sh = ops.make_shadow(w.to(DEV))
+    idx = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 300), torch.arange(M - 300, M)])
+    if mode in ('conv-fwd', 'conv-dgrad'):
+        buf = g(rows_buf, C, seed=1).to(torch.bfloat16)
+        ad = buf.to(DEV)
+        a_view = torch.as_strided(ad, (M, K), (C, 1))                      # row j = buffer rows j .. j + 2
+        a_ref = torch.as_strided(buf, (M, K), (C, 1))[idx].double()
+    else:
+        a = g(M, K, seed=1).to(torch.bfloat16)
+        a_view = a.to(DEV)
+        a_ref = a[idx].double()
+    want = a_ref @ bf(w)
+    if mode == 'conv-fwd':
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        ops.hgemm_tn(a_view, sh.wt, b.to(DEV), relu=True, out=out)
+        want, tol = (want + b.double()).relu(), 4e-3
+    elif mode == 'conv-dgrad':
+        mask = g(M, N, seed=7).to(torch.bfloat16)
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        ops.hgemm_tn(a_view, sh.wt, None, relu_src=mask.to(DEV), out=out)
+        want, tol = want * (mask[idx].double() > 0), 4e-3
+    else:
+        out = ops.hgemm_tn(a_view, sh.wt, b.to(DEV))
+        want, tol = want + b.double(), 3e-6
+    torch.cuda.synchronize()
+    assert last_kernel(l) == 'gemm_bf16_dma256_kernel'
+    assert rel_err(out[idx.to(DEV)].float(), want) < tol
+    assert torch.isfinite(out.float()).all()
+
+
 @pytest.mark.parametrize('M,fwd_kernel,bwd_kernel', [(28800, 'gemm_k256_wide_kernel<1>', 'gemm_k256_wide_kernel<4>'),
                                                       (6400, 'gemm_k256_kernel<1>', 'gemm_k256_kernel<4>'),
                                                       (4096 + 37, 'gemm_k256_kernel<1>', 'gemm_k256_kernel<4>')])

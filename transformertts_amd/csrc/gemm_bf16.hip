@@ -554,6 +554,215 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(HGemmP p) {
 }
 
 // =================================================================================================
+// 256 x 256 tiles for the LARGE launches (the reference-default conv stacks: M = 28 864, N = 1 536, K = 1 152 / 4 608 -
+// 100 GFLOP each).  What the LDS-DMA fill of a CU sustains is ~64 GB/s (tools/probes/stream_tile_probe.hip: 16 TB/s over
+// the chip, whatever the ring depth); a 128 x 128 x 64 step is 2.1 MFLOP per 32 KB filled = 64 FLOP per byte, i.e. at most
+// ~1.05 PFLOP/s however the loop is written - the kernel above measures 0.69-0.78.  A 256 x 256 x 64 step is 8.4 MFLOP per
+// 64 KB = 131 FLOP per byte.  One 8-wave workgroup per CU (2 x 4 waves, wave tile 128 x 64 = eight accumulators), two
+// 64 KB stages; everything else - images, swizzle, persistent tile walk, the next tile's first k-tile under the epilogue,
+// the per-wave epilogue patches - is the kernel above's.
+// =================================================================================================
+#define D2BM 256
+#define D2BN 256
+#define D2STAGE ((D2BM + D2BN) * HBK_ * 2)         // 65 536 bytes per stage
+
+__global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(HGemmP p) {
+    static_assert(HBK_ == 64, "the swizzled image assumes 8 chunks of 8 bf16 per row");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * D2STAGE];
+    typedef __attribute__((address_space(1))) const void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;          // 2 x 4 waves, wave tile 128 x 64
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int kend = p.K;
+    const int nk = p.K / HBK_;
+    // persistent tile walk (see gemm_bf16_kernel's XCD note): XCD x owns tiles [base, base + len)
+    const int T = p.tiles_m * p.tiles_n;
+    const int nx = 8, xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+    const int per = (gridDim.x + nx - 1 - xcd) / nx;
+    const int tq = T / nx, tr = T % nx;
+    const int len = tq + (xcd < tr ? 1 : 0);
+    const int base = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+
+    const uint16_t* A = (const uint16_t*)p.A;
+    const uint16_t* A2 = (const uint16_t*)p.A2;
+    // this lane's place in a DMA wave instruction: 8 rows x 8 chunk positions
+    const int drow = lane >> 3, dpos = lane & 7;
+    // q < 0: the whole k-tile (8 DMA instructions per wave); q = 0..3: piece q of the A image and of the B image.  Inside the
+    // k-loop the pieces are spread over the four 16-wide slices, each pair issued while that slice's fragment reads are in
+    // flight: a DMA instruction costs its wave 60-180 cycles of issue time, and eight of them right behind the barrier
+    // stalled all eight waves at the same moment with the matrix pipe empty (TTSMI_HGEMM_T256_BURST=1 restores that)
+    auto issue = [&](int m0, int n0, int k0, int st, int q) {
+        unsigned char* As = smem + st * D2STAGE;
+        unsigned char* Bs = As + D2BM * HBK_ * 2;
+        const uint16_t* Ab = A;
+        long lda = p.lda;
+        int ka = k0;
+        if (A2 != nullptr && k0 >= p.K1) { Ab = A2; lda = p.lda2; ka = k0 - p.K1; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (q >= 0 && i != q) continue;
+            const int row = wave * 32 + i * 8 + drow;
+            const int c = dpos ^ ((row >> 1) & 7);
+            const int gm = min(m0 + row, p.M - 1);
+            lds_dma16(Ab + (long)gm * lda + ka + c * 8, lds_offset(As + (wave * 32 + i * 8) * 128));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (q >= 0 && i != q) continue;
+            const int row = wave * 32 + i * 8 + drow;
+            const int c = dpos ^ ((row >> 1) & 7);
+            const int gn = min(n0 + row, p.N - 1);
+            lds_dma16(p.B + (long)gn * p.ldb + k0 + c * 8, lds_offset(Bs + (wave * 32 + i * 8) * 128));
+        }
+    };
+    const bool burst = p.k_per_split < 0;             // (measurement knob, passed in an otherwise unused field)
+    int st = 0;
+    if (slot < len) {
+        const int t0 = base + slot;
+        issue((t0 / p.tiles_n) * D2BM, (t0 % p.tiles_n) * D2BN, 0, 0, -1);
+    }
+    __builtin_amdgcn_s_waitcnt(0xF70);
+    lds_stage_barrier();
+
+    for (int ti = slot; ti < len; ti += per) {
+        const int tile = base + ti;
+        const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+        const int m0 = tm * D2BM, n0 = tn * D2BN;
+        const bool has_next = (ti + per) < len;
+        const int tnext = tile + per;
+        const int m0n = (tnext / p.tiles_n) * D2BM, n0n = (tnext % p.tiles_n) * D2BN;
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int ks = 0; ks < nk; ++ks) {
+            const bool more = ks + 1 < nk;
+            const bool fill = more || has_next;                    // (else: the last k-step of the workgroup's last tile)
+            const int fm = more ? m0 : m0n, fn = more ? n0 : n0n, fk = more ? (ks + 1) * HBK_ : 0;   // next tile's first k-tile: under the epilogue
+            if (fill && burst) issue(fm, fn, fk, st ^ 1, -1);
+            const unsigned char* As = smem + st * D2STAGE;
+            const unsigned char* Bs = As + D2BM * HBK_ * 2;
+#pragma unroll
+            for (int kk = 0; kk < HBK_ / 16; ++kk) {
+                const int c = kk * 2 + kg;
+                bf16x8 a[4], b[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = wr * 128 + i * 32 + l31;
+                    a[i] = *reinterpret_cast<const bf16x8*>(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wc * 64 + j * 32 + l31;
+                    b[j] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
+                if (fill && !burst) issue(fm, fn, fk, st ^ 1, kk);
+                __builtin_amdgcn_sched_barrier(0);        // the six fragment reads (and two DMA pieces) are in flight before the eight multiplies
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xF70);    // vmcnt(0): this wave's DMA pieces of the next stage have landed
+            lds_stage_barrier();                  // ... everybody's have, and nobody still reads stage `st`
+            st ^= 1;
+        }
+        // ---- epilogue: the stage just consumed (st ^ 1) is free - its first 35 KB hold the eight per-wave patches
+        float* patch = reinterpret_cast<float*>(smem + (st ^ 1) * D2STAGE) + wave * 16 * DPLD;
+        const long ldc = p.ldc;
+        const bool vec = ((ldc & 3) == 0) && ((p.N & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0);
+        const int rl = lane >> 4, c4 = lane & 15;
+        const int col = n0 + wc * 64 + c4 * 4;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            if (col + 0 < p.N) bias4.x = p.bias[col + 0];
+            if (col + 1 < p.N) bias4.y = p.bias[col + 1];
+            if (col + 2 < p.N) bias4.z = p.bias[col + 2];
+            if (col + 3 < p.N) bias4.w = p.bias[col + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                 // registers 8h..8h+7 = rows 16h..16h+15 of the 32-row tile
+                // global-memory epilogue operands first (see gemm_bf16_kernel): their latency hides under the patch round trip
+                float4 pre_o[4];
+                uint2 pre_m[4];
+                const bool pre_acc = vec && p.accumulate && !p.c_bf16;
+                const bool pre_msk = vec && p.relu_src != nullptr && p.mask_bf16;
+                const int colc = col < p.N ? col : 0;
+                if (pre_acc || pre_msk) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = min(m0 + wr * 128 + i * 32 + h * 16 + it * 4 + rl, p.M - 1);
+                        if (pre_acc) pre_o[it] = *reinterpret_cast<const float4*>(p.C + (long)row * ldc + colc);
+                        if (pre_msk) pre_m[it] = *reinterpret_cast<const uint2*>((const uint16_t*)p.relu_src + (long)row * p.ld_relu + colc);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        patch[((r & 3) + 8 * (r >> 2) + 4 * kg) * DPLD + j * 32 + l31] = acc[i][j][8 * h + r];
+                HWAVE_SYNC();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int prow = it * 4 + rl;
+                    const int row = m0 + wr * 128 + i * 32 + h * 16 + prow;
+                    if (row >= p.M || col >= p.N) continue;
+                    float4 v = *reinterpret_cast<const float4*>(patch + prow * DPLD + c4 * 4);
+                    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    float* dst = p.C + (long)row * ldc + col;
+                    if (vec) {
+                        if (p.relu_src) {
+                            if (p.mask_bf16) {
+                                const uint2 mb = pre_m[it];
+                                auto pos = [](uint32_t hh) { return ((hh & 0x8000u) == 0u) && ((hh & 0x7FFFu) != 0u); };
+                                v.x = pos(mb.x & 0xFFFFu) ? v.x : 0.f; v.y = pos(mb.x >> 16) ? v.y : 0.f;
+                                v.z = pos(mb.y & 0xFFFFu) ? v.z : 0.f; v.w = pos(mb.y >> 16) ? v.w : 0.f;
+                            } else {
+                                float4 m = *reinterpret_cast<const float4*>(p.relu_src + (long)row * p.ld_relu + col);
+                                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                                v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                            }
+                        }
+                        if (p.c_bf16) {
+                            *reinterpret_cast<uint2*>((uint16_t*)p.C + (long)row * p.ldc + col) = pack4(v);
+                            continue;
+                        }
+                        if (p.accumulate) {
+                            const float4 o = pre_o[it];
+                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                        }
+                        *reinterpret_cast<float4*>(dst) = v;
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (col + e >= p.N) break;
+                            float x = vv[e];
+                            if (p.relu_src) x = p.relu_src[(long)row * p.ld_relu + col + e] > 0.f ? x : 0.f;
+                            if (p.accumulate) x += dst[e];
+                            dst[e] = x;
+                        }
+                    }
+                }
+                HWAVE_SYNC();
+            }
+        }
+        __syncthreads();          // the next step's DMA overwrites the stage the patches live in
+    }
+}
+
+// =================================================================================================
 // Deep-ring variant for launches that cannot fill the GPU (inference at batch 1: M = 400 / 2304 rows; the encoder side
 // of a training step: M = 6400).  There the k-loop is a chain of exposed memory round trips - measured ~1 us per 64-wide
 // k-step whatever M is (K = 256 / 512 / 1024 at M = 400: 7.6 / 10.9 / 20 us) - because a workgroup has nothing
@@ -1261,6 +1470,20 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
         p.tiles_m = ttsmi_cdiv(p.M, DBM);
         p.tiles_n = ttsmi_cdiv(p.N, DBN);
         int nw = p.tiles_m * p.tiles_n;
+        // large launches: 256 x 256 tiles (TTSMI_HGEMM_T256: 0 = never, 1 (default) = N >= 512, K >= 768 and at least two
+        // tiles per CU; the benchmark's dense blocks never qualify - their N is 256)
+        TTSMI_KNOB(t256, "TTSMI_HGEMM_T256", 1);
+        const int nw256 = ttsmi_cdiv(p.M, D2BM) * ttsmi_cdiv(p.N, D2BN);
+        if (t256 && p.N >= 512 && p.K >= 768 && nw256 >= 512) {
+            p.tiles_m = ttsmi_cdiv(p.M, D2BM);
+            p.tiles_n = ttsmi_cdiv(p.N, D2BN);
+            ttsmi_note_kernel("gemm_bf16_dma256_kernel");
+            TTSMI_KNOB(t256_burst, "TTSMI_HGEMM_T256_BURST", 0);
+            if (t256_burst) p.k_per_split = -1;
+            hipLaunchKernelGGL(gemm_bf16_dma256_kernel, dim3(256), dim3(512), 0, st, p);
+            TTSMI_CHECK_LAUNCH(name);
+            return TTSMI_OK;
+        }
         if (nw >= (use_dma == 2 ? 1 : 192)) {         // under-filled launches keep the 64-row register-staged tiles
             if (nw > 512) nw = 512;
             ttsmi_note_kernel("gemm_bf16_dma_kernel");
