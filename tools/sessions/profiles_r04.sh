@@ -45,6 +45,13 @@ run() { env $1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roof
 import sys,json
 d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],3), round(d['host_issue_ms_per_step'],3))"; }
 ( for i in 1 2; do run A=1; run TTSMI_ATTN_FUSED_BWD=1; run TTSMI_DENSE_STACK=0; run TTSMI_WGRAD_WO_DUAL=0; done ) > $O/${TAG}_step_ab.txt 2>&1
+echo "== probes: what paces the kernels"
+tools/probes/stream_tile_probe > $O/${TAG}_stream_tile_probe.txt 2>&1
+tools/probes/wgrad_probe > $O/${TAG}_wgrad_probe.txt 2>&1
+tools/probes/valu_rate_probe > $O/${TAG}_valu_rates.txt 2>&1
+python tools/debug/launch_cost.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_launch_cost.txt
+python tools/debug/host_split.py 30 2>&1 | grep -v amdgpu.ids > $O/${TAG}_host_split.txt
+python tools/debug/conv_gemm_ab.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_conv_gemm.txt
 cp $O/bf16_vs_f32_curve.json $O/${TAG}_bf16_vs_f32_curve.json 2>/dev/null
 rm -rf $O/prof_${TAG}_bf16 $O/pmc_${TAG}_bf16_* $O/sq_${TAG}_bf16_* $O/prof_${TAG}_mel $O/pmc_${TAG}_mel_* $O/prof_${TAG}_refdef
 ls -la $O | tail -34
