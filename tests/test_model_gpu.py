@@ -399,6 +399,29 @@ def test_stack_level_launcher_equals_one_call_per_block(tiny, monkeypatch):
     assert l.ttsmi_dense_stack_fwd(None, 0, None, None) == -1 and b'block list' in l.ttsmi_last_error()
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'f32'])
+def test_one_autograd_node_per_stat_predictor_and_backward_on_the_calling_thread(tiny, monkeypatch, precision):
+    """ops.StatPredictorFn runs the member Functions' forward / backward bodies inside ONE autograd node, and the
+    backward pass runs on the calling thread: the same launches in the same order as eight nodes per predictor on the
+    engine's thread - three train steps with dropout on end in bit-identical parameters, losses and predictor outputs."""
+    from transformertts_amd.model import models as mm
+    cfg, W = tiny
+    batch = fo.synthetic_batch(4, 50, 200, seed=23, ragged=True)
+    kw = dict(dropout_rate=0.1, predictors_dropout=0.1, seed=7, precision=precision)
+    runs = []
+    for one_node, same_thread in ((True, True), (False, False)):
+        monkeypatch.setattr(mm, '_PRED_ONE_NODE', one_node)
+        monkeypatch.setattr(mm, '_BWD_SAME_THREAD', same_thread)
+        m = _model(cfg, W, **kw)
+        m._compile(learning_rate=1e-3)
+        outs = [m.train_step(*batch) for _ in range(3)]
+        torch.cuda.synchronize()
+        runs.append((m.params.data.clone(), [float(o['loss']) for o in outs], outs[-1]['duration'].clone(),
+                     outs[-1]['pitch'].clone()))
+    assert runs[0][1] == runs[1][1], (runs[0][1], runs[1][1])
+    assert all(torch.equal(a, b) for a, b in zip((runs[0][0], runs[0][2], runs[0][3]), (runs[1][0], runs[1][2], runs[1][3])))
+
+
 def test_variable_batch_shapes_reuse_capacity_plans(tiny):
     """Length-bucketed training data brings a new (B, Tp, Tm) almost every step: the C++-driven dense blocks keep ONE
     plan per block sized for the largest batch so far and re-bind it (ops.DenseBlockPlan.rebind) - results equal a

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4, session aj: K = 256 GEMMs with the first tiles requested before the weight fragments
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_bench_shapes_gpu.py tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "k256 or relu_bit or hgemm or one_autograd_node or dense_block" 2>&1 | tail -3 > gpurun_out/r04aj_tests.txt
+cat gpurun_out/r04aj_tests.txt
+timeout 600 python tools/kbench.py --only gemm 2>&1 | grep -E "^gemm" > gpurun_out/r04aj_kbench.txt
+cat gpurun_out/r04aj_kbench.txt
+: > gpurun_out/r04aj_ab.txt
+for i in 1 2 3; do
+  timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline --no-attention-maps 2>/dev/null \
+    | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('configs[1]', 'ms_per_step', round(d['ms_per_step'], 3), 'loss', d['config'].get('loss_after'))" | tee -a gpurun_out/r04aj_ab.txt
+done

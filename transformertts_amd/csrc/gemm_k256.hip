@@ -93,6 +93,31 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
     const int n0 = chunk * KW_BN + wn * 32;
     const int my_tiles = group < p.ntiles ? (p.ntiles - group + p.ngroups - 1) / p.ngroups : 0;
 
+    // Roles (vmcnt is per wave, and it counts stores as well as loads): waves 0-3 issue every tile DMA and wait for them
+    // with exact counts; waves 4-7 issue every output store and never wait on vmcnt inside the loop.
+    const bool loader = wave < 4;
+
+    // ---- A tiles by LDS-DMA.  A wave instruction moves 2 rows (2 x 512 B): lane -> row 2 q + (lane >> 5), 16-byte
+    // position lane & 31; position pos of row r holds source chunk pos ^ (r & 15) (conflict-free ds_read_b128 below).
+    auto issue = [&](int it, int stage) {
+        const int m0 = (group + it * p.ngroups) * KW_BM;
+        unsigned char* base = smem + stage * KW_STAGE;
+#pragma unroll
+        for (int i = 0; i < KW_DMA_PER_WAVE; ++i) {
+            const int q = wave * KW_DMA_PER_WAVE + i;
+            const int row = 2 * q + hh;
+            const int c = l31 ^ (row & 15);
+            const int gm = min(m0 + row, p.M - 1);
+            kw_dma16(p.A + (long)gm * p.lda + c * 8, kw_lds_offset(base + q * 1024));
+        }
+    };
+    // the first two tiles are requested BEFORE the weight fragments: one memory round trip at the head of the kernel instead
+    // of two (the fragments, then the tiles) - these launches are 12-15 us at the encoder's 6 400 rows, mostly such latencies
+    if (loader) {
+        if (my_tiles > 0) issue(0, 0);
+        if (my_tiles > 1) issue(1, 1);
+    }
+
     // ---- this wave's 32 columns of W^T as MFMA A-operand fragments: bfrag[s] = Bt[n0 + l31][16 s + 8 hh .. + 8]
     bf16x8 bfrag[KW_K / 16];
     {
@@ -113,29 +138,6 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_kernel(K256P p) {
         bias[r] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // Roles (vmcnt is per wave, and it counts stores as well as loads): waves 0-3 issue every tile DMA and wait for them
-    // with exact counts; waves 4-7 issue every output store and never wait on vmcnt inside the loop.
-    const bool loader = wave < 4;
-
-    // ---- A tiles by LDS-DMA.  A wave instruction moves 2 rows (2 x 512 B): lane -> row 2 q + (lane >> 5), 16-byte
-    // position lane & 31; position pos of row r holds source chunk pos ^ (r & 15) (conflict-free ds_read_b128 below).
-    auto issue = [&](int it, int stage) {
-        const int m0 = (group + it * p.ngroups) * KW_BM;
-        unsigned char* base = smem + stage * KW_STAGE;
-#pragma unroll
-        for (int i = 0; i < KW_DMA_PER_WAVE; ++i) {
-            const int q = wave * KW_DMA_PER_WAVE + i;
-            const int row = 2 * q + hh;
-            const int c = l31 ^ (row & 15);
-            const int gm = min(m0 + row, p.M - 1);
-            kw_dma16(p.A + (long)gm * p.lda + c * 8, kw_lds_offset(base + q * 1024));
-        }
-    };
-    if (loader) {
-        if (my_tiles > 0) issue(0, 0);
-        if (my_tiles > 1) issue(1, 1);
-    }
-
     const int arow = wmh * 32 + l31;
     for (int it = 0; it < my_tiles; ++it) {
         // tile `it` has landed once at most the 8 DMAs of the tile issued after it are outstanding (loader waves)
@@ -274,6 +276,24 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_wide_kernel(K256P p) {
     const int my_tiles = group < p.ntiles ? (p.ntiles - group + p.ngroups - 1) / p.ngroups : 0;
     const int ab = TTSMI_ABLATE_BITS(p.ablate);
 
+    auto issue = [&](int it, int stage) {                 // compute waves only: 8 DMA instructions per wave and tile
+        const int m0 = (group + it * p.ngroups) * KW_BM;
+        unsigned char* base = smem + stage * KW_STAGE;
+#pragma unroll
+        for (int i = 0; i < KW_DMA_PER_WAVE; ++i) {
+            const int q = wave * KW_DMA_PER_WAVE + i;
+            const int row = 2 * q + hh;
+            const int c = l31 ^ (row & 15);
+            const int gm = min(m0 + row, p.M - 1);
+            kw_dma16(p.A + (long)gm * p.lda + c * 8, kw_lds_offset(base + q * 1024));
+        }
+    };
+    const bool dma_on = !(ab & 4);
+    // (requested before the weight fragments: one round trip at the head of the kernel instead of two)
+    if (compute && dma_on) {
+        if (my_tiles > 0) issue(0, 0);
+        if (my_tiles > 1) issue(1, 1);
+    }
     if (tid < KWW_BN) biasS[tid] = (p.bias != nullptr && ncol0 + tid < p.N) ? p.bias[ncol0 + tid] : 0.f;
     // ---- compute waves: 64 columns of W^T as MFMA A-operand fragments, bfrag[cb][s] = Bt[n0 + 32 cb + l31][16 s + 8 hh ..]
     bf16x8 bfrag[2][KW_K / 16];
@@ -291,23 +311,6 @@ __global__ __launch_bounds__(512, 1) void gemm_k256_wide_kernel(K256P p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    auto issue = [&](int it, int stage) {                 // compute waves only: 8 DMA instructions per wave and tile
-        const int m0 = (group + it * p.ngroups) * KW_BM;
-        unsigned char* base = smem + stage * KW_STAGE;
-#pragma unroll
-        for (int i = 0; i < KW_DMA_PER_WAVE; ++i) {
-            const int q = wave * KW_DMA_PER_WAVE + i;
-            const int row = 2 * q + hh;
-            const int c = l31 ^ (row & 15);
-            const int gm = min(m0 + row, p.M - 1);
-            kw_dma16(p.A + (long)gm * p.lda + c * 8, kw_lds_offset(base + q * 1024));
-        }
-    };
-    const bool dma_on = !(ab & 4);
-    if (compute && dma_on) {
-        if (my_tiles > 0) issue(0, 0);
-        if (my_tiles > 1) issue(1, 1);
-    }
     __syncthreads();                                      // bias table
     // Two loops with the same barrier sequence (T, Y per iteration; iterations 0 .. my_tiles) - one per role, so that the
     // register allocator sees two disjoint live sets (128 weight + 64 accumulator registers on one side, 96 of staging /
