@@ -191,3 +191,41 @@ def test_reconstruct_waveform_of_a_900_frame_mel_takes_milliseconds():
     print(f'reconstruct_waveform, 900 frames: {min(ts) * 1e3:.1f} ms (mel -> linear on the GPU: {t_nnls * 1e3:.2f} ms)')
     assert wav.shape == (HOP * 899,) and np.isfinite(wav).all()
     assert min(ts) < 0.25 and t_nnls < 0.02                             # the host L-BFGS-B path takes tens of seconds here
+
+
+@pytest.mark.gpu
+def test_device_nnls_with_a_basis_whose_bins_are_covered_by_more_than_two_filters():
+    """ttsmi_mel_nnls keeps the first two covering filters of a bin in registers and walks the rest of the range in a
+    slower loop: a synthetic basis with four overlapping rows per bin (and one empty row, one uncovered bin), against
+    scipy.optimize.nnls column by column - the objective it reaches, the KKT conditions, exact zeros where no filter
+    reaches."""
+    import scipy.optimize
+    from transformertts_amd import ops
+    r = np.random.RandomState(5)
+    n_mels, n_bins, T = 24, 170, 37
+    B = np.zeros((n_mels, n_bins), np.float32)
+    for j in range(n_mels):
+        if j == 5:
+            continue                                                    # an empty row
+        lo = 6 * j
+        B[j, lo:lo + 23] = r.rand(23).astype(np.float32) + 0.1          # rows 6 apart, 23 wide: up to 4 rows per bin
+    B[:, 165:] = 0                                                      # bins no filter reaches
+    lo = np.array([int(np.nonzero(B[j])[0][0]) if B[j].any() else 0 for j in range(n_mels)], np.int32)
+    cnt = np.array([int(np.nonzero(B[j])[0][-1]) + 1 - lo[j] if B[j].any() else 0 for j in range(n_mels)], np.int32)
+    ptr = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32)
+    w = np.concatenate([B[j, lo[j]:lo[j] + cnt[j]] for j in range(n_mels)]).astype(np.float32)
+    assert ((B > 0).sum(0).max()) == 4
+    M = (B @ (r.rand(n_bins, T) ** 3) * np.exp(0.3 * r.randn(n_mels, T))).astype(np.float32)
+    B64 = B.astype(np.float64)
+    dev = torch.device('cuda:0')
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = ops.mel_nnls(t(M.T), t(np.linalg.pinv(B64).T.astype(np.float32)), t(lo), t(cnt), t(ptr), t(w),
+                     1.0 / np.linalg.norm(B64, 2) ** 2, n_iter=4000)
+    got = x.cpu().numpy().T.astype(np.float64)
+    assert got.shape == (n_bins, T) and (got >= 0).all() and (got[165:] == 0).all()
+    f = lambda X: 0.5 * np.sum((B64 @ X - M) ** 2)
+    want = np.stack([scipy.optimize.nnls(B64, M[:, c].astype(np.float64))[0] for c in range(T)], 1)
+    assert f(got) <= f(want) * (1 + 1e-3) + 1e-9 * np.sum(M.astype(np.float64) ** 2), (f(got), f(want))
+    grad = B64.T @ (B64 @ got - M)
+    scale = np.abs(B64.T @ M).max()
+    assert np.abs(grad[got > 1e-5 * got.max()]).max() < 1e-4 * scale and grad.min() > -1e-4 * scale
