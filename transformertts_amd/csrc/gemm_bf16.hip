@@ -43,6 +43,7 @@ struct HGemmP {
     int k_per_split;
     float* ws; float* colsum; float* colsum_ws;
     int tiles_m, tiles_n;
+    int dma_burst;                      // gemm_bf16_dma256_kernel: a k-tile's DMA pieces all at once behind the barrier (A/B knob)
 };
 
 __device__ __forceinline__ uint2 pack4(float4 v) {
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma256_kernel(HGemmP p) {
             lds_dma16(p.B + (long)gn * p.ldb + k0 + c * 8, lds_offset(Bs + (wave * 32 + i * 8) * 128));
         }
     };
-    const bool burst = p.k_per_split < 0;             // (measurement knob, passed in an otherwise unused field)
+    const bool burst = p.dma_burst != 0;
     int st = 0;
     if (slot < len) {
         const int t0 = base + slot;
@@ -1479,7 +1480,7 @@ static int hlaunch(HGemmP& p, bool a_f32, int splits, hipStream_t st, const char
             p.tiles_n = ttsmi_cdiv(p.N, D2BN);
             ttsmi_note_kernel("gemm_bf16_dma256_kernel");
             TTSMI_KNOB(t256_burst, "TTSMI_HGEMM_T256_BURST", 0);
-            if (t256_burst) p.k_per_split = -1;
+            p.dma_burst = t256_burst;
             hipLaunchKernelGGL(gemm_bf16_dma256_kernel, dim3(256), dim3(512), 0, st, p);
             TTSMI_CHECK_LAUNCH(name);
             return TTSMI_OK;
