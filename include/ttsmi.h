@@ -398,7 +398,11 @@ int ttsmi_hgemm_wgrad(const uint16_t* xT, const uint16_t* dyT, int64_t ldt, floa
                       ttsmi_stream_t stream);
 /* dw[kin,n] = x[rows,kin]^T . dy[rows,n] (+ db) straight from the row-major fp32 tensors (operands are
  * rounded to bf16 and transposed inside the kernel).  Conv1D wgrad: conv_taps > 1, x is [B*conv_T,
- * conv_C] with conv_C %% 128 == 0 and kin = conv_taps*conv_C. */
+ * conv_C] with conv_C %% 128 == 0 and kin = conv_taps*conv_C (fp32 x, windows clipped at the sequence ends).
+ * conv_taps > 1 with conv_T == 0: SHIFTED-ROWS taps for the zero-margin layout of a 'same' Conv1D (every sequence
+ * carries its own zero rows, so no clipping): rows [j conv_C, (j + 1) conv_C) of dw = x[j : j + rows]^T . dy, all taps in
+ * one launch; bf16 x and dy, ldx == conv_C, conv_pad == 0, conv_C %% 128 == 0, n %% 128 == 0, rows %% 32 == 0, and x
+ * readable for conv_taps - 1 rows past `rows`. */
 size_t ttsmi_hgemm_wgrad_rows_ws_bytes(int rows, int kin, int n);
 int ttsmi_hgemm_wgrad_rows(const void* x, int x_is_bf16, int64_t ldx, const void* dy, int dy_is_bf16, int64_t lddy,
                            float* dw, int64_t lddw, float* db, int rows, int kin, int n, int conv_taps,

@@ -418,6 +418,43 @@ def test_256_tile_dma_gemm_at_the_reference_default_conv_shapes(mode):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize('C,N,B,T', [(384, 1536, 32, 900), (1536, 384, 32, 900), (128, 128, 4, 30)])
+def test_conv_weight_gradient_with_shifted_row_taps(C, N, B, T):
+    """ttsmi_hgemm_wgrad_rows with conv_taps = 3, conv_T = 0: the three taps of a 'same' Conv1D over the zero-margin layout
+    [B (T + 2) + 2, C] as ONE wgrad_dma_kernel launch (rows [j C, (j + 1) C) of dW from x shifted down by j rows) - against
+    the fp64 products on a sample of elements and against the three per-tap launches it replaces
+    (model/layers.py:19-26 differentiated; ops.ConvStackFn._backward_plain)."""
+    ops, _lib, l = _env()
+    k = 3
+    rows = B * (T + 2)
+    x = torch.zeros(rows + 2, C)
+    gy = torch.zeros(rows + 2, N)
+    xv, gv = x[:rows].view(B, T + 2, C), gy[:rows].view(B, T + 2, N)
+    xv[:, 1:T + 1] = g(B, T, C, seed=1)
+    gv[:, 1:T + 1] = g(B, T, N, seed=2) * 0.1
+    xh, gh = x.to(torch.bfloat16), gy.to(torch.bfloat16)
+    xd, gd = xh.to(DEV), gh.to(DEV)
+    dw = torch.full((k, C, N), float('nan'), device=DEV)
+    db = torch.full((N,), float('nan'), device=DEV)
+    ops.hgemm_wgrad_rows(xd[:rows], gd[1:1 + rows], dw.reshape(k * C, N), db, conv=(k, 0, C, 0))
+    torch.cuda.synchronize()
+    assert last_kernel(l) == 'wgrad_dma_kernel'
+    dw2 = torch.full((k, C, N), float('nan'), device=DEV)
+    db2 = torch.full((N,), float('nan'), device=DEV)
+    for tap in range(k):
+        ops.hgemm_wgrad_rows(xd[tap:tap + rows], gd[1:1 + rows], dw2[tap], db2 if tap == 0 else None)
+    torch.cuda.synchronize()
+    assert rel_err(dw, dw2) < 2e-6 and rel_err(db, db2) < 2e-6                  # the same products, other split sizes
+    ci, ni = torch.arange(0, C, max(1, C // 37)), torch.arange(0, N, max(1, N // 41))
+    gd64 = gh[1:1 + rows].double()
+    for tap in range(k):
+        want = xh[tap:tap + rows][:, ci].double().T @ gd64[:, ni]
+        assert rel_err(dw[tap][ci][:, ni], want) < 3e-6, tap
+    assert rel_err(db, gd64.sum(0)) < 3e-6
+    with pytest.raises(Exception):                                            # fp32 x is the windowed form's business
+        ops.hgemm_wgrad_rows(xd[:rows].float(), gd[1:1 + rows], dw.reshape(k * C, N), db, conv=(k, 0, C, 0))
+
+
 @pytest.mark.parametrize('M,fwd_kernel,bwd_kernel', [(28800, 'gemm_k256_wide_kernel<1>', 'gemm_k256_wide_kernel<4>'),
                                                       (6400, 'gemm_k256_kernel<1>', 'gemm_k256_kernel<4>'),
                                                       (4096 + 37, 'gemm_k256_kernel<1>', 'gemm_k256_kernel<4>')])

@@ -1154,7 +1154,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WRowsP p) {
     const bool second = p.X2 != nullptr && k0 >= p.K1;                    // (workgroup-uniform) which X this K tile reads
     const uint16_t* X = (const uint16_t*)(second ? p.X2 : p.X);
     const long ldx = second ? p.ldx2 : p.ldx;
-    const int xk0 = second ? k0 - p.K1 : k0;
+    int xk0 = second ? k0 - p.K1 : k0;
+    if (p.taps > 1) {
+        // SHIFTED-ROWS taps (conv_T == 0: the zero-margin layout of a 'same' Conv1D, ops.ConvStackFn): K_in rows
+        // [j Cin, (j + 1) Cin) of dW come from X shifted down by j rows - every tap of the conv in ONE launch (it was a
+        // launch and a slab reduction per tap).  Cin % 128 == 0, so a K tile never straddles two taps.
+        const int tap = k0 / p.Cin;
+        X += (long)tap * ldx;
+        xk0 = k0 - tap * p.Cin;
+    }
     const uint16_t* DY = (const uint16_t*)p.DY;
     // DMA: a wave instruction = 4 rows x 16 chunks of 16 bytes; wave w owns rows [8w, 8w + 8) of a step
     const int drow = lane >> 4, dpos = lane & 15;
@@ -1710,12 +1718,19 @@ static int wgrad_rows_impl(const void* x, int x_is_bf16, int64_t ldx, const void
     if (x2) TTSMI_CHECK_ARG(conv_taps <= 1 && k1 > 0 && k1 < kin && k1 % 128 == 0 && al16(x2) && ldx2 % 8 == 0,
                             "hgemm_wgrad_rows: dual X needs no conv window, 0 < K1 < K with K1 %% 128 == 0, an aligned X2");
     if (job) job->splits = 0;
-    TTSMI_CHECK_ARG(!(x_is_bf16 && conv_taps > 1), "hgemm_wgrad_rows: conv needs an fp32 x");
+    // conv_taps > 1 with conv_T == 0: shifted-rows taps of the zero-margin layout (bf16 operands, the LDS-DMA kernel only);
+    // x must stay readable for conv_taps - 1 rows past `rows`
+    const bool shifted = conv_taps > 1 && conv_T == 0;
+    TTSMI_CHECK_ARG(!(x_is_bf16 && conv_taps > 1) || shifted, "hgemm_wgrad_rows: conv needs an fp32 x");
+    if (shifted)
+        TTSMI_CHECK_ARG(!x2 && x_is_bf16 && dy_is_bf16 && conv_pad == 0 && conv_C % 128 == 0 && kin == conv_taps * conv_C && ldx == conv_C &&
+                        rows % WR_ROWS == 0 && n % 128 == 0 && ldx % 8 == 0 && lddy % 8 == 0,
+                        "hgemm_wgrad_rows: shifted-rows taps need bf16 operands, Cin %% 128 == 0, N %% 128 == 0, rows %% 32 == 0, ldx == Cin");
     TTSMI_CHECK_ARG(x && dy && dw, "hgemm_wgrad_rows: null pointer");
     TTSMI_CHECK_ARG(rows > 0 && kin > 0 && n > 0, "hgemm_wgrad_rows: bad shape");
     TTSMI_CHECK_ARG(al16(x) && al16(dy) && ldx % 4 == 0 && lddy % 4 == 0 && n % 4 == 0,
                     "hgemm_wgrad_rows: operands must be 16-byte aligned with ld %% 4 == 0");
-    if (conv_taps > 1)
+    if (conv_taps > 1 && !shifted)
         TTSMI_CHECK_ARG(conv_C % 128 == 0 && kin == conv_taps * conv_C && conv_T > 0 && ldx == conv_C,
                         "hgemm_wgrad_rows: conv needs Cin %% 128 == 0");
     else
@@ -1735,7 +1750,7 @@ static int wgrad_rows_impl(const void* x, int x_is_bf16, int64_t ldx, const void
     p.ws = (float*)ws; p.colsum = db; p.colsum_ws = p.ws + (size_t)splits * kin * n;
     dim3 wgrid(tiles * splits);
     TTSMI_KNOB(wdma, "TTSMI_WGRAD_DMA", 1);
-    const bool dma_ok = wdma && x_is_bf16 && dy_is_bf16 && conv_taps <= 1 && rows % WR_ROWS == 0 && kin % 128 == 0 &&
+    const bool dma_ok = (wdma || shifted) && x_is_bf16 && dy_is_bf16 && (conv_taps <= 1 || shifted) && rows % WR_ROWS == 0 && kin % 128 == 0 &&
                         n % 128 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && al16(x) && al16(dy);
     ttsmi_note_kernel(dma_ok ? "wgrad_dma_kernel" : "wgrad_rows_kernel");
     if (dma_ok) hipLaunchKernelGGL(wgrad_dma_kernel, wgrid, dim3(256), 0, st, p);

@@ -839,8 +839,13 @@ class ConvStackFn(torch.autograd.Function):
             xp = acts[j]
             # dW[tap] = x[. + tap]^T . g[. + p] over all buffer rows (the margins of g are zero, so are those of x)
             gv = g[p:p + rows]
-            for tap in range(k):
-                wgrad_rows_async(xp[tap:tap + rows], gv, dw[tap], db if tap == 0 else None)
+            if _CONV_WGRAD_TAPS and rows % 32 == 0 and cin % 128 == 0 and cout % 128 == 0:
+                # every tap in ONE launch (shifted-rows taps of ttsmi_hgemm_wgrad_rows): a third of the launches and slab
+                # reductions; the buffers' 2p spare rows keep the last tap's reads inside them
+                wgrad_rows_async(xp[:rows], gv, dw.reshape(k * cin, cout), db, conv=(k, 0, cin, 0))
+            else:
+                for tap in range(k):
+                    wgrad_rows_async(xp[tap:tap + rows], gv, dw[tap], db if tap == 0 else None)
             if j > 0 or ctx.needs_input_grad[0]:
                 a_view = torch.as_strided(g, (Mp, k * cout), (cout, 1))
                 nxt = torch.empty((rows + 2 * p, cin), dtype=torch.bfloat16 if j > 0 else torch.float32, device=dy.device)
@@ -1644,6 +1649,7 @@ class DenseBlockFn(torch.autograd.Function):
 # =================================================================================================
 # stream priority of the weight-gradient side stream (torch: -1 = high, 0 = default)
 _WGRAD_PRIO = int(os.environ.get('TTSMI_WGRAD_PRIO', '0'))
+_CONV_WGRAD_TAPS = os.environ.get('TTSMI_CONV_WGRAD_TAPS', '1') != '0'     # A/B knob: 0 = one weight-gradient launch per conv tap
 FUSE_LN_MIN_ROWS_INFERENCE = int(os.environ.get('TTSMI_FUSE_LN_MIN_ROWS', '8192'))
 
 
