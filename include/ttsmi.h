@@ -36,9 +36,10 @@ extern "C" {
 #endif
 
 /* Bumped whenever an entry point's argument list or the ttsmi_dense_block layout changes (101: round 3's `denom` argument of
- * ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102: round 4; 103: ttsmi_mel_nnls added).  Bindings check it at load
+ * ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102: round 4; 103: ttsmi_mel_nnls added; 104: the shifted-rows taps of
+ * ttsmi_hgemm_wgrad_rows, which the conv stacks of the host mirror now call).  Bindings check it at load
  * time (transformertts_amd/_lib.py) so that a stale build is refused instead of being called with shifted arguments. */
-#define TTSMI_VERSION 103
+#define TTSMI_VERSION 104
 
 enum {
     TTSMI_OK = 0,

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # version this binding was written for (EXPECTED_VERSION, checked in lib()).
 _override = os.environ.get('TTSMI_LIB') if os.environ.get('TTSMI_ALLOW_LIB_OVERRIDE') == '1' else None
 LIB_PATH = _override or os.path.join(_HERE, 'lib', 'libttsmi.so')
-EXPECTED_VERSION = 103            # include/ttsmi.h: TTSMI_VERSION
+EXPECTED_VERSION = 104            # include/ttsmi.h: TTSMI_VERSION
 
 P = c_void_p          # every device pointer
 I = c_int
