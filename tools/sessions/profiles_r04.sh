@@ -1,5 +1,6 @@
 #!/bin/bash
 # The round-4 artefact set for profiles/: bash tools/sessions/profiles_r04.sh [tag]   (ONE gpurun call, one box)
+# (the probes it runs are in-tree binaries: bash tools/probes/build.sh first; the measurement library: tools/build_variant.sh abl "-DTTSMI_ABLATION_BUILD" dense_block.hip attention_bf16.hip)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r04}
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
