@@ -156,42 +156,43 @@ __device__ __forceinline__ void rows_stash(uint16_t* S, int tid, const float4 (&
         *reinterpret_cast<uint2*>(S + row * LD + c4 * 4) = *reinterpret_cast<uint2*>(&h);
     }
 }
-// bf16-source rows (qkv kept in bf16 by the producer GEMM): 4 bf16 per item, no conversion
+// bf16-source rows (qkv kept in bf16 by the producer GEMM): 8 bf16 = 16 bytes per item, no conversion.  (Round 4: the items
+// were 8 bytes - twice the load and LDS-write instructions; the per-wave section times of the forward,
+// tools/debug/attn_fwd_sections.py, put a quarter of a wave's time into ISSUING a tile's loads.)
 template <int DH>
 __device__ __forceinline__ void rows_fetch_h(const uint16_t* base, long ld, int row0, int nvalid, int tid,
-                                             uint2 (&r)[DH / 16]) {
-    constexpr int V4 = DH / 4;
-    if constexpr (256 % V4 == 0) {
-        // item i of this thread is row (tid / V4) + (256 / V4) i, the same 8-byte column every time: ONE 32-bit lane
+                                             uint4 (&r)[DH / 32]) {
+    constexpr int V8 = DH / 8;
+    if constexpr (256 % V8 == 0) {
+        // item i of this thread is row (tid / V8) + (256 / V8) i, the same 16-byte column every time: ONE 32-bit lane
         // offset (loop invariant in every caller) + a wave-uniform 64-bit base that the scalar unit advances.  Written
-        // the plain way (below) each item cost a 64-bit multiply-add chain per k-tile: ~100 of the ~300 vector
-        // instructions a staged K/V tile costs the forward kernel.
-        constexpr int RPI = 256 / V4;
-        const int row_t = tid / V4, c4 = tid - row_t * V4;
-        const uint32_t voff = ((uint32_t)row_t * (uint32_t)ld + (uint32_t)c4 * 4u) * 2u;        // bytes, < T * ld * 2
+        // the plain way (below) each item cost a 64-bit multiply-add chain per k-tile.
+        constexpr int RPI = 256 / V8;
+        const int row_t = tid / V8, c8 = tid - row_t * V8;
+        const uint32_t voff = ((uint32_t)row_t * (uint32_t)ld + (uint32_t)c8 * 8u) * 2u;        // bytes, < T * ld * 2
         const char* sb = reinterpret_cast<const char*>(base) + (long)row0 * ld * 2;
 #pragma unroll
-        for (int i = 0; i < DH / 16; ++i)
-            r[i] = (row_t + RPI * i < nvalid) ? *reinterpret_cast<const uint2*>(sb + (long)(RPI * i) * ld * 2 + voff)
-                                              : make_uint2(0u, 0u);
+        for (int i = 0; i < DH / 32; ++i)
+            r[i] = (row_t + RPI * i < nvalid) ? *reinterpret_cast<const uint4*>(sb + (long)(RPI * i) * ld * 2 + voff)
+                                              : make_uint4(0u, 0u, 0u, 0u);
     } else {
 #pragma unroll
-        for (int i = 0; i < DH / 16; ++i) {
+        for (int i = 0; i < DH / 32; ++i) {
             int id = tid + 256 * i;
-            int row = id / V4, c4 = id - row * V4;
-            r[i] = (row < nvalid) ? *reinterpret_cast<const uint2*>(base + (long)(row0 + row) * ld + c4 * 4)
-                                  : make_uint2(0u, 0u);
+            int row = id / V8, c8 = id - row * V8;
+            r[i] = (row < nvalid) ? *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * ld + c8 * 8)
+                                  : make_uint4(0u, 0u, 0u, 0u);
         }
     }
 }
 template <int DH>
-__device__ __forceinline__ void rows_stash_h(uint16_t* S, int tid, const uint2 (&r)[DH / 16]) {
-    constexpr int V4 = DH / 4, LD = DH + 8;
+__device__ __forceinline__ void rows_stash_h(uint16_t* S, int tid, const uint4 (&r)[DH / 32]) {
+    constexpr int V8 = DH / 8, LD = DH + 8;                 // LD * 2 bytes = a multiple of 16: the writes stay aligned
 #pragma unroll
-    for (int i = 0; i < DH / 16; ++i) {
+    for (int i = 0; i < DH / 32; ++i) {
         int id = tid + 256 * i;
-        int row = id / V4, c4 = id - row * V4;
-        *reinterpret_cast<uint2*>(S + row * LD + c4 * 4) = r[i];
+        int row = id / V8, c8 = id - row * V8;
+        *reinterpret_cast<uint4*>(S + row * LD + c8 * 8) = r[i];
     }
 }
 template <int DH>
@@ -208,7 +209,7 @@ __device__ __forceinline__ void row_frags_h(const uint16_t* base, long ld, int r
 template <int DH, bool QH>
 struct Tile {
     float4 f[DH / 16];
-    uint2 h[DH / 16];
+    uint4 h[DH / 32];
     __device__ __forceinline__ void fetch(const float* base, long ld, int row0, int nvalid, int tid) {
         if constexpr (QH) rows_fetch_h<DH>((const uint16_t*)base, ld, row0, nvalid, tid, h);
         else rows_fetch<DH>(base, ld, row0, nvalid, tid, f);
@@ -217,6 +218,7 @@ struct Tile {
         if constexpr (QH) rows_stash_h<DH>(S, tid, h);
         else rows_stash<DH>(S, tid, f);
     }
+
 };
 // element pointer into a [.., ld] tensor whose element type is fp32 (QH = false) or bf16 (QH = true),
 // carried as const float* (only ever dereferenced through the helpers above)
@@ -465,6 +467,19 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
     // measurement build only (TTSMI_ATTN_FWD_ABLATE, results WRONG): 1 = no global fetch inside the loop (the first tile is
     // stashed again and again), 2 = no exponentials, 4 = no keep-bit selects, 8 = no barriers and no stash at all, 16 / 32 = no K / V fragment reads
     const int abl = TTSMI_ABLATE_BITS(p.ablate);
+#ifdef TTSMI_ABLATION_BUILD
+    // per-section wall time of every wave (s_memtime, in shader cycles; each stamp first waits for the wave's own LDS /
+    // scalar traffic): [0] barriers + stash, [1] fetch issue, [2] S product up to its first use, [3] softmax arithmetic,
+    // [4] P.V product, [5] blocks; written by lane 0 of each wave to dbg[(block * 4 + wave) * 8 ..]
+    unsigned long long tsec[5] = {0, 0, 0, 0, 0}, tblocks = 0, tempty = 0;      // tempty: two stamps back to back = a stamp's own cost
+    auto stamp = [&]() -> unsigned long long { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return __builtin_readcyclecounter(); };
+    const unsigned long long tk0 = stamp();
+#define FWD_STAMP(var) const unsigned long long var = stamp()
+#define FWD_ADD(i, a, b) tsec[i] += (b) - (a)
+#else
+#define FWD_STAMP(var)
+#define FWD_ADD(i, a, b)
+#endif
     Tile<DH, QH> rk, rv;
     // The padding byte of the NEXT tile is only LOADED in the fetch phase and turned into a float when the tile is
     // stashed (HPAD_*): any arithmetic on it right after the load put an `s_waitcnt vmcnt(0)` behind the K / V prefetch
@@ -482,6 +497,7 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
     }
     for (int k0 = kbeg; k0 < klen; k0 += HKT) {
         int anypad = 0;
+        FWD_STAMP(ta);
         if (!(abl & 8) || k0 == kbeg) {
             __syncthreads();
             rk.stash(Ks, tid);
@@ -490,16 +506,29 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
             __syncthreads();
             anypad = HPAD_ANY();
         }
-        if (k0 + HKT < klen && !(abl & 1)) {
-            int nv = min(HKT, klen - (k0 + HKT));
-            rk.fetch(Kb, p.ld, k0 + HKT, nv, tid);
-            rv.fetch(Vb, p.ld, k0 + HKT, nv, tid);
-            HPAD_FETCH(k0 + HKT, nv);
+        FWD_STAMP(tb);
+        FWD_ADD(0, ta, tb);
+        // The next tile's loads are issued INSIDE the score blocks, right behind each block's S product: a vector-memory
+        // instruction costs its wave ~150-250 cycles of issue time here (the CU's address path serves the 16 resident waves
+        // in order, and the four waves of a workgroup all issue behind the same barrier) - a quarter of a wave's time when
+        // the five (8-byte: nine) loads of a tile sat behind the barrier (tools/debug/attn_fwd_sections.py); behind the MFMAs
+        // part of that wait is the matrix pipe's running time.  (ONE load behind each of the tile's four MFMA groups was
+        // measured too: 62.1 vs 59.9 us, same box - more live address registers, 4 spills.)  A wave without a live query
+        // row runs no block: it issues them here.
+        const bool more = k0 + HKT < klen && !(abl & 1);
+        const int nv_next = more ? min(HKT, klen - (k0 + HKT)) : 0;
+        if (more && !wave_live) {
+            rk.fetch(Kb, p.ld, k0 + HKT, nv_next, tid);
+            rv.fetch(Vb, p.ld, k0 + HKT, nv_next, tid);
+            HPAD_FETCH(k0 + HKT, nv_next);
         }
+        FWD_STAMP(tc);
+        FWD_ADD(1, tb, tc);
 #pragma unroll
         for (int kt = 0; kt < HKT / 32; ++kt) {
             const int kbase = k0 + kt * 32;
             if (kbase >= klen || !wave_live) break;
+            FWD_STAMP(t0);
             f32x16 s;
             if (abl & 16) {                                                   // (measurement: no K fragment reads)
 #pragma unroll
@@ -508,6 +537,11 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
                 for (int t = 0; t < DH / 16; ++t) s = MFMA16(qf[t], qf[t], s);
             } else {
                 s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                     // S^T[key][q]
+            }
+            if (more && kt == 0) {                                           // (block 0 of a tile always runs in a live wave)
+                rk.fetch(Kb, p.ld, k0 + HKT, nv_next, tid);
+                rv.fetch(Vb, p.ld, k0 + HKT, nv_next, tid);
+                HPAD_FETCH(k0 + HKT, nv_next);
             }
             // The 1 / sqrt(dh) scale (c1, log2 units) rides in the exponent's fma: p = 2^(s c1 - m).  Only a block with a
             // padded key or the ragged tail needs the logits themselves scaled first (wave-uniform branch, rare).
@@ -526,6 +560,11 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
                 }
                 cs = 1.0f;
             }
+#ifdef TTSMI_ABLATION_BUILD
+            asm volatile("" : "+v"(s));                               // the S product has arrived: its first use is the stamp's
+#endif
+            FWD_STAMP(t1);
+            FWD_ADD(2, t0, t1);
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -568,6 +607,11 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
             }
             bf16x8 pb[2];
             to_frags(s, pb);
+#ifdef TTSMI_ABLATION_BUILD
+            asm volatile("" : "+v"(pb[0]), "+v"(pb[1]));
+#endif
+            FWD_STAMP(t2);
+            FWD_ADD(3, t1, t2);
             if (abl & 32) {                                                   // (measurement: no V fragment reads)
 #pragma unroll
                 for (int cb = 0; cb < DH / 32; ++cb)
@@ -576,8 +620,19 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
             } else {
                 accumTR<DH>(Vs, kt * 32, lane, pb, o);                        // O^T += V^T.P^T
             }
+#ifdef TTSMI_ABLATION_BUILD
+            asm volatile("" : "+v"(o[0]));                            // (the product's first accumulator has been written)
+            { const unsigned long long t3 = stamp(); tsec[4] += t3 - t2; ++tblocks; const unsigned long long t4 = stamp(); tempty += t4 - t3; }
+#endif
         }
     }
+#ifdef TTSMI_ABLATION_BUILD
+    if (p.dbg && lane == 0) {
+        unsigned long long* o8 = p.dbg + ((long)blockIdx.x * 4 + wave) * 8;
+        o8[0] = tsec[0]; o8[1] = tsec[1]; o8[2] = tsec[2]; o8[3] = tsec[3]; o8[4] = tsec[4]; o8[5] = tblocks;
+        o8[6] = stamp() - tk0; o8[7] = tempty;
+    }
+#endif
     __syncthreads();
     l = xhalf_sum(l);
     // (an empty key range - a split past the last unpadded key - leaves l = 0: weight 0 in the combine)
@@ -1635,6 +1690,17 @@ int ttsmi_hattention_dropmask(void* mask, int B, int H, int T, float p_drop, uin
     return TTSMI_OK;
 }
 
+#ifdef TTSMI_ABLATION_BUILD
+// measurement build: a device buffer of per-workgroup (one-pass backward) or per-wave (forward) records of the LAST launch
+static unsigned long long* g_fused_dbg = nullptr;
+static int g_fused_dbg_n = 0;
+extern "C" int ttsmi_debug_fused_dump(unsigned long long* host, int max_blocks) {
+    if (!g_fused_dbg) return 0;
+    const int n = g_fused_dbg_n < max_blocks ? g_fused_dbg_n : max_blocks;
+    if (hipMemcpy(host, g_fused_dbg, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+#endif
 int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
                          float* lse, int B, int H, int T, int dh, float p_drop, uint64_t seed,
                          const int64_t* step_dev, uint32_t site, int qh, const void* dropmask, hipStream_t st) {
@@ -1648,6 +1714,14 @@ int ttsmi_hattention_fwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     TTSMI_KNOB(fwd_pad, "TTSMI_ATTN_FWD_LDS", 0);        // A/B knob: 24576 caps the forward at 3 workgroups per CU
     TTSMI_ABLATE_KNOB(fwd_abl, "TTSMI_ATTN_FWD_ABLATE");  // measurement build only (see the kernel)
     p.ablate = fwd_abl;
+    p.dbg = nullptr;
+#ifdef TTSMI_ABLATION_BUILD
+    {   // per-wave section times of the LAST forward launch, read back with ttsmi_debug_fused_dump (4 records per block)
+        static unsigned long long* fbuf = nullptr;
+        if (!fbuf && hipMalloc(&fbuf, 8192 * 8 * sizeof(unsigned long long)) != hipSuccess) fbuf = nullptr;
+        if (grid.x * 4 <= 8192) { p.dbg = fbuf; g_fused_dbg = fbuf; g_fused_dbg_n = (int)grid.x * 4; }
+    }
+#endif
     HDISPATCH_LDS(dh, hattn_fwd_kernel, grid, fwd_pad, st, p);
     TTSMI_CHECK_LAUNCH("attention_fwd(bf16)");
     return TTSMI_OK;
@@ -1680,16 +1754,6 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     return TTSMI_OK;
 }
 
-#ifdef TTSMI_ABLATION_BUILD
-static unsigned long long* g_fused_dbg = nullptr;
-static int g_fused_dbg_n = 0;
-extern "C" int ttsmi_debug_fused_dump(unsigned long long* host, int max_blocks) {
-    if (!g_fused_dbg) return 0;
-    const int n = g_fused_dbg_n < max_blocks ? g_fused_dbg_n : max_blocks;
-    if (hipMemcpy(host, g_fused_dbg, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return n;
-}
-#endif
 // ---- one-pass backward (hattn_bwd_fused_kernel) ------------------------------------------------------------------------
 // Workspace layout (bytes): [0, 16) four int32 diagnostic counters ([0]: hand-offs that timed out, [1]: hand-offs between
 // different XCC ids / workgroups off their XCD; both stay 0), [16, 16 + S) the hand-off flags, one per (head, 64-query
