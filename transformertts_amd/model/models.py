@@ -37,7 +37,9 @@ from .transformer_utils import positional_encoding
 _DENSE_STACK = os.environ.get('TTSMI_DENSE_STACK', '1') != '0'      # A/B knob: 0 = one autograd node per planned block
 _PRED_LATE = os.environ.get('TTSMI_PRED_LATE', '1') != '0'      # A/B knob: 0 = predictors issued before the decoder (round 2)
 _PRED_ONE_NODE = os.environ.get('TTSMI_PRED_ONE_NODE', '1') != '0'  # A/B knob: 0 = eight autograd nodes per StatPredictor
-_BWD_SAME_THREAD = os.environ.get('TTSMI_BWD_SAME_THREAD', '1') != '0'  # A/B knob: 0 = backward on the autograd engine's thread
+# A/B knob: 1 = the backward pass on the calling thread (saves ~0.1 ms of host time per step, nothing on a GPU-bound step; off
+# by default: one of seven runs of the whole GPU suite with it on ended in an abort that was not reproduced or explained)
+_BWD_SAME_THREAD = os.environ.get('TTSMI_BWD_SAME_THREAD', '0') == '1'
 _DROPBITS_CONV = os.environ.get('TTSMI_ATTN_DROPBITS_CONV', '0') == '1'
 
 
@@ -818,9 +820,7 @@ class ForwardTransformer:
             loss, loss_vals = self._losses(model_out, ts, td, tp, unit_seed=True)    # seeded by loss.backward() below
             ops.enable_wgrad_stream(self.overlap_wgrad)
             try:
-                # the backward pass on THIS thread: handing the graph to the autograd engine's device thread and waiting for
-                # it costs ~0.1 ms of host time per step and buys nothing here (one graph, one device; the Functions
-                # pick their streams themselves)
+                # (TTSMI_BWD_SAME_THREAD=1: the backward pass on THIS thread instead of the autograd engine's device thread)
                 with ops.ln_param_batch(), torch.autograd.set_multithreading_enabled(not _BWD_SAME_THREAD):
                     loss.backward()                                                  # :480
                     self._mark('bwd')
