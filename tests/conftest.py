@@ -26,3 +26,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Leave the device idle and the garbage collected before the interpreter shuts down: captured graphs, side streams
+    and events of the last tests are then destroyed while the HIP runtime is still whole, not during its teardown."""
+    try:
+        import gc
+
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+            gc.collect()
+            torch.cuda.synchronize()
+    except Exception:  # pragma: no cover
+        pass
