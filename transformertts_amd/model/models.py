@@ -40,6 +40,8 @@ _PRED_ONE_NODE = os.environ.get('TTSMI_PRED_ONE_NODE', '1') != '0'  # A/B knob: 
 # A/B knob: 1 = the backward pass on the calling thread (saves ~0.1 ms of host time per step, nothing on a GPU-bound step; off
 # by default: one of seven runs of the whole GPU suite with it on ended in an abort that was not reproduced or explained)
 _BWD_SAME_THREAD = os.environ.get('TTSMI_BWD_SAME_THREAD', '0') == '1'
+# A/B knob: 0 = the per-layer path (conv blocks) leaves the sums of multiply-used tensors' gradients to autograd
+_GRAD_SINK = os.environ.get('TTSMI_GRAD_SINK', '1') == '1'
 _DROPBITS_CONV = os.environ.get('TTSMI_ATTN_DROPBITS_CONV', '0') == '1'
 
 
@@ -406,7 +408,7 @@ class ForwardTransformer:
                     dmask, site_planned, ev = pre
                     assert site_planned == sites[0], (p, site_planned, sites)
                     if ev is not None and ev is not waited_ev:
-                        torch.cuda.current_stream().wait_event(ev)
+                        ops.cur_stream().wait_event(ev)
                         waited_ev = ev
                 if h_bf is None:
                     h_bf = ops.to_bf16(h)
@@ -437,7 +439,7 @@ class ForwardTransformer:
                     dmask, site_planned, ev = pre
                     assert site_planned == sites[0], (p, site_planned, sites)
                     if ev is not None:
-                        torch.cuda.current_stream().wait_event(ev)
+                        ops.cur_stream().wait_event(ev)
                 h, h_bf, qkv, lse = ops.DenseBlockFn.apply(h, h_bf, Pb, Gb, Sb, pad, klen, B, H, T, rate, drop, sites,
                                                            dtype, want_attn, dmask)
                 if h_bf.numel() == 0:
@@ -456,8 +458,12 @@ class ForwardTransformer:
                     and S(f'{p}.wqkv') is not None and S(f'{p}.wo') is not None)
             if io_h and h_bf is None:
                 h_bf = ops.to_bf16(h)
+            # the block input's three gradients (qkv projection, q_in half of the output projection, residual) and the conv
+            # stack input's two are summed in place (ops.GradSink) instead of by autograd's add launches
+            sink_h = ops.GradSink() if (_GRAD_SINK and h.requires_grad) else None
+            sink_a = ops.GradSink() if (_GRAD_SINK and h.requires_grad) else None
             qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'],
-                                     S(f'{p}.wqkv'), io_h, h_bf if io_h else None)
+                                     S(f'{p}.wqkv'), io_h, h_bf if io_h else None, sink_h)
             site = drop.site()
             dmask = None
             pre = self._dropmask_plan.get(p) if self._dropmask_plan else None
@@ -465,7 +471,7 @@ class ForwardTransformer:
                 dmask, site_planned, ev = pre
                 assert site_planned == site, (p, site_planned, site)
                 if ev is not None:
-                    torch.cuda.current_stream().wait_event(ev)
+                    ops.cur_stream().wait_event(ev)
             ctx, lse = ops.AttentionFn.apply(qkv, pad, klen, B, H, T, d // H, rate, drop, site,
                                              ops._lib.TTSMI_BF16 if self.precision == 'bf16' else ops.TTSMI_F32, dmask)
             if want_attn:
@@ -474,10 +480,11 @@ class ForwardTransformer:
                 attn[key] = ops.attention_weights(qkv.detach(), pad, lse, B, H, T, d // H, rate, drop, site,
                                                   ops._lib.TTSMI_BF16_IO if io_h else ops.TTSMI_F32, dmask if io_h else None)
             o = ops.LinearFn.apply(h, ctx, W[f'{p}.wo'], W[f'{p}.bo'], G[f'{p}.wo'], G[f'{p}.bo'], S(f'{p}.wo'),
-                                   False, h_bf if io_h else None)
+                                   False, h_bf if io_h else None, sink_h)
             h_bf = None
             a = ops.add_layernorm(o, h, W[f'{p}.ln1.gamma'], W[f'{p}.ln1.beta'], G[f'{p}.ln1.gamma'],
-                                  G[f'{p}.ln1.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop)
+                                  G[f'{p}.ln1.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop,
+                                  res_sink=sink_h)
             if dense:
                 f = ops.FFNFn.apply(a, W[f'{p}.ffn.w1'], W[f'{p}.ffn.b1'], W[f'{p}.ffn.w2'], W[f'{p}.ffn.b2'],
                                     G[f'{p}.ffn.w1'], G[f'{p}.ffn.b1'], G[f'{p}.ffn.w2'], G[f'{p}.ffn.b2'],
@@ -491,9 +498,10 @@ class ForwardTransformer:
                     ps += [W[f'{p}.conv{j}.w'], W[f'{p}.conv{j}.b']]
                     gs += [G[f'{p}.conv{j}.w'], G[f'{p}.conv{j}.b']]
                 shs = tuple(S(f'{p}.conv{j}.w') for j in range(n))
-                f = ops.ConvStackFn.apply(a.reshape(B, T, d), n, shs, *ps, *gs).reshape(M, d)
+                f = ops.ConvStackFn.apply(a.reshape(B, T, d), n, shs, *ps, *gs, sink_a).reshape(M, d)
             h = ops.add_layernorm(f, a, W[f'{p}.ln2.gamma'], W[f'{p}.ln2.beta'], G[f'{p}.ln2.gamma'],
-                                  G[f'{p}.ln2.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop, want_h=io_h)
+                                  G[f'{p}.ln2.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop, want_h=io_h,
+                                  res_sink=None if dense else sink_a)
             if io_h:
                 h, h_bf = h             # the next block's bf16 GEMM operand, written by the same LayerNorm launch
             if self._taps is not None:
@@ -628,7 +636,7 @@ class ForwardTransformer:
                         and target_pitch is not None)
         self._deferred_pred = None
         if overlap_pred:
-            main = torch.cuda.current_stream()
+            main = ops.cur_stream()
             if self._pred_stream is None:
                 self._pred_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('TTSMI_PRED_PRIO', '0')))
             side = self._pred_stream
@@ -637,7 +645,7 @@ class ForwardTransformer:
             n_dur, n_pit = len(c['duration_conv_filters']), len(c['pitch_conv_filters'])
 
             def run_predictors(h=h, pad_e=pad_e):
-                with torch.cuda.stream(side), ops.pin_stream(side.cuda_stream):
+                with ops.on_stream(side):
                     hb = ops.BranchFn.apply(h) if h.requires_grad else h      # one gradient edge, summed on the side stream
                     d_ = self._stat_predictor('dur', hb, pad_e, n_dur, True, prate)
                     p_ = self._stat_predictor('pitch', hb, pad_e, n_pit, False, prate)
@@ -717,7 +725,7 @@ class ForwardTransformer:
             return
         d = c['encoder_model_dimension']
         l = ops._lib.lib()
-        main = torch.cuda.current_stream()
+        main = ops.cur_stream()
         if self._pred_stream is None:
             self._pred_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('TTSMI_PRED_PRIO', '0')))
         side = self._pred_stream
@@ -738,7 +746,7 @@ class ForwardTransformer:
                 if (i < nd and dh in (32, 64) and d % 64 == 0) or (i >= nd and dh in (32, 64, 192) and _DROPBITS_CONV):
                     plans.append((f'{prefix}.blk{i}', H, T, site + 1))
                 site += 3
-        with torch.cuda.stream(side), ops.pin_stream(side.cuda_stream):
+        with ops.on_stream(side):
             for prefix in ('enc', 'dec'):          # encoder tables first, with their own event: the encoder starts
                 ev = None                          # ~50 us into the step, the decoder ~1 ms
                 for name, H, T, st in plans:
@@ -769,7 +777,7 @@ class ForwardTransformer:
     def _join_predictors(self):
         """Main stream waits for the predictor side stream (no-op when nothing is in flight there)."""
         if self._pred_pending:
-            torch.cuda.current_stream().wait_stream(self._pred_stream)
+            ops.cur_stream().wait_stream(self._pred_stream)
         self._pred_keep = None
 
     # ------------------------------------------------------------------ steps (models.py:464-507)

@@ -37,6 +37,53 @@ def _stream():
     return h if h is not None else torch.cuda.current_stream().cuda_stream
 
 
+# torch.cuda.current_stream() builds a Stream object behind three device-index helpers (~9 us a call, ~28 calls per train
+# step through Event.record() / `with torch.cuda.stream(...)`).  While a stream is pinned it IS the current stream (every
+# place that pins one also makes it current, and autograd replays a backward node on the stream its forward ran on, which is
+# the handle the node pins), so the object can be remembered by (handle, device).
+_STREAM_OBJS = {}
+
+
+def _remember_stream(s):
+    if len(_STREAM_OBJS) > 64:
+        _STREAM_OBJS.clear()
+    _STREAM_OBJS[(s.cuda_stream, s.device.index)] = s
+    return s
+
+
+def cur_stream():
+    """The current torch.cuda.Stream - without asking torch when a stream is pinned."""
+    h = _PINNED_STREAM
+    if h is not None:
+        s = _STREAM_OBJS.get((h, torch.cuda.current_device()))
+        if s is not None:
+            return s
+    return torch.cuda.current_stream()
+
+
+class on_stream:
+    """`with ops.on_stream(side):` = `with torch.cuda.stream(side), ops.pin_stream(side.cuda_stream):` for a stream of the
+    current device, without the two current_stream() look-ups of torch's context manager."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        global _PINNED_STREAM
+        self.prev_obj = cur_stream()
+        self.prev = _PINNED_STREAM
+        _remember_stream(self.stream)
+        torch.cuda.set_stream(self.stream)
+        _PINNED_STREAM = self.stream.cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        global _PINNED_STREAM
+        _PINNED_STREAM = self.prev
+        torch.cuda.set_stream(self.prev_obj)
+        return False
+
+
 # LayerNorm parameter gradients of a training step, finished in one launch.  Inside `ln_param_batch()` the
 # LayerNorm backward calls that write into caller-owned gradient sinks leave their per-workgroup partial sums in
 # their workspaces (kept alive here) and `ln_flush()` reduces all of them with ONE kernel
@@ -110,7 +157,7 @@ class pinned_stream:
     def __enter__(self):
         global _PINNED_STREAM
         self.prev = _PINNED_STREAM
-        _PINNED_STREAM = torch.cuda.current_stream().cuda_stream
+        _PINNED_STREAM = _remember_stream(torch.cuda.current_stream()).cuda_stream
         return self
 
     def __exit__(self, *exc):
@@ -549,20 +596,17 @@ def _on_wgrad_stream(fn, *inputs):
     if not _WgradStream.enabled:
         return fn()
     W = _WgradStream.cur()
-    main = torch.cuda.current_stream()
+    main = cur_stream()
     if W.stream is None:
         W.stream = torch.cuda.Stream(priority=_WGRAD_PRIO)
     side = W.stream
     side.wait_stream(main)                    # the operands were produced on the main stream
-    global _PINNED_STREAM
-    prev = _PINNED_STREAM
-    with torch.cuda.stream(side):
-        if prev is not None:
-            _PINNED_STREAM = side.cuda_stream
-        try:
+    if _PINNED_STREAM is not None:
+        with on_stream(side):
             fn()                              # workspace allocated in here belongs to the side stream
-        finally:
-            _PINNED_STREAM = prev
+    else:
+        with torch.cuda.stream(side):
+            fn()
     # Hold a reference until the join (which makes the main stream wait for the side stream):
     #  * the caching allocator cannot recycle the operands while the side stream may still read them
     #    (no record_stream needed, which also keeps this legal under hipGraph capture);
@@ -592,7 +636,7 @@ def wgrad_rows_async(x, dy, dw, db, conv=None):
     if W.handle is None:
         W.handle = W.stream.cuda_stream
     ev = torch.cuda.Event()
-    ev.record()                               # on the current (main) stream: the operands are complete here
+    ev.record(cur_stream())                   # on the current (main) stream: the operands are complete here
     W.stream.wait_event(ev)
     M, N = x.shape[0], dy.shape[1]
     taps, T, C, pad = conv if conv is not None else (1, 0, 0, 0)
@@ -613,7 +657,7 @@ def wgrad_rows_async(x, dy, dw, db, conv=None):
 def wgrad_join():
     W = _WgradStream.cur()
     if W.pending:
-        torch.cuda.current_stream().wait_stream(W.stream)
+        cur_stream().wait_stream(W.stream)
         W.pending = False
     W.keep.clear()
 
@@ -657,6 +701,20 @@ def _sink(g, like):
 # =================================================================================================
 # autograd Functions (one per fused layer)
 # =================================================================================================
+class GradSink:
+    """The gradient of a tensor with several consumers on the per-layer path (a block's input feeds the qkv projection, the
+    q_in half of the output projection and the residual of res-norm 1; the conv stack's input is also res-norm 2's residual),
+    summed WITHOUT autograd's add launches.  The residual's LayerNorm backward runs first among the consumers (it consumes
+    what the others produce): it returns its `dres` to autograd as usual and leaves the tensor here; the other consumers
+    ADD their contribution into it in place (the dgrad GEMM's accumulate epilogue) and return None.  Autograd keeps the
+    first gradient that arrives by reference and calls the producer's backward only after every consumer's has run, in
+    stream order - by then the buffer holds the sum.  One object per (tensor, step); never shared across steps."""
+    __slots__ = ('buf',)
+
+    def __init__(self):
+        self.buf = None
+
+
 class LinearFn(torch.autograd.Function):
     """y = [x | x2] . w + b.   Dense at model/layers.py:116-120,148-149; model/models.py:422.
     bf16 plumbing of the per-layer path (conv blocks): out_bf16 stores y as bf16 (the attention kernels' operand);
@@ -664,7 +722,8 @@ class LinearFn(torch.autograd.Function):
     context) receives its gradient as bf16."""
 
     @staticmethod
-    def forward(ctx, x, x2, w, b, gw, gb, sh=None, out_bf16=False, x_h=None):
+    def forward(ctx, x, x2, w, b, gw, gb, sh=None, out_bf16=False, x_h=None, x_sink=None):
+        ctx.x_sink = x_sink
         x = _c(x)
         x2 = None if x2 is None else _c(x2)
         xa = x if x_h is None else _c(x_h)
@@ -689,7 +748,13 @@ class LinearFn(torch.autograd.Function):
         dw = _sink(gw, w)
         db = _sink(gb, w[0]) if ctx.has_b else None
         sh, K = ctx.sh, w.shape[0]
-        dx = dense_dgrad(dy, w, sh, 0, K1) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            sink = ctx.x_sink
+            if sink is not None and sink.buf is not None:
+                dense_dgrad(dy, w, sh, 0, K1, out=sink.buf.view(dy.shape[0], K1), accumulate=True)     # (GradSink)
+            else:
+                dx = dense_dgrad(dy, w, sh, 0, K1)
         dyT = dense_wgrad(x, dy, dw[:K1], db, sh)
         dx2 = None
         if x2 is not None:
@@ -700,7 +765,7 @@ class LinearFn(torch.autograd.Function):
                     dx2 = dense_dgrad(dy, w, sh, K1, K)
             dense_wgrad(x2, dy, dw[K1:], None, sh, dyT)
         return (dx, dx2, (None if gw is not None else dw), (None if (gb is not None or db is None) else db),
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 class FFNFn(torch.autograd.Function):
@@ -854,15 +919,23 @@ class ConvStackFn(torch.autograd.Function):
                     nxt.index_fill_(0, ConvStackFn._margin_rows(B, T, p, dy.device, 'ends'), 0)
                     g = nxt
                 else:
-                    dx = nxt[:rows].view(B, T + 2 * p, cin)[:, p:p + T].contiguous()
+                    inner = nxt[:rows].view(B, T + 2 * p, cin)[:, p:p + T]
+                    sink = ctx.x_sink
+                    if sink is not None and sink.buf is not None:       # (GradSink: one strided add instead of copy + add)
+                        sink.buf.view(B, T, cin).add_(inner)
+                    else:
+                        dx = inner.contiguous()
             outs[2 * j] = None if gw is not None else dw
             outs[2 * j + 1] = None if gb is not None else db
-        return (dx, None, None, *outs, *([None] * len(sinks)))
+        return (dx, None, None, *outs, *([None] * ctx.n_extra))
 
     @staticmethod
     def forward(ctx, x, n_layers, shadows, *args):
+        """args = the 2 n parameters, then (optionally) their 2 n gradient sinks, then (optionally) a GradSink for x."""
         x = _c(x)
-        params, sinks = args[:2 * n_layers], args[2 * n_layers:]
+        params, sinks = args[:2 * n_layers], args[2 * n_layers:4 * n_layers]
+        ctx.x_sink = args[4 * n_layers] if len(args) > 4 * n_layers else None
+        ctx.n_extra = len(args) - 2 * n_layers
         ctx.plain = None
         if ConvStackFn._plain_ok(x, n_layers, shadows, params):
             return ConvStackFn._forward_plain(ctx, x, n_layers, shadows, params, sinks)
@@ -923,7 +996,11 @@ class ConvStackFn(torch.autograd.Function):
                 g = conv1d_dgrad(g, w, relu_src=relu_src)
             outs[2 * j] = None if gw is not None else dw
             outs[2 * j + 1] = None if gb is not None else db
-        return (g, None, None, *outs, *([None] * len(sinks)))
+        sink = ctx.x_sink
+        if sink is not None and sink.buf is not None:
+            sink.buf.view_as(g).add_(g)
+            g = None
+        return (g, None, None, *outs, *([None] * ctx.n_extra))
 
 
 class AddLayerNormFn(torch.autograd.Function):
@@ -931,8 +1008,9 @@ class AddLayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta, ggamma, gbeta, pe, pe_scale, gpe_scale, T, row_pad,
-                p_in, site_in, p_out, site_out, drop, relu_in, want_h=False):
+                p_in, site_in, p_out, site_out, drop, relu_in, want_h=False, res_sink=None):
         ctx.stream_h = _stream()         # backward launches on the stream forward ran on (predictor side stream)
+        ctx.res_sink = res_sink
         x = _c(x)
         res = None if res is None else _c(res)
         shp = x.shape
@@ -959,7 +1037,7 @@ class AddLayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dy_h=None):
         with pin_stream(ctx.stream_h):
-            return AddLayerNormFn._backward(ctx, dy) + (None,)
+            return AddLayerNormFn._backward(ctx, dy) + (None, None)
 
     @staticmethod
     def _backward(ctx, dy):
@@ -968,9 +1046,10 @@ class AddLayerNormFn(torch.autograd.Function):
         ggamma, gbeta, gpe = ctx.sinks
         dy = _c(dy)
         dx = torch.empty_like(x)
+        sink = getattr(ctx, 'res_sink', None)
         if res is None:
             dres = None
-        elif p_in > 0 or relu_in:
+        elif p_in > 0 or relu_in or sink is not None:      # (a GradSink's buffer is added into: it cannot be dx)
             dres = torch.empty_like(x)
         else:
             dres = dx
@@ -991,6 +1070,8 @@ class AddLayerNormFn(torch.autograd.Function):
               'add_layernorm_bwd')
         if defer:
             _ln_defer(ws, dgamma, dbeta, dps, M, C)
+        if sink is not None and dres is not None:
+            sink.buf = dres
         n = lambda g, d: None if g is not None else d
         dps_out = None
         if pe is not None and gpe is None:
@@ -1000,10 +1081,11 @@ class AddLayerNormFn(torch.autograd.Function):
 
 
 def add_layernorm(x, res, gamma, beta, ggamma=None, gbeta=None, pe=None, pe_scale=None, gpe_scale=None,
-                  T=0, row_pad=None, p_in=0.0, site_in=0, p_out=0.0, site_out=0, drop=None, relu_in=False, want_h=False):
-    """want_h: returns (y, y as bf16) - the copy costs no launch of its own."""
+                  T=0, row_pad=None, p_in=0.0, site_in=0, p_out=0.0, site_out=0, drop=None, relu_in=False, want_h=False,
+                  res_sink=None):
+    """want_h: returns (y, y as bf16) - the copy costs no launch of its own.  res_sink: see GradSink."""
     return AddLayerNormFn.apply(x, res, gamma, beta, ggamma, gbeta, pe, pe_scale, gpe_scale, T, row_pad,
-                                p_in, site_in, p_out, site_out, drop, relu_in, want_h)
+                                p_in, site_in, p_out, site_out, drop, relu_in, want_h, res_sink)
 
 
 class AttentionFn(torch.autograd.Function):
