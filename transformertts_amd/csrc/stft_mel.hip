@@ -43,26 +43,43 @@ __device__ __forceinline__ int clip_of_frame(const int64_t* frame_off, int n_cli
 }
 
 template <int NFFT>
-__global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
+__global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(MelP p) {
     constexpr int NC = NFFT / 2;                // complex points
     constexpr int NSUB = NC / SUBN;             // 512-point sub-transforms per frame (1 or 2)
     constexpr int PPL = NC / 64;                // complex points per lane
     constexpr int MEL_ITEMS = NFFT == 1024 ? 128 : 256;   // LDS item-table capacity (LJSpeech bank: 105 items)
     constexpr int MELW_MAX = NFFT == 1024 ? 1536 : 2304;  // LDS copy of the sparse weights (<= 2 per bin)
-    __shared__ float2 tw[NFFT];                       // exp(-2 pi i k / NFFT)
+    // twiddles.  NSUB == 1 (n_fft 1024): the three passes only index the EVEN entries of exp(-2 pi i k / NFFT) = the table
+    // of the 512-point transform itself (tw, NC entries), the real-FFT post-processing the first NC / 2 of the full table
+    // (twp): 6 KB instead of 8 - with the set-up arrays below living in the exchange buffers that brings a workgroup to
+    // 40 KB of LDS, FOUR per CU.  NSUB == 2: the full table (its radix-2 stage and post-processing index all of it).
+    constexpr int TWN = NSUB == 1 ? NC : NFFT;          // entries / period of tw
+    __shared__ float2 tw[TWN];
+    __shared__ float2 twp[NSUB == 1 ? NC / 2 : 1];
     __shared__ float2 buf[FR_PER_WG][NSUB][ZBUF];     // padded: physical index = i + (i >> 3)
     __shared__ __attribute__((aligned(16))) float mag[FR_PER_WG][NC + 8 + MEL_IT];      // bins NC+1.. stay 0 (mel items may read past NC)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int k = tid; k < NFFT; k += 256) {
+    for (int k = tid; k < TWN; k += 256) {
         float s, c;
-        sincospif(-2.0f * (float)k / (float)NFFT, &s, &c);
+        sincospif(-2.0f * (float)k / (float)TWN, &s, &c);
         tw[k] = make_float2(c, s);
+    }
+    if constexpr (NSUB == 1) {
+        for (int k = tid; k < NC / 2; k += 256) {
+            float s, c;
+            sincospif(-2.0f * (float)k / (float)NFFT, &s, &c);
+            twp[k] = make_float2(c, s);
+        }
     }
     // sparse filterbank -> LDS once per workgroup (727 weights + 3 x 80 ints for the LJSpeech setting);
     // larger banks than the LDS copy holds are read from global memory instead
-    __shared__ float melwS[MELW_MAX];
-    __shared__ int melloS[MELS_MAX], melcntS[MELS_MAX], melptrS[MELS_MAX];
+    // (set-up only: the copy lives in the exchange buffers, which the first transform overwrites)
+    static_assert(sizeof(float) * MELW_MAX + 3 * sizeof(int) * MELS_MAX <= sizeof(buf), "the filterbank copy lives in buf");
+    float* melwS = reinterpret_cast<float*>(&buf[0][0][0]);
+    int* melloS = reinterpret_cast<int*>(melwS + MELW_MAX);
+    int* melcntS = melloS + MELS_MAX;
+    int* melptrS = melcntS + MELS_MAX;
     const int nnz = p.mel_ptr[p.n_mels - 1] + p.mel_cnt[p.n_mels - 1];
     const bool mel_in_lds = (nnz <= MELW_MAX) && (p.n_mels <= MELS_MAX);
     if (mel_in_lds) {
@@ -78,7 +95,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
     // sums one item per round, a second short pass adds the (<= 4) partial sums of each filter.
     __shared__ int itLo[MEL_ITEMS], itFirst[MELS_MAX + 1];
     __shared__ __attribute__((aligned(16))) float itWt[MEL_ITEMS][MEL_IT];   // zero-padded: fixed trip count
-    __shared__ float partS[FR_PER_WG][MEL_ITEMS];
+    static_assert(sizeof(float) * MEL_ITEMS <= sizeof(buf[0][0]), "a wave's partial sums live in its exchange buffer");
     if (mel_in_lds) {
         if (tid == 0) {
             // an item starts at a multiple of 4 bins (the filter's first bin rounded down, zero weights in front): its
@@ -115,6 +132,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         for (int m = 0; m < p.n_mels; ++m) bin_hi = max(bin_hi, melloS[m] + melcntS[m] - 1);
         bin_hi = __builtin_amdgcn_readfirstlane(bin_hi);
     }
+    __syncthreads();                                  // the last readers of the filterbank copy: buf is the transforms' from here
 
     float2* zb = buf[wave][0];
     float* mg = mag[wave];
@@ -196,7 +214,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         if (g + 1 < p.groups_per_wg) prefetch_frame(f + FR_PER_WG, xs);
         const bool full = !(TTSMI_ABLATE_BITS(p.ablate) & 4);
         if constexpr (NSUB == 1) {
-            fft512<NFFT>(w, zb, tw, lane, full);           // Z[k] in zb[ZP(k)]
+            fft512<NC>(w, zb, tw, lane, full);             // Z[k] in zb[ZP(k)]
         } else {
             // radix-2 DIF stage in registers: z[n] and z[n + 512] sit in the same lane (r and r + 8);
             //   even bins Z[2k]   = FFT512(z[n] + z[n+512])
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
             float2 zc = Z((NC - k) & (NC - 1));
             zc.y = -zc.y;
             float2 e = cadd(zk, zc), o = csub(zk, zc);
-            float2 wo = cmul(tw[k], o);
+            float2 wo = cmul(NSUB == 1 ? twp[k] : tw[k], o);
             float xr = e.x + wo.y, xi = e.y - wo.x;            // 2 X[k]
             mg[k] = 0.5f * __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
             if (NC - 64 * it - 63 > bin_hi + MEL_IT) continue;  // wave-uniform: no mirror bin of this round is read (they stay 0)
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         WAVE_SYNC();
         // ---- sparse mel + normalisation ---------------------------------------------------------
         if (mel_items && !(TTSMI_ABLATE_BITS(p.ablate) & 2)) {
-            float* part = partS[wave];
+            float* part = reinterpret_cast<float*>(buf[wave][0]);      // (the transform's values have been consumed)
             // The products are formed as PAIRS along the weight index (v_pk_fma_f32 on the two halves of each 16-byte read):
             // written with four scalar accumulators, hipcc's SLP pass paired the SAME accumulator of two loop iterations
             // instead and spent 36 v_mov_b32 per 12 packed FMAs shuffling the operands together (ISA reading, round 4).
@@ -268,13 +286,9 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(MelP p) {
         for (int m = lane; m < p.n_mels && !(TTSMI_ABLATE_BITS(p.ablate) & 2); m += 64) {
             float s = 0.f;
             if (mel_items) {
-                const float* part = partS[wave];
+                const float* part = reinterpret_cast<const float*>(buf[wave][0]);
                 for (int j = itFirst[m]; j < itFirst[m + 1]; ++j) s += part[j];
-            } else if (mel_in_lds) {
-                const int lo = melloS[m], cnt = melcntS[m];
-                const float* w = melwS + melptrS[m];
-                for (int i = 0; i < cnt; ++i) s += w[i] * mg[lo + i];
-            } else {
+            } else {                                  // a bank beyond the item table: straight from global memory
                 const int lo = p.mel_lo[m], cnt = p.mel_cnt[m];
                 const float* w = p.mel_w + p.mel_ptr[m];
                 for (int i = 0; i < cnt; ++i) s += w[i] * mg[lo + i];
@@ -319,10 +333,11 @@ int ttsmi_stft_logmel(const float* wav, const int64_t* clip_off, const int64_t* 
     long groups = (total_frames + FR_PER_WG - 1) / FR_PER_WG;
     // A workgroup's set-up (1024 sincospi, the filterbank copy, a SERIAL 80-step prefix over the filters, the weight
     // item table) costs ~10 us: with 64 frames per workgroup (round 1/2: gpw <= 16) that was ~13 % of a 10 000-clip
-    // launch.  Few, long-lived workgroups instead: ~32 per CU (3 resident, ~10 rounds: measured best of 768 .. 87 000), each a contiguous range of
+    // launch.  Few, long-lived workgroups instead: ~64 per CU (4 resident, ~16 rounds: measured best of 4 096 .. 24 576 at four
+    // resident - 1 327 / 1 386 / 1 416 / 1 410 GB/s at 4 096 / 8 192 / 16 384 / 24 576), each a contiguous range of
     // frames, so the set-up is amortised over hundreds of frames.  TTSMI_MEL_WGS overrides the target (A/B knob).
-    TTSMI_KNOB(target_env, "TTSMI_MEL_WGS", 8192);
-    const long target = target_env > 0 ? target_env : 8192;
+    TTSMI_KNOB(target_env, "TTSMI_MEL_WGS", 16384);
+    const long target = target_env > 0 ? target_env : 16384;
     long gpw_l = (groups + target - 1) / target;
     if (gpw_l < 1) gpw_l = 1;
     if (gpw_l > (1 << 20)) gpw_l = 1 << 20;
