@@ -459,7 +459,9 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
     hmask_sptr mrow = nullptr;
     HMaskWords mw;
     if (DROP == 2) {
-        const long tile_row = ((long)b * p.H + h) * ntile32 + __builtin_amdgcn_readfirstlane(bx * 4 + wave);
+        // (a wave whose 32 queries all lie past T - T = 900: tiles 29..31 of the last 128-row tile - reads the last real tile's
+        // words and ignores them: its own row would lie past this head's tiles, for the last head past the END of the table)
+        const long tile_row = ((long)b * p.H + h) * ntile32 + min(__builtin_amdgcn_readfirstlane(bx * 4 + wave), ntile32 - 1);
         mrow = (hmask_sptr)(p.dmask + tile_row * ntile32 * 16);
         hmask_request(mw, mrow);
     }
@@ -720,7 +722,9 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dq_kernel(HAtt
     hmask_sptr mrow = nullptr;
     HMaskWords mw;
     if (DROP == 2) {
-        const long tile_row = ((long)b * p.H + h) * ntile32 + __builtin_amdgcn_readfirstlane(bx * 4 + wave);
+        // (a wave whose 32 queries all lie past T - T = 900: tiles 29..31 of the last 128-row tile - reads the last real tile's
+        // words and ignores them: its own row would lie past this head's tiles, for the last head past the END of the table)
+        const long tile_row = ((long)b * p.H + h) * ntile32 + min(__builtin_amdgcn_readfirstlane(bx * 4 + wave), ntile32 - 1);
         mrow = (hmask_sptr)(p.dmask + tile_row * ntile32 * 16);
         hmask_request(mw, mrow);
     }

@@ -37,8 +37,9 @@ from .transformer_utils import positional_encoding
 _DENSE_STACK = os.environ.get('TTSMI_DENSE_STACK', '1') != '0'      # A/B knob: 0 = one autograd node per planned block
 _PRED_LATE = os.environ.get('TTSMI_PRED_LATE', '1') != '0'      # A/B knob: 0 = predictors issued before the decoder (round 2)
 _PRED_ONE_NODE = os.environ.get('TTSMI_PRED_ONE_NODE', '1') != '0'  # A/B knob: 0 = eight autograd nodes per StatPredictor
-# A/B knob: 1 = the backward pass on the calling thread (saves ~0.1 ms of host time per step, nothing on a GPU-bound step; off
-# by default: one of seven runs of the whole GPU suite with it on ended in an abort that was not reproduced or explained)
+# A/B knob: 1 = the backward pass on the calling thread (saves ~0.1 ms of host time per step, nothing on a GPU-bound step).
+# (It was switched off when a run of the whole GPU suite aborted; the abort was later traced to an out-of-bounds read of the
+# attention kernels - DESIGN.md section 4 - and had nothing to do with it; it stays opt-in until re-measured.)
 _BWD_SAME_THREAD = os.environ.get('TTSMI_BWD_SAME_THREAD', '0') == '1'
 # A/B knob: 0 = the per-layer path (conv blocks) leaves the sums of multiply-used tensors' gradients to autograd
 _GRAD_SINK = os.environ.get('TTSMI_GRAD_SINK', '1') == '1'
