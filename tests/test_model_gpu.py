@@ -298,6 +298,32 @@ def test_reference_default_config_at_full_depth_6_plus_6(precision):
     assert worst < (2e-4 if f32 else 0.15), worst
 
 
+@pytest.mark.parametrize('precision,rate', [('bf16', 0.1), ('bf16', 0.0), ('f32', 0.1)])
+def test_in_place_gradient_sums_of_the_per_layer_path_change_nothing(precision, rate, monkeypatch):
+    """ops.GradSink (the residual's LayerNorm backward leaves its dres, the other consumers of the tensor accumulate into it
+    through the dgrad GEMM's epilogue) against autograd's own add launches on the conv-block architecture: same loss, and
+    every gradient equal - bit for bit where the summation order is the same (it is: residual first, then the consumers in
+    backward order), with and without dropout (without it the LayerNorm backward must give the sink a tensor of its own)."""
+    import transformertts_amd.model.models as mm
+    cfg = fo.make_config(d_model=128, enc_heads=(2,) * 2, dec_heads=(2,) * 2, ffn=256, enc_dense_blocks=0,
+                         dec_dense_blocks=0, conv_filters=(256, 128), dur_filters=(64, 30), pitch_filters=(64, 30),
+                         dropout_rate=rate, predictors_dropout=rate)
+    W = fo.init_weights(cfg, seed=21, perturb=0.02)
+    batch = fo.synthetic_batch(3, 24, 70, seed=22, ragged=True)
+    runs = []
+    for sink in (True, False):
+        monkeypatch.setattr(mm, '_GRAD_SINK', sink)
+        m = _model(cfg, W, precision=precision)
+        m._compile(learning_rate=1e-3)
+        out = m.train_step(*batch)
+        runs.append((float(out['loss']), {k: np.asarray(v).copy() for k, v in m.grads_dict().items()}))
+    (la, ga), (lb, gb) = runs
+    assert la == lb
+    assert ga.keys() == gb.keys()
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+
+
 def test_graph_captured_predict_equals_eager_predict(tiny):
     """graph_inference=True (two hipGraphs: encoder side per input shape, decoder side per length bucket) returns what
     the eager predict returns - predicted durations (data-dependent length, speed regulator, per-symbol clamps) and
