@@ -155,3 +155,54 @@ def test_phonemizer_adapter_uses_the_dependency_when_present_and_raises_without_
     assert ids[0] == tt.tokenizer.start_token_index and ids[-1] == tt.tokenizer.end_token_index
     with pytest.raises(TypeError):
         ph(3)
+
+
+def test_autograd_keeps_the_first_gradient_by_reference_and_runs_the_producer_last():
+    """What ops.GradSink relies on, checked against the installed torch with three CPU Functions of the same shape as the
+    per-layer path: a tensor h feeds a consumer and, as the residual, the node that consumes the consumer's output.  The
+    residual node's backward runs first, returns its gradient for h and keeps the tensor; the consumer's backward adds its own
+    contribution INTO that tensor and returns None.  The producer of h must then be handed the sum - i.e. autograd stored the
+    first gradient by reference (no copy) and called the producer's backward only after every consumer's."""
+    import torch
+    sink, seen, order = {}, [], []
+
+    class Residual(torch.autograd.Function):              # like AddLayerNormFn with res_sink
+        @staticmethod
+        def forward(ctx, x, res):
+            return x + res
+
+        @staticmethod
+        def backward(ctx, g):
+            order.append('residual')
+            dres = g.clone()
+            sink['buf'] = dres
+            return g, dres
+
+    class Consumer(torch.autograd.Function):              # like LinearFn with x_sink: y = 2 h
+        @staticmethod
+        def forward(ctx, h):
+            return 2 * h
+
+        @staticmethod
+        def backward(ctx, g):
+            order.append('consumer')
+            sink['buf'].add_(2 * g)
+            return None
+
+    class Producer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            order.append('producer')
+            seen.append(g.clone())
+            return g
+
+    x = torch.ones(5, requires_grad=True)
+    h = Producer.apply(x)
+    y = Residual.apply(Consumer.apply(h), h)
+    y.sum().backward()
+    assert order == ['residual', 'consumer', 'producer']
+    assert torch.equal(seen[0], torch.full((5,), 3.0)) and torch.equal(x.grad, torch.full((5,), 3.0))
