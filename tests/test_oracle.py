@@ -291,3 +291,28 @@ def test_group_assembly_equals_the_whole_batch():
         np.testing.assert_allclose(parts['taps'][name], t.numpy(), rtol=0, atol=1e-12)
     for k, g in tr['grads'].items():
         np.testing.assert_allclose(parts['grads'][k], g.numpy(), rtol=0, atol=1e-12 + 1e-10 * float(g.abs().max()))
+
+
+@pytest.mark.parametrize('n_fft,win,hop,fmin,fmax', [(1024, 1024, 256, 0.0, 8000.0), (2048, 1100, 275, 40.0, 11025.0)])
+def test_mel_oracle_against_an_independent_restatement_of_librosa(n_fft, win, hop, fmin, fmax):
+    """librosa is not installable here, but `transformers.audio_utils` (Hugging Face; in this image and on the GPU box) carries
+    its own NumPy restatement of librosa's Slaney filterbank (`norm='slaney', mel_scale='slaney'`) and of its centred,
+    reflect-padded STFT, written and tested against librosa by other people.  It agrees with oracle/mel_oracle.py: the
+    filterbank to rounding, the log-mel of a clip to 1e-6 - for the LJSpeech / MelGAN setting and for the WaveRNN one
+    (n_fft 2048, window 1100 zero-padded and centred, hop 275, fmin 40: config/data_config_wavernn.yaml:16-23).  A third
+    restatement agreeing is evidence, not the reference's own vector: the row stays 'parity unpinned' in DESIGN.md."""
+    au = pytest.importorskip('transformers.audio_utils')
+    basis = mo.mel_filterbank(22050, n_fft, 80, fmin, fmax, dtype=np.float64)
+    fb = au.mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=80, min_frequency=fmin, max_frequency=fmax,
+                            sampling_rate=22050, norm='slaney', mel_scale='slaney')
+    assert fb.shape == basis.T.shape
+    assert np.abs(fb.T - basis).max() < 1e-12 * np.abs(basis).max() + 1e-15
+    y = mo.synthetic_clip(20000 + hop, seed=3)
+    w = au.window_function(win, 'hann', periodic=True, frame_length=n_fft, center=True)
+    S = au.spectrogram(y.astype(np.float64), w, frame_length=n_fft, hop_length=hop, fft_length=n_fft, power=1.0, center=True,
+                       pad_mode='reflect', mel_filters=fb, mel_floor=1e-5, log_mel='log', dtype=np.float64)
+    exact = mo.mel_spectrogram(y, n_fft=n_fft, hop_length=hop, win_length=win, f_min=fmin, f_max=fmax, exact=True)
+    assert S.T.shape == exact.shape
+    assert np.abs(S.T - exact).max() < 1e-6
+    fp32 = mo.mel_spectrogram(y, n_fft=n_fft, hop_length=hop, win_length=win, f_min=fmin, f_max=fmax)
+    assert np.abs(S.T - fp32).max() < 2e-5
