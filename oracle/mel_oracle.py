@@ -19,7 +19,8 @@ tests/test_reference_fixtures.py): the MelGAN / WaveRNN normalisers (data/audio.
 reference) - the STFT and the mel basis (librosa) are not.
 Anchors available without librosa (tests/test_oracle.py): the Slaney mel-frequency table from
 librosa's public documentation, torch.stft(center=True, reflect,
-periodic hann) on CPU, scipy's get_window, and analytic inputs (silence, pure sine).
+periodic hann) on CPU, scipy's get_window, analytic inputs (silence, pure sine), and a third party's NumPy restatement
+of librosa that is installed here (transformers.audio_utils: filterbank to rounding, log-mel to 1e-6).
 """
 from __future__ import annotations
 
