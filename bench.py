@@ -42,6 +42,40 @@ import torch
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
+# The roof that binds the bf16 flash-attention kernels is neither of the two above: the softmax / keep-bit / conversion
+# arithmetic runs on the vector ALU of the SIMD whose matrix pipe does the products.  Vector-ALU issue cycles per SCORE
+# ROW (one wave64 instruction stream covering 64 scores), keep-bit dropout, dh = 64: the instruction mix of each kernel's
+# inner loop read from its ISA (forward ~6 per score; dQ ~8; dK/dV: 2 v_and + v_bfe + v_sub + 1.2 v_fma + v_exp +
+# v_cvt_pk + 0.9 packed = 8.2) times the measured issue cost per wave64 instruction at 4 waves per SIMD
+# (profiles/r04_valu_rates.txt: v_fma / v_and 2.9, v_cndmask / v_cvt_pk / v_bfe 4.25, packed fp32 4.35, v_exp_f32 8.2).
+ATTN_VALU_CYCLES_PER_SCORE_ROW = {'fwd': 26.9, 'bwd': 30.0 + 32.7}           # bwd = dQ + dK/dV (two recomputations)
+SIMDS, SIMD_CLOCK_GHZ = 1024, 2.3                                            # 256 CUs x 4; clock read in the probes: 2.2-2.4
+
+
+def add_attention_valu_roofs(per_kernel: dict, cfg: dict) -> None:
+    """valu_roof_* fields for the bf16 attention families of a `roofline.per_kernel` table (dh = 64 architectures: the
+    instruction counts above are those kernels'); never raises - a missing family or key just leaves the table as it is."""
+    try:
+        heads = cfg.get('decoder_num_heads') or []
+        dh = cfg['decoder_model_dimension'] // heads[0] if heads else 0
+        if dh != 64:
+            return
+        for fam, which in ((HATTN_FWD, 'fwd'), (HATTN_BWD, 'bwd')):
+            e = per_kernel.get(fam)
+            if e and e.get('gflop') and e.get('ms'):
+                e.update(attention_valu_roof(e['gflop'] * 1e9, e['ms'], dh, which))
+    except Exception:       # noqa: BLE001 - a reporting extra must not cost the bench line
+        pass
+
+
+def attention_valu_roof(flops: float, ms: float, dh: int, which: str) -> dict:
+    """Vector-ALU roof of an attention family: `flops` = its algorithmic FLOPs (forward 4 T^2 dh, backward 8 T^2 dh per
+    head), `ms` its measured launch time.  valu_roof_ms = the time the chip's vector ALUs alone need for the scores'
+    arithmetic; valu_roof_frac = that / ms (1.0 = the kernel runs at the VALU roof)."""
+    scores = flops / ((4.0 if which == 'fwd' else 8.0) * dh)
+    cyc = ATTN_VALU_CYCLES_PER_SCORE_ROW[which]
+    roof_ms = scores / 64.0 * cyc / SIMDS / (SIMD_CLOCK_GHZ * 1e9) * 1e3
+    return {'valu_cycles_per_score_row': cyc, 'valu_roof_ms': roof_ms, 'valu_roof_frac': (roof_ms / ms if ms else None)}
 
 
 def workload_config(name: str):
@@ -1023,6 +1057,9 @@ def main():
             'main_stream_launch_ms': sum(v[3] for k, v in groups.items() if not k.endswith(SIDE)),
             'side_stream_launch_ms': sum(v[3] for k, v in groups.items() if k.endswith(SIDE)),
         }
+        # the attention families against the roof that binds them (the vector ALU: see ATTN_VALU_CYCLES_PER_SCORE_ROW)
+        if args.precision == 'bf16':
+            add_attention_valu_roofs(result['roofline']['per_kernel'], cfg)
         # SURVEY 8d names the MFMA roof for the STEP (a dense contraction): algorithmic matmul FLOPs of the whole step
         # (entry points' 2 per MAC, no recompute) over the timed step, against the dense bf16 / fp32 MFMA peak
         step_flops = sum(v[1] for v in groups.values())
