@@ -728,6 +728,36 @@ def also_legs(dev, cfg, shape, dropout, step_flops):
                              'batch64_mfma_frac': rf['batch64']['frac'], 'batch64_tflops': rf['batch64']['achieved']},
                 'cpu_baseline': predict_cpu_baseline(cfg_p, Tp, usable_cpus(), seconds=4.0)}
     run('predict', predict)
+
+    # the two workloads that were builder-run files only until round 4, each in its OWN process (fresh allocator, fresh
+    # plans; the child prints the same one-line JSON this process would): the bucketed ragged batches the reference
+    # actually trains on (train_tts.py:149-160 over data/datasets.py:238-284) and the reference's shipped architecture
+    # (config/training_config.yaml:104-118)
+    def child(argv, keep):
+        import subprocess
+        env = dict(os.environ)
+        env.pop('WORLD_SIZE', None), env.pop('RANK', None), env.pop('LOCAL_RANK', None)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=420, env=env)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f'rc {r.returncode}: {r.stderr.strip()[-400:]}')
+        d = json.loads(lines[-1])
+        return {k: d[k] for k in keep if k in d}
+
+    run('lj_dist', lambda: child(['--workload', 'lj-dist', '--steps', '200', '--warmup', '20', '--dropout', str(dropout)],
+                                 ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config',
+                                  'distinct_batch_shapes', 'padding_fraction', 'padded_mel_frames_per_s',
+                                  'host_stall_ms_per_step', 'host_issue_ms_per_step', 'allocator_growth_mb',
+                                  'us_per_padded_frame', 'max_shape', 'ragged_over_max_shape_per_padded_frame')))
+    run('ref_default', lambda: child(['--workload', 'ref-default', '--steps', '20', '--warmup', '4', '--no-cpu-baseline',
+                                      '--no-attention-maps', '--no-also', '--dropout', str(dropout)],
+                                     ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config',
+                                      'host_issue_ms_per_step', 'roofline')))
+    rd = legs.get('ref_default', {})
+    if 'roofline' in rd:               # the line stays readable: the step's own roof, not the per-kernel table
+        rf = rd['roofline']
+        rd['roofline'] = {k: rf.get(k) for k in ('step_gflop', 'step_tflops', 'step_mfma_frac', 'kernel', 'bound', 'frac',
+                                                 'main_stream_launch_ms', 'side_stream_launch_ms')}
     return legs
 
 
@@ -981,18 +1011,28 @@ def main():
 
     # the same step with the reference's full output dictionary: the 12 attention maps [B,H,T,T] of
     # model/models.py:544-549 materialised too (train_step leaves them out unless asked: reference_outputs=True)
-    ms_attn = None
+    ms_attn = maps_alloc = None
     if args.with_attention_maps and args.precision == 'bf16':
         model.reference_outputs = True
-        for _ in range(2):
-            step()
+        out_a = None
+        for _ in range(3):                   # warm-up in the timed loop's own form (the previous step's output still held)
+            out_a = step()
         sync()
+        st0 = torch.cuda.memory_stats(dev)
         t1 = time.perf_counter()
         n_attn = max(3, args.steps // 2)
         for _ in range(n_attn):
             out_a = step()
         sync()
         ms_attn = 1e3 * (time.perf_counter() - t1) / n_attn
+        st1 = torch.cuda.memory_stats(dev)
+        # allocator activity INSIDE the timed maps loop (BENCH_r04: 11.3 ms at --steps 20 against 6.2 at --steps 40 -
+        # 2.7 GB of fresh map tensors per step went through the allocator; now a ring of persistent buffers, models.py)
+        maps_alloc = {'steps': n_attn, 'map_ring': bool(model.map_ring),
+                      'reserved_growth_mb': (st1['reserved_bytes.all.current'] - st0['reserved_bytes.all.current']) / 1e6,
+                      'segment_allocs': st1['segment.all.allocated'] - st0['segment.all.allocated'],
+                      'alloc_retries': st1['num_alloc_retries'] - st0['num_alloc_retries'],
+                      'device_mallocs': st1.get('num_device_alloc', 0) - st0.get('num_device_alloc', 0)}
         if world > 1:
             t = torch.tensor([ms_attn], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -1000,6 +1040,7 @@ def main():
         assert len(out_a['decoder_attention']) == len(cfg['decoder_num_heads'])
         del out_a
         model.reference_outputs = False
+        model._map_bufs.clear()
 
     result = {
         'metric': 'mel-frames/sec (train step)', 'value': frames / (elapsed / args.steps),
@@ -1016,6 +1057,7 @@ def main():
         # value/ms_per_step: train_step without the 12 [B,H,T,T] attention maps in its output (they are
         # not materialised on the throughput path); the second figure is the same step returning them all
         'ms_per_step_with_attention_maps': ms_attn,
+        'attention_maps_allocator': maps_alloc,
         # host time to enqueue one step (Python + ctypes launch loop); when it approaches ms_per_step the host, not
         # the GPU, bounds the step
         'host_issue_ms_per_step': 1e3 * host_issue / args.steps,
@@ -1049,7 +1091,9 @@ def main():
             'per_kernel': {k: {'launches': v[0], 'gflop': v[1] / 1e9, 'algorithmic_mb': v[2] / 1e6, 'ms': v[3],
                                'tflops': (v[1] / v[3] / 1e9 if v[1] else None),
                                'gbs': (v[2] / v[3] / 1e6 if v[2] else None)} for k, v in groups.items()},
-            'c_abi_calls_per_step': sum(v[0] for v in groups.values()),
+            # launches seen by the observer hook (kernel launches issued from inside the library), NOT C-ABI calls: the
+            # stack launchers issue ~90 launches per call (the step is ~107 C-ABI calls, profiles/r04_host_split.txt)
+            'hooked_launches_per_step': sum(v[0] for v in groups.values()),
             'launch_ms_note': 'sums of per-launch HIP-event times from ONE extra instrumented step (every launch '
                               'bracketed by two events while the weight-gradient stream contends): slower than the '
                               'timed steps, so main_stream_launch_ms may exceed ms_per_step',

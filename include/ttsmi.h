@@ -155,9 +155,12 @@ int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const in
  *       hand-offs off the XCC that block id % 8 names - the placement that keeps the image in one L2);
  *   _supported: non-zero when (B, H, T, dh) can run on a workspace of ws_bytes (dh == 64, counters + tiles fit); the
  *       entry point returns TTSMI_ERR_UNSUPPORTED otherwise and the caller uses ttsmi_attention_bwd.
- * Round-4 status: correct and reproducible, but at the benchmark shape (32, 4, 900, 64) it runs in 222 us against 183 us
- * for ttsmi_attention_bwd_masked (csrc/attention_bf16.hip has the timeline and the stage ablation), so the dense-block
- * launcher only uses it with TTSMI_ATTN_FUSED_BWD=1. */
+ * Round-4 status: correct and reproducible; at the benchmark shape (32, 4, 900, 64) ALONE it is level with
+ * ttsmi_attention_bwd_masked (166-170 us against 166-181 us by box, after the rotated visiting order; the first version
+ * was 222 against 183), but INSIDE the train step it is 0.1-0.2 ms per step slower (5.22 against 5.00 ms,
+ * profiles/r04_step_ab.txt: its workgroups wait for each other beside the weight-gradient stream), so the dense-block
+ * launcher only uses it with TTSMI_ATTN_FUSED_BWD=1.  A caller that opts in MUST read the two diagnostic counters after
+ * the backward (the host mirror does, once per step: ops.fused_bwd_check) - a timed-out hand-off leaves a wrong dQ. */
 size_t ttsmi_attention_bwd_fused_ws_bytes(int B, int H, int T);
 int ttsmi_attention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes);
 int ttsmi_attention_bwd_fused_ws_init(void* ws, size_t ws_bytes, ttsmi_stream_t stream);

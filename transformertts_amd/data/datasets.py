@@ -138,10 +138,17 @@ class Dataset:
                          if isinstance(c, np.ndarray) and c.dtype.kind in 'fiu' else c for c in batch)
         numeric = [(i, np.ascontiguousarray(c)) for i, c in enumerate(batch) if isinstance(c, np.ndarray) and c.dtype.kind in 'fiu']
         need = sum((a.nbytes + 255) // 256 * 256 for _, a in numeric)
-        ring = self.__dict__.setdefault('_stage_ring', [])
+        # one ring PER CALLING THREAD (the producer thread of next_batch and the caller's thread of all_batches may both
+        # be here on one Dataset: a shared slot counter let them pick the same slot and overwrite pinned memory an
+        # in-flight copy was still reading)
+        rings = self.__dict__.setdefault('_stage_rings', {})
+        st = rings.get(threading.get_ident())
+        if st is None:
+            st = rings.setdefault(threading.get_ident(), {'ring': [], 'next': 0})
+        ring = st['ring']
         nslots = self.prefetch + 2                          # in the queue + being consumed + being filled
-        k = self.__dict__.get('_stage_next', 0)
-        self._stage_next = (k + 1) % nslots
+        k = st['next']
+        st['next'] = (k + 1) % nslots
         while len(ring) < nslots:
             ring.append({'buf': None, 'ev': None})
         slot = ring[k]
@@ -151,15 +158,19 @@ class Dataset:
             slot['buf'] = torch.empty(int(need * 5 // 4) + 4096, dtype=torch.uint8).pin_memory()
         out = list(batch)
         off = 0
-        for i, a in numeric:
-            stage = slot['buf'][off:off + a.nbytes].view(torch.from_numpy(a).dtype).reshape(a.shape)
-            stage.numpy()[...] = a                          # one memcpy into pinned memory (numpy releases the GIL for it)
-            dev = torch.empty(a.shape, dtype=stage.dtype, device=self.device)
-            dev.copy_(stage, non_blocking=True)
-            out[i] = dev
-            off += (a.nbytes + 255) // 256 * 256
-        ev = torch.cuda.Event()
-        ev.record()
+        dev_t = torch.device(self.device)
+        # (under the Dataset's own device: the copies run on - and the event is recorded on - THAT device's current
+        # stream, whatever device the calling thread has current)
+        with torch.cuda.device(dev_t if dev_t.index is not None else torch.cuda.current_device()):
+            for i, a in numeric:
+                stage = slot['buf'][off:off + a.nbytes].view(torch.from_numpy(a).dtype).reshape(a.shape)
+                stage.numpy()[...] = a                      # one memcpy into pinned memory (numpy releases the GIL for it)
+                dev = torch.empty(a.shape, dtype=stage.dtype, device=self.device)
+                dev.copy_(stage, non_blocking=True)
+                out[i] = dev
+                off += (a.nbytes + 255) // 256 * 256
+            ev = torch.cuda.Event()
+            ev.record()
         slot['ev'] = ev
         return tuple(out)
 

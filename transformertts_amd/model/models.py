@@ -241,6 +241,12 @@ class ForwardTransformer:
         # reference_outputs=True: train_step returns the 12 attention maps like the reference's _train_step
         # (models.py:544-549) instead of leaving the dicts empty - see the module docstring
         self.reference_outputs = bool(kwargs.get('reference_outputs', False))
+        # the maps of a TRAIN step are written into a ring of MAP_RING_DEPTH persistent buffer sets per (block, shape)
+        # instead of 2.7 GB of fresh tensors per step (config 2): a step's maps stay valid until MAP_RING_DEPTH - 1 more
+        # steps have run (the trainer reads them right after the step, train_tts.py:175-176).  call / val_step / predict
+        # keep returning fresh tensors.  map_ring=False restores fresh tensors everywhere.
+        self.map_ring = bool(kwargs.get('map_ring', True)) and os.environ.get('TTSMI_MAP_RING', '1') != '0'
+        self._map_ring_on, self._map_bufs = False, {}
         self.debug = debug
         self._phase_events = None            # measurement instrumentation (_mark)
         self._taps = None                    # test instrumentation: a list receives (f'{prefix}.blk{i}', block output)
@@ -423,7 +429,7 @@ class ForwardTransformer:
                 if want_attn:
                     attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
                         plan.t['qkv'], pad, plan.t['lse'], B, H, T, d // H, rate, drop, sites[0], ops._lib.TTSMI_BF16_IO,
-                        dmask)
+                        dmask, out=self._map_buffer(p, B, H, T))
                 if self._taps is not None:
                     self._taps.append((p, h.detach().reshape(B, T, d)))
                 continue
@@ -448,7 +454,8 @@ class ForwardTransformer:
                 if want_attn:
                     attn[f'{name}_DenseBlock{i + 1}_SelfAttention'] = ops.attention_weights(
                         qkv, pad, lse, B, H, T, d // H, rate, drop, sites[0],
-                        ops._lib.TTSMI_BF16_IO if qkv.dtype == torch.bfloat16 else ops.TTSMI_F32)
+                        ops._lib.TTSMI_BF16_IO if qkv.dtype == torch.bfloat16 else ops.TTSMI_F32,
+                        out=self._map_buffer(p, B, H, T))
                 if self._taps is not None:
                     self._taps.append((p, h.detach().reshape(B, T, d)))
                 continue
@@ -461,8 +468,8 @@ class ForwardTransformer:
                 h_bf = ops.to_bf16(h)
             # the block input's three gradients (qkv projection, q_in half of the output projection, residual) and the conv
             # stack input's two are summed in place (ops.GradSink) instead of by autograd's add launches
-            sink_h = ops.GradSink() if (_GRAD_SINK and h.requires_grad) else None
-            sink_a = ops.GradSink() if (_GRAD_SINK and h.requires_grad) else None
+            sink_h = ops.GradSink(f'{p}.in').watch(h) if (_GRAD_SINK and h.requires_grad) else None
+            sink_a = ops.GradSink(f'{p}.a') if (_GRAD_SINK and h.requires_grad) else None
             qkv = ops.LinearFn.apply(h, None, W[f'{p}.wqkv'], W[f'{p}.bqkv'], G[f'{p}.wqkv'], G[f'{p}.bqkv'],
                                      S(f'{p}.wqkv'), io_h, h_bf if io_h else None, sink_h)
             site = drop.site()
@@ -479,7 +486,8 @@ class ForwardTransformer:
                 key = (f'{name}_DenseBlock{i + 1}_SelfAttention' if dense
                        else f'{name}_ConvBlock{i - dense_blocks + 1}_SelfAttention')
                 attn[key] = ops.attention_weights(qkv.detach(), pad, lse, B, H, T, d // H, rate, drop, site,
-                                                  ops._lib.TTSMI_BF16_IO if io_h else ops.TTSMI_F32, dmask if io_h else None)
+                                                  ops._lib.TTSMI_BF16_IO if io_h else ops.TTSMI_F32, dmask if io_h else None,
+                                                  out=self._map_buffer(p, B, H, T))
             o = ops.LinearFn.apply(h, ctx, W[f'{p}.wo'], W[f'{p}.bo'], G[f'{p}.wo'], G[f'{p}.bo'], S(f'{p}.wo'),
                                    False, h_bf if io_h else None, sink_h)
             h_bf = None
@@ -499,6 +507,8 @@ class ForwardTransformer:
                     ps += [W[f'{p}.conv{j}.w'], W[f'{p}.conv{j}.b']]
                     gs += [G[f'{p}.conv{j}.w'], G[f'{p}.conv{j}.b']]
                 shs = tuple(S(f'{p}.conv{j}.w') for j in range(n))
+                if sink_a is not None:
+                    sink_a.watch(a)
                 f = ops.ConvStackFn.apply(a.reshape(B, T, d), n, shs, *ps, *gs, sink_a).reshape(M, d)
             h = ops.add_layernorm(f, a, W[f'{p}.ln2.gamma'], W[f'{p}.ln2.beta'], G[f'{p}.ln2.gamma'],
                                   G[f'{p}.ln2.beta'], row_pad=pad, p_in=rate, site_in=drop.site(), drop=drop, want_h=io_h,
@@ -768,6 +778,27 @@ class ForwardTransformer:
                 if ev is not None:
                     ev.record(side)
 
+    MAP_RING_DEPTH = 2
+    MAP_RING_SHAPES = 8        # (block, B, H, T) entries kept per block: ragged batches bring a new shape almost every step
+
+    def _map_buffer(self, block, B, H, T):
+        """The [B,H,T,T] fp32 buffer one attention map of this TRAIN step is written into (None: a fresh tensor)."""
+        if not self._map_ring_on:
+            return None
+        slots = self._map_bufs.setdefault(block, OrderedDict())
+        key = (B, H, T)
+        ring = slots.get(key)
+        if ring is None:
+            if len(slots) >= self.MAP_RING_SHAPES:
+                slots.popitem(last=False)                 # least recently used shape: freed in stream order
+            ring = slots[key] = [None] * self.MAP_RING_DEPTH
+        else:
+            slots.move_to_end(key)
+        i = self._host_step % self.MAP_RING_DEPTH
+        if ring[i] is None:
+            ring[i] = torch.empty((B, H, T, T), dtype=torch.float32, device=self.device)
+        return ring[i]
+
     def _mark(self, name):
         """Measurement hook (tools/probe_phases.py): a timing event on the main stream at a phase boundary."""
         if self._phase_events is not None:
@@ -819,12 +850,14 @@ class ForwardTransformer:
         with ops.pinned_stream():
             self._launch_dropmasks(int(x.shape[0]), int(x.shape[1]), mel_len, float(self.config['dropout_rate']))
             self._use_plans = self.planned_blocks
+            self._map_ring_on = bool(ra) and self.map_ring and not torch.cuda.is_current_stream_capturing()
             try:
                 model_out = self.call(x, td, target_pitch=tp, training=True, mel_len=mel_len, return_attention=ra,
                                       _overlap_predictors=True)
             finally:
                 self._dropmask_plan = {}
                 self._use_plans = False
+                self._map_ring_on = False
             self._join_predictors()              # the duration / pitch losses read the side stream's outputs
             loss, loss_vals = self._losses(model_out, ts, td, tp, unit_seed=True)    # seeded by loss.backward() below
             ops.enable_wgrad_stream(self.overlap_wgrad)
@@ -837,6 +870,8 @@ class ForwardTransformer:
                     self._join_predictors()      # the main stream waits for the predictor stream ...
                     self._pred_pending = False
                 ops.wgrad_join()                 # ... and for the weight-gradient stream, before all-reduce and Adam
+                if ops._FUSED_WS and not torch.cuda.is_current_stream_capturing():
+                    ops.fused_bwd_check()        # (opt-in one-pass attention backward: its time-out counters)
             finally:
                 ops.enable_wgrad_stream(False)
                 self._pred_pending = False

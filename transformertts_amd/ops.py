@@ -312,9 +312,12 @@ def lenreg_index(dur, cap):
 
 
 def attention_weights(qkv, key_pad, lse, B, H, T, dh, p_drop=0.0, drop: Optional[DropCtx] = None,
-                      site=0, dtype=TTSMI_F32, dmask=None):
-    """dmask: the layer's keep-bit table (bf16 tensors only) - the same decisions as the hash, one bit test per weight."""
-    w = torch.empty((B, H, T, T), dtype=torch.float32, device=qkv.device)
+                      site=0, dtype=TTSMI_F32, dmask=None, out=None):
+    """dmask: the layer's keep-bit table (bf16 tensors only) - the same decisions as the hash, one bit test per weight.
+    out: a caller-owned [B,H,T,T] fp32 buffer (the train step's ring of map buffers, models.py:_map_buffer)."""
+    if out is not None:
+        assert out.shape == (B, H, T, T) and out.dtype == torch.float32 and out.is_contiguous()
+    w = out if out is not None else torch.empty((B, H, T, T), dtype=torch.float32, device=qkv.device)
     if dmask is not None and p_drop > 0 and dtype == _lib.TTSMI_BF16_IO:
         check(_lib.lib().ttsmi_attention_weights_masked(_p(qkv), _p(key_pad), _p(lse), _p(w), B, H, T, dh, float(p_drop),
                                                         _p(dmask), dtype, _stream()), 'attention_weights_masked')
@@ -701,6 +704,9 @@ def _sink(g, like):
 # =================================================================================================
 # autograd Functions (one per fused layer)
 # =================================================================================================
+_GRAD_SINK_CHECK = os.environ.get('TTSMI_GRAD_SINK_CHECK', '1') != '0'
+
+
 class GradSink:
     """The gradient of a tensor with several consumers on the per-layer path (a block's input feeds the qkv projection, the
     q_in half of the output projection and the residual of res-norm 1; the conv stack's input is also res-norm 2's residual),
@@ -708,11 +714,30 @@ class GradSink:
     what the others produce): it returns its `dres` to autograd as usual and leaves the tensor here; the other consumers
     ADD their contribution into it in place (the dgrad GEMM's accumulate epilogue) and return None.  Autograd keeps the
     first gradient that arrives by reference and calls the producer's backward only after every consumer's has run, in
-    stream order - by then the buffer holds the sum.  One object per (tensor, step); never shared across steps."""
-    __slots__ = ('buf',)
+    stream order - by then the buffer holds the sum.  One object per (tensor, step); never shared across steps.
 
-    def __init__(self):
+    That first-gradient-by-reference behaviour of the autograd engine is not a documented contract (a second
+    gradient-producing consumer, a cross-stream edge or a future torch would make it sum OUT of place, and the in-place
+    adds would land in a dead buffer): `watch(t)` puts a hook on the guarded tensor that sees the gradient autograd
+    hands to its producer and raises unless it IS the buffer the consumers added into (TTSMI_GRAD_SINK_CHECK=0 removes
+    the hook)."""
+    __slots__ = ('buf', 'name')
+
+    def __init__(self, name=''):
         self.buf = None
+        self.name = name
+
+    def watch(self, t):
+        if _GRAD_SINK_CHECK and t is not None and t.requires_grad:
+            t.register_hook(self._check)
+        return self
+
+    def _check(self, g):
+        if self.buf is not None and (g.data_ptr() != self.buf.data_ptr() or g.numel() != self.buf.numel()):
+            raise RuntimeError(f'GradSink {self.name}: autograd summed the gradient out of place (its buffer {g.data_ptr():#x} is '
+                               f'not the one the consumers accumulated into, {self.buf.data_ptr():#x}): contributions would '
+                               f'be dropped - run with TTSMI_GRAD_SINK=0')
+        return None
 
 
 class LinearFn(torch.autograd.Function):
@@ -1846,6 +1871,7 @@ class DenseBlockPlan:
                 sh.setdefault('attn_fused_ws_retired', []).append(ws)
             ws = sh['attn_fused_ws'] = _ws(need + need // 8, device)
             check(l.ttsmi_attention_bwd_fused_ws_init(_p(ws), ws.numel(), _stream()), 'attention_bwd_fused_ws_init')
+            _FUSED_WS.append({'ws': ws, 'host': None, 'ev': None})
         return ws
 
     def rebind(self, B, T):
@@ -1919,19 +1945,23 @@ class DenseBlockPlan:
     def fwd(self, h, h_bf):
         check(_lib.lib().ttsmi_dense_block_fwd(self._dref, _p(h), _p(h_bf)), 'dense_block_fwd')
 
-    def _prepare_bwd(self, device):
-        """The weight-gradient stream / workspace fields of the descriptor for the coming backward."""
+    def _prepare_bwd(self, device, need=None):
+        """The weight-gradient stream / workspace fields of the descriptor for the coming backward.  need: the largest
+        `wgrad_need` of the plans that one C call will launch (a stack): the shared workspace is grown ONCE, before any
+        descriptor of the stack takes its pointer - growing it between two plans would leave the earlier descriptor
+        pointing at a tensor just handed back to the allocator."""
         assert self.backward, 'forward-only plan'
         D = self.desc
+        need = self.wgrad_need if need is None else max(int(need), self.wgrad_need)
         if _WgradStream.enabled:
             W = _WgradStream.cur()
             if W.stream is None:
                 W.stream = torch.cuda.Stream(priority=_WGRAD_PRIO)
             if W.handle is None:
                 W.handle = W.stream.cuda_stream
-            if W.ws is None or W.ws.numel() < self.wgrad_need:
+            if W.ws is None or W.ws.numel() < need:
                 with torch.cuda.stream(W.stream):
-                    W.ws = torch.empty(int(max(self.wgrad_need, 1 << 26)), dtype=torch.uint8, device=device)
+                    W.ws = torch.empty(int(max(need, 1 << 26)), dtype=torch.uint8, device=device)
             D.side_stream, D.wgrad_ws, D.wgrad_ws_bytes = W.handle, W.ws.data_ptr(), W.ws.numel()
             W.pending = True
         else:
@@ -1962,6 +1992,29 @@ class DenseBlockPlan:
         else:
             with ln_param_batch():
                 defer()
+
+
+_FUSED_WS: list = []      # workspaces of the opt-in one-pass attention backward: their diagnostic counters are read every step
+
+
+def fused_bwd_check() -> None:
+    """TTSMI_ATTN_FUSED_BWD=1 only (a no-op otherwise): the one-pass attention backward finishes with a WRONG dQ instead of
+    hanging when a hand-off between its workgroups times out, or when its workgroups are not placed on the XCD their block
+    id names (include/ttsmi.h: the first two int32 of its workspace count both).  Once per step, after the backward: raise
+    if the counters copied at the END OF THE PREVIOUS STEP are non-zero (that copy completed long ago: no sync), then queue
+    this step's copy."""
+    for e in _FUSED_WS:
+        if e['ev'] is not None:
+            e['ev'].synchronize()
+            bad = e['host'].tolist()
+            if bad[0] or bad[1]:
+                raise RuntimeError(f'ttsmi_attention_bwd_fused: {bad[0]} timed-out hand-offs, {bad[1]} workgroups off their XCD '
+                                   f'- dQ of an earlier step is wrong; run without TTSMI_ATTN_FUSED_BWD=1')
+        if e['host'] is None:
+            e['host'] = torch.zeros(2, dtype=torch.int32).pin_memory()
+        e['host'].copy_(e['ws'][:8].view(torch.int32), non_blocking=True)
+        e['ev'] = torch.cuda.Event()
+        e['ev'].record()
 
 
 class PlannedDenseBlockFn(torch.autograd.Function):
@@ -2007,8 +2060,9 @@ class PlannedDenseStackFn(torch.autograd.Function):
     def backward(ctx, dout, _dout_bf):
         plans = ctx.plans
         dev = ctx.h_bf.device
+        need = max(pl.wgrad_need for pl in plans)
         for pl in plans:
-            pl._prepare_bwd(dev)
+            pl._prepare_bwd(dev, need)
         check(_lib.lib().ttsmi_dense_stack_bwd(ctx.arr, len(plans), _p(ctx.h), _p(ctx.h_bf), _p(_c(dout))), 'dense_stack_bwd')
         for pl in reversed(plans):
             pl._defer_ln()
