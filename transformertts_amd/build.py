@@ -87,5 +87,29 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+GUARD_SRC = os.path.join(HERE, '..', 'tests', 'guard_alloc.cpp')
+GUARD_LIB = os.path.join(HERE, '..', 'tests', '_guard', 'libttsmi_guard_alloc.so')
+
+
+def build_guard_allocator(force: bool = False, verbose: bool = True) -> str:
+    """tests/guard_alloc.cpp -> tests/_guard/libttsmi_guard_alloc.so: the memory-safety gate of the GPU suite (a torch
+    pluggable allocator; TEST infrastructure, host code only - the product path never loads it)."""
+    os.makedirs(os.path.dirname(GUARD_LIB), exist_ok=True)
+    stamp = GUARD_LIB + '.sha'
+    dig = _digest([GUARD_SRC])
+    if not force and os.path.exists(GUARD_LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return GUARD_LIB
+    cmd = [_hipcc(), '-O2', '-std=c++17', '-fPIC', '-shared', '-x', 'hip', '--offload-arch=gfx950', GUARD_SRC, '-o', GUARD_LIB]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed for {GUARD_SRC}:\n{r.stdout}\n{r.stderr}')
+    with open(stamp, 'w') as f:
+        f.write(dig)
+    if verbose:
+        print(f'[ttsmi build] built {GUARD_LIB}', file=sys.stderr)
+    return GUARD_LIB
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv))
+    print(build_guard_allocator(force='--force' in sys.argv))
