@@ -17,7 +17,15 @@
 // Frees synchronise the device first (torch frees a tensor as soon as its last reference dies, in host order; the caching
 // allocator would keep the block alive in stream order - here in-flight kernels must finish before the pages go away).
 // Slow (a reserve + create + map per tensor, a device sync per free) - which is fine for a gate that runs a few times per
-// round:  TTSMI_GUARD_ALLOC=1 python -m pytest tests -m gpu     (tools/sessions/r05_guard.sh)
+// round:  TTSMI_GUARD_ALLOC=1 python -m pytest tests -m gpu -n 1     (tools/sessions/r05_c.sh; xdist so that a faulting
+// test costs one worker, not the run).
+//
+// Address ranges are NEVER handed back (TTSMI_GUARD_KEEP_VA=1, the default).  Measured on ROCm 7.2 / MI355X
+// (tools/sessions/r05_b.sh, profiles/r05_guard_variants.txt): with hipMemAddressFree after every tensor, a later
+// hipMemAddressReserve returns the same range and the GPU keeps using the OLD translation for it - 921 of 3 603 tensors of
+// tools/guard_stress.py (plain torch fills, no library kernel) read back wrong and a third of all canaries were "violated";
+// a device sync around the canary fill changes nothing; without address reuse: 0 / 0.  The ranges cost address space only
+// (the pages are unmapped and released), and a test process ends long before 2^47 bytes are reserved.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -44,6 +52,15 @@ size_t g_gran = 0;
 std::atomic<long> g_allocs{0}, g_frees{0}, g_violations{0}, g_live_bytes{0}, g_peak_bytes{0};
 constexpr unsigned char kCanary = 0xA5;
 constexpr size_t kHeadMax = 4096;
+
+// Probe knobs (tools/sessions/r05_b.sh established which of them the ROCm 7.2 virtual-memory path needs: see the header)
+int env_flag(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+const int g_keep_va = env_flag("TTSMI_GUARD_KEEP_VA", 1);          // 1: address ranges are never handed back (no VA reuse)
+const int g_sync_alloc = env_flag("TTSMI_GUARD_SYNC_ALLOC", 0);    // 1: device sync before and after the canary fill
+const int g_no_release = env_flag("TTSMI_GUARD_NO_RELEASE", 0);    // 1: frees check the canaries but keep the pages mapped
 
 size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -110,12 +127,14 @@ void* ttsmi_guard_alloc(size_t size, int device, hipStream_t /*stream*/) {
     acc.flags = hipMemAccessFlagsProtReadWrite;
     CK(hipMemSetAccess(r.va, r.mapped, &acc, 1));
     r.ptr = r.va + r.mapped - payload;
+    if (g_sync_alloc) CK(hipDeviceSynchronize());
     r.head_checked = static_cast<size_t>(r.ptr - r.va) < kHeadMax ? static_cast<size_t>(r.ptr - r.va) : kHeadMax;
     CK(hipMemset(r.ptr - r.head_checked, kCanary, r.head_checked));
     if (payload > size) CK(hipMemset(r.ptr + size, kCanary, payload - size));
     if (const char* p = std::getenv("TTSMI_GUARD_POISON")) {   // optional: fresh memory reads as NaN (fp32 and bf16)
         if (p[0] == '1') CK(hipMemset(r.ptr, 0xFF, size));
     }
+    if (g_sync_alloc) CK(hipDeviceSynchronize());
     g_live[r.ptr] = r;
     g_allocs++;
     long live = (g_live_bytes += static_cast<long>(r.mapped));
@@ -160,9 +179,11 @@ void ttsmi_guard_free(void* ptr, size_t /*size*/, int device, hipStream_t /*stre
         log_line(buf);
         g_violations++;
     }
-    CK(hipMemUnmap(r.va, r.mapped));
-    CK(hipMemRelease(r.handle));
-    CK(hipMemAddressFree(r.va, r.va_size));
+    if (!g_no_release) {
+        CK(hipMemUnmap(r.va, r.mapped));
+        CK(hipMemRelease(r.handle));
+        if (!g_keep_va) CK(hipMemAddressFree(r.va, r.va_size));
+    }
     g_frees++;
     g_live_bytes -= static_cast<long>(r.mapped);
     if (prev != device) CK(hipSetDevice(prev));

@@ -39,7 +39,9 @@ del a
 gc.collect()
 clean = lib.ttsmi_guard_violations()
 x = torch.zeros(1001, dtype=torch.uint8, device='cuda')            # 7 bytes of slack behind it, still mapped
-torch.as_strided(x, (1004,), (1,)).fill_(3)                        # three bytes past the end
+import ctypes as C
+hip = C.CDLL('libamdhip64.so')
+assert hip.hipMemset(C.c_void_p(x.data_ptr() + 1001), 3, C.c_size_t(3)) == 0    # three bytes past the end
 torch.cuda.synchronize()
 del x
 gc.collect()
