@@ -17,7 +17,7 @@ if ROOT not in sys.path:
 # ---------------------------------------------------------------------------------------------------------------------
 GUARD = os.environ.get('TTSMI_GUARD_ALLOC', '0') == '1'
 _GUARD_LIB = None
-GUARD_SKIP = ('graph', 'hipgraph', 'two_ranks', 'two_rank', 'dp_overlap')      # captures, or child processes / collectives
+GUARD_SKIP = ('graph', 'hipgraph', 'two_ranks', 'two_rank', 'dp_overlap', 'positional_table')      # captures, or child processes / collectives
 
 
 def _install_guard():

@@ -577,7 +577,7 @@ def test_keep_bit_attention_at_the_benchmark_shape():
     assert mean_c < 4e-3 and mean_g < 6e-3, (mean_c, mean_g)
     # ---- the ONE-PASS backward (hattn_bwd_fused_kernel<64, 2>) on the same inputs: against the same fp64 reference, and
     # bit-reproducible (dQ is summed over the key tiles of a head in a fixed order through the hand-off chain)
-    fws = torch.empty(int(l.ttsmi_attention_bwd_fused_ws_bytes(B, H, T)), dtype=torch.uint8, device=DEV)
+    fws = ops._ws(int(l.ttsmi_attention_bwd_fused_ws_bytes(B, H, T)), DEV)             # (whole 256-byte units: the entry point wants 256-byte alignment)
     check(l.ttsmi_attention_bwd_fused_ws_init(_p(fws), fws.numel(), _stream()))
     assert l.ttsmi_attention_bwd_fused_supported(B, H, T, dh, fws.numel())
     runs = []
@@ -642,7 +642,7 @@ def test_one_pass_attention_backward_equals_the_two_kernel_backward(pdrop, bits)
                                         _lib.TTSMI_BF16_IO, _stream()))
             check(l.ttsmi_attention_bwd(_p(qd), _p(padd), _p(klend), _p(ctx), _p(dd), _p(lse), _p(dq1), B, H, T, dh, pdrop,
                                         seed, _p(step), site, _p(ws), ws.numel(), _lib.TTSMI_BF16_IO, _stream()))
-        fws = torch.empty(int(l.ttsmi_attention_bwd_fused_ws_bytes(B, H, T)), dtype=torch.uint8, device=DEV)
+        fws = ops._ws(int(l.ttsmi_attention_bwd_fused_ws_bytes(B, H, T)), DEV)             # (whole 256-byte units: the entry point wants 256-byte alignment)
         check(l.ttsmi_attention_bwd_fused_ws_init(_p(fws), fws.numel(), _stream()))
         assert l.ttsmi_attention_bwd_fused_supported(B, H, T, dh, fws.numel())
         for _ in range(2):                                         # twice: the hand-off flags reset themselves

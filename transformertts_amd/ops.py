@@ -185,7 +185,9 @@ class pin_stream:
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
-    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    """A byte workspace.  Sized in whole 256-byte units: several entry points require 256-byte aligned workspaces, which an
+    allocator that places tensors flush against the END of a mapping (tests/guard_alloc.cpp) only gives to such sizes."""
+    return torch.empty((int(nbytes) + 255) // 256 * 256, dtype=torch.uint8, device=device)
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
