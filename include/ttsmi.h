@@ -36,10 +36,11 @@ extern "C" {
 #endif
 
 /* Bumped whenever an entry point's argument list or the ttsmi_dense_block layout changes (101: round 3's `denom` argument of
- * ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102: round 4; 103: ttsmi_mel_nnls added; 104: the shifted-rows taps of
+ * ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102: round 4; 103: ttsmi_mel_nnls added; 104: the shifted-rows taps of the conv weight gradient; 105: round 5 - ttsmi_dense_chain_* and the chain tail of ttsmi_dense_block;
+ * (104 continued:) the shifted-rows taps of
  * ttsmi_hgemm_wgrad_rows, which the conv stacks of the host mirror now call).  Bindings check it at load
  * time (transformertts_amd/_lib.py) so that a stale build is refused instead of being called with shifted arguments. */
-#define TTSMI_VERSION 104
+#define TTSMI_VERSION 105
 
 enum {
     TTSMI_OK = 0,
@@ -586,6 +587,17 @@ typedef struct ttsmi_dense_block {
      * two-kernel form). */
     void* attn_fused_ws;
     uint64_t attn_fused_ws_bytes;
+    /* round 5 - the row-local chain (csrc/chain.hip, ttsmi_dense_chain_fwd): with chain_w set (fuse_ln and res16 required,
+     * d == 256, F % 64 == 0) the forward's o-projection + res-norm 1, FFN1, FFN2 + res-norm 2 - and, with `above` set, the
+     * qkv projection of the NEXT block of the stack - run as ONE launch on the weight stream chain_w
+     * (ttsmi_dense_chain_pack of this block's wo_t / w1_t / w2_t and above->wqkv_t, repacked whenever the weights change).
+     * qkv_done != 0: this block's qkv was written by the chain of the block below (whose `above` is this descriptor) - its
+     * own qkv projection is skipped.  The caller sets above / qkv_done in pairs and runs the lower block's forward first. */
+    const void* chain_w;
+    uint64_t chain_w_bytes;
+    const struct ttsmi_dense_block* above;
+    int32_t qkv_done;
+    int32_t chain_pad_;
 } ttsmi_dense_block;
 /* ---------------------------------------------------------------------------------------------
  * Batch data parallelism for a binding WITHOUT a collective library of its own (one all-reduce of the
@@ -609,6 +621,30 @@ int ttsmi_allreduce_sum_f32(void* comm, float* buf, int64_t n, ttsmi_stream_t st
  * can bracket the launches with HIP events.  NULL (the default) disables it.  Process-wide, for measurement only. */
 typedef void (*ttsmi_launch_observer)(int phase, const char* name, double flops, double bytes, ttsmi_stream_t stream);
 int ttsmi_set_launch_observer(ttsmi_launch_observer cb);
+/* ---------------------------------------------------------------------------------------------
+ * The row-local chain of a dense block (model/layers.py:148-150,211,229 -> :99-102,230 -> the next block's :116-118) as
+ * one launch for d_model = 256 (csrc/chain.hip): per 128-row workgroup
+ *     a = LN1(keep([h | ctx].Wo + bo) + h) * rowmask;  h1 = relu(a.W1 + b1);  out = LN2(keep(h1.W2 + b2) + a) * rowmask;
+ *     qkv_next = out.Wqkv' + bqkv'                                   (qkv_next / bqkv_next NULL: no next block)
+ * with the activations in registers between the products; only what the backward keeps is written (a_bf, xhat1, rstd1, h1,
+ * xhat2, rstd2, out_bf, qkv_next; out32 = the fp32 block output, or NULL; relu_bits = (h1 > 0) in the layout
+ * ttsmi_hgemm_k256_masked_bits reads for (M, F), or NULL).  Residuals are the bf16 tensors (h_bf, a_bf): the res16
+ * arithmetic of ttsmi_dense_block.  Same results as ttsmi_hgemm_ln_fwd_h + ttsmi_hgemm_k256_relu_bits +
+ * ttsmi_hgemm_ln_fwd_h + ttsmi_hgemm_tn up to fp32 summation order.
+ *   wpack: ttsmi_dense_chain_pack(wo_t [256][512], w1_t [F][256], w2_t [256][F], wqkv_next_t [768][256] or NULL) - the bf16
+ *          W^T matrices as one stream of MFMA fragments in the kernel's order; ttsmi_dense_chain_pack_bytes(F, with_qkv).
+ *   dropout: keep(seed + *step_dev, site, row, column) as in ttsmi_hgemm_ln_fwd (site_ln1 / site_ln2).
+ * ------------------------------------------------------------------------------------------- */
+size_t ttsmi_dense_chain_pack_bytes(int F, int with_qkv);
+int ttsmi_dense_chain_pack(const uint16_t* wo_t, const uint16_t* w1_t, const uint16_t* w2_t, const uint16_t* wqkv_next_t, int F,
+                           void* out, size_t out_bytes, ttsmi_stream_t stream);
+int ttsmi_dense_chain_supported(int M, int d, int F);
+int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void* wpack, size_t wpack_bytes, int M, int F,
+                          const float* bo, const float* ln1_g, const float* ln1_b, const float* b1, const float* b2,
+                          const float* ln2_g, const float* ln2_b, const float* bqkv_next, const uint8_t* row_pad, float p_drop,
+                          uint64_t seed, const int64_t* step_dev, uint32_t site_ln1, uint32_t site_ln2, float eps, uint16_t* a_bf,
+                          uint16_t* xhat1, float* rstd1, uint16_t* h1, void* relu_bits, uint16_t* out_bf, uint16_t* xhat2,
+                          float* rstd2, float* out32, uint16_t* qkv_next, ttsmi_stream_t stream);
 /* h [M,d] fp32 block input, h_bf its bf16 copy.  Writes desc->out / out_bf (+ the kept activations). */
 int ttsmi_dense_block_fwd(const ttsmi_dense_block* desc, const float* h, const uint16_t* h_bf);
 /* dout [M,d] fp32 gradient of the block output.  Writes desc->dh, the parameter gradients, and leaves the two

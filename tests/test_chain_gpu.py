@@ -1,0 +1,175 @@
+"""-m gpu parity of the row-local chain kernel (csrc/chain.hip, ttsmi_dense_chain_fwd) against fp64 evaluations of the
+reference's formulas (model/layers.py:148-150, 211, 229 o-projection + res-norm 1; :99-102, 230 FFN + res-norm 2;
+:116-118 the next block's qkv projection) at the benchmark's row counts, dropout ON (tests/_dropout_ref.py restates the
+keep decisions), ragged and padded rows, with and without the qkv tail / the fp32 output / the ReLU bit matrix.
+
+The chain rounds to bf16 where the four-launch path does (a, h1, out, qkv'), so every stage is checked against an fp64
+evaluation fed with the KERNEL's own bf16 output of the stage before: what remains per stage is the fp32 accumulation
+order and one bf16 rounding of the stored value.  The bit matrix is checked through its real consumer
+(ttsmi_hgemm_k256_masked_bits, both layouts)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _dropout_ref as dr  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+EPS = 1e-6
+D = 256
+
+
+def _env():
+    from transformertts_amd import _lib, ops
+    return ops, _lib, _lib.lib()
+
+
+def rel_err(got, want) -> float:
+    want = want.double().cpu()
+    got = got.double().cpu()
+    return float((got - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+
+
+def g(*shape, seed=0, scale=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=gen) * scale).float()
+
+
+def bf(x):
+    return x.to(torch.bfloat16).double()
+
+
+def _ln_ref(z, gamma, beta):
+    mu = z.mean(-1, keepdim=True)
+    var = ((z - mu) ** 2).mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + EPS)
+    xh = (z - mu) * rstd
+    return xh * gamma + beta, xh, rstd[:, 0]
+
+
+def _run_chain(M, F, pdrop, with_qkv, with_out32, with_bits, seed0=0):
+    ops, _lib, l = _env()
+    from transformertts_amd.ops import _p, _stream, check
+    seed, stepv, s1, s2 = 777123, 5, 9, 10
+    h = g(M, D, seed=seed0 + 1).to(torch.bfloat16)
+    cx = g(M, D, seed=seed0 + 2).to(torch.bfloat16)
+    wo, w1, w2, wq = (g(2 * D, D, seed=seed0 + 3, scale=0.05), g(D, F, seed=seed0 + 4, scale=0.06), g(F, D, seed=seed0 + 5, scale=0.04),
+                      g(D, 3 * D, seed=seed0 + 6, scale=0.06))
+    bo, b1, b2, bq = g(D, seed=seed0 + 7, scale=0.3), g(F, seed=seed0 + 8, scale=0.3), g(D, seed=seed0 + 9, scale=0.3), g(3 * D, seed=seed0 + 10, scale=0.3)
+    g1, be1 = 1 + 0.1 * g(D, seed=seed0 + 11), 0.1 * g(D, seed=seed0 + 12)
+    g2, be2 = 1 + 0.1 * g(D, seed=seed0 + 13), 0.1 * g(D, seed=seed0 + 14)
+    pad = (torch.arange(M) % 11 == 4).to(torch.uint8)
+    dev = {k: v.to(DEV) for k, v in dict(h=h, cx=cx, bo=bo, b1=b1, b2=b2, bq=bq, g1=g1, be1=be1, g2=g2, be2=be2, pad=pad).items()}
+    sh = {k: ops.make_shadow(v.to(DEV)) for k, v in dict(wo=wo, w1=w1, w2=w2, wq=wq).items()}
+    nbytes = int(l.ttsmi_dense_chain_pack_bytes(F, int(with_qkv)))
+    assert nbytes == (8 + 2 * (F // 64) + (12 if with_qkv else 0)) * 32768
+    wpack = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    check(l.ttsmi_dense_chain_pack(_p(sh['wo'].wt), _p(sh['w1'].wt), _p(sh['w2'].wt), _p(sh['wq'].wt) if with_qkv else None, F,
+                                   _p(wpack), nbytes, _stream()), 'pack')
+    step = torch.full((1,), stepv, dtype=torch.int64, device=DEV)
+    e = lambda *s, dt=torch.bfloat16: torch.full(s, float('nan'), dtype=dt, device=DEV)
+    out = dict(a=e(M, D), xh1=e(M, D), rstd1=e(M, dt=torch.float32), h1=e(M, F), o=e(M, D), xh2=e(M, D), rstd2=e(M, dt=torch.float32),
+               o32=e(M, D, dt=torch.float32) if with_out32 else None, qkv=e(M, 3 * D) if with_qkv else None,
+               bits=torch.zeros(int(l.ttsmi_relu_bits_bytes(M, F)), dtype=torch.uint8, device=DEV) if with_bits else None)
+    check(l.ttsmi_dense_chain_fwd(_p(dev['h']), _p(dev['cx']), _p(wpack), nbytes, M, F, _p(dev['bo']), _p(dev['g1']), _p(dev['be1']),
+                                  _p(dev['b1']), _p(dev['b2']), _p(dev['g2']), _p(dev['be2']), _p(dev['bq']) if with_qkv else None,
+                                  _p(dev['pad']), pdrop, seed, _p(step), s1, s2, EPS, _p(out['a']), _p(out['xh1']), _p(out['rstd1']),
+                                  _p(out['h1']), _p(out['bits']), _p(out['o']), _p(out['xh2']), _p(out['rstd2']), _p(out['o32']),
+                                  _p(out['qkv']), _stream()), 'chain')
+    torch.cuda.synchronize()
+    assert l.ttsmi_last_kernel().decode() == 'dense_chain_kernel'
+    inv = 1.0 / (1.0 - float(np.float32(pdrop))) if pdrop > 0 else 1.0
+    live = (pad == 0)
+    rows, cols = np.arange(M), np.arange(D)
+    keep1 = torch.from_numpy(dr.keep_mask(seed, stepv, s1, rows, cols, pdrop)).double() * inv if pdrop > 0 else 1.0
+    keep2 = torch.from_numpy(dr.keep_mask(seed, stepv, s2, rows, cols, pdrop)).double() * inv if pdrop > 0 else 1.0
+    c = {k: (v.cpu() if v is not None else None) for k, v in out.items()}
+    # ---- stage 1: a = LN1(keep([h | ctx].Wo + bo) + h) * rowmask
+    z1 = (torch.cat([h.double(), cx.double()], 1) @ bf(wo) + bo.double()) * keep1 + h.double()
+    a_ref, xh1_ref, r1_ref = _ln_ref(z1, g1.double(), be1.double())
+    a_ref = a_ref * live[:, None]
+    assert rel_err(c['rstd1'], r1_ref) < 2e-5
+    assert rel_err(c['a'].float(), a_ref) < 4e-3
+    assert rel_err(c['xh1'].float()[live], xh1_ref[live]) < 4e-3
+    assert float(c['a'].float()[~live].abs().max()) == 0.0 if (~live).any() else True
+    # ---- stage 2 on the kernel's a: h1 = relu(a.W1 + b1)
+    h1_ref = torch.relu(c['a'].double() @ bf(w1) + b1.double())
+    assert rel_err(c['h1'].float(), h1_ref) < 4e-3
+    # ---- stage 3 on the kernel's h1 and a: out = LN2(keep(h1.W2 + b2) + a) * rowmask
+    z2 = (c['h1'].double() @ bf(w2) + b2.double()) * keep2 + c['a'].double()
+    o_ref, xh2_ref, r2_ref = _ln_ref(z2, g2.double(), be2.double())
+    o_ref = o_ref * live[:, None]
+    assert rel_err(c['rstd2'], r2_ref) < 2e-5
+    assert rel_err(c['o'].float(), o_ref) < 4e-3
+    assert rel_err(c['xh2'].float()[live], xh2_ref[live]) < 4e-3
+    if with_out32:
+        assert rel_err(c['o32'], o_ref) < 2e-5                       # fp32: accumulation order only
+        assert torch.equal(c['o32'].to(torch.bfloat16), c['o'])      # the bf16 copy is the fp32 value rounded once
+    # ---- stage 4 on the kernel's out: qkv' = out.Wqkv' + bqkv'
+    if with_qkv:
+        q_ref = c['o'].double() @ bf(wq) + bq.double()
+        assert rel_err(c['qkv'].float(), q_ref) < 4e-3
+    return ops, _lib, l, out, sh, c
+
+
+@pytest.mark.parametrize('M,pdrop,with_qkv,with_out32', [(28800, 0.1, True, False), (28800, 0.1, False, True), (6400, 0.1, True, False),
+                                                        (16384 + 77, 0.0, True, True), (300, 0.1, True, True), (97, 0.0, False, False)])
+def test_row_local_chain_matches_the_fp64_reference_stage_by_stage(M, pdrop, with_qkv, with_out32):
+    _run_chain(M, 1024, pdrop, with_qkv, with_out32, with_bits=False, seed0=M % 97)
+
+
+def test_row_local_chain_with_another_ffn_width():
+    _run_chain(4096 + 33, 512, 0.1, True, False, with_bits=False, seed0=3)
+    _run_chain(1000, 192, 0.0, False, True, with_bits=False, seed0=4)      # an odd number of 64-feature chunks
+
+
+@pytest.mark.parametrize('M', [28800, 16384 + 77, 6400, 4096 + 50])
+def test_row_local_chain_relu_bit_matrix_through_its_consumer(M):
+    """(h1 > 0) as the bit matrix ttsmi_hgemm_k256_masked_bits reads: its 256-column layout from 16 384 rows, the 128-column
+    one below - dh1 = (df . W2^T) masked by the chain's bits must equal the same product masked by the chain's own h1."""
+    F = 1024
+    ops, _lib, l, out, sh, c = _run_chain(M, F, 0.1, True, False, with_bits=True, seed0=11)
+    from transformertts_amd.ops import _p, _stream, check
+    df = g(M, D, seed=77).to(torch.bfloat16).to(DEV)
+    dh1 = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
+    check(l.ttsmi_hgemm_k256_masked_bits(_p(df), D, _p(sh['w2'].wb), D, _p(out['bits']), _p(dh1), F, M, F, _stream()), 'masked_bits')
+    torch.cuda.synchronize()
+    want = (df.double().cpu() @ sh['w2'].wb.double().cpu().t()) * (c['h1'].double() > 0)
+    got = dh1.double().cpu()
+    assert rel_err(got, want) < 4e-3
+    assert torch.equal(got != 0, (want != 0) & (got != 0))           # nothing leaks through a cleared bit
+    # every kept element survives: where the reference is clearly non-zero, so is the result
+    big = want.abs() > 1e-2 * float(want.abs().max())
+    assert bool((got[big] != 0).all())
+
+
+def test_chained_blocks_equal_the_four_launch_blocks_at_the_benchmarked_architecture():
+    """The model with the chain kernel (default) against the same model with TTSMI_DENSE_CHAIN off (chain_blocks=False):
+    the same arithmetic up to fp32 summation order - losses of a few bf16 train steps agree to 2e-3, parameters stay
+    within bf16-path noise."""
+    from oracle import ft_oracle as fo
+    from transformertts_amd.model.models import ForwardTransformer
+    cfg = dict(fo.make_config(), dropout_rate=0.1, predictors_dropout=0.1, seed=3, precision='bf16')
+    batch = fo.synthetic_batch(4, 120, 500, seed=21, ragged=True)
+    losses = {}
+    params = {}
+    for chain in (True, False):
+        m = ForwardTransformer.from_config(dict(cfg, chain_blocks=chain))
+        m._compile(learning_rate=1e-4)
+        ls = []
+        for _ in range(4):
+            ls.append(float(m.train_step(*batch)['loss']))
+        torch.cuda.synchronize()
+        used = [pl.chain_on for (name, mode), pl in m._plans.items() if mode == 'bwd']
+        assert used and all(u == chain for u in used)
+        losses[chain], params[chain] = ls, m.params.data.clone()
+    for a, b in zip(losses[True], losses[False]):
+        assert abs(a - b) <= 2e-3 * abs(b), (losses[True], losses[False])
+    assert all(np.isfinite(losses[True]))
+    # Adam moves every weight by ~lr per step whatever the gradient's size: compare the update directions loosely
+    d = (params[True] - params[False]).abs()
+    assert float(d.max()) <= 8.5e-4 and float(d.mean()) < 1.5e-4, (float(d.max()), float(d.mean()))

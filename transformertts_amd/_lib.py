@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # version this binding was written for (EXPECTED_VERSION, checked in lib()).
 _override = os.environ.get('TTSMI_LIB') if os.environ.get('TTSMI_ALLOW_LIB_OVERRIDE') == '1' else None
 LIB_PATH = _override or os.path.join(_HERE, 'lib', 'libttsmi.so')
-EXPECTED_VERSION = 104            # include/ttsmi.h: TTSMI_VERSION
+EXPECTED_VERSION = 105            # include/ttsmi.h: TTSMI_VERSION
 
 P = c_void_p          # every device pointer
 I = c_int
@@ -120,6 +120,11 @@ SIGNATURES = {
     'ttsmi_comm_destroy': (I, [P]),
     'ttsmi_allreduce_sum_f32': (I, [P, P, L, S]),
     'ttsmi_set_launch_observer': (I, [P]),
+    'ttsmi_dense_chain_pack_bytes': (c_size_t, [I, I]),
+    'ttsmi_dense_chain_pack': (I, [P, P, P, P, I, P, c_size_t, S]),
+    'ttsmi_dense_chain_supported': (I, [I, I, I]),
+    'ttsmi_dense_chain_fwd': (I, [P, P, P, c_size_t, I, I, P, P, P, P, P, P, P, P, P, F, c_uint64, P, c_uint32, c_uint32, F,
+                                  P, P, P, P, P, P, P, P, P, P, S]),
     'ttsmi_dense_block_fwd': (I, [P, P, P]),
     'ttsmi_dense_block_bwd': (I, [P, P, P, P]),
     'ttsmi_dense_stack_fwd': (I, [P, I, P, P]),
@@ -141,7 +146,8 @@ def _dense_block_fields():
             [(n, p) for n in ('xhat1', 'xhat2', 'lnp_ws1', 'lnp_ws2')] + [('lnp_ws1_bytes', u64), ('lnp_ws2_bytes', u64)] +
             [(n, p) for n in ptrs2] + [(n, u64) for n in ('attn_ws_bytes', 'ln_ws_bytes', 'wgrad_ws_bytes')] +
             [('main_stream', p), ('side_stream', p), ('ev', p * 4), ('below', p), ('ln2_done', i32), ('res16', i32), ('relu_bits', p),
-             ('attn_fused_ws', p), ('attn_fused_ws_bytes', u64)])
+             ('attn_fused_ws', p), ('attn_fused_ws_bytes', u64),
+             ('chain_w', p), ('chain_w_bytes', u64), ('above', p), ('qkv_done', i32), ('chain_pad_', i32)])
 
 
 class DenseBlockDesc(ctypes.Structure):

@@ -1,0 +1,543 @@
+// The row-local chain of a dense block as ONE persistent-per-tile kernel (TTSMI_BF16 path, d_model = 256):
+//
+//   a   = LN1( keep([h | ctx] . Wo + bo) + h ) * rowmask                      (model/layers.py:148-150, 211, 229)
+//   h1  = relu(a . W1 + b1)                                                   (model/layers.py:99)
+//   out = LN2( keep(h1 . W2 + b2) + a ) * rowmask                             (model/layers.py:100-102, 230)
+//   qkv'= out . Wqkv' + bqkv'      (the NEXT block's projection, model/layers.py:116-118 - when there is a next block)
+//
+// Until round 4 these were four launches (full-row GEMM + LN, K = 256 GEMM, full-row GEMM + LN, K = 256 GEMM), each
+// re-reading from HBM what the previous one had just written: a_bf twice, h1 once, out_bf once (118 MB per decoder block
+// at M = 28 800) and each paying its own launch ramp, epilogue and tail.  Here a workgroup takes 128 rows through the whole
+// chain; nothing but the tensors the BACKWARD needs (a_bf, x^1, rstd1, h1, x^2, rstd2, out_bf, qkv') is written, nothing
+// is read back.
+//
+// Layout: a wave owns 32 rows.  Every product is computed transposed (C^T = W . X^T: the MFMA A operand is a 32 x 16
+// weight fragment, the B operand the activation fragment), so a lane holds ONE row (lane & 31) and 16 of every 32 output
+// features in its accumulator registers - and an accumulator register block IS the B operand of the next product:
+// registers 8p .. 8p + 7 of output tile j, rounded to bf16, are the fragment of k-group 2j + p (the register-feedback
+// trick of the attention kernels, attention_bf16.hip:to_frags).  The k order inside such a group is the accumulator's
+// (features 16q + {0..3, 8..11} + 4 * (lane >> 5)), so the weights are stored pre-permuted to match: ttsmi_dense_chain_pack
+// writes the four matrices of a chain as ONE linear stream of 1 KB MFMA A fragments in exactly the order the kernel
+// multiplies them (52 stages of 32 fragments at F = 1 024; 1.66 MB per block and step, repacked after every Adam step).
+// A row's LayerNorm statistics are 128 local adds and one exchange with lane ^ 32; residuals never leave registers.
+//
+// The weight stream arrives by LDS-DMA (global_load_lds_dwordx4, lane-linear = fragment order: no swizzle, conflict-free
+// ds_read_b128) into a three-stage ring of 32 KB stages: one barrier per stage, two stages in flight.  vmcnt counts loads
+// AND stores on gfx950, and stores are not ordered against loads, so the roles are separated (as in gemm_k256.hip): waves
+// 0-1 issue the DMAs and wait on exact counts, waves 2-3 issue the in-loop global stores (h1 chunks, qkv' chunks) for all
+// four waves out of a double-buffered transposing scratch; the two LayerNorm epilogues store per wave (there the DMA
+// waves' counted waits merely over-wait).
+//
+// LDS: 96 KB ring + 36 KB scratch = 132 KB; 512 registers per lane (one wave per SIMD).
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define CH_D 256
+#define CH_FRAG_BYTES 1024
+#define CH_STAGE_FRAGS 32
+#define CH_STAGE_BYTES (CH_STAGE_FRAGS * CH_FRAG_BYTES)
+#define CH_NRING 3
+#define CH_NW 4
+#define CH_ROWS (CH_NW * 32)
+#define CH_SLOT_LD 72                                   // bf16 elements per scratch row: 64 + 8 (144-byte rows)
+#define CH_SLOT_BYTES (32 * CH_SLOT_LD * 2)             // 4 608: 32 rows x 64 bf16, or 32 rows x 32 fp32 (36-float rows)
+#define CH_SCR_BYTES (CH_NW * CH_SLOT_BYTES)            // one parity buffer: a slot per wave
+#define CH_NDMA (CH_STAGE_FRAGS / (CH_NW / 2))          // DMA instructions per DMA wave and stage: 16
+#define CH_WO_STAGES 8                                  // K = 512 in steps of 64
+#define CH_QKV_STAGES 12                                // 768 output features in chunks of 64
+
+struct ChainP {
+    const uint16_t* h_bf;            // [M,256] block input: q_in half of the o-projection AND residual of res-norm 1
+    const uint16_t* cx;              // [M,256] attention context
+    const unsigned char* wpack;      // ttsmi_dense_chain_pack
+    int M, F, nchunk, nstages;
+    const float *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b, *bqkv;
+    const uint8_t* row_pad;
+    uint32_t thr; float inv_keep; uint64_t seed; const int64_t* step_dev; uint32_t site_ln1, site_ln2;
+    float eps;
+    uint16_t *a_bf, *xhat1; float* rstd1;
+    uint16_t* h1; uint32_t* relu_bits; int bits_wide;
+    uint16_t *out_bf, *xhat2; float* rstd2; float* out32;
+    uint16_t* qkv;                   // the next block's [M,768], or NULL
+};
+
+__device__ __forceinline__ void ch_dma16(const void* gsrc, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory", "m0");
+}
+__device__ __forceinline__ void ch_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void ch_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned ch_lds_offset(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ uint2 ch_pack4(float a, float b, float c, float d) {
+    bf16x4 h;
+    h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
+    return *reinterpret_cast<uint2*>(&h);
+}
+__device__ __forceinline__ float ch_bf(const bf16x8& v, int e) { return (float)v[e]; }
+// bit e = bf16 element e of the 8-element group is > 0 (gemm_k256.hip: kw_pos_bits)
+__device__ __forceinline__ uint32_t ch_pos_bits(const uint4& v) {
+    auto two = [](uint32_t w) { return (((int32_t)(w << 16) > 0) ? 1u : 0u) | (((int32_t)(w & 0xFFFF0000u) > 0) ? 2u : 0u); };
+    return two(v.x) | (two(v.y) << 2) | (two(v.z) << 4) | (two(v.w) << 6);
+}
+
+#define CH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// One stage = 32 weight fragments x one MFMA each, in four groups of eight.  The fragments of group g + 1 are requested
+// before the multiplies of group g issue (scheduling barriers pin that order): left to itself hipcc reads two fragments
+// into the same registers, waits, multiplies twice - with ONE wave per SIMD nothing else hides the LDS round trip, and the
+// matrix pipe idles two thirds of the time (first build of this kernel, ISA reading).  mf(g, i, fragment) multiplies.
+template <class MF>
+__device__ __forceinline__ void ch_stage(const unsigned char* Fs, MF&& mf) {
+    bf16x8 a0[8], a1[8];
+#define CH_LOAD8(dst, g)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(Fs + ((g) * 8 + i) * CH_FRAG_BYTES)
+#define CH_MUL8(src, g) \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) mf(g, i, src[i])
+    CH_LOAD8(a0, 0);
+    CH_LOAD8(a1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    CH_MUL8(a0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    CH_LOAD8(a0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    CH_MUL8(a1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    CH_LOAD8(a1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    CH_MUL8(a0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    CH_MUL8(a1, 3);
+#undef CH_LOAD8
+#undef CH_MUL8
+}
+
+// ---- transposing stores -------------------------------------------------------------------------------------------
+// producer: the wave's accumulator-layout values of 64 features (two 32-feature tiles, already bf16) -> its scratch slot
+__device__ __forceinline__ void ch_slot_write(unsigned char* slot, int l31, int hh, int u, int g, uint2 v) {
+    *reinterpret_cast<uint2*>(slot + (l31 * CH_SLOT_LD + u * 32 + 8 * g + 4 * hh) * 2) = v;
+}
+// consumer: the slot's 32 rows x 128 bytes -> global rows [row0, row0 + 32) at column col0 (16 bytes per lane, 8 rows per
+// instruction); optionally the sign bits of what it stores, in the bit-matrix layout of the K = 256 kernels
+__device__ __forceinline__ void ch_slot_flush(const unsigned char* slot, uint16_t* dst, long ld, int col0, int row0, int M, int lane,
+                                              uint32_t* bits, int bits_wide, int nbchunk) {
+    const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+    uint32_t bb[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = r8 + 8 * it;
+        const uint4 v = *reinterpret_cast<const uint4*>(slot + (r * CH_SLOT_LD + c8) * 2);
+        bb[it] = ch_pos_bits(v);
+        if (row0 + r < M) *reinterpret_cast<uint4*>(dst + (long)(row0 + r) * ld + col0 + c8) = v;
+    }
+    if (bits != nullptr && row0 < M) {
+        // (rows of a 64-row tile: R = (row0 & 32) + r8 + 8 it.  tiles past M are never read back: cdiv(M, 64) tiles exist)
+        const long tile = row0 >> 6;
+        const int half = (row0 >> 5) & 1;
+        if (bits_wide) {
+            // gemm_k256_wide_kernel: 64-row x 256-column blocks of 256 threads x two words; thread = (R & 7) * 32 + column / 8,
+            // bit 8 (R >> 3) + e of the pair; rows 0..31 of the tile are the first word, 32..63 the second
+            const int chunk = col0 >> 8, cb = ((col0 & 255) >> 3) + (lane & 7);
+            const uint32_t w = bb[0] | (bb[1] << 8) | (bb[2] << 16) | (bb[3] << 24);
+            bits[((tile * nbchunk + chunk) * 256 + r8 * 32 + cb) * 2 + half] = w;
+        } else {
+            // gemm_k256_kernel: 64-row x 128-column blocks of 256 threads x one word; thread = (R & 15) * 16 + column / 8,
+            // bit 8 (R >> 4) + e: this lane holds rows r8 + {0, 16} (+ 32 half) of thread A and r8 + 8 + {0, 16} of thread B
+            const int chunk = col0 >> 7, cb = ((col0 & 127) >> 3) + (lane & 7);
+            uint16_t* b16 = reinterpret_cast<uint16_t*>(bits);
+            const long base = (tile * nbchunk + chunk) * 256;
+            b16[(base + r8 * 16 + cb) * 2 + half] = (uint16_t)(bb[0] | (bb[2] << 8));
+            b16[(base + (r8 + 8) * 16 + cb) * 2 + half] = (uint16_t)(bb[1] | (bb[3] << 8));
+        }
+    }
+}
+// fp32 variant of the pair for the stack's last block (its fp32 output is read by the next layer): one 32-feature tile
+__device__ __forceinline__ void ch_slot_flush_f32(const unsigned char* slot, float* dst, int col0, int row0, int M, int lane) {
+    const int r8 = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = r8 + 8 * it;
+        const float4 v = *reinterpret_cast<const float4*>(slot + (r * 36 + c4) * 4);
+        if (row0 + r < M) *reinterpret_cast<float4*>(dst + (long)(row0 + r) * CH_D + col0 + c4) = v;
+    }
+}
+
+// ---- LayerNorm of a wave's 32 rows, in the accumulator layout -----------------------------------------------------
+// Z: the product (8 tiles of 32 features); R: the residual as bf16 fragments (fragment 2j + p = registers 8p.. of tile j);
+// on return Y holds LN(keep(Z + bias) + R) * rowmask as bf16 fragments (the next product's B operand and the next
+// residual); y / x^ / rstd (and the fp32 y when asked for) are stored through the wave's own scratch slot.
+__device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[16], bf16x8 (&Y)[16], const ChainP& p, const float* bias,
+                                             const float* gamma, const float* beta, uint32_t site, int row, int rowc, int row0, bool padded,
+                                             unsigned char* slot, int lane, uint16_t* y_bf, uint16_t* xhat, float* rstd_out, float* y32) {
+    const int l31 = lane & 31, hh = lane >> 5;
+    const uint64_t key = p.thr ? ttsmi_drop_key(p.seed, p.step_dev, site) : 0;
+    const uint32_t rb = ttsmi_row_base(key, (uint32_t)rowc);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 32 * j + 8 * g + 4 * hh;
+            const float4 bs = *reinterpret_cast<const float4*>(bias + c0);
+            float v[4] = {Z[j][4 * g + 0] + bs.x, Z[j][4 * g + 1] + bs.y, Z[j][4 * g + 2] + bs.z, Z[j][4 * g + 3] + bs.w};
+            if (p.thr) {
+                const uint32_t h0 = ttsmi_pair_hash(rb, (uint32_t)c0), h1 = ttsmi_pair_hash(rb, (uint32_t)(c0 + 2));
+                v[0] *= ((h0 & 0xFFFFu) >= p.thr) ? p.inv_keep : 0.f;
+                v[1] *= ((h0 >> 16) >= p.thr) ? p.inv_keep : 0.f;
+                v[2] *= ((h1 & 0xFFFFu) >= p.thr) ? p.inv_keep : 0.f;
+                v[3] *= ((h1 >> 16) >= p.thr) ? p.inv_keep : 0.f;
+            }
+            const bf16x8& rr = R[2 * j + (g >> 1)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += ch_bf(rr, 4 * (g & 1) + e);
+                Z[j][4 * g + e] = v[e];
+                sum += v[e];
+            }
+        }
+    const float invC = 1.0f / (float)CH_D;
+    const float mean = (sum + __shfl_xor(sum, 32, 64)) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = Z[j][r] - mean;
+            Z[j][r] = v;
+            q += v * v;
+        }
+    const float rstd = __builtin_amdgcn_rsqf((q + __shfl_xor(q, 32, 64)) * invC + p.eps);
+    if (hh == 0 && row < p.M) rstd_out[row] = rstd;
+    // normalise and leave, 64 features (two tiles) per round through the wave's scratch slot
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        uint2 xh_q[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = 2 * cc + u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * j + 8 * g + 4 * hh;
+                const float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
+                const float4 bt = *reinterpret_cast<const float4*>(beta + c0);
+                const float xh[4] = {Z[j][4 * g + 0] * rstd, Z[j][4 * g + 1] * rstd, Z[j][4 * g + 2] * rstd, Z[j][4 * g + 3] * rstd};
+                float y[4] = {xh[0] * gm.x + bt.x, xh[1] * gm.y + bt.y, xh[2] * gm.z + bt.z, xh[3] * gm.w + bt.w};
+                if (padded) { y[0] = 0.f; y[1] = 0.f; y[2] = 0.f; y[3] = 0.f; }
+                xh_q[u][g] = ch_pack4(xh[0], xh[1], xh[2], xh[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    Y[2 * j + (g >> 1)][4 * (g & 1) + e] = (__bf16)y[e];
+                    Z[j][4 * g + e] = y[e];                       // (kept for the optional fp32 store below)
+                }
+            }
+        }
+        // x^
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ch_slot_write(slot, l31, hh, u, g, xh_q[u][g]);
+        ch_lds_fence();
+        ch_slot_flush(slot, xhat, CH_D, 64 * cc, row0, p.M, lane, nullptr, 0, 0);
+        ch_lds_fence();
+        // y (bf16)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = 2 * cc + u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x8& yy = Y[2 * j + (g >> 1)];
+                bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = yy[4 * (g & 1) + e];
+                ch_slot_write(slot, l31, hh, u, g, *reinterpret_cast<uint2*>(&h));
+            }
+        }
+        ch_lds_fence();
+        ch_slot_flush(slot, y_bf, CH_D, 64 * cc, row0, p.M, lane, nullptr, 0, 0);
+        ch_lds_fence();
+        if (y32 != nullptr) {                                     // (workgroup-uniform: the stack's last block only)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * cc + u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(slot + (l31 * 36 + 8 * g + 4 * hh) * 4) =
+                        make_float4(Z[j][4 * g + 0], Z[j][4 * g + 1], Z[j][4 * g + 2], Z[j][4 * g + 3]);
+                ch_lds_fence();
+                ch_slot_flush_f32(slot, y32, 32 * j, row0, p.M, lane);
+                ch_lds_fence();
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_chain_kernel(ChainP p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + 2 * CH_SCR_BYTES];
+    unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool dma_wave = wave < CH_NW / 2;
+    const int m0 = blockIdx.x * CH_ROWS;
+    const int row0 = m0 + wave * 32, row = row0 + l31, rowc = min(row, p.M - 1);
+    const int nst = p.nstages;
+    const unsigned ring_off = ch_lds_offset(smem);
+
+    auto issue = [&](int s) {                    // DMA waves: this wave's half of stage s
+        const unsigned char* src = p.wpack + (size_t)s * CH_STAGE_BYTES + (size_t)wave * CH_NDMA * CH_FRAG_BYTES + lane * 16;
+        const unsigned dst = ring_off + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES + (unsigned)wave * CH_NDMA * CH_FRAG_BYTES;
+#pragma unroll
+        for (int i = 0; i < CH_NDMA; ++i) ch_dma16(src + i * CH_FRAG_BYTES, dst + i * CH_FRAG_BYTES);
+    };
+    // stage s has landed once at most the next stage's DMA instructions are outstanding on the issuing waves (loads
+    // complete in order; outstanding stores can only make this wait longer, never shorter: see the header)
+    auto stage_begin = [&](int s) -> const unsigned char* {
+        if (dma_wave) {
+            if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH_NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        ch_barrier();                            // everybody's pieces of stage s landed; stage s - 1's slot is retired
+        if (dma_wave && s + 2 < nst) issue(s + 2);
+        return smem + (s % CH_NRING) * CH_STAGE_BYTES + lane * 16;
+    };
+
+    // ---- the wave's rows of [h | ctx] as B fragments, in the accumulator's k order (k-group q: features 16q + 4hh +
+    // {0..3} and 16q + 8 + 4hh + {0..3}); requested BEFORE the first DMAs, so the counted waits cover them
+    bf16x8 X[32];
+    {
+        const uint16_t* hrow = p.h_bf + (long)rowc * CH_D + 4 * hh;
+        const uint16_t* crow = p.cx + (long)rowc * CH_D + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint2 lo = *reinterpret_cast<const uint2*>(hrow + 16 * q), hi = *reinterpret_cast<const uint2*>(hrow + 16 * q + 8);
+            const uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            X[q] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint2 lo = *reinterpret_cast<const uint2*>(crow + 16 * q), hi = *reinterpret_cast<const uint2*>(crow + 16 * q + 8);
+            const uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            X[16 + q] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+    }
+    const bool padded = p.row_pad != nullptr && p.row_pad[rowc] != 0;
+    if (dma_wave) {
+        issue(0);
+        if (nst > 1) issue(1);
+    }
+
+    f32x16 Z[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Z[j][r] = 0.f;
+
+    // ---- o-projection: 8 stages of (4 k-groups x 8 output tiles)
+    int S = 0;
+#pragma unroll
+    for (int s = 0; s < CH_WO_STAGES; ++s) {
+        const unsigned char* Fs = stage_begin(S++);
+        ch_stage(Fs, [&](int kq, int j, const bf16x8& a) { Z[j] = CH_MFMA(a, X[4 * s + kq], Z[j]); });
+    }
+    unsigned char* slot = scr + wave * CH_SLOT_BYTES;              // parity buffer 0 for the per-wave epilogue stores
+    bf16x8 Y[16];
+    {
+        bf16x8 R[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) R[q] = X[q];
+        ch_layernorm(Z, R, Y, p, p.bo, p.ln1_g, p.ln1_b, p.site_ln1, row, rowc, row0, padded, slot, lane, p.a_bf, p.xhat1, p.rstd1, nullptr);
+    }
+
+    // ---- FFN: per 64 hidden features one stage of a . W1 (2 tiles x 16 k-groups) and one of h1 . W2 (4 k-groups x 8 tiles)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Z[j][r] = 0.f;
+    const int store_k = wave - CH_NW / 2;                           // storing waves: slots 2k and 2k + 1
+    const int nbchunk = p.bits_wide ? p.F / 256 : p.F / 128;
+    for (int c = 0; c < p.nchunk; ++c) {
+        const unsigned char* Fs = stage_begin(S++);
+        f32x16 H[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + 64 * c + 32 * u + 8 * g + 4 * hh);
+                H[u][4 * g + 0] = b4.x; H[u][4 * g + 1] = b4.y; H[u][4 * g + 2] = b4.z; H[u][4 * g + 3] = b4.w;
+            }
+        ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { H[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], H[i & 1]); });
+        bf16x8 hf[4];
+        unsigned char* pslot = scr + (c & 1) * CH_SCR_BYTES + wave * CH_SLOT_BYTES;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (__bf16)fmaxf(H[u][4 * g + e], 0.f);
+                    hf[2 * u + (g >> 1)][4 * (g & 1) + e] = h[e];
+                }
+                ch_slot_write(pslot, l31, hh, u, g, *reinterpret_cast<uint2*>(&h));
+            }
+        Fs = stage_begin(S++);                                      // (its barrier publishes the scratch)
+        if (!dma_wave) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int w = 2 * store_k + t;
+                ch_slot_flush(scr + (c & 1) * CH_SCR_BYTES + w * CH_SLOT_BYTES, p.h1, p.F, 64 * c, m0 + w * 32, p.M, lane, p.relu_bits,
+                              p.bits_wide, nbchunk);
+            }
+        }
+        ch_stage(Fs, [&](int g4, int j, const bf16x8& a) { Z[j] = CH_MFMA(a, hf[g4], Z[j]); });
+    }
+    // (the scratch buffer the LAST h1 chunk does not use: its flush by the storing waves may still be reading)
+    slot = scr + (p.nchunk & 1) * CH_SCR_BYTES + wave * CH_SLOT_BYTES;
+    ch_layernorm(Z, Y, Y, p, p.b2, p.ln2_g, p.ln2_b, p.site_ln2, row, rowc, row0, padded, slot, lane, p.out_bf, p.xhat2, p.rstd2, p.out32);
+
+    // ---- the next block's qkv projection: 12 stages of (2 output tiles x 16 k-groups)
+    if (p.qkv != nullptr) {
+        for (int s = 0; s < CH_QKV_STAGES; ++s) {
+            const unsigned char* Fs = stage_begin(S++);
+            if (!dma_wave && s > 0) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int w = 2 * store_k + t;
+                    ch_slot_flush(scr + ((s - 1) & 1) * CH_SCR_BYTES + w * CH_SLOT_BYTES, p.qkv, 3 * CH_D, 64 * (s - 1), m0 + w * 32, p.M,
+                                  lane, nullptr, 0, 0);
+                }
+            }
+            f32x16 acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(p.bqkv + 64 * s + 32 * u + 8 * g + 4 * hh);
+                    acc[u][4 * g + 0] = b4.x; acc[u][4 * g + 1] = b4.y; acc[u][4 * g + 2] = b4.z; acc[u][4 * g + 3] = b4.w;
+                }
+            ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { acc[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], acc[i & 1]); });
+            unsigned char* pslot = scr + (s & 1) * CH_SCR_BYTES + wave * CH_SLOT_BYTES;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    ch_slot_write(pslot, l31, hh, u, g, ch_pack4(acc[u][4 * g + 0], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]));
+        }
+        ch_barrier();
+        if (!dma_wave) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int w = 2 * store_k + t;
+                ch_slot_flush(scr + ((CH_QKV_STAGES - 1) & 1) * CH_SCR_BYTES + w * CH_SLOT_BYTES, p.qkv, 3 * CH_D, 64 * (CH_QKV_STAGES - 1),
+                              m0 + w * 32, p.M, lane, nullptr, 0, 0);
+            }
+        }
+    }
+}
+
+// ---- the weight stream ----------------------------------------------------------------------------------------------
+struct ChainPackP {
+    const uint16_t *wo_t, *w1_t, *w2_t, *wqkv_t;      // [256][512], [F][256], [256][F], [768][256] (W^T as stored by the shadow set)
+    uint16_t* out;
+    int F, nchunk, nstages;
+};
+__global__ __launch_bounds__(256) void dense_chain_pack_kernel(ChainPackP p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // one 16-byte lane item of one fragment
+    const long total = (long)p.nstages * CH_STAGE_FRAGS * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), f = (int)((idx >> 6) & 31), S = (int)(idx >> 11);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const uint16_t* src;
+    long ld;
+    int n, kbase;
+    if (S < CH_WO_STAGES) {
+        const int kq = f >> 3, j = f & 7;
+        src = p.wo_t; ld = 2 * CH_D; n = 32 * j + l31; kbase = 16 * (4 * S + kq);
+    } else if (S < CH_WO_STAGES + 2 * p.nchunk) {
+        const int t = S - CH_WO_STAGES, c = t >> 1;
+        if ((t & 1) == 0) {
+            const int q = f >> 1, u = f & 1;
+            src = p.w1_t; ld = CH_D; n = 64 * c + 32 * u + l31; kbase = 16 * q;
+        } else {
+            const int g4 = f >> 3, j = f & 7;
+            src = p.w2_t; ld = p.F; n = 32 * j + l31; kbase = 64 * c + 16 * g4;
+        }
+    } else {
+        const int s = S - CH_WO_STAGES - 2 * p.nchunk, q = f >> 1, u = f & 1;
+        src = p.wqkv_t; ld = CH_D; n = 64 * s + 32 * u + l31; kbase = 16 * q;
+    }
+    const uint16_t* r = src + (long)n * ld + kbase + 4 * hh;
+    const uint2 lo = *reinterpret_cast<const uint2*>(r), hi = *reinterpret_cast<const uint2*>(r + 8);
+    *reinterpret_cast<uint4*>(p.out + idx * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+static int chain_stages(int F, int with_qkv) { return CH_WO_STAGES + 2 * (F / 64) + (with_qkv ? CH_QKV_STAGES : 0); }
+
+extern "C" {
+
+size_t ttsmi_dense_chain_pack_bytes(int F, int with_qkv) {
+    return F > 0 && F % 64 == 0 ? (size_t)chain_stages(F, with_qkv) * CH_STAGE_BYTES : 0;
+}
+
+int ttsmi_dense_chain_pack(const uint16_t* wo_t, const uint16_t* w1_t, const uint16_t* w2_t, const uint16_t* wqkv_next_t, int F,
+                           void* out, size_t out_bytes, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(wo_t && w1_t && w2_t && out, "dense_chain_pack: null pointer");
+    TTSMI_CHECK_ARG(F > 0 && F % 64 == 0, "dense_chain_pack: F must be a multiple of 64 (got %d)", F);
+    TTSMI_CHECK_ARG(out_bytes >= ttsmi_dense_chain_pack_bytes(F, wqkv_next_t != nullptr), "dense_chain_pack: output buffer too small");
+    TTSMI_CHECK_ARG(((((uintptr_t)wo_t) | ((uintptr_t)w1_t) | ((uintptr_t)w2_t) | ((uintptr_t)wqkv_next_t)) & 7) == 0 && (((uintptr_t)out) & 15) == 0,
+                    "dense_chain_pack: operands must be 8-byte (output: 16-byte) aligned");
+    ChainPackP p;
+    p.wo_t = wo_t; p.w1_t = w1_t; p.w2_t = w2_t; p.wqkv_t = wqkv_next_t; p.out = (uint16_t*)out;
+    p.F = F; p.nchunk = F / 64; p.nstages = chain_stages(F, wqkv_next_t != nullptr);
+    const long total = (long)p.nstages * CH_STAGE_FRAGS * 64;
+    hipLaunchKernelGGL(dense_chain_pack_kernel, dim3(ttsmi_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    TTSMI_CHECK_LAUNCH("dense_chain_pack");
+    return TTSMI_OK;
+}
+
+int ttsmi_dense_chain_supported(int M, int d, int F) { return M > 0 && d == CH_D && F >= 64 && F % 64 == 0; }
+
+int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void* wpack, size_t wpack_bytes, int M, int F,
+                          const float* bo, const float* ln1_g, const float* ln1_b, const float* b1, const float* b2,
+                          const float* ln2_g, const float* ln2_b, const float* bqkv_next, const uint8_t* row_pad, float p_drop,
+                          uint64_t seed, const int64_t* step_dev, uint32_t site_ln1, uint32_t site_ln2, float eps, uint16_t* a_bf,
+                          uint16_t* xhat1, float* rstd1, uint16_t* h1, void* relu_bits, uint16_t* out_bf, uint16_t* xhat2,
+                          float* rstd2, float* out32, uint16_t* qkv_next, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(h_bf && ctx && wpack && bo && ln1_g && ln1_b && b1 && b2 && ln2_g && ln2_b && a_bf && xhat1 && rstd1 && h1 &&
+                        out_bf && xhat2 && rstd2,
+                    "dense_chain_fwd: null pointer");
+    TTSMI_CHECK_ARG(ttsmi_dense_chain_supported(M, CH_D, F), "dense_chain_fwd: unsupported shape M=%d F=%d", M, F);
+    TTSMI_CHECK_ARG((qkv_next == nullptr) == (bqkv_next == nullptr), "dense_chain_fwd: qkv_next and bqkv_next go together");
+    TTSMI_CHECK_ARG(wpack_bytes >= ttsmi_dense_chain_pack_bytes(F, qkv_next != nullptr), "dense_chain_fwd: weight stream too short");
+    TTSMI_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dense_chain_fwd: bad dropout rate");
+    TTSMI_CHECK_ARG(((((uintptr_t)h_bf) | ((uintptr_t)ctx) | ((uintptr_t)wpack) | ((uintptr_t)a_bf) | ((uintptr_t)xhat1) | ((uintptr_t)h1) |
+                      ((uintptr_t)out_bf) | ((uintptr_t)xhat2) | ((uintptr_t)out32) | ((uintptr_t)qkv_next) | ((uintptr_t)bo) |
+                      ((uintptr_t)ln1_g) | ((uintptr_t)ln1_b) | ((uintptr_t)b1) | ((uintptr_t)b2) | ((uintptr_t)ln2_g) | ((uintptr_t)ln2_b) |
+                      ((uintptr_t)bqkv_next)) & 15) == 0 && (((uintptr_t)relu_bits) & 7) == 0,
+                    "dense_chain_fwd: operands must be 16-byte aligned");
+    ChainP p;
+    memset(&p, 0, sizeof(p));
+    p.h_bf = h_bf; p.cx = ctx; p.wpack = (const unsigned char*)wpack; p.M = M; p.F = F; p.nchunk = F / 64;
+    p.nstages = chain_stages(F, qkv_next != nullptr);
+    p.bo = bo; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.b1 = b1; p.b2 = b2; p.ln2_g = ln2_g; p.ln2_b = ln2_b; p.bqkv = bqkv_next;
+    p.row_pad = row_pad;
+    p.thr = p_drop > 0.f ? ttsmi_drop_threshold(p_drop) : 0u;
+    p.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    p.seed = seed; p.step_dev = step_dev; p.site_ln1 = site_ln1; p.site_ln2 = site_ln2; p.eps = eps;
+    p.a_bf = a_bf; p.xhat1 = xhat1; p.rstd1 = rstd1; p.h1 = h1; p.relu_bits = (uint32_t*)relu_bits;
+    // the bit matrix is read back by ttsmi_hgemm_k256_masked_bits: its 256-column variant from 16 384 rows (gemm_k256.hip: kw_launch)
+    TTSMI_KNOB(wide, "TTSMI_HGEMM_K256_WIDE", 1);
+    p.bits_wide = (wide && F % 256 == 0 && (M >= 16384 || wide > 1)) ? 1 : 0;
+    if (relu_bits != nullptr && !p.bits_wide) TTSMI_CHECK_ARG(F % 128 == 0, "dense_chain_fwd: the bit matrix needs F %% 128 == 0");
+    p.out_bf = out_bf; p.xhat2 = xhat2; p.rstd2 = rstd2; p.out32 = out32; p.qkv = qkv_next;
+    ttsmi_note_kernel("dense_chain_kernel");
+    TTSMI_LAUNCH_EV(dense_chain_kernel, dim3(ttsmi_cdiv(M, CH_ROWS)), dim3(CH_NW * 64), 0, (hipStream_t)stream, p);
+    TTSMI_CHECK_LAUNCH("dense_chain_fwd");
+    return TTSMI_OK;
+}
+
+}  // extern "C"

@@ -77,7 +77,9 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
     const int M = D->B * D->T, d = D->d, F = D->F, dh = d / D->H;
     ttsmi_stream_t st = D->main_stream;
     // qkv = h.Wqkv + b                                                     (layers.py:116-118, fused)
-    { OBS("ttsmi_hgemm_tn", 2.0 * M * 3 * d * d, gemm_bytes(M, 3 * d, d, 2, false), st);
+    // (qkv_done: written by the row-local chain of the block below, whose `above` is this descriptor)
+    if (!D->qkv_done) {
+      OBS("ttsmi_hgemm_tn", 2.0 * M * 3 * d * d, gemm_bytes(M, 3 * d, d, 2, false), st);
       TRY(ttsmi_hgemm_tn(h_bf, 0, d, nullptr, 0, 0, D->wqkv_t, d, D->bqkv, nullptr, 0, D->qkv, 3L * d, M, 3 * d, d,
                          TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
     // ctx = softmax(q k^T / sqrt(dh) + mask) v                             (layers.py:176-195)
@@ -93,6 +95,26 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
             TRY(ttsmi_attention_fwd(D->qkv, D->pad, D->klen, D->cx, D->lse, D->B, D->H, D->T, dh, D->rate, D->seed,
                                     D->step_dev, D->site_attn, TTSMI_BF16_IO, st));
     }
+    if (D->chain_w != nullptr) {
+        // the row-local chain (csrc/chain.hip): o-projection + res-norm 1 -> FFN1 -> FFN2 + res-norm 2 -> the next block's
+        // qkv projection in ONE launch; what the backward keeps is written, nothing is read back
+        TTSMI_CHECK_ARG(D->fuse_ln && D->res16 && ttsmi_dense_chain_supported(M, d, F),
+                        "dense_block_fwd: chain_w needs fuse_ln, res16, d == 256 and F %% 64 == 0");
+        const ttsmi_dense_block* A = D->above;
+        if (A != nullptr)
+            TTSMI_CHECK_ARG(A->qkv_done && A->B == D->B && A->T == D->T && A->d == d && A->qkv && A->bqkv,
+                            "dense_block_fwd: `above` is not the next block of the same shape (or its qkv_done is not set)");
+        const double wbytes = (double)ttsmi_dense_chain_pack_bytes(F, A != nullptr);
+        // bytes: h, ctx in; a_bf, x^1, h1 (+ bits), x^2, out_bf (+ fp32 out, + qkv') out; the weight stream once
+        OBS("ttsmi_dense_chain_fwd", 2.0 * M * d * (2.0 * d + 2.0 * F + (A ? 3.0 * d : 0.0)),
+            (double)M * 2 * (2.0 * d + 4.0 * d + F + (A ? 3.0 * d : 0.0)) + ((D->res16 & 2) ? 4.0 * M * d : 0.0) +
+                (relu_bits(D) ? (double)M * F / 8 : 0.0) + wbytes + 8.0 * M, st);
+        return ttsmi_dense_chain_fwd(h_bf, D->cx, D->chain_w, D->chain_w_bytes, M, F, D->bo, D->ln1_g, D->ln1_b, D->b1, D->b2, D->ln2_g,
+                                     D->ln2_b, A ? A->bqkv : nullptr, D->pad, D->rate, D->seed, D->step_dev, D->site_ln1, D->site_ln2,
+                                     kLnEps, D->a_bf, D->xhat1, D->rstd1, D->h1, relu_bits(D) ? D->relu_bits : nullptr, D->out_bf,
+                                     D->xhat2, D->rstd2, (D->res16 & 2) ? D->out : nullptr, A ? A->qkv : nullptr, st);
+    }
+    TTSMI_CHECK_ARG(D->above == nullptr, "dense_block_fwd: `above` without chain_w");
     if (D->fuse_ln) {
         // res16: the residual stream between the fused kernels is the bf16 tensor the next GEMM reads anyway (h_bf, a_bf,
         // out_bf) - the fp32 copies are neither read nor, except for a requested block output (bit 1), written

@@ -232,6 +232,10 @@ class ForwardTransformer:
         # bf16 precision, blocks outside the planned path: bf16 qkv / context tensors around the attention kernels
         self._attn_io_bf16 = os.environ.get('TTSMI_ATTN_IO_BF16', '1') != '0'
         self._use_plans, self._plans, self._plan_shared, self._plans_grown = False, {}, {}, {}
+        # the forward's row-local chain of every planned dense block as one launch (csrc/chain.hip); TTSMI_DENSE_CHAIN=0:
+        # the four launches of rounds 2-4
+        self.chain_blocks = bool(kwargs.get('chain_blocks', os.environ.get('TTSMI_DENSE_CHAIN', '1') != '0'))
+        self._weights_version = 0
         self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
@@ -275,6 +279,7 @@ class ForwardTransformer:
     def _refresh_shadows(self, wb_is_current: bool = False):
         if self.shadow_set is not None:
             self.shadow_set.refresh(wb_is_current)
+        self._weights_version += 1                       # the chain kernels' weight streams are repacked on their next use
 
     # ------------------------------------------------------------------ construction helpers
     def _make_config(self, locals_: dict, kwargs: dict) -> dict:
@@ -421,8 +426,11 @@ class ForwardTransformer:
                     h_bf = ops.to_bf16(h)
                 nxt = i + 1
                 last = not (nxt < len(heads) and nxt < dense_blocks and self._plan_ok(f'{prefix}.blk{nxt}', heads[nxt], d))
+                # forward chaining: this block's chain launch also runs the next planned block's qkv projection
+                plan.chain_forward(None if last else self._block_plan(f'{prefix}.blk{nxt}', prefix, B, heads[nxt], T))
                 plan.bind(pad, klen, rate, drop, sites, dmask, res16=self.residual_bf16,
                           out32=last or self._taps is not None)
+                plan.ensure_packed(self._weights_version)
                 pending.append(plan)
                 if not stack_mode or last:
                     h, h_bf = flush(h, h_bf)
@@ -560,7 +568,8 @@ class ForwardTransformer:
             self._plans_grown[(prefix, key[1])] = True
             plan = self._plans[key] = ops.DenseBlockPlan(Pb, Gb, Sb, B, H, T, self.device,
                                                          self._plan_shared.setdefault((prefix, key[1]), {}), self.fuse_ln,
-                                                         backward=backward, cap_rows=cap)
+                                                         backward=backward, cap_rows=cap,
+                                                         chain=self.chain_blocks and self.residual_bf16)
         else:
             plan.rebind(B, T)
         return plan

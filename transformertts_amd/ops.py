@@ -1776,8 +1776,11 @@ class DenseBlockPlan:
     length-bucketed training data almost every batch has its own (B, Tp, Tm), and a plan per exact shape meant a
     device synchronisation plus ~30 allocations per block on almost every step (round-2 advisor finding)."""
 
-    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True, backward=True, cap_rows=0):
-        """backward=False: a forward-only plan (inference) - the backward temporaries are not allocated."""
+    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True, backward=True, cap_rows=0, chain=False):
+        """backward=False: a forward-only plan (inference) - the backward temporaries are not allocated.
+        chain: the forward's row-local chain (o-projection + res-norm 1 -> FFN -> res-norm 2 -> the next block's qkv
+        projection) as ONE launch (csrc/chain.hip, ttsmi_dense_block.chain_w) - training plans with fused LayerNorms and a
+        bf16 residual stream only."""
         l = _lib.lib()
         self.backward = bool(backward)
         d = P['wqkv'].shape[0]
@@ -1798,6 +1801,12 @@ class DenseBlockPlan:
             unused = (not backward and name in ('df', 'dh1', 'd_o', 'dqkv', 'dh')) or (self.want_fuse and backward and
                                                                                         name in ('o', 'f'))
             t[name] = e((8,) if unused else shape, dt)
+        # the row-local chain kernel and its weight stream (repacked whenever the weights change: ensure_packed)
+        self.chain = bool(chain) and self.want_fuse and self.backward and bool(l.ttsmi_dense_chain_supported(cap, d, F))
+        self.S = S
+        self.chain_next, self.packed_ver, self.chain_on = None, None, False
+        if self.chain:
+            t['chain_w'] = e((int(l.ttsmi_dense_chain_pack_bytes(F, 1)),), torch.uint8)
         # the FFN's ReLU as one bit per element for the backward (ttsmi_dense_block.relu_bits); TTSMI_RELU_BITS=0: re-read h1
         self.relu_bits = backward and self.want_fuse and os.environ.get('TTSMI_RELU_BITS', '1') != '0'
         t['relu_bits'] = e((max(int(l.ttsmi_relu_bits_bytes(cap, F)), 8) if self.relu_bits else 8,), torch.uint8)
@@ -1916,6 +1925,8 @@ class DenseBlockPlan:
                            l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, d // H) > 0)
         if self.above is not None and (self.above.B, self.above.T) != (B, T):
             self.chain_above(None)
+        if self.chain_next is not None and (self.chain_next.B, self.chain_next.T) != (B, T):
+            self.chain_forward(None)
 
     def chain_above(self, above):
         """`above` consumes this block's output and nothing else does: its backward finishes this block's res-norm-2
@@ -1930,6 +1941,31 @@ class DenseBlockPlan:
             above.desc.below = ctypes.addressof(self.desc)
         return ok
 
+    def chain_forward(self, nxt):
+        """FORWARD chaining (ttsmi_dense_block.above / qkv_done): `nxt` is the next block of the stack - this block's chain
+        launch also computes nxt's qkv projection, and nxt skips its own.  None unlinks.  Takes effect only while this
+        block's chain is on (bind decides per step)."""
+        ok = (nxt is not None and self.chain and (nxt.B, nxt.T, nxt.d) == (self.B, self.T, self.d))
+        if self.chain_next is not None and self.chain_next is not nxt:
+            self.chain_next.desc.qkv_done = 0
+        if (nxt if ok else None) is not self.chain_next:
+            self.packed_ver = None                    # the stream's qkv tail belongs to another block (or goes away)
+        self.chain_next = nxt if ok else None
+        return ok
+
+    def ensure_packed(self, version):
+        """The chain's weight stream is current for weight version `version` (the model bumps it whenever the bf16
+        shadows are refreshed).  Under stream capture the pack launch is always issued, so that a replayed step repacks."""
+        if not self.chain_on:
+            return
+        if self.packed_ver == version and not torch.cuda.is_current_stream_capturing():
+            return
+        S, nxt = self.S, self.chain_next
+        check(_lib.lib().ttsmi_dense_chain_pack(_p(S['wo'].wt), _p(S['ffn.w1'].wt), _p(S['ffn.w2'].wt),
+                                                _p(nxt.S['wqkv'].wt) if nxt is not None else None, self.F,
+                                                _p(self.t['chain_w']), self.t['chain_w'].numel(), _stream()), 'dense_chain_pack')
+        self.packed_ver = version
+
     def bind(self, pad, klen, rate, drop, sites, dmask, res16=False, out32=True):
         """Per-step inputs of the descriptor (masks are new tensors every step; the rest rarely changes).
         res16: bf16 residual stream between the fused kernels (ttsmi_dense_block.res16; ignored without fused LayerNorms);
@@ -1943,6 +1979,14 @@ class DenseBlockPlan:
         D.dropmask = _p(dmask)
         D.main_stream = _stream()
         self.keep = (pad, klen, dmask)                    # alive until the next bind
+        # the row-local chain needs the bf16 residual stream; the link to the next block follows it
+        self.chain_on = self.chain and self.res16
+        nxt = self.chain_next if self.chain_on else None
+        D.chain_w = self.t['chain_w'].data_ptr() if self.chain_on else None
+        D.chain_w_bytes = self.t['chain_w'].numel() if self.chain_on else 0
+        D.above = ctypes.addressof(nxt.desc) if nxt is not None else None
+        if self.chain_next is not None:
+            self.chain_next.desc.qkv_done = int(nxt is not None)
 
     def fwd(self, h, h_bf):
         check(_lib.lib().ttsmi_dense_block_fwd(self._dref, _p(h), _p(h_bf)), 'dense_block_fwd')
