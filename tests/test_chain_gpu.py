@@ -149,8 +149,9 @@ def test_row_local_chain_relu_bit_matrix_through_its_consumer(M):
 
 def test_chained_blocks_equal_the_four_launch_blocks_at_the_benchmarked_architecture():
     """The model with the chain kernel (default) against the same model with TTSMI_DENSE_CHAIN off (chain_blocks=False):
-    the same arithmetic up to fp32 summation order - losses of a few bf16 train steps agree to 2e-3, parameters stay
-    within bf16-path noise."""
+    the same arithmetic up to fp32 summation order (which flips bf16 roundings of the stored activations) - the first
+    step's loss agrees to 1e-3 (the bf16 path's own distance from fp64 is 5e-4, tests/test_config1_parity_gpu.py), later
+    steps - different dropout-free trajectories from there - to 1 %; parameters stay within what four Adam steps can move."""
     from oracle import ft_oracle as fo
     from transformertts_amd.model.models import ForwardTransformer
     cfg = dict(fo.make_config(), dropout_rate=0.1, predictors_dropout=0.1, seed=3, precision='bf16')
@@ -167,8 +168,8 @@ def test_chained_blocks_equal_the_four_launch_blocks_at_the_benchmarked_architec
         used = [pl.chain_on for (name, mode), pl in m._plans.items() if mode == 'bwd']
         assert used and all(u == chain for u in used)
         losses[chain], params[chain] = ls, m.params.data.clone()
-    for a, b in zip(losses[True], losses[False]):
-        assert abs(a - b) <= 2e-3 * abs(b), (losses[True], losses[False])
+    for i, (a, b) in enumerate(zip(losses[True], losses[False])):
+        assert abs(a - b) <= (1e-3 if i == 0 else 1e-2) * abs(b), (losses[True], losses[False])
     assert all(np.isfinite(losses[True]))
     # Adam moves every weight by ~lr per step whatever the gradient's size: compare the update directions loosely
     d = (params[True] - params[False]).abs()

@@ -40,7 +40,7 @@ for M in [int(a) for a in sys.argv[1:]] or [28800, 6400, 12000, 2500]:
     e = lambda *s, dt=torch.bfloat16: torch.empty(s, dtype=dt, device=DEV)
     a, xh1, r1, h1, o, xh2, r2, qkv = e(M, D), e(M, D), e(M, dt=torch.float32), e(M, F), e(M, D), e(M, D), e(M, dt=torch.float32), e(M, 3 * D)
     bits = torch.zeros(int(l.ttsmi_relu_bits_bytes(M, F)), dtype=torch.uint8, device=DEV)
-    use_bits = bool(l.ttsmi_hgemm_k256_eligible(M, F, D))
+    use_bits = bool(l._cdll.ttsmi_hgemm_k256_eligible(M, F, D))
 
     def chain():
         check(l.ttsmi_dense_chain_fwd(_p(h), _p(cx), _p(wpack), nb, M, F, _p(bo), _p(g1), _p(be1), _p(b1), _p(b2), _p(g2), _p(be2), _p(bq),

@@ -22,13 +22,18 @@
 // A row's LayerNorm statistics are 128 local adds and one exchange with lane ^ 32; residuals never leave registers.
 //
 // The weight stream arrives by LDS-DMA (global_load_lds_dwordx4, lane-linear = fragment order: no swizzle, conflict-free
-// ds_read_b128) into a three-stage ring of 32 KB stages: one barrier per stage, two stages in flight.  vmcnt counts loads
-// AND stores on gfx950, and stores are not ordered against loads, so the roles are separated (as in gemm_k256.hip): waves
-// 0-1 issue the DMAs and wait on exact counts, waves 2-3 issue the in-loop global stores (h1 chunks, qkv' chunks) for all
-// four waves out of a double-buffered transposing scratch; the two LayerNorm epilogues store per wave (there the DMA
-// waves' counted waits merely over-wait).
+// ds_read_b128) into a FOUR-stage ring of 32 KB stages: one barrier per stage, three stages in flight.  Every wave issues
+// its quarter of a stage (8 pieces of 1 KB), two pieces behind each group of eight MFMAs: a piece costs its wave 100-185
+// cycles of issue time (MI355X_MICROARCH.md), which eight MFMAs (256 cycles of matrix pipe) cover - the first build gave all
+// 32 pieces of a stage to two waves in one burst and was issue-bound at ~1 us per stage (5.57 ms per step against 4.99).
+// vmcnt counts loads AND stores on gfx950 and stores are not ordered against loads, so the counted wait in front of a stage
+// allows exactly the DMA pieces that are YOUNGER than the stage's own (16, 8 or 0): loads complete in order, outstanding
+// stores can only make that wait longer, never shorter - and with three stages in flight there is slack for them.
+// Bias / gamma / beta vectors are staged in LDS once per workgroup (read from global memory inside the LayerNorm they were
+// 32 dependent load -> wait pairs per pass).
 //
-// LDS: 96 KB ring + 36 KB scratch = 132 KB; 512 registers per lane (one wave per SIMD).
+// LDS: 128 KB ring + 18 KB transposing scratch (a slot per wave) + 13 KB parameters = 159 KB; 512 registers per lane (one
+// wave per SIMD).
 #include <stdlib.h>
 
 #include "common.h"
@@ -41,13 +46,23 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define CH_FRAG_BYTES 1024
 #define CH_STAGE_FRAGS 32
 #define CH_STAGE_BYTES (CH_STAGE_FRAGS * CH_FRAG_BYTES)
-#define CH_NRING 3
+#define CH_NRING 4
 #define CH_NW 4
 #define CH_ROWS (CH_NW * 32)
 #define CH_SLOT_LD 72                                   // bf16 elements per scratch row: 64 + 8 (144-byte rows)
 #define CH_SLOT_BYTES (32 * CH_SLOT_LD * 2)             // 4 608: 32 rows x 64 bf16, or 32 rows x 32 fp32 (36-float rows)
-#define CH_SCR_BYTES (CH_NW * CH_SLOT_BYTES)            // one parity buffer: a slot per wave
-#define CH_NDMA (CH_STAGE_FRAGS / (CH_NW / 2))          // DMA instructions per DMA wave and stage: 16
+#define CH_SCR_BYTES (CH_NW * CH_SLOT_BYTES)            // a private slot per wave
+#define CH_NDMA (CH_STAGE_FRAGS / CH_NW)                // DMA pieces per wave and stage: 8
+#define CH_MAXF 1024                                    // the staged parameter block holds b1 up to this many features
+#define CH_PAR_FLOATS (6 * CH_D + CH_MAXF + 3 * CH_D)   // bo g1 be1 b2 g2 be2 | b1 | bqkv
+#define CH_P_BO 0
+#define CH_P_G1 (1 * CH_D)
+#define CH_P_BE1 (2 * CH_D)
+#define CH_P_B2 (3 * CH_D)
+#define CH_P_G2 (4 * CH_D)
+#define CH_P_BE2 (5 * CH_D)
+#define CH_P_B1 (6 * CH_D)
+#define CH_P_BQ (6 * CH_D + CH_MAXF)
 #define CH_WO_STAGES 8                                  // K = 512 in steps of 64
 #define CH_QKV_STAGES 12                                // 768 output features in chunks of 64
 
@@ -92,8 +107,8 @@ __device__ __forceinline__ uint32_t ch_pos_bits(const uint4& v) {
 // before the multiplies of group g issue (scheduling barriers pin that order): left to itself hipcc reads two fragments
 // into the same registers, waits, multiplies twice - with ONE wave per SIMD nothing else hides the LDS round trip, and the
 // matrix pipe idles two thirds of the time (first build of this kernel, ISA reading).  mf(g, i, fragment) multiplies.
-template <class MF>
-__device__ __forceinline__ void ch_stage(const unsigned char* Fs, MF&& mf) {
+template <class MF, class DMA>
+__device__ __forceinline__ void ch_stage(const unsigned char* Fs, MF&& mf, DMA&& dma) {
     bf16x8 a0[8], a1[8];
 #define CH_LOAD8(dst, g)                                                                                  \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(Fs + ((g) * 8 + i) * CH_FRAG_BYTES)
@@ -104,15 +119,21 @@ __device__ __forceinline__ void ch_stage(const unsigned char* Fs, MF&& mf) {
     __builtin_amdgcn_sched_barrier(0);
     CH_MUL8(a0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    dma(0);                                            // two pieces of the stage three ahead, under the multiplies just issued
     CH_LOAD8(a0, 2);
     __builtin_amdgcn_sched_barrier(0);
     CH_MUL8(a1, 1);
     __builtin_amdgcn_sched_barrier(0);
+    dma(1);
     CH_LOAD8(a1, 3);
     __builtin_amdgcn_sched_barrier(0);
     CH_MUL8(a0, 2);
     __builtin_amdgcn_sched_barrier(0);
+    dma(2);
+    __builtin_amdgcn_sched_barrier(0);
     CH_MUL8(a1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    dma(3);
 #undef CH_LOAD8
 #undef CH_MUL8
 }
@@ -171,6 +192,7 @@ __device__ __forceinline__ void ch_slot_flush_f32(const unsigned char* slot, flo
 // Z: the product (8 tiles of 32 features); R: the residual as bf16 fragments (fragment 2j + p = registers 8p.. of tile j);
 // on return Y holds LN(keep(Z + bias) + R) * rowmask as bf16 fragments (the next product's B operand and the next
 // residual); y / x^ / rstd (and the fp32 y when asked for) are stored through the wave's own scratch slot.
+// bias / gamma / beta: the workgroup's staged copies in LDS.
 __device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[16], bf16x8 (&Y)[16], const ChainP& p, const float* bias,
                                              const float* gamma, const float* beta, uint32_t site, int row, int rowc, int row0, bool padded,
                                              unsigned char* slot, int lane, uint16_t* y_bf, uint16_t* xhat, float* rstd_out, float* y32) {
@@ -277,31 +299,32 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[1
 }
 
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_chain_kernel(ChainP p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + 2 * CH_SCR_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + CH_SCR_BYTES + CH_PAR_FLOATS * 4];
     unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
+    float* par = reinterpret_cast<float*>(scr + CH_SCR_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool dma_wave = wave < CH_NW / 2;
     const int m0 = blockIdx.x * CH_ROWS;
     const int row0 = m0 + wave * 32, row = row0 + l31, rowc = min(row, p.M - 1);
     const int nst = p.nstages;
     const unsigned ring_off = ch_lds_offset(smem);
 
-    auto issue = [&](int s) {                    // DMA waves: this wave's half of stage s
-        const unsigned char* src = p.wpack + (size_t)s * CH_STAGE_BYTES + (size_t)wave * CH_NDMA * CH_FRAG_BYTES + lane * 16;
-        const unsigned dst = ring_off + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES + (unsigned)wave * CH_NDMA * CH_FRAG_BYTES;
-#pragma unroll
-        for (int i = 0; i < CH_NDMA; ++i) ch_dma16(src + i * CH_FRAG_BYTES, dst + i * CH_FRAG_BYTES);
+    // two of this wave's eight pieces of stage s (pieces [8 wave + 2 g, + 2)); no-op past the end of the stream
+    auto issue2 = [&](int s, int g) {
+        if (s >= nst) return;
+        const unsigned char* src = p.wpack + (size_t)s * CH_STAGE_BYTES + (size_t)(wave * CH_NDMA + 2 * g) * CH_FRAG_BYTES + lane * 16;
+        const unsigned dst = ring_off + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES + (unsigned)(wave * CH_NDMA + 2 * g) * CH_FRAG_BYTES;
+        ch_dma16(src, dst);
+        ch_dma16(src + CH_FRAG_BYTES, dst + CH_FRAG_BYTES);
     };
-    // stage s has landed once at most the next stage's DMA instructions are outstanding on the issuing waves (loads
-    // complete in order; outstanding stores can only make this wait longer, never shorter: see the header)
+    // Stage s has landed once at most the pieces of the stages BEHIND it are outstanding on every wave: 16 (stages s + 1 and
+    // s + 2 were issued during stages s - 2 and s - 1), 8 or 0 near the end of the stream (see the header for why only
+    // DMA pieces are counted).  The barrier also retires stage s - 1's slot, which stage s + 3 is then issued into.
     auto stage_begin = [&](int s) -> const unsigned char* {
-        if (dma_wave) {
-            if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH_NDMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        ch_barrier();                            // everybody's pieces of stage s landed; stage s - 1's slot is retired
-        if (dma_wave && s + 2 < nst) issue(s + 2);
+        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH_NDMA) : "memory");
+        else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH_NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ch_barrier();
         return smem + (s % CH_NRING) * CH_STAGE_BYTES + lane * 16;
     };
 
@@ -325,10 +348,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
     }
     const bool padded = p.row_pad != nullptr && p.row_pad[rowc] != 0;
-    if (dma_wave) {
-        issue(0);
-        if (nst > 1) issue(1);
+    // ---- parameter vectors -> LDS (13 KB; published by the first stage's barrier)
+    {
+        auto stage_vec = [&](const float* src, int off, int n) {
+            for (int i = tid * 4; i < n; i += 256 * 4) *reinterpret_cast<float4*>(par + off + i) = *reinterpret_cast<const float4*>(src + i);
+        };
+        stage_vec(p.bo, CH_P_BO, CH_D); stage_vec(p.ln1_g, CH_P_G1, CH_D); stage_vec(p.ln1_b, CH_P_BE1, CH_D);
+        stage_vec(p.b2, CH_P_B2, CH_D); stage_vec(p.ln2_g, CH_P_G2, CH_D); stage_vec(p.ln2_b, CH_P_BE2, CH_D);
+        stage_vec(p.b1, CH_P_B1, p.F);
+        if (p.qkv != nullptr) stage_vec(p.bqkv, CH_P_BQ, 3 * CH_D);
     }
+#pragma unroll
+    for (int s = 0; s < CH_NRING - 1; ++s)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) issue2(s, g);
 
     f32x16 Z[8];
 #pragma unroll
@@ -340,16 +373,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     int S = 0;
 #pragma unroll
     for (int s = 0; s < CH_WO_STAGES; ++s) {
-        const unsigned char* Fs = stage_begin(S++);
-        ch_stage(Fs, [&](int kq, int j, const bf16x8& a) { Z[j] = CH_MFMA(a, X[4 * s + kq], Z[j]); });
+        const unsigned char* Fs = stage_begin(S);
+        ch_stage(Fs, [&](int kq, int j, const bf16x8& a) { Z[j] = CH_MFMA(a, X[4 * s + kq], Z[j]); },
+                 [&](int g) { issue2(S + CH_NRING - 1, g); });
+        ++S;
     }
-    unsigned char* slot = scr + wave * CH_SLOT_BYTES;              // parity buffer 0 for the per-wave epilogue stores
+    unsigned char* slot = scr + wave * CH_SLOT_BYTES;              // the wave's own transposing scratch
     bf16x8 Y[16];
     {
         bf16x8 R[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) R[q] = X[q];
-        ch_layernorm(Z, R, Y, p, p.bo, p.ln1_g, p.ln1_b, p.site_ln1, row, rowc, row0, padded, slot, lane, p.a_bf, p.xhat1, p.rstd1, nullptr);
+        ch_layernorm(Z, R, Y, p, par + CH_P_BO, par + CH_P_G1, par + CH_P_BE1, p.site_ln1, row, rowc, row0, padded, slot, lane, p.a_bf,
+                     p.xhat1, p.rstd1, nullptr);
     }
 
     // ---- FFN: per 64 hidden features one stage of a . W1 (2 tiles x 16 k-groups) and one of h1 . W2 (4 k-groups x 8 tiles)
@@ -357,21 +393,21 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Z[j][r] = 0.f;
-    const int store_k = wave - CH_NW / 2;                           // storing waves: slots 2k and 2k + 1
     const int nbchunk = p.bits_wide ? p.F / 256 : p.F / 128;
     for (int c = 0; c < p.nchunk; ++c) {
-        const unsigned char* Fs = stage_begin(S++);
+        const unsigned char* Fs = stage_begin(S);
         f32x16 H[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + 64 * c + 32 * u + 8 * g + 4 * hh);
+                const float4 b4 = *reinterpret_cast<const float4*>(par + CH_P_B1 + 64 * c + 32 * u + 8 * g + 4 * hh);
                 H[u][4 * g + 0] = b4.x; H[u][4 * g + 1] = b4.y; H[u][4 * g + 2] = b4.z; H[u][4 * g + 3] = b4.w;
             }
-        ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { H[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], H[i & 1]); });
+        ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { H[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], H[i & 1]); },
+                 [&](int g) { issue2(S + CH_NRING - 1, g); });
+        ++S;
         bf16x8 hf[4];
-        unsigned char* pslot = scr + (c & 1) * CH_SCR_BYTES + wave * CH_SLOT_BYTES;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -382,60 +418,44 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     h[e] = (__bf16)fmaxf(H[u][4 * g + e], 0.f);
                     hf[2 * u + (g >> 1)][4 * (g & 1) + e] = h[e];
                 }
-                ch_slot_write(pslot, l31, hh, u, g, *reinterpret_cast<uint2*>(&h));
+                ch_slot_write(slot, l31, hh, u, g, *reinterpret_cast<uint2*>(&h));
             }
-        Fs = stage_begin(S++);                                      // (its barrier publishes the scratch)
-        if (!dma_wave) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int w = 2 * store_k + t;
-                ch_slot_flush(scr + (c & 1) * CH_SCR_BYTES + w * CH_SLOT_BYTES, p.h1, p.F, 64 * c, m0 + w * 32, p.M, lane, p.relu_bits,
-                              p.bits_wide, nbchunk);
-            }
-        }
-        ch_stage(Fs, [&](int g4, int j, const bf16x8& a) { Z[j] = CH_MFMA(a, hf[g4], Z[j]); });
+        Fs = stage_begin(S);
+        // the wave's h1 chunk leaves now, as early in this stage as possible: these four stores are the oldest thing on
+        // vmcnt by the next stage's counted wait
+        ch_slot_flush(slot, p.h1, p.F, 64 * c, row0, p.M, lane, p.relu_bits, p.bits_wide, nbchunk);
+        ch_stage(Fs, [&](int g4, int j, const bf16x8& a) { Z[j] = CH_MFMA(a, hf[g4], Z[j]); }, [&](int g) { issue2(S + CH_NRING - 1, g); });
+        ++S;
     }
-    // (the scratch buffer the LAST h1 chunk does not use: its flush by the storing waves may still be reading)
-    slot = scr + (p.nchunk & 1) * CH_SCR_BYTES + wave * CH_SLOT_BYTES;
-    ch_layernorm(Z, Y, Y, p, p.b2, p.ln2_g, p.ln2_b, p.site_ln2, row, rowc, row0, padded, slot, lane, p.out_bf, p.xhat2, p.rstd2, p.out32);
+    ch_lds_fence();
+    ch_layernorm(Z, Y, Y, p, par + CH_P_B2, par + CH_P_G2, par + CH_P_BE2, p.site_ln2, row, rowc, row0, padded, slot, lane, p.out_bf, p.xhat2,
+                 p.rstd2, p.out32);
 
     // ---- the next block's qkv projection: 12 stages of (2 output tiles x 16 k-groups)
     if (p.qkv != nullptr) {
         for (int s = 0; s < CH_QKV_STAGES; ++s) {
-            const unsigned char* Fs = stage_begin(S++);
-            if (!dma_wave && s > 0) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int w = 2 * store_k + t;
-                    ch_slot_flush(scr + ((s - 1) & 1) * CH_SCR_BYTES + w * CH_SLOT_BYTES, p.qkv, 3 * CH_D, 64 * (s - 1), m0 + w * 32, p.M,
-                                  lane, nullptr, 0, 0);
-                }
-            }
+            const unsigned char* Fs = stage_begin(S);
+            if (s > 0) ch_slot_flush(slot, p.qkv, 3 * CH_D, 64 * (s - 1), row0, p.M, lane, nullptr, 0, 0);
             f32x16 acc[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(p.bqkv + 64 * s + 32 * u + 8 * g + 4 * hh);
+                    const float4 b4 = *reinterpret_cast<const float4*>(par + CH_P_BQ + 64 * s + 32 * u + 8 * g + 4 * hh);
                     acc[u][4 * g + 0] = b4.x; acc[u][4 * g + 1] = b4.y; acc[u][4 * g + 2] = b4.z; acc[u][4 * g + 3] = b4.w;
                 }
-            ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { acc[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], acc[i & 1]); });
-            unsigned char* pslot = scr + (s & 1) * CH_SCR_BYTES + wave * CH_SLOT_BYTES;
+            ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { acc[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], acc[i & 1]); },
+                     [&](int g) { issue2(S + CH_NRING - 1, g); });
+            ++S;
+            ch_lds_fence();                                        // (the flush above has read the slot)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    ch_slot_write(pslot, l31, hh, u, g, ch_pack4(acc[u][4 * g + 0], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]));
+                    ch_slot_write(slot, l31, hh, u, g, ch_pack4(acc[u][4 * g + 0], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]));
         }
-        ch_barrier();
-        if (!dma_wave) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int w = 2 * store_k + t;
-                ch_slot_flush(scr + ((CH_QKV_STAGES - 1) & 1) * CH_SCR_BYTES + w * CH_SLOT_BYTES, p.qkv, 3 * CH_D, 64 * (CH_QKV_STAGES - 1),
-                              m0 + w * 32, p.M, lane, nullptr, 0, 0);
-            }
-        }
+        ch_lds_fence();
+        ch_slot_flush(slot, p.qkv, 3 * CH_D, 64 * (CH_QKV_STAGES - 1), row0, p.M, lane, nullptr, 0, 0);
     }
 }
 
@@ -499,7 +519,7 @@ int ttsmi_dense_chain_pack(const uint16_t* wo_t, const uint16_t* w1_t, const uin
     return TTSMI_OK;
 }
 
-int ttsmi_dense_chain_supported(int M, int d, int F) { return M > 0 && d == CH_D && F >= 64 && F % 64 == 0; }
+int ttsmi_dense_chain_supported(int M, int d, int F) { return M > 0 && d == CH_D && F >= 64 && F % 64 == 0 && F <= CH_MAXF; }
 
 int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void* wpack, size_t wpack_bytes, int M, int F,
                           const float* bo, const float* ln1_g, const float* ln1_b, const float* b1, const float* b2,
