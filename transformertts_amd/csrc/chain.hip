@@ -79,6 +79,8 @@ struct ChainP {
     uint16_t* h1; uint32_t* relu_bits; int bits_wide;
     uint16_t *out_bf, *xhat2; float* rstd2; float* out32;
     uint16_t* qkv;                   // the next block's [M,768], or NULL
+    int ablate;                      // measurement build only (TTSMI_CHAIN_ABLATE): 1 no multiplies, 2 no DMA, 8 no in-loop stores
+    unsigned long long* dbg;         // measurement build only: per (workgroup, wave) phase stamps, ttsmi_dense_chain_debug
 };
 
 __device__ __forceinline__ void ch_dma16(const void* gsrc, unsigned lds_off) {
@@ -308,10 +310,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int row0 = m0 + wave * 32, row = row0 + l31, rowc = min(row, p.M - 1);
     const int nst = p.nstages;
     const unsigned ring_off = ch_lds_offset(smem);
+#ifdef TTSMI_ABLATION_BUILD
+    unsigned long long tph[8], twait = 0;
+    int nph = 0;
+#define CH_STAMP() tph[nph++] = __builtin_readcyclecounter()
+#else
+#define CH_STAMP()
+#endif
+    CH_STAMP();
+    const int abl = TTSMI_ABLATE_BITS(p.ablate);
 
     // two of this wave's eight pieces of stage s (pieces [8 wave + 2 g, + 2)); no-op past the end of the stream
     auto issue2 = [&](int s, int g) {
-        if (s >= nst) return;
+        if (s >= nst || (abl & 2)) return;
         const unsigned char* src = p.wpack + (size_t)s * CH_STAGE_BYTES + (size_t)(wave * CH_NDMA + 2 * g) * CH_FRAG_BYTES + lane * 16;
         const unsigned dst = ring_off + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES + (unsigned)(wave * CH_NDMA + 2 * g) * CH_FRAG_BYTES;
         ch_dma16(src, dst);
@@ -321,10 +332,16 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // s + 2 were issued during stages s - 2 and s - 1), 8 or 0 near the end of the stream (see the header for why only
     // DMA pieces are counted).  The barrier also retires stage s - 1's slot, which stage s + 3 is then issued into.
     auto stage_begin = [&](int s) -> const unsigned char* {
+#ifdef TTSMI_ABLATION_BUILD
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
         if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH_NDMA) : "memory");
         else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH_NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ch_barrier();
+#ifdef TTSMI_ABLATION_BUILD
+        twait += __builtin_readcyclecounter() - tw0;
+#endif
         return smem + (s % CH_NRING) * CH_STAGE_BYTES + lane * 16;
     };
 
@@ -368,16 +385,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Z[j][r] = 0.f;
+    CH_STAMP();
 
     // ---- o-projection: 8 stages of (4 k-groups x 8 output tiles)
     int S = 0;
 #pragma unroll
     for (int s = 0; s < CH_WO_STAGES; ++s) {
         const unsigned char* Fs = stage_begin(S);
-        ch_stage(Fs, [&](int kq, int j, const bf16x8& a) { Z[j] = CH_MFMA(a, X[4 * s + kq], Z[j]); },
+        ch_stage(Fs, [&](int kq, int j, const bf16x8& a) { if (!(abl & 1)) Z[j] = CH_MFMA(a, X[4 * s + kq], Z[j]); },
                  [&](int g) { issue2(S + CH_NRING - 1, g); });
         ++S;
     }
+    CH_STAMP();
     unsigned char* slot = scr + wave * CH_SLOT_BYTES;              // the wave's own transposing scratch
     bf16x8 Y[16];
     {
@@ -388,6 +407,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                      p.xhat1, p.rstd1, nullptr);
     }
 
+    CH_STAMP();
     // ---- FFN: per 64 hidden features one stage of a . W1 (2 tiles x 16 k-groups) and one of h1 . W2 (4 k-groups x 8 tiles)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -404,7 +424,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 const float4 b4 = *reinterpret_cast<const float4*>(par + CH_P_B1 + 64 * c + 32 * u + 8 * g + 4 * hh);
                 H[u][4 * g + 0] = b4.x; H[u][4 * g + 1] = b4.y; H[u][4 * g + 2] = b4.z; H[u][4 * g + 3] = b4.w;
             }
-        ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { H[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], H[i & 1]); },
+        ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { if (!(abl & 1)) H[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], H[i & 1]); },
                  [&](int g) { issue2(S + CH_NRING - 1, g); });
         ++S;
         bf16x8 hf[4];
@@ -423,19 +443,22 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         Fs = stage_begin(S);
         // the wave's h1 chunk leaves now, as early in this stage as possible: these four stores are the oldest thing on
         // vmcnt by the next stage's counted wait
-        ch_slot_flush(slot, p.h1, p.F, 64 * c, row0, p.M, lane, p.relu_bits, p.bits_wide, nbchunk);
-        ch_stage(Fs, [&](int g4, int j, const bf16x8& a) { Z[j] = CH_MFMA(a, hf[g4], Z[j]); }, [&](int g) { issue2(S + CH_NRING - 1, g); });
+        if (!(abl & 8)) ch_slot_flush(slot, p.h1, p.F, 64 * c, row0, p.M, lane, p.relu_bits, p.bits_wide, nbchunk);
+        ch_stage(Fs, [&](int g4, int j, const bf16x8& a) { if (!(abl & 1)) Z[j] = CH_MFMA(a, hf[g4], Z[j]); },
+                 [&](int g) { issue2(S + CH_NRING - 1, g); });
         ++S;
     }
     ch_lds_fence();
+    CH_STAMP();
     ch_layernorm(Z, Y, Y, p, par + CH_P_B2, par + CH_P_G2, par + CH_P_BE2, p.site_ln2, row, rowc, row0, padded, slot, lane, p.out_bf, p.xhat2,
                  p.rstd2, p.out32);
 
+    CH_STAMP();
     // ---- the next block's qkv projection: 12 stages of (2 output tiles x 16 k-groups)
     if (p.qkv != nullptr) {
         for (int s = 0; s < CH_QKV_STAGES; ++s) {
             const unsigned char* Fs = stage_begin(S);
-            if (s > 0) ch_slot_flush(slot, p.qkv, 3 * CH_D, 64 * (s - 1), row0, p.M, lane, nullptr, 0, 0);
+            if (s > 0 && !(abl & 8)) ch_slot_flush(slot, p.qkv, 3 * CH_D, 64 * (s - 1), row0, p.M, lane, nullptr, 0, 0);
             f32x16 acc[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -444,7 +467,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     const float4 b4 = *reinterpret_cast<const float4*>(par + CH_P_BQ + 64 * s + 32 * u + 8 * g + 4 * hh);
                     acc[u][4 * g + 0] = b4.x; acc[u][4 * g + 1] = b4.y; acc[u][4 * g + 2] = b4.z; acc[u][4 * g + 3] = b4.w;
                 }
-            ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { acc[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], acc[i & 1]); },
+            ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { if (!(abl & 1)) acc[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], acc[i & 1]); },
                      [&](int g) { issue2(S + CH_NRING - 1, g); });
             ++S;
             ch_lds_fence();                                        // (the flush above has read the slot)
@@ -457,6 +480,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         ch_lds_fence();
         ch_slot_flush(slot, p.qkv, 3 * CH_D, 64 * (CH_QKV_STAGES - 1), row0, p.M, lane, nullptr, 0, 0);
     }
+#ifdef TTSMI_ABLATION_BUILD
+    CH_STAMP();
+    if (p.dbg && lane == 0) {              // [workgroup][wave][8]: start, then the six phase durations, then the time in stage waits
+        unsigned long long* o = p.dbg + ((long)blockIdx.x * CH_NW + wave) * 8;
+        o[0] = tph[0];
+        for (int i = 1; i < 7; ++i) o[i] = tph[i] - tph[i - 1];
+        o[7] = twait;
+    }
+#endif
 }
 
 // ---- the weight stream ----------------------------------------------------------------------------------------------
@@ -496,6 +528,11 @@ __global__ __launch_bounds__(256) void dense_chain_pack_kernel(ChainPackP p) {
 }
 
 static int chain_stages(int F, int with_qkv) { return CH_WO_STAGES + 2 * (F / 64) + (with_qkv ? CH_QKV_STAGES : 0); }
+
+#ifdef TTSMI_ABLATION_BUILD
+static unsigned long long* g_chain_dbg = nullptr;
+extern "C" int ttsmi_dense_chain_debug(void* buf) { g_chain_dbg = (unsigned long long*)buf; return 0; }     // [workgroups][4][8] uint64
+#endif
 
 extern "C" {
 
@@ -554,6 +591,11 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
     p.bits_wide = (wide && F % 256 == 0 && (M >= 16384 || wide > 1)) ? 1 : 0;
     if (relu_bits != nullptr && !p.bits_wide) TTSMI_CHECK_ARG(F % 128 == 0, "dense_chain_fwd: the bit matrix needs F %% 128 == 0");
     p.out_bf = out_bf; p.xhat2 = xhat2; p.rstd2 = rstd2; p.out32 = out32; p.qkv = qkv_next;
+#ifdef TTSMI_ABLATION_BUILD
+    TTSMI_ABLATE_KNOB(ablate, "TTSMI_CHAIN_ABLATE");
+    p.ablate = ablate;
+    p.dbg = g_chain_dbg;
+#endif
     ttsmi_note_kernel("dense_chain_kernel");
     TTSMI_LAUNCH_EV(dense_chain_kernel, dim3(ttsmi_cdiv(M, CH_ROWS)), dim3(CH_NW * 64), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("dense_chain_fwd");
