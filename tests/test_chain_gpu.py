@@ -148,7 +148,7 @@ def test_row_local_chain_relu_bit_matrix_through_its_consumer(M):
 
 
 def test_chained_blocks_equal_the_four_launch_blocks_at_the_benchmarked_architecture():
-    """The model with the chain kernel (default) against the same model with TTSMI_DENSE_CHAIN off (chain_blocks=False):
+    """The model with the chain kernel (chain_blocks=True; opt-in) against the same model on the four launches (the default):
     the same arithmetic up to fp32 summation order (which flips bf16 roundings of the stored activations) - the first
     step's loss agrees to 1e-3 (the bf16 path's own distance from fp64 is 5e-4, tests/test_config1_parity_gpu.py), later
     steps - different dropout-free trajectories from there - to 1 %; parameters stay within what four Adam steps can move."""

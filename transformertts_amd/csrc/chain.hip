@@ -23,14 +23,28 @@
 //
 // The weight stream arrives by LDS-DMA (global_load_lds_dwordx4, lane-linear = fragment order: no swizzle, conflict-free
 // ds_read_b128) into a FOUR-stage ring of 32 KB stages: one barrier per stage, three stages in flight.  Every wave issues
-// its quarter of a stage (8 pieces of 1 KB), two pieces behind each group of eight MFMAs: a piece costs its wave 100-185
-// cycles of issue time (MI355X_MICROARCH.md), which eight MFMAs (256 cycles of matrix pipe) cover - the first build gave all
-// 32 pieces of a stage to two waves in one burst and was issue-bound at ~1 us per stage (5.57 ms per step against 4.99).
-// vmcnt counts loads AND stores on gfx950 and stores are not ordered against loads, so the counted wait in front of a stage
-// allows exactly the DMA pieces that are YOUNGER than the stage's own (16, 8 or 0): loads complete in order, outstanding
-// stores can only make that wait longer, never shorter - and with three stages in flight there is slack for them.
-// Bias / gamma / beta vectors are staged in LDS once per workgroup (read from global memory inside the LayerNorm they were
-// 32 dependent load -> wait pairs per pass).
+// its quarter of a stage (8 pieces of 1 KB), two pieces behind each group of eight MFMAs; inside a stage every multiply is
+// followed by the read of the fragment eight multiplies on.  vmcnt counts loads AND stores on gfx950 and stores are not
+// ordered against loads, so the counted wait in front of a stage allows exactly the DMA pieces that are YOUNGER than the
+// stage's own (16, 8 or 0): loads complete in order, outstanding stores can only make that wait longer, never shorter.
+// Bias / gamma / beta vectors are staged in LDS once per workgroup; accumulators start at their bias.
+//
+// STATUS (round 5): correct at every size and tested (tests/test_chain_gpu.py), but NOT faster than the four launches -
+// opt-in, TTSMI_DENSE_CHAIN=1.  Decoder size (28 800 rows, 225 workgroups): 98 us against 107 us for the four launches
+// alone, level inside the train step (5.09 against 5.01 ms); encoder size (50 workgroups) 81 against 57 us: a workgroup's
+// own latency is ~85 us whatever the row count.  What the measurements say (profiles/r05_chain_*.txt,
+// r05_sq_counters_chain_third_build.txt, tools/probes/mfma_lds_overlap_probe.hip):
+//  * the pipeline itself is sound - the probe runs the same stage (32 MFMAs, 32 fragment reads, 8 DMA pieces per wave, one
+//    barrier) at 1 336 cycles against 1 062 for the multiplies alone, one wave per SIMD;
+//  * the kernel's stages take 2 200-2 900 cycles because ONE wave per SIMD hides at most ~5 other instructions behind each
+//    MFMA and the stages carry ~10 per MFMA (bias / ReLU / pack / transposing stores / DMA address arithmetic / AGPR moves:
+//    12 k vector instructions per wave = 28 % of its cycles, nothing overlaps them), and because the 10 k-instruction
+//    (80 KB) body is executed once per workgroup, front to back, through a 64 KB instruction cache: the straight-line phases
+//    (o-projection, both LayerNorms: ~20 k cycles each for ~2.5 k instructions) run at instruction-fetch speed;
+//  * builds: first 175 us (two waves issued all DMA pieces in bursts), second 99.5 us, third (this one) 98 us, a fourth with
+//    the fragment pipeline carried across stage boundaries 108 us (512 registers, spills).
+// What would make it pay: two row groups per workgroup sharing one pass over the weights with loops instead of unrolled
+// phases (half the code, twice the multiplies per fetched fragment), i.e. 256 registers per wave and two waves per SIMD.
 //
 // LDS: 128 KB ring + 18 KB transposing scratch (a slot per wave) + 13 KB parameters = 159 KB; 512 registers per lane (one
 // wave per SIMD).
@@ -112,32 +126,32 @@ __device__ __forceinline__ uint32_t ch_pos_bits(const uint4& v) {
 template <class MF, class DMA>
 __device__ __forceinline__ void ch_stage(const unsigned char* Fs, MF&& mf, DMA&& dma) {
     bf16x8 a0[8], a1[8];
-#define CH_LOAD8(dst, g)                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(Fs + ((g) * 8 + i) * CH_FRAG_BYTES)
-#define CH_MUL8(src, g) \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) mf(g, i, src[i])
-    CH_LOAD8(a0, 0);
-    CH_LOAD8(a1, 1);
+#define CH_FRAG(g, i) (*reinterpret_cast<const bf16x8*>(Fs + ((g) * 8 + (i)) * CH_FRAG_BYTES))
+    // multiply group g from `cur` while group g + 1 is read into `nxt`: one fragment read behind every multiply
+#define CH_GROUP(cur, nxt, g)                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                  \
+        mf(g, i, cur[i]);                                                            \
+        nxt[i] = CH_FRAG((g) + 1, i);                                                \
+    }                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           \
+    }                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    dma(g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a0[i] = CH_FRAG(0, i);
+    CH_GROUP(a0, a1, 0)
+    CH_GROUP(a1, a0, 1)
+    CH_GROUP(a0, a1, 2)
     __builtin_amdgcn_sched_barrier(0);
-    CH_MUL8(a0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    dma(0);                                            // two pieces of the stage three ahead, under the multiplies just issued
-    CH_LOAD8(a0, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    CH_MUL8(a1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    dma(1);
-    CH_LOAD8(a1, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    CH_MUL8(a0, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    dma(2);
-    __builtin_amdgcn_sched_barrier(0);
-    CH_MUL8(a1, 3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mf(3, i, a1[i]);
     __builtin_amdgcn_sched_barrier(0);
     dma(3);
-#undef CH_LOAD8
-#undef CH_MUL8
+#undef CH_GROUP
+#undef CH_FRAG
 }
 
 // ---- transposing stores -------------------------------------------------------------------------------------------
@@ -194,21 +208,22 @@ __device__ __forceinline__ void ch_slot_flush_f32(const unsigned char* slot, flo
 // Z: the product (8 tiles of 32 features); R: the residual as bf16 fragments (fragment 2j + p = registers 8p.. of tile j);
 // on return Y holds LN(keep(Z + bias) + R) * rowmask as bf16 fragments (the next product's B operand and the next
 // residual); y / x^ / rstd (and the fp32 y when asked for) are stored through the wave's own scratch slot.
-// bias / gamma / beta: the workgroup's staged copies in LDS.
-__device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[16], bf16x8 (&Y)[16], const ChainP& p, const float* bias,
+// gamma / beta: the workgroup's staged copies in LDS.
+template <bool Y32>
+__device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[16], bf16x8 (&Y)[16], const ChainP& p,
                                              const float* gamma, const float* beta, uint32_t site, int row, int rowc, int row0, bool padded,
                                              unsigned char* slot, int lane, uint16_t* y_bf, uint16_t* xhat, float* rstd_out, float* y32) {
+    // (Z already holds product + bias: the accumulators were initialised with the bias vector)
     const int l31 = lane & 31, hh = lane >> 5;
     const uint64_t key = p.thr ? ttsmi_drop_key(p.seed, p.step_dev, site) : 0;
     const uint32_t rb = ttsmi_row_base(key, (uint32_t)rowc);
-    float sum = 0.f;
+    float sum4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c0 = 32 * j + 8 * g + 4 * hh;
-            const float4 bs = *reinterpret_cast<const float4*>(bias + c0);
-            float v[4] = {Z[j][4 * g + 0] + bs.x, Z[j][4 * g + 1] + bs.y, Z[j][4 * g + 2] + bs.z, Z[j][4 * g + 3] + bs.w};
+            float v[4] = {Z[j][4 * g + 0], Z[j][4 * g + 1], Z[j][4 * g + 2], Z[j][4 * g + 3]};
             if (p.thr) {
                 const uint32_t h0 = ttsmi_pair_hash(rb, (uint32_t)c0), h1 = ttsmi_pair_hash(rb, (uint32_t)(c0 + 2));
                 v[0] *= ((h0 & 0xFFFFu) >= p.thr) ? p.inv_keep : 0.f;
@@ -221,21 +236,23 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[1
             for (int e = 0; e < 4; ++e) {
                 v[e] += ch_bf(rr, 4 * (g & 1) + e);
                 Z[j][4 * g + e] = v[e];
-                sum += v[e];
+                sum4[e] += v[e];
             }
         }
     const float invC = 1.0f / (float)CH_D;
+    const float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
     const float mean = (sum + __shfl_xor(sum, 32, 64)) * invC;
-    float q = 0.f;
+    float q4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = Z[j][r] - mean;
-            Z[j][r] = v;
-            q += v * v;
+            q4[r & 3] += v * v;
         }
+    const float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     const float rstd = __builtin_amdgcn_rsqf((q + __shfl_xor(q, 32, 64)) * invC + p.eps);
+    const float nmr = -mean * rstd;                              // x^ = v * rstd - mean * rstd
     if (hh == 0 && row < p.M) rstd_out[row] = rstd;
     // normalise and leave, 64 features (two tiles) per round through the wave's scratch slot
 #pragma unroll
@@ -249,14 +266,15 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[1
                 const int c0 = 32 * j + 8 * g + 4 * hh;
                 const float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
                 const float4 bt = *reinterpret_cast<const float4*>(beta + c0);
-                const float xh[4] = {Z[j][4 * g + 0] * rstd, Z[j][4 * g + 1] * rstd, Z[j][4 * g + 2] * rstd, Z[j][4 * g + 3] * rstd};
-                float y[4] = {xh[0] * gm.x + bt.x, xh[1] * gm.y + bt.y, xh[2] * gm.z + bt.z, xh[3] * gm.w + bt.w};
+                const float xh[4] = {fmaf(Z[j][4 * g + 0], rstd, nmr), fmaf(Z[j][4 * g + 1], rstd, nmr), fmaf(Z[j][4 * g + 2], rstd, nmr),
+                                     fmaf(Z[j][4 * g + 3], rstd, nmr)};
+                float y[4] = {fmaf(xh[0], gm.x, bt.x), fmaf(xh[1], gm.y, bt.y), fmaf(xh[2], gm.z, bt.z), fmaf(xh[3], gm.w, bt.w)};
                 if (padded) { y[0] = 0.f; y[1] = 0.f; y[2] = 0.f; y[3] = 0.f; }
                 xh_q[u][g] = ch_pack4(xh[0], xh[1], xh[2], xh[3]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     Y[2 * j + (g >> 1)][4 * (g & 1) + e] = (__bf16)y[e];
-                    Z[j][4 * g + e] = y[e];                       // (kept for the optional fp32 store below)
+                    if constexpr (Y32) Z[j][4 * g + e] = y[e];    // (kept for the fp32 store below)
                 }
             }
         }
@@ -284,7 +302,7 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[1
         ch_lds_fence();
         ch_slot_flush(slot, y_bf, CH_D, 64 * cc, row0, p.M, lane, nullptr, 0, 0);
         ch_lds_fence();
-        if (y32 != nullptr) {                                     // (workgroup-uniform: the stack's last block only)
+        if constexpr (Y32) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int j = 2 * cc + u;
@@ -300,6 +318,18 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[1
     }
 }
 
+// accumulators of a full-row product start at its bias vector (staged in LDS)
+__device__ __forceinline__ void ch_bias_init(f32x16 (&Z)[8], const float* bias, int hh) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + 32 * j + 8 * g + 4 * hh);
+            Z[j][4 * g + 0] = b4.x; Z[j][4 * g + 1] = b4.y; Z[j][4 * g + 2] = b4.z; Z[j][4 * g + 3] = b4.w;
+        }
+}
+
+template <bool Y32>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_chain_kernel(ChainP p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + CH_SCR_BYTES + CH_PAR_FLOATS * 4];
     unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
@@ -345,24 +375,46 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         return smem + (s % CH_NRING) * CH_STAGE_BYTES + lane * 16;
     };
 
-    // ---- the wave's rows of [h | ctx] as B fragments, in the accumulator's k order (k-group q: features 16q + 4hh +
-    // {0..3} and 16q + 8 + 4hh + {0..3}); requested BEFORE the first DMAs, so the counted waits cover them
+    // ---- the wave's 32 rows of [h | ctx] as B fragments in the accumulator's k order (k-group q: features 16q + 4hh +
+    // {0..3} and 16q + 8 + 4hh + {0..3}).  Read with full-line accesses (a wave instruction = 4 rows x 256 bytes) and turned
+    // into fragments through LDS: the wave's quarter of ring slot 3, which its own DMA pieces only reach during stage 0
+    // (8-byte reads straight from the rows were 64 instructions of 32 scattered segments each: 20 k cycles of prologue).
+    // Chunk c (16 bytes) of row r sits at position c ^ (r & 15): conflict-free 8-byte fragment reads.
     bf16x8 X[32];
     {
-        const uint16_t* hrow = p.h_bf + (long)rowc * CH_D + 4 * hh;
-        const uint16_t* crow = p.cx + (long)rowc * CH_D + 4 * hh;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const uint2 lo = *reinterpret_cast<const uint2*>(hrow + 16 * q), hi = *reinterpret_cast<const uint2*>(hrow + 16 * q + 8);
-            const uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            X[q] = *reinterpret_cast<const bf16x8*>(&v);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const uint2 lo = *reinterpret_cast<const uint2*>(crow + 16 * q), hi = *reinterpret_cast<const uint2*>(crow + 16 * q + 8);
-            const uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            X[16 + q] = *reinterpret_cast<const bf16x8*>(&v);
-        }
+        unsigned char* xs = smem + (CH_NRING - 1) * CH_STAGE_BYTES + wave * 8192;
+        const int lr = lane >> 4, lc = lane & 15;
+        // (four named arrays, not raw[4][8]: hipcc 7.2 sent the two-dimensional array to scratch)
+        uint4 raw0[8], raw1[8], raw2[8], raw3[8];
+#define CH_XLOAD(dst, base, half)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                    \
+        const int r = row0 + 4 * i + lr;              /* (a select, not a clamped index: rowgemm.hip's note on hipcc 7.2) */ \
+        dst[i] = r < p.M ? *reinterpret_cast<const uint4*>((base) + (long)r * CH_D + (half) * 128 + lc * 8)             \
+                         : make_uint4(0u, 0u, 0u, 0u);                                                                  \
+    }
+        CH_XLOAD(raw0, p.h_bf, 0)
+        CH_XLOAD(raw1, p.h_bf, 1)
+        CH_XLOAD(raw2, p.cx, 0)
+        CH_XLOAD(raw3, p.cx, 1)
+#undef CH_XLOAD
+#define CH_XFRAGS(src, t)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                    \
+        const int r = 4 * i + lr;                                                                                      \
+        *reinterpret_cast<uint4*>(xs + r * 256 + ((lc ^ (r & 15)) << 4)) = src[i];                                     \
+    }                                                                                                                  \
+    ch_lds_fence();                                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                                    \
+        const uint2 lo = *reinterpret_cast<const uint2*>(xs + l31 * 256 + (((2 * q) ^ (l31 & 15)) << 4) + 8 * hh);     \
+        const uint2 hi = *reinterpret_cast<const uint2*>(xs + l31 * 256 + (((2 * q + 1) ^ (l31 & 15)) << 4) + 8 * hh); \
+        const uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);                                                            \
+        X[8 * (t) + q] = *reinterpret_cast<const bf16x8*>(&v);                                                         \
+    }                                                                                                                  \
+    ch_lds_fence();
+        CH_XFRAGS(raw0, 0)
+        CH_XFRAGS(raw1, 1)
+        CH_XFRAGS(raw2, 2)
+        CH_XFRAGS(raw3, 3)
+#undef CH_XFRAGS
     }
     const bool padded = p.row_pad != nullptr && p.row_pad[rowc] != 0;
     // ---- parameter vectors -> LDS (13 KB; published by the first stage's barrier)
@@ -381,10 +433,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         for (int g = 0; g < 4; ++g) issue2(s, g);
 
     f32x16 Z[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Z[j][r] = 0.f;
     CH_STAMP();
 
     // ---- o-projection: 8 stages of (4 k-groups x 8 output tiles)
@@ -392,6 +440,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
     for (int s = 0; s < CH_WO_STAGES; ++s) {
         const unsigned char* Fs = stage_begin(S);
+        if (s == 0) ch_bias_init(Z, par + CH_P_BO, hh);             // (the staged vectors are published by the first barrier)
         ch_stage(Fs, [&](int kq, int j, const bf16x8& a) { if (!(abl & 1)) Z[j] = CH_MFMA(a, X[4 * s + kq], Z[j]); },
                  [&](int g) { issue2(S + CH_NRING - 1, g); });
         ++S;
@@ -403,16 +452,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         bf16x8 R[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) R[q] = X[q];
-        ch_layernorm(Z, R, Y, p, par + CH_P_BO, par + CH_P_G1, par + CH_P_BE1, p.site_ln1, row, rowc, row0, padded, slot, lane, p.a_bf,
-                     p.xhat1, p.rstd1, nullptr);
+        ch_layernorm<false>(Z, R, Y, p, par + CH_P_G1, par + CH_P_BE1, p.site_ln1, row, rowc, row0, padded, slot, lane, p.a_bf, p.xhat1,
+                            p.rstd1, nullptr);
     }
 
     CH_STAMP();
     // ---- FFN: per 64 hidden features one stage of a . W1 (2 tiles x 16 k-groups) and one of h1 . W2 (4 k-groups x 8 tiles)
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Z[j][r] = 0.f;
+    ch_bias_init(Z, par + CH_P_B2, hh);
     const int nbchunk = p.bits_wide ? p.F / 256 : p.F / 128;
     for (int c = 0; c < p.nchunk; ++c) {
         const unsigned char* Fs = stage_begin(S);
@@ -450,8 +496,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
     ch_lds_fence();
     CH_STAMP();
-    ch_layernorm(Z, Y, Y, p, par + CH_P_B2, par + CH_P_G2, par + CH_P_BE2, p.site_ln2, row, rowc, row0, padded, slot, lane, p.out_bf, p.xhat2,
-                 p.rstd2, p.out32);
+    ch_layernorm<Y32>(Z, Y, Y, p, par + CH_P_G2, par + CH_P_BE2, p.site_ln2, row, rowc, row0, padded, slot, lane, p.out_bf, p.xhat2, p.rstd2,
+                      p.out32);
 
     CH_STAMP();
     // ---- the next block's qkv projection: 12 stages of (2 output tiles x 16 k-groups)
@@ -597,7 +643,8 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
     p.dbg = g_chain_dbg;
 #endif
     ttsmi_note_kernel("dense_chain_kernel");
-    TTSMI_LAUNCH_EV(dense_chain_kernel, dim3(ttsmi_cdiv(M, CH_ROWS)), dim3(CH_NW * 64), 0, (hipStream_t)stream, p);
+    if (out32 != nullptr) TTSMI_LAUNCH_EV(dense_chain_kernel<true>, dim3(ttsmi_cdiv(M, CH_ROWS)), dim3(CH_NW * 64), 0, (hipStream_t)stream, p);
+    else TTSMI_LAUNCH_EV(dense_chain_kernel<false>, dim3(ttsmi_cdiv(M, CH_ROWS)), dim3(CH_NW * 64), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("dense_chain_fwd");
     return TTSMI_OK;
 }

@@ -232,9 +232,10 @@ class ForwardTransformer:
         # bf16 precision, blocks outside the planned path: bf16 qkv / context tensors around the attention kernels
         self._attn_io_bf16 = os.environ.get('TTSMI_ATTN_IO_BF16', '1') != '0'
         self._use_plans, self._plans, self._plan_shared, self._plans_grown = False, {}, {}, {}
-        # the forward's row-local chain of every planned dense block as one launch (csrc/chain.hip); TTSMI_DENSE_CHAIN=0:
-        # the four launches of rounds 2-4
-        self.chain_blocks = bool(kwargs.get('chain_blocks', os.environ.get('TTSMI_DENSE_CHAIN', '1') != '0'))
+        # the forward's row-local chain of every planned dense block as ONE launch (csrc/chain.hip) instead of four: opt-in
+        # (chain_blocks=True / TTSMI_DENSE_CHAIN=1) - correct and tested, but measured level with the four launches at
+        # decoder size and slower at encoder size (round 5: 5.09 against 5.01 ms per step; csrc/chain.hip has the analysis)
+        self.chain_blocks = bool(kwargs.get('chain_blocks', os.environ.get('TTSMI_DENSE_CHAIN', '0') == '1'))
         self._weights_version = 0
         self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}
