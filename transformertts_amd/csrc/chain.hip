@@ -38,11 +38,13 @@
 //    barrier) at 1 336 cycles against 1 062 for the multiplies alone, one wave per SIMD;
 //  * the kernel's stages take 2 200-2 900 cycles because ONE wave per SIMD hides at most ~5 other instructions behind each
 //    MFMA and the stages carry ~10 per MFMA (bias / ReLU / pack / transposing stores / DMA address arithmetic / AGPR moves:
-//    12 k vector instructions per wave = 28 % of its cycles, nothing overlaps them), and because the 10 k-instruction
-//    (80 KB) body is executed once per workgroup, front to back, through a 64 KB instruction cache: the straight-line phases
-//    (o-projection, both LayerNorms: ~20 k cycles each for ~2.5 k instructions) run at instruction-fetch speed;
-//  * builds: first 175 us (two waves issued all DMA pieces in bursts), second 99.5 us, third (this one) 98 us, a fourth with
-//    the fragment pipeline carried across stage boundaries 108 us (512 registers, spills).
+//    12 k vector instructions per wave = 28 % of its cycles, nothing overlaps them); the two LayerNorms cost ~20 k cycles
+//    each (vector arithmetic ~12 k, 32 row-store instructions, 16 LDS round trips of the transposing stores);
+//  * builds: first 175 us (two waves issued all DMA pieces in bursts), second 99.5 us, third 98 us, a fourth with the
+//    fragment pipeline carried across stage boundaries 108 us (512 registers, spills), fifth (this one: ONE copy of the
+//    LayerNorm code in a two-iteration loop, ReLU as v_pk_max_i16, predicate-free stores, paired DMA pieces - 28 % less
+//    code) 101 us: the straight-line phases did not get faster with less code, so it is instruction ISSUE (3 k vector
+//    instructions, 32 store instructions and 16 LDS round trips per LayerNorm, all in one wave), not instruction fetch.
 // What would make it pay: two row groups per workgroup sharing one pass over the weights with loops instead of unrolled
 // phases (half the code, twice the multiplies per fetched fragment), i.e. 256 registers per wave and two waves per SIMD.
 //
@@ -84,7 +86,7 @@ struct ChainP {
     const uint16_t* h_bf;            // [M,256] block input: q_in half of the o-projection AND residual of res-norm 1
     const uint16_t* cx;              // [M,256] attention context
     const unsigned char* wpack;      // ttsmi_dense_chain_pack
-    int M, F, nchunk, nstages;
+    int M, F, nchunk, nstages, nhalf;
     const float *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b, *bqkv;
     const uint8_t* row_pad;
     uint32_t thr; float inv_keep; uint64_t seed; const int64_t* step_dev; uint32_t site_ln1, site_ln2;
@@ -111,6 +113,14 @@ __device__ __forceinline__ uint2 ch_pack4(float a, float b, float c, float d) {
     return *reinterpret_cast<uint2*>(&h);
 }
 __device__ __forceinline__ float ch_bf(const bf16x8& v, int e) { return (float)v[e]; }
+// relu of two packed bf16 values: a negative bf16 is a negative int16 (v_pk_max_i16 against 0; -0.0 becomes +0.0)
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t ch_relu2(uint32_t w) {
+    short2v v = __builtin_bit_cast(short2v, w);
+    const short2v z = {0, 0};
+    v = __builtin_elementwise_max(v, z);
+    return __builtin_bit_cast(uint32_t, v);
+}
 // bit e = bf16 element e of the 8-element group is > 0 (gemm_k256.hip: kw_pos_bits)
 __device__ __forceinline__ uint32_t ch_pos_bits(const uint4& v) {
     auto two = [](uint32_t w) { return (((int32_t)(w << 16) > 0) ? 1u : 0u) | (((int32_t)(w & 0xFFFF0000u) > 0) ? 2u : 0u); };
@@ -165,12 +175,21 @@ __device__ __forceinline__ void ch_slot_flush(const unsigned char* slot, uint16_
                                               uint32_t* bits, int bits_wide, int nbchunk) {
     const int r8 = lane >> 3, c8 = (lane & 7) * 8;
     uint32_t bb[4];
+    uint4 v[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int r = r8 + 8 * it;
-        const uint4 v = *reinterpret_cast<const uint4*>(slot + (r * CH_SLOT_LD + c8) * 2);
-        bb[it] = ch_pos_bits(v);
-        if (row0 + r < M) *reinterpret_cast<uint4*>(dst + (long)(row0 + r) * ld + col0 + c8) = v;
+    for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const uint4*>(slot + ((r8 + 8 * it) * CH_SLOT_LD + c8) * 2);
+    uint16_t* d0 = dst + (long)(row0 + r8) * ld + col0 + c8;
+    if (row0 + 32 <= M) {                              // (wave-uniform: every row of the slot exists - no per-row predicate)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *reinterpret_cast<uint4*>(d0 + (long)(8 * it) * ld) = v[it];
+    } else {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (row0 + r8 + 8 * it < M) *reinterpret_cast<uint4*>(d0 + (long)(8 * it) * ld) = v[it];
+    }
+    if (bits != nullptr) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) bb[it] = ch_pos_bits(v[it]);
     }
     if (bits != nullptr && row0 < M) {
         // (rows of a 64-row tile: R = (row0 & 32) + r8 + 8 it.  tiles past M are never read back: cdiv(M, 64) tiles exist)
@@ -274,7 +293,7 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[1
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     Y[2 * j + (g >> 1)][4 * (g & 1) + e] = (__bf16)y[e];
-                    if constexpr (Y32) Z[j][4 * g + e] = y[e];    // (kept for the fp32 store below)
+                    if constexpr (Y32) Z[j][4 * g + e] = y[e];    // (kept for the fp32 store below; res-norm 1 ignores it)
                 }
             }
         }
@@ -302,7 +321,7 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&Z)[8], const bf16x8 (&R)[1
         ch_lds_fence();
         ch_slot_flush(slot, y_bf, CH_D, 64 * cc, row0, p.M, lane, nullptr, 0, 0);
         ch_lds_fence();
-        if constexpr (Y32) {
+        if (Y32 && y32 != nullptr) {                               // (template: the stack's last block; run time: its res-norm 2)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int j = 2 * cc + u;
@@ -350,13 +369,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     CH_STAMP();
     const int abl = TTSMI_ABLATE_BITS(p.ablate);
 
-    // two of this wave's eight pieces of stage s (pieces [8 wave + 2 g, + 2)); no-op past the end of the stream
+    // two of this wave's eight pieces of stage s (pieces [8 wave + 2 g, + 2)) as one m0 set-up and two instructions (the
+    // instruction offset applies to the global AND the LDS address); no-op past the end of the stream
+    const unsigned char* wsrc = p.wpack + (size_t)wave * CH_NDMA * CH_FRAG_BYTES + lane * 16;
+    const unsigned wdst = ring_off + (unsigned)wave * CH_NDMA * CH_FRAG_BYTES;
     auto issue2 = [&](int s, int g) {
         if (s >= nst || (abl & 2)) return;
-        const unsigned char* src = p.wpack + (size_t)s * CH_STAGE_BYTES + (size_t)(wave * CH_NDMA + 2 * g) * CH_FRAG_BYTES + lane * 16;
-        const unsigned dst = ring_off + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES + (unsigned)(wave * CH_NDMA + 2 * g) * CH_FRAG_BYTES;
-        ch_dma16(src, dst);
-        ch_dma16(src + CH_FRAG_BYTES, dst + CH_FRAG_BYTES);
+        const unsigned char* src = wsrc + (size_t)s * CH_STAGE_BYTES + (g >> 1) * 4096;
+        const unsigned dst = wdst + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES + (g >> 1) * 4096;
+        if (g & 1)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                         ::"v"(src), "s"(dst) : "memory", "m0");
+        else
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+                         ::"v"(src), "s"(dst) : "memory", "m0");
     };
     // Stage s has landed once at most the pieces of the stages BEHIND it are outstanding on every wave: 16 (stages s + 1 and
     // s + 2 were issued during stages s - 2 and s - 1), 8 or 0 near the end of the stream (see the header for why only
@@ -435,71 +461,70 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     f32x16 Z[8];
     CH_STAMP();
 
-    // ---- o-projection: 8 stages of (4 k-groups x 8 output tiles)
+    // ---- two halves, ONE copy of the LayerNorm code (p.nhalf is 2 at run time: the compiler cannot unroll the loop):
+    //   half 0: o-projection, 8 stages of (4 k-groups x 8 output tiles)             -> res-norm 1
+    //   half 1: FFN, per 64 hidden features a stage of a . W1 and one of h1 . W2    -> res-norm 2
+    // Y (the LayerNorm's output fragments = the next products' B operand = the next residual) lives in the registers of the h
+    // half of X: res-norm 1 reads its residual there and overwrites it in place, as res-norm 2 does with a.
     int S = 0;
-#pragma unroll
-    for (int s = 0; s < CH_WO_STAGES; ++s) {
-        const unsigned char* Fs = stage_begin(S);
-        if (s == 0) ch_bias_init(Z, par + CH_P_BO, hh);             // (the staged vectors are published by the first barrier)
-        ch_stage(Fs, [&](int kq, int j, const bf16x8& a) { if (!(abl & 1)) Z[j] = CH_MFMA(a, X[4 * s + kq], Z[j]); },
-                 [&](int g) { issue2(S + CH_NRING - 1, g); });
-        ++S;
-    }
-    CH_STAMP();
     unsigned char* slot = scr + wave * CH_SLOT_BYTES;              // the wave's own transposing scratch
-    bf16x8 Y[16];
-    {
-        bf16x8 R[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) R[q] = X[q];
-        ch_layernorm<false>(Z, R, Y, p, par + CH_P_G1, par + CH_P_BE1, p.site_ln1, row, rowc, row0, padded, slot, lane, p.a_bf, p.xhat1,
-                            p.rstd1, nullptr);
-    }
-
-    CH_STAMP();
-    // ---- FFN: per 64 hidden features one stage of a . W1 (2 tiles x 16 k-groups) and one of h1 . W2 (4 k-groups x 8 tiles)
-    ch_bias_init(Z, par + CH_P_B2, hh);
+    bf16x8(&Y)[16] = *reinterpret_cast<bf16x8(*)[16]>(&X[0]);
     const int nbchunk = p.bits_wide ? p.F / 256 : p.F / 128;
-    for (int c = 0; c < p.nchunk; ++c) {
-        const unsigned char* Fs = stage_begin(S);
-        f32x16 H[2];
+    for (int half = 0; half < p.nhalf; ++half) {
+        if (half == 0) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 b4 = *reinterpret_cast<const float4*>(par + CH_P_B1 + 64 * c + 32 * u + 8 * g + 4 * hh);
-                H[u][4 * g + 0] = b4.x; H[u][4 * g + 1] = b4.y; H[u][4 * g + 2] = b4.z; H[u][4 * g + 3] = b4.w;
+            for (int s = 0; s < CH_WO_STAGES; ++s) {
+                const unsigned char* Fs = stage_begin(S);
+                if (s == 0) ch_bias_init(Z, par + CH_P_BO, hh);     // (the staged vectors are published by the first barrier)
+                ch_stage(Fs, [&](int kq, int j, const bf16x8& a) { if (!(abl & 1)) Z[j] = CH_MFMA(a, X[4 * s + kq], Z[j]); },
+                         [&](int g) { issue2(S + CH_NRING - 1, g); });
+                ++S;
             }
-        ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { if (!(abl & 1)) H[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], H[i & 1]); },
-                 [&](int g) { issue2(S + CH_NRING - 1, g); });
-        ++S;
-        bf16x8 hf[4];
+        } else {
+            ch_bias_init(Z, par + CH_P_B2, hh);
+            for (int c = 0; c < p.nchunk; ++c) {
+                const unsigned char* Fs = stage_begin(S);
+                f32x16 H[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 h;
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(par + CH_P_B1 + 64 * c + 32 * u + 8 * g + 4 * hh);
+                        H[u][4 * g + 0] = b4.x; H[u][4 * g + 1] = b4.y; H[u][4 * g + 2] = b4.z; H[u][4 * g + 3] = b4.w;
+                    }
+                ch_stage(Fs, [&](int q4, int i, const bf16x8& a) { if (!(abl & 1)) H[i & 1] = CH_MFMA(a, Y[q4 * 4 + (i >> 1)], H[i & 1]); },
+                         [&](int g) { issue2(S + CH_NRING - 1, g); });
+                ++S;
+                bf16x8 hf[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    h[e] = (__bf16)fmaxf(H[u][4 * g + e], 0.f);
-                    hf[2 * u + (g >> 1)][4 * (g & 1) + e] = h[e];
-                }
-                ch_slot_write(slot, l31, hh, u, g, *reinterpret_cast<uint2*>(&h));
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 h = ch_pack4(H[u][4 * g + 0], H[u][4 * g + 1], H[u][4 * g + 2], H[u][4 * g + 3]);
+                        h.x = ch_relu2(h.x);
+                        h.y = ch_relu2(h.y);
+                        const bf16x4 hb = *reinterpret_cast<const bf16x4*>(&h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hf[2 * u + (g >> 1)][4 * (g & 1) + e] = hb[e];
+                        ch_slot_write(slot, l31, hh, u, g, h);
+                    }
+                Fs = stage_begin(S);
+                // the wave's h1 chunk leaves now, as early in this stage as possible: these four stores are the oldest thing
+                // on vmcnt by the next stage's counted wait
+                if (!(abl & 8)) ch_slot_flush(slot, p.h1, p.F, 64 * c, row0, p.M, lane, p.relu_bits, p.bits_wide, nbchunk);
+                ch_stage(Fs, [&](int g4, int j, const bf16x8& a) { if (!(abl & 1)) Z[j] = CH_MFMA(a, hf[g4], Z[j]); },
+                         [&](int g) { issue2(S + CH_NRING - 1, g); });
+                ++S;
             }
-        Fs = stage_begin(S);
-        // the wave's h1 chunk leaves now, as early in this stage as possible: these four stores are the oldest thing on
-        // vmcnt by the next stage's counted wait
-        if (!(abl & 8)) ch_slot_flush(slot, p.h1, p.F, 64 * c, row0, p.M, lane, p.relu_bits, p.bits_wide, nbchunk);
-        ch_stage(Fs, [&](int g4, int j, const bf16x8& a) { if (!(abl & 1)) Z[j] = CH_MFMA(a, hf[g4], Z[j]); },
-                 [&](int g) { issue2(S + CH_NRING - 1, g); });
-        ++S;
+            ch_lds_fence();
+        }
+        CH_STAMP();
+        ch_layernorm<Y32>(Z, Y, Y, p, par + (half ? CH_P_G2 : CH_P_G1), par + (half ? CH_P_BE2 : CH_P_BE1), half ? p.site_ln2 : p.site_ln1, row,
+                          rowc, row0, padded, slot, lane, half ? p.out_bf : p.a_bf, half ? p.xhat2 : p.xhat1, half ? p.rstd2 : p.rstd1,
+                          half ? p.out32 : nullptr);
+        CH_STAMP();
     }
-    ch_lds_fence();
-    CH_STAMP();
-    ch_layernorm<Y32>(Z, Y, Y, p, par + CH_P_G2, par + CH_P_BE2, p.site_ln2, row, rowc, row0, padded, slot, lane, p.out_bf, p.xhat2, p.rstd2,
-                      p.out32);
 
-    CH_STAMP();
     // ---- the next block's qkv projection: 12 stages of (2 output tiles x 16 k-groups)
     if (p.qkv != nullptr) {
         for (int s = 0; s < CH_QKV_STAGES; ++s) {
@@ -531,7 +556,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     if (p.dbg && lane == 0) {              // [workgroup][wave][8]: start, then the six phase durations, then the time in stage waits
         unsigned long long* o = p.dbg + ((long)blockIdx.x * CH_NW + wave) * 8;
         o[0] = tph[0];
-        for (int i = 1; i < 7; ++i) o[i] = tph[i] - tph[i - 1];
+        for (int i = 1; i < 7; ++i) o[i] = tph[i] - tph[i - 1];      // prologue, o-projection, LN1, FFN, LN2, qkv
         o[7] = twait;
     }
 #endif
@@ -626,6 +651,7 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
     memset(&p, 0, sizeof(p));
     p.h_bf = h_bf; p.cx = ctx; p.wpack = (const unsigned char*)wpack; p.M = M; p.F = F; p.nchunk = F / 64;
     p.nstages = chain_stages(F, qkv_next != nullptr);
+    p.nhalf = 2;
     p.bo = bo; p.ln1_g = ln1_g; p.ln1_b = ln1_b; p.b1 = b1; p.b2 = b2; p.ln2_g = ln2_g; p.ln2_b = ln2_b; p.bqkv = bqkv_next;
     p.row_pad = row_pad;
     p.thr = p_drop > 0.f ? ttsmi_drop_threshold(p_drop) : 0u;
