@@ -207,7 +207,7 @@ def kernel_family(name, args):
     return KERNEL_OF.get(name, RIDERS)
 
 
-PMC_FILE = 'r04_pmc_hbm_traffic_bf16.json'
+PMC_FILE = 'r05_pmc_hbm_traffic_bf16.json'
 PMC_KERNELS = {       # kernel family -> (rocprof names of its kernels, names of helper kernels of the same entry point)
     KERNEL_OF['ttsmi_hgemm_tn']: (['gemm_bf16_kernel', 'gemm_bf16_dma_kernel', 'gemm_bf16_deep_kernel', 'gemm_k256_kernel'], []),
     ROWGEMM: (['rowgemm_dma_kernel', 'rowgemm_kernel'], []),
@@ -384,6 +384,9 @@ def cpu_baseline(cfg, shape, threads):
         n += 1
     dt = (time.perf_counter() - t0) / n
     return {'value': Bs * shape['Tm'] / dt, 'unit': 'mel-frames/s', 'cores': threads, 'kind': 'port',
+            # a bounded SAMPLE of the workload (SURVEY 8d names 1 + 3 steps at B = 32: ~40 s of CPU per step count here would
+            # take the default run past a minute of CPU legs): samples are independent, so frames/s of B = 4 is the rate
+            'sample_batch': Bs, 'headline_batch': shape['B'],
             'sample': f'B={Bs} samples of the same {shape["Tp"]}-phoneme/{shape["Tm"]}-frame workload, '
                       f'1 warm-up + {n} timed train steps ({n * dt:.1f} s), torch-CPU fp32 restatement of the TF2 '
                       f'graph (TF2 unavailable offline), {threads} threads, {dt:.2f} s/step; like the reference it '

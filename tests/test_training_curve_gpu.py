@@ -36,6 +36,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 STEPS, BLOCK = 300, 50
 LR = float(os.environ.get('TTSMI_CURVE_LR', '1e-4'))          # (measurement knob: the curve at another learning rate)
+BATCH = int(os.environ.get('TTSMI_CURVE_BATCH', '8'))         # (measurement knob: 32 = the benchmarked batch, profiles/r05_bf16_vs_f32_curve_b32.json)
 
 
 def _curve(precision, cfg, W, batch):
@@ -57,7 +58,7 @@ def test_bf16_training_curve_tracks_fp32_over_300_steps():
     from transformertts_amd.utils.synthetic import learnable_batch
     cfg = dict(fo.make_config(), dropout_rate=0.0, predictors_dropout=0.0)
     W = fo.init_weights(cfg, seed=5)
-    batch = learnable_batch(8, 200, 900, seed=77)
+    batch = learnable_batch(BATCH, 200, 900, seed=77)
     f32 = _curve('f32', cfg, W, batch)
     bf16 = _curve('bf16', cfg, W, batch)
     rng = np.random.default_rng(1)
@@ -69,7 +70,7 @@ def test_bf16_training_curve_tracks_fp32_over_300_steps():
     floor = np.abs(bp - bf) / bf
     mean_rel = abs(bf16[BLOCK:].mean() - f32[BLOCK:].mean()) / f32[BLOCK:].mean()
     mean_floor = abs(f32p[BLOCK:].mean() - f32[BLOCK:].mean()) / f32[BLOCK:].mean()
-    line = {'steps': STEPS, 'block': BLOCK, 'lr': LR, 'f32_block_means': bf.tolist(), 'bf16_block_means': bb.tolist(),
+    line = {'steps': STEPS, 'block': BLOCK, 'lr': LR, 'batch': BATCH, 'f32_block_means': bf.tolist(), 'bf16_block_means': bb.tolist(),
             'f32_perturbed_block_means': bp.tolist(), 'bf16_vs_f32': rel.tolist(), 'f32_perturbed_vs_f32': floor.tolist(),
             'mean_loss_steps_50_299': {'f32': float(f32[BLOCK:].mean()), 'bf16': float(bf16[BLOCK:].mean()),
                                        'f32_perturbed': float(f32p[BLOCK:].mean()), 'bf16_vs_f32': mean_rel,
@@ -78,7 +79,7 @@ def test_bf16_training_curve_tracks_fp32_over_300_steps():
     print('\nbf16 vs f32 training curve', json.dumps(line))
     d = os.path.join(os.path.dirname(HERE), 'gpurun_out')
     if os.path.isdir(d):
-        with open(os.path.join(d, 'bf16_vs_f32_curve.json'), 'w') as f:
+        with open(os.path.join(d, 'bf16_vs_f32_curve.json' if BATCH == 8 else f'bf16_vs_f32_curve_b{BATCH}.json'), 'w') as f:
             json.dump(dict(line, f32_curve=f32.tolist(), bf16_curve=bf16.tolist(), f32_perturbed_curve=f32p.tolist()), f)
     for c in (f32, bf16, f32p):
         assert np.isfinite(c).all()
