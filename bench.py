@@ -504,7 +504,7 @@ def predict_cpu_baseline(cfg, Tp, threads, seconds=10.0):
                       f'materialised as the reference returns them), torch-CPU fp32 restatement, {threads} threads'}
 
 
-MEL_PMC_FILE = 'r04_pmc_hbm_traffic_mel.json'
+MEL_PMC_FILE = 'r05_pmc_hbm_traffic_mel.json'
 
 
 def _mel_cpu_clip(args):
