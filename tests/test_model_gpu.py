@@ -773,3 +773,46 @@ def test_bench_instrumented_step_runs_on_the_planned_path(tiny):
     groups = bench.group_records(bench.instrumented_step(lambda: m.train_step(*batch)))
     assert any('attention' in k for k in groups) and sum(v[0] for v in groups.values()) > 40
     assert all(np.isfinite(v[3]) and v[3] >= 0 for v in groups.values())
+
+
+def test_train_step_attention_maps_live_in_a_ring_of_two_buffer_sets(tiny):
+    """reference_outputs=True: train_step returns the 12 attention maps like the reference's _train_step
+    (model/models.py:544-549).  They are written into a ring of MAP_RING_DEPTH persistent buffer sets per block and shape
+    (2.7 GB of fresh tensors per step at the benchmark shape otherwise): a step's maps stay intact while the NEXT step runs,
+    the step after that reuses their storage, and they are what call() returns for the same weights, dropout off;
+    map_ring=False hands out fresh tensors."""
+    cfg, W = tiny
+    batch = fo.synthetic_batch(3, 40, 150, seed=5, ragged=True)
+    for prec in ('f32', 'bf16'):
+        m = _model(cfg, W, precision=prec, reference_outputs=True, dropout_rate=0.0, predictors_dropout=0.0)
+        m._compile(learning_rate=1e-3)
+        dev = [torch.from_numpy(np.asarray(a)).cuda() for a in batch]
+        with torch.no_grad():
+            want = m.call(dev[0], dev[2][..., None], target_pitch=dev[3][..., None], training=False, mel_len=int(dev[1].shape[1]),
+                          return_attention=True)
+        want = {k: v.clone() for k, v in list(want['encoder_attention'].items()) + list(want['decoder_attention'].items())}
+        o1 = m.train_step(*dev)
+        maps1 = dict(list(o1['encoder_attention'].items()) + list(o1['decoder_attention'].items()))
+        assert len(maps1) == len(cfg['encoder_num_heads']) + len(cfg['decoder_num_heads'])
+        snap = {k: v.clone() for k, v in maps1.items()}
+        for k, v in maps1.items():                                # the same weights, no dropout: the forward's maps
+            torch.testing.assert_close(v, want[k], rtol=0, atol=1e-5 if prec == 'f32' else 2e-2)
+            rows = v.sum(-1)
+            assert float((rows - 1).abs().max()) < 1e-3
+        o2 = m.train_step(*dev)
+        maps2 = dict(list(o2['encoder_attention'].items()) + list(o2['decoder_attention'].items()))
+        torch.cuda.synchronize()
+        for k in maps1:
+            assert maps1[k].data_ptr() != maps2[k].data_ptr()
+            assert torch.equal(maps1[k], snap[k]), k              # step 2 did not touch step 1's maps
+        o3 = m.train_step(*dev)
+        maps3 = dict(list(o3['encoder_attention'].items()) + list(o3['decoder_attention'].items()))
+        assert all(maps3[k].data_ptr() == maps1[k].data_ptr() for k in maps1)      # the ring wraps after two steps
+        fresh = _model(cfg, W, precision=prec, reference_outputs=True, map_ring=False, dropout_rate=0.0, predictors_dropout=0.0)
+        fresh._compile(learning_rate=1e-3)
+        a = fresh.train_step(*dev)
+        b = fresh.train_step(*dev)
+        c = fresh.train_step(*dev)
+        ka = next(iter(a['decoder_attention']))
+        assert len({a['decoder_attention'][ka].data_ptr(), b['decoder_attention'][ka].data_ptr(), c['decoder_attention'][ka].data_ptr()}) == 3
+        torch.testing.assert_close(a['decoder_attention'][ka], snap[ka], rtol=0, atol=1e-6 if prec == 'f32' else 1e-3)
