@@ -81,7 +81,7 @@ def _run_chain(M, F, pdrop, with_qkv, with_out32, with_bits, seed0=0):
                                   _p(out['h1']), _p(out['bits']), _p(out['o']), _p(out['xh2']), _p(out['rstd2']), _p(out['o32']),
                                   _p(out['qkv']), _stream()), 'chain')
     torch.cuda.synchronize()
-    assert l.ttsmi_last_kernel().decode() == 'dense_chain_kernel'
+    assert l.ttsmi_last_kernel().decode() == ('dense_chain_kernel' if os.environ.get('TTSMI_DENSE_CHAIN_FORM') == '32' else 'dense_chain16_kernel')
     inv = 1.0 / (1.0 - float(np.float32(pdrop))) if pdrop > 0 else 1.0
     live = (pad == 0)
     rows, cols = np.arange(M), np.arange(D)
@@ -147,15 +147,17 @@ def test_row_local_chain_relu_bit_matrix_through_its_consumer(M):
     assert bool((got[big] != 0).all())
 
 
-def test_chained_blocks_equal_the_four_launch_blocks_at_the_benchmarked_architecture():
-    """The model with the chain kernel (chain_blocks=True; opt-in) against the same model on the four launches (the default):
+def test_chained_blocks_equal_the_four_launch_blocks_at_the_benchmarked_architecture(monkeypatch):
+    """The model with the chain kernel (chain_blocks=True, here at every row count) against the same model on the four launches:
     the same arithmetic up to fp32 summation order (which flips bf16 roundings of the stored activations) - the first
     step's loss agrees to 1e-3 (the bf16 path's own distance from fp64 is 5e-4, tests/test_config1_parity_gpu.py), later
     steps - different dropout-free trajectories from there - to 1 %; parameters stay within what four Adam steps can move."""
     from oracle import ft_oracle as fo
     from transformertts_amd.model.models import ForwardTransformer
+    from transformertts_amd import ops
     cfg = dict(fo.make_config(), dropout_rate=0.1, predictors_dropout=0.1, seed=3, precision='bf16')
     batch = fo.synthetic_batch(4, 120, 500, seed=21, ragged=True)
+    monkeypatch.setattr(ops, 'CHAIN_MIN_ROWS', 0)             # (the default only switches it on from decoder-size batches)
     losses = {}
     params = {}
     for chain in (True, False):

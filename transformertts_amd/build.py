@@ -42,14 +42,14 @@ def library_digest() -> str:
     """One digest of everything libttsmi.so is compiled from (every source, the shared headers, the flags): measurement
     files that describe the kernels of a particular build (profiles/*_pmc_hbm_traffic_*.json) are stamped with it, and
     bench.py reports `traffic: null` when the stamp is not the digest of the tree it runs from."""
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fft512.h'), os.path.join(HERE, '..', 'include', 'ttsmi.h')]
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fft512.h'), os.path.join(CSRC, 'chain16.h'), os.path.join(HERE, '..', 'include', 'ttsmi.h')]
     return _digest([os.path.join(CSRC, s) for s in SOURCES] + headers)[:16]
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fft512.h'), os.path.join(HERE, '..', 'include', 'ttsmi.h')]
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fft512.h'), os.path.join(CSRC, 'chain16.h'), os.path.join(HERE, '..', 'include', 'ttsmi.h')]
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:

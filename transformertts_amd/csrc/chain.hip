@@ -598,6 +598,15 @@ __global__ __launch_bounds__(256) void dense_chain_pack_kernel(ChainPackP p) {
     *reinterpret_cast<uint4*>(p.out + idx * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
+#include "chain16.h"
+
+// which form of the kernel (and of its weight stream) this process uses: TTSMI_DENSE_CHAIN_FORM = 16 (eight 16-row waves on
+// 16x16x32 MFMAs, two waves per SIMD) or 32 (four 32-row waves on 32x32x16, one wave per SIMD); read once
+static int chain_form() {
+    TTSMI_KNOB(form, "TTSMI_DENSE_CHAIN_FORM", 16);
+    return form == 32 ? 32 : 16;
+}
+
 static int chain_stages(int F, int with_qkv) { return CH_WO_STAGES + 2 * (F / 64) + (with_qkv ? CH_QKV_STAGES : 0); }
 
 #ifdef TTSMI_ABLATION_BUILD
@@ -622,7 +631,8 @@ int ttsmi_dense_chain_pack(const uint16_t* wo_t, const uint16_t* w1_t, const uin
     p.wo_t = wo_t; p.w1_t = w1_t; p.w2_t = w2_t; p.wqkv_t = wqkv_next_t; p.out = (uint16_t*)out;
     p.F = F; p.nchunk = F / 64; p.nstages = chain_stages(F, wqkv_next_t != nullptr);
     const long total = (long)p.nstages * CH_STAGE_FRAGS * 64;
-    hipLaunchKernelGGL(dense_chain_pack_kernel, dim3(ttsmi_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    if (chain_form() == 16) hipLaunchKernelGGL(dense_chain16_pack_kernel, dim3(ttsmi_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(dense_chain_pack_kernel, dim3(ttsmi_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("dense_chain_pack");
     return TTSMI_OK;
 }
@@ -668,6 +678,13 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
     p.ablate = ablate;
     p.dbg = g_chain_dbg;
 #endif
+    if (chain_form() == 16) {
+        ttsmi_note_kernel("dense_chain16_kernel");
+        if (out32 != nullptr) TTSMI_LAUNCH_EV(dense_chain16_kernel<true>, dim3(ttsmi_cdiv(M, C16_ROWS)), dim3(C16_NW * 64), 0, (hipStream_t)stream, p);
+        else TTSMI_LAUNCH_EV(dense_chain16_kernel<false>, dim3(ttsmi_cdiv(M, C16_ROWS)), dim3(C16_NW * 64), 0, (hipStream_t)stream, p);
+        TTSMI_CHECK_LAUNCH("dense_chain_fwd");
+        return TTSMI_OK;
+    }
     ttsmi_note_kernel("dense_chain_kernel");
     if (out32 != nullptr) TTSMI_LAUNCH_EV(dense_chain_kernel<true>, dim3(ttsmi_cdiv(M, CH_ROWS)), dim3(CH_NW * 64), 0, (hipStream_t)stream, p);
     else TTSMI_LAUNCH_EV(dense_chain_kernel<false>, dim3(ttsmi_cdiv(M, CH_ROWS)), dim3(CH_NW * 64), 0, (hipStream_t)stream, p);

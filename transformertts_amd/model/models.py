@@ -232,10 +232,11 @@ class ForwardTransformer:
         # bf16 precision, blocks outside the planned path: bf16 qkv / context tensors around the attention kernels
         self._attn_io_bf16 = os.environ.get('TTSMI_ATTN_IO_BF16', '1') != '0'
         self._use_plans, self._plans, self._plan_shared, self._plans_grown = False, {}, {}, {}
-        # the forward's row-local chain of every planned dense block as ONE launch (csrc/chain.hip) instead of four: opt-in
-        # (chain_blocks=True / TTSMI_DENSE_CHAIN=1) - correct and tested, but measured level with the four launches at
-        # decoder size and slower at encoder size (round 5: 5.09 against 5.01 ms per step; csrc/chain.hip has the analysis)
-        self.chain_blocks = bool(kwargs.get('chain_blocks', os.environ.get('TTSMI_DENSE_CHAIN', '0') == '1'))
+        # the forward's row-local chain of every planned dense block (o-projection + res-norm 1 -> FFN -> res-norm 2 -> the next
+        # block's qkv projection) as ONE launch (csrc/chain.hip, chain16.h) instead of four, from ops.CHAIN_MIN_ROWS rows on
+        # (decoder-size batches: 4.88 against 5.00 ms per step, round 5); chain_blocks=False / TTSMI_DENSE_CHAIN=0: always
+        # the four launches
+        self.chain_blocks = bool(kwargs.get('chain_blocks', os.environ.get('TTSMI_DENSE_CHAIN', '1') != '0'))
         self._weights_version = 0
         self._block_cache: Dict[str, tuple] = {}
         self._graphs: Dict[tuple, dict] = {}

@@ -1762,6 +1762,9 @@ _CONV_WGRAD_TAPS = os.environ.get('TTSMI_CONV_WGRAD_TAPS', '1') != '0'     # A/B
 FUSE_LN_MIN_ROWS_INFERENCE = int(os.environ.get('TTSMI_FUSE_LN_MIN_ROWS', '8192'))
 
 
+CHAIN_MIN_ROWS = int(os.environ.get('TTSMI_DENSE_CHAIN_MIN_ROWS', '16384'))      # rows from which the chain kernel replaces the four launches
+
+
 class DenseBlockPlan:
     """Persistent buffers + the filled `ttsmi_dense_block` descriptor of ONE dense block, sized for a CAPACITY of rows.
 
@@ -1979,8 +1982,10 @@ class DenseBlockPlan:
         D.dropmask = _p(dmask)
         D.main_stream = _stream()
         self.keep = (pad, klen, dmask)                    # alive until the next bind
-        # the row-local chain needs the bf16 residual stream; the link to the next block follows it
-        self.chain_on = self.chain and self.res16
+        # the row-local chain needs the bf16 residual stream, and pays from decoder-size batches on (measured, 16-row form:
+        # 85.7 us against 104.7 for the four launches at 28 800 rows, level at 12 000, 66 against 57 at 6 400 - a workgroup
+        # takes ~60 us whatever the row count); the link to the next block follows it
+        self.chain_on = self.chain and self.res16 and self.M >= CHAIN_MIN_ROWS
         nxt = self.chain_next if self.chain_on else None
         D.chain_w = self.t['chain_w'].data_ptr() if self.chain_on else None
         D.chain_w_bytes = self.t['chain_w'].numel() if self.chain_on else 0
