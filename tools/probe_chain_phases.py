@@ -25,7 +25,8 @@ check(l.ttsmi_dense_chain_pack(_p(sh['wo'].wt), _p(sh['w1'].wt), _p(sh['w2'].wt)
 e = lambda *s, dt=torch.bfloat16: torch.empty(s, dtype=dt, device=DEV)
 a, xh1, r1, h1, o, xh2, r2, qkv = e(M, D), e(M, D), e(M, dt=torch.float32), e(M, F), e(M, D), e(M, D), e(M, dt=torch.float32), e(M, 3 * D)
 nwg = (M + 127) // 128
-dbg = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=DEV)
+NWV = 4 if os.environ.get('TTSMI_DENSE_CHAIN_FORM') == '32' else 8      # waves per workgroup of the form in use
+dbg = torch.zeros(nwg * NWV * 8, dtype=torch.int64, device=DEV)
 if hasattr(l._cdll, 'ttsmi_dense_chain_debug'):
     l._cdll.ttsmi_dense_chain_debug(ctypes.c_void_p(dbg.data_ptr()))
 
@@ -45,7 +46,7 @@ for _ in range(20):
     chain()
 e1.record()
 torch.cuda.synchronize()
-d = dbg.cpu().reshape(nwg, 4, 8).double()
+d = dbg.cpu().reshape(nwg, NWV, 8).double()
 names = ['prologue (X / parameter loads, first DMAs)', 'o-projection (8 stages)', 'LayerNorm 1 + stores', 'FFN (32 stages)', 'LayerNorm 2 + stores',
          'qkv (12 stages)']
 print(f'M={M} TTSMI_CHAIN_ABLATE={os.environ.get("TTSMI_CHAIN_ABLATE", "0")}: {1e3 * e0.elapsed_time(e1) / 20:.1f} us per launch')
@@ -54,4 +55,4 @@ print(f'  cycles per wave: mean {tot.mean():.0f}  max {tot.max():.0f}   (in stag
 for i, n in enumerate(names):
     print(f'  {n:45s} mean {d[:, :, 1 + i].mean():8.0f}  max {d[:, :, 1 + i].max():8.0f}')
 start = d[:, :, 0]
-print(f'  workgroup start spread: {start.max() - start.min():.0f} cycles; per-wave means of total: {[round(float(tot[:, w].mean())) for w in range(4)]}')
+print(f'  workgroup start spread: {start.max() - start.min():.0f} cycles; per-wave means of total: {[round(float(tot[:, w].mean())) for w in range(NWV)]}')

@@ -219,6 +219,14 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int row0 = m0 + wave * 16, row = row0 + t, rowc = min(row, p.M - 1);
     const int nst = p.nstages;
     const unsigned ring_off = ch_lds_offset(smem);
+#ifdef TTSMI_ABLATION_BUILD
+    unsigned long long tph[8], twait = 0;
+    int nph = 0;
+#define C16_STAMP() tph[nph++] = __builtin_readcyclecounter()
+#else
+#define C16_STAMP()
+#endif
+    C16_STAMP();
 
     // two of this wave's four pieces of stage s (one m0 set-up, instruction offsets on both addresses)
     const unsigned char* wsrc = p.wpack + (size_t)wave * C16_NDMA * CH_FRAG_BYTES + lane * 16;
@@ -236,10 +244,16 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     };
     // stage s has landed once at most the pieces of the two stages behind it are outstanding on every wave (chain.hip)
     auto stage_begin = [&](int s) -> const unsigned char* {
+#ifdef TTSMI_ABLATION_BUILD
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
         if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C16_NDMA) : "memory");
         else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C16_NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ch_barrier();
+#ifdef TTSMI_ABLATION_BUILD
+        twait += __builtin_readcyclecounter() - tw0;
+#endif
         return smem + (s % CH_NRING) * CH_STAGE_BYTES + lane * 16;
     };
 
@@ -299,6 +313,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     f32x4v Z[16];
     int S = 0;
+    C16_STAMP();
     unsigned char* slot = scr + wave * C16_SLOT_BYTES;
     bf16x8(&Y)[8] = XH;
     const int nbchunk = p.bits_wide ? p.F / 256 : p.F / 128;
@@ -349,9 +364,11 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             ch_lds_fence();
         }
+        C16_STAMP();
         c16_layernorm<Y32>(Z, Y, Y, p, par + (half ? CH_P_G2 : CH_P_G1), par + (half ? CH_P_BE2 : CH_P_BE1), half ? p.site_ln2 : p.site_ln1, row,
                            rowc, row0, padded, slot, lane, half ? p.out_bf : p.a_bf, half ? p.xhat2 : p.xhat1, half ? p.rstd2 : p.rstd1,
                            half ? p.out32 : nullptr);
+        C16_STAMP();
     }
 
     // the next block's qkv projection: 12 stages of (4 output tiles x 8 k-blocks)
@@ -375,6 +392,15 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         ch_lds_fence();
         c16_slot_flush(slot, p.qkv, 3 * CH_D, 64 * (CH_QKV_STAGES - 1), row0, p.M, lane, nullptr, 0, 0);
     }
+#ifdef TTSMI_ABLATION_BUILD
+    C16_STAMP();
+    if (p.dbg && lane == 0) {              // [workgroup][wave][8]: start, prologue, o-projection, LN1, FFN, LN2, qkv, time in stage waits
+        unsigned long long* o = p.dbg + ((long)blockIdx.x * C16_NW + wave) * 8;
+        o[0] = tph[0];
+        for (int i = 1; i < 7; ++i) o[i] = tph[i] - tph[i - 1];
+        o[7] = twait;
+    }
+#endif
 }
 
 // the weight stream of this form: fragment = 16 output features x one 32-wide k-block, slot (kg, e) = k 16 (e >> 2) + 4 kg + (e & 3)

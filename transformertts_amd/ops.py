@@ -1805,7 +1805,7 @@ class DenseBlockPlan:
                                                                                         name in ('o', 'f'))
             t[name] = e((8,) if unused else shape, dt)
         # the row-local chain kernel and its weight stream (repacked whenever the weights change: ensure_packed)
-        self.chain = bool(chain) and self.want_fuse and self.backward and bool(l.ttsmi_dense_chain_supported(cap, d, F))
+        self.chain = bool(chain) and self.want_fuse and bool(l.ttsmi_dense_chain_supported(cap, d, F))     # (training and forward-only plans)
         self.S = S
         self.chain_next, self.packed_ver, self.chain_on = None, None, False
         if self.chain:
