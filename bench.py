@@ -193,10 +193,10 @@ SIDE = ' [side stream]'
 HATTN_FWD = 'hattn_fwd_kernel (bf16 MFMA flash attention forward)'
 HATTN_BWD = 'hattn_bwd_fused_kernel | hattn_bwd_dq_kernel + hattn_bwd_dkv_kernel (bf16 MFMA flash attention backward)'
 ROWGEMM = 'rowgemm_dma_kernel / rowgemm_kernel (full-row GEMM + fused LayerNorm forward / backward, bf16 MFMA)'
-CHAIN = 'dense_chain16_kernel / dense_chain_kernel (row-local chain of a dense block: o-projection + res-norm 1 + FFN + res-norm 2 + next qkv in one launch, bf16 MFMA)'
+CHAIN = 'dense_chain16_kernel / dense_chain_kernel (row-local chain of a dense block: o-projection + res-norm 1 + FFN + res-norm 2 + next qkv in one launch - and its backward between the two res-norms, bf16 MFMA)'
 # launch groups announced by the C++ block launcher (ttsmi_set_launch_observer) -> kernel family
 OBSERVED = {'ttsmi_hgemm_tn': KERNEL_OF['ttsmi_hgemm_tn'], 'ttsmi_hgemm_ln_fwd': ROWGEMM, 'ttsmi_hgemm_ln_bwd': ROWGEMM,
-            'ttsmi_attention_fwd': HATTN_FWD, 'ttsmi_attention_bwd': HATTN_BWD, 'ttsmi_dense_chain_fwd': CHAIN,
+            'ttsmi_attention_fwd': HATTN_FWD, 'ttsmi_attention_bwd': HATTN_BWD, 'ttsmi_dense_chain_fwd': CHAIN, 'ttsmi_dense_chain_bwd': CHAIN,
             'ttsmi_hgemm_wgrad_rows': KERNEL_OF['ttsmi_hgemm_wgrad_rows']}
 
 
@@ -212,7 +212,7 @@ PMC_FILE = 'r05_pmc_hbm_traffic_bf16.json'
 PMC_KERNELS = {       # kernel family -> (rocprof names of its kernels, names of helper kernels of the same entry point)
     KERNEL_OF['ttsmi_hgemm_tn']: (['gemm_bf16_kernel', 'gemm_bf16_dma_kernel', 'gemm_bf16_deep_kernel', 'gemm_k256_kernel'], []),
     ROWGEMM: (['rowgemm_dma_kernel', 'rowgemm_kernel'], []),
-    CHAIN: (['dense_chain16_kernel', 'dense_chain_kernel'], ['dense_chain16_pack_kernel', 'dense_chain_pack_kernel']),
+    CHAIN: (['dense_chain16_kernel', 'dense_chain16_bwd_kernel', 'dense_chain_kernel'], ['dense_chain16_pack_kernel', 'dense_chain_pack_kernel']),
     KERNEL_OF['ttsmi_hgemm_wgrad_rows']: (['wgrad_rows_kernel', 'wgrad_dma_kernel'], ['hsplit_reduce']),
     HATTN_FWD: (['hattn_fwd_kernel'], []),
     HATTN_BWD: (['hattn_bwd_dq_kernel', 'hattn_bwd_fused_kernel'], ['hattn_bwd_dkv_kernel']),

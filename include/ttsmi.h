@@ -36,11 +36,11 @@ extern "C" {
 #endif
 
 /* Bumped whenever an entry point's argument list or the ttsmi_dense_block layout changes (101: round 3's `denom` argument of
- * ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102: round 4; 103: ttsmi_mel_nnls added; 104: the shifted-rows taps of the conv weight gradient; 105: round 5 - ttsmi_dense_chain_* and the chain tail of ttsmi_dense_block;
+ * ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102: round 4; 103: ttsmi_mel_nnls added; 104: the shifted-rows taps of the conv weight gradient; 105: round 5 - ttsmi_dense_chain_* and the chain tail of ttsmi_dense_block; 106: the backward chain (ttsmi_dense_chain_bwd*, chain_bw, relu_bits_layout);
  * (104 continued:) the shifted-rows taps of
  * ttsmi_hgemm_wgrad_rows, which the conv stacks of the host mirror now call).  Bindings check it at load
  * time (transformertts_amd/_lib.py) so that a stale build is refused instead of being called with shifted arguments. */
-#define TTSMI_VERSION 105
+#define TTSMI_VERSION 106
 
 enum {
     TTSMI_OK = 0,
@@ -598,6 +598,12 @@ typedef struct ttsmi_dense_block {
     const struct ttsmi_dense_block* above;
     int32_t qkv_done;
     int32_t chain_pad_;
+    /* the backward chain (ttsmi_dense_chain_bwd): with chain_bw set (chain_w required; the forward then writes relu_bits in the
+     * backward chain's lane layout, so relu_bits must hold ttsmi_dense_chain_bits_bytes(B * T, F)) the FFN2 dgrad, the FFN1
+     * dgrad + res-norm 1 backward and the dctx product of ttsmi_dense_block_bwd run as ONE launch on the weight stream
+     * chain_bw (ttsmi_dense_chain_bwd_pack of w1_b / w2_b / wo_b). */
+    const void* chain_bw;
+    uint64_t chain_bw_bytes;
 } ttsmi_dense_block;
 /* ---------------------------------------------------------------------------------------------
  * Batch data parallelism for a binding WITHOUT a collective library of its own (one all-reduce of the
@@ -643,8 +649,29 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
                           const float* bo, const float* ln1_g, const float* ln1_b, const float* b1, const float* b2,
                           const float* ln2_g, const float* ln2_b, const float* bqkv_next, const uint8_t* row_pad, float p_drop,
                           uint64_t seed, const int64_t* step_dev, uint32_t site_ln1, uint32_t site_ln2, float eps, uint16_t* a_bf,
-                          uint16_t* xhat1, float* rstd1, uint16_t* h1, void* relu_bits, uint16_t* out_bf, uint16_t* xhat2,
-                          float* rstd2, float* out32, uint16_t* qkv_next, ttsmi_stream_t stream);
+                          uint16_t* xhat1, float* rstd1, uint16_t* h1, void* relu_bits, int relu_bits_layout, uint16_t* out_bf,
+                          uint16_t* xhat2, float* rstd2, float* out32, uint16_t* qkv_next, ttsmi_stream_t stream);
+/* relu_bits_layout: 0 = the bit matrix ttsmi_hgemm_k256_masked_bits reads (ttsmi_relu_bits_bytes(M, F) bytes), 1 = the layout
+ * ttsmi_dense_chain_bwd reads (16-bit word (row / 16, 64-feature chunk, lane) of the kernel's own lanes; M * F / 8 bytes
+ * rounded up to whole 16-row tiles).
+ *
+ * The BACKWARD of the same block between its two res-norms as one launch (csrc/chain16b.h; needs the 16-row form of the
+ * forward chain, TTSMI_DENSE_CHAIN_FORM != 32):
+ *     dh1 = (df . W2^T) * [h1 > 0];  g = da + dh1 . W1^T;  (d_o, dres) = LN1'(g) with x^1, rstd1, gamma1 (ttsmi_hgemm_ln_bwd's
+ *     arithmetic: d_o = keep(dz), dres = dz, one partial row of dgamma / dbeta per 128-row workgroup in part_ws:
+ *     ttsmi_layernorm_partials_bytes(cdiv(M, 128), 256));  dctx = d_o . Wo[256:512]^T
+ * df / da: bf16 [M,256] (the res-norm 2 backward's outputs); relu_bits_lane: the forward chain's relu_bits with
+ * relu_bits_layout = 1; wpack: ttsmi_dense_chain_bwd_pack(w1_b [256][F], w2_b [F][256], wo_b [512][256]) - the weights AS
+ * STORED (bf16); dres: bf16 [M,256] when dres_is_bf16, else fp32.  Replaces ttsmi_hgemm_k256_masked_bits +
+ * ttsmi_hgemm_ln_bwd_dual_h + the dctx GEMM of ttsmi_dense_block_bwd (same results up to fp32 summation order). */
+size_t ttsmi_dense_chain_bwd_pack_bytes(int F);
+int ttsmi_dense_chain_bwd_supported(int M, int d, int F);
+int ttsmi_dense_chain_bwd_pack(const uint16_t* w1_b, const uint16_t* w2_b, const uint16_t* wo_b, int F, void* out, size_t out_bytes,
+                               ttsmi_stream_t stream);
+int ttsmi_dense_chain_bwd(const uint16_t* df, const uint16_t* da, const uint16_t* xhat1, const float* rstd1, const float* ln1_g,
+                          const uint8_t* row_pad, const void* relu_bits_lane, const void* wpack, size_t wpack_bytes, int M, int F,
+                          float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site_ln1, uint16_t* dh1, uint16_t* d_o,
+                          void* dres, int dres_is_bf16, uint16_t* dctx, void* part_ws, size_t part_ws_bytes, ttsmi_stream_t stream);
 /* h [M,d] fp32 block input, h_bf its bf16 copy.  Writes desc->out / out_bf (+ the kept activations). */
 int ttsmi_dense_block_fwd(const ttsmi_dense_block* desc, const float* h, const uint16_t* h_bf);
 /* dout [M,d] fp32 gradient of the block output.  Writes desc->dh, the parameter gradients, and leaves the two

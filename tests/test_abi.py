@@ -45,7 +45,7 @@ def test_library_exports_and_binds_every_declared_symbol(built):
     for name, nparams in d.items():
         assert hasattr(l, name), f'{name} not exported'
         assert len(built.SIGNATURES[name][1]) == nparams, name
-    assert l.ttsmi_version() == built.EXPECTED_VERSION == 105         # include/ttsmi.h TTSMI_VERSION, checked at load time
+    assert l.ttsmi_version() == built.EXPECTED_VERSION == 106         # include/ttsmi.h TTSMI_VERSION, checked at load time
 
 
 def test_invalid_arguments_return_error_codes_not_crashes(built):

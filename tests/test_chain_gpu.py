@@ -51,7 +51,7 @@ def _ln_ref(z, gamma, beta):
     return xh * gamma + beta, xh, rstd[:, 0]
 
 
-def _run_chain(M, F, pdrop, with_qkv, with_out32, with_bits, seed0=0):
+def _run_chain(M, F, pdrop, with_qkv, with_out32, with_bits, seed0=0, bits_layout=0):
     ops, _lib, l = _env()
     from transformertts_amd.ops import _p, _stream, check
     seed, stepv, s1, s2 = 777123, 5, 9, 10
@@ -74,11 +74,11 @@ def _run_chain(M, F, pdrop, with_qkv, with_out32, with_bits, seed0=0):
     e = lambda *s, dt=torch.bfloat16: torch.full(s, float('nan'), dtype=dt, device=DEV)
     out = dict(a=e(M, D), xh1=e(M, D), rstd1=e(M, dt=torch.float32), h1=e(M, F), o=e(M, D), xh2=e(M, D), rstd2=e(M, dt=torch.float32),
                o32=e(M, D, dt=torch.float32) if with_out32 else None, qkv=e(M, 3 * D) if with_qkv else None,
-               bits=torch.zeros(int(l.ttsmi_relu_bits_bytes(M, F)), dtype=torch.uint8, device=DEV) if with_bits else None)
+               bits=torch.zeros(int(l.ttsmi_relu_bits_bytes(M, F)) + 4096, dtype=torch.uint8, device=DEV) if with_bits else None)
     check(l.ttsmi_dense_chain_fwd(_p(dev['h']), _p(dev['cx']), _p(wpack), nbytes, M, F, _p(dev['bo']), _p(dev['g1']), _p(dev['be1']),
                                   _p(dev['b1']), _p(dev['b2']), _p(dev['g2']), _p(dev['be2']), _p(dev['bq']) if with_qkv else None,
                                   _p(dev['pad']), pdrop, seed, _p(step), s1, s2, EPS, _p(out['a']), _p(out['xh1']), _p(out['rstd1']),
-                                  _p(out['h1']), _p(out['bits']), _p(out['o']), _p(out['xh2']), _p(out['rstd2']), _p(out['o32']),
+                                  _p(out['h1']), _p(out['bits']), bits_layout, _p(out['o']), _p(out['xh2']), _p(out['rstd2']), _p(out['o32']),
                                   _p(out['qkv']), _stream()), 'chain')
     torch.cuda.synchronize()
     assert l.ttsmi_last_kernel().decode() == ('dense_chain_kernel' if os.environ.get('TTSMI_DENSE_CHAIN_FORM') == '32' else 'dense_chain16_kernel')
@@ -176,3 +176,97 @@ def test_chained_blocks_equal_the_four_launch_blocks_at_the_benchmarked_architec
     # Adam moves every weight by ~lr per step whatever the gradient's size: compare the update directions loosely
     d = (params[True] - params[False]).abs()
     assert float(d.max()) <= 8.5e-4 and float(d.mean()) < 1.5e-4, (float(d.max()), float(d.mean()))
+
+
+def _lane_bits(pos):
+    """(h1 > 0) [M, F] in the chains' lane layout (csrc/chain16b.h): 16-bit word (row // 16, 64-feature chunk, lane) with
+    lane = (row % 16) + 16 kg, bit 4 u + r = feature 64 chunk + 16 u + 4 kg + r."""
+    M, F = pos.shape
+    Mp = (M + 15) // 16 * 16
+    p = np.zeros((Mp, F), bool)
+    p[:M] = pos
+    p = p.reshape(Mp // 16, 16, F // 64, 4, 4, 4)            # tile, t, chunk, u, kg, r
+    w = np.zeros((Mp // 16, F // 64, 4, 16), np.uint16)       # tile, chunk, kg, t
+    for u in range(4):
+        for r in range(4):
+            w |= (p[:, :, :, u, :, r].transpose(0, 2, 3, 1).astype(np.uint16) << (4 * u + r))
+    return w.reshape(Mp // 16, F // 64, 64)
+
+
+@pytest.mark.parametrize('M', [28800, 16384 + 77, 300])
+def test_forward_chain_writes_the_relu_pattern_in_the_backward_chains_layout(M):
+    if os.environ.get('TTSMI_DENSE_CHAIN_FORM') == '32':
+        pytest.skip('the lane layout belongs to the 16-row form')
+    F = 1024
+    ops, _lib, l, out, sh, c = _run_chain(M, F, 0.1, True, False, with_bits=True, seed0=5, bits_layout=1)
+    want = _lane_bits((c['h1'].float() > 0).numpy())
+    got = c['bits'].numpy().view(np.uint16)[:want.size].reshape(want.shape)
+    # (words of rows past M in the last 16-row tile hold whatever the kernel computed for its clamped rows: compare live rows)
+    live = np.zeros((want.shape[0] * 16,), bool)
+    live[:M] = True
+    lane_live = np.tile(live.reshape(-1, 1, 16), (1, 1, 4)).reshape(want.shape[0], 1, 64)
+    assert np.array_equal(np.where(lane_live, got, 0), np.where(lane_live, want, 0))
+
+
+@pytest.mark.parametrize('M,pdrop,dres_bf16', [(28800, 0.1, True), (16384 + 77, 0.1, False), (6400, 0.0, True), (300, 0.1, True)])
+def test_backward_chain_matches_the_fp64_reference_stage_by_stage(M, pdrop, dres_bf16):
+    """ttsmi_dense_chain_bwd (csrc/chain16b.h): dh1 = (df . W2^T) [h1 > 0]; g = da + dh1 . W1^T; res-norm 1 backward in its
+    x^ form (ttsmi_hgemm_ln_bwd's arithmetic) with dropout; dctx = d_o . Wo_ctx^T; the partial rows of dgamma / dbeta - each
+    stage against fp64 on the kernel's own bf16 output of the stage before."""
+    if os.environ.get('TTSMI_DENSE_CHAIN_FORM') == '32':
+        pytest.skip('the backward chain exists in the 16-row form only')
+    ops, _lib, l = _env()
+    from transformertts_amd.ops import _p, _stream, check
+    F, seed, stepv, site = 1024, 424242, 7, 13
+    df = g(M, D, seed=1, scale=0.5).to(torch.bfloat16)
+    da = g(M, D, seed=2, scale=0.5).to(torch.bfloat16)
+    z = g(M, D, seed=3)
+    xh = ((z - z.mean(-1, keepdim=True)) / z.std(-1, keepdim=True, unbiased=False)).to(torch.bfloat16)
+    rstd = (0.5 + g(M, seed=4).abs()).float()
+    gam = 1 + 0.1 * g(D, seed=5)
+    w1, w2, wo = g(D, F, seed=6, scale=0.06), g(F, D, seed=7, scale=0.04), g(2 * D, D, seed=8, scale=0.05)
+    pos = torch.from_numpy(np.random.default_rng(9).random((M, F)) < 0.5)
+    pad = (torch.arange(M) % 11 == 4).to(torch.uint8)
+    bits = torch.from_numpy(_lane_bits(pos.numpy()).view(np.uint8).copy())
+    sh = {k: ops.make_shadow(v.to(DEV)) for k, v in dict(w1=w1, w2=w2, wo=wo).items()}
+    nb = int(l.ttsmi_dense_chain_bwd_pack_bytes(F))
+    assert nb == (2 * (F // 64) + 4) * 32768
+    wpack = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    check(l.ttsmi_dense_chain_bwd_pack(_p(sh['w1'].wb), _p(sh['w2'].wb), _p(sh['wo'].wb), F, _p(wpack), nb, _stream()), 'bwd pack')
+    dev = {k: v.to(DEV) for k, v in dict(df=df, da=da, xh=xh, rstd=rstd, gam=gam, pad=pad, bits=bits).items()}
+    step = torch.full((1,), stepv, dtype=torch.int64, device=DEV)
+    e = lambda *s_, dt=torch.bfloat16: torch.full(s_, float('nan'), dtype=dt, device=DEV)
+    dh1, d_o, dctx = e(M, F), e(M, D), e(M, D)
+    dres = e(M, D) if dres_bf16 else e(M, D, dt=torch.float32)
+    nparts = (M + 127) // 128
+    part = ops._ws(int(l.ttsmi_layernorm_partials_bytes(nparts, D)), DEV)
+    check(l.ttsmi_dense_chain_bwd(_p(dev['df']), _p(dev['da']), _p(dev['xh']), _p(dev['rstd']), _p(dev['gam']), _p(dev['pad']), _p(dev['bits']),
+                                  _p(wpack), nb, M, F, pdrop, seed, _p(step), site, _p(dh1), _p(d_o), _p(dres), int(dres_bf16), _p(dctx),
+                                  _p(part), part.numel(), _stream()), 'chain bwd')
+    torch.cuda.synchronize()
+    assert l.ttsmi_last_kernel().decode() == 'dense_chain16_bwd_kernel'
+    dh1_c, d_o_c, dctx_c, dres_c = dh1.cpu(), d_o.cpu(), dctx.cpu(), dres.cpu()
+    # stage 1: the masked FFN2 dgrad
+    want = (df.double() @ bf(w2).t()) * pos
+    assert rel_err(dh1_c.float(), want) < 4e-3
+    assert torch.equal(dh1_c.float() != 0, (want != 0) & (dh1_c.float() != 0))            # nothing leaks through a cleared bit
+    # stage 2 on the kernel's dh1: g, res-norm 1 backward
+    live = (pad == 0)
+    gg = (da.double() + dh1_c.double() @ bf(w1).t()) * live[:, None]
+    t_ = gg * gam.double()
+    xhd = xh.double()
+    m1, m2 = t_.mean(-1, keepdim=True), (t_ * xhd).mean(-1, keepdim=True)
+    dz = rstd.double()[:, None] * (t_ - m1 - xhd * m2)
+    inv = 1.0 / (1.0 - float(np.float32(pdrop))) if pdrop > 0 else 1.0
+    keep = torch.from_numpy(dr.keep_mask(seed, stepv, site, np.arange(M), np.arange(D), pdrop)).double() * inv if pdrop > 0 else 1.0
+    assert rel_err(dres_c.float(), dz) < (4e-3 if dres_bf16 else 3e-5)
+    assert rel_err(d_o_c.float(), dz * keep) < 4e-3
+    # stage 3 on the kernel's d_o: dctx
+    assert rel_err(dctx_c.float(), d_o_c.double() @ bf(wo)[D:].t()) < 4e-3
+    # parameter-gradient partial rows: one per 128-row workgroup
+    pf = part.cpu()[:2 * nparts * D * 4].view(torch.float32).reshape(2, nparts, D).double()
+    gx, gb = gg * xhd, gg
+    padrows = nparts * 128 - M
+    gx = torch.cat([gx, torch.zeros(padrows, D, dtype=torch.float64)]).reshape(nparts, 128, D).sum(1)
+    gb = torch.cat([gb, torch.zeros(padrows, D, dtype=torch.float64)]).reshape(nparts, 128, D).sum(1)
+    assert rel_err(pf[0], gx) < 3e-5 and rel_err(pf[1], gb) < 3e-5

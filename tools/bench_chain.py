@@ -44,7 +44,7 @@ for M in [int(a) for a in sys.argv[1:]] or [28800, 6400, 12000, 2500]:
 
     def chain():
         check(l.ttsmi_dense_chain_fwd(_p(h), _p(cx), _p(wpack), nb, M, F, _p(bo), _p(g1), _p(be1), _p(b1), _p(b2), _p(g2), _p(be2), _p(bq),
-                                      _p(pad), 0.1, 99, _p(step), 5, 6, EPS, _p(a), _p(xh1), _p(r1), _p(h1), _p(bits) if use_bits else None,
+                                      _p(pad), 0.1, 99, _p(step), 5, 6, EPS, _p(a), _p(xh1), _p(r1), _p(h1), _p(bits) if use_bits else None, 0,
                                       _p(o), _p(xh2), _p(r2), None, _p(qkv), _stream()))
 
     def four():

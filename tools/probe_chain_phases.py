@@ -33,7 +33,7 @@ if hasattr(l._cdll, 'ttsmi_dense_chain_debug'):
 
 def chain():
     check(l.ttsmi_dense_chain_fwd(_p(h), _p(cx), _p(wpack), nb, M, F, _p(bo), _p(g1), _p(be1), _p(b1), _p(b2), _p(g2), _p(be2), _p(bq),
-                                  _p(pad), 0.1, 99, _p(step), 5, 6, EPS, _p(a), _p(xh1), _p(r1), _p(h1), None,
+                                  _p(pad), 0.1, 99, _p(step), 5, 6, EPS, _p(a), _p(xh1), _p(r1), _p(h1), None, 0,
                                   _p(o), _p(xh2), _p(r2), None, _p(qkv), _stream()))
 
 

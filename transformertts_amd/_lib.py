@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # version this binding was written for (EXPECTED_VERSION, checked in lib()).
 _override = os.environ.get('TTSMI_LIB') if os.environ.get('TTSMI_ALLOW_LIB_OVERRIDE') == '1' else None
 LIB_PATH = _override or os.path.join(_HERE, 'lib', 'libttsmi.so')
-EXPECTED_VERSION = 105            # include/ttsmi.h: TTSMI_VERSION
+EXPECTED_VERSION = 106            # include/ttsmi.h: TTSMI_VERSION
 
 P = c_void_p          # every device pointer
 I = c_int
@@ -124,7 +124,11 @@ SIGNATURES = {
     'ttsmi_dense_chain_pack': (I, [P, P, P, P, I, P, c_size_t, S]),
     'ttsmi_dense_chain_supported': (I, [I, I, I]),
     'ttsmi_dense_chain_fwd': (I, [P, P, P, c_size_t, I, I, P, P, P, P, P, P, P, P, P, F, c_uint64, P, c_uint32, c_uint32, F,
-                                  P, P, P, P, P, P, P, P, P, P, S]),
+                                  P, P, P, P, P, I, P, P, P, P, P, S]),
+    'ttsmi_dense_chain_bwd_pack_bytes': (c_size_t, [I]),
+    'ttsmi_dense_chain_bwd_supported': (I, [I, I, I]),
+    'ttsmi_dense_chain_bwd_pack': (I, [P, P, P, I, P, c_size_t, S]),
+    'ttsmi_dense_chain_bwd': (I, [P, P, P, P, P, P, P, P, c_size_t, I, I, F, c_uint64, P, c_uint32, P, P, P, I, P, P, c_size_t, S]),
     'ttsmi_dense_block_fwd': (I, [P, P, P]),
     'ttsmi_dense_block_bwd': (I, [P, P, P, P]),
     'ttsmi_dense_stack_fwd': (I, [P, I, P, P]),
@@ -147,7 +151,8 @@ def _dense_block_fields():
             [(n, p) for n in ptrs2] + [(n, u64) for n in ('attn_ws_bytes', 'ln_ws_bytes', 'wgrad_ws_bytes')] +
             [('main_stream', p), ('side_stream', p), ('ev', p * 4), ('below', p), ('ln2_done', i32), ('res16', i32), ('relu_bits', p),
              ('attn_fused_ws', p), ('attn_fused_ws_bytes', u64),
-             ('chain_w', p), ('chain_w_bytes', u64), ('above', p), ('qkv_done', i32), ('chain_pad_', i32)])
+             ('chain_w', p), ('chain_w_bytes', u64), ('above', p), ('qkv_done', i32), ('chain_pad_', i32),
+             ('chain_bw', p), ('chain_bw_bytes', u64)])
 
 
 class DenseBlockDesc(ctypes.Structure):

@@ -567,6 +567,7 @@ struct ChainPackP {
     const uint16_t *wo_t, *w1_t, *w2_t, *wqkv_t;      // [256][512], [F][256], [256][F], [768][256] (W^T as stored by the shadow set)
     uint16_t* out;
     int F, nchunk, nstages;
+    int wo_stages;                                    // 8 (forward stream) or 0 (backward stream: no product in front of the FFN pair)
 };
 __global__ __launch_bounds__(256) void dense_chain_pack_kernel(ChainPackP p) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // one 16-byte lane item of one fragment
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(256) void dense_chain_pack_kernel(ChainPackP p) {
 }
 
 #include "chain16.h"
+#include "chain16b.h"
 
 // which form of the kernel (and of its weight stream) this process uses: TTSMI_DENSE_CHAIN_FORM = 16 (eight 16-row waves on
 // 16x16x32 MFMAs, two waves per SIMD) or 32 (four 32-row waves on 32x32x16, one wave per SIMD); read once
@@ -630,6 +632,7 @@ int ttsmi_dense_chain_pack(const uint16_t* wo_t, const uint16_t* w1_t, const uin
     ChainPackP p;
     p.wo_t = wo_t; p.w1_t = w1_t; p.w2_t = w2_t; p.wqkv_t = wqkv_next_t; p.out = (uint16_t*)out;
     p.F = F; p.nchunk = F / 64; p.nstages = chain_stages(F, wqkv_next_t != nullptr);
+    p.wo_stages = CH_WO_STAGES;
     const long total = (long)p.nstages * CH_STAGE_FRAGS * 64;
     if (chain_form() == 16) hipLaunchKernelGGL(dense_chain16_pack_kernel, dim3(ttsmi_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(dense_chain_pack_kernel, dim3(ttsmi_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
@@ -643,8 +646,8 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
                           const float* bo, const float* ln1_g, const float* ln1_b, const float* b1, const float* b2,
                           const float* ln2_g, const float* ln2_b, const float* bqkv_next, const uint8_t* row_pad, float p_drop,
                           uint64_t seed, const int64_t* step_dev, uint32_t site_ln1, uint32_t site_ln2, float eps, uint16_t* a_bf,
-                          uint16_t* xhat1, float* rstd1, uint16_t* h1, void* relu_bits, uint16_t* out_bf, uint16_t* xhat2,
-                          float* rstd2, float* out32, uint16_t* qkv_next, ttsmi_stream_t stream) {
+                          uint16_t* xhat1, float* rstd1, uint16_t* h1, void* relu_bits, int relu_bits_layout, uint16_t* out_bf,
+                          uint16_t* xhat2, float* rstd2, float* out32, uint16_t* qkv_next, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(h_bf && ctx && wpack && bo && ln1_g && ln1_b && b1 && b2 && ln2_g && ln2_b && a_bf && xhat1 && rstd1 && h1 &&
                         out_bf && xhat2 && rstd2,
                     "dense_chain_fwd: null pointer");
@@ -671,6 +674,10 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
     // the bit matrix is read back by ttsmi_hgemm_k256_masked_bits: its 256-column variant from 16 384 rows (gemm_k256.hip: kw_launch)
     TTSMI_KNOB(wide, "TTSMI_HGEMM_K256_WIDE", 1);
     p.bits_wide = (wide && F % 256 == 0 && (M >= 16384 || wide > 1)) ? 1 : 0;
+    if (relu_bits != nullptr && relu_bits_layout == 1) {
+        TTSMI_CHECK_ARG(chain_form() == 16, "dense_chain_fwd: the backward chain's bit layout needs the 16-row form");
+        p.bits_wide = 2;
+    }
     if (relu_bits != nullptr && !p.bits_wide) TTSMI_CHECK_ARG(F % 128 == 0, "dense_chain_fwd: the bit matrix needs F %% 128 == 0");
     p.out_bf = out_bf; p.xhat2 = xhat2; p.rstd2 = rstd2; p.out32 = out32; p.qkv = qkv_next;
 #ifdef TTSMI_ABLATION_BUILD
@@ -689,6 +696,62 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
     if (out32 != nullptr) TTSMI_LAUNCH_EV(dense_chain_kernel<true>, dim3(ttsmi_cdiv(M, CH_ROWS)), dim3(CH_NW * 64), 0, (hipStream_t)stream, p);
     else TTSMI_LAUNCH_EV(dense_chain_kernel<false>, dim3(ttsmi_cdiv(M, CH_ROWS)), dim3(CH_NW * 64), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("dense_chain_fwd");
+    return TTSMI_OK;
+}
+
+// ---- backward chain (chain16b.h) -----------------------------------------------------------------------------------
+static int chain_bwd_stages(int F) { return 2 * (F / 64) + C16B_CTX_STAGES; }
+
+size_t ttsmi_dense_chain_bwd_pack_bytes(int F) { return F > 0 && F % 64 == 0 ? (size_t)chain_bwd_stages(F) * CH_STAGE_BYTES : 0; }
+
+int ttsmi_dense_chain_bwd_supported(int M, int d, int F) { return chain_form() == 16 && ttsmi_dense_chain_supported(M, d, F) && M >= 1; }
+
+/* w1_b [256][F], w2_b [F][256], wo_b [512][256]: the weights AS STORED (bf16 shadows) */
+int ttsmi_dense_chain_bwd_pack(const uint16_t* w1_b, const uint16_t* w2_b, const uint16_t* wo_b, int F, void* out, size_t out_bytes,
+                               ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(w1_b && w2_b && wo_b && out, "dense_chain_bwd_pack: null pointer");
+    TTSMI_CHECK_ARG(F > 0 && F % 64 == 0, "dense_chain_bwd_pack: F must be a multiple of 64 (got %d)", F);
+    TTSMI_CHECK_ARG(out_bytes >= ttsmi_dense_chain_bwd_pack_bytes(F), "dense_chain_bwd_pack: output buffer too small");
+    TTSMI_CHECK_ARG(((((uintptr_t)w1_b) | ((uintptr_t)w2_b) | ((uintptr_t)wo_b)) & 7) == 0 && (((uintptr_t)out) & 15) == 0,
+                    "dense_chain_bwd_pack: operands must be 8-byte (output: 16-byte) aligned");
+    // the forward packer's three roles with the backward's matrices: "W1^T [F][256]" = W2 as stored (rows = hidden feature, k = d),
+    // "W2^T [256][F]" = W1 as stored (rows = d, k = hidden feature), the tail = the ctx half of Wo as stored ([256][256]: 4 stages)
+    ChainPackP p;
+    p.wo_t = nullptr; p.w1_t = w2_b; p.w2_t = w1_b; p.wqkv_t = wo_b + (long)CH_D * CH_D; p.out = (uint16_t*)out;
+    p.F = F; p.nchunk = F / 64; p.nstages = chain_bwd_stages(F); p.wo_stages = 0;
+    const long total = (long)p.nstages * CH_STAGE_FRAGS * 64;
+    hipLaunchKernelGGL(dense_chain16_pack_kernel, dim3(ttsmi_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    TTSMI_CHECK_LAUNCH("dense_chain_bwd_pack");
+    return TTSMI_OK;
+}
+
+int ttsmi_dense_chain_bwd(const uint16_t* df, const uint16_t* da, const uint16_t* xhat1, const float* rstd1, const float* ln1_g,
+                          const uint8_t* row_pad, const void* relu_bits_lane, const void* wpack, size_t wpack_bytes, int M, int F,
+                          float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site_ln1, uint16_t* dh1, uint16_t* d_o,
+                          void* dres, int dres_is_bf16, uint16_t* dctx, void* part_ws, size_t part_ws_bytes, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(df && da && xhat1 && rstd1 && ln1_g && relu_bits_lane && wpack && dh1 && d_o && dres && dctx && part_ws,
+                    "dense_chain_bwd: null pointer");
+    TTSMI_CHECK_ARG(ttsmi_dense_chain_bwd_supported(M, CH_D, F), "dense_chain_bwd: unsupported shape M=%d F=%d (or TTSMI_DENSE_CHAIN_FORM=32)", M, F);
+    TTSMI_CHECK_ARG(wpack_bytes >= ttsmi_dense_chain_bwd_pack_bytes(F), "dense_chain_bwd: weight stream too short");
+    TTSMI_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dense_chain_bwd: bad dropout rate");
+    const int nparts = ttsmi_cdiv(M, C16_ROWS);
+    TTSMI_CHECK_ARG(part_ws_bytes >= ttsmi_layernorm_partials_bytes(nparts, CH_D), "dense_chain_bwd: partial-sum workspace too small");
+    TTSMI_CHECK_ARG(((((uintptr_t)df) | ((uintptr_t)da) | ((uintptr_t)xhat1) | ((uintptr_t)wpack) | ((uintptr_t)dh1) | ((uintptr_t)d_o) |
+                      ((uintptr_t)dres) | ((uintptr_t)dctx) | ((uintptr_t)ln1_g) | ((uintptr_t)part_ws)) & 15) == 0 &&
+                        (((uintptr_t)relu_bits_lane) & 1) == 0,
+                    "dense_chain_bwd: operands must be 16-byte aligned");
+    ChainBP p;
+    memset(&p, 0, sizeof(p));
+    p.df = df; p.da = da; p.xhat = xhat1; p.rstd = rstd1; p.gamma = ln1_g; p.row_pad = row_pad;
+    p.bits16 = (const uint16_t*)relu_bits_lane; p.wpack = (const unsigned char*)wpack;
+    p.M = M; p.F = F; p.nchunk = F / 64; p.nstages = chain_bwd_stages(F); p.nparts = nparts;
+    p.thr = p_drop > 0.f ? ttsmi_drop_threshold(p_drop) : 0u;
+    p.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    p.seed = seed; p.step_dev = step_dev; p.site = site_ln1;
+    p.dh1 = dh1; p.d_o = d_o; p.dctx = dctx; p.dres = dres; p.dres_bf16 = dres_is_bf16 ? 1 : 0; p.part = (float*)part_ws;
+    ttsmi_note_kernel("dense_chain16_bwd_kernel");
+    TTSMI_LAUNCH_EV(dense_chain16_bwd_kernel, dim3(nparts), dim3(C16_NW * 64), 0, (hipStream_t)stream, p);
+    TTSMI_CHECK_LAUNCH("dense_chain_bwd");
     return TTSMI_OK;
 }
 

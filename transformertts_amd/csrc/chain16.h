@@ -346,6 +346,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                           [&](int g) { issue2(S + CH_NRING - 1, g); });
                 ++S;
                 bf16x8 hf[2];
+                uint32_t lane_bits = 0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     uint2 h = ch_pack4(H[u][0], H[u][1], H[u][2], H[u][3]);
@@ -355,9 +356,14 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hf[u >> 1][4 * (u & 1) + e] = hb[e];
                     c16_slot_write(slot, t, kg, u, h);
+                    // (a positive bf16 after the ReLU = a non-zero half: bit 4 u + e of the lane's word)
+                    lane_bits |= (((h.x & 0xFFFFu) ? 1u : 0u) | ((h.x >> 16) ? 2u : 0u) | ((h.y & 0xFFFFu) ? 4u : 0u) | ((h.y >> 16) ? 8u : 0u)) << (4 * u);
                 }
+                // the ReLU pattern in the BACKWARD CHAIN's layout (chain16b.h): one 16-bit word per lane, 128 bytes per wave and chunk
+                if (p.bits_wide == 2 && p.relu_bits != nullptr && row0 < p.M)
+                    reinterpret_cast<uint16_t*>(p.relu_bits)[((long)(row0 >> 4) * p.nchunk + c) * 64 + lane] = (uint16_t)lane_bits;
                 Fs = stage_begin(S);
-                c16_slot_flush(slot, p.h1, p.F, 64 * c, row0, p.M, lane, p.relu_bits, p.bits_wide, nbchunk);
+                c16_slot_flush(slot, p.h1, p.F, 64 * c, row0, p.M, lane, p.bits_wide == 2 ? nullptr : p.relu_bits, p.bits_wide, nbchunk);
                 c16_stage(Fs, [&](int g, int i, const bf16x8& a) { const int j = (g & 1) * 8 + i; Z[j] = C16_MFMA(a, hf[g >> 1], Z[j]); },
                           [&](int g) { issue2(S + CH_NRING - 1, g); });
                 ++S;
@@ -413,11 +419,12 @@ __global__ __launch_bounds__(256) void dense_chain16_pack_kernel(ChainPackP p) {
     const uint16_t* src;
     long ld;
     int n, kbase;
-    if (S < CH_WO_STAGES) {
+    const int wo = p.wo_stages;
+    if (S < wo) {
         const int kb = f >> 4, j = f & 15;
         src = p.wo_t; ld = 2 * CH_D; n = 16 * j + n16; kbase = 32 * (2 * S + kb);
-    } else if (S < CH_WO_STAGES + 2 * p.nchunk) {
-        const int tt = S - CH_WO_STAGES, c = tt >> 1;
+    } else if (S < wo + 2 * p.nchunk) {
+        const int tt = S - wo, c = tt >> 1;
         if ((tt & 1) == 0) {
             const int q = f >> 2, u = f & 3;
             src = p.w1_t; ld = CH_D; n = 64 * c + 16 * u + n16; kbase = 32 * q;
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(256) void dense_chain16_pack_kernel(ChainPackP p) {
             src = p.w2_t; ld = p.F; n = 16 * j + n16; kbase = 64 * c + 32 * kb;
         }
     } else {
-        const int s = S - CH_WO_STAGES - 2 * p.nchunk, q = f >> 2, u = f & 3;
+        const int s = S - wo - 2 * p.nchunk, q = f >> 2, u = f & 3;
         src = p.wqkv_t; ld = CH_D; n = 64 * s + 16 * u + n16; kbase = 32 * q;
     }
     const uint16_t* r = src + (long)n * ld + kbase + 4 * kg;

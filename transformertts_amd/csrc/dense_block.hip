@@ -109,9 +109,12 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
         OBS("ttsmi_dense_chain_fwd", 2.0 * M * d * (2.0 * d + 2.0 * F + (A ? 3.0 * d : 0.0)),
             (double)M * 2 * (2.0 * d + 4.0 * d + F + (A ? 3.0 * d : 0.0)) + ((D->res16 & 2) ? 4.0 * M * d : 0.0) +
                 (relu_bits(D) ? (double)M * F / 8 : 0.0) + wbytes + 8.0 * M, st);
+        // (chain_bw: the backward runs as a chain too and reads the ReLU pattern in the chain's own lane layout)
+        const bool lane_bits = D->chain_bw != nullptr && D->relu_bits != nullptr;
         return ttsmi_dense_chain_fwd(h_bf, D->cx, D->chain_w, D->chain_w_bytes, M, F, D->bo, D->ln1_g, D->ln1_b, D->b1, D->b2, D->ln2_g,
                                      D->ln2_b, A ? A->bqkv : nullptr, D->pad, D->rate, D->seed, D->step_dev, D->site_ln1, D->site_ln2,
-                                     kLnEps, D->a_bf, D->xhat1, D->rstd1, D->h1, relu_bits(D) ? D->relu_bits : nullptr, D->out_bf,
+                                     kLnEps, D->a_bf, D->xhat1, D->rstd1, D->h1,
+                                     lane_bits ? D->relu_bits : (relu_bits(D) ? D->relu_bits : nullptr), lane_bits ? 1 : 0, D->out_bf,
                                      D->xhat2, D->rstd2, (D->res16 & 2) ? D->out : nullptr, A ? A->qkv : nullptr, st);
     }
     TTSMI_CHECK_ARG(D->above == nullptr, "dense_block_fwd: `above` without chain_w");
@@ -319,6 +322,25 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
                                     D->site_ln2, 0.f, 0, D->seed, D->step_dev, 0, dropout ? nullptr : D->da, D->da, nullptr,
                                     nullptr, nullptr, M, d, D->ln_ws2, D->ln_ws_bytes, D->df, st));
     if (!lazy) TRY(wgrad_side(D, &wb, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
+    // ---- the backward chain (csrc/chain16b.h): FFN2 dgrad + ReLU mask, FFN1 dgrad + res-norm 1 backward and the dctx product
+    // in ONE launch; dh1 and d_o are written for the weight-gradient stream, nothing is read back
+    const bool chain_bw = D->chain_bw != nullptr && D->chain_w != nullptr && r16 && !lazy && D->relu_bits != nullptr &&
+                          ttsmi_dense_chain_bwd_supported(M, d, F);
+    if (chain_bw) {
+        { OBS("ttsmi_dense_chain_bwd", 2.0 * M * d * (2.0 * F + d),
+              (double)M * 2 * (4.0 * d + F + 2.0 * d) + (double)M * F / 8 + (double)ttsmi_dense_chain_bwd_pack_bytes(F) + 4.0 * M, st);
+          arm(D, 1);
+          TRY(ttsmi_dense_chain_bwd(D->df, (const uint16_t*)D->da, D->xhat1, D->rstd1, D->ln1_g, D->pad, D->relu_bits, D->chain_bw,
+                                    D->chain_bw_bytes, M, F, D->rate, D->seed, D->step_dev, D->site_ln1, D->dh1, D->d_o, D->dh,
+                                    dh16 ? 1 : 0, D->dctx, D->lnp_ws1, D->lnp_ws1_bytes, st)); }
+        TRY(wgrad_side(D, &wb, 1, true, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));
+        TRY(wgrad_wo(D, &wb, 2, false, h_bf));
+        if (!fold) {         // the bottom block of a stack: the q_in half's gradient joins the fp32 dh here
+            OBS("ttsmi_hgemm_tn", 2.0 * M * d * d, gemm_bytes(M, d, d, 4, true), st);
+            TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b, d, nullptr, nullptr, 0, D->dh, d, M, d, d,
+                               TTSMI_GEMM_ACCUMULATE, 1, 0, 0, 0, st));
+        }
+    } else {
     { OBS("ttsmi_hgemm_tn", 2.0 * M * F * d, gemm_bytes(M, F, d, 2, false, relu_bits(D) ? (double)M * F / 8 : (double)M * F * 2), st);
       if (!pre_attn) arm(D, 1);
       if (relu_bits(D))           // relu' from the bit matrix the forward left: 1 / 16 of the bytes of re-reading h1
@@ -374,6 +396,7 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
           TRY(ttsmi_hgemm_tn(D->d_o, 0, d, nullptr, 0, 0, D->wo_b + (long)d * d, d, nullptr, nullptr, 0, D->dctx, d, M, d, d,
                              TTSMI_GEMM_OUT_BF16, 1, 0, 0, 0, st)); }
     }
+    }   // (!chain_bw)
     if (pre_attn) {      // everything the weight-gradient stream can do before dqkv exists, handed over in one go
         TRY(wgrad_side(D, &wb, 2, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
         TRY(wgrad_side(D, &wb, 2, false, D->a_bf, d, D->dh1, F, D->g_w1, D->g_b1, d, F));

@@ -1762,6 +1762,7 @@ _CONV_WGRAD_TAPS = os.environ.get('TTSMI_CONV_WGRAD_TAPS', '1') != '0'     # A/B
 FUSE_LN_MIN_ROWS_INFERENCE = int(os.environ.get('TTSMI_FUSE_LN_MIN_ROWS', '8192'))
 
 
+_CHAIN_BWD = os.environ.get('TTSMI_DENSE_CHAIN_BWD', '1') != '0'
 CHAIN_MIN_ROWS = int(os.environ.get('TTSMI_DENSE_CHAIN_MIN_ROWS', '16384'))      # rows from which the chain kernel replaces the four launches
 
 
@@ -1810,6 +1811,11 @@ class DenseBlockPlan:
         self.chain_next, self.packed_ver, self.chain_on = None, None, False
         if self.chain:
             t['chain_w'] = e((int(l.ttsmi_dense_chain_pack_bytes(F, 1)),), torch.uint8)
+        # ... and the backward's (csrc/chain16b.h: FFN dgrads + res-norm 1 backward + dctx as one launch; TTSMI_DENSE_CHAIN_BWD=0:
+        # the three launches)
+        self.chain_bwd = (self.chain and self.backward and _CHAIN_BWD and bool(l.ttsmi_dense_chain_bwd_supported(cap, d, F)))
+        if self.chain_bwd:
+            t['chain_bw'] = e((int(l.ttsmi_dense_chain_bwd_pack_bytes(F)),), torch.uint8)
         # the FFN's ReLU as one bit per element for the backward (ttsmi_dense_block.relu_bits); TTSMI_RELU_BITS=0: re-read h1
         self.relu_bits = backward and self.want_fuse and os.environ.get('TTSMI_RELU_BITS', '1') != '0'
         t['relu_bits'] = e((max(int(l.ttsmi_relu_bits_bytes(cap, F)), 8) if self.relu_bits else 8,), torch.uint8)
@@ -1967,6 +1973,10 @@ class DenseBlockPlan:
         check(_lib.lib().ttsmi_dense_chain_pack(_p(S['wo'].wt), _p(S['ffn.w1'].wt), _p(S['ffn.w2'].wt),
                                                 _p(nxt.S['wqkv'].wt) if nxt is not None else None, self.F,
                                                 _p(self.t['chain_w']), self.t['chain_w'].numel(), _stream()), 'dense_chain_pack')
+        if self.chain_bwd:
+            check(_lib.lib().ttsmi_dense_chain_bwd_pack(_p(S['ffn.w1'].wb), _p(S['ffn.w2'].wb), _p(S['wo'].wb), self.F,
+                                                        _p(self.t['chain_bw']), self.t['chain_bw'].numel(), _stream()),
+                  'dense_chain_bwd_pack')
         self.packed_ver = version
 
     def bind(self, pad, klen, rate, drop, sites, dmask, res16=False, out32=True):
@@ -1992,6 +2002,9 @@ class DenseBlockPlan:
         D.above = ctypes.addressof(nxt.desc) if nxt is not None else None
         if self.chain_next is not None:
             self.chain_next.desc.qkv_done = int(nxt is not None)
+        bw_on = self.chain_on and self.chain_bwd and self.relu_bits and torch.is_grad_enabled()
+        D.chain_bw = self.t['chain_bw'].data_ptr() if bw_on else None
+        D.chain_bw_bytes = self.t['chain_bw'].numel() if bw_on else 0
 
     def fwd(self, h, h_bf):
         check(_lib.lib().ttsmi_dense_block_fwd(self._dref, _p(h), _p(h_bf)), 'dense_block_fwd')
