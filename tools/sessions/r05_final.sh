@@ -41,13 +41,13 @@ python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_bf16_steps20.json 2>/dev
 python bench.py --workload mel > $O/${TAG}_bench_mel.json 2>/dev/null; echo rc=$?
 python bench.py --workload predict > $O/${TAG}_predict_latency.json 2>/dev/null; echo rc=$?
 python bench.py --graph --no-cpu-baseline --no-roofline --no-attention-maps --steps 30 --warmup 6 > $O/${TAG}_bench_graph.json 2>/dev/null; echo rc=$?
-TTSMI_DENSE_CHAIN=1 python bench.py --no-cpu-baseline --no-attention-maps --no-also > $O/${TAG}_bench_bf16_chain.json 2>/dev/null; echo rc=$?
+TTSMI_DENSE_CHAIN=0 python bench.py --no-cpu-baseline --no-attention-maps --no-also > $O/${TAG}_bench_bf16_nochain.json 2>/dev/null; echo rc=$?
 echo "== the training curve at the benchmarked batch"
 TTSMI_CURVE_BATCH=32 timeout 600 python -m pytest tests/test_training_curve_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -2
 rm -rf $O/prof_${TAG}_bf16 $O/pmc_${TAG}_bf16_* $O/sq_${TAG}_bf16_* $O/prof_${TAG}_mel $O/pmc_${TAG}_mel_* $O/prof_${TAG}_refdef
 python - <<'PY'
 import json
-for f in ('bf16', 'bf16_steps20', 'mel', 'bf16_chain'):
+for f in ('bf16', 'bf16_steps20', 'mel', 'bf16_nochain'):
     try:
         d = json.loads(open('gpurun_out/r05_bench_' + f + '.json').read().strip().splitlines()[-1])
         print(f, round(d['value'], 1), d['unit'], 'ms', round(d['ms_per_step'], 3), 'maps', d.get('ms_per_step_with_attention_maps'), 'traffic', (d.get('roofline') or {}).get('traffic'))

@@ -29,24 +29,18 @@
 // stage's own (16, 8 or 0): loads complete in order, outstanding stores can only make that wait longer, never shorter.
 // Bias / gamma / beta vectors are staged in LDS once per workgroup; accumulators start at their bias.
 //
-// STATUS (round 5): correct at every size and tested (tests/test_chain_gpu.py), but NOT faster than the four launches -
-// opt-in, TTSMI_DENSE_CHAIN=1.  Decoder size (28 800 rows, 225 workgroups): 98 us against 107 us for the four launches
-// alone, level inside the train step (5.09 against 5.01 ms); encoder size (50 workgroups) 81 against 57 us: a workgroup's
-// own latency is ~85 us whatever the row count.  What the measurements say (profiles/r05_chain_*.txt,
-// r05_sq_counters_chain_third_build.txt, tools/probes/mfma_lds_overlap_probe.hip):
-//  * the pipeline itself is sound - the probe runs the same stage (32 MFMAs, 32 fragment reads, 8 DMA pieces per wave, one
-//    barrier) at 1 336 cycles against 1 062 for the multiplies alone, one wave per SIMD;
-//  * the kernel's stages take 2 200-2 900 cycles because ONE wave per SIMD hides at most ~5 other instructions behind each
-//    MFMA and the stages carry ~10 per MFMA (bias / ReLU / pack / transposing stores / DMA address arithmetic / AGPR moves:
-//    12 k vector instructions per wave = 28 % of its cycles, nothing overlaps them); the two LayerNorms cost ~20 k cycles
-//    each (vector arithmetic ~12 k, 32 row-store instructions, 16 LDS round trips of the transposing stores);
-//  * builds: first 175 us (two waves issued all DMA pieces in bursts), second 99.5 us, third 98 us, a fourth with the
-//    fragment pipeline carried across stage boundaries 108 us (512 registers, spills), fifth (this one: ONE copy of the
-//    LayerNorm code in a two-iteration loop, ReLU as v_pk_max_i16, predicate-free stores, paired DMA pieces - 28 % less
-//    code) 101 us: the straight-line phases did not get faster with less code, so it is instruction ISSUE (3 k vector
-//    instructions, 32 store instructions and 16 LDS round trips per LayerNorm, all in one wave), not instruction fetch.
-// What would make it pay: two row groups per workgroup sharing one pass over the weights with loops instead of unrolled
-// phases (half the code, twice the multiplies per fetched fragment), i.e. 256 registers per wave and two waves per SIMD.
+// TWO FORMS of the forward kernel live behind ttsmi_dense_chain_fwd (TTSMI_DENSE_CHAIN_FORM, default 16):
+//  * this file's dense_chain_kernel: four 32-row waves on v_mfma_f32_32x32x16_bf16, 450-512 registers, ONE wave per SIMD.
+//    Correct and tested, but only level with the four launches (decoder size, 28 800 rows: 98-101 us against 105-107): with
+//    a single in-order wave per SIMD the MFMA issue (27 % of the cycles), 12 k vector instructions (28 %) and the waits
+//    (30 %) simply ADD - stages of 2 200-2 900 cycles for 1 024 of multiplies, while the same stage skeleton alone
+//    (tools/probes/mfma_lds_overlap_probe.hip) runs at 1 336.  Six builds were measured (DESIGN.md section 4, round 5;
+//    profiles/r05_chain_*.txt, r05_sq_counters_chain_third_build.txt); this is the fifth.
+//  * chain16.h's dense_chain16_kernel (the default): eight 16-row waves on v_mfma_f32_16x16x32_bf16, <= 256 registers, TWO
+//    waves per SIMD - what the first form's analysis asked for.  85.7 us at 28 800 rows; the train step 4.99 -> 4.85 ms.
+// chain16b.h holds the BACKWARD chain on the second form's layout (ttsmi_dense_chain_bwd; step 4.85 -> 4.78 ms).
+// The host uses the chains from 16 384 rows on (ops.CHAIN_MIN_ROWS): a workgroup's own latency is ~60 us whatever the row
+// count, which the four launches beat at encoder sizes (57 us).
 //
 // LDS: 128 KB ring + 18 KB transposing scratch (a slot per wave) + 13 KB parameters = 159 KB; 512 registers per lane (one
 // wave per SIMD).
