@@ -38,18 +38,24 @@ def _digest(paths) -> str:
     return h.hexdigest()
 
 
+def _headers():
+    """Every header a source may include: all of csrc/*.h (a header missing from a hand-kept list once left a kernel edit
+    out of the build and out of the digest) and the public include/ttsmi.h."""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(HERE, '..', 'include', 'ttsmi.h')]
+
+
 def library_digest() -> str:
     """One digest of everything libttsmi.so is compiled from (every source, the shared headers, the flags): measurement
     files that describe the kernels of a particular build (profiles/*_pmc_hbm_traffic_*.json) are stamped with it, and
     bench.py reports `traffic: null` when the stamp is not the digest of the tree it runs from."""
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fft512.h'), os.path.join(CSRC, 'chain16.h'), os.path.join(HERE, '..', 'include', 'ttsmi.h')]
+    headers = _headers()
     return _digest([os.path.join(CSRC, s) for s in SOURCES] + headers)[:16]
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fft512.h'), os.path.join(CSRC, 'chain16.h'), os.path.join(HERE, '..', 'include', 'ttsmi.h')]
+    headers = _headers()
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:

@@ -104,7 +104,11 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #undef C16B_XFRAGS
     }
     const bool padded = p.row_pad != nullptr && p.row_pad[rowc] != 0;
-    const float rstd = p.rstd[rowc];
+    float rstd = p.rstd[rowc];
+    // (everything that is loaded is waited for HERE, in front of the first DMA issue: a compiler-placed wait at a later first use
+    // would be vmcnt(0) and drain the ring's prefetch - the compiler does not count the inline-asm DMA instructions)
+    const uint64_t key = p.thr ? ttsmi_drop_key(p.seed, p.step_dev, p.site) : 0;
+    asm volatile("" : "+v"(rstd));
     for (int i = tid * 4; i < CH_D; i += 512 * 4) *reinterpret_cast<float4*>(gam + i) = *reinterpret_cast<const float4*>(p.gamma + i);
 #pragma unroll
     for (int s = 0; s < CH_NRING - 1; ++s) {
@@ -122,9 +126,18 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     int S = 0;
     unsigned char* slot = scr + wave * C16_SLOT_BYTES;
     const long tile16 = min(row0, p.M - 1) >> 4;         // the wave's 16-row tile (the bit words are laid out per tile; clamped past M)
+    static_assert(C16B_CTX_STAGES >= CH_NRING - 1, "the chunk loop's counted wait for the ReLU word assumes a DMA issue in every one of its stages");
+    const uint16_t* bitp = p.bits16 + tile16 * p.nchunk * 64 + lane;
     for (int c = 0; c < p.nchunk; ++c) {
+        // The chunk's ReLU word.  A compiler-tracked load here costs a full drain: the compiler does not see the LDS-DMA
+        // instructions (inline asm), so its wait in front of the first use is vmcnt(0) - behind the stage that has just
+        // put four more DMA pieces in flight.  Issued by hand in front of the stage's barrier and waited for with the count
+        // of what is younger than it (exactly this stage's four DMA pieces; the chunk loop never runs out of stages to
+        // fetch, see the assert), it costs nothing.
+        uint32_t bits;
+        asm volatile("global_load_ushort %0, %1, off" : "=v"(bits) : "v"(bitp) : "memory");
+        bitp += 64;
         const unsigned char* Fs = stage_begin(S);
-        const uint32_t bits = p.bits16[(tile16 * p.nchunk + c) * 64 + lane];
         f32x4v H[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -133,6 +146,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         c16_stage(Fs, [&](int g, int i, const bf16x8& a) { H[i & 3] = C16_MFMA(a, DF[2 * g + (i >> 2)], H[i & 3]); },
                   [&](int g) { issue2(S + CH_NRING - 1, g); });
         ++S;
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(bits) : "n"(C16_NDMA) : "memory");
         bf16x8 hf[2];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -156,7 +170,6 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // ---- res-norm 1 backward on the wave's 16 rows (rowgemm.hip: rg_epilogue<1>, same arithmetic)
     bf16x8(&DO)[8] = DF;                                 // d_o's fragments take the registers of df's
     {
-        const uint64_t key = p.thr ? ttsmi_drop_key(p.seed, p.step_dev, p.site) : 0;
         const uint32_t rb = ttsmi_row_base(key, (uint32_t)rowc);
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -571,7 +571,8 @@ class ForwardTransformer:
             plan = self._plans[key] = ops.DenseBlockPlan(Pb, Gb, Sb, B, H, T, self.device,
                                                          self._plan_shared.setdefault((prefix, key[1]), {}), self.fuse_ln,
                                                          backward=backward, cap_rows=cap,
-                                                         chain=self.chain_blocks and self.residual_bf16)
+                                                         chain=self.chain_blocks and self.residual_bf16,
+                                                         wgrad_lane=1 if prefix.startswith('enc') and ops.WGRAD_LANES > 1 else 0)
         else:
             plan.rebind(B, T)
         return plan

@@ -585,12 +585,21 @@ class _WgradStream:
     per_device = {}
 
     @classmethod
-    def cur(cls) -> _WgradState:
-        d = torch.cuda.current_device()
-        st = cls.per_device.get(d)
+    def cur(cls, lane: int = 0) -> _WgradState:
+        """lane 0: the weight-gradient stream.  lane 1 (round 5, opt-in: TTSMI_WGRAD_LANES=2): a second one for the ENCODER
+        stack's blocks - backward reaches them last, while lane 0 is still working off the decoder's weight gradients.
+        Measured level to slightly slower (4.77 against 4.74 ms per step, three alternating pairs on one box:
+        profiles/r05_wgrad_lanes_ab.txt), so one lane stays the default."""
+        key = (torch.cuda.current_device(), int(lane))
+        st = cls.per_device.get(key)
         if st is None:
-            st = cls.per_device[d] = _WgradState()
+            st = cls.per_device[key] = _WgradState()
         return st
+
+    @classmethod
+    def lanes(cls):
+        d = torch.cuda.current_device()
+        return [st for (dev, _), st in cls.per_device.items() if dev == d]
 
 
 def enable_wgrad_stream(flag: bool = True):
@@ -623,6 +632,7 @@ def _on_wgrad_stream(fn, *inputs):
     W.pending = True
 
 
+WGRAD_LANES = int(os.environ.get('TTSMI_WGRAD_LANES', '1'))             # 2: the encoder stack's weight gradients on a second side stream (measured: 4.77 against 4.74 ms, profiles/r05_wgrad_lanes_ab.txt)
 _WGRAD_GENERIC = os.environ.get('TTSMI_WGRAD_GENERIC', '0') == '1'      # measurement knob: old submission path
 
 
@@ -660,11 +670,11 @@ def wgrad_rows_async(x, dy, dw, db, conv=None):
 
 
 def wgrad_join():
-    W = _WgradStream.cur()
-    if W.pending:
-        cur_stream().wait_stream(W.stream)
-        W.pending = False
-    W.keep.clear()
+    for W in _WgradStream.lanes():
+        if W.pending:
+            cur_stream().wait_stream(W.stream)
+            W.pending = False
+        W.keep.clear()
 
 
 def dense_wgrad(x, dy, dw, db, sh, dyT=None):
@@ -1780,13 +1790,14 @@ class DenseBlockPlan:
     length-bucketed training data almost every batch has its own (B, Tp, Tm), and a plan per exact shape meant a
     device synchronisation plus ~30 allocations per block on almost every step (round-2 advisor finding)."""
 
-    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True, backward=True, cap_rows=0, chain=False):
+    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True, backward=True, cap_rows=0, chain=False, wgrad_lane=0):
         """backward=False: a forward-only plan (inference) - the backward temporaries are not allocated.
         chain: the forward's row-local chain (o-projection + res-norm 1 -> FFN -> res-norm 2 -> the next block's qkv
         projection) as ONE launch (csrc/chain.hip, ttsmi_dense_block.chain_w) - training plans with fused LayerNorms and a
         bf16 residual stream only."""
         l = _lib.lib()
         self.backward = bool(backward)
+        self.wgrad_lane = int(wgrad_lane)         # which weight-gradient side stream this block's launches go to (_WgradStream.cur)
         d = P['wqkv'].shape[0]
         F = P['ffn.w1'].shape[1]
         cap = self.cap = max(int(cap_rows), B * T)
@@ -2018,14 +2029,14 @@ class DenseBlockPlan:
         D = self.desc
         need = self.wgrad_need if need is None else max(int(need), self.wgrad_need)
         if _WgradStream.enabled:
-            W = _WgradStream.cur()
+            W = _WgradStream.cur(self.wgrad_lane)
             if W.stream is None:
                 W.stream = torch.cuda.Stream(priority=_WGRAD_PRIO)
             if W.handle is None:
                 W.handle = W.stream.cuda_stream
             if W.ws is None or W.ws.numel() < need:
                 with torch.cuda.stream(W.stream):
-                    W.ws = torch.empty(int(max(need, 1 << 26)), dtype=torch.uint8, device=device)
+                    W.ws = torch.empty(int(max(need, 1 << 26 if self.wgrad_lane == 0 else 0)), dtype=torch.uint8, device=device)
             D.side_stream, D.wgrad_ws, D.wgrad_ws_bytes = W.handle, W.ws.data_ptr(), W.ws.numel()
             W.pending = True
         else:
