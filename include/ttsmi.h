@@ -599,7 +599,7 @@ typedef struct ttsmi_dense_block {
     int32_t qkv_done;
     int32_t chain_pad_;
     /* the backward chain (ttsmi_dense_chain_bwd): with chain_bw set (chain_w required; the forward then writes relu_bits in the
-     * backward chain's lane layout, so relu_bits must hold ttsmi_dense_chain_bits_bytes(B * T, F)) the FFN2 dgrad, the FFN1
+     * backward chain's lane layout - the same ttsmi_relu_bits_bytes(B * T, F) bytes hold it) the FFN2 dgrad, the FFN1
      * dgrad + res-norm 1 backward and the dctx product of ttsmi_dense_block_bwd run as ONE launch on the weight stream
      * chain_bw (ttsmi_dense_chain_bwd_pack of w1_b / w2_b / wo_b). */
     const void* chain_bw;

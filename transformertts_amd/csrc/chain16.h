@@ -113,10 +113,10 @@ __device__ __forceinline__ void c16_bias_init(f32x4v (&Z)[16], const float* bias
 // (fragment kb = tiles 2 kb, 2 kb + 1); Y: the result's fragments (may alias R).
 template <bool Y32>
 __device__ __forceinline__ void c16_layernorm(f32x4v (&Z)[16], const bf16x8 (&R)[8], bf16x8 (&Y)[8], const ChainP& p, const float* gamma,
-                                              const float* beta, uint32_t site, int row, int rowc, int row0, bool padded,
+                                              const float* beta, uint64_t drop_base, uint32_t site, int row, int rowc, int row0, bool padded,
                                               unsigned char* slot, int lane, uint16_t* y_bf, uint16_t* xhat, float* rstd_out, float* y32) {
     const int t = lane & 15, kg = lane >> 4;
-    const uint64_t key = p.thr ? ttsmi_drop_key(p.seed, p.step_dev, site) : 0;
+    const uint64_t key = p.thr ? ttsmi_drop_key_of(drop_base, site) : 0;
     const uint32_t rb = ttsmi_row_base(key, (uint32_t)rowc);
     float sum4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -296,6 +296,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #undef C16_XFRAGS
     }
     const bool padded = p.row_pad != nullptr && p.row_pad[rowc] != 0;
+    const uint64_t drop_base = p.thr ? ttsmi_drop_base(p.seed, p.step_dev) : 0;      // (read here, in front of the first DMA issue)
     {
         auto stage_vec = [&](const float* src, int off, int n) {
             for (int i = tid * 4; i < n; i += 512 * 4) *reinterpret_cast<float4*>(par + off + i) = *reinterpret_cast<const float4*>(src + i);
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             ch_lds_fence();
         }
         C16_STAMP();
-        c16_layernorm<Y32>(Z, Y, Y, p, par + (half ? CH_P_G2 : CH_P_G1), par + (half ? CH_P_BE2 : CH_P_BE1), half ? p.site_ln2 : p.site_ln1, row,
+        c16_layernorm<Y32>(Z, Y, Y, p, par + (half ? CH_P_G2 : CH_P_G1), par + (half ? CH_P_BE2 : CH_P_BE1), drop_base, half ? p.site_ln2 : p.site_ln1, row,
                            rowc, row0, padded, slot, lane, half ? p.out_bf : p.a_bf, half ? p.xhat2 : p.xhat1, half ? p.rstd2 : p.rstd1,
                            half ? p.out32 : nullptr);
         C16_STAMP();

@@ -196,9 +196,16 @@ __device__ __forceinline__ uint32_t ttsmi_mix32(uint32_t h) {
 }
 // The host seed is advanced by a DEVICE step counter so that a captured hipGraph draws fresh masks
 // on every replay (kernel arguments are frozen at capture).
+// (two steps for kernels with more than one site: the step counter is read once, early - a load in the middle of a kernel
+// that feeds LDS by inline-asm DMA makes the compiler wait for EVERYTHING in flight, it does not count those instructions)
+__device__ __forceinline__ uint64_t ttsmi_drop_base(uint64_t seed, const int64_t* step_dev) {
+    return step_dev ? seed + 0xA0761D6478BD642Full * (uint64_t)(*step_dev) : seed;
+}
+__device__ __forceinline__ uint64_t ttsmi_drop_key_of(uint64_t base, uint32_t site) {
+    return ttsmi_mix64(base + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1));
+}
 __device__ __forceinline__ uint64_t ttsmi_drop_key(uint64_t seed, const int64_t* step_dev, uint32_t site) {
-    uint64_t s = step_dev ? seed + 0xA0761D6478BD642Full * (uint64_t)(*step_dev) : seed;
-    return ttsmi_mix64(s + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1));
+    return ttsmi_drop_key_of(ttsmi_drop_base(seed, step_dev), site);
 }
 __device__ __forceinline__ uint32_t ttsmi_row_base(uint64_t key, uint32_t row) {
     return ttsmi_mix32(row ^ (uint32_t)key) + (uint32_t)(key >> 32);

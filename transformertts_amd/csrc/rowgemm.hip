@@ -132,9 +132,32 @@ __device__ __forceinline__ void rg_prefetch(const RowGemmP& p, int m0, int wave,
 
 // NJ = 32-column blocks of a wave's accumulator tile (4: waves 2-wide over the 256 columns; 2: 4-wide)
 // W64: the wave's tile is 64 rows x 64 columns = acc[mi * 2 + nj] (wm = row half, wc = column quarter) instead of 32 x NJ*32
+// What the epilogue needs that does not depend on the tile: the dropout key of the launch (one load of the step counter) and this
+// lane's four columns of bias / gamma / beta.  The LDS-DMA kernel requests them in FRONT of its first DMA issue: asked for in
+// the epilogue they were two dependent memory round trips (counter -> wait -> vectors -> wait) at the end of every workgroup.
+struct RgConst {
+    uint64_t key_in;
+    float4 bs, gm, bt;
+};
+template <int EPI>
+__device__ __forceinline__ RgConst rg_const(const RowGemmP& p, int lane) {
+    RgConst c;
+    const int c4 = lane * 4;
+    c.key_in = p.thr_in ? ttsmi_drop_key(p.seed, p.step_dev, p.site_in) : 0;
+    c.gm = *reinterpret_cast<const float4*>(p.gamma + c4);
+    if constexpr (EPI == 0) {
+        c.bs = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        c.bt = *reinterpret_cast<const float4*>(p.beta + c4);
+    } else {
+        c.bs = make_float4(0.f, 0.f, 0.f, 0.f);
+        c.bt = c.bs;
+    }
+    return c;
+}
+
 template <int EPI, int NW, int BM, int RT, int NJ = 4, bool W64 = false>
 __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ], int m0, float* Z, int wave, int wm, int wc,
-                                            int lane, const RgPre<EPI, BM / NW, RT>& pre) {
+                                            int lane, const RgPre<EPI, BM / NW, RT>& pre, const RgConst& ec) {
     const int l31 = lane & 31, hh = lane >> 5;
     // ---- accumulators -> Z (all waves finished reading the operand stages: the caller synchronised)
     if constexpr (W64) {
@@ -161,12 +184,10 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
     __syncthreads();
     constexpr int RPW = BM / NW;                       // rows per wave
     const int c4 = lane * 4;
-    const uint64_t key_in = p.thr_in ? ttsmi_drop_key(p.seed, p.step_dev, p.site_in) : 0;
+    const uint64_t key_in = ec.key_in;
     const float invC = 1.0f / (float)RG_N;
     if constexpr (EPI == 0) {
-        const float4 bs = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c4);
-        const float4 bt = *reinterpret_cast<const float4*>(p.beta + c4);
+        const float4 bs = ec.bs, gm = ec.gm, bt = ec.bt;
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int rl = wave * RPW + i, row = m0 + rl;
@@ -207,7 +228,7 @@ __device__ __forceinline__ void rg_epilogue(const RowGemmP& p, f32x16 (&acc)[NJ]
     } else {
         // dy = acc + partial;  g = dy * rowmask;  t = g * gamma;  dz = rstd (t - mean(t) - x^ mean(t x^));
         // d_o = keep(dz) (bf16), dres = dz (fp32); dgamma += g x^, dbeta += g summed over the tile's rows
-        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c4);
+        const float4 gm = ec.gm;
         float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
         const uint2 (&xs)[RPW] = pre.xs;
 #pragma unroll
@@ -326,7 +347,8 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(RowGemmP p) {
 
     RgPre<EPI, RG_BM / 4, RT> pre;
     rg_prefetch<EPI, 4, RG_BM, RT>(p, m0, wave, lane, pre);
-    rg_epilogue<EPI, 4, RG_BM, RT>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
+    const RgConst ec = rg_const<EPI>(p, lane);
+    rg_epilogue<EPI, 4, RG_BM, RT>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre, ec);
 }
 
 // =================================================================================================
@@ -370,6 +392,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
     const int wm = W64 ? wave >> 2 : (BM == 128 ? wave >> 1 : wave >> 2), wc = W64 ? wave & 3 : (BM == 128 ? wave & 1 : wave & 3);
     const int m0 = blockIdx.x * BM;
     const int nk = p.K / RG_BK;
+    const RgConst ec = rg_const<EPI>(p, lane);          // (older than every DMA instruction: the counted waits below are unaffected)
 
     f32x16 acc[NJ];
 #pragma unroll
@@ -478,7 +501,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_dma_kernel(RowGemmP p) {
     }
     __syncthreads();
     if (TTSMI_ABLATE_BITS(p.ablate) & 4) return;
-    rg_epilogue<EPI, 8, BM, RT, NJ, W64>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre);
+    rg_epilogue<EPI, 8, BM, RT, NJ, W64>(p, acc, m0, reinterpret_cast<float*>(smem), wave, wm, wc, lane, pre, ec);
 }
 
 // ---- standalone backward of a LayerNorm whose forward kept x^ (bf16) and rstd: the fused forward's counterpart for the
