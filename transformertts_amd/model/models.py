@@ -44,6 +44,7 @@ _BWD_SAME_THREAD = os.environ.get('TTSMI_BWD_SAME_THREAD', '0') == '1'
 # A/B knob: 0 = the per-layer path (conv blocks) leaves the sums of multiply-used tensors' gradients to autograd
 _GRAD_SINK = os.environ.get('TTSMI_GRAD_SINK', '1') == '1'
 _DROPBITS_CONV = os.environ.get('TTSMI_ATTN_DROPBITS_CONV', '0') == '1'
+_CHAIN_PREPACK = os.environ.get('TTSMI_CHAIN_PREPACK', '1') != '0'      # 0: the chain kernels' weight streams are packed in line (A/B knob)
 
 
 def _on_device(fn):
@@ -790,6 +791,30 @@ class ForwardTransformer:
                 if ev is not None:
                     ev.record(side)
 
+    def _launch_chain_packs(self):
+        """The chain kernels' weight streams (ops.DenseBlockPlan.ensure_packed: 12 launches of ~3 us per step, one after the
+        other in front of the decoder stack) repacked on the side stream instead, under the encoder's small launches: the
+        plans that ran their chains in the previous step are packed for this step's weights now, and the main stream waits
+        for one event when the first of them is reached.  A plan that is new, or whose shape falls under the row threshold
+        this time, takes the in-line path as before."""
+        if not (_CHAIN_PREPACK and self.chain_blocks and self.planned_blocks) or torch.cuda.is_current_stream_capturing():
+            return
+        todo = [pl for pl in self._plans.values() if pl.chain_on and pl.backward and pl.packed_ver != self._weights_version]
+        if not todo:
+            return
+        main = ops.cur_stream()
+        if self._pred_stream is None:
+            self._pred_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('TTSMI_PRED_PRIO', '0')))
+        side = self._pred_stream
+        side.wait_stream(main)                 # the refreshed bf16 shadows, and the previous step's readers of the old streams
+        with ops.on_stream(side):
+            for pl in todo:
+                pl.ensure_packed(self._weights_version)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for pl in todo:
+            pl.pack_ev = ev
+
     MAP_RING_DEPTH = 2
     MAP_RING_SHAPES = 8        # (block, B, H, T) entries kept per block: ragged batches bring a new shape almost every step
 
@@ -861,6 +886,7 @@ class ForwardTransformer:
         ra = self.reference_outputs if self.return_attention is None else self.return_attention
         with ops.pinned_stream():
             self._launch_dropmasks(int(x.shape[0]), int(x.shape[1]), mel_len, float(self.config['dropout_rate']))
+            self._launch_chain_packs()
             self._use_plans = self.planned_blocks
             self._map_ring_on = bool(ra) and self.map_ring and not torch.cuda.is_current_stream_capturing()
             try:

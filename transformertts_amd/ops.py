@@ -1797,6 +1797,7 @@ class DenseBlockPlan:
         bf16 residual stream only."""
         l = _lib.lib()
         self.backward = bool(backward)
+        self.pack_ev = None                       # event of a weight-stream pack issued ahead of this step on a side stream
         self.wgrad_lane = int(wgrad_lane)         # which weight-gradient side stream this block's launches go to (_WgradStream.cur)
         d = P['wqkv'].shape[0]
         F = P['ffn.w1'].shape[1]
@@ -1979,7 +1980,11 @@ class DenseBlockPlan:
         if not self.chain_on:
             return
         if self.packed_ver == version and not torch.cuda.is_current_stream_capturing():
+            ev, self.pack_ev = self.pack_ev, None
+            if ev is not None:                    # packed ahead on a side stream (ForwardTransformer._launch_chain_packs)
+                cur_stream().wait_event(ev)
             return
+        self.pack_ev = None
         S, nxt = self.S, self.chain_next
         check(_lib.lib().ttsmi_dense_chain_pack(_p(S['wo'].wt), _p(S['ffn.w1'].wt), _p(S['ffn.w2'].wt),
                                                 _p(nxt.S['wqkv'].wt) if nxt is not None else None, self.F,
