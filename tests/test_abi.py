@@ -123,3 +123,25 @@ def test_a_stale_library_is_refused_and_the_override_needs_an_opt_in(tmp_path):
     env['TTSMI_ALLOW_LIB_OVERRIDE'] = '1'
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.split('\n')
     assert out[0] == str(so) and out[1] == 'REFUSED True', out
+
+
+def test_every_included_header_is_a_build_dependency_and_part_of_the_digest():
+    """A header that a source includes but the build does not list neither triggers a rebuild nor moves the library digest
+    (round 5: csrc/chain16b.h was edited, the library stayed the old one and a GPU session measured it).  Every quoted
+    #include of csrc/ must resolve to a file in build._headers(), and every source must be in build.SOURCES."""
+    import re
+    from transformertts_amd import build
+    csrc = build.CSRC
+    listed = {os.path.realpath(h) for h in build._headers()}
+    files = [f for f in os.listdir(csrc) if f.endswith(('.hip', '.cpp', '.h'))]
+    assert {f for f in files if f.endswith(('.hip', '.cpp'))} == set(build.SOURCES)
+    for f in files:
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(os.path.join(csrc, f)).read(), re.M):
+            cands = [os.path.join(csrc, inc), os.path.join(csrc, '..', '..', 'include', inc)]
+            hit = [os.path.realpath(c) for c in cands if os.path.exists(c)]
+            assert hit, f'{f}: #include "{inc}" not found'
+            assert hit[0] in listed, f'{f} includes {inc}, which is not a build dependency'
+    # the digest moves with a header: same inputs plus one byte
+    base = build.library_digest()
+    extra = build._digest([os.path.join(csrc, s) for s in build.SOURCES] + build._headers() + [__file__])[:16]
+    assert base != extra and len(base) == 16
