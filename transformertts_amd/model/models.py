@@ -235,7 +235,7 @@ class ForwardTransformer:
         self._use_plans, self._plans, self._plan_shared, self._plans_grown = False, {}, {}, {}
         # the forward's row-local chain of every planned dense block (o-projection + res-norm 1 -> FFN -> res-norm 2 -> the next
         # block's qkv projection) as ONE launch (csrc/chain.hip, chain16.h) instead of four, from ops.CHAIN_MIN_ROWS rows on
-        # (decoder-size batches: 4.88 against 5.00 ms per step, round 5); chain_blocks=False / TTSMI_DENSE_CHAIN=0: always
+        # (decoder-size batches: 4.71 against 4.94 ms per step on the final build of round 5); chain_blocks=False / TTSMI_DENSE_CHAIN=0: always
         # the four launches
         self.chain_blocks = bool(kwargs.get('chain_blocks', os.environ.get('TTSMI_DENSE_CHAIN', '1') != '0'))
         self._weights_version = 0

@@ -1979,12 +1979,11 @@ class DenseBlockPlan:
         shadows are refreshed).  Under stream capture the pack launch is always issued, so that a replayed step repacks."""
         if not self.chain_on:
             return
+        ev, self.pack_ev = self.pack_ev, None
+        if ev is not None:                        # packed ahead on a side stream (ForwardTransformer._launch_chain_packs): the
+            cur_stream().wait_event(ev)           # consumer waits for it - and so does an in-line repack of the same buffers
         if self.packed_ver == version and not torch.cuda.is_current_stream_capturing():
-            ev, self.pack_ev = self.pack_ev, None
-            if ev is not None:                    # packed ahead on a side stream (ForwardTransformer._launch_chain_packs)
-                cur_stream().wait_event(ev)
             return
-        self.pack_ev = None
         S, nxt = self.S, self.chain_next
         check(_lib.lib().ttsmi_dense_chain_pack(_p(S['wo'].wt), _p(S['ffn.w1'].wt), _p(S['ffn.w2'].wt),
                                                 _p(nxt.S['wqkv'].wt) if nxt is not None else None, self.F,
