@@ -56,3 +56,22 @@ def test_attention_valu_roofs_are_added_to_a_per_kernel_table_and_never_raise():
     t2 = {bench.HATTN_FWD: {'gflop': 1.0, 'ms': 1.0}}
     bench.add_attention_valu_roofs(t2, ref_cfg)                              # dh = 192: the counts are not its kernels'
     assert 'valu_roof_frac' not in t2[bench.HATTN_FWD]
+
+
+def test_every_launch_group_the_block_launcher_announces_has_a_family_in_the_bench_table():
+    """The C++ block launcher names its launches to the profiling observer (OBS("...") in csrc/dense_block.hip); bench.py sorts
+    them into kernel families by that name (OBSERVED) and everything it does not know lands in the riders' bucket.  A new
+    launch group (round 5: the two chain entry points) must be sorted on purpose: either a family, or the explicit list of
+    HBM-bound riders here.  The PMC table must know every family that has kernels of its own."""
+    import bench
+    src = open(os.path.join(ROOT, 'transformertts_amd', 'csrc', 'dense_block.hip')).read()
+    announced = set(re.findall(r'OBS\("([a-z0-9_]+)"', src))
+    assert {'ttsmi_dense_chain_fwd', 'ttsmi_dense_chain_bwd', 'ttsmi_attention_bwd', 'ttsmi_hgemm_ln_bwd'} <= announced
+    riders_on_purpose = {'ttsmi_layernorm_bwd_xhat'}
+    unsorted = announced - set(bench.OBSERVED) - riders_on_purpose
+    assert not unsorted, f'launch groups without a kernel family in bench.OBSERVED: {sorted(unsorted)}'
+    assert bench.OBSERVED['ttsmi_dense_chain_fwd'] == bench.OBSERVED['ttsmi_dense_chain_bwd'] == bench.CHAIN
+    for fam in set(bench.OBSERVED.values()):
+        assert fam in bench.PMC_KERNELS, f'no rocprof kernel names for the family {fam[:40]}...'
+    names, helpers = bench.PMC_KERNELS[bench.CHAIN]
+    assert 'dense_chain16_bwd_kernel' in names and 'dense_chain16_pack_kernel' in helpers
