@@ -35,12 +35,14 @@
 extern "C" {
 #endif
 
-/* Bumped whenever an entry point's argument list or the ttsmi_dense_block layout changes (101: round 3's `denom` argument of
- * ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102: round 4; 103: ttsmi_mel_nnls added; 104: the shifted-rows taps of the conv weight gradient; 105: round 5 - ttsmi_dense_chain_* and the chain tail of ttsmi_dense_block; 106: the backward chain (ttsmi_dense_chain_bwd*, chain_bw, relu_bits_layout);
- * (104 continued:) the shifted-rows taps of
- * ttsmi_hgemm_wgrad_rows, which the conv stacks of the host mirror now call).  Bindings check it at load
- * time (transformertts_amd/_lib.py) so that a stale build is refused instead of being called with shifted arguments. */
-#define TTSMI_VERSION 106
+/* Bumped whenever an entry point's argument list or the ttsmi_dense_block layout changes.  History: 101 round 3's `denom`
+ * argument of ttsmi_l1_losses_weighted and the res16 / relu_bits tail of ttsmi_dense_block; 102 round 4; 103 ttsmi_mel_nnls
+ * added; 104 the shifted-rows taps of ttsmi_hgemm_wgrad_rows (the conv weight gradient, which the conv stacks of the host
+ * mirror call); 105 round 5 - ttsmi_dense_chain_* and the chain tail of ttsmi_dense_block; 106 the backward chain
+ * (ttsmi_dense_chain_bwd*, chain_bw, relu_bits_layout); 107 round 6 - ttsmi_dense_chain_bwd_nparts,
+ * ttsmi_dense_block_bwd_chained.  Bindings check it at load time (transformertts_amd/_lib.py) so that a stale build is
+ * refused instead of being called with shifted arguments. */
+#define TTSMI_VERSION 107
 
 enum {
     TTSMI_OK = 0,
@@ -666,6 +668,9 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
  * ttsmi_hgemm_ln_bwd_dual_h + the dctx GEMM of ttsmi_dense_block_bwd (same results up to fp32 summation order). */
 size_t ttsmi_dense_chain_bwd_pack_bytes(int F);
 int ttsmi_dense_chain_bwd_supported(int M, int d, int F);
+/* rows of dgamma / dbeta partials ttsmi_dense_chain_bwd leaves in part_ws (one per 128-row workgroup): the `nw` of the
+ * reduction that follows (ttsmi_layernorm_param_reduce_batched_nw) */
+int ttsmi_dense_chain_bwd_nparts(int M);
 int ttsmi_dense_chain_bwd_pack(const uint16_t* w1_b, const uint16_t* w2_b, const uint16_t* wo_b, int F, void* out, size_t out_bytes,
                                ttsmi_stream_t stream);
 int ttsmi_dense_chain_bwd(const uint16_t* df, const uint16_t* da, const uint16_t* xhat1, const float* rstd1, const float* ln1_g,
@@ -678,6 +683,10 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* desc, const float* h, const u
  * LayerNorm parameter-gradient partials in ln_ws1 / ln_ws2 for ttsmi_layernorm_param_reduce_batched.
  * The caller joins side_stream before it reads the weight gradients. */
 int ttsmi_dense_block_bwd(const ttsmi_dense_block* desc, const float* h, const uint16_t* h_bf, const float* dout);
+/* 1 when ttsmi_dense_block_bwd(desc) will take the backward chain (chain_bw, chain_w, fuse_ln, res16, relu_bits set, the
+ * shape supported, TTSMI_WGRAD_EVENTS at its default): lnp_ws1 then holds ttsmi_dense_chain_bwd_nparts(B * T) partial rows,
+ * otherwise ttsmi_hgemm_ln_bwd_nparts(B * T).  ttsmi_dense_block_fwd asks the same predicate for the ReLU bit layout. */
+int ttsmi_dense_block_bwd_chained(const ttsmi_dense_block* desc);
 /* A whole STACK of n consecutive dense blocks (SelfAttentionBlocks.call's loop over its dense blocks, model/layers.py:
  * 303-306) from one call: block i reads block i - 1's out / out_bf, the backward walks n - 1 .. 0 and hands block i + 1's
  * dh to block i as its dout (ignored by a chained block, see `below`).  Exactly the launches, in exactly the order, of n

@@ -178,6 +178,37 @@ def test_chained_blocks_equal_the_four_launch_blocks_at_the_benchmarked_architec
     assert float(d.max()) <= 8.5e-4 and float(d.mean()) < 1.5e-4, (float(d.max()), float(d.mean()))
 
 
+def test_chained_blocks_layernorm_parameter_gradients_below_the_row_threshold(monkeypatch):
+    """Advisor finding of round 5: the backward chain leaves one dgamma / dbeta partial row per 128-row workgroup while the
+    reducer was told the full-row GEMM's count (64-row tiles below 16 257 rows) - with the chain forced on at small row
+    counts ln1.gamma / ln1.beta gradients summed the wrong rows.  One forward + backward, dropout off, chain against
+    four launches: every LayerNorm parameter gradient agrees to bf16-path noise (the bug gave O(1) relative errors)."""
+    from oracle import ft_oracle as fo
+    from transformertts_amd.model.models import ForwardTransformer
+    from transformertts_amd import ops
+    cfg = dict(fo.make_config(), dropout_rate=0.0, predictors_dropout=0.0, seed=3, precision='bf16')
+    batch = fo.synthetic_batch(4, 120, 500, seed=21, ragged=True)       # 480 / 2 000 rows: 64-row tiles in the full-row kernels
+    monkeypatch.setattr(ops, 'CHAIN_MIN_ROWS', 0)
+    grads = {}
+    for chain in (True, False):
+        m = ForwardTransformer.from_config(dict(cfg, chain_blocks=chain))
+        m._compile(learning_rate=0.0)
+        m.train_step(*batch)
+        torch.cuda.synchronize()
+        pl = [pl for (name, mode), pl in m._plans.items() if mode == 'bwd']
+        assert pl and all(p.chain_on == chain for p in pl)
+        if chain:
+            l = ops._lib.lib()
+            assert any(p.lnp_nw1 == l.ttsmi_dense_chain_bwd_nparts(p.M) != p.lnp_nw1_rowgemm for p in pl)
+        grads[chain] = {k: v.clone() for k, v in m.params.g.items() if '.ln' in k}
+    worst = {}
+    for k, a in grads[True].items():
+        b = grads[False][k]
+        worst[k] = float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+    bad = {k: v for k, v in worst.items() if v > 5e-2}
+    assert not bad, bad
+
+
 def _lane_bits(pos):
     """(h1 > 0) [M, F] in the chains' lane layout (csrc/chain16b.h): 16-bit word (row // 16, 64-feature chunk, lane) with
     lane = (row % 16) + 16 kg, bit 4 u + r = feature 64 chunk + 16 u + 4 kg + r."""

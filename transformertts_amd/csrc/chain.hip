@@ -700,6 +700,9 @@ size_t ttsmi_dense_chain_bwd_pack_bytes(int F) { return F > 0 && F % 64 == 0 ? (
 
 int ttsmi_dense_chain_bwd_supported(int M, int d, int F) { return chain_form() == 16 && ttsmi_dense_chain_supported(M, d, F) && M >= 1; }
 
+/* rows of dgamma / dbeta partials ttsmi_dense_chain_bwd leaves in part_ws: one per 128-row workgroup */
+int ttsmi_dense_chain_bwd_nparts(int M) { return ttsmi_cdiv(M, C16_ROWS); }
+
 /* w1_b [256][F], w2_b [F][256], wo_b [512][256]: the weights AS STORED (bf16 shadows) */
 int ttsmi_dense_chain_bwd_pack(const uint16_t* w1_b, const uint16_t* w2_b, const uint16_t* wo_b, int F, void* out, size_t out_bytes,
                                ttsmi_stream_t stream) {
@@ -728,7 +731,7 @@ int ttsmi_dense_chain_bwd(const uint16_t* df, const uint16_t* da, const uint16_t
     TTSMI_CHECK_ARG(ttsmi_dense_chain_bwd_supported(M, CH_D, F), "dense_chain_bwd: unsupported shape M=%d F=%d (or TTSMI_DENSE_CHAIN_FORM=32)", M, F);
     TTSMI_CHECK_ARG(wpack_bytes >= ttsmi_dense_chain_bwd_pack_bytes(F), "dense_chain_bwd: weight stream too short");
     TTSMI_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dense_chain_bwd: bad dropout rate");
-    const int nparts = ttsmi_cdiv(M, C16_ROWS);
+    const int nparts = ttsmi_dense_chain_bwd_nparts(M);
     TTSMI_CHECK_ARG(part_ws_bytes >= ttsmi_layernorm_partials_bytes(nparts, CH_D), "dense_chain_bwd: partial-sum workspace too small");
     TTSMI_CHECK_ARG(((((uintptr_t)df) | ((uintptr_t)da) | ((uintptr_t)xhat1) | ((uintptr_t)wpack) | ((uintptr_t)dh1) | ((uintptr_t)d_o) |
                       ((uintptr_t)dres) | ((uintptr_t)dctx) | ((uintptr_t)ln1_g) | ((uintptr_t)part_ws)) & 15) == 0 &&

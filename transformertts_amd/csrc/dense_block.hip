@@ -36,6 +36,20 @@ static bool relu_bits(const ttsmi_dense_block* D) {
     return D->relu_bits != nullptr && D->fuse_ln && D->d == 256 && ttsmi_hgemm_k256_eligible(D->B * D->T, D->F, D->d);
 }
 
+// TTSMI_WGRAD_EVENTS (A/B knob, read once): 2 / 1 = "lazy" hand-offs to the weight-gradient stream (dense_block_bwd_impl)
+static bool lazy_wgrad_events() {
+    TTSMI_KNOB(wev, "TTSMI_WGRAD_EVENTS", 4);
+    return wev == 2 || wev == 1;
+}
+// THE predicate of the backward chain (csrc/chain16b.h): the forward asks it to choose the ReLU bit layout it writes, the
+// backward to choose its path, the host (ttsmi_dense_block_bwd_chained) to size the LayerNorm-partial reduction - one
+// definition, so the three cannot disagree (advisor findings, round 5: the forward used to look at chain_bw alone and
+// wrote the lane layout for a backward that then read it as the bit matrix under TTSMI_WGRAD_EVENTS=1/2).
+static bool chain_bw_path(const ttsmi_dense_block* D) {
+    return D->chain_bw != nullptr && D->chain_w != nullptr && D->fuse_ln && D->res16 != 0 && !lazy_wgrad_events() &&
+           D->relu_bits != nullptr && ttsmi_dense_chain_bwd_supported(D->B * D->T, D->d, D->F);
+}
+
 static int check_desc(const ttsmi_dense_block* D, const char* who) {
     TTSMI_CHECK_ARG(D, "%s: null descriptor", who);
     TTSMI_CHECK_ARG(D->B > 0 && D->H > 0 && D->T > 0 && D->d > 0 && D->F > 0 && D->d % D->H == 0,
@@ -58,6 +72,9 @@ static thread_local hipEvent_t t_armed = nullptr, t_prerecorded = nullptr;
 // (a stream that is being captured into a hipGraph takes the ordinary event record: the graph's cross-stream edge is
 // built from hipEventRecord / hipStreamWaitEvent pairs, a kernel's stop event is not captured as a dependency)
 static thread_local bool t_capturing = false;
+// the block whose qkv projection the last forward chain of this thread computed (ttsmi_dense_block.above): consumed by that
+// block's own forward, which then skips its projection
+static thread_local const ttsmi_dense_block* t_qkv_written_for = nullptr;
 static void note_capture(const ttsmi_dense_block* D) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     t_capturing = hipStreamIsCapturing((hipStream_t)D->main_stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
@@ -78,6 +95,12 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
     ttsmi_stream_t st = D->main_stream;
     // qkv = h.Wqkv + b                                                     (layers.py:116-118, fused)
     // (qkv_done: written by the row-local chain of the block below, whose `above` is this descriptor)
+    // ... and only then: a descriptor whose qkv_done survived a rebind, or that is run out of order, would attend over stale qkv
+    // without any error (advisor finding, round 5) - the chain that writes a block's qkv leaves its descriptor's address here
+    if (D->qkv_done) {
+        TTSMI_CHECK_ARG(t_qkv_written_for == D, "dense_block_fwd: qkv_done is set but the block below did not just run its chain into this block");
+        t_qkv_written_for = nullptr;
+    }
     if (!D->qkv_done) {
       OBS("ttsmi_hgemm_tn", 2.0 * M * 3 * d * d, gemm_bytes(M, 3 * d, d, 2, false), st);
       TRY(ttsmi_hgemm_tn(h_bf, 0, d, nullptr, 0, 0, D->wqkv_t, d, D->bqkv, nullptr, 0, D->qkv, 3L * d, M, 3 * d, d,
@@ -110,7 +133,8 @@ int ttsmi_dense_block_fwd(const ttsmi_dense_block* D, const float* h, const uint
             (double)M * 2 * (2.0 * d + 4.0 * d + F + (A ? 3.0 * d : 0.0)) + ((D->res16 & 2) ? 4.0 * M * d : 0.0) +
                 (relu_bits(D) ? (double)M * F / 8 : 0.0) + wbytes + 8.0 * M, st);
         // (chain_bw: the backward runs as a chain too and reads the ReLU pattern in the chain's own lane layout)
-        const bool lane_bits = D->chain_bw != nullptr && D->relu_bits != nullptr;
+        const bool lane_bits = chain_bw_path(D);
+        t_qkv_written_for = A;
         return ttsmi_dense_chain_fwd(h_bf, D->cx, D->chain_w, D->chain_w_bytes, M, F, D->bo, D->ln1_g, D->ln1_b, D->b1, D->b2, D->ln2_g,
                                      D->ln2_b, A ? A->bqkv : nullptr, D->pad, D->rate, D->seed, D->step_dev, D->site_ln1, D->site_ln2,
                                      kLnEps, D->a_bf, D->xhat1, D->rstd1, D->h1,
@@ -277,6 +301,10 @@ int ttsmi_dense_block_bwd(const ttsmi_dense_block* D, const float* h, const uint
     return rc;
 }
 
+/* 1 when ttsmi_dense_block_bwd(D) will run the backward chain (its res-norm 1 parameter partials are then
+ * ttsmi_dense_chain_bwd_nparts(B * T) rows in lnp_ws1, otherwise ttsmi_hgemm_ln_bwd_nparts(B * T)). */
+int ttsmi_dense_block_bwd_chained(const ttsmi_dense_block* D) { return D != nullptr && chain_bw_path(D) ? 1 : 0; }
+
 }  // extern "C"
 
 static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, const uint16_t* h_bf, const float* dout) {
@@ -302,7 +330,7 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
     // backward - the full-row GEMM+LN kernels own a CU's LDS (144 KB), so a weight-gradient workgroup sitting on a CU
     // (48 KB) keeps their workgroups off it, while the attention kernels (19 KB, latency bound) share a CU with it
     TTSMI_KNOB(wev, "TTSMI_WGRAD_EVENTS", 4);
-    const bool lazy = wev == 2 || wev == 1;
+    const bool lazy = lazy_wgrad_events();
     const bool pre_attn = wev == 1;
     // ---- LN2 + FFN: df (bf16) = dLN2/dx, da (fp32) = dLN2/dres
     if (D->fuse_ln) {
@@ -324,8 +352,7 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
     if (!lazy) TRY(wgrad_side(D, &wb, 0, true, D->h1, F, D->df, d, D->g_w2, D->g_b2, F, d));
     // ---- the backward chain (csrc/chain16b.h): FFN2 dgrad + ReLU mask, FFN1 dgrad + res-norm 1 backward and the dctx product
     // in ONE launch; dh1 and d_o are written for the weight-gradient stream, nothing is read back
-    const bool chain_bw = D->chain_bw != nullptr && D->chain_w != nullptr && r16 && !lazy && D->relu_bits != nullptr &&
-                          ttsmi_dense_chain_bwd_supported(M, d, F);
+    const bool chain_bw = chain_bw_path(D);
     if (chain_bw) {
         { OBS("ttsmi_dense_chain_bwd", 2.0 * M * d * (2.0 * F + d),
               (double)M * 2 * (4.0 * d + F + 2.0 * d) + (double)M * F / 8 + (double)ttsmi_dense_chain_bwd_pack_bytes(F) + 4.0 * M, st);
@@ -469,6 +496,9 @@ static int check_stack(const ttsmi_dense_block* const* blocks, int n, const char
 
 int ttsmi_dense_stack_fwd(const ttsmi_dense_block* const* blocks, int n, const float* h, const uint16_t* h_bf) {
     TRY(check_stack(blocks, n, "dense_stack_fwd"));
+    for (int i = 0; i < n; ++i)        // a block that skips its qkv projection must sit right above the chain that wrote it
+        TTSMI_CHECK_ARG(!blocks[i]->qkv_done || (i > 0 && blocks[i - 1]->above == blocks[i] && blocks[i - 1]->chain_w != nullptr),
+                        "dense_stack_fwd: block %d has qkv_done set but block %d does not run a chain into it", i, i - 1);
     for (int i = 0; i < n; ++i) {
         TRY(ttsmi_dense_block_fwd(blocks[i], h, h_bf));
         h = blocks[i]->out;                       // (not written inside a res16 stack, and then not read either)

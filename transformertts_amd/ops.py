@@ -1924,7 +1924,8 @@ class DenseBlockPlan:
         # backward is where most of the gain is)
         self.fuse_ln = self.want_fuse and (self.backward or M >= FUSE_LN_MIN_ROWS_INFERENCE)
         D.fuse_ln = int(self.fuse_ln)
-        self.lnp_nw1, self.lnp_nw2 = int(l.ttsmi_hgemm_ln_bwd_nparts(M)), int(l.ttsmi_layernorm_bwd_xhat_nparts(M))
+        self.lnp_nw1_rowgemm, self.lnp_nw2 = int(l.ttsmi_hgemm_ln_bwd_nparts(M)), int(l.ttsmi_layernorm_bwd_xhat_nparts(M))
+        self.lnp_nw1 = self.lnp_nw1_rowgemm           # (bind: the backward chain's count when that is what will run)
         if self.backward:
             need = int(l.ttsmi_attention_bwd_ws_bytes(B, H, T, d // H))
             assert need <= sh['attn_ws'].numel(), (need, sh['attn_ws'].numel())
@@ -2020,6 +2021,11 @@ class DenseBlockPlan:
         bw_on = self.chain_on and self.chain_bwd and self.relu_bits and torch.is_grad_enabled()
         D.chain_bw = self.t['chain_bw'].data_ptr() if bw_on else None
         D.chain_bw_bytes = self.t['chain_bw'].numel() if bw_on else 0
+        # res-norm 1's parameter partials: one row per workgroup of whichever kernel will run its backward (the library's own
+        # predicate - the backward chain has 128-row workgroups, the full-row GEMM 64 or 128 by row count)
+        l = _lib.lib()
+        self.lnp_nw1 = int(l.ttsmi_dense_chain_bwd_nparts(self.M) if (bw_on and l.ttsmi_dense_block_bwd_chained(self._dref))
+                           else self.lnp_nw1_rowgemm)
 
     def fwd(self, h, h_bf):
         check(_lib.lib().ttsmi_dense_block_fwd(self._dref, _p(h), _p(h_bf)), 'dense_block_fwd')
@@ -2061,7 +2067,7 @@ class DenseBlockPlan:
         def defer():
             if self.fuse_ln:       # partial rows left by ttsmi_layernorm_bwd_xhat / the epilogue of ttsmi_hgemm_ln_bwd
                 _ln_defer(t['lnp_ws2'], G['ln2.gamma'], G['ln2.beta'], None, M, d,
-                          self.lnp_nw1 if D.ln2_done else self.lnp_nw2)
+                          self.lnp_nw1_rowgemm if D.ln2_done else self.lnp_nw2)
                 _ln_defer(t['lnp_ws1'], G['ln1.gamma'], G['ln1.beta'], None, M, d, self.lnp_nw1)
             else:
                 _ln_defer(t['ln_ws2'], G['ln2.gamma'], G['ln2.beta'], None, M, d)
