@@ -235,7 +235,7 @@ def instrumented_step(step_fn):
     def hook(name, args, fn):
         if (name.endswith('_bytes') or name.endswith('_nparts') or
                 name in ('ttsmi_last_error', 'ttsmi_version', 'ttsmi_last_kernel', 'ttsmi_dense_block_fwd', 'ttsmi_dense_block_bwd',
-                         'ttsmi_dense_stack_fwd', 'ttsmi_dense_stack_bwd', 'ttsmi_set_launch_observer', 'ttsmi_dense_block_bwd_chained') or
+                         'ttsmi_dense_stack_fwd', 'ttsmi_dense_stack_bwd', 'ttsmi_set_launch_observer', 'ttsmi_dense_block_bwd_chained', 'ttsmi_debug_stream_create_cu_mask') or
                 'comm' in name or name.endswith('_supported')):
             return fn(*args)          # queries / entry points without a stream; the block and stack launchers announce
             #                           their launches through the observer

@@ -629,6 +629,12 @@ int ttsmi_allreduce_sum_f32(void* comm, float* buf, int64_t n, ttsmi_stream_t st
  * can bracket the launches with HIP events.  NULL (the default) disables it.  Process-wide, for measurement only. */
 typedef void (*ttsmi_launch_observer)(int phase, const char* name, double flops, double bytes, ttsmi_stream_t stream);
 int ttsmi_set_launch_observer(ttsmi_launch_observer cb);
+/* Measurement only (the CU-partitioning A/B of the weight-gradient side stream): a HIP stream whose
+ * kernels may only run on the CUs whose bits are set in mask[0 .. nwords) (hipExtStreamCreateWithCUMask; the caller owns
+ * the stream), and a census - counts8[x] += the number of one-wave workgroups of an nblocks launch on `stream` that ran on
+ * XCC x - that shows which CUs a mask really selects.  Neither is used unless TTSMI_WGRAD_XCDS is set. */
+int ttsmi_debug_stream_create_cu_mask(const uint32_t* mask, int nwords, ttsmi_stream_t* out);
+int ttsmi_debug_xcc_census(int32_t* counts8, int nblocks, ttsmi_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * The row-local chain of a dense block (model/layers.py:148-150,211,229 -> :99-102,230 -> the next block's :116-118) as
  * one launch for d_model = 256 (csrc/chain.hip): per 128-row workgroup

@@ -120,6 +120,8 @@ SIGNATURES = {
     'ttsmi_comm_destroy': (I, [P]),
     'ttsmi_allreduce_sum_f32': (I, [P, P, L, S]),
     'ttsmi_set_launch_observer': (I, [P]),
+    'ttsmi_debug_stream_create_cu_mask': (I, [P, I, P]),
+    'ttsmi_debug_xcc_census': (I, [P, I, S]),
     'ttsmi_dense_chain_pack_bytes': (c_size_t, [I, I]),
     'ttsmi_dense_chain_pack': (I, [P, P, P, P, I, P, c_size_t, S]),
     'ttsmi_dense_chain_supported': (I, [I, I, I]),

@@ -18,6 +18,8 @@
 //  * softmax runs in the log2 domain (one fma + v_exp_f32 per element), the additive -1e9 mask,
 //    the tail-of-sequence test and the O rescale are wave-/block-uniform branches that are skipped
 //    on the common path, dropout is a template parameter and costs one 32-bit hash per PAIR of keys.
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -119,16 +121,28 @@ __device__ __forceinline__ int rowmap16(int r, int hh) { return (r & 3) + 8 * (r
         rpad_nv = (nv_);                                                                                   \
         if (tid < HKT) rpad_raw = p.key_pad[(long)b * p.T + min((k0f_) + tid, p.T - 1)];                   \
     } while (0)
-#define HPAD_STASH()                                                                                       \
+#define HPAD_STASH_TO(padS_)                                                                               \
     do {                                                                                                   \
         if (tid < HKT) {                                      /* exactly wave 0 */                           \
             const bool pd_ = tid < rpad_nv && rpad_raw != 0;                                               \
-            padS[tid] = pd_ ? 1.f : 0.f;                                                                   \
+            (padS_)[tid] = pd_ ? 1.f : 0.f;                                                                \
             const unsigned long long any_ = __ballot(pd_);                                                 \
-            if (tid == 0) padS[HKT] = any_ ? 1.f : 0.f;                                                    \
+            if (tid == 0) (padS_)[HKT] = any_ ? 1.f : 0.f;                                                 \
         }                                                                                                  \
     } while (0)
-#define HPAD_ANY() (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, padS[HKT])) != 0)
+#define HPAD_ANY_OF(padS_) (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (padS_)[HKT])) != 0)
+#define HPAD_STASH() HPAD_STASH_TO(padS)
+#define HPAD_ANY() HPAD_ANY_OF(padS)
+// Two LDS images of the staged tiles for head dims <= 64 (round 6): the tile of iteration i + 1 is written into the other
+// image while iteration i is multiplied, so a tile costs ONE workgroup barrier instead of two (stash -> barrier -> use ->
+// barrier), and a wave's stash no longer sits between two barriers that all four waves wait at.  37 KB per workgroup:
+// still four (forward), three (dQ), two (dK/dV) workgroups per CU.  -DHATTN_DB=0: the single-image loop (A/B builds).
+#ifndef HATTN_DB
+#define HATTN_DB 1
+#endif
+#ifndef HATTN_LSE_FOLD            // -DHATTN_LSE_FOLD=0: the dK/dV kernel subtracts the log-sum-exp per score (A/B builds)
+#define HATTN_LSE_FOLD 1
+#endif
 #define TLD (HKT + 4)          // transposed image row stride (bf16 elements)
 
 // ---- row-major staging: [HKT][DH] fp32 rows -> bf16 [HKT][DH+8] ----------------------------------
@@ -300,6 +314,28 @@ __device__ __forceinline__ f32x16 dot16(const uint16_t* S, int row, int g, const
     return acc;
 }
 
+// the same product on top of an initial accumulator (dK/dV kernel: the accumulator starts at -lse / c1, so the softmax's
+// exponent is ONE fma of the product instead of an fma and a subtraction per score - the kernel is bound by its vector ALU)
+template <int DH>
+__device__ __forceinline__ f32x16 dot16_from(const uint16_t* S, int row, int g, const bf16x8 (&f)[DH / 16], f32x16 acc) {
+    const uint16_t* src = S + row * (DH + 8) + 8 * g;
+    if constexpr (DH <= 64) {
+        bf16x8 a[DH / 16];
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) a[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) acc = MFMA16(a[s], f[s], acc);
+        return acc;
+    }
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+        acc = MFMA16(a, f[s], acc);
+    }
+    return acc;
+}
+
 // score tile registers -> two bf16 B-operand fragments (k-steps t = 0, 1)
 __device__ __forceinline__ void to_frags(const f32x16& p, bf16x8 (&pb)[2]) {
 #pragma unroll
@@ -414,10 +450,12 @@ struct HSm {
 template <int DH, int DROP, bool QH>
 __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP p) {
     using SM = HSm<DH>;
+    constexpr bool DB = HATTN_DB && DH <= 64;             // two tile images: one barrier per tile
+    constexpr int NBUF = DB ? 2 : 1;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
-    constexpr int MAIN = TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + (HKT + 4) * 4];
+    constexpr int MAIN = NBUF * TILE_BYTES > PATCH_BYTES ? NBUF * TILE_BYTES : PATCH_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + NBUF * (HKT + 4) * 4];
     uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vs = Ks + SM::ROWS;
     float* padS = reinterpret_cast<float*>(smem + MAIN);
@@ -497,10 +535,41 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
         rv.fetch(Vb, p.ld, kbeg, nv, tid);
         HPAD_FETCH(kbeg, nv);
     }
-    for (int k0 = kbeg; k0 < klen; k0 += HKT) {
+    if constexpr (DB) {
+        // image 0 <- the first tile; the second tile's loads are in flight while it is multiplied
+        if (kbeg < klen) {
+            rk.stash(Ks, tid);
+            rv.stash(Vs, tid);
+            HPAD_STASH();
+            if (kbeg + HKT < klen) {
+                const int nv = min(HKT, klen - (kbeg + HKT));
+                rk.fetch(Kb, p.ld, kbeg + HKT, nv, tid);
+                rv.fetch(Vb, p.ld, kbeg + HKT, nv, tid);
+                HPAD_FETCH(kbeg + HKT, nv);
+            }
+        }
+    }
+    // The body of one staged tile; CUR = the image it multiplies (a compile-time constant, so that every LDS address stays
+    // "per-lane base + immediate": with a run-time image index the forward spilled 7 registers at its 128).
+    auto tile = [&](auto curc, const int k0) {
+        constexpr int cur = decltype(curc)::value;
         int anypad = 0;
         FWD_STAMP(ta);
-        if (!(abl & 8) || k0 == kbeg) {
+        if constexpr (DB) {
+            // ONE barrier per tile: image `cur` is complete (every wave stashed its share an iteration ago) and nobody reads
+            // image `cur ^ 1` any more; the tile whose loads were issued an iteration ago goes there now
+            __syncthreads();
+            Ks = reinterpret_cast<uint16_t*>(smem) + cur * (TILE_BYTES / 2);
+            Vs = Ks + SM::ROWS;
+            padS = reinterpret_cast<float*>(smem + MAIN) + cur * (HKT + 4);
+            anypad = HPAD_ANY();
+            if (k0 + HKT < klen) {
+                uint16_t* Kn = reinterpret_cast<uint16_t*>(smem) + (cur ^ 1) * (TILE_BYTES / 2);
+                rk.stash(Kn, tid);
+                rv.stash(Kn + SM::ROWS, tid);
+                HPAD_STASH_TO(reinterpret_cast<float*>(smem + MAIN) + (cur ^ 1) * (HKT + 4));
+            }
+        } else if (!(abl & 8) || k0 == kbeg) {
             __syncthreads();
             rk.stash(Ks, tid);
             rv.stash(Vs, tid);
@@ -517,12 +586,13 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
         // part of that wait is the matrix pipe's running time.  (ONE load behind each of the tile's four MFMA groups was
         // measured too: 62.1 vs 59.9 us, same box - more live address registers, 4 spills.)  A wave without a live query
         // row runs no block: it issues them here.
-        const bool more = k0 + HKT < klen && !(abl & 1);
-        const int nv_next = more ? min(HKT, klen - (k0 + HKT)) : 0;
+        constexpr int AHEAD = DB ? 2 * HKT : HKT;            // the tile the loads issued in this iteration belong to
+        const bool more = k0 + AHEAD < klen && !(abl & 1);
+        const int nv_next = more ? min(HKT, klen - (k0 + AHEAD)) : 0;
         if (more && !wave_live) {
-            rk.fetch(Kb, p.ld, k0 + HKT, nv_next, tid);
-            rv.fetch(Vb, p.ld, k0 + HKT, nv_next, tid);
-            HPAD_FETCH(k0 + HKT, nv_next);
+            rk.fetch(Kb, p.ld, k0 + AHEAD, nv_next, tid);
+            rv.fetch(Vb, p.ld, k0 + AHEAD, nv_next, tid);
+            HPAD_FETCH(k0 + AHEAD, nv_next);
         }
         FWD_STAMP(tc);
         FWD_ADD(1, tb, tc);
@@ -541,9 +611,9 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
                 s = dot16<DH>(Ks, kt * 32 + l31, hh, qf);                     // S^T[key][q]
             }
             if (more && kt == 0) {                                           // (block 0 of a tile always runs in a live wave)
-                rk.fetch(Kb, p.ld, k0 + HKT, nv_next, tid);
-                rv.fetch(Vb, p.ld, k0 + HKT, nv_next, tid);
-                HPAD_FETCH(k0 + HKT, nv_next);
+                rk.fetch(Kb, p.ld, k0 + AHEAD, nv_next, tid);
+                rv.fetch(Vb, p.ld, k0 + AHEAD, nv_next, tid);
+                HPAD_FETCH(k0 + AHEAD, nv_next);
             }
             // The 1 / sqrt(dh) scale (c1, log2 units) rides in the exponent's fma: p = 2^(s c1 - m).  Only a block with a
             // padded key or the ragged tail needs the logits themselves scaled first (wave-uniform branch, rare).
@@ -627,6 +697,14 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
             { const unsigned long long t3 = stamp(); tsec[4] += t3 - t2; ++tblocks; const unsigned long long t4 = stamp(); tempty += t4 - t3; }
 #endif
         }
+    };
+    if constexpr (DB) {
+        for (int k0 = kbeg; k0 < klen; k0 += 2 * HKT) {
+            tile(std::integral_constant<int, 0>{}, k0);
+            if (k0 + HKT < klen) tile(std::integral_constant<int, 1>{}, k0 + HKT);
+        }
+    } else {
+        for (int k0 = kbeg; k0 < klen; k0 += HKT) tile(std::integral_constant<int, 0>{}, k0);
     }
 #ifdef TTSMI_ABLATION_BUILD
     if (p.dbg && lane == 0) {
@@ -653,10 +731,12 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 4) void hattn_fwd_kernel(HAttnP 
 template <int DH, int DROP, bool QH>
 __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dq_kernel(HAttnP p) {
     using SM = HSm<DH>;
+    constexpr bool DB = HATTN_DB && DH <= 64;             // two tile images: one barrier per tile (see the forward kernel)
+    constexpr int NBUF = DB ? 2 : 1;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
-    constexpr int MAIN = TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + (HKT + 4) * 4];
+    constexpr int MAIN = NBUF * TILE_BYTES > PATCH_BYTES ? NBUF * TILE_BYTES : PATCH_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + NBUF * (HKT + 4) * 4];
     uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vs = Ks + SM::ROWS;
     float* padS = reinterpret_cast<float*>(smem + MAIN);
@@ -738,18 +818,53 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dq_kernel(HAtt
         rv.fetch(Vb, p.ld, 0, nv, tid);
         HPAD_FETCH(0, nv);
     }
-    for (int k0 = 0; k0 < klen; k0 += HKT) {
-        __syncthreads();
-        rk.stash(Ks, tid);
-        rv.stash(Vs, tid);
-        HPAD_STASH();
-        __syncthreads();
-        const int anypad = HPAD_ANY();
-        if (k0 + HKT < klen) {
-            int nv = min(HKT, klen - (k0 + HKT));
-            rk.fetch(Kb, p.ld, k0 + HKT, nv, tid);
-            rv.fetch(Vb, p.ld, k0 + HKT, nv, tid);
-            HPAD_FETCH(k0 + HKT, nv);
+    if constexpr (DB) {
+        if (klen > 0) {
+            rk.stash(Ks, tid);
+            rv.stash(Vs, tid);
+            HPAD_STASH();
+            if (HKT < klen) {
+                const int nv = min(HKT, klen - HKT);
+                rk.fetch(Kb, p.ld, HKT, nv, tid);
+                rv.fetch(Vb, p.ld, HKT, nv, tid);
+                HPAD_FETCH(HKT, nv);
+            }
+        }
+    }
+    auto tile = [&](auto curc, const int k0) {         // one staged tile; cur = the image it multiplies (compile-time)
+        constexpr int cur = decltype(curc)::value;
+        int anypad;
+        if constexpr (DB) {
+            __syncthreads();                      // image `cur` complete, image `cur ^ 1` free
+            Ks = reinterpret_cast<uint16_t*>(smem) + cur * (TILE_BYTES / 2);
+            Vs = Ks + SM::ROWS;
+            padS = reinterpret_cast<float*>(smem + MAIN) + cur * (HKT + 4);
+            anypad = HPAD_ANY();
+            if (k0 + HKT < klen) {
+                uint16_t* Kn = reinterpret_cast<uint16_t*>(smem) + (cur ^ 1) * (TILE_BYTES / 2);
+                rk.stash(Kn, tid);
+                rv.stash(Kn + SM::ROWS, tid);
+                HPAD_STASH_TO(reinterpret_cast<float*>(smem + MAIN) + (cur ^ 1) * (HKT + 4));
+            }
+            if (k0 + 2 * HKT < klen) {
+                const int nv = min(HKT, klen - (k0 + 2 * HKT));
+                rk.fetch(Kb, p.ld, k0 + 2 * HKT, nv, tid);
+                rv.fetch(Vb, p.ld, k0 + 2 * HKT, nv, tid);
+                HPAD_FETCH(k0 + 2 * HKT, nv);
+            }
+        } else {
+            __syncthreads();
+            rk.stash(Ks, tid);
+            rv.stash(Vs, tid);
+            HPAD_STASH();
+            __syncthreads();
+            anypad = HPAD_ANY();
+            if (k0 + HKT < klen) {
+                int nv = min(HKT, klen - (k0 + HKT));
+                rk.fetch(Kb, p.ld, k0 + HKT, nv, tid);
+                rv.fetch(Vb, p.ld, k0 + HKT, nv, tid);
+                HPAD_FETCH(k0 + HKT, nv);
+            }
         }
 #pragma unroll
         for (int kt = 0; kt < HKT / 32; ++kt) {
@@ -790,6 +905,14 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dq_kernel(HAtt
             to_frags(s, pb);
             accumTR<DH>(Ks, kt * 32, lane, pb, dq);                           // dQ^T += K^T.dS^T
         }
+    };
+    if constexpr (DB) {
+        for (int k0 = 0; k0 < klen; k0 += 2 * HKT) {
+            tile(std::integral_constant<int, 0>{}, k0);
+            if (k0 + HKT < klen) tile(std::integral_constant<int, 1>{}, k0 + HKT);
+        }
+    } else {
+        for (int k0 = 0; k0 < klen; k0 += HKT) tile(std::integral_constant<int, 0>{}, k0);
     }
     __syncthreads();
     float* patch = reinterpret_cast<float*>(smem + wave * (QH ? 32 * (DH + 8) * 2 : 32 * (DH + 1) * 4));
@@ -808,10 +931,12 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dq_kernel(HAtt
 template <int DH, int DROP, bool QH>
 __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAttnP p) {
     using SM = HSm<DH>;
+    constexpr bool DB = HATTN_DB && DH <= 64;             // two tile images: one barrier per tile (see the forward kernel)
+    constexpr int NBUF = DB ? 2 : 1;
     constexpr int TILE_BYTES = 2 * SM::ROWS * 2;
     constexpr int PATCH_BYTES = QH ? SM::PATCH_H : SM::PATCH_F32;
-    constexpr int MAIN = TILE_BYTES > PATCH_BYTES ? TILE_BYTES : PATCH_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + 3 * HKT * 4];
+    constexpr int MAIN = NBUF * TILE_BYTES > PATCH_BYTES ? NBUF * TILE_BYTES : PATCH_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + NBUF * 3 * HKT * 4];
     uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Os = Qs + SM::ROWS;
     float* lseS = reinterpret_cast<float*>(smem + MAIN);
@@ -896,16 +1021,70 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
                 rd = p.delta[stat0 + min(tid, p.T - 1)];
             }
         }
-        for (int q0 = 0; q0 < p.T; q0 += HKT) {
+        // (DB) write the staged registers - query tile at q0s - into image `img`
+        auto stash_tile = [&](int img, int q0s) {
+            uint16_t* Qn = reinterpret_cast<uint16_t*>(smem) + img * (TILE_BYTES / 2);
+            float* ln = reinterpret_cast<float*>(smem + MAIN) + img * 3 * HKT;
+            rq.stash(Qn, tid);
+            ro.stash(Qn + SM::ROWS, tid);
+            if (tid < HKT) {
+                if (HATTN_LSE_FOLD) ln[tid] = tid < rnv ? -rl * p.sqrt_dk : -INFINITY;      // -lse / c1 (log2 units): the S accumulator's start
+                else ln[tid] = tid < rnv ? rl * LOG2E : INFINITY;
+                ln[HKT + tid] = tid < rnv ? rd * inv_sqrt : 0.f;
+                if (DROP == 1) reinterpret_cast<uint32_t*>(ln + 2 * HKT)[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0s + tid));
+            }
+        };
+        auto fetch_tile = [&](int q0f) {
+            const int nv = min(HKT, p.T - q0f);
+            rq.fetch(Qb, p.ld, q0f, nv, tid);
+            ro.fetch(dOb, d, q0f, nv, tid);
+            rnv = nv;
+            if (tid < HKT) {
+                rl = p.lse[stat0 + min(q0f + tid, p.T - 1)];
+                rd = p.delta[stat0 + min(q0f + tid, p.T - 1)];
+            }
+        };
+        uint32_t mstage[HKT / 32] = {0u, 0u};         // (DB) keep bits of the tile that sits in the staging registers
+        if constexpr (DB) {
+            stash_tile(0, 0);
+#pragma unroll
+            for (int u = 0; u < HKT / 32; ++u) mstage[u] = mnext[u];
+            if (HKT < p.T) {
+                fetch_tile(HKT);
+                mask_fetch(HKT);
+            }
+        }
+        auto tile = [&](auto curc, const int q0) {     // one staged query tile; cur = the image it multiplies (compile-time)
+            constexpr int cur = decltype(curc)::value;
+            uint32_t mcur[HKT / 32];
+            if constexpr (DB) {
+                __syncthreads();                  // image `cur` complete, image `cur ^ 1` free
+                Qs = reinterpret_cast<uint16_t*>(smem) + cur * (TILE_BYTES / 2);
+                Os = Qs + SM::ROWS;
+                lseS = reinterpret_cast<float*>(smem + MAIN) + cur * 3 * HKT;
+                delS = lseS + HKT;
+                rbS = reinterpret_cast<uint32_t*>(delS + HKT);
+#pragma unroll
+                for (int u = 0; u < HKT / 32; ++u) mcur[u] = mstage[u] >> (4 * hh);  // the bits of the tile multiplied now
+                if (q0 + HKT < p.T) {
+                    stash_tile(cur ^ 1, q0 + HKT);
+#pragma unroll
+                    for (int u = 0; u < HKT / 32; ++u) mstage[u] = mnext[u];
+                }
+                if (q0 + 2 * HKT < p.T) {
+                    fetch_tile(q0 + 2 * HKT);
+                    mask_fetch(q0 + 2 * HKT);
+                }
+            } else {
             __syncthreads();
             rq.stash(Qs, tid);
             ro.stash(Os, tid);
             if (tid < HKT) {
-                lseS[tid] = tid < rnv ? rl * LOG2E : INFINITY;
+                if (HATTN_LSE_FOLD) lseS[tid] = tid < rnv ? -rl * p.sqrt_dk : -INFINITY;
+                else lseS[tid] = tid < rnv ? rl * LOG2E : INFINITY;
                 delS[tid] = tid < rnv ? rd * inv_sqrt : 0.f;  // dS = P (keep dP / (1 - p) - delta) / sqrt(dh): scale folded in
                 if (DROP == 1) rbS[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0 + tid));
             }
-            uint32_t mcur[HKT / 32];
 #pragma unroll
             for (int u = 0; u < HKT / 32; ++u) mcur[u] = mnext[u] >> (4 * hh);      // bit c of mcur = query rowmap16(., hh)
             __syncthreads();
@@ -920,10 +1099,21 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
                     rd = p.delta[stat0 + min(q0 + HKT + tid, p.T - 1)];
                 }
             }
+            }
 #pragma unroll
             for (int qt = 0; qt < HKT / 32; ++qt) {
                 if (q0 + qt * 32 >= p.T || !wave_live) break;
-                f32x16 s = dot16<DH>(Qs, qt * 32 + l31, hh, kf);             // S[q][key]
+                f32x16 s;                                                    // S[q][key] - lse[q] / c1
+                if constexpr (HATTN_LSE_FOLD != 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 l4 = *reinterpret_cast<const float4*>(lseS + qt * 32 + 8 * j + 4 * hh);     // rowmap16(4 j .., hh)
+                        s[4 * j] = l4.x; s[4 * j + 1] = l4.y; s[4 * j + 2] = l4.z; s[4 * j + 3] = l4.w;
+                    }
+                    s = dot16_from<DH>(Qs, qt * 32 + l31, hh, kf, s);
+                } else {
+                    s = dot16<DH>(Qs, qt * 32 + l31, hh, kf);
+                }
                 f32x16 dp;
                 if (do_dk) dp = dot16<DH>(Os, qt * 32 + l31, hh, vf);        // dP = dO.V^T
                 else {
@@ -935,7 +1125,8 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = qt * 32 + rowmap16(r, hh);
-                    float pr = EXP2(s[r] * c1 + padterm - lseS[ql]);        // lse = +inf for q >= T
+                    float pr = HATTN_LSE_FOLD ? EXP2(fmaf(s[r], c1, padterm))                // (lse = +inf for q >= T: the accumulator started at -inf)
+                                              : EXP2(s[r] * c1 + padterm - lseS[ql]);
                     float dpr = dp[r];
                     // the 1 / keep factor: on dV once at the end, on dS inside the fma
                     if (DROP == 1) {
@@ -968,6 +1159,14 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
                     accumTR<DH, NCB>(Qs, qt * 32, lane, sb, dk, cb0);         // dK^T += Q^T.dS
                 }
             }
+        };
+        if constexpr (DB) {
+            for (int q0 = 0; q0 < p.T; q0 += 2 * HKT) {
+                tile(std::integral_constant<int, 0>{}, q0);
+                if (q0 + HKT < p.T) tile(std::integral_constant<int, 1>{}, q0 + HKT);
+            }
+        } else {
+            for (int q0 = 0; q0 < p.T; q0 += HKT) tile(std::integral_constant<int, 0>{}, q0);
         }
     }
     __syncthreads();

@@ -602,6 +602,27 @@ class _WgradStream:
         return [st for (dev, _), st in cls.per_device.items() if dev == d]
 
 
+_WGRAD_XCDS = os.environ.get('TTSMI_WGRAD_XCDS', '')      # measurement knob: "3" = the side stream confined to XCDs 0..2, "5-7" = XCDs 5..7
+
+
+def _new_wgrad_stream():
+    """The weight-gradient side stream.  TTSMI_WGRAD_XCDS (measurement only, profiles/r06_wgrad_cu_mask_ab.txt): a stream whose
+    kernels may only run on the named whole XCDs (CU mask bit i = CU i / 8 of XCC i % 8 on this part, checked by
+    tools/probe_cu_mask.py) instead of competing with the main stream for every CU."""
+    if not _WGRAD_XCDS:
+        return torch.cuda.Stream(priority=_WGRAD_PRIO)
+    lo, _, hi = _WGRAD_XCDS.partition('-')
+    xs = range(int(lo), int(hi) + 1) if hi else range(0, int(lo))
+    ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    words = (ctypes.c_uint32 * ((ncu + 31) // 32))()
+    for i in range(ncu):
+        if i % 8 in xs:
+            words[i // 32] |= 1 << (i % 32)
+    h = ctypes.c_void_p()
+    check(_lib.lib().ttsmi_debug_stream_create_cu_mask(ctypes.addressof(words), len(words), ctypes.addressof(h)), 'stream_create_cu_mask')
+    return torch.cuda.ExternalStream(h.value)
+
+
 def enable_wgrad_stream(flag: bool = True):
     _WgradStream.enabled = bool(flag)
 
@@ -612,7 +633,7 @@ def _on_wgrad_stream(fn, *inputs):
     W = _WgradStream.cur()
     main = cur_stream()
     if W.stream is None:
-        W.stream = torch.cuda.Stream(priority=_WGRAD_PRIO)
+        W.stream = _new_wgrad_stream()
     side = W.stream
     side.wait_stream(main)                    # the operands were produced on the main stream
     if _PINNED_STREAM is not None:
@@ -647,7 +668,7 @@ def wgrad_rows_async(x, dy, dw, db, conv=None):
     if _WGRAD_GENERIC:
         return _on_wgrad_stream(lambda: hgemm_wgrad_rows(x, dy, dw, db, conv), x, dy)
     if W.stream is None:
-        W.stream = torch.cuda.Stream(priority=_WGRAD_PRIO)
+        W.stream = _new_wgrad_stream()
     if W.handle is None:
         W.handle = W.stream.cuda_stream
     ev = torch.cuda.Event()
@@ -2041,7 +2062,7 @@ class DenseBlockPlan:
         if _WgradStream.enabled:
             W = _WgradStream.cur(self.wgrad_lane)
             if W.stream is None:
-                W.stream = torch.cuda.Stream(priority=_WGRAD_PRIO)
+                W.stream = _new_wgrad_stream()
             if W.handle is None:
                 W.handle = W.stream.cuda_stream
             if W.ws is None or W.ws.numel() < need:
