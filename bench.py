@@ -235,7 +235,7 @@ def instrumented_step(step_fn):
     def hook(name, args, fn):
         if (name.endswith('_bytes') or name.endswith('_nparts') or
                 name in ('ttsmi_last_error', 'ttsmi_version', 'ttsmi_last_kernel', 'ttsmi_dense_block_fwd', 'ttsmi_dense_block_bwd',
-                         'ttsmi_dense_stack_fwd', 'ttsmi_dense_stack_bwd', 'ttsmi_set_launch_observer', 'ttsmi_dense_block_bwd_chained', 'ttsmi_debug_stream_create_cu_mask') or
+                         'ttsmi_dense_stack_fwd', 'ttsmi_dense_stack_bwd', 'ttsmi_set_launch_observer', 'ttsmi_dense_block_bwd_chained', 'ttsmi_debug_stream_create_cu_mask', 'ttsmi_ft_train_step') or
                 'comm' in name or name.endswith('_supported')):
             return fn(*args)          # queries / entry points without a stream; the block and stack launchers announce
             #                           their launches through the observer
@@ -865,15 +865,15 @@ def lj_dist_bench(args):
     # the max-shape step of the SAME process (plans already at capacity): ms per padded frame to compare with
     batch = [torch.from_numpy(a).to(dev) for a in synthetic_batch(shape['B'], shape['Tp'], shape['Tm'], seed=1234 + rank)]
     gshape = (shape['B'] * world, shape['Tp'], shape['Tm'])
-    for _ in range(3):
+    n_max = 0 if args.lj_skip_max_shape else 20          # (profiling runs: only the ragged steps in the trace)
+    for _ in range(3 if n_max else 0):
         wrapped.train_step(*batch, global_shape=gshape, reduce_losses=False)
     sync()
     t1 = time.perf_counter()
-    n_max = 20
     for _ in range(n_max):
         wrapped.train_step(*batch, global_shape=gshape, reduce_losses=False)
     sync()
-    ms_max = 1e3 * (time.perf_counter() - t1) / n_max
+    ms_max = 1e3 * (time.perf_counter() - t1) / max(n_max, 1)
     us_per_padded = 1e6 * elapsed / padded
     us_per_padded_max = 1e3 * ms_max / (shape['B'] * shape['Tm'])
     result = {
@@ -929,6 +929,7 @@ def main():
     ap.add_argument('--clips', type=int, default=10000, help='--workload mel: clips per GPU (BASELINE configs[3]: 10 000)')
     ap.add_argument('--no-also', action='store_true', help='skip the extra legs of the default run (f32 step, mel, predict)')
     ap.add_argument('--lj-samples', type=int, default=4096, help='--workload lj-dist: synthetic samples per GPU')
+    ap.add_argument('--lj-skip-max-shape', action='store_true', help='--workload lj-dist: no max-shape steps after the timed loop (profiling)')
     ap.add_argument('--lj-preload', action='store_true', help='--workload lj-dist: produce every batch before the timed loop '
                                                               '(diagnosis: the step without the producer thread beside it)')
     args = ap.parse_args()

@@ -703,6 +703,113 @@ int ttsmi_dense_block_bwd_chained(const ttsmi_dense_block* desc);
 int ttsmi_dense_stack_fwd(const ttsmi_dense_block* const* blocks, int n, const float* h, const uint16_t* h_bf);
 int ttsmi_dense_stack_bwd(const ttsmi_dense_block* const* blocks, int n, const float* h, const uint16_t* h_bf, const float* dout);
 
+/* ---------------------------------------------------------------------------------------------
+ * One teacher-forced TRAIN STEP of ForwardTransformer from ONE descriptor (round 6): the reference compiles its step
+ * once (model/models.py:442-451, tf.function + input signature) and its loop (train_tts.py:149-160) only feeds batches;
+ * here the whole launch sequence of `_train_step` (models.py:464-482) - masks, embedding, encoder stack, the two
+ * StatPredictors on a side stream, pitch embedding, Expand, decoder stack, mel projection, the three L1 losses, the
+ * hand-ordered backward, the LayerNorm parameter reductions, TF-form Adam and the bf16 shadow refresh - is issued from
+ * C++ by three calls (phases), with no autograd engine and no interpreter between the ~290 launches.  Every buffer is
+ * caller-owned and persistent (sized for the largest batch seen), the dense blocks are the ttsmi_dense_block descriptors
+ * of ttsmi_dense_stack_fwd / _bwd, events are caller-created hipEvent_t.  Same launches, same arguments, same streams as
+ * the per-layer host path (transformertts_amd/ops.py): results are bit-identical to it.
+ *   phase 0: keep-bit tables + chain weight streams (side stream), forward, losses, backward down to the decoder's entry
+ *            LayerNorm;   [a data-parallel host launches the decoder-half all-reduce here]
+ *   phase 1: Expand backward .. embedding backward, LayerNorm parameter reductions, stream joins;
+ *   phase 2: step counter, Adam, bf16 shadows.
+ * ------------------------------------------------------------------------------------------- */
+#define TTSMI_FT_MAX_PRED_LAYERS 8
+#define TTSMI_FT_MAX_BLOCKS 32
+typedef struct {
+    /* Conv1D(k, 'same') + ReLU -> LayerNorm -> dropout: one layer of a StatPredictor (model/layers.py:510-515) */
+    int32_t k, Cin, Cout, Cout_pad;            /* Cout_pad = Cout rounded up to 8 (row pitch of dc, column count of w_d) */
+    uint32_t site;                             /* dropout site of the layer's output */
+    int32_t pad_;
+    const uint16_t* w_t;                       /* bf16 [Cout][k Cin]: forward operand */
+    const uint16_t* w_d;                       /* bf16 [Cin][k Cout_pad]: dgrad operand (ttsmi_conv_wdgrad_layout_bf16) */
+    const float* bias;
+    const float* ln_g; const float* ln_b;
+    float* g_w; float* g_b; float* g_ln_g; float* g_ln_b;      /* gradient sinks */
+    float* c;                                  /* [rows, Cout] relu(conv) */
+    float* n;                                  /* [rows, Cout] LayerNorm output */
+    float* mean; float* rstd;                  /* [rows] */
+    float* dc;                                 /* [rows, Cout] gradient of c (ReLU' applied) */
+    float* dc_pad;                             /* [rows, Cout_pad] zero-padded copy when Cout_pad != Cout, else unused */
+    float* dx;                                 /* [rows, Cin] gradient of the layer's input */
+    void* ln_ws; uint64_t ln_ws_bytes;         /* ttsmi_add_layernorm_bwd workspace (kept until the batched reduce) */
+    uint16_t* xT; uint16_t* dyT;               /* cast-transpose scratch of the weight gradient when Cin % 128 or Cout % 4 != 0 */
+    void* wg_ws; uint64_t wg_ws_bytes;         /* weight-gradient workspace */
+} ttsmi_ft_pred_layer;
+
+typedef struct {
+    int32_t n_layers, relu_head;
+    ttsmi_ft_pred_layer layer[TTSMI_FT_MAX_PRED_LAYERS];
+    const float* lin_w; const float* lin_b; float* g_lin_w; float* g_lin_b;     /* Dense(1) head */
+    float* hm;                                 /* [rows, d] masked encoder output (layers.py:482) */
+    float* y;                                  /* [rows] prediction */
+    float* dn;                                 /* [rows, C_last] gradient of the last LayerNorm output */
+    float* dbranch;                            /* [rows, d] gradient wrt the encoder output (row-masked) */
+    void* rd_ws; uint64_t rd_ws_bytes;         /* ttsmi_rowdot_bwd workspace */
+} ttsmi_ft_predictor;
+
+typedef struct {
+    int32_t B, Tp, Tm, d, V, n_mel, n_enc, n_dec;
+    float rate, prate;                         /* dropout_rate, predictors_dropout */
+    uint64_t seed; const int64_t* step_dev;
+    uint32_t site_enc_ln, site_dec_ln;
+    ttsmi_stream_t main_stream, side_stream, wgrad_stream;
+    void* ev[12];                              /* hipEvent_t, caller-created (cross-stream hand-offs, one use each per step) */
+    /* the batch (device) */
+    const int32_t* tokens; const float* tgt_mel; const int32_t* tgt_dur; const float* tgt_pitch;
+    /* parameters outside the blocks and their gradient sinks */
+    const float* emb; float* g_emb;
+    const float* enc_ln_g; const float* enc_ln_b; const float* enc_ps; float* g_enc_ln_g; float* g_enc_ln_b; float* g_enc_ps;
+    const float* dec_ln_g; const float* dec_ln_b; const float* dec_ps; float* g_dec_ln_g; float* g_dec_ln_b; float* g_dec_ps;
+    const float* pe_enc; const float* pe_dec;  /* sinusoid tables [max_pos, d] */
+    const float* pit_w; const float* pit_b; float* g_pit_w; float* g_pit_b;
+    const uint16_t* out_wt; const uint16_t* out_wb; const float* out_b; float* g_out_w; float* g_out_b;
+    const ttsmi_dense_block* enc[TTSMI_FT_MAX_BLOCKS];
+    const ttsmi_dense_block* dec[TTSMI_FT_MAX_BLOCKS];
+    ttsmi_ft_predictor dur, pit;
+    /* persistent activations / gradients */
+    uint8_t* pad_e; int32_t* klen_e; uint8_t* pad_d; int32_t* klen_d;
+    float* x_emb; float* h0; uint16_t* h0_bf; float* mean0; float* rstd0;      /* encoder entry */
+    float* hp;                                 /* [B Tp, d] encoder output + pitch embedding */
+    int32_t* idx; int32_t* cum; int32_t* lens; /* Expand tables */
+    float* x_dec; float* h1; uint16_t* h1_bf; float* mean1; float* rstd1;      /* decoder entry */
+    float* mel;                                /* [B Tm, n_mel] */
+    float* loss_out;                           /* [4]: mel, duration, pitch, total */
+    float* g_mel; float* g_dur; float* g_pit;  /* loss gradients */
+    void* loss_ws; uint64_t loss_ws_bytes;
+    float loss_w[3]; int32_t pad2_;
+    int64_t loss_denom[3];                     /* 0 = the term's own element count */
+    float* d_dec_out;                          /* [B Tm, d] */
+    float* d_x_dec;                            /* [B Tm, d] */
+    float* d_hp;                               /* [B Tp, d] */
+    float* d_branch;                           /* [B Tp, d] sum of the predictors' gradients */
+    float* d_enc_out;                          /* [B Tp, d] */
+    float* d_x_emb;                            /* [B Tp, d] */
+    void* ln_ws0; void* ln_ws1; uint64_t ln_ws0_bytes, ln_ws1_bytes;            /* entry LayerNorm backward workspaces */
+    void* pit_ws; uint64_t pit_ws_bytes;
+    void* wgrad_ws; uint64_t wgrad_ws_bytes;   /* the weight-gradient stream's workspace (shared with the blocks) */
+    /* phase 2 */
+    float* p_flat; float* g_flat; float* m_flat; float* v_flat; int64_t n_flat;
+    const float* lr_dev; int64_t* step_rw;
+    float beta1, beta2, eps; int32_t pad3_;
+    uint16_t* flat_bf16;
+    const void* tr_desc; int32_t tr_n, tr_tiles;
+    int32_t n_conv_wd, pad4_;
+    const float* conv_w[2 * TTSMI_FT_MAX_PRED_LAYERS]; uint16_t* conv_wd[2 * TTSMI_FT_MAX_PRED_LAYERS];
+    int32_t conv_k[2 * TTSMI_FT_MAX_PRED_LAYERS], conv_cin[2 * TTSMI_FT_MAX_PRED_LAYERS], conv_cout[2 * TTSMI_FT_MAX_PRED_LAYERS];
+} ttsmi_ft_step;
+/* phase: 0, 1, 2 as above.  Returns TTSMI_OK or the first failing entry point's code (ttsmi_last_error()). */
+int ttsmi_ft_train_step(const ttsmi_ft_step* step, int phase);
+/* out = a + b (fp32, n elements): the sum of a multiply-used tensor's gradients (the encoder output feeds the pitch
+ * embedding and both predictors) */
+int ttsmi_add2_f32(const float* a, const float* b, float* out, int64_t n, ttsmi_stream_t stream);
+/* dst[m, 0 .. C) = src[m, 0 .. C), dst[m, C .. Cp) = 0: the zero-padded gradient a Conv1D dgrad with Cout % 8 != 0 reads */
+int ttsmi_pad_cols_f32(const float* src, int C, float* dst, int Cp, int M, ttsmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

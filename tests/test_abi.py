@@ -101,6 +101,32 @@ def test_dense_block_descriptor_layout_matches_the_header(tmp_path):
     assert out[1:] == [getattr(DenseBlockDesc, n).offset for n in names]
 
 
+def test_train_step_descriptor_layout_matches_the_header(tmp_path):
+    """_lib.FtStep / FtPredictor / FtPredLayer (ctypes) mirror `ttsmi_ft_step` and its members field for field."""
+    import ctypes
+    import subprocess
+    from transformertts_amd import _lib
+    structs = (('ttsmi_ft_pred_layer', _lib.FtPredLayer), ('ttsmi_ft_predictor', _lib.FtPredictor), ('ttsmi_ft_step', _lib.FtStep))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "ttsmi.h")}"', 'int main(void) {']
+    want = []
+    for cname, cls in structs:
+        lines.append(f'  printf("%zu\\n", sizeof({cname}));')
+        want.append(ctypes.sizeof(cls))
+        for n, _ in cls._fields_:
+            lines.append(f'  printf("%zu\\n", offsetof({cname}, {n}));')
+            want.append(getattr(cls, n).offset)
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout_ft.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout_ft'
+    subprocess.run(['gcc', str(src), '-o', str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out == want
+    assert _lib.FT_MAX_PRED_LAYERS == 8 and _lib.FT_MAX_BLOCKS == 32      # TTSMI_FT_MAX_* of the header
+    hdr = open(os.path.join(ROOT, 'include', 'ttsmi.h')).read()
+    assert '#define TTSMI_FT_MAX_PRED_LAYERS 8' in hdr and '#define TTSMI_FT_MAX_BLOCKS 32' in hdr
+
+
 def test_a_stale_library_is_refused_and_the_override_needs_an_opt_in(tmp_path):
     """A build with another ABI version must not be called (its argument lists differ): _lib.lib() raises.  TTSMI_LIB is a
     measurement knob: ignored unless TTSMI_ALLOW_LIB_OVERRIDE=1 is set with it (advisor finding, round 3)."""

@@ -137,6 +137,9 @@ SIGNATURES = {
     'ttsmi_dense_block_bwd': (I, [P, P, P, P]),
     'ttsmi_dense_stack_fwd': (I, [P, I, P, P]),
     'ttsmi_dense_stack_bwd': (I, [P, I, P, P, P]),
+    'ttsmi_ft_train_step': (I, [P, I]),
+    'ttsmi_add2_f32': (I, [P, P, P, L, S]),
+    'ttsmi_pad_cols_f32': (I, [P, I, P, I, I, S]),
 }
 
 
@@ -163,6 +166,53 @@ class DenseBlockDesc(ctypes.Structure):
     """ctypes mirror of `ttsmi_dense_block` (include/ttsmi.h) - field order and types must match
     (tests/test_abi.py compares the size and a few offsets with the compiled header)."""
     _fields_ = _dense_block_fields()
+
+FT_MAX_PRED_LAYERS, FT_MAX_BLOCKS, FT_EVENTS = 8, 32, 12
+
+
+class FtPredLayer(ctypes.Structure):
+    """ctypes mirror of `ttsmi_ft_pred_layer` (include/ttsmi.h; tests/test_abi.py compares every offset)."""
+    _fields_ = ([(n, ctypes.c_int32) for n in ('k', 'Cin', 'Cout', 'Cout_pad')] + [('site', ctypes.c_uint32), ('pad_', ctypes.c_int32)] +
+                [(n, ctypes.c_void_p) for n in ('w_t', 'w_d', 'bias', 'ln_g', 'ln_b', 'g_w', 'g_b', 'g_ln_g', 'g_ln_b', 'c', 'n', 'mean',
+                                                'rstd', 'dc', 'dc_pad', 'dx', 'ln_ws')] + [('ln_ws_bytes', ctypes.c_uint64)] +
+                [(n, ctypes.c_void_p) for n in ('xT', 'dyT', 'wg_ws')] + [('wg_ws_bytes', ctypes.c_uint64)])
+
+
+class FtPredictor(ctypes.Structure):
+    """ctypes mirror of `ttsmi_ft_predictor`."""
+    _fields_ = ([('n_layers', ctypes.c_int32), ('relu_head', ctypes.c_int32), ('layer', FtPredLayer * FT_MAX_PRED_LAYERS)] +
+                [(n, ctypes.c_void_p) for n in ('lin_w', 'lin_b', 'g_lin_w', 'g_lin_b', 'hm', 'y', 'dn', 'dbranch', 'rd_ws')] +
+                [('rd_ws_bytes', ctypes.c_uint64)])
+
+
+def _ft_step_fields():
+    i32, u32, u64, i64, f, p = ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+    P = lambda *names: [(n, p) for n in names]
+    return ([(n, i32) for n in ('B', 'Tp', 'Tm', 'd', 'V', 'n_mel', 'n_enc', 'n_dec')] + [('rate', f), ('prate', f), ('seed', u64)] +
+            P('step_dev') + [('site_enc_ln', u32), ('site_dec_ln', u32)] + P('main_stream', 'side_stream', 'wgrad_stream') +
+            [('ev', p * FT_EVENTS)] + P('tokens', 'tgt_mel', 'tgt_dur', 'tgt_pitch', 'emb', 'g_emb',
+                                        'enc_ln_g', 'enc_ln_b', 'enc_ps', 'g_enc_ln_g', 'g_enc_ln_b', 'g_enc_ps',
+                                        'dec_ln_g', 'dec_ln_b', 'dec_ps', 'g_dec_ln_g', 'g_dec_ln_b', 'g_dec_ps',
+                                        'pe_enc', 'pe_dec', 'pit_w', 'pit_b', 'g_pit_w', 'g_pit_b',
+                                        'out_wt', 'out_wb', 'out_b', 'g_out_w', 'g_out_b') +
+            [('enc', p * FT_MAX_BLOCKS), ('dec', p * FT_MAX_BLOCKS), ('dur', FtPredictor), ('pit', FtPredictor)] +
+            P('pad_e', 'klen_e', 'pad_d', 'klen_d', 'x_emb', 'h0', 'h0_bf', 'mean0', 'rstd0', 'hp', 'idx', 'cum', 'lens',
+              'x_dec', 'h1', 'h1_bf', 'mean1', 'rstd1', 'mel', 'loss_out', 'g_mel', 'g_dur', 'g_pit', 'loss_ws') +
+            [('loss_ws_bytes', u64), ('loss_w', f * 3), ('pad2_', i32), ('loss_denom', i64 * 3)] +
+            P('d_dec_out', 'd_x_dec', 'd_hp', 'd_branch', 'd_enc_out', 'd_x_emb', 'ln_ws0', 'ln_ws1') +
+            [('ln_ws0_bytes', u64), ('ln_ws1_bytes', u64)] + P('pit_ws') + [('pit_ws_bytes', u64)] + P('wgrad_ws') +
+            [('wgrad_ws_bytes', u64)] + P('p_flat', 'g_flat', 'm_flat', 'v_flat') + [('n_flat', i64)] + P('lr_dev', 'step_rw') +
+            [('beta1', f), ('beta2', f), ('eps', f), ('pad3_', i32)] + P('flat_bf16', 'tr_desc') +
+            [('tr_n', i32), ('tr_tiles', i32), ('n_conv_wd', i32), ('pad4_', i32),
+             ('conv_w', p * (2 * FT_MAX_PRED_LAYERS)), ('conv_wd', p * (2 * FT_MAX_PRED_LAYERS)),
+             ('conv_k', i32 * (2 * FT_MAX_PRED_LAYERS)), ('conv_cin', i32 * (2 * FT_MAX_PRED_LAYERS)),
+             ('conv_cout', i32 * (2 * FT_MAX_PRED_LAYERS))])
+
+
+class FtStep(ctypes.Structure):
+    """ctypes mirror of `ttsmi_ft_step`."""
+    _fields_ = _ft_step_fields()
+
 
 TTSMI_F32, TTSMI_BF16, TTSMI_BF16_IO = 0, 1, 2
 LAUNCH_OBSERVER = ctypes.CFUNCTYPE(None, c_int, c_char_p, ctypes.c_double, ctypes.c_double, c_void_p)

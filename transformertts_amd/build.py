@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(LIBDIR, 'libttsmi.so')
 SOURCES = ['api.cpp', 'gemm.hip', 'gemm_bf16.hip', 'attention.hip', 'attention_bf16.hip', 'layernorm.hip',
-           'elementwise.hip', 'lenreg.hip', 'stft_mel.hip', 'dense_block.hip', 'rowgemm.hip', 'gemm_k256.hip', 'chain.hip', 'griffinlim.hip', 'nnls.hip', 'collective.cpp']
+           'elementwise.hip', 'lenreg.hip', 'stft_mel.hip', 'dense_block.hip', 'rowgemm.hip', 'gemm_k256.hip', 'chain.hip', 'train_step.hip', 'griffinlim.hip', 'nnls.hip', 'collective.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 # measurement builds only, e.g. TTSMI_EXTRA_HIPCC_FLAGS=-DTTSMI_ABLATION_BUILD (stage-ablation knobs, csrc/common.h)
 FLAGS += os.environ.get('TTSMI_EXTRA_HIPCC_FLAGS', '').split()

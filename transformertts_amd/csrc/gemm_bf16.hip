@@ -1133,7 +1133,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WRowsP p) {
     const int k0 = tk * 128, n0 = tn * 128;
     const int mbeg = zsplit * p.k_per_split;
     const int mend = min(p.M, mbeg + p.k_per_split);
-    const int nsteps = (mend - mbeg) / WR_ROWS;          // rows % 32 == 0 is a launch precondition
+    // Round 6: the row count need not be a multiple of 32 any more (the reference's bucketed batches: B x T is anything) -
+    // the LAST step of the last split loads its missing rows from the last valid row (clamped addresses: finite data) and
+    // zeroes their X fragments (and the ones of the bias gradient's all-ones operand), so they add exactly nothing.  Such
+    // row counts used to fall back to the register-staged kernel: 37 us per launch at ~12 k rows against ~15.
+    const int nsteps = (mend - mbeg + WR_ROWS - 1) / WR_ROWS;
+    const int tail = (mend - mbeg) - (nsteps - 1) * WR_ROWS;         // live rows of the last step: 1 .. 32
 
     f32x16 acc[2][2], cs[2];
 #pragma unroll
@@ -1174,13 +1179,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WRowsP p) {
         for (int i = 0; i < 2; ++i) {
             const int row = wave * 8 + i * 4 + drow;
             const int c = dpos ^ ((row & 3) << 2);
-            lds_dma16(X + (m0 + row) * ldx + xk0 + c * 8, lds_offset(Xi + (wave * 8 + i * 4) * 256));
+            lds_dma16(X + min(m0 + row, (long)mend - 1) * ldx + xk0 + c * 8, lds_offset(Xi + (wave * 8 + i * 4) * 256));
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = wave * 8 + i * 4 + drow;
             const int c = dpos ^ ((row & 3) << 2);
-            lds_dma16(DY + (m0 + row) * p.lddy + n0 + c * 8, lds_offset(Yi + (wave * 8 + i * 4) * 256));
+            lds_dma16(DY + min(m0 + row, (long)mend - 1) * p.lddy + n0 + c * 8, lds_offset(Yi + (wave * 8 + i * 4) * 256));
         }
     };
     // transposing-read lane geometry (see wgrad_rows_kernel): rows (lane>>5)*8 + ((lane&15)>>2) (+4),
@@ -1208,13 +1213,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WRowsP p) {
                 bf16x8 a1 = wd_tr8(Xi, row, wr * 16 + 8 + tunit);
                 bf16x8 b0 = wd_tr8(Yi, row, wc * 16 + tunit);
                 bf16x8 b1 = wd_tr8(Yi, row, wc * 16 + 8 + tunit);
+                bf16x8 one8 = ones;
+                if (tail < WR_ROWS && s_ + 1 == nsteps) {          // (workgroup-uniform, the last step of a ragged split only)
+                    // element e of a fragment is row 16 ks + 8 kg + e of the step (the transposing read hands a lane the
+                    // 4 + 4 rows of its column): rows past the tail multiply as zeros
+                    const int live = tail - (ks * 16 + kg * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e >= live) { a0[e] = (__bf16)0.f; a1[e] = (__bf16)0.f; one8[e] = (__bf16)0.f; }
+                }
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
                 if constexpr (kColsum) {
-                    cs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b0, cs[0], 0, 0, 0);
-                    cs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b1, cs[1], 0, 0, 0);
+                    cs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one8, b0, cs[0], 0, 0, 0);
+                    cs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one8, b1, cs[1], 0, 0, 0);
                 }
             }
         }
@@ -1750,7 +1764,7 @@ static int wgrad_rows_impl(const void* x, int x_is_bf16, int64_t ldx, const void
     p.ws = (float*)ws; p.colsum = db; p.colsum_ws = p.ws + (size_t)splits * kin * n;
     dim3 wgrid(tiles * splits);
     TTSMI_KNOB(wdma, "TTSMI_WGRAD_DMA", 1);
-    const bool dma_ok = (wdma || shifted) && x_is_bf16 && dy_is_bf16 && (conv_taps <= 1 || shifted) && rows % WR_ROWS == 0 && kin % 128 == 0 &&
+    const bool dma_ok = (wdma || shifted) && x_is_bf16 && dy_is_bf16 && (conv_taps <= 1 || shifted) && kin % 128 == 0 &&
                         n % 128 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && al16(x) && al16(dy);
     ttsmi_note_kernel(dma_ok ? "wgrad_dma_kernel" : "wgrad_rows_kernel");
     if (dma_ok) hipLaunchKernelGGL(wgrad_dma_kernel, wgrid, dim3(256), 0, st, p);

@@ -213,5 +213,5 @@ class DataParallel:
             vals = torch.stack([out['loss'].reshape(()), out['losses']['mel'].reshape(()),
                                 out['losses']['duration'].reshape(()), out['losses']['pitch'].reshape(())])
             dist.all_reduce(vals, op=dist.ReduceOp.SUM, group=self.sync.group)
-            out = dict(out, loss=vals[0], losses={'mel': vals[1], 'duration': vals[2], 'pitch': vals[3]})
+            out = dict(out.items(), loss=vals[0], losses={'mel': vals[1], 'duration': vals[2], 'pitch': vals[3]})   # (.items(): a lazily built entry of the C-step's dict is built)
         return out

@@ -255,6 +255,10 @@ class ForwardTransformer:
         self.map_ring = bool(kwargs.get('map_ring', True)) and os.environ.get('TTSMI_MAP_RING', '1') != '0'
         self._map_ring_on, self._map_bufs = False, {}
         self.debug = debug
+        # the train step as ONE descriptor issued from C++ (transformertts_amd/step.py; use_cstep=False / TTSMI_CSTEP=0: the
+        # per-layer autograd path, which stays the path of everything the descriptor does not cover)
+        self.use_cstep = bool(kwargs.get('use_cstep', True))
+        self._cstep, self._cstep_eligible = None, None
         self._phase_events = None            # measurement instrumentation (_mark)
         self._taps = None                    # test instrumentation: a list receives (f'{prefix}.blk{i}', block output)
         self._init_weights(int(kwargs.get('seed', 0)))
@@ -858,7 +862,7 @@ class ForwardTransformer:
 
     def _prep(self, input_sequence, target_sequence, target_durations, target_pitch):
         dev = self.device
-        x = torch.as_tensor(input_sequence, device=dev).to(torch.int32)
+        x = torch.as_tensor(input_sequence, device=dev).to(torch.int32).contiguous()
         ts = torch.as_tensor(target_sequence, device=dev).to(torch.float32).contiguous()
         td = torch.as_tensor(target_durations, device=dev).to(torch.int32)[..., None].contiguous()   # :465
         tp = torch.as_tensor(target_pitch, device=dev).to(torch.float32)[..., None].contiguous()     # :466
@@ -872,12 +876,52 @@ class ForwardTransformer:
         x, ts, td, tp = self._prep(input_sequence, target_sequence, target_durations, target_pitch)
         if self.use_graph:
             return self._train_step_graphed(x, ts, td, tp)
+        if self._cstep_ok():
+            return self._train_step_c(x, ts, td, tp)
         model_out = self._forward_backward(x, ts, td, tp)
         if self.grad_sync is not None:
             self.grad_sync(self.params.grad)          # the single RCCL all-reduce of the step
         self._apply_gradients()                                                      # :481
         self._host_step += 1
         return model_out
+
+    def _cstep_ok(self) -> bool:
+        """The step as one descriptor issued from C++ (transformertts_amd/step.py) covers this model and this call: bf16
+        planned dense blocks throughout, no attention maps returned, no instrumentation that lives in the per-layer path."""
+        if self._cstep_eligible is None:
+            from .. import step as _step
+            self._cstep_eligible = bool(self.use_cstep) and _step.eligible(self)
+        ra = self.reference_outputs if self.return_attention is None else self.return_attention
+        # (a C-ABI trace hook - bench.py's instrumented step - wants to see every entry point: the per-layer path shows them)
+        return (self._cstep_eligible and not ra and self._taps is None and self._phase_events is None
+                and ops._lib._trace is None and not torch.cuda.is_current_stream_capturing() and torch.is_grad_enabled())
+
+    def _train_step_c(self, x, ts, td, tp):
+        """_train_step on a TrainStepPlan: three C calls (forward + loss + decoder backward / the rest of the backward /
+        optimiser), the data-parallel all-reduces between them where the per-layer path launches them."""
+        from .. import step as _step
+        if self._cstep is None:
+            self._cstep = _step.TrainStepPlan(self)
+        plan = self._cstep
+        with ops.pinned_stream():
+            if self.grad_sync is None and self._lenreg_hook is None:
+                out = plan.run(x, ts, td, tp)
+            else:
+                out = plan.run(x, ts, td, tp, phases=(0,))
+                if self._lenreg_hook is not None:
+                    plan.flush_decoder_ln()      # the decoder half's LayerNorm gradients are final before their all-reduce
+                    W = ops._WgradStream.cur(0) if self.overlap_wgrad else None
+                    if W is not None:
+                        W.pending = True         # (the hook orders its collective behind the weight-gradient stream too)
+                    self._lenreg_hook()
+                    if W is not None:
+                        W.pending = False        # phase 1 joins that stream itself
+                plan.run(x, ts, td, tp, phases=(1,))
+                if self.grad_sync is not None:
+                    self.grad_sync(self.params.grad)
+                plan.run(x, ts, td, tp, phases=(2,))
+        self._host_step += 1
+        return out
 
     def _forward_backward(self, x, ts, td, tp):
         """forward(training=True) + losses + backward into the flat gradient buffer.  No host sync,
