@@ -191,7 +191,7 @@ KERNEL_OF = {
 RIDERS = 'hbm-bound riders (LN, lenreg, loss, Adam, ...)'
 SIDE = ' [side stream]'
 HATTN_FWD = 'hattn_fwd_kernel (bf16 MFMA flash attention forward)'
-HATTN_BWD = 'hattn_bwd_fused_kernel | hattn_bwd_dq_kernel + hattn_bwd_dkv_kernel (bf16 MFMA flash attention backward)'
+HATTN_BWD = 'hattn_bwd_dq_kernel + hattn_bwd_dkv_kernel (bf16 MFMA flash attention backward)'
 ROWGEMM = 'rowgemm_dma_kernel / rowgemm_kernel (full-row GEMM + fused LayerNorm forward / backward, bf16 MFMA)'
 CHAIN = 'dense_chain16_kernel / dense_chain_kernel (row-local chain of a dense block: o-projection + res-norm 1 + FFN + res-norm 2 + next qkv in one launch - and its backward between the two res-norms, bf16 MFMA)'
 # launch groups announced by the C++ block launcher (ttsmi_set_launch_observer) -> kernel family
@@ -215,7 +215,7 @@ PMC_KERNELS = {       # kernel family -> (rocprof names of its kernels, names of
     CHAIN: (['dense_chain16_kernel', 'dense_chain16_bwd_kernel', 'dense_chain_kernel'], ['dense_chain16_pack_kernel', 'dense_chain_pack_kernel']),
     KERNEL_OF['ttsmi_hgemm_wgrad_rows']: (['wgrad_rows_kernel', 'wgrad_dma_kernel'], ['hsplit_reduce']),
     HATTN_FWD: (['hattn_fwd_kernel'], []),
-    HATTN_BWD: (['hattn_bwd_dq_kernel', 'hattn_bwd_fused_kernel'], ['hattn_bwd_dkv_kernel']),
+    HATTN_BWD: (['hattn_bwd_dq_kernel'], ['hattn_bwd_dkv_kernel']),
 }
 
 

@@ -40,7 +40,8 @@ extern "C" {
  * added; 104 the shifted-rows taps of ttsmi_hgemm_wgrad_rows (the conv weight gradient, which the conv stacks of the host
  * mirror call); 105 round 5 - ttsmi_dense_chain_* and the chain tail of ttsmi_dense_block; 106 the backward chain
  * (ttsmi_dense_chain_bwd*, chain_bw, relu_bits_layout); 107 round 6 - ttsmi_dense_chain_bwd_nparts,
- * ttsmi_dense_block_bwd_chained.  Bindings check it at load time (transformertts_amd/_lib.py) so that a stale build is
+ * ttsmi_dense_block_bwd_chained, ttsmi_ft_train_step; the opt-in one-pass attention backward
+ * (ttsmi_attention_bwd_fused*, attn_fused_ws) removed - it never beat the two kernels inside the step.  Bindings check it at load time (transformertts_amd/_lib.py) so that a stale build is
  * refused instead of being called with shifted arguments. */
 #define TTSMI_VERSION 107
 
@@ -143,34 +144,6 @@ int ttsmi_attention_bwd_masked(const void* qkv, const uint8_t* key_pad, const in
                                const void* ctx, const void* dctx, const float* lse, void* dqkv, int B,
                                int H, int T, int dh, float p_drop, const void* dropmask, void* ws, size_t ws_bytes,
                                int dtype, ttsmi_stream_t stream);
-/* ONE-PASS backward for TTSMI_BF16_IO tensors at head dim 64 (model/layers.py:176-195 differentiated once): dK, dV and dQ
- * from a single recomputation of S = q.k^T and dP = d(ctx).v^T - 10 T^2 dh of products and one softmax pass where
- * ttsmi_attention_bwd runs two kernels, 14 T^2 dh and two softmax passes.  Key-stationary workgroups; the running sum of a
- * dQ tile travels down the key tiles of a head through one fp32 image in `ws` (hand-off flags inside one XCD's L2, a FIXED
- * order, no float atomics: results are bit-reproducible; waits are bounded).  Same results
- * as ttsmi_attention_bwd / _bwd_masked up to fp32 summation order (dQ is rounded to bf16 once, after the whole sum).
- * dropmask: the keep-bit table of ttsmi_attention_dropmask, or NULL (then seed / step_dev / site drive the hashed dropout
- * as in ttsmi_attention_bwd; p_drop == 0: no dropout).
- *   ws: 256-byte aligned, at least ttsmi_attention_bwd_fused_ws_bytes(B, H, T) bytes, initialised ONCE after allocation
- *       with ttsmi_attention_bwd_fused_ws_init (zeroes the hand-off flags: they reset themselves at the end of every
- *       launch, whatever its shape); the first 8 bytes are two int32 diagnostic counters that stay 0 in a healthy run
- *       ([0] hand-offs that timed out - the kernel then finishes with a wrong dQ instead of hanging -, [1] workgroups /
- *       hand-offs off the XCC that block id % 8 names - the placement that keeps the image in one L2);
- *   _supported: non-zero when (B, H, T, dh) can run on a workspace of ws_bytes (dh == 64, counters + tiles fit); the
- *       entry point returns TTSMI_ERR_UNSUPPORTED otherwise and the caller uses ttsmi_attention_bwd.
- * Round-4 status: correct and reproducible; at the benchmark shape (32, 4, 900, 64) ALONE it is level with
- * ttsmi_attention_bwd_masked (166-170 us against 166-181 us by box, after the rotated visiting order; the first version
- * was 222 against 183), but INSIDE the train step it is 0.1-0.2 ms per step slower (5.22 against 5.00 ms,
- * profiles/r04_step_ab.txt: its workgroups wait for each other beside the weight-gradient stream), so the dense-block
- * launcher only uses it with TTSMI_ATTN_FUSED_BWD=1.  A caller that opts in MUST read the two diagnostic counters after
- * the backward (the host mirror does, once per step: ops.fused_bwd_check) - a timed-out hand-off leaves a wrong dQ. */
-size_t ttsmi_attention_bwd_fused_ws_bytes(int B, int H, int T);
-int ttsmi_attention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes);
-int ttsmi_attention_bwd_fused_ws_init(void* ws, size_t ws_bytes, ttsmi_stream_t stream);
-int ttsmi_attention_bwd_fused(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
-                              const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
-                              float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, const void* dropmask,
-                              void* ws, size_t ws_bytes, ttsmi_stream_t stream);
 /* Inference forward (no dropout, TTSMI_BF16_IO tensors) for launches too small to fill the GPU - batch 1, a few heads:
  * the keys are split over extra workgroups, each split writes a normalised partial context + log-sum-exp into `ws`, and a
  * combine pass forms the result (model/layers.py:176-195 with training=False).  _ws_bytes returns 0 when B*H*T already
@@ -583,12 +556,6 @@ typedef struct ttsmi_dense_block {
      * K = 256 weight-stationary kernel (fuse_ln, d == 256, ttsmi_hgemm_k256_eligible), the forward also leaves
      * (h1 > 0) as one bit per element here and the backward masks the FFN2 dgrad with it instead of re-reading h1. */
     void* relu_bits;
-    /* optional (NULL = not used): a workspace of the one-pass attention backward, sized by
-     * ttsmi_attention_bwd_fused_ws_bytes and initialised by ttsmi_attention_bwd_fused_ws_init - the backward then runs
-     * ttsmi_attention_bwd_fused whenever ttsmi_attention_bwd_fused_supported says so (attn_ws stays the scratch of the
-     * two-kernel form). */
-    void* attn_fused_ws;
-    uint64_t attn_fused_ws_bytes;
     /* round 5 - the row-local chain (csrc/chain.hip, ttsmi_dense_chain_fwd): with chain_w set (fuse_ln and res16 required,
      * d == 256, F % 64 == 0) the forward's o-projection + res-norm 1, FFN1, FFN2 + res-norm 2 - and, with `above` set, the
      * qkv projection of the NEXT block of the stack - run as ONE launch on the weight stream chain_w
@@ -632,7 +599,7 @@ int ttsmi_set_launch_observer(ttsmi_launch_observer cb);
 /* Measurement only (the CU-partitioning A/B of the weight-gradient side stream): a HIP stream whose
  * kernels may only run on the CUs whose bits are set in mask[0 .. nwords) (hipExtStreamCreateWithCUMask; the caller owns
  * the stream), and a census - counts8[x] += the number of one-wave workgroups of an nblocks launch on `stream` that ran on
- * XCC x - that shows which CUs a mask really selects.  Neither is used unless TTSMI_WGRAD_XCDS is set. */
+ * XCC x - that shows which CUs a mask really selects (tools/probe_cu_mask.py).  The product never calls either. */
 int ttsmi_debug_stream_create_cu_mask(const uint32_t* mask, int nwords, ttsmi_stream_t* out);
 int ttsmi_debug_xcc_census(int32_t* counts8, int nblocks, ttsmi_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
@@ -663,8 +630,7 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
  * ttsmi_dense_chain_bwd reads (16-bit word (row / 16, 64-feature chunk, lane) of the kernel's own lanes; M * F / 8 bytes
  * rounded up to whole 16-row tiles).
  *
- * The BACKWARD of the same block between its two res-norms as one launch (csrc/chain16b.h; needs the 16-row form of the
- * forward chain, TTSMI_DENSE_CHAIN_FORM != 32):
+ * The BACKWARD of the same block between its two res-norms as one launch (csrc/chain16b.h):
  *     dh1 = (df . W2^T) * [h1 > 0];  g = da + dh1 . W1^T;  (d_o, dres) = LN1'(g) with x^1, rstd1, gamma1 (ttsmi_hgemm_ln_bwd's
  *     arithmetic: d_o = keep(dz), dres = dz, one partial row of dgamma / dbeta per 128-row workgroup in part_ws:
  *     ttsmi_layernorm_partials_bytes(cdiv(M, 128), 256));  dctx = d_o . Wo[256:512]^T

@@ -81,7 +81,7 @@ def _run_chain(M, F, pdrop, with_qkv, with_out32, with_bits, seed0=0, bits_layou
                                   _p(out['h1']), _p(out['bits']), bits_layout, _p(out['o']), _p(out['xh2']), _p(out['rstd2']), _p(out['o32']),
                                   _p(out['qkv']), _stream()), 'chain')
     torch.cuda.synchronize()
-    assert l.ttsmi_last_kernel().decode() == ('dense_chain_kernel' if os.environ.get('TTSMI_DENSE_CHAIN_FORM') == '32' else 'dense_chain16_kernel')
+    assert l.ttsmi_last_kernel().decode() == 'dense_chain16_kernel'
     inv = 1.0 / (1.0 - float(np.float32(pdrop))) if pdrop > 0 else 1.0
     live = (pad == 0)
     rows, cols = np.arange(M), np.arange(D)
@@ -226,8 +226,6 @@ def _lane_bits(pos):
 
 @pytest.mark.parametrize('M', [28800, 16384 + 77, 300])
 def test_forward_chain_writes_the_relu_pattern_in_the_backward_chains_layout(M):
-    if os.environ.get('TTSMI_DENSE_CHAIN_FORM') == '32':
-        pytest.skip('the lane layout belongs to the 16-row form')
     F = 1024
     ops, _lib, l, out, sh, c = _run_chain(M, F, 0.1, True, False, with_bits=True, seed0=5, bits_layout=1)
     want = _lane_bits((c['h1'].float() > 0).numpy())
@@ -244,8 +242,6 @@ def test_backward_chain_matches_the_fp64_reference_stage_by_stage(M, pdrop, dres
     """ttsmi_dense_chain_bwd (csrc/chain16b.h): dh1 = (df . W2^T) [h1 > 0]; g = da + dh1 . W1^T; res-norm 1 backward in its
     x^ form (ttsmi_hgemm_ln_bwd's arithmetic) with dropout; dctx = d_o . Wo_ctx^T; the partial rows of dgamma / dbeta - each
     stage against fp64 on the kernel's own bf16 output of the stage before."""
-    if os.environ.get('TTSMI_DENSE_CHAIN_FORM') == '32':
-        pytest.skip('the backward chain exists in the 16-row form only')
     ops, _lib, l = _env()
     from transformertts_amd.ops import _p, _stream, check
     F, seed, stepv, site = 1024, 424242, 7, 13

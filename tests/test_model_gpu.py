@@ -426,19 +426,18 @@ def test_stack_level_launcher_equals_one_call_per_block(tiny, monkeypatch):
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'f32'])
-def test_one_autograd_node_per_stat_predictor_and_backward_on_the_calling_thread(tiny, monkeypatch, precision):
-    """ops.StatPredictorFn runs the member Functions' forward / backward bodies inside ONE autograd node, and the
-    backward pass runs on the calling thread: the same launches in the same order as eight nodes per predictor on the
-    engine's thread - three train steps with dropout on end in bit-identical parameters, losses and predictor outputs."""
+def test_one_autograd_node_per_stat_predictor(tiny, monkeypatch, precision):
+    """ops.StatPredictorFn runs the member Functions' forward / backward bodies inside ONE autograd node: the same launches
+    in the same order as eight nodes per predictor - three train steps with dropout on end in bit-identical parameters,
+    losses and predictor outputs.  (use_cstep=False: both runs on the per-layer path, which is what the knob belongs to.)"""
     from transformertts_amd.model import models as mm
     cfg, W = tiny
     batch = fo.synthetic_batch(4, 50, 200, seed=23, ragged=True)
     kw = dict(dropout_rate=0.1, predictors_dropout=0.1, seed=7, precision=precision)
     runs = []
-    for one_node, same_thread in ((True, True), (False, False)):
+    for one_node in (True, False):
         monkeypatch.setattr(mm, '_PRED_ONE_NODE', one_node)
-        monkeypatch.setattr(mm, '_BWD_SAME_THREAD', same_thread)
-        m = _model(cfg, W, **kw)
+        m = _model(cfg, W, use_cstep=False, **kw)
         m._compile(learning_rate=1e-3)
         outs = [m.train_step(*batch) for _ in range(3)]
         torch.cuda.synchronize()

@@ -154,37 +154,12 @@ def bench_attn():
                                                    _stream()), 'attention_bwd_masked')
             fl = 4.0 * B * H * T * T * dh
             cases = [('gen bits', gen, 0), ('fwd bits', fwd_m, 1), ('bwd bits', bwd_m, 2)]
-            if io == 'h' and dh == 64:                  # the one-pass backward (ttsmi_attention_bwd_fused), keep-bit dropout
-                fws = torch.empty(int(l.ttsmi_attention_bwd_fused_ws_bytes(B, H, T)), dtype=torch.uint8, device=dev)
-                check(l.ttsmi_attention_bwd_fused_ws_init(_p(fws), fws.numel(), _stream()))
-
-                def bwd_f():
-                    j = i[0] % R
-                    i[0] += 1
-                    check(l.ttsmi_attention_bwd_fused(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(dctx[j]), _p(lse), _p(dqkv),
-                                                      B, H, T, dh, pdrop, 0, None, 0, _p(dm), _p(fws), fws.numel(), _stream()),
-                          'attention_bwd_fused')
-                cases.append(('bwd 1pass bits', bwd_f, 2))
             for nm, fn, mult in cases:
                 t = timeit(fn, n=20)
                 out.append(dict(kind='attn', name=f'{nm} p={pdrop}' + ('' if io == 'h' else ' f32io'), M=B * T, K=T, N=dh, us=t, tflops=mult * fl / t / 1e6 + 1e-9, tbs=0.0))
         tf_ = timeit(fwd, n=20)
         tb_ = timeit(bwd, n=20)
         fl = 4.0 * B * H * T * T * dh
-        if io == 'h' and dh == 64 and pdrop == 0:
-            fws0 = torch.empty(int(l.ttsmi_attention_bwd_fused_ws_bytes(B, H, T)), dtype=torch.uint8, device=dev)
-            check(l.ttsmi_attention_bwd_fused_ws_init(_p(fws0), fws0.numel(), _stream()))
-
-            def bwd_f0():
-                j = i[0] % R
-                i[0] += 1
-                check(l.ttsmi_attention_bwd_fused(_p(qkvs[j]), _p(pad), _p(klen), _p(ctx), _p(dctx[j]), _p(lse), _p(dqkv),
-                                                  B, H, T, dh, 0.0, 0, None, 0, None, _p(fws0), fws0.numel(), _stream()),
-                      'attention_bwd_fused')
-            t1 = timeit(bwd_f0, n=20)
-            out.append(dict(kind='attn', name='bwd 1pass p=0.0', M=B * T, K=T, N=dh, us=t1, tflops=2 * fl / t1 / 1e6, tbs=0.0))
-            dg = fws0[:8].view(torch.int32).cpu().tolist()
-            assert dg == [0, 0], f'one-pass backward diagnostics {dg}'
         out.append(dict(kind='attn', name=f'fwd p={pdrop}' + ('' if io == 'h' else ' f32io'), M=B * T, K=T, N=dh, us=tf_, tflops=fl / tf_ / 1e6, tbs=0.0))
         out.append(dict(kind='attn', name=f'bwd p={pdrop}' + ('' if io == 'h' else ' f32io'), M=B * T, K=T, N=dh, us=tb_, tflops=2 * fl / tb_ / 1e6, tbs=0.0))
     return out

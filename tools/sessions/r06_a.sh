@@ -2,6 +2,8 @@
 # Round 6, first session: (1) which CUs a stream mask selects, (2) parity of the re-built attention kernels (two tile images,
 # log-sum-exp folded into the dK/dV accumulator) and of the backward chain's LayerNorm partial count, (3) the attention
 # kernels alone, four builds side by side, (4) the train step with the weight-gradient stream confined to whole XCDs.
+# (History: the TTSMI_WGRAD_XCDS knob of step 4 and the -DHATTN_* variant builds existed at commit 9c2cbc7 only; the result is
+# profiles/r06_wgrad_cu_mask_ab.txt.)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 L=$PWD/transformertts_amd/lib

@@ -54,10 +54,6 @@ SIGNATURES = {
     'ttsmi_attention_fwd_splitkeys_ws_bytes': (c_size_t, [I, I, I, I]),
     'ttsmi_attention_fwd_splitkeys': (I, [P, P, P, P, P, I, I, I, I, P, c_size_t, S]),
     'ttsmi_attention_bwd_masked': (I, [P, P, P, P, P, P, P, I, I, I, I, F, P, P, c_size_t, I, S]),
-    'ttsmi_attention_bwd_fused_ws_bytes': (c_size_t, [I, I, I]),
-    'ttsmi_attention_bwd_fused_supported': (I, [I, I, I, I, c_size_t]),
-    'ttsmi_attention_bwd_fused_ws_init': (I, [P, c_size_t, S]),
-    'ttsmi_attention_bwd_fused': (I, [P, P, P, P, P, P, P, I, I, I, I, F, c_uint64, P, c_uint32, P, P, c_size_t, S]),
     'ttsmi_add_layernorm_fwd': (I, [P, P, P, P, P, P, I, P, F, c_uint32, F, c_uint32, c_uint64, P,
                                     F, P, P, P, I, I, P, S]),
     'ttsmi_add_layernorm_bwd_ws_bytes': (c_size_t, [I, I]),
@@ -157,7 +153,6 @@ def _dense_block_fields():
             [(n, p) for n in ('xhat1', 'xhat2', 'lnp_ws1', 'lnp_ws2')] + [('lnp_ws1_bytes', u64), ('lnp_ws2_bytes', u64)] +
             [(n, p) for n in ptrs2] + [(n, u64) for n in ('attn_ws_bytes', 'ln_ws_bytes', 'wgrad_ws_bytes')] +
             [('main_stream', p), ('side_stream', p), ('ev', p * 4), ('below', p), ('ln2_done', i32), ('res16', i32), ('relu_bits', p),
-             ('attn_fused_ws', p), ('attn_fused_ws_bytes', u64),
              ('chain_w', p), ('chain_w_bytes', u64), ('above', p), ('qkv_done', i32), ('chain_pad_', i32),
              ('chain_bw', p), ('chain_bw_bytes', u64)])
 

@@ -553,21 +553,6 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
     return TTSMI_OK;
 }
 
-size_t ttsmi_attention_bwd_fused_ws_bytes(int B, int H, int T) { return ttsmi_hattention_bwd_fused_ws_bytes(B, H, T); }
-int ttsmi_attention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes) {
-    return ttsmi_hattention_bwd_fused_supported(B, H, T, dh, ws_bytes);
-}
-int ttsmi_attention_bwd_fused_ws_init(void* ws, size_t ws_bytes, ttsmi_stream_t stream) {
-    return ttsmi_hattention_bwd_fused_ws_init(ws, ws_bytes, (hipStream_t)stream);
-}
-int ttsmi_attention_bwd_fused(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
-                              const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
-                              float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, const void* dropmask,
-                              void* ws, size_t ws_bytes, ttsmi_stream_t stream) {
-    return ttsmi_hattention_bwd_fused(qkv, key_pad, klen, ctx, dctx, lse, dqkv, B, H, T, dh, p_drop, seed, step_dev, site,
-                                      dropmask, ws, ws_bytes, (hipStream_t)stream);
-}
-
 size_t ttsmi_attention_fwd_splitkeys_ws_bytes(int B, int H, int T, int dh) {
     return ttsmi_hattention_fwd_split_ws_bytes(B, H, T, dh);
 }

@@ -63,11 +63,8 @@ struct HAttnP {
     // forward only, split_keys != 0: blockIdx.y = key split s owns keys [s*split_keys, (s+1)*split_keys) and writes its
     // own softmax-normalised partial context / log-sum-exp at ctx + s*ctx_split (elements) / lse + s*lse_split
     int split_keys; long ctx_split, lse_split;
-    // one-pass backward only (hattn_bwd_fused_kernel): the fp32 partial dQ tiles of the key tiles of a head (a 16 KB register
-    // image per (b, h, 64-query tile, key tile)), the ticket counters (`sem`), and the diagnostic counters
-    float* dq_acc; int* sem; int* diag;
-    int ablate;                     // measurement build only: 1 = no hand-off waits / incoming image, 2 = no image stores, 4 = no dQ product
-    unsigned long long* dbg;        // measurement build only (-DTTSMI_ABLATION_BUILD): per-workgroup time stamps of the one-pass backward
+    int ablate;                     // measurement build only (TTSMI_ATTN_FWD_ABLATE, see the forward kernel)
+    unsigned long long* dbg;        // measurement build only (-DTTSMI_ABLATION_BUILD): per-wave section times of the forward
 };
 
 // DROP template values: 0 = no dropout, 1 = keep decisions hashed in the inner loop (ttsmi_pair_hash), 2 = keep
@@ -1184,403 +1181,6 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
 }
 
 // =================================================================================================
-// backward, ONE pass: dK, dV AND dQ from a single recomputation of S / dP   (model/layers.py:176-195 differentiated once)
-// =================================================================================================
-// The two-kernel backward above recomputes S = Q.K^T, dP = dO.V^T and the softmax twice (14 T^2 dh of products for 8
-// algorithmic, two passes of ~8 vector instructions per score).  Here a key-stationary workgroup (128 keys, as in the dK/dV
-// kernel) also produces dQ: every wave writes its 32 x 32 dS tile (bf16) into an LDS image dS[128 keys][64 queries], and
-// after the two query sub-tiles of a staged tile the four waves multiply dQ^T[c][q] = sum_key K^T[c][key] dS^T[key][q] over
-// all 128 keys of the workgroup - one 32 x 32 block per wave, both operands through the transposing LDS read - 10 T^2 dh
-// of products and ONE softmax recomputation.
-//
-// dQ still has to be summed over the key tiles of a head, i.e. ACROSS workgroups - reproducibly, so no float atomics.
-// The running sum of a (head, 64-query tile) travels from key tile to key tile through ONE fp32 register image (16 KB) in
-// scratch: the k-th contributor of a query tile waits for flag == k, adds the image to its own product, stores it back and
-// posts k + 1; the last one converts to bf16 and writes dqkv.  The order of the contributors of a query tile is fixed (see
-// the rotated visiting order in the kernel), so the bits are.  All key tiles of a head are dispatched to one XCD (block id =
-// 8 * slot + xcd; head = xcd + 8 * (slot / nkt), key tile = slot % nkt; XCC_ID == block id % 8 on this part -
-// tools/probes/xcd_sem_probe.hip - and re-checked here: diag[1]), so the image (31 MB for a whole decoder layer, rewritten
-// in place 8 times) lives in that XCD's L2: plain write-through stores, `s_waitcnt vmcnt(0)` + a barrier before the flag,
-// L1-bypassing (agent-scope) loads on the reading side; no L2 write-back / invalidate (what an agent-scope release / acquire
-// fence costs on a multi-XCD part; the probe shows the same protocol reading stale data ACROSS XCDs and being exact inside
-// one).
-// Three round trips per hand-off are kept off the critical path (the first version exposed them: +2.6 us on a 2.9 us
-// step): every wave issues its own flag load right after the barrier that starts a step and looks at the value after the
-// two query sub-tiles; the incoming image is requested as soon as the flag is seen, before the barrier that completes the
-// dS image, and added after the dQ product; the outgoing image's acknowledgement is waited for one step later (before the
-// next step's second barrier), where the flag is posted; the barriers inside the loop order LDS only (hlds_barrier: a
-// __syncthreads() drains the vector-memory counter, i.e. waits for exactly those round trips - 203 vs 139 us measured).
-// Waits are bounded: one that never ends raises diag[0] and the kernel finishes (with a wrong dQ) instead of hanging.  A
-// workgroup waits for workgroups of its own head only; block ids are dispatched in order and a head's key tiles have
-// consecutive slots of one XCD, so at most the NEWEST head of an XCD is partly resident - every other resident workgroup
-// has its whole head beside it and finishes without anybody's help, which frees the slots the newest head is waiting for.
-// Flags reset themselves (the last contributor posts 0), so their region only has to be zero once, at allocation
-// (ttsmi_attention_bwd_fused_ws_init).
-// STATUS (round 4): correct, bit-reproducible, tested; opt-in (TTSMI_ATTN_FUSED_BWD=1 for the planned dense blocks; the
-// entry point is always available).  Decoder layer (32, 4, 900, 64), keep-bit dropout, ALONE: two kernels 181 us, this
-// kernel 166 us (with its delta launch); first version 222 us - every key tile walked the query tiles 0, 1, 2 ... and the
-// chain was a pipeline that fills (key tile 7 waited 27 of its 95 us; tools/debug/fused_bwd_timeline.py) - 182 us with the
-// rotated order, 166 us with delta taken out of the loop.  INSIDE the train step it still loses: 5.18 against 5.10 ms
-// per step (4.97 / 4.91 without the weight-gradient stream beside it): a launch that follows a draining kernel gets its
-// slots one at a time, heads stay partly resident for longer, and a workgroup that spins keeps a slot busy - the two
-// kernels have no workgroup that waits for another.  What is left per step of a key tile besides the dK/dV kernel's work:
-// the dS image (written and read back transposed), the dQ product, 16 KB of image in and 16 KB out through L2 (0.5 GB per
-// decoder layer), a third barrier.
-// (Also measured: a ticket scheme without any waiting - every key tile stores its own partial image, the last arrival adds
-// them in fixed order - is 40 % SLOWER than the two kernels: 251 MB of partials per decoder layer do not stay in L2.)
-__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* img, int k0, int t, int colblock, int lane) {
-    // MFMA 32x32x16 operand (A or B alike) whose 8 reduction elements are rows k0 + 16 t + 4 hh + {0..3, 8..11} of the
-    // row-major image img[row][72] at column colblock * 32 + (lane & 31): the addressing of accumTR
-    typedef __attribute__((address_space(3))) as16x4* lds_ptr;
-    constexpr int LD = 72;
-    const uint16_t* a = img + (k0 + 16 * t + 4 * (lane >> 5) + ((lane & 15) >> 2)) * LD + ((lane >> 4) & 1) * 16 + 4 * (lane & 3) +
-                        colblock * 32;
-    as16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
-    as16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 8 * LD));
-    as16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-__device__ __forceinline__ float row16_sum(float v) {          // sum over the 16 lanes of a DPP row, in every lane of it
-    v += ttsmi_dpp<TTSMI_DPP_QUAD_1032, 0xF>(v, 0.f);
-    v += ttsmi_dpp<TTSMI_DPP_QUAD_2301, 0xF>(v, 0.f);
-    v += ttsmi_dpp<TTSMI_DPP_ROW_HALF_MIRROR, 0xF>(v, 0.f);
-    v += ttsmi_dpp<TTSMI_DPP_ROW_MIRROR, 0xF>(v, 0.f);
-    return v;
-}
-#define HFUSED_SPIN_LIMIT (1 << 18)
-// A workgroup barrier that orders LDS accesses only.  __syncthreads() also drains the vector-memory counter
-// (s_waitcnt vmcnt(0)): every barrier of a step would then wait for the dQ image stores to be acknowledged, for the
-// incoming image and for the next tile's prefetch - the round trips this kernel keeps in flight across its barriers.
-__device__ __forceinline__ void hlds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// delta[b, h, t] = sum_c dO[b, t, h, c] O[b, t, h, c] for the one-pass backward (bf16 tensors, head dim 64): 8 lanes share a
-// (row, head) pair, 16 bytes of each tensor per lane.  Every key tile of a head needs the value of every query BEFORE its
-// scores, so it cannot travel down the chain; computed inside the one-pass kernel it was a third staged tile and 16 DPP
-// sums per step in each of the 8 key tiles of a head (the two-kernel backward takes it from its dQ kernel).
-__global__ __launch_bounds__(256) void hattn_delta_kernel(const uint16_t* __restrict__ dO, const uint16_t* __restrict__ O,
-                                                          float* __restrict__ delta, int B, int H, int T) {
-    const int lane = threadIdx.x & 63;
-    const long pair = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);       // (row, head)
-    const long rows = (long)B * T;
-    const bool ok = pair < rows * H;
-    const long row = ok ? pair / H : 0;
-    const int h = ok ? (int)(pair - row * H) : 0;
-    const long off = row * (long)(H * 64) + h * 64 + (lane & 7) * 8;
-    const uint4 xa = *reinterpret_cast<const uint4*>(dO + off), ya = *reinterpret_cast<const uint4*>(O + off);
-    const bf16x8 x = __builtin_bit_cast(bf16x8, xa), y = __builtin_bit_cast(bf16x8, ya);
-    float v = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v += (float)x[e] * (float)y[e];
-    v += ttsmi_dpp<TTSMI_DPP_QUAD_1032, 0xF>(v, 0.f);
-    v += ttsmi_dpp<TTSMI_DPP_QUAD_2301, 0xF>(v, 0.f);
-    v += ttsmi_dpp<TTSMI_DPP_ROW_HALF_MIRROR, 0xF>(v, 0.f);                 // every lane: the sum of its group of 8
-    const long b = row / T, t = row - b * T;
-    if (ok && (lane & 7) == 0) delta[(b * H + h) * T + t] = v;
-}
-
-template <int DH, int DROP>
-__global__ __launch_bounds__(256, 2) void hattn_bwd_fused_kernel(HAttnP p) {
-    static_assert(DH == 64, "the one-pass backward is built for head dim 64 (one 32 x 32 dQ block per wave)");
-    constexpr bool QH = true;                        // bf16 tensors only
-    constexpr int LD = DH + 8;                       // row stride of every LDS image (bf16 elements); HKT + 8 as well
-    constexpr int IMG = HKT * LD;
-    __shared__ __attribute__((aligned(16))) uint16_t smem_h[2 * IMG + 2 * 128 * LD];
-    __shared__ float statS[3 * HKT];
-    uint16_t* Qs = smem_h;                           // [64 queries][72]
-    uint16_t* Os = Qs + IMG;                         // dO tile
-    uint16_t* Ks = Os + IMG;                         // [128 keys][72]: this workgroup's K rows, stationary (dQ's A operand)
-    uint16_t* dSs = Ks + 128 * LD;                   // [128 keys][64 queries + 8]
-    float* lseS = statS;
-    float* delS = lseS + HKT;
-    uint32_t* rbS = reinterpret_cast<uint32_t*>(delS + HKT);
-
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nkt = (p.T + 127) >> 7, nqt = (p.T + HKT - 1) / HKT;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int bx = slot % nkt;                                     // this workgroup's key tile
-    // The grid holds hx heads per XCD and a workgroup walks heads gi, gi + hx, ...: by default hx = every head (one head per
-    // workgroup).  TTSMI_ATTN_FUSED_PERSIST=1 caps hx at what is resident at once (2 workgroups per CU) so that no second
-    // ROUND of workgroups starts one by one with its heads partly resident - measured SLOWER (decoder layer alone 179.6
-    // against 166 us, +0.16 instead of +0.09 ms per step): the prologue (fragments, the K image, the first tile's round
-    // trip) and the dK / dV stores of a team of 8 then run back to back instead of beside other workgroups' steps.
-    const int hx = (int)(gridDim.x >> 3) / nkt, ngi = (p.B * p.H + 7) >> 3;
-  for (int gi = slot / nkt; gi < ngi; gi += hx) {
-    const int grp = xcd + 8 * gi;                                  // grp = b * H + h
-    if (grp >= p.B * p.H) break;
-#ifdef TTSMI_ABLATION_BUILD
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
-    unsigned long long dbg_spin = 0, dbg_first = 0;
-    int dbg_polls = 0;
-#endif
-    const int h = grp % p.H, b = grp / p.H;
-    const int d = p.H * DH;
-    const int key = bx * 128 + wave * 32 + l31;
-    const int klen = p.klen[b];
-    const int nact = max(1, (klen + 127) >> 7);      // key tiles that take part in the chain (tile 0 always does)
-    const bool kok = key < p.T;
-    const bool kact = key < klen;
-    const bool wave_live = (bx * 128 + wave * 32) < klen;
-    const bool wg_active = bx < nact;
-    const int abl = TTSMI_ABLATE_BITS(p.ablate);
-    // ROTATED visiting order: key tile j walks the query tiles (s + j c) mod nqt, s = 0 .. nqt - 1.  With every key tile
-    // walking 0, 1, 2 ... the chain was a pipeline that FILLS: key tile j could not add anything before step j (tile 7 of
-    // the benchmark shape spent 27 of its 95 us waiting).  Rotated, the active key tiles start on nact DIFFERENT query
-    // tiles - each opens that tile's sum instead of waiting for it - and afterwards always find a tile whose previous
-    // contributor finished it at least one step earlier.  The order in which the key tiles add to ONE query tile is still
-    // fixed (by the steps at which they reach it), so the bits are; it differs from query tile to query tile.
-    const int rot_c = nact > 1 ? max(1, (nqt - 1) / (nact - 1)) : 1;         // offsets j c <= nqt - 1: all different
-    const int rot_off = bx * rot_c;
-    const float* Qb = eptr<QH>(p.qkv, (long)b * p.T * p.ld + h * DH);
-    const float* Kb = eptr<QH>(Qb, d);
-    const float* Vb = eptr<QH>(Qb, 2 * d);
-    const float* dOb = eptr<QH>(p.dctx, (long)b * p.T * d + h * DH);
-
-    f32x16 dk[DH / 32], dv[DH / 32];
-#pragma unroll
-    for (int cb = 0; cb < DH / 32; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[cb][r] = 0.f; dv[cb][r] = 0.f; }
-
-    if (wg_active) {
-        unsigned xid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
-        xid &= 15;
-        if (tid == 0 && (int)xid != xcd) atomicAdd(p.diag + 1, 1);            // the placement this kernel relies on does not hold
-        bf16x8 kf[DH / 16], vf[DH / 16];
-        frags_of<DH, QH>(Kb, p.ld, key, kok, hh, kf);
-        frags_of<DH, QH>(Vb, p.ld, key, kok, hh, vf);
-        const float padterm = !kact ? -INFINITY : ((p.key_pad[(long)b * p.T + key]) ? -1e9f * LOG2E : 0.f);
-        const float inv_sqrt = 1.0f / p.sqrt_dk;
-        const float c1 = LOG2E * inv_sqrt;
-        const long stat0 = (long)grp * p.T;
-        uint64_t dkey = 0;
-        if (DROP == 1) dkey = ttsmi_drop_key(p.seed, p.step_dev, p.site);
-        const int ntile32 = (p.T + 31) >> 5;
-        const uint32_t* mlane = nullptr;
-        uint32_t mnext[HKT / 32] = {0u, 0u};
-        if (DROP == 2) {
-            const int rp = (l31 & 3) + 4 * (l31 >> 3), hp = (l31 >> 2) & 1;
-            mlane = reinterpret_cast<const uint32_t*>(p.dmask) +
-                    (((long)grp * ntile32 * ntile32 + (bx * 4 + wave)) * 16 + rp) * 2 + hp;
-        }
-        auto mask_fetch = [&](int q0) {
-            if (DROP == 2 && kok) {
-#pragma unroll
-                for (int u = 0; u < HKT / 32; ++u) {
-                    const int qt = (q0 >> 5) + u;
-                    mnext[u] = qt < ntile32 ? mlane[(long)qt * ntile32 * 32] : 0u;
-                }
-            }
-        };
-        // ---- the stationary K image (dQ's A operand) and a zeroed dS image (dead waves never write theirs)
-        {
-            Tile<DH, QH> t0, t1;
-            t0.fetch(Kb, p.ld, bx * 128, max(0, min(HKT, p.T - bx * 128)), tid);
-            t1.fetch(Kb, p.ld, bx * 128 + HKT, max(0, min(HKT, p.T - bx * 128 - HKT)), tid);
-            t0.stash(Ks, tid);
-            t1.stash(Ks + IMG, tid);
-            for (int i = tid; i < 128 * LD / 8; i += 256) reinterpret_cast<uint4*>(dSs)[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        int* const sem = p.sem + (long)grp * nqt;                              // one hand-off flag per query tile of this head
-        float* const acc0 = p.dq_acc + (long)grp * nqt * 4096 + (wave * 16 * 64 + lane);      // register image: + r * 64, + tile * 4096
-        const int cbq = wave & 1, qbq = wave >> 1;       // this wave's 32 x 32 block of the dQ^T tile: columns / queries
-        bool dead = false;                               // (wave-uniform) a hand-off timed out: stop waiting, finish the kernel
-        int post = -1;                                   // (thread 0) flag to post for the previous tile, once its stores are acknowledged
-
-        Tile<DH, QH> rq, ro;
-        float rl = 0.f, rdl = 0.f;
-        int rnv = 0;
-        {
-            const int qf = (rot_off % nqt) * HKT;
-            int nv = min(HKT, p.T - qf);
-            rq.fetch(Qb, p.ld, qf, nv, tid);
-            ro.fetch(dOb, d, qf, nv, tid);
-            mask_fetch(qf);
-            rnv = nv;
-            if (tid < HKT) {
-                rl = p.lse[stat0 + min(qf + tid, p.T - 1)];
-                rdl = p.delta[stat0 + min(qf + tid, p.T - 1)];
-            }
-        }
-        int post_it = 0;                                 // the query tile `post` belongs to
-        for (int st = 0; st < nqt; ++st) {
-            const int it = (st + rot_off) % nqt, q0 = it * HKT;              // this step's query tile
-            // position of this key tile among the contributors of query tile `it`: the active key tiles ordered by the step
-            // at which they reach it (all different)
-            int pos = 0;
-            for (int j = 0; j < nact; ++j) {
-                int sj = it - j * rot_c;
-                sj += sj < 0 ? nqt : 0;
-                pos += sj < st ? 1 : 0;
-            }
-            const bool chained = pos > 0 && !(abl & 1);
-            const bool chain_last = pos == nact - 1;
-            hlds_barrier();                                    // nobody still reads the previous step's Q / dO / dS images
-            rq.stash(Qs, tid);
-            ro.stash(Os, tid);
-            if (tid < HKT) {
-                delS[tid] = rdl * inv_sqrt;      // dS = P (keep dP / (1 - p) - delta) / sqrt(dh): the scale is folded in
-                lseS[tid] = tid < rnv ? rl * LOG2E : INFINITY;
-                if (DROP == 1) rbS[tid] = ttsmi_row_base(dkey, (uint32_t)(stat0 + q0 + tid));
-            }
-            uint32_t mcur[HKT / 32];
-#pragma unroll
-            for (int u = 0; u < HKT / 32; ++u) mcur[u] = mnext[u] >> (4 * hh);
-            // the previous tile's image has reached L2 by now: nothing younger is in flight - this step's prefetches are
-            // issued below - so the wait is for stores issued a barrier and a stash ago
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            hlds_barrier();
-            if (tid == 0 && post >= 0) {
-                __hip_atomic_store(sem + post_it, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                post = -1;
-            }
-            // every wave reads this tile's flag for itself, now; the value is looked at after the sub-tiles
-            int flag = 0;
-            if (chained && !dead) flag = __hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (st + 1 < nqt) {
-                const int qn = ((st + 1 + rot_off) % nqt) * HKT;
-                int nv = min(HKT, p.T - qn);
-                rq.fetch(Qb, p.ld, qn, nv, tid);
-                ro.fetch(dOb, d, qn, nv, tid);
-                mask_fetch(qn);
-                rnv = nv;
-                if (tid < HKT) {
-                    rl = p.lse[stat0 + min(qn + tid, p.T - 1)];
-                    rdl = p.delta[stat0 + min(qn + tid, p.T - 1)];
-                }
-            }
-#pragma unroll
-            for (int qt = 0; qt < HKT / 32; ++qt) {
-                if (!wave_live) break;                         // (its dS rows stay zero)
-                f32x16 s = dot16<DH>(Qs, qt * 32 + l31, hh, kf);             // S[q][key]
-                f32x16 dp = dot16<DH>(Os, qt * 32 + l31, hh, vf);            // dP = dO.V^T
-                f32x16 pt;
-                const float ik2 = (DROP ? p.inv_keep : 1.0f) * inv_sqrt;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = qt * 32 + rowmap16(r, hh);
-                    float pr = EXP2(s[r] * c1 + padterm - lseS[ql]);        // lse = +inf for q >= T
-                    float dpr = dp[r];
-                    if (DROP == 1) {
-                        const uint32_t hsh = ttsmi_pair_hash(rbS[ql], (uint32_t)key);
-                        const bool keep = ttsmi_keep_of(hsh, (uint32_t)key, p.thr, 1.0f) != 0.f;
-                        dpr = keep ? dpr : 0.f;
-                        pt[r] = keep ? pr : 0.f;
-                    } else if (DROP == 2) {
-                        const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe(mcur[qt], (r & 3) + 8 * (r >> 2), 1);   // 0 / ~0
-                        dpr = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, dpr) & km);
-                        pt[r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, pr) & km);
-                    } else {
-                        pt[r] = pr;
-                    }
-                    s[r] = pr * fmaf(dpr, ik2, -delS[ql]);                                     // dS
-                }
-                bf16x8 pb[2], sb[2];
-                to_frags(pt, pb);
-                to_frags(s, sb);
-                accumTR<DH, DH / 32>(Os, qt * 32, lane, pb, dv, 0);           // dV^T += dO^T.P
-                accumTR<DH, DH / 32>(Qs, qt * 32, lane, sb, dk, 0);           // dK^T += Q^T.dS
-                // dS[key = this lane][q = qt * 32 + 8 g + 4 hh + 0..3] = registers 4 g .. 4 g + 3 = sb[g >> 1][4 (g & 1) ..]
-                uint16_t* row = dSs + (wave * 32 + l31) * LD + qt * 32 + 4 * hh;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const as16x8 v = __builtin_bit_cast(as16x8, sb[g4 >> 1]);
-                    as16x4 w;
-                    w[0] = v[4 * (g4 & 1)]; w[1] = v[4 * (g4 & 1) + 1]; w[2] = v[4 * (g4 & 1) + 2]; w[3] = v[4 * (g4 & 1) + 3];
-                    *reinterpret_cast<as16x4*>(row + 8 * g4) = w;
-                }
-            }
-            // ---- the chain: key tile bx - 1 must have stored its sum for this query tile (normally seen by the early load)
-            float* const acc = acc0 + (long)it * 4096;
-            float in[16];
-            if (chained) {
-                if (!dead) {
-                    int spins = 0;
-                    flag = __builtin_amdgcn_readfirstlane(flag);
-#ifdef TTSMI_ABLATION_BUILD
-                    const unsigned long long dbg_w0 = __builtin_amdgcn_s_memrealtime();
-#endif
-                    while ((flag & 0xFF) != pos) {
-                        __builtin_amdgcn_s_sleep(1);
-                        flag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sem + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        if (++spins > HFUSED_SPIN_LIMIT ||
-                            ((spins & 1023) == 0 && __hip_atomic_load(p.diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                            if (lane == 0) atomicAdd(p.diag, 1);
-                            dead = true;
-                            break;
-                        }
-                    }
-                    if (!dead && (unsigned)(flag >> 8) != xid && lane == 0) atomicAdd(p.diag + 1, 1);
-#ifdef TTSMI_ABLATION_BUILD
-                    if (wave == 0) {
-                        const unsigned long long dbg_w1 = __builtin_amdgcn_s_memrealtime();
-                        dbg_spin += dbg_w1 - dbg_w0;
-                        dbg_polls += spins;
-                        if (st == 0) dbg_first = dbg_w1 - dbg_t0;
-                    }
-#endif
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) in[r] = __hip_atomic_load(acc + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            hlds_barrier();                                    // the dS image is complete (the incoming image may still be in flight)
-            f32x16 dqa, dqb;                                   // two independent accumulation chains
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dqa[r] = 0.f; dqb[r] = 0.f; }
-            if (!(abl & 4))
-#pragma unroll
-            for (int kk = 0; kk < 4; kk += 2)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    dqa = MFMA16(tr_frag(Ks, kk * 32, t, cbq, lane), tr_frag(dSs, kk * 32, t, qbq, lane), dqa);   // dQ^T += K^T.dS^T
-                    dqb = MFMA16(tr_frag(Ks, kk * 32 + 32, t, cbq, lane), tr_frag(dSs, kk * 32 + 32, t, qbq, lane), dqb);
-                }
-            float dq[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dq[r] = chained ? in[r] + (dqa[r] + dqb[r]) : dqa[r] + dqb[r];
-            if (chain_last) {
-                const int q = q0 + qbq * 32 + l31;
-                if (q < p.T) {
-                    uint16_t* dst = reinterpret_cast<uint16_t*>(p.dqkv) + ((long)b * p.T + q) * p.ld + h * DH + cbq * 32 + 4 * hh;
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        bf16x4 o4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = (__bf16)dq[4 * g4 + e];
-                        *reinterpret_cast<uint2*>(dst + 8 * g4) = __builtin_bit_cast(uint2, o4);
-                    }
-                }
-            } else if (!(abl & 2)) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r * 64] = dq[r];       // plain stores: written through to the XCD's L2
-            }
-            if (tid == 0) { post = chain_last ? 0 : ((pos + 1) | ((int)xid << 8)); post_it = it; }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        hlds_barrier();
-        if (tid == 0 && post >= 0) __hip_atomic_store(sem + post_it, post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    // dK / dV of this workgroup's 128 keys (zeros for a key tile past the last unpadded key)
-    float* patch = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(smem_h) + wave * (32 * (DH + 8) * 2));
-    const int row0 = bx * 128 + wave * 32;
-    const int nvalid = min(32, p.T - row0);
-    const float* dst = eptr<QH>(p.dqkv, (long)b * p.T * p.ld + h * DH);
-    storeT16<DH, QH>(patch, dk, 1.0f, const_cast<float*>(eptr<QH>(dst, d)), p.ld, row0, nvalid, lane);
-    storeT16<DH, QH>(patch, dv, DROP ? p.inv_keep : 1.0f, const_cast<float*>(eptr<QH>(dst, 2 * d)), p.ld, row0, nvalid, lane);
-    __syncthreads();                         // the patches alias the images the next head stages
-#ifdef TTSMI_ABLATION_BUILD
-    if (p.dbg && tid == 0) {                 // [block id][8]: start, end, time spent waiting, time to the first hand-off, polls, key tile, head, active
-        unsigned long long* o = p.dbg + (long)blockIdx.x * 8;
-        o[0] = dbg_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = dbg_spin; o[3] = dbg_first;
-        o[4] = (unsigned long long)dbg_polls; o[5] = (unsigned long long)bx; o[6] = (unsigned long long)grp; o[7] = wg_active ? 1 : 0;
-    }
-#endif
-  }
-}
-
-// =================================================================================================
 // keep-bit generator for DROP == 2 (layout: see the top of the file).  One wave per 32-query tile walks the key
 // blocks; the decisions are the SAME hash the DROP == 1 kernels, the exact-fp32 kernels and attention_weights
 // evaluate, so every consumer sees one mask.
@@ -1957,83 +1557,3 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
     return TTSMI_OK;
 }
 
-// ---- one-pass backward (hattn_bwd_fused_kernel) ------------------------------------------------------------------------
-// Workspace layout (bytes): [0, 16) four int32 diagnostic counters ([0]: hand-offs that timed out, [1]: hand-offs between
-// different XCC ids / workgroups off their XCD; both stay 0), [16, 16 + S) the hand-off flags, one per (head, 64-query
-// tile) (S from the workspace size alone, so the region does not move with the batch shape and stays all-zero between
-// launches), then the fp32 dQ images [head][query tile][4096], then delta [batch][head][T] (hattn_delta_kernel).
-static size_t hfused_flag_bytes(size_t ws_bytes) { return ((ws_bytes / 4096 + 255) / 256) * 256; }
-static size_t hfused_delta_bytes(int B, int H, int T) { return (((size_t)B * H * T * sizeof(float) + 255) / 256) * 256; }
-size_t ttsmi_hattention_bwd_fused_ws_bytes(int B, int H, int T) {
-    const size_t tiles = (size_t)B * H * ttsmi_cdiv(T, HKT);
-    const size_t acc = tiles * 16384;
-    const size_t dl = hfused_delta_bytes(B, H, T);
-    return 16 + hfused_flag_bytes(acc + dl + acc / 2048 + 8192) + 512 + acc + dl;
-}
-int ttsmi_hattention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes) {
-    if (dh != 64 || B <= 0 || H <= 0 || T <= 0) return 0;
-    const size_t flags = hfused_flag_bytes(ws_bytes);
-    const size_t qtiles = (size_t)B * H * ttsmi_cdiv(T, HKT);
-    return qtiles * 4 <= flags && 16 + flags + 256 + qtiles * 16384 + hfused_delta_bytes(B, H, T) <= ws_bytes;
-}
-int ttsmi_hattention_bwd_fused_ws_init(void* ws, size_t ws_bytes, hipStream_t st) {
-    TTSMI_CHECK_ARG(ws && ws_bytes >= 4096 && (((uintptr_t)ws) & 255) == 0, "attention_bwd_fused_ws_init: workspace missing, < 4096 bytes or not 256-byte aligned");
-    if (hipMemsetAsync(ws, 0, 16 + hfused_flag_bytes(ws_bytes), st) != hipSuccess) {
-        ttsmi_set_error("attention_bwd_fused_ws_init: memset failed");
-        return TTSMI_ERR_LAUNCH;
-    }
-    return TTSMI_OK;
-}
-int ttsmi_hattention_bwd_fused(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
-                               const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
-                               float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, const void* dropmask,
-                               void* ws, size_t ws_bytes, hipStream_t st) {
-    HAttnP p;
-    int rc = hfill(p, qkv, key_pad, klen, B, H, T, dh, p_drop, seed, step_dev, site, "attention_bwd_fused");
-    if (rc) return rc;
-    TTSMI_CHECK_ARG(ctx && dctx && lse && dqkv && ws, "attention_bwd_fused: null pointer");
-    TTSMI_CHECK_ARG((((uintptr_t)ws) & 255) == 0, "attention_bwd_fused: workspace must be 256-byte aligned");
-    if (!ttsmi_hattention_bwd_fused_supported(B, H, T, dh, ws_bytes)) {
-        ttsmi_set_error("attention_bwd_fused: head dim %d / workspace of %zu bytes not supported for B=%d H=%d T=%d "
-                        "(ttsmi_attention_bwd_fused_supported)", dh, ws_bytes, B, H, T);
-        return TTSMI_ERR_UNSUPPORTED;
-    }
-    p.dmask = (const uint64_t*)dropmask;
-    p.octx = (const float*)ctx; p.dctx = (const float*)dctx; p.lse = (float*)lse; p.dqkv = (float*)dqkv;
-    p.diag = (int*)ws;
-    p.sem = (int*)((char*)ws + 16);
-    p.dq_acc = (float*)((char*)ws + 16 + hfused_flag_bytes(ws_bytes) + 240);        // 256-byte aligned
-    p.delta = p.dq_acc + (size_t)B * H * ttsmi_cdiv(T, HKT) * 4096;                  // [B][H][T], behind the images
-    hipLaunchKernelGGL(hattn_delta_kernel, dim3((unsigned)ttsmi_cdiv((long)B * T * H, 32)), dim3(256), 0, st,
-                       (const uint16_t*)dctx, (const uint16_t*)ctx, p.delta, B, H, T);
-    const int nkt = ttsmi_cdiv(T, 128), groups = B * H;
-    // heads per XCD in the grid: all of them, or (TTSMI_ATTN_FUSED_PERSIST=1) what fits the chip at once at 2 workgroups per CU
-    static const int cus = [] { hipDeviceProp_t pr; int dv = 0; return hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess ? pr.multiProcessorCount : 256; }();
-    TTSMI_KNOB(fused_persist, "TTSMI_ATTN_FUSED_PERSIST", 0);
-    int hx = ttsmi_cdiv(groups, 8);
-    if (fused_persist) { const int cap = (2 * cus / 8) / nkt; hx = hx < cap ? hx : (cap > 0 ? cap : 1); }
-    dim3 grid(8 * hx * nkt);
-    p.dbg = nullptr;
-    TTSMI_ABLATE_KNOB(fabl, "TTSMI_ATTN_FUSED_ABLATE");      // wrong results by construction: measurement build only
-    p.ablate = fabl;
-#ifdef TTSMI_ABLATION_BUILD
-    {   // measurement build: time stamps of the LAST launch, read back with ttsmi_debug_fused_dump (not in include/ttsmi.h)
-        static unsigned long long* dbuf = nullptr;
-        if (!dbuf && hipMalloc(&dbuf, 8192 * 8 * sizeof(unsigned long long)) != hipSuccess) dbuf = nullptr;
-        if (grid.x <= 8192) p.dbg = dbuf;
-        g_fused_dbg = dbuf; g_fused_dbg_n = (int)grid.x;
-    }
-#endif
-    if (p.thr && p.dmask) {
-        ttsmi_note_kernel("hattn_bwd_fused_kernel<64, 2>");
-        TTSMI_LAUNCH_EV((hattn_bwd_fused_kernel<64, 2>), grid, dim3(256), 0, st, p);
-    } else if (p.thr) {
-        ttsmi_note_kernel("hattn_bwd_fused_kernel<64, 1>");
-        TTSMI_LAUNCH_EV((hattn_bwd_fused_kernel<64, 1>), grid, dim3(256), 0, st, p);
-    } else {
-        ttsmi_note_kernel("hattn_bwd_fused_kernel<64, 0>");
-        TTSMI_LAUNCH_EV((hattn_bwd_fused_kernel<64, 0>), grid, dim3(256), 0, st, p);
-    }
-    TTSMI_CHECK_LAUNCH("attention_bwd_fused");
-    return TTSMI_OK;
-}

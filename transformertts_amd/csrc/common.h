@@ -109,13 +109,6 @@ int ttsmi_hattention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t*
 int ttsmi_hattention_weights(const void* qkv, const uint8_t* key_pad, const float* lse, float* weights, int B, int H, int T,
                              int dh, float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, const void* dropmask,
                              hipStream_t st);
-size_t ttsmi_hattention_bwd_fused_ws_bytes(int B, int H, int T);
-int ttsmi_hattention_bwd_fused_supported(int B, int H, int T, int dh, size_t ws_bytes);
-int ttsmi_hattention_bwd_fused_ws_init(void* ws, size_t ws_bytes, hipStream_t st);
-int ttsmi_hattention_bwd_fused(const void* qkv, const uint8_t* key_pad, const int32_t* klen, const void* ctx,
-                               const void* dctx, const float* lse, void* dqkv, int B, int H, int T, int dh,
-                               float p_drop, uint64_t seed, const int64_t* step_dev, uint32_t site, const void* dropmask,
-                               void* ws, size_t ws_bytes, hipStream_t st);
 size_t ttsmi_hattention_fwd_split_ws_bytes(int B, int H, int T, int dh);
 int ttsmi_hattention_fwd_split(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx, float* lse,
                                int B, int H, int T, int dh, void* ws, size_t ws_bytes, hipStream_t st);

@@ -434,12 +434,7 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
     const double T2 = (double)D->T * D->T;
     OBS("ttsmi_attention_bwd", 8.0 * D->B * D->H * T2 * dh, (double)M * 3 * d * 2 * 3 + (double)M * d * 2 * 3 + 16.0 * D->B * D->H * D->T, st);
     arm(D, 3);
-    // (opt-in: measured slower than the two kernels at the benchmark shape, see hattn_bwd_fused_kernel)
-    if (D->attn_fused_ws && ttsmi_attention_bwd_fused_supported(D->B, D->H, D->T, dh, D->attn_fused_ws_bytes))
-        TRY(ttsmi_attention_bwd_fused(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh, D->rate,
-                                      D->seed, D->step_dev, D->site_attn, dropout ? D->dropmask : nullptr, D->attn_fused_ws,
-                                      D->attn_fused_ws_bytes, st));
-    else if (D->dropmask && dropout)
+    if (D->dropmask && dropout)
         TRY(ttsmi_attention_bwd_masked(D->qkv, D->pad, D->klen, D->cx, D->dctx, D->lse, D->dqkv, D->B, D->H, D->T, dh,
                                        D->rate, D->dropmask, D->attn_ws, D->attn_ws_bytes, TTSMI_BF16_IO, st));
     else

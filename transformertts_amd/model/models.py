@@ -37,10 +37,6 @@ from .transformer_utils import positional_encoding
 _DENSE_STACK = os.environ.get('TTSMI_DENSE_STACK', '1') != '0'      # A/B knob: 0 = one autograd node per planned block
 _PRED_LATE = os.environ.get('TTSMI_PRED_LATE', '1') != '0'      # A/B knob: 0 = predictors issued before the decoder (round 2)
 _PRED_ONE_NODE = os.environ.get('TTSMI_PRED_ONE_NODE', '1') != '0'  # A/B knob: 0 = eight autograd nodes per StatPredictor
-# A/B knob: 1 = the backward pass on the calling thread (saves ~0.1 ms of host time per step, nothing on a GPU-bound step).
-# (It was switched off when a run of the whole GPU suite aborted; the abort was later traced to an out-of-bounds read of the
-# attention kernels - DESIGN.md section 4 - and had nothing to do with it; it stays opt-in until re-measured.)
-_BWD_SAME_THREAD = os.environ.get('TTSMI_BWD_SAME_THREAD', '0') == '1'
 # A/B knob: 0 = the per-layer path (conv blocks) leaves the sums of multiply-used tensors' gradients to autograd
 _GRAD_SINK = os.environ.get('TTSMI_GRAD_SINK', '1') == '1'
 _DROPBITS_CONV = os.environ.get('TTSMI_ATTN_DROPBITS_CONV', '0') == '1'
@@ -576,8 +572,7 @@ class ForwardTransformer:
             plan = self._plans[key] = ops.DenseBlockPlan(Pb, Gb, Sb, B, H, T, self.device,
                                                          self._plan_shared.setdefault((prefix, key[1]), {}), self.fuse_ln,
                                                          backward=backward, cap_rows=cap,
-                                                         chain=self.chain_blocks and self.residual_bf16,
-                                                         wgrad_lane=1 if prefix.startswith('enc') and ops.WGRAD_LANES > 1 else 0)
+                                                         chain=self.chain_blocks and self.residual_bf16)
         else:
             plan.rebind(B, T)
         return plan
@@ -910,7 +905,7 @@ class ForwardTransformer:
                 out = plan.run(x, ts, td, tp, phases=(0,))
                 if self._lenreg_hook is not None:
                     plan.flush_decoder_ln()      # the decoder half's LayerNorm gradients are final before their all-reduce
-                    W = ops._WgradStream.cur(0) if self.overlap_wgrad else None
+                    W = ops._WgradStream.cur() if self.overlap_wgrad else None
                     if W is not None:
                         W.pending = True         # (the hook orders its collective behind the weight-gradient stream too)
                     self._lenreg_hook()
@@ -944,16 +939,13 @@ class ForwardTransformer:
             loss, loss_vals = self._losses(model_out, ts, td, tp, unit_seed=True)    # seeded by loss.backward() below
             ops.enable_wgrad_stream(self.overlap_wgrad)
             try:
-                # (TTSMI_BWD_SAME_THREAD=1: the backward pass on THIS thread instead of the autograd engine's device thread)
-                with ops.ln_param_batch(), torch.autograd.set_multithreading_enabled(not _BWD_SAME_THREAD):
+                with ops.ln_param_batch():
                     loss.backward()                                                  # :480
                     self._mark('bwd')
                     ops.ln_flush()               # LayerNorm parameter gradients: one reduce per producing stream, then
                     self._join_predictors()      # the main stream waits for the predictor stream ...
                     self._pred_pending = False
                 ops.wgrad_join()                 # ... and for the weight-gradient stream, before all-reduce and Adam
-                if ops._FUSED_WS and not torch.cuda.is_current_stream_capturing():
-                    ops.fused_bwd_check()        # (opt-in one-pass attention backward: its time-out counters)
             finally:
                 ops.enable_wgrad_stream(False)
                 self._pred_pending = False

@@ -585,12 +585,10 @@ class _WgradStream:
     per_device = {}
 
     @classmethod
-    def cur(cls, lane: int = 0) -> _WgradState:
-        """lane 0: the weight-gradient stream.  lane 1 (round 5, opt-in: TTSMI_WGRAD_LANES=2): a second one for the ENCODER
-        stack's blocks - backward reaches them last, while lane 0 is still working off the decoder's weight gradients.
-        Measured level to slightly slower (4.77 against 4.74 ms per step, three alternating pairs on one box:
-        profiles/r05_wgrad_lanes_ab.txt), so one lane stays the default."""
-        key = (torch.cuda.current_device(), int(lane))
+    def cur(cls) -> _WgradState:
+        """The weight-gradient stream's state on the current device.  (Round 5 measured a second stream for the encoder
+        stack's blocks - level to slightly slower, profiles/r05_wgrad_lanes_ab.txt - and round 6 removed it.)"""
+        key = torch.cuda.current_device()
         st = cls.per_device.get(key)
         if st is None:
             st = cls.per_device[key] = _WgradState()
@@ -598,29 +596,15 @@ class _WgradStream:
 
     @classmethod
     def lanes(cls):
-        d = torch.cuda.current_device()
-        return [st for (dev, _), st in cls.per_device.items() if dev == d]
-
-
-_WGRAD_XCDS = os.environ.get('TTSMI_WGRAD_XCDS', '')      # measurement knob: "3" = the side stream confined to XCDs 0..2, "5-7" = XCDs 5..7
+        st = cls.per_device.get(torch.cuda.current_device())
+        return [st] if st is not None else []
 
 
 def _new_wgrad_stream():
-    """The weight-gradient side stream.  TTSMI_WGRAD_XCDS (measurement only, profiles/r06_wgrad_cu_mask_ab.txt): a stream whose
-    kernels may only run on the named whole XCDs (CU mask bit i = CU i / 8 of XCC i % 8 on this part, checked by
-    tools/probe_cu_mask.py) instead of competing with the main stream for every CU."""
-    if not _WGRAD_XCDS:
-        return torch.cuda.Stream(priority=_WGRAD_PRIO)
-    lo, _, hi = _WGRAD_XCDS.partition('-')
-    xs = range(int(lo), int(hi) + 1) if hi else range(0, int(lo))
-    ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    words = (ctypes.c_uint32 * ((ncu + 31) // 32))()
-    for i in range(ncu):
-        if i % 8 in xs:
-            words[i // 32] |= 1 << (i % 32)
-    h = ctypes.c_void_p()
-    check(_lib.lib().ttsmi_debug_stream_create_cu_mask(ctypes.addressof(words), len(words), ctypes.addressof(h)), 'stream_create_cu_mask')
-    return torch.cuda.ExternalStream(h.value)
+    """The weight-gradient side stream.  (Round 6 measured it confined to a CU mask - hipExtStreamCreateWithCUMask through
+    ttsmi_debug_stream_create_cu_mask, tools/probe_cu_mask.py: no mask selects whole XCDs on this part and any mask costs the
+    step 72 %, profiles/r06_wgrad_cu_mask_ab.txt - so it is an ordinary stream.)"""
+    return torch.cuda.Stream(priority=_WGRAD_PRIO)
 
 
 def enable_wgrad_stream(flag: bool = True):
@@ -653,7 +637,6 @@ def _on_wgrad_stream(fn, *inputs):
     W.pending = True
 
 
-WGRAD_LANES = int(os.environ.get('TTSMI_WGRAD_LANES', '1'))             # 2: the encoder stack's weight gradients on a second side stream (measured: 4.77 against 4.74 ms, profiles/r05_wgrad_lanes_ab.txt)
 _WGRAD_GENERIC = os.environ.get('TTSMI_WGRAD_GENERIC', '0') == '1'      # measurement knob: old submission path
 
 
@@ -1811,7 +1794,7 @@ class DenseBlockPlan:
     length-bucketed training data almost every batch has its own (B, Tp, Tm), and a plan per exact shape meant a
     device synchronisation plus ~30 allocations per block on almost every step (round-2 advisor finding)."""
 
-    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True, backward=True, cap_rows=0, chain=False, wgrad_lane=0):
+    def __init__(self, P, G, S, B, H, T, device, shared, fuse_ln=True, backward=True, cap_rows=0, chain=False):
         """backward=False: a forward-only plan (inference) - the backward temporaries are not allocated.
         chain: the forward's row-local chain (o-projection + res-norm 1 -> FFN -> res-norm 2 -> the next block's qkv
         projection) as ONE launch (csrc/chain.hip, ttsmi_dense_block.chain_w) - training plans with fused LayerNorms and a
@@ -1819,7 +1802,6 @@ class DenseBlockPlan:
         l = _lib.lib()
         self.backward = bool(backward)
         self.pack_ev = None                       # event of a weight-stream pack issued ahead of this step on a side stream
-        self.wgrad_lane = int(wgrad_lane)         # which weight-gradient side stream this block's launches go to (_WgradStream.cur)
         d = P['wqkv'].shape[0]
         F = P['ffn.w1'].shape[1]
         cap = self.cap = max(int(cap_rows), B * T)
@@ -1868,8 +1850,7 @@ class DenseBlockPlan:
         if key not in shared or shared[key]['cap'] < cap:
             # (the model drops a stack's plans together when one of them has to grow, so nobody holds the old entry)
             shared[key] = ({'cap': cap, 'da': e((cap, d), f32), 'dctx': e((cap, d), bf),
-                            'attn_ws': _ws(4 * cap * H + 1024, device),
-                            'attn_fused_ws': None} if backward else
+                            'attn_ws': _ws(4 * cap * H + 1024, device)} if backward else
                            {'cap': cap, 'da': e((8,), f32), 'dctx': e((8,), bf),  # forward only: scratch of the split-key attention
                             'attn_ws': None})
         sh = shared[key]
@@ -1908,25 +1889,6 @@ class DenseBlockPlan:
         self.B = self.T = self.M = 0
         self.rebind(B, T)
 
-    @staticmethod
-    def _attn_fused_ws(l, sh, B, H, T, dh, device):
-        """Workspace of the one-pass attention backward (ttsmi_attention_bwd_fused: the fp32 partial dQ tiles of a head's
-        key tiles + their ticket counters), shared by the blocks of a stack and grown when a batch shape needs more; the
-        counter region is zeroed once per allocation and resets itself after every launch.  None: head dim other than 64,
-        or TTSMI_ATTN_FUSED_BWD is not 1 (the default: the two-kernel backward measured faster)."""
-        if dh != 64 or os.environ.get('TTSMI_ATTN_FUSED_BWD', '0') != '1':       # opt-in: not faster than two kernels (round 4)
-            return None
-        ws = sh.get('attn_fused_ws')
-        if ws is None or not l.ttsmi_attention_bwd_fused_supported(B, H, T, dh, ws.numel()):
-            need = int(l.ttsmi_attention_bwd_fused_ws_bytes(B, H, T))
-            # (the old workspace stays alive: captured graphs hold its raw pointer; growth is monotone, so the list stays short)
-            if ws is not None:
-                sh.setdefault('attn_fused_ws_retired', []).append(ws)
-            ws = sh['attn_fused_ws'] = _ws(need + need // 8, device)
-            check(l.ttsmi_attention_bwd_fused_ws_init(_p(ws), ws.numel(), _stream()), 'attention_bwd_fused_ws_init')
-            _FUSED_WS.append({'ws': ws, 'host': None, 'ev': None})
-        return ws
-
     def rebind(self, B, T):
         """Point the plan at a batch of B x T rows (<= the capacity): shape fields, the row-count dependent workgroup
         counts and workspace sizes.  No allocation except the forward-only split-key scratch when it has to grow."""
@@ -1962,8 +1924,6 @@ class DenseBlockPlan:
                 sh['attn_ws'] = _ws(need, self.t['qkv'].device)
             self._attn_ws = sh['attn_ws']
         D.attn_ws, D.attn_ws_bytes = sh['attn_ws'].data_ptr(), sh['attn_ws'].numel()
-        fws = self._attn_fused_ws(l, sh, B, H, T, d // H, self.t['qkv'].device) if self.backward else None
-        D.attn_fused_ws, D.attn_fused_ws_bytes = (fws.data_ptr(), fws.numel()) if fws is not None else (None, 0)
         D.attn_split = int(not self.backward and os.environ.get('TTSMI_ATTN_SPLIT', '1') != '0' and
                            l.ttsmi_attention_fwd_splitkeys_ws_bytes(B, H, T, d // H) > 0)
         if self.above is not None and (self.above.B, self.above.T) != (B, T):
@@ -2060,14 +2020,14 @@ class DenseBlockPlan:
         D = self.desc
         need = self.wgrad_need if need is None else max(int(need), self.wgrad_need)
         if _WgradStream.enabled:
-            W = _WgradStream.cur(self.wgrad_lane)
+            W = _WgradStream.cur()
             if W.stream is None:
                 W.stream = _new_wgrad_stream()
             if W.handle is None:
                 W.handle = W.stream.cuda_stream
             if W.ws is None or W.ws.numel() < need:
                 with torch.cuda.stream(W.stream):
-                    W.ws = torch.empty(int(max(need, 1 << 26 if self.wgrad_lane == 0 else 0)), dtype=torch.uint8, device=device)
+                    W.ws = torch.empty(int(max(need, 1 << 26)), dtype=torch.uint8, device=device)
             D.side_stream, D.wgrad_ws, D.wgrad_ws_bytes = W.handle, W.ws.data_ptr(), W.ws.numel()
             W.pending = True
         else:
@@ -2098,29 +2058,6 @@ class DenseBlockPlan:
         else:
             with ln_param_batch():
                 defer()
-
-
-_FUSED_WS: list = []      # workspaces of the opt-in one-pass attention backward: their diagnostic counters are read every step
-
-
-def fused_bwd_check() -> None:
-    """TTSMI_ATTN_FUSED_BWD=1 only (a no-op otherwise): the one-pass attention backward finishes with a WRONG dQ instead of
-    hanging when a hand-off between its workgroups times out, or when its workgroups are not placed on the XCD their block
-    id names (include/ttsmi.h: the first two int32 of its workspace count both).  Once per step, after the backward: raise
-    if the counters copied at the END OF THE PREVIOUS STEP are non-zero (that copy completed long ago: no sync), then queue
-    this step's copy."""
-    for e in _FUSED_WS:
-        if e['ev'] is not None:
-            e['ev'].synchronize()
-            bad = e['host'].tolist()
-            if bad[0] or bad[1]:
-                raise RuntimeError(f'ttsmi_attention_bwd_fused: {bad[0]} timed-out hand-offs, {bad[1]} workgroups off their XCD '
-                                   f'- dQ of an earlier step is wrong; run without TTSMI_ATTN_FUSED_BWD=1')
-        if e['host'] is None:
-            e['host'] = torch.zeros(2, dtype=torch.int32).pin_memory()
-        e['host'].copy_(e['ws'][:8].view(torch.int32), non_blocking=True)
-        e['ev'] = torch.cuda.Event()
-        e['ev'].record()
 
 
 class PlannedDenseBlockFn(torch.autograd.Function):

@@ -257,7 +257,7 @@ class TrainStepPlan:
         every step brings a new (B, Tp, Tm): the full re-bind (12 x rebind / chain_above / chain_forward / bind /
         _prepare_bwd) was ~1 ms of interpreter time per step."""
         S, t = self.S, self.t
-        if self.shape is None or self.shape[3] != ops._stream() or not self.plans_e or os.environ.get('TTSMI_ATTN_FUSED_BWD', '0') == '1':
+        if self.shape is None or self.shape[3] != ops._stream() or not self.plans_e:
             return False
         for plans, T in ((self.plans_e, Tp), (self.plans_d, Tm)):
             M = B * T
@@ -312,7 +312,7 @@ class TrainStepPlan:
         finally:
             ops.enable_wgrad_stream(False)
         if m.overlap_wgrad:
-            W = ops._WgradStream.cur(0)
+            W = ops._WgradStream.cur()
             S.wgrad_stream, S.wgrad_ws, S.wgrad_ws_bytes = W.handle, W.ws.data_ptr(), W.ws.numel()
             self._wg_ptr = (W.ws.data_ptr(), W.ws.numel())
             W.pending = False                      # the step joins the stream itself (phase 1)
@@ -340,7 +340,7 @@ class TrainStepPlan:
                 if not self._retarget(B, Tp, Tm):
                     self._bind(B, Tp, Tm)
             elif self._wg_ptr is not None:
-                W = ops._WgradStream.cur(0)
+                W = ops._WgradStream.cur()
                 if W.ws is None or (W.ws.data_ptr(), W.ws.numel()) != self._wg_ptr:
                     self._bind_wgrad()             # somebody else grew the shared workspace
             t = self.t
