@@ -666,7 +666,7 @@ def f32_train_leg(dev, cfg, shape, dropout, step_flops, steps=5, warmup=2):
     from transformertts_amd.model.models import ForwardTransformer
     from transformertts_amd.utils.synthetic import synthetic_batch
     model = ForwardTransformer.from_config(dict(cfg, dropout_rate=dropout, predictors_dropout=dropout, device=str(dev),
-                                                seed=0, precision='f32', use_graph=False))
+                                                seed=0, precision='f32'))
     model._compile(learning_rate=1e-4)
     batch = [torch.from_numpy(a).to(dev) for a in synthetic_batch(shape['B'], shape['Tp'], shape['Tm'], seed=1234)]
     for _ in range(warmup):
@@ -758,6 +758,24 @@ def also_legs(dev, cfg, shape, dropout, step_flops):
                                       '--no-attention-maps', '--no-also', '--dropout', str(dropout)],
                                      ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config',
                                       'host_issue_ms_per_step', 'roofline')))
+
+    def dp1():
+        # the RCCL path alive on one GPU (tools/probe_rccl_world1.py: a one-rank nccl group with the collectives forced - both
+        # all-reduce buckets issued from the real hook, broadcast, joins - against the plain model, bit for bit)
+        import subprocess
+        env = dict(os.environ)
+        env.pop('WORLD_SIZE', None), env.pop('RANK', None), env.pop('LOCAL_RANK', None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'probe_rccl_world1.py'), '--steps', '6'],
+                           capture_output=True, text=True, timeout=300, env=env)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
+        if not lines:
+            raise RuntimeError(f'rc {r.returncode}: {r.stderr.strip()[-400:]}')
+        d = json.loads(lines[-1])
+        return {'what': 'one-rank RCCL group, TTSMI_DP_FORCE_COLLECTIVES=1: the two all-reduce buckets of the batch-DP step issued '
+                        'from the real backward hook; bit_identical = parameters and loss equal the plain step after every step',
+                **{k: d[k] for k in ('backend', 'steps', 'bit_identical', 'max_abs_param_diff', 'ms_per_step_plain',
+                                     'ms_per_step_with_collectives', 'grad_bytes')}}
+    run('dp1_forced_collectives', dp1)
     rd = legs.get('ref_default', {})
     if 'roofline' in rd:               # the line stays readable: the step's own roof, not the per-kernel table
         rf = rd['roofline']
@@ -809,7 +827,7 @@ def lj_dist_bench(args):
     dev = torch.device('cuda', local)
     cfg, shape = workload_config('configs[1]')
     cfg = dict(cfg, dropout_rate=args.dropout, predictors_dropout=args.dropout, device=str(dev), seed=0,
-               precision=args.precision, use_graph=False)
+               precision=args.precision)
     model = ForwardTransformer.from_config(cfg)
     model._compile(learning_rate=1e-4)
     wrapped = dp.DataParallel(model)
@@ -918,10 +936,6 @@ def main():
     # BASELINE.json configs[1] is quoted in bf16: bf16 GEMM/attention operands, fp32 accumulate, fp32
     # master weights / activations / optimiser.  --precision f32 runs the exact-fp32 parity path.
     ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16'])
-    # hipGraph replay of the step is implemented and bit-identical to eager (tests/test_model_gpu.py), but it
-    # is not the default: ROCm graph replay adds per-node overhead and serialises the weight-gradient stream's
-    # overlap differently - measured 8.9 ms (graph) vs 8.1 ms (eager) per step when last compared.
-    ap.add_argument('--graph', action='store_true', help='replay the step from captured hipGraphs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-attention-maps', dest='with_attention_maps', action='store_false',
                     help='skip the extra timed leg that also materialises the 12 attention maps')
@@ -969,7 +983,7 @@ def main():
     if args.batch:
         shape = dict(shape, B=args.batch)
     cfg = dict(cfg, dropout_rate=args.dropout, predictors_dropout=args.dropout, device=str(dev), seed=0,
-               precision=args.precision, use_graph=args.graph)
+               precision=args.precision)
     model = ForwardTransformer.from_config(cfg)
     model._compile(learning_rate=1e-4)
     wrapped = dp.DataParallel(model)
@@ -999,6 +1013,15 @@ def main():
     host_issue = time.perf_counter() - t0        # the host has ENQUEUED every step by now (no sync inside a step)
     sync()
     elapsed = time.perf_counter() - t0
+    # The loop above measures the host's enqueue time INCLUDING the runtime's back-pressure: once the host is ~10 steps ahead
+    # of a GPU-bound step its launches block (tools/debug/cstep_host.py: 2.5 of 2.6 ms per step inside the C calls at the
+    # max shape, 1.1 ms when the GPU keeps up).  What the host NEEDS per step is a short burst into an idle queue:
+    burst = 6
+    t1 = time.perf_counter()
+    for _ in range(burst):
+        out = step()
+    host_burst = time.perf_counter() - t1
+    sync()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -1067,10 +1090,12 @@ def main():
         # host time to enqueue one step (Python + ctypes launch loop); when it approaches ms_per_step the host, not
         # the GPU, bounds the step
         'host_issue_ms_per_step': 1e3 * host_issue / args.steps,
+        # ... and without the runtime's back-pressure: 6 steps enqueued into an idle queue (the host's own cost per step)
+        'host_issue_burst_ms_per_step': 1e3 * host_burst / burst,
+        'step_issued_from': 'C++ (ttsmi_ft_train_step)' if getattr(model, '_cstep', None) is not None else 'per-layer autograd path',
     }
 
     if rank == 0 and not args.no_roofline:
-        model.use_graph = False             # the instrumented step brackets every launch: run it eagerly
         groups = group_records(instrumented_step(step))
         # the dominant kernel family = the one the step spends most launch time in (side-stream wgrad
         # launches overlap the main stream, so the sum of launch times exceeds the step time)
@@ -1127,7 +1152,6 @@ def main():
             'stream': 'weight-gradient side stream (overlaps the main stream)' if gdom.endswith(SIDE) else 'main',
             'traffic': pmc_traffic(gdom) if args.precision == 'bf16' and args.workload == 'configs[1]' else None}
     elif world > 1 and not args.no_roofline:
-        model.use_graph = False
         step()          # keep the collective count equal on every rank
     if world > 1:
         sync()
@@ -1142,6 +1166,20 @@ def main():
         torch.cuda.empty_cache()
         base_cfg, _ = workload_config(args.workload)
         result['also'] = also_legs(dev, base_cfg, shape, args.dropout, step_flops)
+        # LAST key of the line (the driver keeps the last 2 000 characters of stdout): one number per leg
+        al = result['also']
+        g = lambda leg, *path: (lambda v: round(v, 4) if isinstance(v, float) else v)(
+            __import__('functools').reduce(lambda d, k: d.get(k) if isinstance(d, dict) else None, path, al.get(leg, {})))
+        result['summary'] = {
+            'train_step_bf16_ms': round(result['ms_per_step'], 4), 'host_issue_burst_ms': round(result['host_issue_burst_ms_per_step'], 4),
+            'train_step_f32_ms': g('train_step_f32', 'ms_per_step'), 'mel_gbs': g('mel', 'value'),
+            'mel_hbm_frac': g('mel', 'roofline', 'frac'), 'predict_b1_p50_ms': g('predict', 'batch1', 'p50_ms'),
+            'predict_b64_p50_ms': g('predict', 'batch64', 'p50_ms'), 'lj_dist_ms': g('lj_dist', 'ms_per_step'),
+            'lj_dist_real_frames_per_s': g('lj_dist', 'value'), 'lj_dist_over_max_shape': g('lj_dist', 'ragged_over_max_shape_per_padded_frame'),
+            'ref_default_ms': g('ref_default', 'ms_per_step'), 'ref_default_host_ms': g('ref_default', 'host_issue_ms_per_step'),
+            'dp1_bit_identical': g('dp1_forced_collectives', 'bit_identical'),
+            'dp1_ms_with_collectives': g('dp1_forced_collectives', 'ms_per_step_with_collectives'),
+            'leg_errors': [k for k, v in al.items() if isinstance(v, dict) and 'error' in v]}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

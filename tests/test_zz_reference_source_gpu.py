@@ -64,14 +64,21 @@ def test_train_step_equals_the_reference_source_run(frozen, name):
     names = [k[len(name) + 7:] for k in frozen if k.startswith(f'{name}/grad::')]
     assert sorted(names) == sorted(grads)
     gnorm = max(float(np.abs(g(f'grad::{k}')).max()) for k in names)
-    worst = ('', 0.0)
+    worst, worst_own = ('', 0.0), ('', 0.0)
     for k in names:
         want = g(f'grad::{k}')
-        scale = max(float(np.abs(want).max()), 1e-3 * gnorm)   # per tensor, floored at 1e-3 of the global scale
-        e = float(np.abs(grads[k].astype(np.float64) - want).max()) / scale
+        own = float(np.abs(want).max())
+        err = float(np.abs(grads[k].astype(np.float64) - want).max())
+        e = err / max(own, 1e-3 * gnorm)                       # per tensor, floored at 1e-3 of the global scale
         if e > worst[1]:
             worst = (k, e)
-    assert worst[1] < 2e-4, worst
+        # ... and UNFLOORED, against the tensor's own scale, for every tensor that has a gradient at all (the key bias's is
+        # zero by construction: softmax is shift invariant): small tensors - LayerNorm vectors, the pitch head - are held to a
+        # relative bound too, not only to an absolute one (review of round 5)
+        if own > 1e-5 * gnorm and err / own > worst_own[1]:
+            worst_own = (k, err / own)
+    assert worst[1] < 2e-4, (worst, 'unfloored worst', worst_own)
+    assert worst_own[1] < 2e-3, ('relative to the tensor itself', worst_own, 'floored worst', worst)
 
 
 @pytest.mark.parametrize('name', list(gen.CASES))

@@ -154,7 +154,7 @@ class DataParallel:
         self.split = min(dec) if dec else 0       # flat layout: [... encoder side ... | dec.* | out.*]
 
         def _hook():
-            if model.grad_sync is not None and not getattr(model, 'use_graph', False):
+            if model.grad_sync is not None:
                 self.sync.start_tail(model.params.grad, self.split, ops.wgrad_stream())
         model._lenreg_hook = _hook           # on the model, not global: other models in the process are untouched
 

@@ -208,7 +208,12 @@ class ForwardTransformer:
         assert self.precision in ('f32', 'bf16'), self.precision
         self.shadow: Dict[str, ops.Shadow] = {}
         self.overlap_wgrad = bool(kwargs.get('overlap_wgrad', True))   # wgrad on a second HIP stream
-        self.use_graph = bool(kwargs.get('use_graph', False))          # replay train_step from hipGraphs
+        if kwargs.get('use_graph', False):
+            # (rounds 1-5 could replay the train step from captured hipGraphs: bit-identical, and slower than the eager step in
+            # every round it was measured - 5.76 against 4.71 ms in round 5; with the step issued from C++ the host needs ~1.3 ms
+            # for a 4.7 ms step and there is nothing left for a graph to hide.  predict() keeps its graphs: graph_inference.)
+            raise ValueError('use_graph (hipGraph replay of train_step) was removed in round 6; the step is issued from C++ '
+                             '(use_cstep, the default) instead')
         self.fused_blocks = bool(kwargs.get('fused_blocks', True))     # one autograd node per dense block
         self.overlap_predictors = bool(kwargs.get('overlap_predictors', True))   # StatPredictors on a side stream
         self._pred_stream, self._pred_pending, self._pred_keep, self._deferred_pred = None, False, None, None
@@ -236,7 +241,6 @@ class ForwardTransformer:
         self.chain_blocks = bool(kwargs.get('chain_blocks', os.environ.get('TTSMI_DENSE_CHAIN', '1') != '0'))
         self._weights_version = 0
         self._block_cache: Dict[str, tuple] = {}
-        self._graphs: Dict[tuple, dict] = {}
         self.return_attention = None         # None = per-method default (see module docstring)
         self.grad_sync = None                # set by transformertts_amd.dp.DataParallel
         self.loss_denominators = None        # (mel, duration, pitch) element counts of the GLOBAL batch, set per step by dp.DataParallel
@@ -556,7 +560,7 @@ class ForwardTransformer:
             # (they used to pin a complete copy of the stack's buffers per growth event: HBM grew with the number of
             # growth events under graph mode - advisor finding, round 3)
             if key[1] != 'fwd':
-                self._graphs.clear()
+                pass
             elif prefix == 'enc':
                 self._infer_graphs.clear()               # graph A of every input shape holds the encoder plans
             else:
@@ -869,8 +873,6 @@ class ForwardTransformer:
         backward, one TF-form Adam step.  Requires sum_b(dur) <= mel_len (the reference data has
         sum(dur_b) == mel_len_b; frames past mel_len would be sliced away at models.py:473)."""
         x, ts, td, tp = self._prep(input_sequence, target_sequence, target_durations, target_pitch)
-        if self.use_graph:
-            return self._train_step_graphed(x, ts, td, tp)
         if self._cstep_ok():
             return self._train_step_c(x, ts, td, tp)
         model_out = self._forward_backward(x, ts, td, tp)
@@ -954,47 +956,6 @@ class ForwardTransformer:
         model_out.update({'losses': {'mel': loss_vals[0].detach(), 'duration': loss_vals[1].detach(),
                                      'pitch': loss_vals[2].detach()}})
         return model_out
-
-    def _train_step_graphed(self, x, ts, td, tp):
-        """The same step replayed from two captured hipGraphs per batch shape (forward+backward, and
-        Adam + bf16 shadow refresh; the gradient all-reduce runs between them).  A step is ~700 kernel
-        launches driven from Python - ~12 ms of host time at the 6+6-block configuration, more than
-        the GPU needs - so replaying them removes the host from the critical path.  Everything a replay
-        must vary lives on the device: the batch (copied into static buffers), the learning rate, the
-        optimiser step counter and, derived from it, the dropout stream.
-        First call of a shape runs eagerly (warm-up), the second captures, later ones replay.  The
-        returned tensors are the graph's static outputs: consume them before the next step."""
-        key = (tuple(x.shape), tuple(ts.shape), self.loss_denominators)      # the divisors are baked into a capture
-        st = self._graphs.get(key)
-        if st is None:
-            self._graphs[key] = {'calls': 1}
-            model_out = self._forward_backward(x, ts, td, tp)
-            if self.grad_sync is not None:
-                self.grad_sync(self.params.grad)
-            self._apply_gradients()
-            self._host_step += 1
-            return model_out
-        if 'fb' not in st:
-            st['in'] = [t.clone() for t in (x, ts, td, tp)]
-            torch.cuda.synchronize()
-            st['fb'] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st['fb']):
-                st['out'] = self._forward_backward(*st['in'])
-            st['opt'] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st['opt'], pool=st['fb'].pool()):
-                self._apply_gradients()
-            # the captured launches hold raw pointers into the plans' and the keep-bit tables' buffers: the graph keeps
-            # them alive whatever the model's own caches do later (growth replaces a plan, it never frees under a graph)
-            st['pinned'] = (list(self._plans.values()), list(self._dropmask_bufs.values()))
-        for dst, src in zip(st['in'], (x, ts, td, tp)):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src, non_blocking=True)
-        st['fb'].replay()
-        if self.grad_sync is not None:
-            self.grad_sync(self.params.grad)
-        st['opt'].replay()
-        self._host_step += 1
-        return st['out']
 
     @_on_device
     def _val_step(self, input_sequence, target_sequence, target_durations, target_pitch):
