@@ -761,10 +761,12 @@ typedef struct {
     /* phase 2 */
     float* p_flat; float* g_flat; float* m_flat; float* v_flat; int64_t n_flat;
     const float* lr_dev; int64_t* step_rw;
-    float beta1, beta2, eps; int32_t pad3_;
+    float beta1, beta2, eps;
+    int32_t pack_now;                          /* phase 0 packs the chain kernels' weight streams itself (else: the previous phase 2 did) */
     uint16_t* flat_bf16;
     const void* tr_desc; int32_t tr_n, tr_tiles;
-    int32_t n_conv_wd, pad4_;
+    int32_t n_conv_wd;
+    int32_t pack_ahead;                        /* phase 2 packs the NEXT step's weight streams on the side stream */
     const float* conv_w[2 * TTSMI_FT_MAX_PRED_LAYERS]; uint16_t* conv_wd[2 * TTSMI_FT_MAX_PRED_LAYERS];
     int32_t conv_k[2 * TTSMI_FT_MAX_PRED_LAYERS], conv_cin[2 * TTSMI_FT_MAX_PRED_LAYERS], conv_cout[2 * TTSMI_FT_MAX_PRED_LAYERS];
 } ttsmi_ft_step;

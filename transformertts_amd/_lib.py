@@ -197,8 +197,8 @@ def _ft_step_fields():
             P('d_dec_out', 'd_x_dec', 'd_hp', 'd_branch', 'd_enc_out', 'd_x_emb', 'ln_ws0', 'ln_ws1') +
             [('ln_ws0_bytes', u64), ('ln_ws1_bytes', u64)] + P('pit_ws') + [('pit_ws_bytes', u64)] + P('wgrad_ws') +
             [('wgrad_ws_bytes', u64)] + P('p_flat', 'g_flat', 'm_flat', 'v_flat') + [('n_flat', i64)] + P('lr_dev', 'step_rw') +
-            [('beta1', f), ('beta2', f), ('eps', f), ('pad3_', i32)] + P('flat_bf16', 'tr_desc') +
-            [('tr_n', i32), ('tr_tiles', i32), ('n_conv_wd', i32), ('pad4_', i32),
+            [('beta1', f), ('beta2', f), ('eps', f), ('pack_now', i32)] + P('flat_bf16', 'tr_desc') +
+            [('tr_n', i32), ('tr_tiles', i32), ('n_conv_wd', i32), ('pack_ahead', i32),
              ('conv_w', p * (2 * FT_MAX_PRED_LAYERS)), ('conv_wd', p * (2 * FT_MAX_PRED_LAYERS)),
              ('conv_k', i32 * (2 * FT_MAX_PRED_LAYERS)), ('conv_cin', i32 * (2 * FT_MAX_PRED_LAYERS)),
              ('conv_cout', i32 * (2 * FT_MAX_PRED_LAYERS))])

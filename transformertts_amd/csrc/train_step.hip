@@ -68,6 +68,8 @@ enum {
     EV_OUT_WGRAD,        // main -> weight-gradient stream: the mel projection's operands
     EV_WGRAD_JOIN,       // weight-gradient stream -> main
     EV_SIDE_JOIN,        // side -> main at the end of the backward
+    EV_PACK_START,       // main -> side: the bf16 shadows of this step's weights are written (phase 2)
+    EV_PACK,             // side -> main: the chain kernels' weight streams for the next step
     EV_COUNT
 };
 
@@ -214,18 +216,24 @@ static int phase0(const ttsmi_ft_step* S) {
     t_ln_main.n = 0;
     t_ln_side.n = 0;
     // ---- side stream: keep-bit tables of the attention dropout and the chain kernels' weight streams, ahead of their use
-    TRY(hand_off(S->ev[EV_STEP_START], mn, sd, "step start"));
-    TRY(side_prepare_stack(S, S->enc, S->n_enc));
-    TRY(side_pack_stack(S, S->enc, S->n_enc));
-    TRY(side_pack_stack(S, S->dec, S->n_dec));
-    TRY(ev_record(S->ev[EV_MASK_ENC], sd, "encoder tables"));
-    TRY(side_prepare_stack(S, S->dec, S->n_dec));
-    TRY(ev_record(S->ev[EV_MASK_DEC], sd, "decoder tables"));
+    // (the main stream's first launches are enqueued in front of the side stream's dozen: when the host, not the GPU, bounds
+    // the step - small batches, a traced run - the main queue does not sit empty while the side work is being enqueued)
+    TRY(ev_record(S->ev[EV_STEP_START], mn, "step start"));
     // ---- forward                                                                                   models.py:521-543
     TRY(ttsmi_token_pad_mask(S->tokens, S->pad_e, S->klen_e, B, Tp, mn));                             // :521
     TRY(ttsmi_embedding_fwd(S->tokens, S->emb, S->x_emb, Me, S->V, d, mn));                           // :522
     TRY(ttsmi_add_layernorm_fwd(S->x_emb, nullptr, S->enc_ln_g, S->enc_ln_b, S->pe_enc, S->enc_ps, Tp, nullptr, 0.f, 0, S->rate,
                                 S->site_enc_ln, S->seed, S->step_dev, kLnEps, S->h0, S->mean0, S->rstd0, Me, d, S->h0_bf, mn));
+    TRY(ev_wait(S->ev[EV_STEP_START], sd, "step start"));
+    TRY(side_prepare_stack(S, S->enc, S->n_enc));
+    if (S->pack_now) {             // the weight streams were not packed ahead by the previous step's phase 2 (first step, new binding)
+        TRY(side_pack_stack(S, S->enc, S->n_enc));
+        TRY(side_pack_stack(S, S->dec, S->n_dec));
+    }
+    TRY(ev_record(S->ev[EV_MASK_ENC], sd, "encoder tables"));
+    TRY(side_prepare_stack(S, S->dec, S->n_dec));
+    TRY(ev_record(S->ev[EV_MASK_DEC], sd, "decoder tables"));
+    if (!S->pack_now) TRY(ev_wait(S->ev[EV_PACK], mn, "chain weight streams"));
     TRY(ev_wait(S->ev[EV_MASK_ENC], mn, "encoder tables"));
     TRY(ttsmi_dense_stack_fwd(S->enc, S->n_enc, S->h0, S->h0_bf));                                    // :523
     const float* enc_out = S->enc[S->n_enc - 1]->out;
@@ -261,11 +269,7 @@ static int phase0(const ttsmi_ft_step* S) {
                                      S->loss_out, S->loss_out + 3, S->loss_ws, S->loss_ws_bytes, mn));
     }
     // ---- backward (the autograd engine's order: newest node first)                                 models.py:480
-    TRY(hand_off(S->ev[EV_LOSS], mn, sd, "loss gradients"));
-    TRY(predictor_bwd(S, &S->pit, S->g_pit, sd));
-    TRY(predictor_bwd(S, &S->dur, S->g_dur, sd));
-    TRY(ttsmi_add2_f32(S->pit.dbranch, S->dur.dbranch, S->d_branch, (int64_t)Me * d, sd));
-    TRY(ev_record(S->ev[EV_PRED_BWD], sd, "predictor gradients"));
+    TRY(ev_record(S->ev[EV_LOSS], mn, "loss gradients"));
     // mel projection: input gradient, then its weight gradient on the weight-gradient stream
     TRY(ttsmi_hgemm_tn(S->g_mel, 1, S->n_mel, nullptr, 0, 0, S->out_wb, S->n_mel, nullptr, nullptr, 0, S->d_dec_out, d, Md, d,
                        S->n_mel, 0, 1, 0, 0, 0, mn));
@@ -275,6 +279,13 @@ static int phase0(const ttsmi_ft_step* S) {
         TRY(ttsmi_hgemm_wgrad_rows(dec_out, 0, d, S->g_mel, 0, S->n_mel, S->g_out_w, S->n_mel, S->g_out_b, Md, d, S->n_mel, 1, 0, 0,
                                    0, S->wgrad_ws, S->wgrad_ws_bytes, wg));
     }
+    // the predictors' backward (~50 small launches on the side stream) is enqueued now - behind the main stream's first
+    // backward launches, in front of the decoder stack's hundred - and runs underneath the decoder's backward
+    TRY(ev_wait(S->ev[EV_LOSS], sd, "loss gradients"));
+    TRY(predictor_bwd(S, &S->pit, S->g_pit, sd));
+    TRY(predictor_bwd(S, &S->dur, S->g_dur, sd));
+    TRY(ttsmi_add2_f32(S->pit.dbranch, S->dur.dbranch, S->d_branch, (int64_t)Me * d, sd));
+    TRY(ev_record(S->ev[EV_PRED_BWD], sd, "predictor gradients"));
     TRY(ttsmi_dense_stack_bwd(S->dec, S->n_dec, S->h1, S->h1_bf, S->d_dec_out));
     defer_stack_ln(S->dec, S->n_dec);
     TRY(ttsmi_add_layernorm_bwd(S->dec[0]->dh, S->x_dec, nullptr, S->dec_ln_g, S->mean1, S->rstd1, S->pe_dec, S->dec_ps, Tm,
@@ -319,6 +330,15 @@ static int phase2(const ttsmi_ft_step* S) {
     for (int i = 0; i < S->n_conv_wd; ++i)
         TRY(ttsmi_conv_wdgrad_layout_bf16(S->conv_w[i], S->conv_wd[i], S->conv_k[i], S->conv_cin[i], S->conv_cout[i],
                                           (S->conv_cout[i] + 7) / 8 * 8, mn));
+    if (S->pack_ahead) {
+        // the chain kernels' weight streams of the NEXT step, packed from the shadows just written, on the side stream: 24
+        // launches that the next step's start does not have to enqueue in front of its first kernel (the same blocks, the
+        // same chain links: the host clears pack_now for the next step only when that holds)
+        TRY(hand_off(S->ev[EV_PACK_START], mn, S->side_stream, "bf16 shadows"));
+        TRY(side_pack_stack(S, S->enc, S->n_enc));
+        TRY(side_pack_stack(S, S->dec, S->n_dec));
+        TRY(ev_record(S->ev[EV_PACK], S->side_stream, "chain weight streams"));
+    }
     return TTSMI_OK;
 }
 

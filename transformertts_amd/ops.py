@@ -1887,6 +1887,7 @@ class DenseBlockPlan:
         self.above = None
         self._dref = ctypes.byref(D)
         self.B = self.T = self.M = 0
+        self.bound_by = None
         self.rebind(B, T)
 
     def rebind(self, B, T):
@@ -1981,6 +1982,7 @@ class DenseBlockPlan:
         res16: bf16 residual stream between the fused kernels (ttsmi_dense_block.res16; ignored without fused LayerNorms);
         out32: the fp32 block output is read by somebody (the last block of a stack, activation taps)."""
         D = self.desc
+        self.bound_by = None                              # (a TrainStepPlan that binds this plan stamps itself here afterwards)
         self.res16 = bool(res16) and self.fuse_ln
         D.res16 = (1 | (2 if out32 else 0)) if self.res16 else 0
         D.pad, D.klen = pad.data_ptr(), klen.data_ptr()

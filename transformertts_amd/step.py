@@ -91,13 +91,14 @@ class TrainStepPlan:
         self.cap = (0, 0, 0)                       # (batch, encoder rows, decoder rows)
         self.shape = None
         self.t = {}
-        self.events = [torch.cuda.Event() for _ in range(10)]
+        self.events = [torch.cuda.Event() for _ in range(12)]
         for ev in self.events:
             ev.record()                            # materialises the hipEvent_t
         self.loss_ring = torch.zeros((LOSS_RING, 4), dtype=torch.float32, device=self.dev)
         self.keep = None
         self.plans_e, self.plans_d = [], []
         self._wg_ptr = None
+        self._packed_version = None                # the weights version the chain kernels' streams were packed ahead for (phase 2)
         self._static()
 
     # ------------------------------------------------------------------ descriptor parts that never change
@@ -245,6 +246,7 @@ class TrainStepPlan:
             last = i == n - 1
             plan.chain_forward(None if last else m._block_plan(f'{prefix}.blk{i + 1}', prefix, B, heads[i + 1], T))
             plan.bind(pad, klen, rate, m.drop, sites, dmask, res16=m.residual_bf16, out32=last)
+            plan.bound_by = self                       # (the per-layer path's bind() resets it: its masks are per-step tensors)
             plan.name = p
             plans.append(plan)
         below.chain_above(None)
@@ -298,7 +300,8 @@ class TrainStepPlan:
         for i, pl in enumerate(self.plans_d):
             S.dec[i] = ctypes.addressof(pl.desc)
         self._bind_wgrad()
-        self.shape = (B, Tp, Tm, S.main_stream)
+        self._packed_version = None                # new chain links / buffers: phase 0 packs
+        self.shape = (B, Tp, Tm, main.cuda_stream)     # (not S.main_stream: a c_void_p field reads the null stream back as None)
 
     def _bind_wgrad(self):
         """The weight-gradient stream / workspace fields of every block descriptor and of the step (ops.DenseBlockPlan._prepare_bwd)."""
@@ -336,6 +339,8 @@ class TrainStepPlan:
             assert ts.shape[0] == B and ts.shape[2] == S.n_mel and td.numel() == B * Tp and tp.numel() == B * Tp
             self._alloc(B, B * Tp, B * Tm)
             main_h = ops._stream()
+            if self.shape is not None and any(pl.bound_by is not self for pl in self.plans_e + self.plans_d):
+                self.shape = None                  # the per-layer path ran on these plans in between and re-bound them
             if self.shape != (B, Tp, Tm, main_h):
                 if not self._retarget(B, Tp, Tm):
                     self._bind(B, Tp, Tm)
@@ -354,12 +359,15 @@ class TrainStepPlan:
             den = m.loss_denominators or (0, 0, 0)
             S.loss_denom[0], S.loss_denom[1], S.loss_denom[2] = [int(n) for n in den]
             S.beta1, S.beta2, S.eps = float(m.beta_1), float(m.beta_2), float(m.epsilon)    # (_compile may change them)
+            # the chain kernels' weight streams: packed by the previous step's phase 2 (same binding, same weights), else now
+            chained = any(pl.chain_on for pl in self.plans_e + self.plans_d)
+            S.pack_now = int(chained and self._packed_version != m._weights_version)
+            S.pack_ahead = int(chained)
             self.keep = (x, ts, td, tp)            # alive until the next step's inputs replace them
             check(l.ttsmi_ft_train_step(self._sref, 0), 'ft_train_step(0)')
             for pl in self.plans_e + self.plans_d:
                 if pl.chain_on:
-                    pl.packed_ver = m._weights_version     # packed on the side stream by phase 0
-                    pl.pack_ev = None
+                    pl.packed_ver, pl.pack_ev = None, None     # (the per-layer path, should it run next, packs for itself)
             pad_d = t['pad_d'][:B * Tm].view(B, Tm)
             self.out = _LazyOut(pad_d, {
                 'mel': t['mel'][r][:B * Tm].view(B, Tm, S.n_mel), 'duration': t['dur']['y'][r][:B * Tp].view(B, Tp, 1),
@@ -371,6 +379,7 @@ class TrainStepPlan:
         if 2 in phases:
             check(l.ttsmi_ft_train_step(self._sref, 2), 'ft_train_step(2)')
             m._weights_version += 1                # (ForwardTransformer._refresh_shadows' bookkeeping)
+            self._packed_version = m._weights_version if S.pack_ahead else None
         return self.out
 
     def flush_decoder_ln(self):
