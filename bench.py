@@ -208,7 +208,7 @@ def kernel_family(name, args):
     return KERNEL_OF.get(name, RIDERS)
 
 
-PMC_FILE = 'r05_pmc_hbm_traffic_bf16.json'
+PMC_FILE = 'r06_pmc_hbm_traffic_bf16.json'
 PMC_KERNELS = {       # kernel family -> (rocprof names of its kernels, names of helper kernels of the same entry point)
     KERNEL_OF['ttsmi_hgemm_tn']: (['gemm_bf16_kernel', 'gemm_bf16_dma_kernel', 'gemm_bf16_deep_kernel', 'gemm_k256_kernel'], []),
     ROWGEMM: (['rowgemm_dma_kernel', 'rowgemm_kernel'], []),
@@ -506,7 +506,7 @@ def predict_cpu_baseline(cfg, Tp, threads, seconds=10.0):
                       f'materialised as the reference returns them), torch-CPU fp32 restatement, {threads} threads'}
 
 
-MEL_PMC_FILE = 'r05_pmc_hbm_traffic_mel.json'
+MEL_PMC_FILE = 'r06_pmc_hbm_traffic_mel.json'
 
 
 def _mel_cpu_clip(args):
