@@ -81,7 +81,8 @@ def _run_chain(M, F, pdrop, with_qkv, with_out32, with_bits, seed0=0, bits_layou
                                   _p(out['h1']), _p(out['bits']), bits_layout, _p(out['o']), _p(out['xh2']), _p(out['rstd2']), _p(out['o32']),
                                   _p(out['qkv']), _stream()), 'chain')
     torch.cuda.synchronize()
-    assert l.ttsmi_last_kernel().decode() == 'dense_chain16_kernel'
+    # (four 16-row waves per workgroup up to 16 384 rows, eight from there on: csrc/chain.hip chain_nw)
+    assert l.ttsmi_last_kernel().decode() == ('dense_chain16_kernel<4 waves>' if M <= 16384 else 'dense_chain16_kernel')
     inv = 1.0 / (1.0 - float(np.float32(pdrop))) if pdrop > 0 else 1.0
     live = (pad == 0)
     rows, cols = np.arange(M), np.arange(D)
@@ -117,7 +118,8 @@ def _run_chain(M, F, pdrop, with_qkv, with_out32, with_bits, seed0=0, bits_layou
 
 
 @pytest.mark.parametrize('M,pdrop,with_qkv,with_out32', [(28800, 0.1, True, False), (28800, 0.1, False, True), (6400, 0.1, True, False),
-                                                        (16384 + 77, 0.0, True, True), (300, 0.1, True, True), (97, 0.0, False, False)])
+                                                        (16384 + 77, 0.0, True, True), (300, 0.1, True, True), (97, 0.0, False, False),
+                                                        (9000, 0.1, True, False), (12800, 0.1, True, True), (16384, 0.1, True, False)])
 def test_row_local_chain_matches_the_fp64_reference_stage_by_stage(M, pdrop, with_qkv, with_out32):
     _run_chain(M, 1024, pdrop, with_qkv, with_out32, with_bits=False, seed0=M % 97)
 
@@ -127,7 +129,7 @@ def test_row_local_chain_with_another_ffn_width():
     _run_chain(1000, 192, 0.0, False, True, with_bits=False, seed0=4)      # an odd number of 64-feature chunks
 
 
-@pytest.mark.parametrize('M', [28800, 16384 + 77, 6400, 4096 + 50])
+@pytest.mark.parametrize('M', [28800, 16384 + 77, 12800, 6400, 4096 + 50])
 def test_row_local_chain_relu_bit_matrix_through_its_consumer(M):
     """(h1 > 0) as the bit matrix ttsmi_hgemm_k256_masked_bits reads: its 256-column layout from 16 384 rows, the 128-column
     one below - dh1 = (df . W2^T) masked by the chain's bits must equal the same product masked by the chain's own h1."""
@@ -199,7 +201,7 @@ def test_chained_blocks_layernorm_parameter_gradients_below_the_row_threshold(mo
         assert pl and all(p.chain_on == chain for p in pl)
         if chain:
             l = ops._lib.lib()
-            assert any(p.lnp_nw1 == l.ttsmi_dense_chain_bwd_nparts(p.M) != p.lnp_nw1_rowgemm for p in pl)
+            assert all(p.lnp_nw1 == l.ttsmi_dense_chain_bwd_nparts(p.M) for p in pl)      # (one partial row per workgroup of the chain: 64- or 128-row tiles by row count)
         grads[chain] = {k: v.clone() for k, v in m.params.g.items() if '.ln' in k}
     worst = {}
     for k, a in grads[True].items():
@@ -224,7 +226,7 @@ def _lane_bits(pos):
     return w.reshape(Mp // 16, F // 64, 64)
 
 
-@pytest.mark.parametrize('M', [28800, 16384 + 77, 300])
+@pytest.mark.parametrize('M', [28800, 16384 + 77, 9000, 300])
 def test_forward_chain_writes_the_relu_pattern_in_the_backward_chains_layout(M):
     F = 1024
     ops, _lib, l, out, sh, c = _run_chain(M, F, 0.1, True, False, with_bits=True, seed0=5, bits_layout=1)
@@ -237,7 +239,8 @@ def test_forward_chain_writes_the_relu_pattern_in_the_backward_chains_layout(M):
     assert np.array_equal(np.where(lane_live, got, 0), np.where(lane_live, want, 0))
 
 
-@pytest.mark.parametrize('M,pdrop,dres_bf16', [(28800, 0.1, True), (16384 + 77, 0.1, False), (6400, 0.0, True), (300, 0.1, True)])
+@pytest.mark.parametrize('M,pdrop,dres_bf16', [(28800, 0.1, True), (16384 + 77, 0.1, False), (6400, 0.0, True), (300, 0.1, True),
+                                                 (12800, 0.1, True), (9000, 0.1, False), (16384, 0.1, True)])
 def test_backward_chain_matches_the_fp64_reference_stage_by_stage(M, pdrop, dres_bf16):
     """ttsmi_dense_chain_bwd (csrc/chain16b.h): dh1 = (df . W2^T) [h1 > 0]; g = da + dh1 . W1^T; res-norm 1 backward in its
     x^ form (ttsmi_hgemm_ln_bwd's arithmetic) with dropout; dctx = d_o . Wo_ctx^T; the partial rows of dgamma / dbeta - each
@@ -265,7 +268,9 @@ def test_backward_chain_matches_the_fp64_reference_stage_by_stage(M, pdrop, dres
     e = lambda *s_, dt=torch.bfloat16: torch.full(s_, float('nan'), dtype=dt, device=DEV)
     dh1, d_o, dctx = e(M, F), e(M, D), e(M, D)
     dres = e(M, D) if dres_bf16 else e(M, D, dt=torch.float32)
-    nparts = (M + 127) // 128
+    nparts = int(l.ttsmi_dense_chain_bwd_nparts(M))              # one partial row per workgroup: 64-row tiles up to 16 384 rows, 128 above
+    tile = 64 if M <= 16384 else 128
+    assert nparts == (M + tile - 1) // tile
     part = ops._ws(int(l.ttsmi_layernorm_partials_bytes(nparts, D)), DEV)
     check(l.ttsmi_dense_chain_bwd(_p(dev['df']), _p(dev['da']), _p(dev['xh']), _p(dev['rstd']), _p(dev['gam']), _p(dev['pad']), _p(dev['bits']),
                                   _p(wpack), nb, M, F, pdrop, seed, _p(step), site, _p(dh1), _p(d_o), _p(dres), int(dres_bf16), _p(dctx),
@@ -293,7 +298,7 @@ def test_backward_chain_matches_the_fp64_reference_stage_by_stage(M, pdrop, dres
     # parameter-gradient partial rows: one per 128-row workgroup
     pf = part.cpu()[:2 * nparts * D * 4].view(torch.float32).reshape(2, nparts, D).double()
     gx, gb = gg * xhd, gg
-    padrows = nparts * 128 - M
-    gx = torch.cat([gx, torch.zeros(padrows, D, dtype=torch.float64)]).reshape(nparts, 128, D).sum(1)
-    gb = torch.cat([gb, torch.zeros(padrows, D, dtype=torch.float64)]).reshape(nparts, 128, D).sum(1)
+    padrows = nparts * tile - M
+    gx = torch.cat([gx, torch.zeros(padrows, D, dtype=torch.float64)]).reshape(nparts, tile, D).sum(1)
+    gb = torch.cat([gb, torch.zeros(padrows, D, dtype=torch.float64)]).reshape(nparts, tile, D).sum(1)
     assert rel_err(pf[0], gx) < 3e-5 and rel_err(pf[1], gb) < 3e-5

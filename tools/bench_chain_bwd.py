@@ -41,7 +41,7 @@ for M in [int(a) for a in sys.argv[1:]] or [28800, 16384]:
     bits_k256 = torch.randint(0, 256, (int(l.ttsmi_relu_bits_bytes(M, F)),), dtype=torch.uint8, device=DEV)
     e = lambda *s, dt=torch.bfloat16: torch.empty(s, dtype=dt, device=DEV)
     dh1, d_o, dres, dctx = e(M, F), e(M, D), e(M, D), e(M, D)
-    nparts = (M + 127) // 128
+    nparts = int(l.ttsmi_dense_chain_bwd_nparts(M))
     part = ops._ws(int(l.ttsmi_layernorm_partials_bytes(max(nparts, int(l.ttsmi_hgemm_ln_bwd_nparts(M))), D)), DEV)
 
     def chain():

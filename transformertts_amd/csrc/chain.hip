@@ -125,6 +125,15 @@ struct ChainPackP {
 #include "chain16.h"
 #include "chain16b.h"
 
+// waves per workgroup of both chain kernels by row count: four 16-row waves (64-row tiles, one wave per SIMD) while 128-row
+// tiles would leave half of the 256 CUs without a workgroup, eight (two per SIMD) from there on; TTSMI_DENSE_CHAIN_NW = 4 / 8
+// forces one form (A/B knob)
+static int chain_nw(int M) {
+    TTSMI_KNOB(forced, "TTSMI_DENSE_CHAIN_NW", 0);
+    if (forced == 4 || forced == 8) return forced;
+    return M <= 16384 ? 4 : 8;
+}
+
 static int chain_stages(int F, int with_qkv) { return CH_WO_STAGES + 2 * (F / 64) + (with_qkv ? CH_QKV_STAGES : 0); }
 
 #ifdef TTSMI_ABLATION_BUILD
@@ -197,9 +206,15 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
     p.ablate = ablate;
     p.dbg = g_chain_dbg;
 #endif
-    ttsmi_note_kernel("dense_chain16_kernel");
-    if (out32 != nullptr) TTSMI_LAUNCH_EV(dense_chain16_kernel<true>, dim3(ttsmi_cdiv(M, C16_ROWS)), dim3(C16_NW * 64), 0, (hipStream_t)stream, p);
-    else TTSMI_LAUNCH_EV(dense_chain16_kernel<false>, dim3(ttsmi_cdiv(M, C16_ROWS)), dim3(C16_NW * 64), 0, (hipStream_t)stream, p);
+    if (chain_nw(M) == 4) {
+        ttsmi_note_kernel("dense_chain16_kernel<4 waves>");
+        if (out32 != nullptr) TTSMI_LAUNCH_EV((dense_chain16_kernel<true, 4>), dim3(ttsmi_cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, p);
+        else TTSMI_LAUNCH_EV((dense_chain16_kernel<false, 4>), dim3(ttsmi_cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        ttsmi_note_kernel("dense_chain16_kernel");
+        if (out32 != nullptr) TTSMI_LAUNCH_EV((dense_chain16_kernel<true, 8>), dim3(ttsmi_cdiv(M, 128)), dim3(512), 0, (hipStream_t)stream, p);
+        else TTSMI_LAUNCH_EV((dense_chain16_kernel<false, 8>), dim3(ttsmi_cdiv(M, 128)), dim3(512), 0, (hipStream_t)stream, p);
+    }
     TTSMI_CHECK_LAUNCH("dense_chain_fwd");
     return TTSMI_OK;
 }
@@ -212,7 +227,7 @@ size_t ttsmi_dense_chain_bwd_pack_bytes(int F) { return F > 0 && F % 64 == 0 ? (
 int ttsmi_dense_chain_bwd_supported(int M, int d, int F) { return ttsmi_dense_chain_supported(M, d, F) && M >= 1; }
 
 /* rows of dgamma / dbeta partials ttsmi_dense_chain_bwd leaves in part_ws: one per 128-row workgroup */
-int ttsmi_dense_chain_bwd_nparts(int M) { return ttsmi_cdiv(M, C16_ROWS); }
+int ttsmi_dense_chain_bwd_nparts(int M) { return ttsmi_cdiv(M, chain_nw(M) * 16); }
 
 /* w1_b [256][F], w2_b [F][256], wo_b [512][256]: the weights AS STORED (bf16 shadows) */
 int ttsmi_dense_chain_bwd_pack(const uint16_t* w1_b, const uint16_t* w2_b, const uint16_t* wo_b, int F, void* out, size_t out_bytes,
@@ -258,7 +273,8 @@ int ttsmi_dense_chain_bwd(const uint16_t* df, const uint16_t* da, const uint16_t
     p.seed = seed; p.step_dev = step_dev; p.site = site_ln1;
     p.dh1 = dh1; p.d_o = d_o; p.dctx = dctx; p.dres = dres; p.dres_bf16 = dres_is_bf16 ? 1 : 0; p.part = (float*)part_ws;
     ttsmi_note_kernel("dense_chain16_bwd_kernel");
-    TTSMI_LAUNCH_EV(dense_chain16_bwd_kernel, dim3(nparts), dim3(C16_NW * 64), 0, (hipStream_t)stream, p);
+    if (chain_nw(M) == 4) TTSMI_LAUNCH_EV(dense_chain16_bwd_kernel<4>, dim3(nparts), dim3(256), 0, (hipStream_t)stream, p);
+    else TTSMI_LAUNCH_EV(dense_chain16_bwd_kernel<8>, dim3(nparts), dim3(512), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("dense_chain_bwd");
     return TTSMI_OK;
 }

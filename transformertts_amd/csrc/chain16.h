@@ -14,11 +14,13 @@
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-#define C16_NW 8
-#define C16_ROWS (C16_NW * 16)
+// NW = waves per workgroup: 8 (128 rows, two waves per SIMD: decoder-size launches) or 4 (64 rows, one wave per SIMD, round 6: a
+// workgroup's lifetime is its 52 weight stages whatever the row count - ~60 us at two waves per SIMD - so below ~16 k rows,
+// where 128-row tiles leave half of the CUs without a workgroup, 64-row tiles halve each SIMD's matrix work per stage and
+// double the workgroups; the four launches this kernel replaces cost ~70 us per block at 6 400 rows in the step)
+#define C16_NW_MAX 8
 #define C16_SLOT_BYTES (16 * CH_SLOT_LD * 2)            // 2 304: 16 rows x 64 bf16 (144-byte rows), or 16 rows x 32 fp32 (36-float rows)
-#define C16_SCR_BYTES (C16_NW * C16_SLOT_BYTES)
-#define C16_NDMA (CH_STAGE_FRAGS / C16_NW)              // 4 pieces per wave and stage
+#define C16_SCR_BYTES (C16_NW_MAX * C16_SLOT_BYTES)
 #define C16_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 // one stage: 32 fragments x one 16x16x32 multiply, four groups of eight, the read of group g + 1 behind the multiplies of g
@@ -208,8 +210,25 @@ __device__ __forceinline__ void c16_layernorm(f32x4v (&Z)[16], const bf16x8 (&R)
     }
 }
 
-template <bool Y32>
-__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_chain16_kernel(ChainP p) {
+// one DMA call of a wave = HALF of its pieces of a stage (NDMA = 32 / NW pieces of 1 KB per wave and stage; `half` 0 / 1), issued
+// with one m0 set-up and instruction offsets: 2 pieces (NW = 8) or 4 (NW = 4)
+template <int NDMA>
+__device__ __forceinline__ void c16_issue_half(const unsigned char* src, unsigned dst, int half) {
+    static_assert(NDMA == 4 || NDMA == 8, "8 or 4 waves");
+    src += half * (NDMA / 2) * CH_FRAG_BYTES;
+    dst += (unsigned)(half * (NDMA / 2) * CH_FRAG_BYTES);
+    if constexpr (NDMA == 4)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+                     ::"v"(src), "s"(dst) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                     ::"v"(src), "s"(dst) : "memory", "m0");
+}
+
+template <bool Y32, int NW>
+__global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void dense_chain16_kernel(ChainP p) {
+    constexpr int C16_ROWS = NW * 16, C16_NDMA = CH_STAGE_FRAGS / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + C16_SCR_BYTES + CH_PAR_FLOATS * 4];
     unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
     float* par = reinterpret_cast<float*>(scr + C16_SCR_BYTES);
@@ -233,14 +252,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const unsigned wdst = ring_off + (unsigned)wave * C16_NDMA * CH_FRAG_BYTES;
     auto issue2 = [&](int s, int g) {
         if (s >= nst) return;
-        const unsigned char* src = wsrc + (size_t)s * CH_STAGE_BYTES;
-        const unsigned dst = wdst + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES;
-        if (g & 1)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
-                         ::"v"(src), "s"(dst) : "memory", "m0");
-        else
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
-                         ::"v"(src), "s"(dst) : "memory", "m0");
+        c16_issue_half<C16_NDMA>(wsrc + (size_t)s * CH_STAGE_BYTES, __builtin_amdgcn_readfirstlane(wdst + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES), g & 1);
     };
     // stage s has landed once at most the pieces of the two stages behind it are outstanding on every wave (chain.hip)
     auto stage_begin = [&](int s) -> const unsigned char* {
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const uint64_t drop_base = p.thr ? ttsmi_drop_base(p.seed, p.step_dev) : 0;      // (read here, in front of the first DMA issue)
     {
         auto stage_vec = [&](const float* src, int off, int n) {
-            for (int i = tid * 4; i < n; i += 512 * 4) *reinterpret_cast<float4*>(par + off + i) = *reinterpret_cast<const float4*>(src + i);
+            for (int i = tid * 4; i < n; i += NW * 64 * 4) *reinterpret_cast<float4*>(par + off + i) = *reinterpret_cast<const float4*>(src + i);
         };
         stage_vec(p.bo, CH_P_BO, CH_D); stage_vec(p.ln1_g, CH_P_G1, CH_D); stage_vec(p.ln1_b, CH_P_BE1, CH_D);
         stage_vec(p.b2, CH_P_B2, CH_D); stage_vec(p.ln2_g, CH_P_G2, CH_D); stage_vec(p.ln2_b, CH_P_BE2, CH_D);
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #ifdef TTSMI_ABLATION_BUILD
     C16_STAMP();
     if (p.dbg && lane == 0) {              // [workgroup][wave][8]: start, prologue, o-projection, LN1, FFN, LN2, qkv, time in stage waits
-        unsigned long long* o = p.dbg + ((long)blockIdx.x * C16_NW + wave) * 8;
+        unsigned long long* o = p.dbg + ((long)blockIdx.x * NW + wave) * 8;
         o[0] = tph[0];
         for (int i = 1; i < 7; ++i) o[i] = tph[i] - tph[i - 1];
         o[7] = twait;

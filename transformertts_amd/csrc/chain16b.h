@@ -31,7 +31,9 @@ struct ChainBP {
 
 #define C16B_CTX_STAGES 4
 
-__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_chain16_bwd_kernel(ChainBP p) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void dense_chain16_bwd_kernel(ChainBP p) {
+    constexpr int C16_ROWS = NW * 16, C16_NDMA = CH_STAGE_FRAGS / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + C16_SCR_BYTES + 2 * CH_D * 4];
     unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
     float* gam = reinterpret_cast<float*>(scr + C16_SCR_BYTES);          // gamma1, staged
@@ -45,14 +47,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const unsigned wdst = ring_off + (unsigned)wave * C16_NDMA * CH_FRAG_BYTES;
     auto issue2 = [&](int s, int g) {
         if (s >= nst) return;
-        const unsigned char* src = wsrc + (size_t)s * CH_STAGE_BYTES;
-        const unsigned dst = wdst + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES;
-        if (g & 1)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
-                         ::"v"(src), "s"(dst) : "memory", "m0");
-        else
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
-                         ::"v"(src), "s"(dst) : "memory", "m0");
+        c16_issue_half<C16_NDMA>(wsrc + (size_t)s * CH_STAGE_BYTES, __builtin_amdgcn_readfirstlane(wdst + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES), g & 1);
     };
     auto stage_begin = [&](int s) -> const unsigned char* {
         if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C16_NDMA) : "memory");
@@ -109,7 +104,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // would be vmcnt(0) and drain the ring's prefetch - the compiler does not count the inline-asm DMA instructions)
     const uint64_t key = p.thr ? ttsmi_drop_key(p.seed, p.step_dev, p.site) : 0;
     asm volatile("" : "+v"(rstd));
-    for (int i = tid * 4; i < CH_D; i += 512 * 4) *reinterpret_cast<float4*>(gam + i) = *reinterpret_cast<const float4*>(p.gamma + i);
+    for (int i = tid * 4; i < CH_D; i += NW * 64 * 4) *reinterpret_cast<float4*>(gam + i) = *reinterpret_cast<const float4*>(p.gamma + i);
 #pragma unroll
     for (int s = 0; s < CH_NRING - 1; ++s) {
         issue2(s, 0);
@@ -279,11 +274,14 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const unsigned char* Fs = stage_begin(S);
         if (s == 0) {
             // (the barrier above published every wave's column sums)
-            const int col = 64 * wave + lane;                          // 0..511: dgamma columns, then dbeta columns
-            float a = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < C16_NW; ++wv) a += reinterpret_cast<const float*>(scr + wv * C16_SLOT_BYTES)[col];
-            p.part[((long)(col >> 8) * p.nparts + blockIdx.x) * CH_D + (col & 255)] = a;
+            for (int cpart = 0; cpart < 8 / NW; ++cpart) {
+                const int col = 64 * (wave * (8 / NW) + cpart) + lane;     // 0..511: dgamma columns, then dbeta columns
+                float a = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < NW; ++wv) a += reinterpret_cast<const float*>(scr + wv * C16_SLOT_BYTES)[col];
+                p.part[((long)(col >> 8) * p.nparts + blockIdx.x) * CH_D + (col & 255)] = a;
+            }
             ch_barrier();                                              // the slots are free again
         } else {
             c16_slot_flush(slot, p.dctx, CH_D, 64 * (s - 1), row0, p.M, lane, nullptr, 0, 0);

@@ -1777,7 +1777,11 @@ FUSE_LN_MIN_ROWS_INFERENCE = int(os.environ.get('TTSMI_FUSE_LN_MIN_ROWS', '8192'
 
 
 _CHAIN_BWD = os.environ.get('TTSMI_DENSE_CHAIN_BWD', '1') != '0'
-CHAIN_MIN_ROWS = int(os.environ.get('TTSMI_DENSE_CHAIN_MIN_ROWS', '16384'))      # rows from which the chain kernel replaces the four launches
+# rows from which the chain kernels replace the four / three launches.  Round 5: 16 384 (the 128-row form's workgroup lives ~60 us
+# whatever the row count).  Round 6: the 64-row form (four waves, csrc/chain16.h) wins alone from ~2 000 rows on - 52 against 56 us
+# forward and 37 against 40 us backward at 6 400 rows, 56 / 67 and 40 / 49 at 12 000 (profiles/r06_chain64_alone.txt) - and in
+# the step saves the launches' boundaries as well
+CHAIN_MIN_ROWS = int(os.environ.get('TTSMI_DENSE_CHAIN_MIN_ROWS', '1024'))
 
 
 class DenseBlockPlan:
