@@ -134,6 +134,12 @@ static int chain_nw(int M) {
     return M <= 16384 ? 4 : 8;
 }
 
+// two loader waves beside the four compute waves of the 64-row form (chain16.h: c16_loader_loop); TTSMI_DENSE_CHAIN_LOADERS=0: none (A/B knob)
+static bool chain_loaders() {
+    TTSMI_KNOB(on, "TTSMI_DENSE_CHAIN_LOADERS", 1);
+    return on != 0;
+}
+
 static int chain_stages(int F, int with_qkv) { return CH_WO_STAGES + 2 * (F / 64) + (with_qkv ? CH_QKV_STAGES : 0); }
 
 #ifdef TTSMI_ABLATION_BUILD
@@ -208,8 +214,13 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
 #endif
     if (chain_nw(M) == 4) {
         ttsmi_note_kernel("dense_chain16_kernel<4 waves>");
-        if (out32 != nullptr) TTSMI_LAUNCH_EV((dense_chain16_kernel<true, 4>), dim3(ttsmi_cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, p);
-        else TTSMI_LAUNCH_EV((dense_chain16_kernel<false, 4>), dim3(ttsmi_cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, p);
+        if (chain_loaders()) {
+            if (out32 != nullptr) TTSMI_LAUNCH_EV((dense_chain16_kernel<true, 4, 2>), dim3(ttsmi_cdiv(M, 64)), dim3(384), 0, (hipStream_t)stream, p);
+            else TTSMI_LAUNCH_EV((dense_chain16_kernel<false, 4, 2>), dim3(ttsmi_cdiv(M, 64)), dim3(384), 0, (hipStream_t)stream, p);
+        } else {
+            if (out32 != nullptr) TTSMI_LAUNCH_EV((dense_chain16_kernel<true, 4>), dim3(ttsmi_cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, p);
+            else TTSMI_LAUNCH_EV((dense_chain16_kernel<false, 4>), dim3(ttsmi_cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, p);
+        }
     } else {
         ttsmi_note_kernel("dense_chain16_kernel");
         if (out32 != nullptr) TTSMI_LAUNCH_EV((dense_chain16_kernel<true, 8>), dim3(ttsmi_cdiv(M, 128)), dim3(512), 0, (hipStream_t)stream, p);
@@ -273,7 +284,8 @@ int ttsmi_dense_chain_bwd(const uint16_t* df, const uint16_t* da, const uint16_t
     p.seed = seed; p.step_dev = step_dev; p.site = site_ln1;
     p.dh1 = dh1; p.d_o = d_o; p.dctx = dctx; p.dres = dres; p.dres_bf16 = dres_is_bf16 ? 1 : 0; p.part = (float*)part_ws;
     ttsmi_note_kernel("dense_chain16_bwd_kernel");
-    if (chain_nw(M) == 4) TTSMI_LAUNCH_EV(dense_chain16_bwd_kernel<4>, dim3(nparts), dim3(256), 0, (hipStream_t)stream, p);
+    if (chain_nw(M) == 4 && chain_loaders()) TTSMI_LAUNCH_EV((dense_chain16_bwd_kernel<4, 2>), dim3(nparts), dim3(384), 0, (hipStream_t)stream, p);
+    else if (chain_nw(M) == 4) TTSMI_LAUNCH_EV(dense_chain16_bwd_kernel<4>, dim3(nparts), dim3(256), 0, (hipStream_t)stream, p);
     else TTSMI_LAUNCH_EV(dense_chain16_bwd_kernel<8>, dim3(nparts), dim3(512), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("dense_chain_bwd");
     return TTSMI_OK;

@@ -226,8 +226,38 @@ __device__ __forceinline__ void c16_issue_half(const unsigned char* src, unsigne
                      ::"v"(src), "s"(dst) : "memory", "m0");
 }
 
-template <bool Y32, int NW>
-__global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void dense_chain16_kernel(ChainP p) {
+// LOADER waves (round 6, the four-wave form): with one compute wave per SIMD nothing hides the issue time of a stage's DMA
+// pieces - eight per wave, ~400 of a stage's ~1 300 cycles (profiles/r06_chain64_phases.txt) - so NL = 2 extra waves do nothing
+// but stream the weights: each issues 16 of a stage's 32 pieces right after the stage barrier that retires the ring slot, waits
+// for its own pieces with a counted vmcnt and joins every workgroup barrier the compute waves execute (`extra_barrier_after`:
+// the backward kernel has one more, behind the barrier of that stage).  The compute waves then neither issue nor wait for DMA.
+template <int NL>
+__device__ __forceinline__ void c16_loader_loop(const unsigned char* wpack, unsigned ring_off, int nst, int lw, int lane, int extra_barrier_after) {
+    constexpr int PL = CH_STAGE_FRAGS / NL;                      // pieces per loader wave and stage
+    static_assert(PL % 4 == 0 && 3 * PL <= 63, "vmcnt is a 6-bit counter");
+    const unsigned char* src0 = wpack + (size_t)lw * PL * CH_FRAG_BYTES + lane * 16;
+    const unsigned dst0 = ring_off + (unsigned)lw * PL * CH_FRAG_BYTES;
+    auto issue = [&](int s) {
+        if (s >= nst) return;
+        const unsigned char* src = src0 + (size_t)s * CH_STAGE_BYTES;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES);
+#pragma unroll
+        for (int k = 0; k < PL / 4; ++k) c16_issue_half<8>(src + k * 4 * CH_FRAG_BYTES, dst + (unsigned)(k * 4 * CH_FRAG_BYTES), 0);
+    };
+#pragma unroll
+    for (int s = 0; s < CH_NRING - 1; ++s) issue(s);
+    for (int s = 0; s < nst; ++s) {
+        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PL) : "memory");
+        else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ch_barrier();
+        if (s == extra_barrier_after) ch_barrier();
+        issue(s + CH_NRING - 1);
+    }
+}
+
+template <bool Y32, int NW, int NL = 0>
+__global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_eu(NW / 4, (NW + NL + 3) / 4))) void dense_chain16_kernel(ChainP p) {
     constexpr int C16_ROWS = NW * 16, C16_NDMA = CH_STAGE_FRAGS / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + C16_SCR_BYTES + CH_PAR_FLOATS * 4];
     unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
@@ -250,7 +280,14 @@ __global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW /
     // two of this wave's four pieces of stage s (one m0 set-up, instruction offsets on both addresses)
     const unsigned char* wsrc = p.wpack + (size_t)wave * C16_NDMA * CH_FRAG_BYTES + lane * 16;
     const unsigned wdst = ring_off + (unsigned)wave * C16_NDMA * CH_FRAG_BYTES;
+    if constexpr (NL > 0) {
+        if (wave >= NW) {                                         // (wave-uniform: the loader waves never touch rows)
+            c16_loader_loop<NL>(p.wpack, ring_off, nst, wave - NW, lane, -1);
+            return;
+        }
+    }
     auto issue2 = [&](int s, int g) {
+        if constexpr (NL > 0) return;                             // the loader waves stream the weights
         if (s >= nst) return;
         c16_issue_half<C16_NDMA>(wsrc + (size_t)s * CH_STAGE_BYTES, __builtin_amdgcn_readfirstlane(wdst + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES), g & 1);
     };
@@ -259,9 +296,11 @@ __global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW /
 #ifdef TTSMI_ABLATION_BUILD
         const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
-        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C16_NDMA) : "memory");
-        else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C16_NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NL == 0) {
+            if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C16_NDMA) : "memory");
+            else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C16_NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         ch_barrier();
 #ifdef TTSMI_ABLATION_BUILD
         twait += __builtin_readcyclecounter() - tw0;

@@ -31,8 +31,8 @@ struct ChainBP {
 
 #define C16B_CTX_STAGES 4
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void dense_chain16_bwd_kernel(ChainBP p) {
+template <int NW, int NL = 0>
+__global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_eu(NW / 4, (NW + NL + 3) / 4))) void dense_chain16_bwd_kernel(ChainBP p) {
     constexpr int C16_ROWS = NW * 16, C16_NDMA = CH_STAGE_FRAGS / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + C16_SCR_BYTES + 2 * CH_D * 4];
     unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
@@ -45,14 +45,23 @@ __global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW /
     const unsigned ring_off = ch_lds_offset(smem);
     const unsigned char* wsrc = p.wpack + (size_t)wave * C16_NDMA * CH_FRAG_BYTES + lane * 16;
     const unsigned wdst = ring_off + (unsigned)wave * C16_NDMA * CH_FRAG_BYTES;
+    if constexpr (NL > 0) {
+        if (wave >= NW) {             // loader waves (chain16.h): the one extra barrier sits behind the first dctx stage's
+            c16_loader_loop<NL>(p.wpack, ring_off, nst, wave - NW, lane, 2 * p.nchunk);
+            return;
+        }
+    }
     auto issue2 = [&](int s, int g) {
+        if constexpr (NL > 0) return;
         if (s >= nst) return;
         c16_issue_half<C16_NDMA>(wsrc + (size_t)s * CH_STAGE_BYTES, __builtin_amdgcn_readfirstlane(wdst + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES), g & 1);
     };
     auto stage_begin = [&](int s) -> const unsigned char* {
-        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C16_NDMA) : "memory");
-        else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C16_NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NL == 0) {
+            if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C16_NDMA) : "memory");
+            else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C16_NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         ch_barrier();
         return smem + (s % CH_NRING) * CH_STAGE_BYTES + lane * 16;
     };
@@ -141,7 +150,8 @@ __global__ __launch_bounds__(NW * 64, 1) __attribute__((amdgpu_waves_per_eu(NW /
         c16_stage(Fs, [&](int g, int i, const bf16x8& a) { H[i & 3] = C16_MFMA(a, DF[2 * g + (i >> 2)], H[i & 3]); },
                   [&](int g) { issue2(S + CH_NRING - 1, g); });
         ++S;
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(bits) : "n"(C16_NDMA) : "memory");
+        // (with loader waves nothing of this wave is younger than the word's load: a plain drain - its stores are a stage old)
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(bits) : "n"(NL > 0 ? 0 : C16_NDMA) : "memory");
         bf16x8 hf[2];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
