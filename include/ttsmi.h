@@ -43,7 +43,7 @@ extern "C" {
  * ttsmi_dense_block_bwd_chained, ttsmi_ft_train_step; the opt-in one-pass attention backward
  * (ttsmi_attention_bwd_fused*, attn_fused_ws) removed - it never beat the two kernels inside the step.  Bindings check it at load time (transformertts_amd/_lib.py) so that a stale build is
  * refused instead of being called with shifted arguments. */
-#define TTSMI_VERSION 107
+#define TTSMI_VERSION 108
 
 enum {
     TTSMI_OK = 0,
@@ -137,6 +137,10 @@ int ttsmi_attention_bwd(const void* qkv, const uint8_t* key_pad, const int32_t* 
 size_t ttsmi_attention_dropmask_bytes(int B, int H, int T);
 int ttsmi_attention_dropmask(void* mask, int B, int H, int T, float p_drop, uint64_t seed,
                              const int64_t* step_dev, uint32_t site, ttsmi_stream_t stream);
+/* the tables of n layers of one stack (same B, H, T, rate, seed, step; masks[i] gets site sites[i]) in one launch; the
+ * same bits as n ttsmi_attention_dropmask calls */
+int ttsmi_attention_dropmask_stack(void* const* masks, const uint32_t* sites, int n, int B, int H, int T, float p_drop,
+                                   uint64_t seed, const int64_t* step_dev, ttsmi_stream_t stream);
 int ttsmi_attention_fwd_masked(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
                                float* lse, int B, int H, int T, int dh, float p_drop, const void* dropmask, int dtype,
                                ttsmi_stream_t stream);
@@ -619,6 +623,17 @@ int ttsmi_debug_xcc_census(int32_t* counts8, int nblocks, ttsmi_stream_t stream)
 size_t ttsmi_dense_chain_pack_bytes(int F, int with_qkv);
 int ttsmi_dense_chain_pack(const uint16_t* wo_t, const uint16_t* w1_t, const uint16_t* w2_t, const uint16_t* wqkv_next_t, int F,
                            void* out, size_t out_bytes, ttsmi_stream_t stream);
+/* Several weight streams in one launch (a train step repacks every block's two streams after each optimiser update).
+ * backward == 0: wo / w1 / w2 / wqkv_next are ttsmi_dense_chain_pack's wo_t / w1_t / w2_t / wqkv_next_t;
+ * backward != 0: wo / w1 / w2 are ttsmi_dense_chain_bwd_pack's wo_b / w1_b / w2_b (wqkv_next unused).  Same bytes as the
+ * single calls. */
+typedef struct ttsmi_chain_pack_job {
+    const uint16_t *wo, *w1, *w2, *wqkv_next;
+    void* out;
+    size_t out_bytes;
+    int32_t F, backward;
+} ttsmi_chain_pack_job;
+int ttsmi_dense_chain_pack_batched(const ttsmi_chain_pack_job* jobs, int n, ttsmi_stream_t stream);
 int ttsmi_dense_chain_supported(int M, int d, int F);
 int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void* wpack, size_t wpack_bytes, int M, int F,
                           const float* bo, const float* ln1_g, const float* ln1_b, const float* b1, const float* b2,

@@ -302,3 +302,43 @@ def test_backward_chain_matches_the_fp64_reference_stage_by_stage(M, pdrop, dres
     gx = torch.cat([gx, torch.zeros(padrows, D, dtype=torch.float64)]).reshape(nparts, tile, D).sum(1)
     gb = torch.cat([gb, torch.zeros(padrows, D, dtype=torch.float64)]).reshape(nparts, tile, D).sum(1)
     assert rel_err(pf[0], gx) < 3e-5 and rel_err(pf[1], gb) < 3e-5
+
+
+@pytest.mark.gpu
+def test_batched_pack_writes_the_bytes_of_the_single_calls():
+    """ttsmi_dense_chain_pack_batched (one launch for every weight stream a train step repacks) = the single forward / backward
+    pack calls byte for byte, for streams of different length in one job list (F 1024 with and without the qkv tail, F 256)."""
+    import ctypes
+    ops, _lib, l = _env()
+    from transformertts_amd.ops import _p, _stream, check
+
+    class Job(ctypes.Structure):
+        _fields_ = [('wo', ctypes.c_void_p), ('w1', ctypes.c_void_p), ('w2', ctypes.c_void_p), ('wqkv_next', ctypes.c_void_p),
+                    ('out', ctypes.c_void_p), ('out_bytes', ctypes.c_size_t), ('F', ctypes.c_int32), ('backward', ctypes.c_int32)]
+
+    cases = [(1024, True, 0), (1024, False, 0), (256, True, 0), (1024, False, 1), (256, False, 1)]
+    jobs, want, got, keep = (Job * len(cases))(), [], [], []
+    for i, (F, with_qkv, backward) in enumerate(cases):
+        sh = {k: ops.make_shadow(v.to(DEV)) for k, v in dict(wo=g(2 * D, D, seed=10 * i + 1, scale=0.05), w1=g(D, F, seed=10 * i + 2, scale=0.06),
+                                                              w2=g(F, D, seed=10 * i + 3, scale=0.04), wq=g(D, 3 * D, seed=10 * i + 4, scale=0.06)).items()}
+        keep.append(sh)
+        nb = int(l.ttsmi_dense_chain_bwd_pack_bytes(F)) if backward else int(l.ttsmi_dense_chain_pack_bytes(F, int(with_qkv)))
+        a, b = torch.zeros(nb, dtype=torch.uint8, device=DEV), torch.full((nb + 64,), 0xA5, dtype=torch.uint8, device=DEV)
+        if backward:
+            check(l.ttsmi_dense_chain_bwd_pack(_p(sh['w1'].wb), _p(sh['w2'].wb), _p(sh['wo'].wb), F, _p(a), nb, _stream()))
+            jobs[i] = Job(sh['wo'].wb.data_ptr(), sh['w1'].wb.data_ptr(), sh['w2'].wb.data_ptr(), None, b.data_ptr(), nb, F, 1)
+        else:
+            check(l.ttsmi_dense_chain_pack(_p(sh['wo'].wt), _p(sh['w1'].wt), _p(sh['w2'].wt), _p(sh['wq'].wt) if with_qkv else None, F, _p(a), nb,
+                                           _stream()))
+            jobs[i] = Job(sh['wo'].wt.data_ptr(), sh['w1'].wt.data_ptr(), sh['w2'].wt.data_ptr(), sh['wq'].wt.data_ptr() if with_qkv else None,
+                          b.data_ptr(), nb, F, 0)
+        want.append(a)
+        got.append(b)
+    check(l.ttsmi_dense_chain_pack_batched(ctypes.addressof(jobs), len(cases), _stream()))
+    torch.cuda.synchronize()
+    for (F, with_qkv, backward), a, b in zip(cases, want, got):
+        assert torch.equal(a, b[:a.numel()]), (F, with_qkv, backward)
+        assert bool((b[a.numel():] == 0xA5).all()), 'wrote past the end of a shorter stream'
+    # a short output buffer is refused before anything is launched
+    jobs[1].out_bytes = 10
+    assert l.ttsmi_dense_chain_pack_batched(ctypes.addressof(jobs), len(cases), _stream()) != 0

@@ -686,6 +686,31 @@ def test_attention_keep_bit_table_equals_the_hashed_dropout(B, H, T, dh):
     assert live.any()
 
 
+def test_keep_bit_tables_of_a_stack_in_one_launch_equal_the_single_calls():
+    """ttsmi_attention_dropmask_stack (the train step's form: every layer of a stack, one launch) writes the same bits as one
+    ttsmi_attention_dropmask call per layer, T % 32 != 0 included."""
+    import ctypes
+    ops = _ops()
+    from transformertts_amd import _lib
+    from transformertts_amd.ops import _p, _stream, check
+    l = _lib.lib()
+    B, H, T, pdrop, seed, n = 3, 4, 173, 0.1, 991, 5
+    step = torch.full((1,), 7, dtype=torch.int64, device=DEV)
+    nb = int(l.ttsmi_attention_dropmask_bytes(B, H, T))
+    sites = [3, 9, 4, 100, 17]
+    single = [torch.zeros(nb, dtype=torch.uint8, device=DEV) for _ in range(n)]
+    stack = [torch.full((nb + 64,), 0x5A, dtype=torch.uint8, device=DEV) for _ in range(n)]
+    for m, s_ in zip(single, sites):
+        check(l.ttsmi_attention_dropmask(_p(m), B, H, T, pdrop, seed, _p(step), s_, _stream()))
+    ptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m in stack])
+    csites = (ctypes.c_uint32 * n)(*sites)
+    check(l.ttsmi_attention_dropmask_stack(ctypes.addressof(ptrs), ctypes.addressof(csites), n, B, H, T, pdrop, seed, _p(step), _stream()))
+    torch.cuda.synchronize()
+    for a, b in zip(single, stack):
+        assert torch.equal(a, b[:nb]) and bool((b[nb:] == 0x5A).all())
+    assert not torch.equal(single[0], single[1])
+
+
 @pytest.mark.parametrize('B,H,T,dh', [(1, 4, 2304, 64), (1, 4, 400, 64), (2, 2, 333, 32), (1, 2, 700, 192), (3, 4, 100, 64),
                                       (32, 4, 900, 64)])
 def test_split_key_attention_forward_equals_the_plain_forward(B, H, T, dh):

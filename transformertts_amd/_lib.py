@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # version this binding was written for (EXPECTED_VERSION, checked in lib()).
 _override = os.environ.get('TTSMI_LIB') if os.environ.get('TTSMI_ALLOW_LIB_OVERRIDE') == '1' else None
 LIB_PATH = _override or os.path.join(_HERE, 'lib', 'libttsmi.so')
-EXPECTED_VERSION = 107            # include/ttsmi.h: TTSMI_VERSION
+EXPECTED_VERSION = 108            # include/ttsmi.h: TTSMI_VERSION
 
 P = c_void_p          # every device pointer
 I = c_int
@@ -50,6 +50,7 @@ SIGNATURES = {
     'ttsmi_attention_weights_masked': (I, [P, P, P, P, I, I, I, I, F, P, I, S]),
     'ttsmi_attention_dropmask_bytes': (c_size_t, [I, I, I]),
     'ttsmi_attention_dropmask': (I, [P, I, I, I, F, c_uint64, P, c_uint32, S]),
+    'ttsmi_attention_dropmask_stack': (I, [P, P, I, I, I, I, F, c_uint64, P, S]),
     'ttsmi_attention_fwd_masked': (I, [P, P, P, P, P, I, I, I, I, F, P, I, S]),
     'ttsmi_attention_fwd_splitkeys_ws_bytes': (c_size_t, [I, I, I, I]),
     'ttsmi_attention_fwd_splitkeys': (I, [P, P, P, P, P, I, I, I, I, P, c_size_t, S]),
@@ -128,6 +129,7 @@ SIGNATURES = {
     'ttsmi_dense_chain_bwd_nparts': (I, [I]),
     'ttsmi_dense_block_bwd_chained': (I, [P]),
     'ttsmi_dense_chain_bwd_pack': (I, [P, P, P, I, P, c_size_t, S]),
+    'ttsmi_dense_chain_pack_batched': (I, [P, I, S]),
     'ttsmi_dense_chain_bwd': (I, [P, P, P, P, P, P, P, P, c_size_t, I, I, F, c_uint64, P, c_uint32, P, P, P, I, P, P, c_size_t, S]),
     'ttsmi_dense_block_fwd': (I, [P, P, P]),
     'ttsmi_dense_block_bwd': (I, [P, P, P, P]),

@@ -569,6 +569,11 @@ int ttsmi_attention_dropmask(void* mask, int B, int H, int T, float p_drop, uint
     return ttsmi_hattention_dropmask(mask, B, H, T, p_drop, seed, step_dev, site, (hipStream_t)stream);
 }
 
+int ttsmi_attention_dropmask_stack(void* const* masks, const uint32_t* sites, int n, int B, int H, int T, float p_drop,
+                                   uint64_t seed, const int64_t* step_dev, ttsmi_stream_t stream) {
+    return ttsmi_hattention_dropmask_stack(masks, sites, n, B, H, T, p_drop, seed, step_dev, (hipStream_t)stream);
+}
+
 int ttsmi_attention_fwd_masked(const void* qkv, const uint8_t* key_pad, const int32_t* klen, void* ctx,
                                float* lse, int B, int H, int T, int dh, float p_drop, const void* dropmask, int dtype,
                                ttsmi_stream_t stream) {

@@ -1185,8 +1185,8 @@ __global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void hattn_bwd_dkv_kernel(HAt
 // blocks; the decisions are the SAME hash the DROP == 1 kernels, the exact-fp32 kernels and attention_weights
 // evaluate, so every consumer sees one mask.
 // =================================================================================================
-__global__ __launch_bounds__(256) void hattn_dropmask_kernel(uint64_t* __restrict__ mask, int BH, int T, uint32_t thr,
-                                                             uint64_t seed, const int64_t* step_dev, uint32_t site) {
+__device__ __forceinline__ void hattn_dropmask_body(uint64_t* __restrict__ mask, int BH, int T, uint32_t thr, uint64_t seed,
+                                                    const int64_t* step_dev, uint32_t site) {
     const int nt = (T + 31) >> 5;
     const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
     const long wid = blockIdx.x * 4L + (threadIdx.x >> 6);
@@ -1207,6 +1207,20 @@ __global__ __launch_bounds__(256) void hattn_dropmask_kernel(uint64_t* __restric
         }
         if (lane < 16) dst[kb * 16 + lane] = mine;
     }
+}
+__global__ __launch_bounds__(256) void hattn_dropmask_kernel(uint64_t* __restrict__ mask, int BH, int T, uint32_t thr,
+                                                             uint64_t seed, const int64_t* step_dev, uint32_t site) {
+    hattn_dropmask_body(mask, BH, T, thr, seed, step_dev, site);
+}
+// the tables of a whole stack of layers (same shape, rate, seed and step; one site each) in one launch: blockIdx.y = layer
+#define HATTN_DROPMASK_MAX_LAYERS 32
+struct HDropmaskStack {
+    uint64_t* mask[HATTN_DROPMASK_MAX_LAYERS];
+    uint32_t site[HATTN_DROPMASK_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void hattn_dropmask_stack_kernel(HDropmaskStack L, int BH, int T, uint32_t thr, uint64_t seed,
+                                                                   const int64_t* step_dev) {
+    hattn_dropmask_body(L.mask[blockIdx.y], BH, T, thr, seed, step_dev, L.site[blockIdx.y]);
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -1490,6 +1504,27 @@ int ttsmi_hattention_dropmask(void* mask, int B, int H, int T, float p_drop, uin
     hipLaunchKernelGGL(hattn_dropmask_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (uint64_t*)mask,
                        B * H, T, ttsmi_drop_threshold(p_drop), seed, step_dev, site);
     TTSMI_CHECK_LAUNCH("attention_dropmask");
+    return TTSMI_OK;
+}
+
+int ttsmi_hattention_dropmask_stack(void* const* masks, const uint32_t* sites, int n, int B, int H, int T, float p_drop,
+                                    uint64_t seed, const int64_t* step_dev, hipStream_t st) {
+    TTSMI_CHECK_ARG(masks && sites && n > 0 && B > 0 && H > 0 && T > 0, "attention_dropmask_stack: bad argument");
+    TTSMI_CHECK_ARG(p_drop > 0.f && p_drop < 1.f, "attention_dropmask_stack: dropout rate must be in (0,1)");
+    const long waves = (long)B * H * ((T + 31) / 32);
+    for (int i0 = 0; i0 < n; i0 += HATTN_DROPMASK_MAX_LAYERS) {
+        const int m = n - i0 < HATTN_DROPMASK_MAX_LAYERS ? n - i0 : HATTN_DROPMASK_MAX_LAYERS;
+        HDropmaskStack L;
+        memset(&L, 0, sizeof(L));
+        for (int i = 0; i < m; ++i) {
+            TTSMI_CHECK_ARG(masks[i0 + i] && (((uintptr_t)masks[i0 + i]) & 7) == 0, "attention_dropmask_stack: table %d is null or not 8-byte aligned", i0 + i);
+            L.mask[i] = (uint64_t*)masks[i0 + i];
+            L.site[i] = sites[i0 + i];
+        }
+        hipLaunchKernelGGL(hattn_dropmask_stack_kernel, dim3((unsigned)((waves + 3) / 4), m), dim3(256), 0, st, L, B * H, T,
+                           ttsmi_drop_threshold(p_drop), seed, step_dev);
+        TTSMI_CHECK_LAUNCH("attention_dropmask_stack");
+    }
     return TTSMI_OK;
 }
 

@@ -140,6 +140,7 @@ static bool chain_loaders() {
     return on != 0;
 }
 
+static int chain_bwd_stages(int F) { return 2 * (F / 64) + C16B_CTX_STAGES; }
 static int chain_stages(int F, int with_qkv) { return CH_WO_STAGES + 2 * (F / 64) + (with_qkv ? CH_QKV_STAGES : 0); }
 
 #ifdef TTSMI_ABLATION_BUILD
@@ -167,6 +168,43 @@ int ttsmi_dense_chain_pack(const uint16_t* wo_t, const uint16_t* w1_t, const uin
     const long total = (long)p.nstages * CH_STAGE_FRAGS * 64;
     hipLaunchKernelGGL(dense_chain16_pack_kernel, dim3(ttsmi_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
     TTSMI_CHECK_LAUNCH("dense_chain_pack");
+    return TTSMI_OK;
+}
+
+/* n weight streams in one launch (ttsmi_chain_pack_job: a forward stream = ttsmi_dense_chain_pack's operands, a backward
+ * stream = ttsmi_dense_chain_bwd_pack's); same bytes as the single calls */
+int ttsmi_dense_chain_pack_batched(const ttsmi_chain_pack_job* jobs, int n, ttsmi_stream_t stream) {
+    TTSMI_CHECK_ARG(jobs && n > 0, "dense_chain_pack_batched: bad job list");
+    for (int i0 = 0; i0 < n; i0 += C16_PACK_MAX_JOBS) {
+        const int m = n - i0 < C16_PACK_MAX_JOBS ? n - i0 : C16_PACK_MAX_JOBS;
+        ChainPackJobs J;
+        memset(&J, 0, sizeof(J));
+        long most = 0;
+        for (int i = 0; i < m; ++i) {
+            const ttsmi_chain_pack_job* q = &jobs[i0 + i];
+            ChainPackP& p = J.job[i];
+            TTSMI_CHECK_ARG(q->w1 && q->w2 && q->wo && q->out, "dense_chain_pack_batched: job %d: null pointer", i0 + i);
+            TTSMI_CHECK_ARG(q->F > 0 && q->F % 64 == 0, "dense_chain_pack_batched: job %d: F must be a multiple of 64 (got %d)", i0 + i, q->F);
+            TTSMI_CHECK_ARG(((((uintptr_t)q->wo) | ((uintptr_t)q->w1) | ((uintptr_t)q->w2) | ((uintptr_t)q->wqkv_next)) & 7) == 0 &&
+                                (((uintptr_t)q->out) & 15) == 0,
+                            "dense_chain_pack_batched: job %d: operands must be 8-byte (output: 16-byte) aligned", i0 + i);
+            if (q->backward) {           // (ttsmi_dense_chain_bwd_pack: the forward packer's roles with the matrices as stored)
+                TTSMI_CHECK_ARG(q->out_bytes >= ttsmi_dense_chain_bwd_pack_bytes(q->F), "dense_chain_pack_batched: job %d: output buffer too small", i0 + i);
+                p.wo_t = nullptr; p.w1_t = q->w2; p.w2_t = q->w1; p.wqkv_t = q->wo + (long)CH_D * CH_D;
+                p.nstages = chain_bwd_stages(q->F); p.wo_stages = 0;
+            } else {
+                TTSMI_CHECK_ARG(q->out_bytes >= ttsmi_dense_chain_pack_bytes(q->F, q->wqkv_next != nullptr),
+                                "dense_chain_pack_batched: job %d: output buffer too small", i0 + i);
+                p.wo_t = q->wo; p.w1_t = q->w1; p.w2_t = q->w2; p.wqkv_t = q->wqkv_next;
+                p.nstages = chain_stages(q->F, q->wqkv_next != nullptr); p.wo_stages = CH_WO_STAGES;
+            }
+            p.out = (uint16_t*)q->out; p.F = q->F; p.nchunk = q->F / 64;
+            const long total = (long)p.nstages * CH_STAGE_FRAGS * 64;
+            most = total > most ? total : most;
+        }
+        hipLaunchKernelGGL(dense_chain16_pack_jobs_kernel, dim3(ttsmi_cdiv(most, 256), m), dim3(256), 0, (hipStream_t)stream, J);
+        TTSMI_CHECK_LAUNCH("dense_chain_pack_batched");
+    }
     return TTSMI_OK;
 }
 
@@ -231,7 +269,6 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
 }
 
 // ---- backward chain (chain16b.h) -----------------------------------------------------------------------------------
-static int chain_bwd_stages(int F) { return 2 * (F / 64) + C16B_CTX_STAGES; }
 
 size_t ttsmi_dense_chain_bwd_pack_bytes(int F) { return F > 0 && F % 64 == 0 ? (size_t)chain_bwd_stages(F) * CH_STAGE_BYTES : 0; }
 

@@ -462,7 +462,7 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
 }
 
 // the weight stream of this form: fragment = 16 output features x one 32-wide k-block, slot (kg, e) = k 16 (e >> 2) + 4 kg + (e & 3)
-__global__ __launch_bounds__(256) void dense_chain16_pack_kernel(ChainPackP p) {
+__device__ __forceinline__ void c16_pack_body(const ChainPackP& p) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)p.nstages * CH_STAGE_FRAGS * 64;
     if (idx >= total) return;
@@ -492,3 +492,8 @@ __global__ __launch_bounds__(256) void dense_chain16_pack_kernel(ChainPackP p) {
     const uint2 lo = *reinterpret_cast<const uint2*>(r), hi = *reinterpret_cast<const uint2*>(r + 16);
     *reinterpret_cast<uint4*>(p.out + idx * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
+__global__ __launch_bounds__(256) void dense_chain16_pack_kernel(ChainPackP p) { c16_pack_body(p); }
+// several weight streams in one launch (a train step repacks 24 of them after every optimiser update): blockIdx.y = job
+#define C16_PACK_MAX_JOBS 32
+struct ChainPackJobs { ChainPackP job[C16_PACK_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void dense_chain16_pack_jobs_kernel(ChainPackJobs J) { c16_pack_body(J.job[blockIdx.y]); }

@@ -115,6 +115,8 @@ int ttsmi_hattention_fwd_split(const void* qkv, const uint8_t* key_pad, const in
 size_t ttsmi_hattention_dropmask_bytes(int B, int H, int T);
 int ttsmi_hattention_dropmask(void* mask, int B, int H, int T, float p_drop, uint64_t seed, const int64_t* step_dev,
                               uint32_t site, hipStream_t st);
+int ttsmi_hattention_dropmask_stack(void* const* masks, const uint32_t* sites, int n, int B, int H, int T, float p_drop,
+                                    uint64_t seed, const int64_t* step_dev, hipStream_t st);
 
 // weight-stationary K = 256 GEMM (gemm_k256.hip), reached through ttsmi_hgemm_tn
 extern "C" int ttsmi_hgemm_k256_eligible(int M, int N, int K);

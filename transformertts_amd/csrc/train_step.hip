@@ -116,6 +116,24 @@ static int check_step(const ttsmi_ft_step* S) {
 
 // keep-bit tables (ttsmi_attention_dropmask) and chain weight streams of a stack, on the side stream
 static int side_prepare_stack(const ttsmi_ft_step* S, const ttsmi_dense_block* const* blk, int n) {
+    // one launch per stack when its layers share shape and rate (they do: one stack = one (B, T), one dropout rate)
+    void* masks[TTSMI_FT_MAX_BLOCKS];
+    uint32_t sites[TTSMI_FT_MAX_BLOCKS];
+    int m = 0;
+    bool same = n <= TTSMI_FT_MAX_BLOCKS;
+    for (int i = 0; i < n && same; ++i) {
+        const ttsmi_dense_block* D = blk[i];
+        if (!(D->dropmask && D->rate > 0.f)) continue;
+        same = D->B == blk[0]->B && D->H == blk[0]->H && D->T == blk[0]->T && D->rate == blk[0]->rate && D->seed == blk[0]->seed &&
+               D->step_dev == blk[0]->step_dev && blk[0]->dropmask && blk[0]->rate > 0.f;
+        masks[m] = (void*)D->dropmask;
+        sites[m++] = D->site_attn;
+    }
+    if (same) {
+        if (m == 0) return TTSMI_OK;
+        return ttsmi_attention_dropmask_stack(masks, sites, m, blk[0]->B, blk[0]->H, blk[0]->T, blk[0]->rate, blk[0]->seed,
+                                              blk[0]->step_dev, S->side_stream);
+    }
     for (int i = 0; i < n; ++i) {
         const ttsmi_dense_block* D = blk[i];
         if (D->dropmask && D->rate > 0.f)
@@ -123,16 +141,27 @@ static int side_prepare_stack(const ttsmi_ft_step* S, const ttsmi_dense_block* c
     }
     return TTSMI_OK;
 }
-static int side_pack_stack(const ttsmi_ft_step* S, const ttsmi_dense_block* const* blk, int n) {
-    for (int i = 0; i < n; ++i) {
-        const ttsmi_dense_block* D = blk[i];
-        if (!D->chain_w) continue;
-        TRY(ttsmi_dense_chain_pack(D->wo_t, D->w1_t, D->w2_t, D->above ? D->above->wqkv_t : nullptr, D->F, (void*)D->chain_w,
-                                   D->chain_w_bytes, S->side_stream));
-        if (D->chain_bw)
-            TRY(ttsmi_dense_chain_bwd_pack(D->w1_b, D->w2_b, D->wo_b, D->F, (void*)D->chain_bw, D->chain_bw_bytes, S->side_stream));
+// both stacks' chain weight streams (forward and backward: 24 at the benchmark's 6 + 6 blocks) as one launch
+static int side_pack_stacks(const ttsmi_ft_step* S) {
+    ttsmi_chain_pack_job jobs[4 * TTSMI_FT_MAX_BLOCKS];
+    int m = 0;
+    for (int s = 0; s < 2; ++s) {
+        const ttsmi_dense_block* const* blk = s ? S->dec : S->enc;
+        const int n = s ? S->n_dec : S->n_enc;
+        for (int i = 0; i < n; ++i) {
+            const ttsmi_dense_block* D = blk[i];
+            if (!D->chain_w) continue;
+            ttsmi_chain_pack_job* q = &jobs[m++];
+            q->wo = D->wo_t; q->w1 = D->w1_t; q->w2 = D->w2_t; q->wqkv_next = D->above ? D->above->wqkv_t : nullptr;
+            q->out = (void*)D->chain_w; q->out_bytes = D->chain_w_bytes; q->F = D->F; q->backward = 0;
+            if (D->chain_bw) {
+                q = &jobs[m++];
+                q->wo = D->wo_b; q->w1 = D->w1_b; q->w2 = D->w2_b; q->wqkv_next = nullptr;
+                q->out = (void*)D->chain_bw; q->out_bytes = D->chain_bw_bytes; q->F = D->F; q->backward = 1;
+            }
+        }
     }
-    return TTSMI_OK;
+    return m ? ttsmi_dense_chain_pack_batched(jobs, m, S->side_stream) : TTSMI_OK;
 }
 
 // ---- StatPredictor (model/layers.py:481-485, 510-524): ops.StatPredictorFn's launches ---------------------------------
@@ -227,8 +256,7 @@ static int phase0(const ttsmi_ft_step* S) {
     TRY(ev_wait(S->ev[EV_STEP_START], sd, "step start"));
     TRY(side_prepare_stack(S, S->enc, S->n_enc));
     if (S->pack_now) {             // the weight streams were not packed ahead by the previous step's phase 2 (first step, new binding)
-        TRY(side_pack_stack(S, S->enc, S->n_enc));
-        TRY(side_pack_stack(S, S->dec, S->n_dec));
+        TRY(side_pack_stacks(S));
     }
     TRY(ev_record(S->ev[EV_MASK_ENC], sd, "encoder tables"));
     TRY(side_prepare_stack(S, S->dec, S->n_dec));
@@ -335,8 +363,7 @@ static int phase2(const ttsmi_ft_step* S) {
         // launches that the next step's start does not have to enqueue in front of its first kernel (the same blocks, the
         // same chain links: the host clears pack_now for the next step only when that holds)
         TRY(hand_off(S->ev[EV_PACK_START], mn, S->side_stream, "bf16 shadows"));
-        TRY(side_pack_stack(S, S->enc, S->n_enc));
-        TRY(side_pack_stack(S, S->dec, S->n_dec));
+        TRY(side_pack_stacks(S));
         TRY(ev_record(S->ev[EV_PACK], S->side_stream, "chain weight streams"));
     }
     return TTSMI_OK;
