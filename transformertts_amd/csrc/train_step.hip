@@ -355,17 +355,18 @@ static int phase2(const ttsmi_ft_step* S) {
                       S->flat_bf16, mn));                               // utils/training_config_manager.py:102-106
     if (S->tr_desc && S->tr_n > 0)
         TRY(ttsmi_cast_transpose_bf16_batched((const ttsmi_transpose_desc*)S->tr_desc, S->tr_n, S->tr_tiles, mn));
-    for (int i = 0; i < S->n_conv_wd; ++i)
-        TRY(ttsmi_conv_wdgrad_layout_bf16(S->conv_w[i], S->conv_wd[i], S->conv_k[i], S->conv_cin[i], S->conv_cout[i],
-                                          (S->conv_cout[i] + 7) / 8 * 8, mn));
     if (S->pack_ahead) {
-        // the chain kernels' weight streams of the NEXT step, packed from the shadows just written, on the side stream: 24
-        // launches that the next step's start does not have to enqueue in front of its first kernel (the same blocks, the
-        // same chain links: the host clears pack_now for the next step only when that holds)
+        // the chain kernels' weight streams of the NEXT step, packed from the shadows just written, on the side stream (one
+        // launch, beside the predictors' layout kernels below), so that the next step's start does not have to enqueue
+        // them in front of its first kernel (the same blocks, the same chain links: the host clears pack_now for the
+        // next step only when that holds)
         TRY(hand_off(S->ev[EV_PACK_START], mn, S->side_stream, "bf16 shadows"));
         TRY(side_pack_stacks(S));
         TRY(ev_record(S->ev[EV_PACK], S->side_stream, "chain weight streams"));
     }
+    for (int i = 0; i < S->n_conv_wd; ++i)
+        TRY(ttsmi_conv_wdgrad_layout_bf16(S->conv_w[i], S->conv_wd[i], S->conv_k[i], S->conv_cin[i], S->conv_cout[i],
+                                          (S->conv_cout[i] + 7) / 8 * 8, mn));
     return TTSMI_OK;
 }
 
