@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(WRowsP p) {
 // =================================================================================================
 // LDS-DMA variant of the row-major wgrad (both operands bf16, no conv window, rows % 32 == 0,
 // K_in % 128 == 0, N % 128 == 0): the 32-row tiles of X and dY arrive by global_load_lds_dwordx4 into a
-// THREE-stage ring (48 KB), two steps in flight while one is multiplied.  The register-staged kernel
+// WD_STAGES-stage ring (four: 64 KB), WD_STAGES - 1 steps in flight while one is multiplied.  The register-staged kernel
 // above completes one step per memory round trip (its 24 KB of loads are issued after the barrier and
 // needed at the next one: ~1.3 us per step measured, 57 steps for the FFN weights); here a step costs its
 // MFMAs and transposing reads.  The DMA image is dense (256-byte rows), which would put the 4 rows a
@@ -1103,9 +1103,13 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(WRowsP p) {
 // chunk position c ^ ((r & 3) << 2) (load side, free), and the reads XOR their 8-byte unit index with
 // (r & 3) << 3: the 32 lanes of a read phase then cover 32 distinct units = all 64 banks.
 // vmcnt bookkeeping: a wave issues exactly 4 DMA instructions per step and nothing else on the vector
-// memory counter inside the loop, so "vmcnt(4)" = the previous step has landed, the newest may be in flight.
+// memory counter inside the loop, so "vmcnt(4 j)" = everything but the newest j steps has landed.
 // =================================================================================================
-#define WD_STAGES 3
+// (round 6: FOUR stages, 64 KB - three steps in flight: 66 -> 59 us alone at 28 800 x 1024 x 256, 4.52 -> 4.49 ms per step; a
+// fifth stage leaves one workgroup per CU and gives it all back: profiles/r06_wgrad_ring_ab.txt.  -DWD_STAGES=3/5: variants)
+#ifndef WD_STAGES
+#define WD_STAGES 4
+#endif
 #define WD_STAGE_BYTES (2 * WR_ROWS * 256)        // X image then dY image, [32 rows][128 bf16]
 
 __device__ __forceinline__ bf16x8 wd_tr8(const unsigned char* img, int row, int unit) {
@@ -1192,18 +1196,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WRowsP p) {
     // 8-byte unit = column / 4
     const int trow = (lane >> 5) * 8 + ((lane & 15) >> 2);
     const int tunit = ((lane >> 4) & 1) * 4 + (lane & 3);
-    if (nsteps > 0) issue(0, 0);
-    if (nsteps > 1) issue(1, 1);
+#pragma unroll
+    for (int s_ = 0; s_ < WD_STAGES - 1; ++s_)
+        if (s_ < nsteps) issue(s_, s_);
     auto run = [&](auto colsum_tag) {
         constexpr bool kColsum = decltype(colsum_tag)::value;
         for (int s_ = 0; s_ < nsteps; ++s_) {
             // step s_ has landed once at most the newest step's 4 DMA instructions are still outstanding
-            if (s_ + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0xF74);      // vmcnt(4), expcnt/lgkmcnt untouched
+            // (s_waitcnt imm: vmcnt = bits 3:0 (+ 15:14), expcnt / lgkmcnt untouched)
+            if (WD_STAGES > 4 && s_ + 3 < nsteps) __builtin_amdgcn_s_waitcnt(0xF7C);   // vmcnt(12): three newer steps may be in flight
+            else if (WD_STAGES > 3 && s_ + 2 < nsteps) __builtin_amdgcn_s_waitcnt(0xF78);   // vmcnt(8): two
+            else if (s_ + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0xF74);      // vmcnt(4)
             else __builtin_amdgcn_s_waitcnt(0xF70);                      // vmcnt(0)
             // not __syncthreads(): its fence is vmcnt(0), which would also wait for the step that was just put in
             // flight.  Everybody's pieces of this step have landed; stage (s_-1)%3 is retired (its reads returned)
             lds_stage_barrier();
-            if (s_ + 2 < nsteps) issue(s_ + 2, (s_ + 2) % WD_STAGES);
+            if (s_ + WD_STAGES - 1 < nsteps) issue(s_ + WD_STAGES - 1, (s_ + WD_STAGES - 1) % WD_STAGES);
             const unsigned char* Xi = smem + (s_ % WD_STAGES) * WD_STAGE_BYTES;
             const unsigned char* Yi = Xi + WR_ROWS * 256;
 #pragma unroll
