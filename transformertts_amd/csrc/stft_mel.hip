@@ -93,27 +93,45 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
     // the top, so "one lane per filter" leaves most of the wave idle behind the widest filter.  Filters
     // are cut into work items of at most MEL_IT weights (about 105 items for the LJSpeech bank); a lane
     // sums one item per round, a second short pass adds the (<= 4) partial sums of each filter.
-    __shared__ int itLo[MEL_ITEMS], itFirst[MELS_MAX + 1];
+    // (the item tables that only the set-up reads - where an item's magnitudes start, its place in its filter, the filters'
+    // first slots - live behind the filterbank copy in the exchange buffers; every lane keeps its own entries in registers)
+    static_assert(sizeof(float) * MELW_MAX + sizeof(int) * (3 * MELS_MAX + 2 * MEL_ITEMS + MELS_MAX + 2) <= sizeof(buf), "the set-up tables live in buf");
+    int* itLo = melptrS + MELS_MAX;
+    int* itMeta = itLo + MEL_ITEMS;
+    int* itFirst = itMeta + MEL_ITEMS;
+    int& itMaxN = itFirst[MELS_MAX + 1];
     __shared__ __attribute__((aligned(16))) float itWt[MEL_ITEMS][MEL_IT];   // zero-padded: fixed trip count
-    static_assert(sizeof(float) * MEL_ITEMS <= sizeof(buf[0][0]), "a wave's partial sums live in its exchange buffer");
+    // Round 6: a filter's items sit in ADJACENT lanes of one 16-lane DPP row (a filter that would straddle a row starts at the
+    // next one; the skipped slots multiply zeros), so a filter's sum is a segmented scan over row_shr 1 / 2 / 4 in registers and
+    // the lane that holds a filter's LAST item finishes it (clip, log, store).  The partial sums used to go through LDS to a
+    // second sweep - a loop of data-dependent length over them, two more table reads per filter and a wave fence: ~100 of a
+    // frame's ~750 instructions.  itMeta: bits 0-7 = the item's index within its filter, bits 8.. = filter + 1 on its last item.
+    for (int i = tid; i < MEL_ITEMS * MEL_IT; i += 256) (&itWt[0][0])[i] = 0.f;
+    for (int i = tid; i < MEL_ITEMS; i += 256) { itLo[i] = 0; itMeta[i] = 0; }
     if (mel_in_lds) {
         if (tid == 0) {
             // an item starts at a multiple of 4 bins (the filter's first bin rounded down, zero weights in front): its
             // magnitudes are read as three aligned float4 instead of twelve scalars
-            int acc = 0;
+            int acc = 0, most = 0;
             for (int m = 0; m < p.n_mels; ++m) {
+                const int n = ((melloS[m] & 3) + melcntS[m] + MEL_IT - 1) / MEL_IT;
+                if ((acc & 15) + n > 16) acc = (acc + 15) & ~15;
                 itFirst[m] = acc;
-                acc += ((melloS[m] & 3) + melcntS[m] + MEL_IT - 1) / MEL_IT;
+                acc += n;
+                most = n > most ? n : most;
             }
             itFirst[p.n_mels] = acc;
+            itMaxN = most;
         }
         __syncthreads();
-        if (itFirst[p.n_mels] <= MEL_ITEMS) {
+        if (itFirst[p.n_mels] <= MEL_ITEMS && itMaxN <= 8) {
             for (int m = tid; m < p.n_mels; m += 256) {
-                const int first = itFirst[m], n = itFirst[m + 1] - first;
+                const int first = itFirst[m];
                 const int lead = melloS[m] & 3, lo4 = melloS[m] - lead;
+                const int n = (lead + melcntS[m] + MEL_IT - 1) / MEL_IT;
                 for (int j = 0; j < n; ++j) {
                     itLo[first + j] = lo4 + j * MEL_IT;
+                    itMeta[first + j] = j | (j == n - 1 ? (m + 1) << 8 : 0);
                     for (int i = 0; i < MEL_IT; ++i) {
                         const int wi = j * MEL_IT + i - lead;                   // index into the filter's weights
                         itWt[first + j][i] = (wi >= 0 && wi < melcntS[m]) ? melwS[melptrS[m] + wi] : 0.f;
@@ -123,8 +141,16 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
         }
         __syncthreads();
     }
-    const int n_items = mel_in_lds ? itFirst[p.n_mels] : 0;
-    const bool mel_items = mel_in_lds && n_items <= MEL_ITEMS;
+    const int n_items = mel_in_lds ? itFirst[p.n_mels] : 0;          // item slots, row padding included
+    const bool mel_items = mel_in_lds && n_items <= MEL_ITEMS && itMaxN <= 8;
+    // the lane's item of every round never changes: where its magnitudes start, its place in its filter
+    constexpr int MEL_ROUNDS = MEL_ITEMS / 64;
+    int it_lo[MEL_ROUNDS], it_meta[MEL_ROUNDS];
+#pragma unroll
+    for (int rd = 0; rd < MEL_ROUNDS; ++rd) {
+        it_lo[rd] = mel_items ? itLo[(tid & 63) + 64 * rd] : 0;
+        it_meta[rd] = mel_items ? itMeta[(tid & 63) + 64 * rd] : 0;
+    }
     // last bin any filter reads (filters are stored in ascending order of their first bin; without the LDS copy: all)
     int bin_hi = NC;
     if (mel_in_lds) {
@@ -260,17 +286,23 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
         }
         WAVE_SYNC();
         // ---- sparse mel + normalisation ---------------------------------------------------------
+        auto finish = [&](float sum) -> float {
+            if (p.normalizer == 0) return __logf(fmaxf(sum, p.clip_min));   // v_log_f32 (1 ulp in log2) x ln 2; the argument is >= clip_min > 0
+            const float db = 20.f * log10f(fmaxf(1e-5f, sum));
+            const float nz = fminf(fmaxf((db + 100.f) / 100.f, 0.f), 1.f);
+            return nz * 8.f - 4.f;
+        };
         if (mel_items && !(TTSMI_ABLATE_BITS(p.ablate) & 2)) {
-            float* part = reinterpret_cast<float*>(buf[wave][0]);      // (the transform's values have been consumed)
             // The products are formed as PAIRS along the weight index (v_pk_fma_f32 on the two halves of each 16-byte read):
             // written with four scalar accumulators, hipcc's SLP pass paired the SAME accumulator of two loop iterations
             // instead and spent 36 v_mov_b32 per 12 packed FMAs shuffling the operands together (ISA reading, round 4).
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
             typedef float f32x4_t __attribute__((ext_vector_type(4)));
-#pragma clang loop unroll(disable)
-            for (int it = lane; it < n_items; it += 64) {
-                const f32x4_t* w4 = reinterpret_cast<const f32x4_t*>(itWt[it]);
-                const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(mg + itLo[it]);   // 16-byte aligned; may run past the filter: zero weights
+#pragma unroll
+            for (int rd = 0; rd < MEL_ROUNDS; ++rd) {
+                if (64 * rd >= n_items) break;                                  // wave-uniform
+                const f32x4_t* w4 = reinterpret_cast<const f32x4_t*>(itWt[lane + 64 * rd]);
+                const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(mg + it_lo[rd]);   // 16-byte aligned; may run past the filter: zero weights
                 f32x2_t a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < MEL_IT / 4; ++i) {
@@ -279,29 +311,27 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
                     a1 += w.zw * x.zw;
                 }
                 a0 += a1;
-                part[it] = a0.x + a0.y;
+                float a = a0.x + a0.y;
+                // segmented inclusive scan over the filter's (<= 8) adjacent items: row_shr never leaves the 16-lane row, and
+                // an item adds its d-th left neighbour only when that one belongs to the same filter
+                const int pos = it_meta[rd] & 0xFF, mel = (it_meta[rd] >> 8) - 1;
+                float v = ttsmi_dpp<0x111, 0xF>(a, 0.f);
+                a += pos >= 1 ? v : 0.f;
+                v = ttsmi_dpp<0x112, 0xF>(a, 0.f);
+                a += pos >= 2 ? v : 0.f;
+                v = ttsmi_dpp<0x114, 0xF>(a, 0.f);
+                a += pos >= 4 ? v : 0.f;
+                if (mel >= 0 && active) p.out[f * p.n_mels + mel] = finish(a);
+                __builtin_amdgcn_sched_barrier(0);                              // one round's twelve reads in flight at a time
             }
-            WAVE_SYNC();
-        }
-        for (int m = lane; m < p.n_mels && !(TTSMI_ABLATE_BITS(p.ablate) & 2); m += 64) {
-            float s = 0.f;
-            if (mel_items) {
-                const float* part = reinterpret_cast<const float*>(buf[wave][0]);
-                for (int j = itFirst[m]; j < itFirst[m + 1]; ++j) s += part[j];
-            } else {                                  // a bank beyond the item table: straight from global memory
+        } else if (!(TTSMI_ABLATE_BITS(p.ablate) & 2)) {
+            for (int m = lane; m < p.n_mels; m += 64) {   // a bank beyond the item table: straight from global memory
                 const int lo = p.mel_lo[m], cnt = p.mel_cnt[m];
                 const float* w = p.mel_w + p.mel_ptr[m];
-                for (int i = 0; i < cnt; ++i) s += w[i] * mg[lo + i];
+                float sum = 0.f;
+                for (int i = 0; i < cnt; ++i) sum += w[i] * mg[lo + i];
+                if (active) p.out[f * p.n_mels + m] = finish(sum);
             }
-            float o;
-            if (p.normalizer == 0) {
-                o = __logf(fmaxf(s, p.clip_min));            // v_log_f32 (1 ulp in log2) x ln 2; the argument is >= clip_min > 0
-            } else {
-                float db = 20.f * log10f(fmaxf(1e-5f, s));
-                float nz = fminf(fmaxf((db + 100.f) / 100.f, 0.f), 1.f);
-                o = nz * 8.f - 4.f;
-            }
-            if (active) p.out[f * p.n_mels + m] = o;
         }
         WAVE_SYNC();
     }
