@@ -85,7 +85,8 @@ __device__ __forceinline__ void fft8(float2 (&u)[8]) {
 // One 512-point complex FFT of the values u[r] = z[lane + 64 r] (three radix-8 Stockham passes, two
 // exchanges through the wave-private buffer zb); the result is left in natural order in zb[ZP(k)].
 // tw is the table exp(-2 pi i k / N); TS = N / 512 scales a 512-point twiddle index into it.
-template <int N>
+// TO_LDS = false: the last pass's results stay in registers instead - u[rev3(r)] = Z[lane + 64 r] (no third exchange).
+template <int N, bool TO_LDS = true>
 __device__ __forceinline__ void fft512(float2 (&u)[8], float2* zb, const float2* tw, int lane, bool full) {
     constexpr int TS = N / SUBN;
     const int rev[8] = {0, 4, 2, 6, 1, 5, 3, 7};
@@ -121,8 +122,10 @@ __device__ __forceinline__ void fft512(float2 (&u)[8], float2* zb, const float2*
         }
         WAVE_SYNC();
         fft8(u);
+        if constexpr (TO_LDS) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) zb[ZP(k + r * 64)] = u[rev[r]];
+            for (int r = 0; r < 8; ++r) zb[ZP(k + r * 64)] = u[rev[r]];
+        }
     }
     WAVE_SYNC();
 }

@@ -9,8 +9,11 @@
 // per pass, the two inter-pass exchanges go through a per-wave 4 KB LDS buffer, twiddles come from
 // an LDS table of exp(-2 pi i k / 1024) built once per workgroup with sincospi.  The magnitude
 // spectrum (513 bins) stays in LDS; the mel filterbank is applied in its sparse form (each filter
-// is one contiguous run of bins, 727 non-zeros for the LJSpeech setting) and the [frames, n_mels]
-// output row is written with one coalesced store.  HBM traffic: every sample is fetched ~once
+// is one contiguous run of bins, 727 non-zeros for the LJSpeech setting).  Round 6 (1 447 -> 1 610 GB/s on one box,
+// profiles/r06_mel_scan_bpermute_ab.txt): the n_fft = 1024 transform's last pass stays in registers and the real-FFT
+// post-processing fetches each mirror bin from its partner lane (ds_bpermute) instead of a third exchange through LDS; a
+// filter's <= 8 work items sit in adjacent lanes and are summed by a segmented DPP scan, the lane with a filter's last item
+// writes its output (the second sweep over partial sums in LDS is gone); the factor 1/2 of |X| lives in the weights.  HBM traffic: every sample is fetched ~once
 // (the 4x frame overlap is served by L2 because consecutive frames run in the same workgroup),
 // 4*n_mels bytes written per frame.
 #include <stdlib.h>
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
                     itMeta[first + j] = j | (j == n - 1 ? (m + 1) << 8 : 0);
                     for (int i = 0; i < MEL_IT; ++i) {
                         const int wi = j * MEL_IT + i - lead;                   // index into the filter's weights
-                        itWt[first + j][i] = (wi >= 0 && wi < melcntS[m]) ? melwS[melptrS[m] + wi] : 0.f;
+                        itWt[first + j][i] = (wi >= 0 && wi < melcntS[m]) ? 0.5f * melwS[melptrS[m] + wi] : 0.f;   // (x 1/2: mag holds 2 |X|)
                     }
                 }
             }
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
         if (g + 1 < p.groups_per_wg) prefetch_frame(f + FR_PER_WG, xs);
         const bool full = !(TTSMI_ABLATE_BITS(p.ablate) & 4);
         if constexpr (NSUB == 1) {
-            fft512<NC>(w, zb, tw, lane, full);             // Z[k] in zb[ZP(k)]
+            fft512<NC, false>(w, zb, tw, lane, full);      // Z[lane + 64 r] in w[rev3(r)]
         } else {
             // radix-2 DIF stage in registers: z[n] and z[n + 512] sit in the same lane (r and r + 8);
             //   even bins Z[2k]   = FFT512(z[n] + z[n+512])
@@ -265,24 +268,40 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
         // (v_sqrt_f32 is accurate to 1 ulp; the library sqrtf adds a denormal rescale and a correctly-rounded fix-up -
         // ~15 instructions each, 10 square roots per lane and frame were a sixth of the kernel's VALU work.  Bins above
         // the highest filter's last bin - 371 of 512 for the LJSpeech bank - feed nothing: their mirror is skipped.)
+        // NSUB == 1 (round 6): the transform's last pass leaves Z[lane + 64 r] in the lane's registers, and the mirror of
+        // bin lane + 64 r is register 7 - r of lane 64 - lane: one cross-lane read (ds_bpermute, no LDS bytes) per component
+        // instead of eight 8-byte stores, a fence and eight loads.  Lane 0 is its own partner with the registers shifted by
+        // one (the mirror of bin 64 r is bin 64 (8 - r)): two selects per round.
+        const int rev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+        const int partner = ((64 - lane) & 63) << 2;
 #pragma unroll
         for (int it = 0; it < NC / 128; ++it) {                 // k = 0 .. NC/2 - 1 in full waves; k = NC/2 below
             if (TTSMI_ABLATE_BITS(p.ablate) & 8) break;
             const int k = lane + 64 * it;
-            float2 zk = Z(k);
-            float2 zc = Z((NC - k) & (NC - 1));
+            float2 zk, zc;
+            if constexpr (NSUB == 1) {
+                zk = w[rev3[it]];
+                const float2 src = w[rev3[7 - it]], own = w[rev3[(8 - it) & 7]];
+                zc.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, src.x)));
+                zc.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, src.y)));
+                zc.x = lane == 0 ? own.x : zc.x;
+                zc.y = lane == 0 ? own.y : zc.y;
+            } else {
+                zk = Z(k);
+                zc = Z((NC - k) & (NC - 1));
+            }
             zc.y = -zc.y;
             float2 e = cadd(zk, zc), o = csub(zk, zc);
             float2 wo = cmul(NSUB == 1 ? twp[k] : tw[k], o);
             float xr = e.x + wo.y, xi = e.y - wo.x;            // 2 X[k]
-            mg[k] = 0.5f * __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+            mg[k] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);          // 2 |X[k]|: the exact factor 1/2 lives in the filter weights
             if (NC - 64 * it - 63 > bin_hi + MEL_IT) continue;  // wave-uniform: no mirror bin of this round is read (they stay 0)
             float yr = e.x - wo.y, yi = e.y + wo.x;            // 2 conj-mirrored X[NC-k]
-            mg[NC - k] = 0.5f * __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
+            mg[NC - k] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
         }
         if (lane == 0 && !(TTSMI_ABLATE_BITS(p.ablate) & 8)) {                    // k = NC/2 is its own mirror: X = conj(Z)
-            const float2 zh = Z(NC / 2);
-            mg[NC / 2] = __builtin_amdgcn_sqrtf(zh.x * zh.x + zh.y * zh.y);
+            const float2 zh = NSUB == 1 ? w[rev3[(NC / 128) & 7]] : Z(NC / 2);      // (NSUB == 1: lane 0's register 4 = Z[256])
+            mg[NC / 2] = 2.f * __builtin_amdgcn_sqrtf(zh.x * zh.x + zh.y * zh.y);
         }
         WAVE_SYNC();
         // ---- sparse mel + normalisation ---------------------------------------------------------
@@ -330,7 +349,7 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
                 const float* w = p.mel_w + p.mel_ptr[m];
                 float sum = 0.f;
                 for (int i = 0; i < cnt; ++i) sum += w[i] * mg[lo + i];
-                if (active) p.out[f * p.n_mels + m] = finish(sum);
+                if (active) p.out[f * p.n_mels + m] = finish(0.5f * sum);
             }
         }
         WAVE_SYNC();
