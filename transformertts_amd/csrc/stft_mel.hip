@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
     // reflection when they are consumed.  (Round 1/2 chose between the two patterns in the prefetch: the merge of the two
     // paths copied the loaded registers, i.e. `s_waitcnt vmcnt(0)` right behind the prefetch - nothing overlapped.)
     const long total_samples = p.clip_off[p.n_clips];
+    const bool can_prefetch = total_samples >= NFFT;          // (always, except on toy inputs)
     struct Pending { bool act, interior; long base; int L, start; } nx = {false, true, 0, 1, 0};
     auto prefetch_frame = [&](long f, float2 (&x)[PPL]) {
         nx.act = (f < p.total_frames) && !(TTSMI_ABLATE_BITS(p.ablate) & 1);
@@ -201,14 +202,16 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
             t = (int)(f - cur_f0);
         }
         nx.start = t * p.hop - NFFT / 2;
-        nx.interior = nx.act && nx.start >= 0 && nx.start + NFFT <= nx.L && total_samples >= NFFT;
-        if (total_samples >= NFFT) {                      // (always, except on toy inputs)
-            long s0 = nx.base + nx.start;
-            s0 = s0 < 0 ? 0 : (s0 > total_samples - NFFT ? total_samples - NFFT : s0);
-            const float* src = p.wav + s0 + 2 * lane;
+        nx.interior = nx.act && nx.start >= 0 && nx.start + NFFT <= nx.L && can_prefetch;
+        // UNCONDITIONAL loads (round 6): under `if (total_samples >= NFFT)` and `if (g + 1 < groups)` the prefetched
+        // registers were a phi of "loaded" and "kept" - 16 v_mov_b64 per frame around the loads (ISA reading).  A toy input
+        // shorter than one frame prefetches from the window table instead (n_fft floats, always there) and loads every
+        // frame in fix_frame.
+        long s0 = nx.base + nx.start;
+        s0 = s0 < 0 ? 0 : (s0 > total_samples - NFFT ? total_samples - NFFT : s0);
+        const float* src = (can_prefetch ? p.wav + s0 : p.window) + 2 * lane;
 #pragma unroll
-            for (int r = 0; r < PPL; ++r) x[r] = make_float2(src[128 * r], src[128 * r + 1]);
-        }
+        for (int r = 0; r < PPL; ++r) x[r] = make_float2(src[128 * r], src[128 * r + 1]);
     };
     // at consumption: an edge frame (or an inactive slot) replaces the speculative prefetch
     auto fix_frame = [&](float2 (&x)[PPL]) {
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256, NFFT == 1024 ? 4 : 1) void stft_logmel_kernel(
         float2 w[PPL];
 #pragma unroll
         for (int r = 0; r < PPL; ++r) w[r] = make_float2(xs[r].x * win[r].x, xs[r].y * win[r].y);
-        if (g + 1 < p.groups_per_wg) prefetch_frame(f + FR_PER_WG, xs);
+        prefetch_frame(f + FR_PER_WG, xs);                 // (past the last group: an inactive frame, a clamped in-bounds address)
         const bool full = !(TTSMI_ABLATE_BITS(p.ablate) & 4);
         if constexpr (NSUB == 1) {
             fft512<NC, false>(w, zb, tw, lane, full);      // Z[lane + 64 r] in w[rev3(r)]
