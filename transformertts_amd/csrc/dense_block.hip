@@ -331,7 +331,8 @@ static int dense_block_bwd_impl(const ttsmi_dense_block* D, const float* h, cons
     // (48 KB) keeps their workgroups off it, while the attention kernels (19 KB, latency bound) share a CU with it
     // (round 6: ONE hand-off per chained block, on the attention backward's last kernel - three kernel-borne hand-offs cost the
     // main queue ~5 us of idle each in the trace - measured 4.567 against 4.534 ms per step, 2.910 against 2.903 on lj-dist:
-    // the later start of the weight gradients costs more than the idle; profiles/r06_one_handoff_per_block_ab.txt; not kept)
+    // the later start of the weight gradients costs more than the idle; TWO hand-offs - W2 behind the backward chain - 4.491 against
+    // 4.479; profiles/r06_one_handoff_per_block_ab.txt; neither kept)
     TTSMI_KNOB(wev, "TTSMI_WGRAD_EVENTS", 4);
     const bool lazy = lazy_wgrad_events();
     const bool pre_attn = wev == 1;
