@@ -82,7 +82,10 @@ def _run_chain(M, F, pdrop, with_qkv, with_out32, with_bits, seed0=0, bits_layou
                                   _p(out['qkv']), _stream()), 'chain')
     torch.cuda.synchronize()
     # (four 16-row waves per workgroup up to 16 384 rows, eight from there on: csrc/chain.hip chain_nw)
-    assert l.ttsmi_last_kernel().decode() == ('dense_chain16_kernel<4 waves>' if M <= 16384 else 'dense_chain16_kernel')
+    forced = os.environ.get('TTSMI_DENSE_CHAIN_NW', '0')              # (A/B knob: then the forced form is what must have run)
+    want = {'4': 'dense_chain16_kernel<4 waves>', '8': 'dense_chain16_kernel'}.get(
+        forced, 'dense_chain16_kernel<4 waves>' if M <= 16384 else 'dense_chain16_kernel')
+    assert l.ttsmi_last_kernel().decode() == want
     inv = 1.0 / (1.0 - float(np.float32(pdrop))) if pdrop > 0 else 1.0
     live = (pad == 0)
     rows, cols = np.arange(M), np.arange(D)
@@ -269,7 +272,7 @@ def test_backward_chain_matches_the_fp64_reference_stage_by_stage(M, pdrop, dres
     dh1, d_o, dctx = e(M, F), e(M, D), e(M, D)
     dres = e(M, D) if dres_bf16 else e(M, D, dt=torch.float32)
     nparts = int(l.ttsmi_dense_chain_bwd_nparts(M))              # one partial row per workgroup: 64-row tiles up to 16 384 rows, 128 above
-    tile = 64 if M <= 16384 else 128
+    tile = {'4': 64, '8': 128}.get(os.environ.get('TTSMI_DENSE_CHAIN_NW', '0'), 64 if M <= 16384 else 128)   # (A/B knob: the forced form)
     assert nparts == (M + tile - 1) // tile
     part = ops._ws(int(l.ttsmi_layernorm_partials_bytes(nparts, D)), DEV)
     check(l.ttsmi_dense_chain_bwd(_p(dev['df']), _p(dev['da']), _p(dev['xh']), _p(dev['rstd']), _p(dev['gam']), _p(dev['pad']), _p(dev['bits']),

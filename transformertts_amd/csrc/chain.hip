@@ -134,10 +134,13 @@ static int chain_nw(int M) {
     return M <= 16384 ? 4 : 8;
 }
 
-// two loader waves beside the four compute waves of the 64-row form (chain16.h: c16_loader_loop); TTSMI_DENSE_CHAIN_LOADERS=0: none (A/B knob)
-static bool chain_loaders() {
-    TTSMI_KNOB(on, "TTSMI_DENSE_CHAIN_LOADERS", 1);
-    return on != 0;
+// loader waves beside the four compute waves of the 64-row form (chain16.h: c16_loader_loop): FOUR by default (two: 45.0 -> 44.3 us
+// alone at 6 400 rows, 4.50 -> 4.48 ms per step, lj-dist 2.91 -> 2.88; a 32-row form of two compute + four loader waves is no
+// faster - 43.4 us, a workgroup's lifetime is its 52 stages of DMA - and was not kept: profiles/r06_chain_loaders4_ab.txt);
+// TTSMI_DENSE_CHAIN_LOADERS = 0 / 2: none / two (A/B knob)
+static int chain_loaders() {
+    TTSMI_KNOB(on, "TTSMI_DENSE_CHAIN_LOADERS", 4);
+    return on == 2 ? 2 : on != 0 ? 4 : 0;
 }
 
 static int chain_bwd_stages(int F) { return 2 * (F / 64) + C16B_CTX_STAGES; }
@@ -250,20 +253,24 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
     p.ablate = ablate;
     p.dbg = g_chain_dbg;
 #endif
-    if (chain_nw(M) == 4) {
+#define CHAIN_FWD_LAUNCH(NW_, NL_)                                                                                              \
+    do {                                                                                                                        \
+        if (out32 != nullptr)                                                                                                   \
+            TTSMI_LAUNCH_EV((dense_chain16_kernel<true, NW_, NL_>), dim3(ttsmi_cdiv(M, 16 * NW_)), dim3(64 * (NW_ + NL_)), 0, (hipStream_t)stream, p); \
+        else                                                                                                                    \
+            TTSMI_LAUNCH_EV((dense_chain16_kernel<false, NW_, NL_>), dim3(ttsmi_cdiv(M, 16 * NW_)), dim3(64 * (NW_ + NL_)), 0, (hipStream_t)stream, p); \
+    } while (0)
+    const int nw = chain_nw(M), nl = chain_loaders();
+    if (nw == 4) {
         ttsmi_note_kernel("dense_chain16_kernel<4 waves>");
-        if (chain_loaders()) {
-            if (out32 != nullptr) TTSMI_LAUNCH_EV((dense_chain16_kernel<true, 4, 2>), dim3(ttsmi_cdiv(M, 64)), dim3(384), 0, (hipStream_t)stream, p);
-            else TTSMI_LAUNCH_EV((dense_chain16_kernel<false, 4, 2>), dim3(ttsmi_cdiv(M, 64)), dim3(384), 0, (hipStream_t)stream, p);
-        } else {
-            if (out32 != nullptr) TTSMI_LAUNCH_EV((dense_chain16_kernel<true, 4>), dim3(ttsmi_cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, p);
-            else TTSMI_LAUNCH_EV((dense_chain16_kernel<false, 4>), dim3(ttsmi_cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, p);
-        }
+        if (nl == 4) CHAIN_FWD_LAUNCH(4, 4);
+        else if (nl == 2) CHAIN_FWD_LAUNCH(4, 2);
+        else CHAIN_FWD_LAUNCH(4, 0);
     } else {
         ttsmi_note_kernel("dense_chain16_kernel");
-        if (out32 != nullptr) TTSMI_LAUNCH_EV((dense_chain16_kernel<true, 8>), dim3(ttsmi_cdiv(M, 128)), dim3(512), 0, (hipStream_t)stream, p);
-        else TTSMI_LAUNCH_EV((dense_chain16_kernel<false, 8>), dim3(ttsmi_cdiv(M, 128)), dim3(512), 0, (hipStream_t)stream, p);
+        CHAIN_FWD_LAUNCH(8, 0);
     }
+#undef CHAIN_FWD_LAUNCH
     TTSMI_CHECK_LAUNCH("dense_chain_fwd");
     return TTSMI_OK;
 }
@@ -321,9 +328,13 @@ int ttsmi_dense_chain_bwd(const uint16_t* df, const uint16_t* da, const uint16_t
     p.seed = seed; p.step_dev = step_dev; p.site = site_ln1;
     p.dh1 = dh1; p.d_o = d_o; p.dctx = dctx; p.dres = dres; p.dres_bf16 = dres_is_bf16 ? 1 : 0; p.part = (float*)part_ws;
     ttsmi_note_kernel("dense_chain16_bwd_kernel");
-    if (chain_nw(M) == 4 && chain_loaders()) TTSMI_LAUNCH_EV((dense_chain16_bwd_kernel<4, 2>), dim3(nparts), dim3(384), 0, (hipStream_t)stream, p);
-    else if (chain_nw(M) == 4) TTSMI_LAUNCH_EV(dense_chain16_bwd_kernel<4>, dim3(nparts), dim3(256), 0, (hipStream_t)stream, p);
-    else TTSMI_LAUNCH_EV(dense_chain16_bwd_kernel<8>, dim3(nparts), dim3(512), 0, (hipStream_t)stream, p);
+#define CHAIN_BWD_LAUNCH(NW_, NL_) TTSMI_LAUNCH_EV((dense_chain16_bwd_kernel<NW_, NL_>), dim3(nparts), dim3(64 * (NW_ + NL_)), 0, (hipStream_t)stream, p)
+    const int nw = chain_nw(M), nl = chain_loaders();
+    if (nw == 4 && nl == 4) CHAIN_BWD_LAUNCH(4, 4);
+    else if (nw == 4 && nl == 2) CHAIN_BWD_LAUNCH(4, 2);
+    else if (nw == 4) CHAIN_BWD_LAUNCH(4, 0);
+    else CHAIN_BWD_LAUNCH(8, 0);
+#undef CHAIN_BWD_LAUNCH
     TTSMI_CHECK_LAUNCH("dense_chain_bwd");
     return TTSMI_OK;
 }

@@ -257,7 +257,7 @@ __device__ __forceinline__ void c16_loader_loop(const unsigned char* wpack, unsi
 }
 
 template <bool Y32, int NW, int NL = 0>
-__global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_eu(NW / 4, (NW + NL + 3) / 4))) void dense_chain16_kernel(ChainP p) {
+__global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_eu((NW + 3) / 4, (NW + NL + 3) / 4))) void dense_chain16_kernel(ChainP p) {
     constexpr int C16_ROWS = NW * 16, C16_NDMA = CH_STAGE_FRAGS / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + C16_SCR_BYTES + CH_PAR_FLOATS * 4];
     unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
@@ -287,9 +287,10 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
         }
     }
     auto issue2 = [&](int s, int g) {
-        if constexpr (NL > 0) return;                             // the loader waves stream the weights
+        if constexpr (NL == 0) {                                  // (NL > 0: the loader waves stream the weights)
         if (s >= nst) return;
         c16_issue_half<C16_NDMA>(wsrc + (size_t)s * CH_STAGE_BYTES, __builtin_amdgcn_readfirstlane(wdst + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES), g & 1);
+        }
     };
     // stage s has landed once at most the pieces of the two stages behind it are outstanding on every wave (chain.hip)
     auto stage_begin = [&](int s) -> const unsigned char* {

@@ -32,7 +32,7 @@ struct ChainBP {
 #define C16B_CTX_STAGES 4
 
 template <int NW, int NL = 0>
-__global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_eu(NW / 4, (NW + NL + 3) / 4))) void dense_chain16_bwd_kernel(ChainBP p) {
+__global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_eu((NW + 3) / 4, (NW + NL + 3) / 4))) void dense_chain16_bwd_kernel(ChainBP p) {
     constexpr int C16_ROWS = NW * 16, C16_NDMA = CH_STAGE_FRAGS / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + C16_SCR_BYTES + 2 * CH_D * 4];
     unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
@@ -52,9 +52,10 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
         }
     }
     auto issue2 = [&](int s, int g) {
-        if constexpr (NL > 0) return;
+        if constexpr (NL == 0) {
         if (s >= nst) return;
         c16_issue_half<C16_NDMA>(wsrc + (size_t)s * CH_STAGE_BYTES, __builtin_amdgcn_readfirstlane(wdst + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES), g & 1);
+        }
     };
     auto stage_begin = [&](int s) -> const unsigned char* {
         if constexpr (NL == 0) {
