@@ -84,7 +84,10 @@ def _run_chain(M, F, pdrop, with_qkv, with_out32, with_bits, seed0=0, bits_layou
     # (four 16-row waves per workgroup up to 16 384 rows, eight from there on: csrc/chain.hip chain_nw)
     forced = os.environ.get('TTSMI_DENSE_CHAIN_NW', '0')              # (A/B knob: then the forced form is what must have run)
     want = {'4': 'dense_chain16_kernel<4 waves>', '8': 'dense_chain16_kernel'}.get(
-        forced, 'dense_chain16_kernel<4 waves>' if M <= 16384 else 'dense_chain16_kernel')
+        forced, ('dense_chain16_kernel<4 waves, split>' if M <= 8192 and (F // 64) % 2 == 0 and os.environ.get('TTSMI_DENSE_CHAIN_SPLIT', '1') != '0'
+                 else 'dense_chain16_kernel<4 waves>') if M <= 16384 else 'dense_chain16_kernel')
+    if forced == '4' and M <= 8192 and (F // 64) % 2 == 0 and os.environ.get('TTSMI_DENSE_CHAIN_SPLIT', '1') != '0':
+        want = 'dense_chain16_kernel<4 waves, split>'
     assert l.ttsmi_last_kernel().decode() == want
     inv = 1.0 / (1.0 - float(np.float32(pdrop))) if pdrop > 0 else 1.0
     live = (pad == 0)
@@ -279,7 +282,9 @@ def test_backward_chain_matches_the_fp64_reference_stage_by_stage(M, pdrop, dres
                                   _p(wpack), nb, M, F, pdrop, seed, _p(step), site, _p(dh1), _p(d_o), _p(dres), int(dres_bf16), _p(dctx),
                                   _p(part), part.numel(), _stream()), 'chain bwd')
     torch.cuda.synchronize()
-    assert l.ttsmi_last_kernel().decode() == 'dense_chain16_bwd_kernel'
+    split = (M <= 8192 and (F // 64) % 2 == 0 and os.environ.get('TTSMI_DENSE_CHAIN_SPLIT', '1') != '0'
+             and os.environ.get('TTSMI_DENSE_CHAIN_NW', '0') in ('0', '4'))
+    assert l.ttsmi_last_kernel().decode() == ('dense_chain16_bwd_kernel<split>' if split else 'dense_chain16_bwd_kernel')
     dh1_c, d_o_c, dctx_c, dres_c = dh1.cpu(), d_o.cpu(), dctx.cpu(), dres.cpu()
     # stage 1: the masked FFN2 dgrad
     want = (df.double() @ bf(w2).t()) * pos

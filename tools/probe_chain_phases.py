@@ -26,6 +26,8 @@ e = lambda *s, dt=torch.bfloat16: torch.empty(s, dtype=dt, device=DEV)
 a, xh1, r1, h1, o, xh2, r2, qkv = e(M, D), e(M, D), e(M, dt=torch.float32), e(M, F), e(M, D), e(M, D), e(M, dt=torch.float32), e(M, 3 * D)
 NWV = 4 if (M <= 16384 and os.environ.get('TTSMI_DENSE_CHAIN_NW', '0') != '8') or os.environ.get('TTSMI_DENSE_CHAIN_NW') == '4' else 8      # waves per workgroup (csrc/chain.hip: chain_nw)
 nwg = (M + 16 * NWV - 1) // (16 * NWV)
+if NWV == 4 and M <= 8192 and os.environ.get('TTSMI_DENSE_CHAIN_SPLIT', '1') != '0':
+    nwg = (nwg + 7) // 8 * 16                      # the SPLIT form: two workgroups per tile, groups of 16
 dbg = torch.zeros(nwg * NWV * 8, dtype=torch.int64, device=DEV)
 if hasattr(l._cdll, 'ttsmi_dense_chain_debug'):
     l._cdll.ttsmi_dense_chain_debug(ctypes.c_void_p(dbg.data_ptr()))

@@ -40,6 +40,9 @@
 // count, which the four launches beat at encoder sizes (57 us).
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -85,6 +88,8 @@ struct ChainP {
     uint16_t* qkv;                   // the next block's [M,768], or NULL
     int ablate;                      // measurement build only (TTSMI_CHAIN_ABLATE): 1 no multiplies, 2 no DMA, 8 no in-loop stores
     unsigned long long* dbg;         // measurement build only: per (workgroup, wave) phase stamps, ttsmi_dense_chain_debug
+    float* xbuf;                     // SPLIT form: [tiles][2][waves][16 tiles x 64 lanes x 4] fp32 partial sums of the FFN output
+    uint32_t* xflag;                 // SPLIT form: [tiles][2][waves], 0 between launches
 };
 
 __device__ __forceinline__ void ch_dma16(const void* gsrc, unsigned lds_off) {
@@ -141,6 +146,37 @@ static int chain_nw(int M) {
 static int chain_loaders() {
     TTSMI_KNOB(on, "TTSMI_DENSE_CHAIN_LOADERS", 4);
     return on == 2 ? 2 : on != 0 ? 4 : 0;
+}
+
+// ---- the SPLIT forms' exchange buffers: one set per stream (launches of one stream are ordered; two streams may run chains at
+// the same time), allocated on first use outside a capture, never freed.  Flags are zero between launches (chain16.h).
+#define CHAIN_SPLIT_MAX_TILES 128                       // 64-row tiles: 8 192 rows, 256 workgroups
+struct ChainSplitBuf { float* x; uint32_t* flag; };
+static bool chain_split_buffers(hipStream_t st, ChainSplitBuf* out) {
+    static std::mutex mu;
+    static std::map<hipStream_t, ChainSplitBuf> bufs;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = bufs.find(st);
+    if (it != bufs.end()) { *out = it->second; return true; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;   // no allocation inside a capture
+    ChainSplitBuf b = {nullptr, nullptr};
+    const size_t xbytes = (size_t)CHAIN_SPLIT_MAX_TILES * 2 * 4 * 16 * 256 * sizeof(float), fbytes = (size_t)CHAIN_SPLIT_MAX_TILES * 2 * 4 * sizeof(uint32_t);
+    if (hipMalloc((void**)&b.x, xbytes) != hipSuccess) return false;
+    if (hipMalloc((void**)&b.flag, fbytes) != hipSuccess || hipMemset(b.flag, 0, fbytes) != hipSuccess) {
+        (void)hipFree(b.x);
+        return false;
+    }
+    bufs[st] = b;
+    *out = b;
+    return true;
+}
+// two workgroups per 64-row tile (chain16.h: SPLIT) while twice the workgroups still fit the CUs; TTSMI_DENSE_CHAIN_SPLIT=0: never
+static bool chain_split(int M, int F) {
+    TTSMI_KNOB(on, "TTSMI_DENSE_CHAIN_SPLIT", 1);
+    static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const int tiles = ttsmi_cdiv(M, 64);
+    return on && chain_nw(M) == 4 && chain_loaders() == 4 && tiles <= CHAIN_SPLIT_MAX_TILES && ttsmi_cdiv(tiles, 8) * 16 <= cus && (F / 64) % 2 == 0;
 }
 
 static int chain_bwd_stages(int F) { return 2 * (F / 64) + C16B_CTX_STAGES; }
@@ -261,7 +297,14 @@ int ttsmi_dense_chain_fwd(const uint16_t* h_bf, const uint16_t* ctx, const void*
             TTSMI_LAUNCH_EV((dense_chain16_kernel<false, NW_, NL_>), dim3(ttsmi_cdiv(M, 16 * NW_)), dim3(64 * (NW_ + NL_)), 0, (hipStream_t)stream, p); \
     } while (0)
     const int nw = chain_nw(M), nl = chain_loaders();
-    if (nw == 4) {
+    ChainSplitBuf xb = {nullptr, nullptr};
+    if (chain_split(M, F) && chain_split_buffers((hipStream_t)stream, &xb)) {
+        ttsmi_note_kernel("dense_chain16_kernel<4 waves, split>");
+        p.xbuf = xb.x; p.xflag = xb.flag;
+        const dim3 grid(ttsmi_cdiv(ttsmi_cdiv(M, 64), 8) * 16);
+        if (out32 != nullptr) TTSMI_LAUNCH_EV((dense_chain16_kernel<true, 4, 4, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+        else TTSMI_LAUNCH_EV((dense_chain16_kernel<false, 4, 4, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    } else if (nw == 4) {
         ttsmi_note_kernel("dense_chain16_kernel<4 waves>");
         if (nl == 4) CHAIN_FWD_LAUNCH(4, 4);
         else if (nl == 2) CHAIN_FWD_LAUNCH(4, 2);
@@ -330,7 +373,12 @@ int ttsmi_dense_chain_bwd(const uint16_t* df, const uint16_t* da, const uint16_t
     ttsmi_note_kernel("dense_chain16_bwd_kernel");
 #define CHAIN_BWD_LAUNCH(NW_, NL_) TTSMI_LAUNCH_EV((dense_chain16_bwd_kernel<NW_, NL_>), dim3(nparts), dim3(64 * (NW_ + NL_)), 0, (hipStream_t)stream, p)
     const int nw = chain_nw(M), nl = chain_loaders();
-    if (nw == 4 && nl == 4) CHAIN_BWD_LAUNCH(4, 4);
+    ChainSplitBuf xb = {nullptr, nullptr};
+    if (chain_split(M, F) && chain_split_buffers((hipStream_t)stream, &xb)) {
+        ttsmi_note_kernel("dense_chain16_bwd_kernel<split>");
+        p.xbuf = xb.x; p.xflag = xb.flag;
+        TTSMI_LAUNCH_EV((dense_chain16_bwd_kernel<4, 4, true>), dim3(ttsmi_cdiv(nparts, 8) * 16), dim3(512), 0, (hipStream_t)stream, p);
+    } else if (nw == 4 && nl == 4) CHAIN_BWD_LAUNCH(4, 4);
     else if (nw == 4 && nl == 2) CHAIN_BWD_LAUNCH(4, 2);
     else if (nw == 4) CHAIN_BWD_LAUNCH(4, 0);
     else CHAIN_BWD_LAUNCH(8, 0);

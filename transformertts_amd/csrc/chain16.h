@@ -116,7 +116,9 @@ __device__ __forceinline__ void c16_bias_init(f32x4v (&Z)[16], const float* bias
 template <bool Y32>
 __device__ __forceinline__ void c16_layernorm(f32x4v (&Z)[16], const bf16x8 (&R)[8], bf16x8 (&Y)[8], const ChainP& p, const float* gamma,
                                               const float* beta, uint64_t drop_base, uint32_t site, int row, int rowc, int row0, bool padded,
-                                              unsigned char* slot, int lane, uint16_t* y_bf, uint16_t* xhat, float* rstd_out, float* y32) {
+                                              unsigned char* slot, int lane, uint16_t* y_bf, uint16_t* xhat, float* rstd_out, float* y32,
+                                              bool wr = true) {
+    // wr (wave-uniform): false = compute the result's fragments only (the SPLIT form's second workgroup: its partner stores)
     const int t = lane & 15, kg = lane >> 4;
     const uint64_t key = p.thr ? ttsmi_drop_key_of(drop_base, site) : 0;
     const uint32_t rb = ttsmi_row_base(key, (uint32_t)rowc);
@@ -158,7 +160,7 @@ __device__ __forceinline__ void c16_layernorm(f32x4v (&Z)[16], const bf16x8 (&R)
     q += __shfl_xor(q, 32, 64);
     const float rstd = __builtin_amdgcn_rsqf(q * invC + p.eps);
     const float nmr = -mean * rstd;
-    if (kg == 0 && row < p.M) rstd_out[row] = rstd;
+    if (kg == 0 && row < p.M && wr) rstd_out[row] = rstd;
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {                 // 64 features (four tiles) per round through the wave's scratch slot
         uint2 xh_q[4];
@@ -177,6 +179,7 @@ __device__ __forceinline__ void c16_layernorm(f32x4v (&Z)[16], const bf16x8 (&R)
                 if constexpr (Y32) Z[j][e] = y[e];
             }
         }
+        if (!wr) continue;
 #pragma unroll
         for (int u = 0; u < 4; ++u) c16_slot_write(slot, t, kg, u, xh_q[u]);
         ch_lds_fence();
@@ -231,15 +234,17 @@ __device__ __forceinline__ void c16_issue_half(const unsigned char* src, unsigne
 // but stream the weights: each issues 16 of a stage's 32 pieces right after the stage barrier that retires the ring slot, waits
 // for its own pieces with a counted vmcnt and joins every workgroup barrier the compute waves execute (`extra_barrier_after`:
 // the backward kernel has one more, behind the barrier of that stage).  The compute waves then neither issue nor wait for DMA.
-template <int NL>
-__device__ __forceinline__ void c16_loader_loop(const unsigned char* wpack, unsigned ring_off, int nst, int lw, int lane, int extra_barrier_after) {
+struct C16IdentityStage { __device__ __forceinline__ int operator()(int s) const { return s; } };
+template <int NL, class MAP = C16IdentityStage>
+__device__ __forceinline__ void c16_loader_loop(const unsigned char* wpack, unsigned ring_off, int nst, int lw, int lane, int extra_barrier_after,
+                                                MAP packed_stage = MAP()) {
     constexpr int PL = CH_STAGE_FRAGS / NL;                      // pieces per loader wave and stage
     static_assert(PL % 4 == 0 && 3 * PL <= 63, "vmcnt is a 6-bit counter");
     const unsigned char* src0 = wpack + (size_t)lw * PL * CH_FRAG_BYTES + lane * 16;
     const unsigned dst0 = ring_off + (unsigned)lw * PL * CH_FRAG_BYTES;
     auto issue = [&](int s) {
         if (s >= nst) return;
-        const unsigned char* src = src0 + (size_t)s * CH_STAGE_BYTES;
+        const unsigned char* src = src0 + (size_t)packed_stage(s) * CH_STAGE_BYTES;    // (the workgroup's stage s of the packed stream)
         const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)(s % CH_NRING) * CH_STAGE_BYTES);
 #pragma unroll
         for (int k = 0; k < PL / 4; ++k) c16_issue_half<8>(src + k * 4 * CH_FRAG_BYTES, dst + (unsigned)(k * 4 * CH_FRAG_BYTES), 0);
@@ -256,17 +261,54 @@ __device__ __forceinline__ void c16_loader_loop(const unsigned char* wpack, unsi
     }
 }
 
-template <bool Y32, int NW, int NL = 0>
+// coherent accesses of the SPLIT form's exchange (sc0 sc1: system scope - the partner workgroup may sit on another XCD, whose L2
+// is not coherent with this one's)
+// (OFF: the instruction's immediate byte offset, 0 .. 4095 - one address register serves four of a wave's 1 KB rows)
+template <int OFF>
+__device__ __forceinline__ void c16_store16_sc(float* ptr, f32x4v v) {
+    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc0 sc1" ::"v"(ptr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void c16_load16_sc(f32x4v& v, const float* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1" : "=v"(v) : "v"(ptr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void c16_store_flag_sc(uint32_t* ptr, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint32_t c16_load_flag_sc(const uint32_t* ptr) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
+// SPLIT (round 6, row counts up to 8 192): TWO workgroups per 64-row tile.  Both run the o-projection and res-norm 1, each
+// streams HALF of the FFN's hidden chunks and half of the qkv columns - 30 weight stages instead of 52 - and they exchange the
+// fp32 partial sum of the FFN output (wave by wave: a wave's 16 rows only need the same wave of the partner) through global
+// memory between the FFN and res-norm 2.  Workgroups b and b + 8 of a group of 16 share a tile.  Both compute P0 + P1 in this
+// order, so they normalise identical sums; the first of the pair stores the row-wise results.  A launch's time below 16 k rows is
+// its stages whatever the row count - this form halves them where the CUs to run twice the workgroups are idle anyway.
+template <bool Y32, int NW, int NL = 0, bool SPLIT = false>
 __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_eu((NW + 3) / 4, (NW + NL + 3) / 4))) void dense_chain16_kernel(ChainP p) {
+    static_assert(!SPLIT || NL > 0, "the split form streams through loader waves");
     constexpr int C16_ROWS = NW * 16, C16_NDMA = CH_STAGE_FRAGS / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + C16_SCR_BYTES + CH_PAR_FLOATS * 4];
     unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
     float* par = reinterpret_cast<float*>(scr + C16_SCR_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, t = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * C16_ROWS;
+    const int side = SPLIT ? (blockIdx.x >> 3) & 1 : 0;                                  // which of the tile's two workgroups
+    const int tile = SPLIT ? (blockIdx.x >> 4) * 8 + (blockIdx.x & 7) : blockIdx.x;
+    const int m0 = tile * C16_ROWS;
     const int row0 = m0 + wave * 16, row = row0 + t, rowc = min(row, p.M - 1);
-    const int nst = p.nstages;
+    const int nc_w = SPLIT ? p.nchunk / 2 : p.nchunk, c_first = side * nc_w;             // this workgroup's hidden chunks
+    const int nq_w = p.qkv == nullptr ? 0 : SPLIT ? CH_QKV_STAGES / 2 : CH_QKV_STAGES;   // ... and qkv stages
+    const int nst = SPLIT ? CH_WO_STAGES + 2 * nc_w + nq_w : p.nstages;
+    // the workgroup's stage s in the packed stream: three contiguous runs (o-projection, its chunks, its qkv columns)
+    auto packed_stage = [=](int s) -> int {
+        if (!SPLIT || s < CH_WO_STAGES) return s;
+        if (s < CH_WO_STAGES + 2 * nc_w) return s + 2 * c_first;
+        return s + 2 * (p.nchunk - nc_w) + side * nq_w;
+    };
     const unsigned ring_off = ch_lds_offset(smem);
 #ifdef TTSMI_ABLATION_BUILD
     unsigned long long tph[8], twait = 0;
@@ -282,7 +324,7 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
     const unsigned wdst = ring_off + (unsigned)wave * C16_NDMA * CH_FRAG_BYTES;
     if constexpr (NL > 0) {
         if (wave >= NW) {                                         // (wave-uniform: the loader waves never touch rows)
-            c16_loader_loop<NL>(p.wpack, ring_off, nst, wave - NW, lane, -1);
+            c16_loader_loop<NL>(p.wpack, ring_off, nst, wave - NW, lane, -1, packed_stage);
             return;
         }
     }
@@ -386,8 +428,16 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
             }
         } else {
             // FFN: per 64 hidden features a stage of a . W1 (4 tiles x 8 k-blocks) and one of h1 . W2 (2 k-blocks x 16 tiles)
-            c16_bias_init(Z, par + CH_P_B2, kg);
-            for (int c = 0; c < p.nchunk; ++c) {
+            if (side == 0) {
+                c16_bias_init(Z, par + CH_P_B2, kg);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Z[j][e] = 0.f;
+            }
+            for (int cc_ = 0; cc_ < nc_w; ++cc_) {
+                const int c = c_first + cc_;
                 const unsigned char* Fs = stage_begin(S);
                 f32x4v H[4];
 #pragma unroll
@@ -422,19 +472,53 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
                 ++S;
             }
             ch_lds_fence();
+            if constexpr (SPLIT) {
+                // ---- the partner's partial sum: store mine, raise my flag, wait for the partner's, load, lower it (its only reader)
+                const long wslot = ((long)tile * 2 + side) * NW + wave, oslot = ((long)tile * 2 + (side ^ 1)) * NW + wave;
+                float* mine = p.xbuf + wslot * (16 * 256) + lane * 4;
+                const float* theirs = p.xbuf + oslot * (16 * 256) + lane * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float* m4 = mine + q * 1024;
+                    c16_store16_sc<0>(m4, Z[4 * q]); c16_store16_sc<1024>(m4, Z[4 * q + 1]);
+                    c16_store16_sc<2048>(m4, Z[4 * q + 2]); c16_store16_sc<3072>(m4, Z[4 * q + 3]);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) c16_store_flag_sc(p.xflag + wslot, 1u);
+                while (__builtin_amdgcn_readfirstlane(c16_load_flag_sc(p.xflag + oslot)) != 1u) __builtin_amdgcn_s_sleep(2);
+                f32x4v O[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float* t4 = theirs + q * 1024;
+                    c16_load16_sc<0>(O[4 * q], t4); c16_load16_sc<1024>(O[4 * q + 1], t4);
+                    c16_load16_sc<2048>(O[4 * q + 2], t4); c16_load16_sc<3072>(O[4 * q + 3], t4);
+                }
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(O[0]), "+v"(O[1]), "+v"(O[2]), "+v"(O[3]), "+v"(O[4]), "+v"(O[5]), "+v"(O[6]), "+v"(O[7]), "+v"(O[8]), "+v"(O[9]),
+                               "+v"(O[10]), "+v"(O[11]), "+v"(O[12]), "+v"(O[13]), "+v"(O[14]), "+v"(O[15])
+                             :
+                             : "memory");
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Z[jj][e] = side == 0 ? Z[jj][e] + O[jj][e] : O[jj][e] + Z[jj][e];     // P0 + P1 on both sides
+                if (lane == 0) c16_store_flag_sc(p.xflag + oslot, 0u);
+            }
         }
         C16_STAMP();
         c16_layernorm<Y32>(Z, Y, Y, p, par + (half ? CH_P_G2 : CH_P_G1), par + (half ? CH_P_BE2 : CH_P_BE1), drop_base, half ? p.site_ln2 : p.site_ln1, row,
                            rowc, row0, padded, slot, lane, half ? p.out_bf : p.a_bf, half ? p.xhat2 : p.xhat1, half ? p.rstd2 : p.rstd1,
-                           half ? p.out32 : nullptr);
+                           half ? p.out32 : nullptr, side == 0);
         C16_STAMP();
     }
 
     // the next block's qkv projection: 12 stages of (4 output tiles x 8 k-blocks)
     if (p.qkv != nullptr) {
-        for (int s = 0; s < CH_QKV_STAGES; ++s) {
+        const int q0 = side * nq_w;                                 // (SPLIT: this workgroup's half of the 768 columns)
+        for (int s_ = 0; s_ < nq_w; ++s_) {
+            const int s = q0 + s_;
             const unsigned char* Fs = stage_begin(S);
-            if (s > 0) c16_slot_flush(slot, p.qkv, 3 * CH_D, 64 * (s - 1), row0, p.M, lane, nullptr, 0, 0);
+            if (s_ > 0) c16_slot_flush(slot, p.qkv, 3 * CH_D, 64 * (s - 1), row0, p.M, lane, nullptr, 0, 0);
             f32x4v acc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -449,7 +533,7 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
             for (int u = 0; u < 4; ++u) c16_slot_write(slot, t, kg, u, ch_pack4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]));
         }
         ch_lds_fence();
-        c16_slot_flush(slot, p.qkv, 3 * CH_D, 64 * (CH_QKV_STAGES - 1), row0, p.M, lane, nullptr, 0, 0);
+        c16_slot_flush(slot, p.qkv, 3 * CH_D, 64 * (q0 + nq_w - 1), row0, p.M, lane, nullptr, 0, 0);
     }
 #ifdef TTSMI_ABLATION_BUILD
     C16_STAMP();

@@ -27,27 +27,41 @@ struct ChainBP {
     uint16_t *dh1, *d_o, *dctx;
     void* dres; int dres_bf16;
     float* part;                         // [2 nparts][256]: dgamma partial rows, then dbeta partial rows
+    float* xbuf; uint32_t* xflag;        // SPLIT form: the exchange buffers of the forward's (chain16.h)
 };
 
 #define C16B_CTX_STAGES 4
 
-template <int NW, int NL = 0>
+// SPLIT: two workgroups per 64-row tile, as in the forward (chain16.h): each streams half of the hidden chunks (the partial sums
+// of g = da + dh1 . W1^T are exchanged before res-norm 1's backward, which both run) and half of the dctx columns; the first of
+// the pair stores d_o / dres and the tile's parameter-gradient partial row.
+template <int NW, int NL = 0, bool SPLIT = false>
 __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_eu((NW + 3) / 4, (NW + NL + 3) / 4))) void dense_chain16_bwd_kernel(ChainBP p) {
+    static_assert(!SPLIT || NL > 0, "the split form streams through loader waves");
     constexpr int C16_ROWS = NW * 16, C16_NDMA = CH_STAGE_FRAGS / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[CH_NRING * CH_STAGE_BYTES + C16_SCR_BYTES + 2 * CH_D * 4];
     unsigned char* scr = smem + CH_NRING * CH_STAGE_BYTES;
     float* gam = reinterpret_cast<float*>(scr + C16_SCR_BYTES);          // gamma1, staged
     const int tid = threadIdx.x, lane = tid & 63, t = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * C16_ROWS;
+    const int side = SPLIT ? (blockIdx.x >> 3) & 1 : 0;
+    const int tile = SPLIT ? (blockIdx.x >> 4) * 8 + (blockIdx.x & 7) : blockIdx.x;
+    const int m0 = tile * C16_ROWS;
     const int row0 = m0 + wave * 16, row = row0 + t, rowc = min(row, p.M - 1);
-    const int nst = p.nstages;
+    const int nc_w = SPLIT ? p.nchunk / 2 : p.nchunk, c_first = side * nc_w;
+    const int nq_w = SPLIT ? C16B_CTX_STAGES / 2 : C16B_CTX_STAGES;
+    const int nst = SPLIT ? 2 * nc_w + nq_w : p.nstages;
+    auto packed_stage = [=](int s) -> int {
+        if (!SPLIT) return s;
+        if (s < 2 * nc_w) return s + 2 * c_first;
+        return s + 2 * (p.nchunk - nc_w) + side * nq_w;
+    };
     const unsigned ring_off = ch_lds_offset(smem);
     const unsigned char* wsrc = p.wpack + (size_t)wave * C16_NDMA * CH_FRAG_BYTES + lane * 16;
     const unsigned wdst = ring_off + (unsigned)wave * C16_NDMA * CH_FRAG_BYTES;
     if constexpr (NL > 0) {
         if (wave >= NW) {             // loader waves (chain16.h): the one extra barrier sits behind the first dctx stage's
-            c16_loader_loop<NL>(p.wpack, ring_off, nst, wave - NW, lane, 2 * p.nchunk);
+            c16_loader_loop<NL>(p.wpack, ring_off, nst, wave - NW, lane, 2 * nc_w, packed_stage);
             return;
         }
     }
@@ -126,14 +140,15 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
 #pragma unroll
     for (int j = 0; j < 16; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Z[j][e] = ch_bf(DA[j >> 1], 4 * (j & 1) + e);
+        for (int e = 0; e < 4; ++e) Z[j][e] = side == 0 ? ch_bf(DA[j >> 1], 4 * (j & 1) + e) : 0.f;
 
     int S = 0;
     unsigned char* slot = scr + wave * C16_SLOT_BYTES;
     const long tile16 = min(row0, p.M - 1) >> 4;         // the wave's 16-row tile (the bit words are laid out per tile; clamped past M)
     static_assert(C16B_CTX_STAGES >= CH_NRING - 1, "the chunk loop's counted wait for the ReLU word assumes a DMA issue in every one of its stages");
-    const uint16_t* bitp = p.bits16 + tile16 * p.nchunk * 64 + lane;
-    for (int c = 0; c < p.nchunk; ++c) {
+    const uint16_t* bitp = p.bits16 + (tile16 * p.nchunk + c_first) * 64 + lane;
+    for (int cc_ = 0; cc_ < nc_w; ++cc_) {
+        const int c = c_first + cc_;
         // The chunk's ReLU word.  A compiler-tracked load here costs a full drain: the compiler does not see the LDS-DMA
         // instructions (inline asm), so its wait in front of the first use is vmcnt(0) - behind the stage that has just
         // put four more DMA pieces in flight.  Issued by hand in front of the stage's barrier and waited for with the count
@@ -172,6 +187,41 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
         ++S;
     }
     ch_lds_fence();
+    if constexpr (SPLIT) {
+        // ---- the partner's partial sum of g (chain16.h: the same hand-shake, wave by wave)
+        const long wslot = ((long)tile * 2 + side) * NW + wave, oslot = ((long)tile * 2 + (side ^ 1)) * NW + wave;
+        float* mine = p.xbuf + wslot * (16 * 256) + lane * 4;
+        const float* theirs = p.xbuf + oslot * (16 * 256) + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* m4 = mine + q * 1024;
+            c16_store16_sc<0>(m4, Z[4 * q]); c16_store16_sc<1024>(m4, Z[4 * q + 1]);
+            c16_store16_sc<2048>(m4, Z[4 * q + 2]); c16_store16_sc<3072>(m4, Z[4 * q + 3]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) c16_store_flag_sc(p.xflag + wslot, 1u);
+        while (__builtin_amdgcn_readfirstlane(c16_load_flag_sc(p.xflag + oslot)) != 1u) __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+        for (int b8 = 0; b8 < 2; ++b8) {                 // (two round trips of eight tiles: this kernel has no 64 registers to spare)
+            f32x4v O[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float* t4 = theirs + (2 * b8 + q) * 1024;
+                c16_load16_sc<0>(O[4 * q], t4); c16_load16_sc<1024>(O[4 * q + 1], t4);
+                c16_load16_sc<2048>(O[4 * q + 2], t4); c16_load16_sc<3072>(O[4 * q + 3], t4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(O[0]), "+v"(O[1]), "+v"(O[2]), "+v"(O[3]), "+v"(O[4]), "+v"(O[5]), "+v"(O[6]), "+v"(O[7])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Z[8 * b8 + j][e] = side == 0 ? Z[8 * b8 + j][e] + O[j][e] : O[j][e] + Z[8 * b8 + j][e];   // P0 + P1
+        }
+        if (lane == 0) c16_store_flag_sc(p.xflag + oslot, 0u);
+    }
+    const bool wr = side == 0;                           // (wave-uniform) the first workgroup of a pair stores the row-wise results
 
     // ---- res-norm 1 backward on the wave's 16 rows (rowgemm.hip: rg_epilogue<1>, same arithmetic)
     bf16x8(&DO)[8] = DF;                                 // d_o's fragments take the registers of df's
@@ -229,6 +279,7 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) DO[j >> 1][4 * (j & 1) + e] = hb[e];      // (df's value at this slot is no longer needed)
             }
+            if (!wr) continue;
             // d_o
 #pragma unroll
             for (int u = 0; u < 4; ++u) c16_slot_write(slot, t, kg, u, do_q[u]);
@@ -281,9 +332,11 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
     }
 
     // ---- dctx = d_o . Wo[d:2d]^T: 4 stages of (4 output tiles x 8 k-blocks)
-    for (int s = 0; s < C16B_CTX_STAGES; ++s) {
+    const int q0 = side * nq_w;                          // (SPLIT: this workgroup's half of the 256 columns)
+    for (int s_ = 0; s_ < nq_w; ++s_) {
+        const int s = q0 + s_;
         const unsigned char* Fs = stage_begin(S);
-        if (s == 0) {
+        if (s_ == 0) {
             // (the barrier above published every wave's column sums)
 #pragma unroll
             for (int cpart = 0; cpart < 8 / NW; ++cpart) {
@@ -291,7 +344,7 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
                 float a = 0.f;
 #pragma unroll
                 for (int wv = 0; wv < NW; ++wv) a += reinterpret_cast<const float*>(scr + wv * C16_SLOT_BYTES)[col];
-                p.part[((long)(col >> 8) * p.nparts + blockIdx.x) * CH_D + (col & 255)] = a;
+                if (wr && tile < p.nparts) p.part[((long)(col >> 8) * p.nparts + tile) * CH_D + (col & 255)] = a;
             }
             ch_barrier();                                              // the slots are free again
         } else {
@@ -310,5 +363,5 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
         for (int u = 0; u < 4; ++u) c16_slot_write(slot, t, kg, u, ch_pack4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]));
     }
     ch_lds_fence();
-    c16_slot_flush(slot, p.dctx, CH_D, 64 * (C16B_CTX_STAGES - 1), row0, p.M, lane, nullptr, 0, 0);
+    c16_slot_flush(slot, p.dctx, CH_D, 64 * (q0 + nq_w - 1), row0, p.M, lane, nullptr, 0, 0);
 }
