@@ -281,6 +281,20 @@ __device__ __forceinline__ uint32_t c16_load_flag_sc(const uint32_t* ptr) {
     return v;
 }
 
+// wait for the partner's flag.  A partner that never raises it (it was never dispatched: something else holds every CU for good)
+// would hang the queue and the device with it: after ~4 M polls (seconds) the wave traps instead - the launch fails loudly.
+// (Two streams launching split forms at the same time - 2 x 208 workgroups for 256 CUs - make progress: workgroups are dispatched
+// in order, so at most one pair per XCD is half-resident; tools/probe_chain_split_two_streams.py, profiles/r06_chain_split_two_streams.txt.)
+// Measured and not kept: an XCD-aware exchange (waves publish their XCC id; partners under one L2 store and load at agent scope):
+// 39.9 against 37.5 us forward - the system-scope round trips are not what the exchange costs (profiles/r06_chain_split_xcd_exchange_ab.txt).
+__device__ __forceinline__ void c16_wait_flag(const uint32_t* flag) {
+    int polls = 0;
+    while (__builtin_amdgcn_readfirstlane(c16_load_flag_sc(flag)) != 1u) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++polls > (1 << 22)) __builtin_trap();
+    }
+}
+
 // SPLIT (round 6, row counts up to 8 192): TWO workgroups per 64-row tile.  Both run the o-projection and res-norm 1, each
 // streams HALF of the FFN's hidden chunks and half of the qkv columns - 30 weight stages instead of 52 - and they exchange the
 // fp32 partial sum of the FFN output (wave by wave: a wave's 16 rows only need the same wave of the partner) through global
@@ -485,7 +499,7 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) c16_store_flag_sc(p.xflag + wslot, 1u);
-                while (__builtin_amdgcn_readfirstlane(c16_load_flag_sc(p.xflag + oslot)) != 1u) __builtin_amdgcn_s_sleep(2);
+                c16_wait_flag(p.xflag + oslot);
                 f32x4v O[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {

@@ -200,7 +200,7 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) __attribute__((amdgpu_waves_per_
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) c16_store_flag_sc(p.xflag + wslot, 1u);
-        while (__builtin_amdgcn_readfirstlane(c16_load_flag_sc(p.xflag + oslot)) != 1u) __builtin_amdgcn_s_sleep(2);
+        c16_wait_flag(p.xflag + oslot);
 #pragma unroll
         for (int b8 = 0; b8 < 2; ++b8) {                 // (two round trips of eight tiles: this kernel has no 64 registers to spare)
             f32x4v O[8];
