@@ -50,6 +50,7 @@ TTSMI_CSTEP=0 python bench.py --no-cpu-baseline --no-attention-maps --no-also > 
 TTSMI_DENSE_CHAIN=0 python bench.py --no-cpu-baseline --no-attention-maps --no-also > $O/${TAG}_bench_bf16_nochain.json 2>/dev/null; echo rc=$?
 python tools/kbench.py --only attn > $O/${TAG}_kbench_attn.txt 2>&1
 python tools/debug/cstep_host.py 2>&1 | grep -v amdgpu.ids | head -8 > $O/${TAG}_cstep_host.txt
+( timeout 120 python tools/probe_chain_split_two_streams.py 6400 50; echo "rc=$?"; timeout 120 python tools/probe_chain_split_two_streams.py 2500 50; echo "rc=$?" ) 2>&1 | grep -v amdgpu.ids > $O/${TAG}_chain_split_two_streams.txt
 echo "== the training curve at the benchmarked batch"
 TTSMI_CURVE_BATCH=32 timeout 600 python -m pytest tests/test_training_curve_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -2
 cp $O/bf16_vs_f32_curve.json $O/${TAG}_bf16_vs_f32_curve_b32.json 2>/dev/null
