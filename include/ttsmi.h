@@ -43,7 +43,7 @@ extern "C" {
  * ttsmi_dense_block_bwd_chained, ttsmi_ft_train_step; the opt-in one-pass attention backward
  * (ttsmi_attention_bwd_fused*, attn_fused_ws) removed - it never beat the two kernels inside the step.  Bindings check it at load time (transformertts_amd/_lib.py) so that a stale build is
  * refused instead of being called with shifted arguments. */
-#define TTSMI_VERSION 108
+#define TTSMI_VERSION 109
 
 enum {
     TTSMI_OK = 0,
@@ -55,7 +55,10 @@ enum {
 /* TTSMI_BF16_IO (attention entry points only): as TTSMI_BF16, and every activation the entry point
  * touches - qkv, ctx, dctx, dqkv - is bf16 in HBM (written by / feeding ttsmi_hgemm_tn and
  * ttsmi_hgemm_wgrad_rows, which take bf16 operands); lse and the delta scratch stay fp32. */
-enum { TTSMI_F32 = 0, TTSMI_BF16 = 1, TTSMI_BF16_IO = 2 };
+/* TTSMI_BF16X3 (the fp32 GEMM entry points: ttsmi_linear_* / ttsmi_conv1d_*): fp32 tensors as TTSMI_F32, every product as THREE
+ * bf16 MFMAs on hi / lo splits of both operands (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate): ~2^-16 per product instead
+ * of bf16's 2^-8, at ~4 x the exact-fp32 kernels' rate - the GEMM family of the host mirror's precision='bf16x3'. */
+enum { TTSMI_F32 = 0, TTSMI_BF16 = 1, TTSMI_BF16_IO = 2, TTSMI_BF16X3 = 3 };
 
 typedef void* ttsmi_stream_t; /* hipStream_t */
 

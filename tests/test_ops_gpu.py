@@ -115,6 +115,69 @@ def test_conv1d_fwd_bwd(B, T, Cin, Cout, k):
     assert rel_err(dxm, xd.grad * (hmask > 0)) < 3e-6
 
 
+# ---- the same family on three bf16 MFMAs per product (dtype TTSMI_BF16X3): ~2^-16 per product instead of fp32's 2^-24
+X3_TOL = 4e-5
+
+
+@pytest.mark.parametrize('M,K,N', [(128, 256, 256), (200, 64, 192), (1, 16, 4), (333, 100, 60), (77, 226, 1), (1000, 512, 130), (129, 17, 33),
+                                   (4000, 256, 1024)])
+def test_bf16x3_linear_family(M, K, N):
+    ops = _ops()
+    from transformertts_amd import _lib
+    X3 = _lib.TTSMI_BF16X3
+    x, w, b, dy, h = g(M, K, seed=1), g(K, N, seed=2), g(N, seed=3), g(M, N, seed=4), g(M, K, seed=5)
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), True, dtype=X3)
+    assert _lib.lib().ttsmi_last_kernel().decode() == 'gemm_x3_kernel'
+    assert rel_err(y, (x.double() @ w.double() + b.double()).relu()) < X3_TOL
+    dx = ops.linear_dgrad(dy.to(DEV), w.to(DEV), relu_src=h.to(DEV), dtype=X3)
+    assert rel_err(dx, (dy.double() @ w.double().T) * (h > 0)) < X3_TOL
+    acc = torch.ones(M, K, device=DEV)
+    ops.linear_dgrad(dy.to(DEV), w.to(DEV), out=acc, accumulate=True, dtype=X3)
+    assert rel_err(acc, dy.double() @ w.double().T + 1.0) < X3_TOL
+    dw, db = torch.full((K, N), 7.0, device=DEV), torch.full((N,), 7.0, device=DEV)
+    ops.linear_wgrad(x.to(DEV), dy.to(DEV), dw, db, dtype=X3)
+    assert rel_err(dw, x.double().T @ dy.double()) < X3_TOL
+    assert rel_err(db, dy.double().sum(0)) < X3_TOL
+    # the hi / lo split really carries the low bits: plain bf16 rounding of the operands would be ~4e-3
+    assert rel_err(y, (x.bfloat16().double() @ w.bfloat16().double() + b.double()).relu()) > 1e-4 or M * K * N < 1000
+
+
+def test_bf16x3_dual_a_and_strided_input():
+    ops = _ops()
+    from transformertts_amd import _lib
+    X3 = _lib.TTSMI_BF16X3
+    M, K1, K2, N = 300, 64, 192, 96
+    x, x2, w, b = g(M, K1, seed=1), g(M, K2, seed=4), g(K1 + K2, N, seed=2), g(N, seed=3)
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), False, x2.to(DEV), dtype=X3)
+    assert rel_err(y, torch.cat([x, x2], 1).double() @ w.double() + b.double()) < X3_TOL
+    big = g(100, 192, seed=5).to(DEV)
+    w2 = g(64, 32, seed=6)
+    y2 = ops.linear_fwd(big[:, 64:128], w2.to(DEV), None, False, dtype=X3)
+    assert rel_err(y2, big.cpu()[:, 64:128].double() @ w2.double()) < X3_TOL
+    n = 160                                   # A = I with an asymmetric B: a transposed C write shows
+    wa = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97) - 3.0 * torch.arange(n)[None, :]
+    assert rel_err(ops.linear_fwd(torch.eye(n).to(DEV), wa.to(DEV), None, False, dtype=X3), wa) < X3_TOL
+
+
+@pytest.mark.parametrize('B,T,Cin,Cout,k', [(2, 50, 64, 64, 3), (3, 17, 32, 226, 3), (2, 40, 226, 8, 3), (1, 9, 4, 4, 5), (2, 30, 16, 24, 1),
+                                            (4, 200, 256, 256, 3), (2, 13, 12, 20, 4)])
+def test_bf16x3_conv1d_family(B, T, Cin, Cout, k):
+    ops = _ops()
+    from transformertts_amd import _lib
+    X3 = _lib.TTSMI_BF16X3
+    x, w, b = g(B, T, Cin, seed=1), g(k, Cin, Cout, seed=2, scale=0.2), g(Cout, seed=3)
+    xd, wd, bd = (t.double().requires_grad_() for t in (x, w, b))
+    y = ops.conv1d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), relu=True, dtype=X3)
+    assert rel_err(y, fo.conv1d_same(xd, wd, bd).relu().detach()) < X3_TOL
+    dy = g(B, T, Cout, seed=4)
+    fo.conv1d_same(xd, wd, bd).backward(dy.double())
+    assert rel_err(ops.conv1d_dgrad(dy.to(DEV), w.to(DEV), dtype=X3), xd.grad) < X3_TOL
+    dw, db = torch.empty_like(w, device=DEV), torch.empty(Cout, device=DEV)
+    ops.conv1d_wgrad(x.to(DEV), dy.to(DEV), dw, db, dtype=X3)
+    assert rel_err(dw, wd.grad) < X3_TOL
+    assert rel_err(db, bd.grad) < X3_TOL
+
+
 def test_ffn_and_convstack_autograd():
     ops = _ops()
     M, d, F = 300, 64, 256

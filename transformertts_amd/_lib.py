@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # version this binding was written for (EXPECTED_VERSION, checked in lib()).
 _override = os.environ.get('TTSMI_LIB') if os.environ.get('TTSMI_ALLOW_LIB_OVERRIDE') == '1' else None
 LIB_PATH = _override or os.path.join(_HERE, 'lib', 'libttsmi.so')
-EXPECTED_VERSION = 108            # include/ttsmi.h: TTSMI_VERSION
+EXPECTED_VERSION = 109            # include/ttsmi.h: TTSMI_VERSION
 
 P = c_void_p          # every device pointer
 I = c_int
@@ -211,7 +211,7 @@ class FtStep(ctypes.Structure):
     _fields_ = _ft_step_fields()
 
 
-TTSMI_F32, TTSMI_BF16, TTSMI_BF16_IO = 0, 1, 2
+TTSMI_F32, TTSMI_BF16, TTSMI_BF16_IO, TTSMI_BF16X3 = 0, 1, 2, 3
 LAUNCH_OBSERVER = ctypes.CFUNCTYPE(None, c_int, c_char_p, ctypes.c_double, ctypes.c_double, c_void_p)
 
 _lib = None

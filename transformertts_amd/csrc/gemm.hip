@@ -48,6 +48,7 @@ struct GemmP {
     float* colsum;                     // optional: column sums of the B operand (bias gradient)
     float* colsum_ws;                  //           their split slabs [gridDim.z][N]
     int tiles_m, tiles_n;
+    int x3;                            // TTSMI_BF16X3: gemm_x3_kernel (host side only)
 };
 
 // ---- element address + validity ---------------------------------------------------------------
@@ -274,6 +275,222 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     }
 }
 
+// =================================================================================================
+// The same GEMM family on bf16 MFMA with THREE products per pair (round 6, dtype TTSMI_BF16X3): every fp32 operand element
+// is split into hi = bf16(v) and lo = bf16(v - hi) when its tile goes to LDS, and a . b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi
+// (fp32 accumulate; the dropped lo . lo term and the rounding of lo are ~2^-17 of the product).  Interface, tiling, split-K,
+// epilogue and the fused bias gradient are gemm_f32_kernel's; what changes is the LDS image - [x][k] bf16 with k contiguous,
+// 80-byte rows (16-byte fragment reads of 16 consecutive rows then cover all 64 banks), hi and lo images side by side - and
+// the rate: 12 v_mfma_f32_32x32x16_bf16 (384 cycles) per 32-deep k-tile instead of 64 v_mfma_f32_32x32x2_f32 (4 096).
+// Every thread fetches (row x, 4 consecutive k): one float4 where k is the contiguous dimension, four row-coalesced dwords
+// where x is.
+// =================================================================================================
+typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 x3_bf16x4 __attribute__((ext_vector_type(4)));
+#define X3_BK 32
+#define X3_LD 40                      // bf16 elements per LDS row: 32 + 8 of padding
+#ifndef X3_WGS_PER_CU
+#define X3_WGS_PER_CU 3
+#endif
+
+// Fetch geometry (both operands, a 128 x 32 tile = 16 elements per thread as four float4):
+//   k contiguous in memory (A_KC, B_KC): four passes of (row x = id >> 3, k-quad kq = id & 7) - eight lanes read one row's 128
+//     bytes, r[i] = the four k of row x_i;
+//   x contiguous in memory (A_MC, B_NC): ONE 4 x 4 block per thread (x-quad xq = tid & 31, k-quad kq = tid >> 5) - 32 lanes read
+//     512 contiguous bytes of one k row, r[e] = the four x at k = 4 kq + e; the block is transposed on its way into LDS.
+template <bool KC>
+__device__ __forceinline__ void x3_coords(int tid, int i, int& x, int& kq) {
+    if (KC) { const int id = tid + 256 * i; x = id >> 3; kq = id & 7; }
+    else { x = (tid & 31) * 4; kq = tid >> 5; }
+}
+template <int AM, bool VEC>
+__device__ __forceinline__ void x3_fetch_a(const GemmP& p, int m0, int k0, int kend, int tid, float4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int x, kq;
+        x3_coords<AM == A_KC>(tid, i, x, kq);
+        bool oks[4];
+        const float* ptrs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (AM == A_KC) {
+                ptrs[e] = a_ptr<AM>(p, m0 + x, k0 + kq * 4 + e, oks[e]);
+                oks[e] = oks[e] && (k0 + kq * 4 + e < kend);
+            } else {
+                ptrs[e] = a_ptr<AM>(p, m0 + x + e, k0 + kq * 4 + i, oks[e]);
+                oks[e] = oks[e] && (k0 + kq * 4 + i < kend);
+            }
+        }
+        r[i] = ld4<VEC>(ptrs[0], oks[0], oks, ptrs);
+    }
+}
+template <int BMODE, bool VEC>
+__device__ __forceinline__ void x3_fetch_b(const GemmP& p, int n0, int k0, int kend, int tid, float4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int x, kq;
+        x3_coords<BMODE == B_KC>(tid, i, x, kq);
+        bool oks[4];
+        const float* ptrs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (BMODE == B_KC) {
+                ptrs[e] = b_ptr<BMODE>(p, k0 + kq * 4 + e, n0 + x, oks[e]);
+                oks[e] = oks[e] && (k0 + kq * 4 + e < kend);
+            } else {
+                ptrs[e] = b_ptr<BMODE>(p, k0 + kq * 4 + i, n0 + x + e, oks[e]);
+                oks[e] = oks[e] && (k0 + kq * 4 + i < kend);
+            }
+        }
+        r[i] = ld4<VEC>(ptrs[0], oks[0], oks, ptrs);
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void x3_stash(uint16_t (*Hi)[X3_LD], uint16_t (*Lo)[X3_LD], int tid, const float4 (&r)[4]) {
+    const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w}, {r[2].x, r[2].y, r[2].z, r[2].w},
+                           {r[3].x, r[3].y, r[3].z, r[3].w}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int x, kq;
+        x3_coords<KC>(tid, i, x, kq);
+        x3_bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f = KC ? v[i][e] : v[e][i];            // (x contiguous: row x + i of the 4 x 4 block, its four k)
+            hi[e] = (__bf16)f;
+            lo[e] = (__bf16)(f - (float)hi[e]);
+        }
+        const int row = KC ? x : x + i;
+        *reinterpret_cast<x3_bf16x4*>(&Hi[row][kq * 4]) = hi;
+        *reinterpret_cast<x3_bf16x4*>(&Lo[row][kq * 4]) = lo;
+    }
+}
+
+template <int AM, int BMODE, bool VEC>
+__global__ __launch_bounds__(256, X3_WGS_PER_CU) void gemm_x3_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) uint16_t smem[4][GBM][X3_LD];          // A hi, A lo, B hi, B lo: 40 KB
+    uint16_t(*Ah)[X3_LD] = smem[0];
+    uint16_t(*Al)[X3_LD] = smem[1];
+    uint16_t(*Bh)[X3_LD] = smem[2];
+    uint16_t(*Bl)[X3_LD] = smem[3];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int m0 = tm * GBM, n0 = tn * GBN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // bias gradient fused into wgrad: the B tile IS dy[rows, n-tile]; the m-tile-0 workgroups add up its columns from the
+    // fetched registers - four columns per thread, eight threads (the k-quads) per column, reduced through LDS at the end
+    const bool do_colsum = (p.colsum != nullptr) && (tm == 0);
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 ra[4], rb[4];
+    auto stash_both = [&]() {
+        x3_stash<AM == A_KC>(Ah, Al, tid, ra);
+        x3_stash<BMODE == B_KC>(Bh, Bl, tid, rb);
+        if (do_colsum) {
+            if (BMODE == B_KC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cs[i] += (rb[i].x + rb[i].y) + (rb[i].z + rb[i].w);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cs[0] += rb[e].x; cs[1] += rb[e].y; cs[2] += rb[e].z; cs[3] += rb[e].w; }
+            }
+        }
+    };
+    if (kbeg < kend) {
+        x3_fetch_a<AM, VEC>(p, m0, kbeg, kend, tid, ra);
+        x3_fetch_b<BMODE, VEC>(p, n0, kbeg, kend, tid, rb);
+        stash_both();
+    }
+    __syncthreads();
+
+    const int l31 = lane & 31, kh = lane >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += X3_BK) {
+        const bool more = (k0 + X3_BK) < kend;
+        if (more) {
+            x3_fetch_a<AM, VEC>(p, m0, k0 + X3_BK, kend, tid, ra);
+            x3_fetch_b<BMODE, VEC>(p, n0, k0 + X3_BK, kend, tid, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < X3_BK / 16; ++ks) {
+            const int off = ks * 16 + kh * 8;
+            x3_bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const x3_bf16x8*>(&Ah[wr * 64 + t * 32 + l31][off]);
+                al[t] = *reinterpret_cast<const x3_bf16x8*>(&Al[wr * 64 + t * 32 + l31][off]);
+                bh[t] = *reinterpret_cast<const x3_bf16x8*>(&Bh[wc * 64 + t * 32 + l31][off]);
+                bl[t] = *reinterpret_cast<const x3_bf16x8*>(&Bl[wc * 64 + t * 32 + l31][off]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (more) stash_both();
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool split = gridDim.z > 1;
+    if (do_colsum) {
+        float* red = reinterpret_cast<float*>(&smem[0][0][0]);         // [8 k-quads][128 columns] (the k-loop's last barrier retired the images)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int x, kq;
+            x3_coords<BMODE == B_KC>(tid, i, x, kq);
+            red[kq * GBN + (BMODE == B_KC ? x : x + i)] = cs[i];
+        }
+        __syncthreads();
+        if (tid < GBN && n0 + tid < p.N) {
+            float c2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) c2 += red[q * GBN + tid];
+            if (split) p.colsum_ws[(long)blockIdx.z * p.N + n0 + tid] = c2;
+            else p.colsum[n0 + tid] = c2;
+        }
+    }
+    float* Cb = split ? p.ws + (long)blockIdx.z * p.M * p.N : p.C;
+    const long ldc = split ? (long)p.N : p.ldc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int col = n0 + wc * 64 + j * 32 + l31;
+        if (col >= p.N) continue;
+        float bv = (!split && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (!split) {
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu_src) v = p.relu_src[(long)row * p.ld_relu + col] > 0.f ? v : 0.f;
+                    if (p.accumulate) v += Cb[(long)row * ldc + col];
+                }
+                Cb[(long)row * ldc + col] = v;
+            }
+        }
+    }
+}
+
 // dw[i] = sum_s ws[s][i]
 __global__ void split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                     long ldo, int M, int N, int splits,
@@ -331,7 +548,11 @@ static int launch_gemm(GemmP& p, bool vec, int splits, hipStream_t st, const cha
     p.tiles_m = ttsmi_cdiv(p.M, GBM);
     p.tiles_n = ttsmi_cdiv(p.N, GBN);
     dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-    if (vec)
+    if (p.x3) {
+        ttsmi_note_kernel("gemm_x3_kernel");
+        if (vec) hipLaunchKernelGGL((gemm_x3_kernel<AM, BMODE, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_x3_kernel<AM, BMODE, false>), grid, dim3(256), 0, st, p);
+    } else if (vec)
         hipLaunchKernelGGL((gemm_f32_kernel<AM, BMODE, true>), grid, dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<AM, BMODE, false>), grid, dim3(256), 0, st, p);
@@ -402,11 +623,12 @@ int ttsmi_linear_fwd(const void* x, int64_t ldx, const void* x2, int64_t ldx2, i
                      int N, int K, int relu, int dtype, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(x && w && y, "linear_fwd: null pointer");
     TTSMI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
-    TTSMI_CHECK_ARG(dtype == TTSMI_F32, "linear_fwd: dtype %d not built", dtype);
+    TTSMI_CHECK_ARG(dtype == TTSMI_F32 || dtype == TTSMI_BF16X3, "linear_fwd: dtype %d not built", dtype);
     if (x2) TTSMI_CHECK_ARG(K1 > 0 && K1 < K, "linear_fwd: bad K1=%d for K=%d", K1, K);
     if (M == 0) return TTSMI_OK;
     GemmP p;
     init_p(p);
+    p.x3 = dtype == TTSMI_BF16X3;
     p.A = (const float*)x; p.lda = ldx;
     p.A2 = (const float*)x2; p.lda2 = ldx2; p.K1 = K1;
     p.B = (const float*)w; p.ldb = ldw;
@@ -423,10 +645,11 @@ int ttsmi_linear_dgrad(const void* dy, int64_t lddy, const void* w, int64_t ldw,
                        int K, int accumulate, int dtype, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(dy && w && dx, "linear_dgrad: null pointer");
     TTSMI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_dgrad: bad shape");
-    TTSMI_CHECK_ARG(dtype == TTSMI_F32, "linear_dgrad: dtype %d not built", dtype);
+    TTSMI_CHECK_ARG(dtype == TTSMI_F32 || dtype == TTSMI_BF16X3, "linear_dgrad: dtype %d not built", dtype);
     if (M == 0) return TTSMI_OK;
     GemmP p;
     init_p(p);
+    p.x3 = dtype == TTSMI_BF16X3;
     // GEMM view: C[M, K] = dy[M, N] . B(kk = n_out, n = k_in) with B = w[k_in*ldw + n_out]
     p.A = (const float*)dy; p.lda = lddy;
     p.B = (const float*)w; p.ldb = ldw;
@@ -445,11 +668,12 @@ int ttsmi_linear_wgrad(const void* x, int64_t ldx, const void* dy, int64_t lddy,
                        int dtype, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(x && dy && dw, "linear_wgrad: null pointer");
     TTSMI_CHECK_ARG(M > 0 && N > 0 && K > 0, "linear_wgrad: bad shape");
-    TTSMI_CHECK_ARG(dtype == TTSMI_F32, "linear_wgrad: dtype %d not built", dtype);
+    TTSMI_CHECK_ARG(dtype == TTSMI_F32 || dtype == TTSMI_BF16X3, "linear_wgrad: dtype %d not built", dtype);
     TTSMI_CHECK_ARG(ws_bytes >= wgrad_ws_bytes(M, K, N) && ws, "linear_wgrad: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     GemmP p;
     init_p(p);
+    p.x3 = dtype == TTSMI_BF16X3;
     // GEMM view: C[K_in, N] = A(m = k_in, kk = row) . B(kk = row, n); reduction over the M rows
     p.A = (const float*)x; p.lda = ldx;
     p.B = (const float*)dy; p.ldb = lddy;
@@ -468,10 +692,11 @@ int ttsmi_conv1d_fwd(const void* x, const void* w, const float* bias, void* y, i
                      int Cin, int Cout, int k, int relu, int dtype, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(x && w && y, "conv1d_fwd: null pointer");
     TTSMI_CHECK_ARG(B >= 0 && T > 0 && Cin > 0 && Cout > 0 && k > 0, "conv1d_fwd: bad shape");
-    TTSMI_CHECK_ARG(dtype == TTSMI_F32, "conv1d_fwd: dtype %d not built", dtype);
+    TTSMI_CHECK_ARG(dtype == TTSMI_F32 || dtype == TTSMI_BF16X3, "conv1d_fwd: dtype %d not built", dtype);
     if (B == 0) return TTSMI_OK;
     GemmP p;
     init_p(p);
+    p.x3 = dtype == TTSMI_BF16X3;
     p.A = (const float*)x; p.lda = Cin;
     p.a_taps = k; p.T = T; p.Cw = Cin; p.pad = (k - 1) / 2;
     p.B = (const float*)w; p.ldb = Cout;            // [k*Cin, Cout] contiguous
@@ -487,10 +712,11 @@ int ttsmi_conv1d_dgrad(const void* dy, const void* w, const void* relu_src, void
                        int Cin, int Cout, int k, int dtype, ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(dy && w && dx, "conv1d_dgrad: null pointer");
     TTSMI_CHECK_ARG(B >= 0 && T > 0 && Cin > 0 && Cout > 0 && k > 0, "conv1d_dgrad: bad shape");
-    TTSMI_CHECK_ARG(dtype == TTSMI_F32, "conv1d_dgrad: dtype %d not built", dtype);
+    TTSMI_CHECK_ARG(dtype == TTSMI_F32 || dtype == TTSMI_BF16X3, "conv1d_dgrad: dtype %d not built", dtype);
     if (B == 0) return TTSMI_OK;
     GemmP p;
     init_p(p);
+    p.x3 = dtype == TTSMI_BF16X3;
     // dx[s, ci] = sum_{j'} sum_co dy[s + j' - (k-1-pl), co] * w[k-1-j', ci, co]
     p.A = (const float*)dy; p.lda = Cout;
     p.a_taps = k; p.T = T; p.Cw = Cout; p.pad = k - 1 - (k - 1) / 2;
@@ -513,13 +739,14 @@ int ttsmi_conv1d_wgrad(const void* x, const void* dy, float* dw, float* db, int 
                        ttsmi_stream_t stream) {
     TTSMI_CHECK_ARG(x && dy && dw, "conv1d_wgrad: null pointer");
     TTSMI_CHECK_ARG(B > 0 && T > 0 && Cin > 0 && Cout > 0 && k > 0, "conv1d_wgrad: bad shape");
-    TTSMI_CHECK_ARG(dtype == TTSMI_F32, "conv1d_wgrad: dtype %d not built", dtype);
+    TTSMI_CHECK_ARG(dtype == TTSMI_F32 || dtype == TTSMI_BF16X3, "conv1d_wgrad: dtype %d not built", dtype);
     int rows = B * T, kin = k * Cin;
     TTSMI_CHECK_ARG(ws && ws_bytes >= wgrad_ws_bytes(rows, kin, Cout),
                     "conv1d_wgrad: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     GemmP p;
     init_p(p);
+    p.x3 = dtype == TTSMI_BF16X3;
     // dw[(j,ci), co] = sum_{(b,t)} x[b, t + j - pl, ci] * dy[(b,t), co]
     p.A = (const float*)x; p.lda = Cin;
     p.a_taps = k; p.T = T; p.Cw = Cin; p.pad = (k - 1) / 2;

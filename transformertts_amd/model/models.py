@@ -50,6 +50,8 @@ def _on_device(fn):
 
     @functools.wraps(fn)
     def wrapper(self, *args, **kw):
+        # (the GEMM family of the fp32-tensor path this model's launches take: exact fp32, or three bf16 products)
+        ops.set_f32_gemm_dtype(ops._lib.TTSMI_BF16X3 if getattr(self, 'precision', 'f32') == 'bf16x3' else ops.TTSMI_F32)
         if torch.cuda.current_device() == self.device.index:
             return fn(self, *args, **kw)
         with torch.cuda.device(self.device):
@@ -205,7 +207,9 @@ class ForwardTransformer:
         # 'f32': exact-fp32 MFMA everywhere (the 1e-4 parity path).  'bf16': GEMM / attention operands
         # rounded to bf16, fp32 accumulate, fp32 master weights + activations (throughput path).
         self.precision = str(kwargs.get('precision', 'f32'))
-        assert self.precision in ('f32', 'bf16'), self.precision
+        # 'bf16x3': the exact-fp32 path with its GEMM family on three bf16 MFMAs per product (ops.F32_GEMM_DTYPE); everything
+        # else - attention, LayerNorm, residual stream, optimiser - is the fp32 path's
+        assert self.precision in ('f32', 'bf16', 'bf16x3'), self.precision
         self.shadow: Dict[str, ops.Shadow] = {}
         self.overlap_wgrad = bool(kwargs.get('overlap_wgrad', True))   # wgrad on a second HIP stream
         if kwargs.get('use_graph', False):

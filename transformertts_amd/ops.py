@@ -219,7 +219,19 @@ class DropCtx:
 # =================================================================================================
 # raw calls
 # =================================================================================================
-def linear_fwd(x, w, b, relu=False, x2=None, out=None, dtype=TTSMI_F32):
+# dtype of the fp32-tensor GEMM family (ttsmi_linear_* / ttsmi_conv1d_*) when a caller does not name one: TTSMI_F32 (exact-fp32
+# MFMA) or TTSMI_BF16X3 (three bf16 MFMAs per product).  A model sets it at the top of every public call (precision='bf16x3');
+# the autograd nodes that run inside that call read it at launch time.
+F32_GEMM_DTYPE = TTSMI_F32
+
+
+def set_f32_gemm_dtype(dtype):
+    global F32_GEMM_DTYPE
+    F32_GEMM_DTYPE = int(dtype)
+
+
+def linear_fwd(x, w, b, relu=False, x2=None, out=None, dtype=None):
+    dtype = F32_GEMM_DTYPE if dtype is None else dtype
     _need_gpu(x)
     M, K1 = x.shape
     K, N = w.shape
@@ -234,8 +246,9 @@ def linear_fwd(x, w, b, relu=False, x2=None, out=None, dtype=TTSMI_F32):
     return y
 
 
-def linear_dgrad(dy, w, relu_src=None, out=None, dtype=TTSMI_F32, accumulate=False):
+def linear_dgrad(dy, w, relu_src=None, out=None, dtype=None, accumulate=False):
     """dx = dy . w^T (* relu mask); accumulate=True adds into `out` instead of overwriting it."""
+    dtype = F32_GEMM_DTYPE if dtype is None else dtype
     M, N = dy.shape
     K = w.shape[0]
     assert not accumulate or out is not None
@@ -246,7 +259,8 @@ def linear_dgrad(dy, w, relu_src=None, out=None, dtype=TTSMI_F32, accumulate=Fal
     return dx
 
 
-def linear_wgrad(x, dy, dw, db, dtype=TTSMI_F32):
+def linear_wgrad(x, dy, dw, db, dtype=None):
+    dtype = F32_GEMM_DTYPE if dtype is None else dtype
     M, K = x.shape
     N = dy.shape[1]
     l = _lib.lib()
@@ -255,7 +269,8 @@ def linear_wgrad(x, dy, dw, db, dtype=TTSMI_F32):
                                M, N, K, _p(ws), ws.numel(), dtype, _stream()), 'linear_wgrad')
 
 
-def conv1d_fwd(x, w, b, relu=False, dtype=TTSMI_F32):
+def conv1d_fwd(x, w, b, relu=False, dtype=None):
+    dtype = F32_GEMM_DTYPE if dtype is None else dtype
     B, T, Cin = x.shape
     k, _, Cout = w.shape
     y = torch.empty((B, T, Cout), dtype=torch.float32, device=x.device)
@@ -264,7 +279,8 @@ def conv1d_fwd(x, w, b, relu=False, dtype=TTSMI_F32):
     return y
 
 
-def conv1d_dgrad(dy, w, relu_src=None, dtype=TTSMI_F32):
+def conv1d_dgrad(dy, w, relu_src=None, dtype=None):
+    dtype = F32_GEMM_DTYPE if dtype is None else dtype
     B, T, Cout = dy.shape
     k, Cin, _ = w.shape
     dx = torch.empty((B, T, Cin), dtype=torch.float32, device=dy.device)
@@ -273,7 +289,8 @@ def conv1d_dgrad(dy, w, relu_src=None, dtype=TTSMI_F32):
     return dx
 
 
-def conv1d_wgrad(x, dy, dw, db, dtype=TTSMI_F32):
+def conv1d_wgrad(x, dy, dw, db, dtype=None):
+    dtype = F32_GEMM_DTYPE if dtype is None else dtype
     B, T, Cin = x.shape
     Cout = dy.shape[2]
     k = dw.shape[0]
