@@ -345,6 +345,24 @@ __device__ __forceinline__ void x3_fetch_b(const GemmP& p, int n0, int k0, int k
         r[i] = ld4<VEC>(ptrs[0], oks[0], oks, ptrs);
     }
 }
+// FAST path of the fetch (workgroup-uniform: vectorisable operands, no conv window, no second K segment, the tile wholly inside
+// M x N): one pointer per thread and operand, set up once - the generic path above spends ~1 000 scalar / vector instructions per
+// k-tile on addresses and validity, against the tile's 24 MFMAs (ISA reading).  base = the operand's tile origin plus the thread's
+// own offset (KC: row tid >> 3, k-quad tid & 7; x contiguous: x-quad tid & 31 - its k-quad tid >> 5 enters with k).
+template <bool KC>
+__device__ __forceinline__ void x3_fetch_fast(const float* base, long ld, int k0, int kend, int tid, float4 (&r)[4]) {
+    // (UNCONDITIONAL loads - the fast path also requires a reduction range of whole k-tiles: a `valid ? load : 0` consumes the
+    // loaded value at once, i.e. puts the wait for the prefetch in front of the multiplies it should hide under)
+    if (KC) {
+        const float* q = base + k0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(q + (long)(32 * i) * ld);
+    } else {
+        const int kk = k0 + (tid >> 5) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = *reinterpret_cast<const float4*>(base + (long)(kk + e) * ld);
+    }
+}
 template <bool KC>
 __device__ __forceinline__ void x3_stash(uint16_t (*Hi)[X3_LD], uint16_t (*Lo)[X3_LD], int tid, const float4 (&r)[4]) {
     const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w}, {r[2].x, r[2].y, r[2].z, r[2].w},
@@ -408,9 +426,20 @@ __global__ __launch_bounds__(256, X3_WGS_PER_CU) void gemm_x3_kernel(GemmP p) {
             }
         }
     };
+    const bool fast = VEC && p.a_taps == 1 && p.A2 == nullptr && p.b_taps == 1 && m0 + GBM <= p.M && n0 + GBN <= p.N && (kend - kbeg) % X3_BK == 0;
+    const float* fa = AM == A_KC ? p.A + (long)(m0 + (tid >> 3)) * p.lda + (tid & 7) * 4 : p.A + m0 + (tid & 31) * 4;
+    const float* fb = BMODE == B_KC ? p.B + (long)(n0 + (tid >> 3)) * p.ldb + (tid & 7) * 4 : p.B + n0 + (tid & 31) * 4;
+    auto fetch_both = [&](int k0) {
+        if (fast) {
+            x3_fetch_fast<AM == A_KC>(fa, p.lda, k0, kend, tid, ra);
+            x3_fetch_fast<BMODE == B_KC>(fb, p.ldb, k0, kend, tid, rb);
+        } else {
+            x3_fetch_a<AM, VEC>(p, m0, k0, kend, tid, ra);
+            x3_fetch_b<BMODE, VEC>(p, n0, k0, kend, tid, rb);
+        }
+    };
     if (kbeg < kend) {
-        x3_fetch_a<AM, VEC>(p, m0, kbeg, kend, tid, ra);
-        x3_fetch_b<BMODE, VEC>(p, n0, kbeg, kend, tid, rb);
+        fetch_both(kbeg);
         stash_both();
     }
     __syncthreads();
@@ -418,10 +447,7 @@ __global__ __launch_bounds__(256, X3_WGS_PER_CU) void gemm_x3_kernel(GemmP p) {
     const int l31 = lane & 31, kh = lane >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += X3_BK) {
         const bool more = (k0 + X3_BK) < kend;
-        if (more) {
-            x3_fetch_a<AM, VEC>(p, m0, k0 + X3_BK, kend, tid, ra);
-            x3_fetch_b<BMODE, VEC>(p, n0, k0 + X3_BK, kend, tid, rb);
-        }
+        if (more) fetch_both(k0 + X3_BK);
 #pragma unroll
         for (int ks = 0; ks < X3_BK / 16; ++ks) {
             const int off = ks * 16 + kh * 8;
